@@ -1,0 +1,916 @@
+/*
+ * pysparse_oracle.c -- CPU restatement of PySparse's SpMV + Krylov hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker for the HIP product in
+ * pysparse_amd/: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call it.  Nothing under pysparse_amd/
+ * links, imports or executes anything from oracle/.
+ *
+ * Parity status: PINNED.  Every solver routine below is checked (tests/
+ * test_oracle_*.py, oracle/make_golden.py) against
+ *   (1) the reference's own compilable PCG kernel, examples/poisson_test/pcg.c,
+ *       built unmodified into oracle/_ref/ by oracle/Makefile and driven through
+ *       the bound-callback shims at the bottom of this file, and
+ *   (2) the golden vectors committed under tests/golden/ that were produced by
+ *       that build (G1..G5 of BASELINE.md) plus the ten-digit known answer K1.
+ *
+ * Each function cites the reference file:line (relative to /root/reference) whose
+ * arithmetic -- operation order included -- it restates.  Plain C, single thread,
+ * no FMA contraction (build with -ffp-contract=off): that is how the reference
+ * itself is built (gcc -O2, x86-64 baseline has no FMA), and it is what makes the
+ * HIP SpMV bit-comparable with this file.
+ *
+ * Third-party arithmetic: the reference calls Fortran BLAS-1 (dnrm2, ddot, daxpy,
+ * dcopy -- pysparse/include/blas.h:97-118) from whatever system BLAS the build
+ * found; no version is pinned.  The routines orc_ddot/orc_dnrm2/orc_daxpy/orc_dcopy
+ * restate the published netlib reference BLAS (3.8 and earlier) algorithms:
+ * ddot/daxpy are sequential left-to-right loops (netlib's 5-/4-way unrolling is
+ * written as one left-associated expression, i.e. the same order), dnrm2 is the
+ * classic scale/ssq one-pass form.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ BLAS-1 */
+
+/* netlib ddot, incx = incy = 1: dtemp accumulated left to right. */
+ORC_API double orc_ddot(int n, const double *x, const double *y) {
+  double s = 0.0;
+  int i;
+  for (i = 0; i < n; i++)
+    s = s + x[i] * y[i];
+  return s;
+}
+
+/* netlib dnrm2 (reference BLAS <= 3.8): scale / sum-of-squares recurrence. */
+ORC_API double orc_dnrm2(int n, const double *x) {
+  double scale = 0.0, ssq = 1.0, absxi, t;
+  int i;
+  if (n < 1)
+    return 0.0;
+  if (n == 1)
+    return fabs(x[0]);
+  for (i = 0; i < n; i++) {
+    if (x[i] != 0.0) {
+      absxi = fabs(x[i]);
+      if (scale < absxi) {
+        t = scale / absxi;
+        ssq = 1.0 + ssq * t * t;
+        scale = absxi;
+      } else {
+        t = absxi / scale;
+        ssq = ssq + t * t;
+      }
+    }
+  }
+  return scale * sqrt(ssq);
+}
+
+/* netlib daxpy: y := y + a*x (returns early for a == 0, as netlib does). */
+ORC_API void orc_daxpy(int n, double a, const double *x, double *y) {
+  int i;
+  if (a == 0.0)
+    return;
+  for (i = 0; i < n; i++)
+    y[i] = y[i] + a * x[i];
+}
+
+ORC_API void orc_dcopy(int n, const double *x, double *y) {
+  memcpy(y, x, (size_t)n * sizeof(double));
+}
+
+/* --------------------------------------------------------------- CSR SpMV */
+
+/* pysparse/sparse/src/csr_mat.c:49-54 (live branch, UNROLL_LOOPS == 0 at :11):
+ * y[i] = sum_k va[k]*x[ja[k]], accumulated left to right from 0.0, y overwritten. */
+ORC_API void orc_csr_matvec(int m, const double *x, double *y,
+                            const double *va, const int *ja, const int *ia) {
+  double s;
+  int i, k;
+  for (i = 0; i < m; i++) {
+    s = 0.0;
+    for (k = ia[i]; k < ia[i + 1]; k++)
+      s += va[k] * x[ja[k]];
+    y[i] = s;
+  }
+}
+
+/* csr_mat.c:58-72: element strides for non-contiguous NumPy views. */
+ORC_API void orc_csr_matvec_stride(int m, const double *x, int incx, double *y, int incy,
+                                   const double *va, const int *ja, const int *ia) {
+  double s;
+  int i, k;
+  for (i = 0; i < m; i++) {
+    s = 0.0;
+    for (k = ia[i]; k < ia[i + 1]; k++)
+      s += va[k] * x[(long)ja[k] * incx];
+    y[(long)i * incy] = s;
+  }
+}
+
+/* csr_mat.c:74-88: y = A^T x; zero y (length n = number of columns), then row-wise scatter. */
+ORC_API void orc_csr_matvec_transp(int m, int n, const double *x, double *y,
+                                   const double *va, const int *ja, const int *ia) {
+  double xi;
+  int i, k;
+  for (i = 0; i < n; i++)
+    y[i] = 0.0;
+  for (i = 0; i < m; i++) {
+    xi = x[i];
+    for (k = ia[i]; k < ia[i + 1]; k++)
+      y[ja[k]] += va[k] * xi;
+  }
+}
+
+/* --------------------------------------------------------------- SSS SpMV */
+
+/* pysparse/sparse/src/sss_mat.c:40-56: one ascending sweep; row i gathers its strict
+ * lower entries, scatters the mirrored contribution into y[j] (j < i, already
+ * assigned) and then ASSIGNS y[i] = s + diag[i]*x[i]. */
+ORC_API void orc_sss_matvec(int n, const double *x, double *y, const double *va,
+                            const double *da, const int *ja, const int *ia) {
+  double s, v, xi;
+  int i, j, k;
+  for (i = 0; i < n; i++) {
+    xi = x[i];
+    s = 0.0;
+    for (k = ia[i]; k < ia[i + 1]; k++) {
+      j = ja[k];
+      v = va[k];
+      s += v * x[j];
+      y[j] += v * xi;
+    }
+    y[i] = s + da[i] * xi;
+  }
+}
+
+/* sss_mat.c:58-76 */
+ORC_API void orc_sss_matvec_stride(int n, const double *x, int incx, double *y, int incy,
+                                   const double *va, const double *da, const int *ja,
+                                   const int *ia) {
+  double s, v, xi;
+  int i, j, k;
+  for (i = 0; i < n; i++) {
+    xi = x[(long)i * incx];
+    s = 0.0;
+    for (k = ia[i]; k < ia[i + 1]; k++) {
+      j = ja[k];
+      v = va[k];
+      s += v * x[(long)j * incx];
+      y[(long)j * incy] += v * xi;
+    }
+    y[(long)i * incy] = s + da[i] * xi;
+  }
+}
+
+/* sss_mat.c:14-28: A[i,j] lookup the way getitem() intends it. */
+ORC_API double orc_sss_getitem(int i, int j, const double *va, const double *da,
+                               const int *ja, const int *ia) {
+  int k, t;
+  if (i == j)
+    return da[i];
+  if (i < j) {
+    t = i;
+    i = j;
+    j = t;
+  }
+  for (k = ia[i]; k < ia[i + 1]; k++)
+    if (ja[k] == j)
+      return va[k];
+  return 0.0;
+}
+
+/* ------------------------------------------------ operator callback protocol */
+
+/* The reference reaches A and K through SpMatrix_Matvec / SpMatrix_Precon
+ * (pysparse/sparse/src/spmatrixmodule.c:169-248).  Here: C callbacks + context. */
+typedef int (*orc_matvec_fn)(void *ctx, int n, const double *x, double *y);
+typedef int (*orc_precon_fn)(void *ctx, int n, const double *x, double *y);
+
+typedef struct {
+  int m, n;
+  const double *va;
+  const int *ja, *ia;
+} orc_csr_t;
+
+typedef struct {
+  int n;
+  const double *va, *da;
+  const int *ja, *ia;
+} orc_sss_t;
+
+ORC_API int orc_csr_matvec_cb(void *ctx, int n, const double *x, double *y) {
+  const orc_csr_t *A = (const orc_csr_t *)ctx;
+  (void)n;
+  orc_csr_matvec(A->m, x, y, A->va, A->ja, A->ia);
+  return 0;
+}
+
+ORC_API int orc_sss_matvec_cb(void *ctx, int n, const double *x, double *y) {
+  const orc_sss_t *A = (const orc_sss_t *)ctx;
+  (void)n;
+  orc_sss_matvec(A->n, x, y, A->va, A->da, A->ja, A->ia);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ Jacobi */
+
+/* pysparse/precon/src/preconmodule.c:389-401: dinv[i] = omega / A[i,i]; a diagonal
+ * entry d with 1.0 + d == 1.0 is "close to zero" -> error (returns the row + 1). */
+ORC_API int orc_jacobi_setup(int n, const double *diag, double omega, double *dinv) {
+  int i;
+  double d;
+  for (i = 0; i < n; i++) {
+    d = diag[i];
+    if (1.0 + d == 1.0)
+      return i + 1;
+    dinv[i] = omega / d;
+  }
+  return 0;
+}
+
+typedef struct {
+  int n;
+  const double *dinv;
+  int steps;
+  double *temp; /* n doubles, needed only when steps > 1 */
+  orc_matvec_fn matvec;
+  void *mctx;
+} orc_jacobi_t;
+
+/* preconmodule.c:35-54: y = x .* dinv, then (steps-1) sweeps
+ * temp = y; y = A*temp; y = (x - y) .* dinv + temp. */
+ORC_API int orc_jacobi_apply(void *ctx, int n, const double *x, double *y) {
+  const orc_jacobi_t *K = (const orc_jacobi_t *)ctx;
+  int i, step;
+  for (i = 0; i < n; i++)
+    y[i] = x[i] * K->dinv[i];
+  for (step = 1; step < K->steps; step++) {
+    orc_dcopy(n, y, K->temp);
+    if (K->matvec(K->mctx, n, K->temp, y))
+      return -1;
+    for (i = 0; i < n; i++)
+      y[i] = (x[i] - y[i]) * K->dinv[i] + K->temp[i];
+  }
+  return 0;
+}
+
+/* --------------------------------------------------------------------- PCG */
+
+/* pysparse/itsolvers/src/pcg.c:22-171 (Itsolvers_pcg_kernel).  work = 4n doubles
+ * laid out (r, z, p, q) as at :50-53.  hist (may be NULL, length >= maxit+1) records
+ * the residual norm: hist[0] = initial, hist[it] = normr after iteration it.
+ * Returns 0, or -1 if a callback failed (:8-11). */
+ORC_API int orc_pcg(int n, double *x, const double *b, double tol, int maxit, int *iter,
+                    double *relres, int *flag, double *work, orc_matvec_fn matvec,
+                    void *mctx, orc_precon_fn precon, void *pctx, double *hist) {
+  double n2b, tolb, normr, alpha, beta, rho, rho1, pq, dmax, ddum;
+  int stag, it, i;
+  double *r = work, *z = work + n, *p = work + 2 * (long)n, *q = work + 3 * (long)n;
+
+  n2b = orc_dnrm2(n, b); /* :57 */
+  if (n2b == 0.0) {      /* :58-67: zero rhs -> zero solution, flag 0 */
+    for (i = 0; i < n; i++)
+      x[i] = 0.0;
+    *flag = 0;
+    *relres = 0.0;
+    *iter = 0;
+    return 0;
+  }
+
+  *flag = -1; /* :70 */
+  tolb = tol * n2b;
+  if (matvec(mctx, n, x, r)) /* :72 */
+    return -1;
+  for (i = 0; i < n; i++) /* :73-74 */
+    r[i] = b[i] - r[i];
+  normr = orc_dnrm2(n, r); /* :75 */
+  if (hist)
+    hist[0] = normr;
+
+  if (normr <= tolb) { /* :77-84 */
+    *flag = 0;
+    *relres = normr / n2b;
+    *iter = 0;
+    return 0;
+  }
+
+  rho = 1.0;
+  stag = 0;
+
+  for (it = 1; it <= maxit; it++) { /* :91 */
+    if (precon) {                   /* :93-97 */
+      if (precon(pctx, n, r, z))
+        return -1;
+    } else {
+      orc_dcopy(n, r, z);
+    }
+
+    rho1 = rho;
+    rho = orc_ddot(n, r, z); /* :100 */
+    if (rho == 0.0) {
+      *flag = -2;
+      break;
+    }
+    if (it == 1) {
+      orc_dcopy(n, z, p); /* :106 */
+    } else {
+      beta = rho / rho1;
+      if (beta == 0.0) {
+        *flag = -6;
+        break;
+      }
+      for (i = 0; i < n; i++) /* :113-114 */
+        p[i] = z[i] + beta * p[i];
+    }
+    if (matvec(mctx, n, p, q)) /* :116 */
+      return -1;
+    pq = orc_ddot(n, p, q); /* :117 */
+    if (pq == 0.0) {
+      *flag = -6;
+      break;
+    } else {
+      alpha = rho / pq;
+    }
+    if (alpha == 0.0)
+      stag = 1;
+
+    if (stag == 0) { /* :127-139 */
+      dmax = 0.0;
+      for (i = 0; i < n; i++)
+        if (x[i] != 0.0) {
+          ddum = fabs(alpha * p[i] / x[i]);
+          if (ddum > dmax)
+            dmax = ddum;
+        } else if (p[i] != 0.0)
+          dmax = 1.0;
+      stag = (1.0 + dmax == 1.0);
+    }
+
+    orc_daxpy(n, alpha, p, x);  /* :141 */
+    orc_daxpy(n, -alpha, q, r); /* :142-143 */
+
+    normr = orc_dnrm2(n, r); /* :152 (EXPENSIVE_CRIT undefined) */
+    if (hist)
+      hist[it] = normr;
+    if (normr <= tolb) { /* :154-157 */
+      *flag = 0;
+      break;
+    }
+    if (stag == 1) { /* :159-162 */
+      *flag = -5;
+      break;
+    }
+  }
+
+  *iter = it; /* :165 -- maxit+1 when the loop ran out */
+  *relres = normr / n2b;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ MINRES */
+
+/* pysparse/itsolvers/src/minres.c:43-200 (Itsolvers_minres_kernel).  work = 7n doubles
+ * (v_hat_old, v_hat, y, w, w_old, v, av) as at :54-60.  Return value is the info code
+ * (0, -1, -3, -6; or -100 for a failed callback); *nrm_res is left untouched on the
+ * -3 / -6 exits exactly like the reference. */
+ORC_API int orc_minres(int n, double errtol, int it_max, int *it, double *nrm_res, double *x,
+                       const double *b, double *work, orc_matvec_fn matvec, void *mctx,
+                       orc_precon_fn precon, void *pctx, double *hist) {
+  double norm_r0, beta, beta_old, c, c_old, c_oold, s, s_old, s_oold, eta, norm_rmr, alpha,
+      dconst1, dconst2, r1, r1_hat, r2, r3, tmp;
+  int i;
+  double *v_hat_old = work, *v_hat = work + n, *y = work + 2 * (long)n,
+         *w = work + 3 * (long)n, *w_old = work + 4 * (long)n, *v = work + 5 * (long)n,
+         *av = work + 6 * (long)n;
+
+  *it = 0;
+  for (i = 0; i < n; i++) /* :63-65 */
+    v_hat_old[i] = 0.0;
+  if (matvec(mctx, n, x, v_hat)) /* :67 */
+    return -100;
+  for (i = 0; i < n; i++)
+    v_hat[i] = b[i] - v_hat[i];
+  norm_r0 = orc_dnrm2(n, v_hat); /* :71 */
+  if (precon) {                  /* :73-76 */
+    if (precon(pctx, n, v_hat, y))
+      return -100;
+  } else {
+    orc_dcopy(n, v_hat, y);
+  }
+  beta = orc_ddot(n, v_hat, y); /* :78 */
+  if (beta < 0.0)
+    return -3;
+  beta = sqrt(beta);
+  beta_old = 1.0;
+
+  c = 1.0;
+  c_old = 1.0;
+  s = 0.0;
+  s_old = 0.0;
+  for (i = 0; i < n; i++)
+    w[i] = 0.0;
+  for (i = 0; i < n; i++)
+    w_old[i] = 0.0;
+  eta = beta;
+  norm_rmr = norm_r0;
+  if (hist)
+    hist[0] = norm_rmr;
+
+  while (1) {
+    if (*it >= it_max || norm_rmr < errtol * norm_r0) /* :114 -- strict < */
+      break;
+    *it = *it + 1;
+
+    for (i = 0; i < n; i++) /* :123-124: v = y / beta */
+      v[i] = y[i] / beta;
+    orc_dcopy(n, v_hat, y);     /* :125 */
+    if (matvec(mctx, n, v, av)) /* :127 */
+      return -100;
+    alpha = orc_ddot(n, v, av); /* :129 */
+    dconst1 = alpha / beta;
+    dconst2 = beta / beta_old;
+    for (i = 0; i < n; i++) /* :132-133 */
+      v_hat[i] = av[i] - dconst1 * v_hat[i] - dconst2 * v_hat_old[i];
+    orc_dcopy(n, y, v_hat_old); /* :135 */
+    if (precon) {               /* :137-140 */
+      if (precon(pctx, n, v_hat, y))
+        return -100;
+    } else {
+      orc_dcopy(n, v_hat, y);
+    }
+    beta_old = beta;
+    beta = orc_ddot(n, v_hat, y); /* :143 */
+    if (beta < 0.0)
+      return -3;
+    beta = sqrt(beta);
+
+    c_oold = c_old; /* :151 */
+    c_old = c;
+    s_oold = s_old;
+    s_old = s;
+
+    r1_hat = c_old * alpha - c_oold * s_old * beta_old;
+    r1 = sqrt(r1_hat * r1_hat + beta * beta);
+    r2 = s_old * alpha + c_oold * c_old * beta_old;
+    r3 = s_oold * beta_old;
+
+    if (r1 == 0.0) /* :161-162 */
+      return -6;
+    c = r1_hat / r1;
+    s = beta / r1;
+
+    for (i = 0; i < n; i++) { /* :172-176 */
+      tmp = w[i];
+      w[i] = (v[i] - r3 * w_old[i] - r2 * tmp) / r1;
+      w_old[i] = tmp;
+    }
+    dconst1 = c * eta; /* :178-180 */
+    for (i = 0; i < n; i++)
+      x[i] += dconst1 * w[i];
+    eta = -s * eta;
+
+    norm_rmr *= fabs(s); /* :192 */
+    if (hist)
+      hist[*it] = norm_rmr;
+  }
+
+  *nrm_res = norm_rmr / norm_r0; /* :195 */
+  if (norm_rmr < errtol * norm_r0)
+    return 0;
+  else
+    return -1;
+}
+
+/* ---------------------------------------------------- ll_mat feeder semantics */
+
+/* A minimal linked-list matrix with the insertion and conversion semantics of
+ * pysparse/sparse/src/ll_mat.c: rows kept as singly linked lists sorted by ascending
+ * column (:272-279), zero assignment deletes the entry unless storeZeros (:263,
+ * :336-352), freed slots are recycled through a free chain (:282-287), growth by
+ * factor 1.5 + 1 (:293-309), symmetric matrices reject writes with i < j (:256-260). */
+typedef struct {
+  int dim[2];
+  int issym, store_zeros;
+  int nnz, nalloc, free_;
+  double *val;
+  int *col, *link, *root;
+} orc_ll_t;
+
+ORC_API orc_ll_t *orc_ll_new(int m, int n, int size_hint, int issym, int store_zeros) {
+  orc_ll_t *a = (orc_ll_t *)calloc(1, sizeof(orc_ll_t));
+  int i;
+  if (size_hint < 1)
+    size_hint = 1;
+  a->dim[0] = m;
+  a->dim[1] = n;
+  a->issym = issym;
+  a->store_zeros = store_zeros;
+  a->nalloc = size_hint;
+  a->free_ = -1;
+  a->val = (double *)malloc(sizeof(double) * size_hint);
+  a->col = (int *)malloc(sizeof(int) * size_hint);
+  a->link = (int *)malloc(sizeof(int) * size_hint);
+  a->root = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+  for (i = 0; i < m; i++)
+    a->root[i] = -1;
+  return a;
+}
+
+ORC_API void orc_ll_free(orc_ll_t *a) {
+  if (!a)
+    return;
+  free(a->val);
+  free(a->col);
+  free(a->link);
+  free(a->root);
+  free(a);
+}
+
+ORC_API int orc_ll_nnz(const orc_ll_t *a) { return a->nnz; }
+
+/* ll_mat.c:250-356.  Returns 0, -1 (upper-triangle write on symmetric), -2 (range). */
+ORC_API int orc_ll_set(orc_ll_t *a, int i, int j, double x) {
+  int k, new_elem, last, col;
+  if (a->issym && i < j)
+    return -1;
+  if (i < 0 || i >= a->dim[0] || j < 0 || j >= a->dim[1])
+    return -2;
+  col = last = -1;
+  k = a->root[i];
+  while (k != -1) {
+    col = a->col[k];
+    if (col >= j)
+      break;
+    last = k;
+    k = a->link[k];
+  }
+  if (x != 0.0 || a->store_zeros == 1) {
+    if (col == j) {
+      a->val[k] = x;
+    } else {
+      if (a->free_ != -1) {
+        new_elem = a->free_;
+        a->free_ = a->link[new_elem];
+      } else {
+        /* the reference appends at index nnz (:290); that equals the high-water
+         * mark only while nothing was ever freed, which holds here because the
+         * free chain is consumed first and nnz counts live entries */
+        new_elem = a->nnz;
+        if (a->nnz == a->nalloc) {
+          int nalloc_new = (int)(1.5 * a->nalloc) + 1;
+          a->col = (int *)realloc(a->col, sizeof(int) * nalloc_new);
+          a->link = (int *)realloc(a->link, sizeof(int) * nalloc_new);
+          a->val = (double *)realloc(a->val, sizeof(double) * nalloc_new);
+          a->nalloc = nalloc_new;
+        }
+      }
+      a->val[new_elem] = x;
+      a->col[new_elem] = j;
+      a->link[new_elem] = k;
+      if (last == -1)
+        a->root[i] = new_elem;
+      else
+        a->link[last] = new_elem;
+      a->nnz++;
+    }
+  } else if (col == j) {
+    if (last == -1)
+      a->root[i] = a->link[k];
+    else
+      a->link[last] = a->link[k];
+    a->link[k] = a->free_;
+    a->free_ = k;
+    a->nnz--;
+  }
+  return 0;
+}
+
+/* ll_mat.c:210-244 */
+ORC_API double orc_ll_get(const orc_ll_t *a, int i, int j) {
+  int k, t;
+  if (a->issym && i < j) {
+    t = i;
+    i = j;
+    j = t;
+  }
+  for (k = a->root[i]; k != -1; k = a->link[k])
+    if (a->col[k] == j)
+      return a->val[k];
+  return 0.0;
+}
+
+/* number of entries to_csr() will emit: ll_mat.c:1592-1593 (sym: 2*nzLo + nzDiag). */
+ORC_API int orc_ll_csr_nnz(const orc_ll_t *a) {
+  int i, k, lo = 0, dg = 0;
+  if (!a->issym)
+    return a->nnz;
+  for (i = 0; i < a->dim[0]; i++)
+    for (k = a->root[i]; k != -1; k = a->link[k]) {
+      if (i > a->col[k])
+        lo++;
+      else if (i == a->col[k])
+        dg++;
+    }
+  return 2 * lo + dg;
+}
+
+/* ll_mat.c:1577-1648.  General: copy each sorted row list.  Symmetric: per row i, the
+ * stored (lower + diagonal) entries, then the mirrored entries (i, j > i) in ascending
+ * j obtained from a column index built bottom-up (:135-184). */
+ORC_API void orc_ll_to_csr(const orc_ll_t *a, double *val, int *col, int *ind) {
+  int i, k, r = 0;
+  ind[0] = 0;
+  if (!a->issym) {
+    for (i = 0; i < a->dim[0]; i++) {
+      for (k = a->root[i]; k != -1; k = a->link[k]) {
+        val[r] = a->val[k];
+        col[r] = a->col[k];
+        r++;
+      }
+      ind[i + 1] = r;
+    }
+    return;
+  }
+  {
+    int n = a->dim[1];
+    int *clink = (int *)malloc(sizeof(int) * (a->nalloc > 0 ? a->nalloc : 1));
+    int *crow = (int *)malloc(sizeof(int) * (a->nalloc > 0 ? a->nalloc : 1));
+    int *croot = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int j;
+    for (j = 0; j < n; j++)
+      croot[j] = -1;
+    for (i = a->dim[0] - 1; i >= 0; i--)
+      for (k = a->root[i]; k != -1; k = a->link[k]) {
+        j = a->col[k];
+        if (i != j) {
+          clink[k] = croot[j];
+          croot[j] = k;
+          crow[k] = i;
+        }
+      }
+    for (i = 0; i < a->dim[0]; i++) {
+      for (k = a->root[i]; k != -1; k = a->link[k]) {
+        val[r] = a->val[k];
+        col[r] = a->col[k];
+        r++;
+      }
+      for (k = croot[i]; k != -1; k = clink[k]) {
+        val[r] = a->val[k];
+        col[r] = crow[k];
+        r++;
+      }
+      ind[i + 1] = r;
+    }
+    free(clink);
+    free(crow);
+    free(croot);
+  }
+}
+
+/* ll_mat.c:1671-1680: strict-lower count. */
+ORC_API int orc_ll_sss_nnz(const orc_ll_t *a) {
+  int i, k, nnz = 0;
+  for (i = 0; i < a->dim[0]; i++)
+    for (k = a->root[i]; k != -1; k = a->link[k])
+      if (i > a->col[k])
+        nnz++;
+  return nnz;
+}
+
+/* ll_mat.c:1654-1708: strict lower -> (val, col, ind), diagonal -> diag (0.0 when
+ * absent), upper entries dropped. */
+ORC_API void orc_ll_to_sss(const orc_ll_t *a, double *val, double *diag, int *col, int *ind) {
+  int i, j, k, r = 0, n = a->dim[0];
+  for (i = 0; i < n; i++)
+    diag[i] = 0.0;
+  ind[0] = 0;
+  for (i = 0; i < n; i++) {
+    for (k = a->root[i]; k != -1; k = a->link[k]) {
+      j = a->col[k];
+      if (i > j) {
+        val[r] = a->val[k];
+        col[r] = j;
+        r++;
+      } else if (i == j)
+        diag[i] = a->val[k];
+    }
+    ind[i + 1] = r;
+  }
+}
+
+/* ll_mat.c:1262-1277 (general) and :1300-1320 (symmetric storage) matvec. */
+ORC_API void orc_ll_matvec(const orc_ll_t *a, const double *x, double *y) {
+  double s, v, xi;
+  int i, j, k;
+  if (!a->issym) {
+    for (i = 0; i < a->dim[0]; i++) {
+      s = 0.0;
+      for (k = a->root[i]; k != -1; k = a->link[k])
+        s += a->val[k] * x[a->col[k]];
+      y[i] = s;
+    }
+  } else {
+    for (i = 0; i < a->dim[0]; i++) {
+      xi = x[i];
+      s = 0.0;
+      for (k = a->root[i]; k != -1; k = a->link[k]) {
+        j = a->col[k];
+        v = a->val[k];
+        s += v * x[j];
+        if (i != j)
+          y[j] += v * xi;
+      }
+      y[i] = s;
+    }
+  }
+}
+
+/* -------------------------------------------------------- Poisson generators */
+
+/* Direct CSR generators in the ordering of pysparse/tools/poisson.py:22-37
+ * (k = i + nx*j, diag 4, off-diag -1, Dirichlet truncation) extended to 3-D
+ * (k = i + nx*j + nx*ny*l, diag 6).  Columns ascending within a row, i.e. what
+ * poisson2d(n).to_csr() yields through the sorted ll_mat lists.  nz == 0 selects 2-D.
+ * Returns nnz; pass NULL arrays to only count. */
+ORC_API long orc_poisson_csr(int nx, int ny, int nz, double *val, int *col, int *ind) {
+  long r = 0, k, nxy = (long)nx * ny;
+  int i, j, l, three_d = nz > 0;
+  double dg = three_d ? 6.0 : 4.0;
+  if (!three_d)
+    nz = 1;
+  if (ind)
+    ind[0] = 0;
+  for (l = 0; l < nz; l++)
+    for (j = 0; j < ny; j++)
+      for (i = 0; i < nx; i++) {
+        k = i + (long)nx * j + nxy * l;
+#define ORC_EMIT(c, v)    \
+  do {                    \
+    if (val) {            \
+      val[r] = (v);       \
+      col[r] = (int)(c);  \
+    }                     \
+    r++;                  \
+  } while (0)
+        if (three_d && l > 0)
+          ORC_EMIT(k - nxy, -1.0);
+        if (j > 0)
+          ORC_EMIT(k - nx, -1.0);
+        if (i > 0)
+          ORC_EMIT(k - 1, -1.0);
+        ORC_EMIT(k, dg);
+        if (i < nx - 1)
+          ORC_EMIT(k + 1, -1.0);
+        if (j < ny - 1)
+          ORC_EMIT(k + nx, -1.0);
+        if (three_d && l < nz - 1)
+          ORC_EMIT(k + nxy, -1.0);
+        if (ind)
+          ind[k + 1] = (int)r;
+      }
+  return r;
+}
+
+/* Symmetric-skyline form of the same operator: what poisson2d_sym(n).to_sss()
+ * (tools/poisson.py:39-50 + ll_mat.c:1654-1708) yields.  Returns strict-lower nnz. */
+ORC_API long orc_poisson_sss(int nx, int ny, int nz, double *val, double *diag, int *col,
+                             int *ind) {
+  long r = 0, k, nxy = (long)nx * ny;
+  int i, j, l, three_d = nz > 0;
+  double dg = three_d ? 6.0 : 4.0;
+  if (!three_d)
+    nz = 1;
+  if (ind)
+    ind[0] = 0;
+  for (l = 0; l < nz; l++)
+    for (j = 0; j < ny; j++)
+      for (i = 0; i < nx; i++) {
+        k = i + (long)nx * j + nxy * l;
+        if (three_d && l > 0)
+          ORC_EMIT(k - nxy, -1.0);
+        if (j > 0)
+          ORC_EMIT(k - nx, -1.0);
+        if (i > 0)
+          ORC_EMIT(k - 1, -1.0);
+        if (diag)
+          diag[k] = dg;
+        if (ind)
+          ind[k + 1] = (int)r;
+      }
+#undef ORC_EMIT
+  return r;
+}
+
+/* --------------------------------------- bound shims for the compiled reference */
+
+/* examples/poisson_test/pcg.c takes context-free callbacks
+ * void (*matvec)(double *x, double *y), void (*precon)(double *x, double *y)
+ * (examples/poisson_test/pcg.h:6-17).  These shims bind one operator / one
+ * preconditioner in file-static state so that the reference kernel in oracle/_ref/
+ * can be driven with exactly the arithmetic above. */
+static orc_csr_t g_csr;
+static orc_sss_t g_sss;
+static const double *g_dinv;
+static int g_n;
+
+ORC_API void orc_bind_csr(int m, int n, const double *va, const int *ja, const int *ia) {
+  g_csr.m = m;
+  g_csr.n = n;
+  g_csr.va = va;
+  g_csr.ja = ja;
+  g_csr.ia = ia;
+}
+ORC_API void orc_bind_sss(int n, const double *va, const double *da, const int *ja,
+                          const int *ia) {
+  g_sss.n = n;
+  g_sss.va = va;
+  g_sss.da = da;
+  g_sss.ja = ja;
+  g_sss.ia = ia;
+}
+ORC_API void orc_bind_dinv(int n, const double *dinv) {
+  g_n = n;
+  g_dinv = dinv;
+}
+ORC_API void orc_bound_csr_matvec(double *x, double *y) {
+  orc_csr_matvec(g_csr.m, x, y, g_csr.va, g_csr.ja, g_csr.ia);
+}
+ORC_API void orc_bound_sss_matvec(double *x, double *y) {
+  orc_sss_matvec(g_sss.n, x, y, g_sss.va, g_sss.da, g_sss.ja, g_sss.ia);
+}
+ORC_API void orc_bound_jacobi(double *x, double *y) {
+  int i;
+  for (i = 0; i < g_n; i++)
+    y[i] = x[i] * g_dinv[i];
+}
+
+/* Convenience drivers used by the ctypes wrapper: whole solves on CSR / SSS operators
+ * with K = None (dinv == NULL) or Jacobi(steps). */
+ORC_API int orc_pcg_csr(int n, const double *va, const int *ja, const int *ia, const double *dinv,
+                        int steps, double *x, const double *b, double tol, int maxit, int *iter,
+                        double *relres, int *flag, double *hist) {
+  orc_csr_t A = {n, n, va, ja, ia};
+  orc_jacobi_t K = {n, dinv, steps, NULL, orc_csr_matvec_cb, &A};
+  double *work = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+  int rc;
+  if (dinv && steps > 1)
+    K.temp = (double *)malloc(sizeof(double) * (size_t)n);
+  rc = orc_pcg(n, x, b, tol, maxit, iter, relres, flag, work, orc_csr_matvec_cb, &A,
+               dinv ? orc_jacobi_apply : NULL, &K, hist);
+  free(K.temp);
+  free(work);
+  return rc;
+}
+
+ORC_API int orc_pcg_sss(int n, const double *va, const double *da, const int *ja, const int *ia,
+                        const double *dinv, int steps, double *x, const double *b, double tol,
+                        int maxit, int *iter, double *relres, int *flag, double *hist) {
+  orc_sss_t A = {n, va, da, ja, ia};
+  orc_jacobi_t K = {n, dinv, steps, NULL, orc_sss_matvec_cb, &A};
+  double *work = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+  int rc;
+  if (dinv && steps > 1)
+    K.temp = (double *)malloc(sizeof(double) * (size_t)n);
+  rc = orc_pcg(n, x, b, tol, maxit, iter, relres, flag, work, orc_sss_matvec_cb, &A,
+               dinv ? orc_jacobi_apply : NULL, &K, hist);
+  free(K.temp);
+  free(work);
+  return rc;
+}
+
+ORC_API int orc_minres_csr(int n, const double *va, const int *ja, const int *ia,
+                           const double *dinv, int steps, double *x, const double *b, double tol,
+                           int maxit, int *iter, double *relres, double *hist) {
+  orc_csr_t A = {n, n, va, ja, ia};
+  orc_jacobi_t K = {n, dinv, steps, NULL, orc_csr_matvec_cb, &A};
+  double *work = (double *)malloc(sizeof(double) * 7 * (size_t)n);
+  int info;
+  if (dinv && steps > 1)
+    K.temp = (double *)malloc(sizeof(double) * (size_t)n);
+  info = orc_minres(n, tol, maxit, iter, relres, x, b, work, orc_csr_matvec_cb, &A,
+                    dinv ? orc_jacobi_apply : NULL, &K, hist);
+  free(K.temp);
+  free(work);
+  return info;
+}
+
+ORC_API int orc_minres_sss(int n, const double *va, const double *da, const int *ja,
+                           const int *ia, const double *dinv, int steps, double *x,
+                           const double *b, double tol, int maxit, int *iter, double *relres,
+                           double *hist) {
+  orc_sss_t A = {n, va, da, ja, ia};
+  orc_jacobi_t K = {n, dinv, steps, NULL, orc_sss_matvec_cb, &A};
+  double *work = (double *)malloc(sizeof(double) * 7 * (size_t)n);
+  int info;
+  if (dinv && steps > 1)
+    K.temp = (double *)malloc(sizeof(double) * (size_t)n);
+  info = orc_minres(n, tol, maxit, iter, relres, x, b, work, orc_sss_matvec_cb, &A,
+                    dinv ? orc_jacobi_apply : NULL, &K, hist);
+  free(K.temp);
+  free(work);
+  return info;
+}
