@@ -1,0 +1,228 @@
+/*
+ * pysparse_hip.h -- C ABI of libpysparse_hip.so, the MI355X (gfx950) implementation of
+ * PySparse's SpMV + Krylov hot path.
+ *
+ * Plain C: ints, doubles, raw pointers and opaque handles only -- no Python, NumPy or
+ * torch types cross this boundary.  The CPython extension modules in pysparse_amd/
+ * (spmatrix, krylov, precon), bench.py and the GPU tests all go through these entry
+ * points.  Citations are file:line under the reference tree (PythonOptimizers/pysparse).
+ *
+ * Conventions
+ *   - every function returns PSP_OK (0) or a negative PSP_E* status; psp_last_error()
+ *     returns the message of the calling thread's last failure.  Nothing throws.
+ *   - "host" pointers are ordinary process memory, borrowed for the call;
+ *     "dev" pointers are HIP device memory on the library's current device.
+ *   - handles own their device memory; destroy releases it.
+ *   - all work is enqueued on ONE stream (psp_set_stream; default = the null stream);
+ *     host-pointer entry points synchronise before returning, *_dev entry points that
+ *     return no scalar do not.
+ *   - handles are not thread-safe; there is NO CPU fallback: without a usable GPU every
+ *     compute entry point fails with PSP_ENODEV.
+ *   - indices are 32-bit (the reference's C int: csr_mat.h:6-13), values are double.
+ */
+#ifndef PYSPARSE_HIP_H
+#define PYSPARSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSP_OK 0
+#define PSP_EINVAL (-1)   /* bad argument (shape, NULL, range)                     */
+#define PSP_ENODEV (-2)   /* no HIP device / runtime error                         */
+#define PSP_ENOMEM (-3)   /* device or host allocation failed                      */
+#define PSP_ESINGULAR (-4) /* jacobi: diagonal element close to zero               */
+#define PSP_ECALLBACK (-5) /* a host operator callback reported failure            */
+
+/* solver info codes: pysparse/itsolvers/src/itsolversmodule.c:625-646 */
+#define PSP_INFO_CONVERGED 0
+#define PSP_INFO_MAXIT (-1)
+#define PSP_INFO_ILLCOND_PRECON (-2)
+#define PSP_INFO_NOT_SPD_PRECON (-3)
+#define PSP_INFO_STAGNATION (-5)
+#define PSP_INFO_BREAKDOWN (-6)
+
+typedef struct psp_csr psp_csr_t;       /* device mirror of CSRMatObject, csr_mat.h:6-13     */
+typedef struct psp_sss psp_sss_t;       /* device mirror of SSSMatObject, sss_mat.h:6-14     */
+typedef struct psp_jacobi psp_jacobi_t; /* device mirror of JacobiObject, preconmodule.c:11-19 */
+typedef struct psp_op psp_op_t;         /* "anything with shape + matvec / precon":
+                                           the operator protocol of spmatrixmodule.c:169-248 */
+
+/* ------------------------------------------------------------------ runtime */
+
+const char *psp_last_error(void);
+const char *psp_version(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int psp_device_count(void);
+/* select the device all later calls use (hipSetDevice) */
+int psp_set_device(int device);
+/* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = null stream */
+int psp_set_stream(void *hip_stream);
+int psp_synchronize(void);
+/* name, CU count and HBM bytes of the current device */
+int psp_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+
+/* device memory + timing hooks used by bench.py and the tests */
+int psp_malloc(void **dev, size_t bytes);
+int psp_free(void *dev);
+int psp_memcpy_h2d(void *dev, const void *host, size_t bytes);
+int psp_memcpy_d2h(void *host, const void *dev, size_t bytes);
+int psp_memset(void *dev, int byte, size_t bytes);
+int psp_event_create(void **event);
+int psp_event_destroy(void *event);
+int psp_event_record(void *event);                       /* on the library stream */
+int psp_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+/* ------------------------------------------------------------------ csr_mat */
+
+/* replaces newCSRMatObject + the fill loop of LLMat_to_csr
+ * (pysparse/sparse/src/csr_mat.c:259-296, ll_mat.c:1577-1648): uploads a host CSR
+ * triple.  ind has nrows+1 entries, ind[0] == 0, ind[nrows] == nnz. */
+int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int *col_host,
+                   const double *val_host, psp_csr_t **out);
+/* scalable constructor: 5-/7-point Poisson operator generated ON the
+ * device in the ordering of pysparse/tools/poisson.py:22-37, k = i + nx*j (+ nx*ny*l),
+ * diag 4 (nz == 0, 2-D) or 6 (3-D), off-diagonals -1, columns ascending.
+ * The slab form keeps only global rows [row_lo, row_hi) and shifts column indices by
+ * -col_shift (row-range partition for multi-GPU; ncols_local = width of the local
+ * extended x vector).  psp_csr_poisson == slab over all rows with shift 0. */
+int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out);
+int psp_csr_poisson_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
+                         int ncols_local, psp_csr_t **out);
+int psp_csr_destroy(psp_csr_t *A);
+/* shape / nnz attributes: CSRMatType_getattr, csr_mat.c:208-231 */
+int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz);
+/* copy the device arrays back (structure parity tests; any pointer may be NULL) */
+int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host);
+/* A[i,i] for all rows (0.0 where no diagonal entry is stored) */
+int psp_csr_diagonal(const psp_csr_t *A, double *diag_host);
+
+/* y := A x.  CSRMat_matvec, csr_mat.c:141-163 (kernel :49-54); x has ncols, y nrows
+ * entries; y is overwritten.  Per-row summation is left to right from 0.0 with separate
+ * multiply and add, so results are bit-identical to the reference loop. */
+int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host);
+/* element strides of non-contiguous NumPy views: csr_matvec_kernel_stride, csr_mat.c:58-72 */
+int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
+                          ptrdiff_t incy);
+/* y := A^T x.  CSRMat_matvec_transp, csr_mat.c:114-133 (kernel :74-88) */
+int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host);
+int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
+                                 double *y_host, ptrdiff_t incy);
+/* device-pointer flavours (no synchronisation) */
+int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev);
+int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev);
+/* kernel tuning knob for A/B measurements: variant < 0 restores the default */
+int psp_csr_set_variant(psp_csr_t *A, int variant);
+/* bytes of device memory held by the handle */
+int64_t psp_csr_device_bytes(const psp_csr_t *A);
+
+/* ------------------------------------------------------------------ sss_mat */
+
+/* replaces newSSSMatObject + LLMat_to_sss (sss_mat.c:243-284, ll_mat.c:1654-1708):
+ * strict lower triangle in CSR form (nnz_lower entries) + dense diagonal. */
+int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_host,
+                   const double *val_host, const double *diag_host, psp_sss_t **out);
+/* symmetric-skyline form of the Poisson operator (poisson2d_sym(n).to_sss()) */
+int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out);
+int psp_sss_destroy(psp_sss_t *A);
+/* n, and nnz as the reference reports it: strict-lower count + n (sss_mat.c:155) */
+int psp_sss_shape(const psp_sss_t *A, int *n, int *nnz_reported);
+int psp_sss_download(const psp_sss_t *A, int *ind_host, int *col_host, double *val_host,
+                     double *diag_host);
+/* A[i,j]: getitem, sss_mat.c:14-28 */
+int psp_sss_getitem(const psp_sss_t *A, int i, int j, double *value);
+/* y := A x (== A^T x).  SSSMat_matvec, sss_mat.c:78-96 (kernel :40-56).  Per row the
+ * terms are added in the reference's order: lower entries by ascending column, the
+ * diagonal term, then the mirrored upper entries by ascending row. */
+int psp_sss_matvec(psp_sss_t *A, const double *x_host, double *y_host);
+int psp_sss_matvec_stride(psp_sss_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
+                          ptrdiff_t incy);
+int psp_sss_matvec_dev(psp_sss_t *A, const double *x_dev, double *y_dev);
+int64_t psp_sss_device_bytes(const psp_sss_t *A);
+
+/* ------------------------------------------------------------------- jacobi */
+
+/* replaces newJacobiObject (pysparse/precon/src/preconmodule.c:352-412):
+ * dinv[i] = omega / A[i,i]; PSP_ESINGULAR if 1.0 + A[i,i] == 1.0 for some i (:395).
+ * The native forms read the diagonal on the device instead of n calls of A[i,i].
+ * steps > 1 keeps a reference to the operator for the extra sweeps (:45-52). */
+int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **out);
+int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **out);
+/* generic form: host diagonal (already fetched through A[i,i]) + the operator used by
+ * the steps > 1 sweeps (may be NULL when steps == 1) */
+int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int steps,
+                           const psp_op_t *A_or_null, psp_jacobi_t **out);
+int psp_jacobi_destroy(psp_jacobi_t *K);
+int psp_jacobi_shape(const psp_jacobi_t *K, int *n);
+/* y := K x.  Jacobi_precon, preconmodule.c:60-80 (kernel :35-54) */
+int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host);
+int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev);
+
+/* --------------------------------------------------------- operator protocol */
+
+/* Host callback operator: the C image of SpMatrix_Matvec / SpMatrix_Precon
+ * (spmatrixmodule.c:169-201, :215-248).  Called with HOST vectors; returns 0, or
+ * non-zero when the callee failed (a Python exception is pending). */
+typedef int (*psp_host_apply_fn)(void *ctx, int n, const double *x_host, double *y_host);
+
+int psp_op_from_csr(psp_csr_t *A, psp_op_t **out);
+int psp_op_from_sss(psp_sss_t *A, psp_op_t **out);
+int psp_op_from_jacobi(psp_jacobi_t *K, psp_op_t **out);
+int psp_op_from_callback(int n, psp_host_apply_fn fn, void *ctx, psp_op_t **out);
+int psp_op_destroy(psp_op_t *op);
+
+/* ------------------------------------------------------------------ solvers */
+
+/* info, iter, relres = pcg(A, b, x, tol, maxit[, K]) -- ItSolvers_pcg
+ * (itsolversmodule.c:32-118) + Itsolvers_pcg_kernel (pysparse/itsolvers/src/pcg.c:22-171).
+ * The whole loop runs on the device; b and x cross PCIe once each way.  Semantics kept:
+ * tolb = tol*||b||; b == 0 -> x := 0, info 0; iter == maxit+1 when not converged;
+ * stagnation / breakdown codes as above.  K may be NULL.  hist_host (may be NULL, maxit+1
+ * doubles) receives ||r|| per iteration.  Returns PSP_ECALLBACK when a callback failed
+ * (the reference returns -1 from the kernel, pcg.c:8-11). */
+int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+            double tol, int maxit, int *info, int *iter, double *relres, double *hist_host);
+int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, const double *b_dev,
+                double tol, int maxit, int *info, int *iter, double *relres, double *hist_host);
+
+/* info, iter, relres = minres(A, b, x, tol, maxit[, K]) -- ItSolvers_minres
+ * (itsolversmodule.c:217-305) + Itsolvers_minres_kernel (pysparse/itsolvers/src/minres.c:43-200).
+ * *relres is written only on the 0 / -1 exits, as in the reference. */
+int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+               double tol, int maxit, int *info, int *iter, double *relres, double *hist_host);
+int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
+                   const double *b_dev, double tol, int maxit, int *info, int *iter,
+                   double *relres, double *hist_host);
+
+/* ------------------------------------------ solver phase kernels (device pointers)
+ * The building blocks of the loops above, exported so that the row-partitioned
+ * multi-GPU driver (pysparse_amd/distributed.py) can interleave them with RCCL
+ * collectives issued through torch.distributed.  Each reduction leaves its result(s) in
+ * out_dev[0..k) on the device (no host synchronisation). */
+
+/* out[0] = sum x_i*y_i */
+int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev);
+/* r := b - r (pcg.c:73-74); out = { r.r, r.z } with z = dinv.*r (dinv may be NULL: z = r) */
+int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv_dev,
+                   double *out_dev);
+/* p := z + beta*p (pcg.c:113-114), z = dinv.*r or r; first != 0: p := z (pcg.c:106) */
+int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double beta, int first,
+                  double *p_dev);
+/* q := A p and out[0] = p.q in one pass (pcg.c:116-117); p has A.ncols entries of which
+ * the first p_offset.. rows' worth are the owned ones: out = sum p[p_offset+i]*q[i] */
+int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
+                         double *out_dev);
+/* stagnation scan + x += alpha p, r -= alpha q (pcg.c:127-143) and
+ * out = { r.r, r.z (z = dinv.*r), nonstag } where nonstag != 0 iff 1 + dmax != 1 */
+int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,
+                    const double *dinv_dev, double *x_dev, double *r_dev, double *out_dev);
+/* gather send_dev[i] = v[idx[i]] (halo packing) */
+int psp_k_gather(int count, const int *idx_dev, const double *v_dev, double *send_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSPARSE_HIP_H */

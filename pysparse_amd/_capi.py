@@ -1,0 +1,115 @@
+"""ctypes binding of libpysparse_hip.so (include/pysparse_hip.h).
+
+Used by bench.py, the GPU tests and the multi-GPU driver; the drop-in extension modules
+(pysparse_amd.sparse.spmatrix, .itsolvers.krylov, .precon.precon) link the same library
+directly from C.  There is no CPU fallback: every compute call raises when no GPU is
+present or the library is missing.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpysparse_hip.so")
+
+# every symbol include/pysparse_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = """
+psp_last_error psp_version psp_device_count psp_set_device psp_set_stream psp_synchronize
+psp_device_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset
+psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms
+psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_destroy psp_csr_shape
+psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
+psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
+psp_csr_device_bytes
+psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
+psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
+psp_jacobi_create_csr psp_jacobi_create_sss psp_jacobi_create_diag psp_jacobi_destroy
+psp_jacobi_shape psp_jacobi_precon psp_jacobi_precon_dev
+psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_callback psp_op_destroy
+psp_pcg psp_pcg_dev psp_minres psp_minres_dev
+psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
+""".split()
+
+HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+class PspError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libpysparse_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PspError(rc, lib().psp_last_error().decode())
+    return rc
+
+
+def _declare(L):
+    vp, i, d, i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
+    pvp, pi, pd = C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_double)
+    sz, pt = C.c_size_t, C.c_ssize_t
+    L.psp_last_error.restype = C.c_char_p
+    L.psp_last_error.argtypes = []
+    L.psp_version.restype = C.c_char_p
+    L.psp_version.argtypes = []
+    L.psp_device_count.restype = i
+    L.psp_device_count.argtypes = []
+    sig = {
+        "psp_set_device": [i], "psp_set_stream": [vp], "psp_synchronize": [],
+        "psp_device_info": [C.c_char_p, i, pi, C.POINTER(i64)],
+        "psp_malloc": [pvp, sz], "psp_free": [vp], "psp_memcpy_h2d": [vp, vp, sz],
+        "psp_memcpy_d2h": [vp, vp, sz], "psp_memset": [vp, i, sz],
+        "psp_event_create": [pvp], "psp_event_destroy": [vp], "psp_event_record": [vp],
+        "psp_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "psp_csr_create": [i, i, i, vp, vp, vp, pvp],
+        "psp_csr_poisson": [i, i, i, pvp],
+        "psp_csr_poisson_slab": [i, i, i, i64, i64, i64, i, pvp],
+        "psp_csr_destroy": [vp], "psp_csr_shape": [vp, pi, pi, pi],
+        "psp_csr_download": [vp, vp, vp, vp], "psp_csr_diagonal": [vp, vp],
+        "psp_csr_matvec": [vp, vp, vp], "psp_csr_matvec_stride": [vp, vp, pt, vp, pt],
+        "psp_csr_matvec_transp": [vp, vp, vp], "psp_csr_matvec_transp_stride": [vp, vp, pt, vp, pt],
+        "psp_csr_matvec_dev": [vp, vp, vp], "psp_csr_matvec_transp_dev": [vp, vp, vp],
+        "psp_csr_set_variant": [vp, i],
+        "psp_sss_create": [i, i, vp, vp, vp, vp, pvp], "psp_sss_poisson": [i, i, i, pvp],
+        "psp_sss_destroy": [vp], "psp_sss_shape": [vp, pi, pi],
+        "psp_sss_download": [vp, vp, vp, vp, vp], "psp_sss_getitem": [vp, i, i, pd],
+        "psp_sss_matvec": [vp, vp, vp], "psp_sss_matvec_stride": [vp, vp, pt, vp, pt],
+        "psp_sss_matvec_dev": [vp, vp, vp],
+        "psp_jacobi_create_csr": [vp, d, i, pvp], "psp_jacobi_create_sss": [vp, d, i, pvp],
+        "psp_jacobi_create_diag": [i, vp, d, i, vp, pvp], "psp_jacobi_destroy": [vp],
+        "psp_jacobi_shape": [vp, pi], "psp_jacobi_precon": [vp, vp, vp],
+        "psp_jacobi_precon_dev": [vp, vp, vp],
+        "psp_op_from_csr": [vp, pvp], "psp_op_from_sss": [vp, pvp], "psp_op_from_jacobi": [vp, pvp],
+        "psp_op_from_callback": [i, HOST_APPLY_FN, vp, pvp], "psp_op_destroy": [vp],
+        "psp_pcg": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
+        "psp_pcg_dev": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
+        "psp_minres": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
+        "psp_minres_dev": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
+        "psp_k_dot": [i, vp, vp, vp], "psp_k_residual": [i, vp, vp, vp, vp],
+        "psp_k_pupdate": [i, vp, vp, d, i, vp], "psp_k_csr_matvec_dot": [vp, vp, i, vp, vp],
+        "psp_k_xr_update": [i, d, vp, vp, vp, vp, vp, vp], "psp_k_gather": [i, vp, vp, vp],
+    }
+    for name, argtypes in sig.items():
+        f = getattr(L, name)
+        f.restype = i
+        f.argtypes = argtypes
+    L.psp_csr_device_bytes.restype = i64
+    L.psp_csr_device_bytes.argtypes = [vp]
+    L.psp_sss_device_bytes.restype = i64
+    L.psp_sss_device_bytes.argtypes = [vp]

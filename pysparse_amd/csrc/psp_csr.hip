@@ -1,0 +1,877 @@
+// psp_csr.hip -- csr_mat / sss_mat device containers and the SpMV kernels.
+//
+// The hot kernel is csr_spmv_stream.  Reference loop: pysparse/sparse/src/csr_mat.c:49-54
+//     for i: s = 0; for k in [ia[i], ia[i+1]): s += va[k]*x[ja[k]]; y[i] = s
+// 5-7 nonzeros per row (Poisson) means one wavefront per row would idle 57+ lanes and
+// uncoalesce val/col, so the work is cut by NONZEROS, not rows:
+//   * a "chunk" is a run of whole rows holding at most ~TILE nonzeros (table built once
+//     per matrix); a 256-thread workgroup takes one chunk at a time (persistent grid);
+//   * stream phase: the workgroup reads val/col of the chunk with 16-byte-per-lane
+//     coalesced loads, gathers x[col] (L1/L2/Infinity-Cache hits for banded operators),
+//     and parks the rounded products val*x in an LDS tile;
+//   * reduce phase: one lane per row adds that row's products from LDS left to right,
+//     i.e. in exactly the reference's order with separate multiply and add (the library
+//     is built with -ffp-contract=off), so y is bit-identical to the CPU loop;
+//   * optional epilogue: per-workgroup partial of sum u[i]*y[i] (the PCG p.q product)
+//     reduced by wave shuffles + LDS, one slot per workgroup, finished in fixed order.
+// HBM traffic per call: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "psp_internal.h"
+
+using namespace psp;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ chunk table
+
+// chunk c covers rows [tab[c].x, tab[c+1].x) and nonzeros [tab[c].y, tab[c+1].y):
+// tab[c].x = first row r with ind[r] >= c*target  (binary search, one thread per chunk)
+__global__ void build_chunk_table(int nrows, const int *__restrict__ ind, int target, int nchunks,
+                                  int2 *__restrict__ tab) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nchunks) return;
+  int r;
+  if (c == nchunks) {
+    r = nrows;
+  } else {
+    long want = (long)c * target;
+    int lo = 0, hi = nrows;  // first r in [0, nrows] with ind[r] >= want
+    while (lo < hi) {
+      int mid = lo + ((hi - lo) >> 1);
+      if ((long)ind[mid] >= want)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    r = lo;
+  }
+  tab[c] = make_int2(r, ind[r]);
+}
+
+// ------------------------------------------------------------------ SpMV kernel
+
+// native clang vectors: legal operands of the non-temporal load builtin
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ldg(const T *p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-wide sum of v; result valid in thread 0.  sh: 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int TILE, int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_spmv_stream(
+    int nchunks, int map_mode, const int2 *__restrict__ tab, const int *__restrict__ ind,
+    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+  static_assert(TILE % (kBlock * VEC) == 0, "tile must be a whole number of steps");
+  constexpr int STEPS = TILE / (kBlock * VEC);
+  __shared__ double prod[TILE];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int G = gridDim.x;
+  double dsum = 0.0;
+
+  for (int it = 0;; ++it) {
+    int chunk;
+    if (map_mode == 0) {
+      chunk = it * G + (int)blockIdx.x;  // neighbouring chunks run at the same time chip-wide
+    } else {
+      // XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares
+      // an L2), so give each XCD a contiguous stripe of G/8 chunks per sweep: the x
+      // segments of neighbouring grid lines then hit in that XCD's own L2.
+      const int W = G >> 3;
+      chunk = (it * 8 + ((int)blockIdx.x & 7)) * W + ((int)blockIdx.x >> 3);
+    }
+    if (chunk >= nchunks) break;
+
+    const int2 c0 = tab[chunk];
+    const int2 c1 = tab[chunk + 1];
+    const int r0 = c0.x, r1 = c1.x;
+    const int s = c0.y, e = c1.y;
+    double carry = 0.0;
+
+    for (int ts = s & ~3; ts < e || ts == (s & ~3); ts += TILE) {
+      const int te = ts + TILE;
+      // ---- stream phase: products of this tile into LDS
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int off = (st * kBlock + tid) * VEC;
+        int k = ts + off;
+        k = (k < e) ? k : ts;  // past the chunk: re-read the (cached) tile head, result unused
+        if constexpr (VEC == 4) {
+          const i4v c = ldg<NT>(reinterpret_cast<const i4v *>(col + k));
+          const d2v v0 = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
+          const d2v v1 = ldg<NT>(reinterpret_cast<const d2v *>(val + k + 2));
+          d2v p0, p1;
+          p0.x = v0.x * x[c.x];
+          p0.y = v0.y * x[c.y];
+          p1.x = v1.x * x[c.z];
+          p1.y = v1.y * x[c.w];
+          *reinterpret_cast<d2v *>(&prod[off]) = p0;
+          *reinterpret_cast<d2v *>(&prod[off + 2]) = p1;
+        } else if constexpr (VEC == 2) {
+          const i2v c = ldg<NT>(reinterpret_cast<const i2v *>(col + k));
+          const d2v v0 = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
+          d2v p0;
+          p0.x = v0.x * x[c.x];
+          p0.y = v0.y * x[c.y];
+          *reinterpret_cast<d2v *>(&prod[off]) = p0;
+        } else {
+          const int c = ldg<NT>(col + k);
+          const double v0 = ldg<NT>(val + k);
+          prod[off] = v0 * x[c];
+        }
+      }
+      __syncthreads();
+
+      // ---- reduce phase: one lane per row, products added left to right
+      for (int r = r0 + tid; r < r1; r += kBlock) {
+        const int lo = ind[r], hi = ind[r + 1];
+        // A row is finished in the tile that holds its last product (hi <= te); an empty
+        // row sitting exactly on a tile boundary counts for the earlier tile.
+        const bool done_earlier = hi <= ts && ts != (s & ~3);
+        const bool starts_later = lo >= te && hi > te;
+        if (done_earlier || starts_later) continue;
+        double acc = (lo < ts) ? carry : 0.0;
+        const int a = lo > ts ? lo : ts;
+        const int b = hi < te ? hi : te;
+        for (int k = a; k < b; k += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int idx = k + u - ts;
+            idx = idx < TILE ? idx : TILE - 1;
+            v[u] = prod[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < b) ? v[u] : 0.0;
+        }
+        if (hi <= te) {
+          y[r] = acc;
+          if (dotv) dsum += dotv[r] * acc;
+        } else {
+          carry = acc;  // the one row that crosses into the next tile stays with this lane
+        }
+      }
+      __syncthreads();
+      if (te >= e) break;
+    }
+  }
+
+  if (partials) {
+    const double t = block_sum(dsum, red);
+    if (tid == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// y = A^T x: scatter with fp64 HBM atomics (csr_mat.c:74-88).  Not on the Krylov path.
+__global__ void csr_spmv_transp_kernel(int nrows, const int *__restrict__ ind,
+                                       const int *__restrict__ col,
+                                       const double *__restrict__ val,
+                                       const double *__restrict__ x, double *__restrict__ y) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < nrows; r += nwaves) {
+    const double xi = x[r];
+    for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) atomicAdd(&y[col[k]], val[k] * xi);
+  }
+}
+
+__global__ void csr_diag_kernel(int nrows, const int *__restrict__ ind,
+                                const int *__restrict__ col, const double *__restrict__ val,
+                                double *__restrict__ diag) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    double d = 0.0;
+    for (int k = ind[r]; k < ind[r + 1]; ++k)
+      if (col[k] == r) d = val[k];
+    diag[r] = d;
+  }
+}
+
+__global__ void max_row_kernel(int nrows, const int *__restrict__ ind, int *__restrict__ out) {
+  int m = 0;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
+    m = max(m, ind[r + 1] - ind[r]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------ Poisson generators
+
+// nonzeros stored in rows < k of the nx*ny(*nz) 5-/7-point operator (full CSR form)
+__device__ __host__ inline long poisson_prefix(long k, long nx, long ny, long nz) {
+  const long nxy = nx * ny;
+  const bool three_d = nz > 0;
+  const long n = nxy * (three_d ? nz : 1);
+  long missing = (k + nx - 1) / nx;                                  // i == 0
+  missing += k / nx;                                                 // i == nx-1
+  missing += (k / nxy) * nx + (k % nxy < nx ? k % nxy : nx);         // j == 0
+  {
+    long rem = k % nxy - (nxy - nx);
+    missing += (k / nxy) * nx + (rem > 0 ? rem : 0);                 // j == ny-1
+  }
+  if (three_d) {
+    missing += k < nxy ? k : nxy;                                    // l == 0
+    long rem = k - (n - nxy);
+    missing += rem > 0 ? rem : 0;                                    // l == nz-1
+  }
+  return (three_d ? 7 : 5) * k - missing;
+}
+
+// strict-lower nonzeros stored in rows < k (SSS form)
+__device__ __host__ inline long poisson_lower_prefix(long k, long nx, long ny, long nz) {
+  const long nxy = nx * ny;
+  const bool three_d = nz > 0;
+  long missing = (k + nx - 1) / nx;                                  // i == 0: no k-1
+  missing += (k / nxy) * nx + (k % nxy < nx ? k % nxy : nx);         // j == 0: no k-nx
+  if (three_d) missing += k < nxy ? k : nxy;                         // l == 0: no k-nxy
+  return (three_d ? 3 : 2) * k - missing;
+}
+
+__global__ void poisson_csr_kernel(int nx, int ny, int nz, long row_lo, long row_hi, long col_shift,
+                                   int *__restrict__ ind, int *__restrict__ col,
+                                   double *__restrict__ val) {
+  const long nxy = (long)nx * ny;
+  const bool three_d = nz > 0;
+  const double dg = three_d ? 6.0 : 4.0;
+  const long base = poisson_prefix(row_lo, nx, ny, nz);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = row_lo + (long)blockIdx.x * blockDim.x + threadIdx.x; k <= row_hi; k += stride) {
+    long p = poisson_prefix(k, nx, ny, nz) - base;
+    ind[k - row_lo] = (int)p;
+    if (k == row_hi) break;
+    const int i = (int)(k % nx);
+    const int j = (int)((k / nx) % ny);
+    const long l = k / nxy;
+    if (three_d && l > 0) { col[p] = (int)(k - nxy - col_shift); val[p++] = -1.0; }
+    if (j > 0)            { col[p] = (int)(k - nx - col_shift);  val[p++] = -1.0; }
+    if (i > 0)            { col[p] = (int)(k - 1 - col_shift);   val[p++] = -1.0; }
+    col[p] = (int)(k - col_shift); val[p++] = dg;
+    if (i < nx - 1)       { col[p] = (int)(k + 1 - col_shift);   val[p++] = -1.0; }
+    if (j < ny - 1)       { col[p] = (int)(k + nx - col_shift);  val[p++] = -1.0; }
+    if (three_d && l < nz - 1) { col[p] = (int)(k + nxy - col_shift); val[p++] = -1.0; }
+  }
+}
+
+__global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restrict__ ind,
+                                   int *__restrict__ col, double *__restrict__ val,
+                                   double *__restrict__ diag) {
+  const long nxy = (long)nx * ny;
+  const bool three_d = nz > 0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += stride) {
+    long p = poisson_lower_prefix(k, nx, ny, nz);
+    ind[k] = (int)p;
+    if (k == n) break;
+    const int i = (int)(k % nx);
+    const int j = (int)((k / nx) % ny);
+    const long l = k / nxy;
+    if (three_d && l > 0) { col[p] = (int)(k - nxy); val[p++] = -1.0; }
+    if (j > 0)            { col[p] = (int)(k - nx);  val[p++] = -1.0; }
+    if (i > 0)            { col[p] = (int)(k - 1);   val[p++] = -1.0; }
+    diag[k] = three_d ? 6.0 : 4.0;
+  }
+}
+
+// ------------------------------------------------------------------ host helpers
+
+struct Variant {
+  int tile, vec;
+  bool nt;
+  int map_mode;
+};
+
+Variant decode_variant(int v) {
+  // bits 0-1: vec (0 -> 4, 1 -> 2, 2 -> 1); bit 2: tile 2048 instead of 4096;
+  // bit 3: non-temporal val/col loads; bit 4: XCD-striped chunk order
+  if (v < 0) v = 0;
+  Variant r;
+  static const int vecs[4] = {4, 2, 1, 4};
+  r.vec = vecs[v & 3];
+  r.tile = (v & 4) ? 2048 : 4096;
+  r.nt = (v & 8) != 0;
+  r.map_mode = (v & 16) ? 1 : 0;
+  return r;
+}
+
+int alloc_csr(int nrows, int ncols, long nnz, psp_csr **out) {
+  if (nrows < 0 || ncols < 0 || nnz < 0 || nnz > 0x7fffffffL)
+    return fail(PSP_EINVAL, "csr: invalid shape (%d x %d, nnz %ld)", nrows, ncols, nnz);
+  PSP_TRY(ensure_device());
+  psp_csr *A = new psp_csr();
+  A->nrows = nrows;
+  A->ncols = ncols;
+  A->nnz = (int)nnz;
+  A->padded = ((size_t)nnz + 3) / 4 * 4 + 8;  // vector loads may run past nnz by < 8 entries
+  hipError_t e1 = hipMalloc((void **)&A->ind, sizeof(int) * ((size_t)nrows + 1));
+  hipError_t e2 = hipMalloc((void **)&A->col, sizeof(int) * A->padded);
+  hipError_t e3 = hipMalloc((void **)&A->val, sizeof(double) * A->padded);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    (void)hipFree(A->ind);
+    (void)hipFree(A->col);
+    (void)hipFree(A->val);
+    delete A;
+    return fail(PSP_ENOMEM, "csr: device allocation of %ld nonzeros failed", nnz);
+  }
+  // the padding must hold valid column indices (they are gathered, results unused)
+  (void)hipMemsetAsync(A->col + nnz, 0, sizeof(int) * (A->padded - nnz), stream());
+  (void)hipMemsetAsync(A->val + nnz, 0, sizeof(double) * (A->padded - nnz), stream());
+  *out = A;
+  return PSP_OK;
+}
+
+}  // namespace
+
+// chunk tables are cached per (matrix, tile) in the handle
+struct ChunkTable {
+  int tile = 0;
+  int nchunks = 0;
+  int2 *tab = nullptr;
+};
+static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
+
+namespace psp {
+
+struct CsrExtra {
+  ChunkTable t[2];
+};
+
+}  // namespace psp
+
+// one side table per handle, keyed by pointer (keeps psp_csr POD-like for the solvers)
+#include <mutex>
+#include <unordered_map>
+static std::unordered_map<const psp_csr *, psp::CsrExtra> g_extra;
+static std::mutex g_extra_mu;
+
+static int finalize_csr(psp_csr *A) {
+  // max row length decides the chunk target (TILE - max_row - 3 keeps a chunk in one tile)
+  int *d_max;
+  PSP_HIP(hipMalloc((void **)&d_max, sizeof(int)));
+  PSP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), stream()));
+  if (A->nrows > 0) {
+    int grid = std::min((A->nrows + 255) / 256, 2048);
+    hipLaunchKernelGGL(max_row_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind, d_max);
+    PSP_LAUNCH_CHECK();
+  }
+  PSP_HIP(hipMemcpyAsync(&A->max_row_nnz, d_max, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_max));
+  return PSP_OK;
+}
+
+static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  psp::CsrExtra &ex = g_extra[A];
+  ChunkTable &t = ex.t[tile == 4096 ? 0 : 1];
+  if (t.tab == nullptr) {
+    int target = tile - 3 - A->max_row_nnz;
+    if (target < tile / 2) target = tile / 2;  // very long rows: chunks spill into more tiles
+    long nch = ((long)A->nnz + target - 1) / target;
+    if (nch < 1) nch = 1;
+    t.tile = tile;
+    t.nchunks = (int)nch;
+    PSP_HIP(hipMalloc((void **)&t.tab, sizeof(int2) * (nch + 1)));
+    int grid = (int)((nch + 1 + 255) / 256);
+    hipLaunchKernelGGL(build_chunk_table, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind,
+                       target, (int)nch, t.tab);
+    PSP_LAUNCH_CHECK();
+  }
+  *out = &t;
+  return PSP_OK;
+}
+
+namespace psp {
+
+template <int TILE, int VEC, bool NT>
+static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab, const psp_csr *A,
+                           const double *x, double *y, const double *dotv, double *partials) {
+  hipLaunchKernelGGL((csr_spmv_stream<TILE, VEC, NT>), dim3(grid), dim3(kBlock), 0, stream(),
+                     nchunks, map_mode, tab, A->ind, A->col, A->val, x, y, dotv, partials);
+}
+
+int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
+                    double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const Variant v = decode_variant(A->variant);
+  ChunkTable *t;
+  PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
+  // persistent grid: as many workgroups as stay resident (LDS: 32 KiB -> 5/CU, 16 KiB -> 8/CU)
+  const int per_cu = v.tile == 4096 ? 5 : 8;
+  int grid = std::min(t->nchunks, std::min(w->num_cu * per_cu, kMaxParts));
+  if (v.map_mode == 1) {
+    grid = grid / 8 * 8;
+    if (grid < 8) grid = 8;
+  }
+  if (grid < 1) grid = 1;
+#define PSP_CASE(TILE, VEC, NT)                                                             \
+  launch_variant<TILE, VEC, NT>(grid, t->nchunks, v.map_mode, t->tab, A, x, y, dotv, partials)
+  if (v.tile == 4096) {
+    if (v.vec == 4) { if (v.nt) PSP_CASE(4096, 4, true); else PSP_CASE(4096, 4, false); }
+    else if (v.vec == 2) { if (v.nt) PSP_CASE(4096, 2, true); else PSP_CASE(4096, 2, false); }
+    else { if (v.nt) PSP_CASE(4096, 1, true); else PSP_CASE(4096, 1, false); }
+  } else {
+    if (v.vec == 4) { if (v.nt) PSP_CASE(2048, 4, true); else PSP_CASE(2048, 4, false); }
+    else if (v.vec == 2) { if (v.nt) PSP_CASE(2048, 2, true); else PSP_CASE(2048, 2, false); }
+    else { if (v.nt) PSP_CASE(2048, 1, true); else PSP_CASE(2048, 1, false); }
+  }
+#undef PSP_CASE
+  PSP_LAUNCH_CHECK();
+  if (nparts) *nparts = grid;
+  return PSP_OK;
+}
+
+}  // namespace psp
+
+// ------------------------------------------------------------------ staging helpers
+
+namespace {
+
+struct DevBuf {
+  double *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t n) {
+    PSP_HIP(hipMalloc((void **)&p, sizeof(double) * (n ? n : 1)));
+    return PSP_OK;
+  }
+};
+
+int upload_strided(double *dev, const double *host, size_t n, ptrdiff_t inc) {
+  if (inc == 1) {
+    PSP_HIP(hipMemcpyAsync(dev, host, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    return PSP_OK;
+  }
+  std::vector<double> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = host[(ptrdiff_t)i * inc];
+  PSP_HIP(hipMemcpyAsync(dev, tmp.data(), sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int download_strided(double *host, const double *dev, size_t n, ptrdiff_t inc) {
+  if (inc == 1) {
+    PSP_HIP(hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    return PSP_OK;
+  }
+  std::vector<double> tmp(n);
+  PSP_HIP(hipMemcpyAsync(tmp.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  for (size_t i = 0; i < n; ++i) host[(ptrdiff_t)i * inc] = tmp[i];
+  return PSP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI: csr
+
+extern "C" {
+
+int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int *col_host,
+                   const double *val_host, psp_csr_t **out) {
+  if (!out || !ind_host || (nnz > 0 && (!col_host || !val_host)))
+    return fail(PSP_EINVAL, "psp_csr_create: NULL argument");
+  if (nrows < 0 || ncols < 0 || nnz < 0) return fail(PSP_EINVAL, "psp_csr_create: negative size");
+  // validate on the host: a malformed triple must never reach a kernel
+  if (ind_host[0] != 0 || ind_host[nrows] != nnz)
+    return fail(PSP_EINVAL, "psp_csr_create: ind[0] must be 0 and ind[nrows] == nnz");
+  for (int i = 0; i < nrows; ++i)
+    if (ind_host[i + 1] < ind_host[i])
+      return fail(PSP_EINVAL, "psp_csr_create: ind not monotone at row %d", i);
+  for (int k = 0; k < nnz; ++k)
+    if (col_host[k] < 0 || col_host[k] >= ncols)
+      return fail(PSP_EINVAL, "psp_csr_create: column index %d out of range at %d", col_host[k], k);
+  psp_csr *A;
+  PSP_TRY(alloc_csr(nrows, ncols, nnz, &A));
+  PSP_HIP(hipMemcpyAsync(A->ind, ind_host, sizeof(int) * ((size_t)nrows + 1),
+                         hipMemcpyHostToDevice, stream()));
+  if (nnz > 0) {
+    PSP_HIP(hipMemcpyAsync(A->col, col_host, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice,
+                           stream()));
+    PSP_HIP(hipMemcpyAsync(A->val, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice,
+                           stream()));
+  }
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_TRY(finalize_csr(A));
+  *out = A;
+  return PSP_OK;
+}
+
+int psp_csr_poisson_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi,
+                         int64_t col_shift, int ncols_local, psp_csr_t **out) {
+  if (!out || nx < 1 || ny < 1 || nz < 0) return fail(PSP_EINVAL, "psp_csr_poisson: bad grid");
+  const long n = (long)nx * ny * (nz > 0 ? nz : 1);
+  if (row_lo < 0 || row_hi > n || row_lo > row_hi)
+    return fail(PSP_EINVAL, "psp_csr_poisson: bad row range");
+  const long nloc = row_hi - row_lo;
+  const long nnz = poisson_prefix(row_hi, nx, ny, nz) - poisson_prefix(row_lo, nx, ny, nz);
+  if (nloc > 0x7fffffffL || nnz > 0x7fffffffL || ncols_local < 0)
+    return fail(PSP_EINVAL, "psp_csr_poisson: local part exceeds 32-bit indices");
+  // every local column index must land inside [0, ncols_local)
+  const long reach = nz > 0 ? (long)nx * ny : nx;
+  long cmin = (row_lo - reach > 0 ? row_lo - reach : 0) - col_shift;
+  long cmax = (row_hi - 1 + reach < n - 1 ? row_hi - 1 + reach : n - 1) - col_shift;
+  if (nloc > 0 && (cmin < 0 || cmax >= ncols_local))
+    return fail(PSP_EINVAL, "psp_csr_poisson: col_shift/ncols_local do not cover the halo");
+  psp_csr *A;
+  PSP_TRY(alloc_csr((int)nloc, ncols_local, nnz, &A));
+  int grid = (int)std::min<long>((nloc + 1 + 255) / 256, 8192);
+  hipLaunchKernelGGL(poisson_csr_kernel, dim3(grid), dim3(256), 0, stream(), nx, ny, nz,
+                     (long)row_lo, (long)row_hi, (long)col_shift, A->ind, A->col, A->val);
+  PSP_LAUNCH_CHECK();
+  PSP_TRY(finalize_csr(A));
+  *out = A;
+  return PSP_OK;
+}
+
+int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out) {
+  const long n = (long)nx * ny * (nz > 0 ? nz : 1);
+  if (n > 0x7fffffffL) return fail(PSP_EINVAL, "psp_csr_poisson: n exceeds 32-bit indices");
+  return psp_csr_poisson_slab(nx, ny, nz, 0, n, 0, (int)n, out);
+}
+
+int psp_csr_destroy(psp_csr_t *A) {
+  if (!A) return PSP_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    auto it = g_extra.find(A);
+    if (it != g_extra.end()) {
+      for (auto &t : it->second.t)
+        if (t.tab) (void)hipFree(t.tab);
+      g_extra.erase(it);
+    }
+  }
+  (void)hipFree(A->ind);
+  (void)hipFree(A->col);
+  (void)hipFree(A->val);
+  delete A;
+  return PSP_OK;
+}
+
+int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz) {
+  if (!A) return fail(PSP_EINVAL, "psp_csr_shape: NULL handle");
+  if (nrows) *nrows = A->nrows;
+  if (ncols) *ncols = A->ncols;
+  if (nnz) *nnz = A->nnz;
+  return PSP_OK;
+}
+
+int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host) {
+  if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
+  if (ind_host)
+    PSP_HIP(hipMemcpyAsync(ind_host, A->ind, sizeof(int) * ((size_t)A->nrows + 1),
+                           hipMemcpyDeviceToHost, stream()));
+  if (col_host && A->nnz)
+    PSP_HIP(hipMemcpyAsync(col_host, A->col, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost,
+                           stream()));
+  if (val_host && A->nnz)
+    PSP_HIP(hipMemcpyAsync(val_host, A->val, sizeof(double) * (size_t)A->nnz,
+                           hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
+  if (A->nrows == 0) return PSP_OK;
+  int grid = std::min((A->nrows + 255) / 256, 4096);
+  hipLaunchKernelGGL(csr_diag_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind, A->col,
+                     A->val, diag_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
+  if (!A || !diag_host) return fail(PSP_EINVAL, "psp_csr_diagonal: NULL argument");
+  DevBuf d;
+  PSP_TRY(d.alloc(A->nrows));
+  PSP_TRY(psp_csr_diagonal_dev(A, d.p));
+  return download_strided(diag_host, d.p, A->nrows, 1);
+}
+
+int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
+  if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_dev: NULL argument");
+  if (A->nrows == 0) return PSP_OK;
+  return csr_spmv_launch(A, x_dev, y_dev, nullptr, nullptr, nullptr);
+}
+
+int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
+                          ptrdiff_t incy) {
+  if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
+  PSP_TRY(ensure_device());
+  DevBuf x, y;
+  PSP_TRY(x.alloc(A->ncols));
+  PSP_TRY(y.alloc(A->nrows));
+  PSP_TRY(upload_strided(x.p, x_host, A->ncols, incx));
+  PSP_TRY(psp_csr_matvec_dev(A, x.p, y.p));
+  return download_strided(y_host, y.p, A->nrows, incy);
+}
+
+int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
+  return psp_csr_matvec_stride(A, x_host, 1, y_host, 1);
+}
+
+int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
+  if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
+  PSP_HIP(hipMemsetAsync(y_dev, 0, sizeof(double) * (size_t)A->ncols, stream()));
+  if (A->nrows == 0 || A->nnz == 0) return PSP_OK;
+  int grid = std::min((A->nrows + 3) / 4, 8192);
+  hipLaunchKernelGGL(csr_spmv_transp_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind,
+                     A->col, A->val, x_dev, y_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
+                                 double *y_host, ptrdiff_t incy) {
+  if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec_transp: NULL argument");
+  PSP_TRY(ensure_device());
+  DevBuf x, y;
+  PSP_TRY(x.alloc(A->nrows));
+  PSP_TRY(y.alloc(A->ncols));
+  PSP_TRY(upload_strided(x.p, x_host, A->nrows, incx));
+  PSP_TRY(psp_csr_matvec_transp_dev(A, x.p, y.p));
+  return download_strided(y_host, y.p, A->ncols, incy);
+}
+
+int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host) {
+  return psp_csr_matvec_transp_stride(A, x_host, 1, y_host, 1);
+}
+
+int psp_csr_set_variant(psp_csr_t *A, int variant) {
+  if (!A) return fail(PSP_EINVAL, "psp_csr_set_variant: NULL handle");
+  A->variant = variant;
+  return PSP_OK;
+}
+
+int64_t psp_csr_device_bytes(const psp_csr_t *A) {
+  if (!A) return 0;
+  return (int64_t)(sizeof(int) * ((size_t)A->nrows + 1) + (sizeof(int) + sizeof(double)) * A->padded);
+}
+
+// ------------------------------------------------------------------ C ABI: sss
+
+int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_host,
+                   const double *val_host, const double *diag_host, psp_sss_t **out) {
+  if (!out || !ind_host || !diag_host || (nnz_lower > 0 && (!col_host || !val_host)))
+    return fail(PSP_EINVAL, "psp_sss_create: NULL argument");
+  if (n < 0 || nnz_lower < 0) return fail(PSP_EINVAL, "psp_sss_create: negative size");
+  if (ind_host[0] != 0 || ind_host[n] != nnz_lower)
+    return fail(PSP_EINVAL, "psp_sss_create: ind[0] must be 0 and ind[n] == nnz");
+  for (int i = 0; i < n; ++i) {
+    if (ind_host[i + 1] < ind_host[i])
+      return fail(PSP_EINVAL, "psp_sss_create: ind not monotone at row %d", i);
+    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k)
+      if (col_host[k] < 0 || col_host[k] >= i)
+        return fail(PSP_EINVAL, "psp_sss_create: entry (%d,%d) is not strictly lower", i,
+                    col_host[k]);
+  }
+  if (2L * nnz_lower + n > 0x7fffffffL)
+    return fail(PSP_EINVAL, "psp_sss_create: expanded matrix exceeds 32-bit indices");
+  PSP_TRY(ensure_device());
+
+  // Expand to the full, column-sorted CSR the device multiplies with.  Row i receives its
+  // lower entries (stored order), the diagonal, then the mirrored entries (i, r) for the
+  // rows r > i that reference column i, appended in ascending r -- the summation order of
+  // sss_matvec (sss_mat.c:45-55).
+  std::vector<int> find((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    find[i + 1] += ind_host[i + 1] - ind_host[i] + 1;
+    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) find[col_host[k] + 1] += 1;
+  }
+  for (int i = 0; i < n; ++i) find[i + 1] += find[i];
+  const int fnnz = find[n];
+  std::vector<int> fcol((size_t)fnnz), fill(find.begin(), find.end() - 1);
+  std::vector<double> fval((size_t)fnnz);
+  for (int i = 0; i < n; ++i) {
+    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) {
+      fcol[fill[i]] = col_host[k];
+      fval[fill[i]++] = val_host[k];
+    }
+    fcol[fill[i]] = i;
+    fval[fill[i]++] = diag_host[i];
+  }
+  for (int i = 0; i < n; ++i)
+    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) {
+      const int j = col_host[k];
+      fcol[fill[j]] = i;
+      fval[fill[j]++] = val_host[k];
+    }
+
+  psp_sss *S = new psp_sss();
+  S->n = n;
+  S->nnz_lower = nnz_lower;
+  int rc = psp_csr_create(n, n, fnnz, find.data(), fcol.data(), fval.data(), &S->full);
+  if (rc != PSP_OK) {
+    delete S;
+    return rc;
+  }
+  hipError_t e1 = hipMalloc((void **)&S->ind, sizeof(int) * ((size_t)n + 1));
+  hipError_t e2 = hipMalloc((void **)&S->col, sizeof(int) * (size_t)(nnz_lower ? nnz_lower : 1));
+  hipError_t e3 = hipMalloc((void **)&S->val, sizeof(double) * (size_t)(nnz_lower ? nnz_lower : 1));
+  hipError_t e4 = hipMalloc((void **)&S->diag, sizeof(double) * (size_t)(n ? n : 1));
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    psp_sss_destroy(S);
+    return fail(PSP_ENOMEM, "psp_sss_create: device allocation failed");
+  }
+  PSP_HIP(hipMemcpyAsync(S->ind, ind_host, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice,
+                         stream()));
+  if (nnz_lower) {
+    PSP_HIP(hipMemcpyAsync(S->col, col_host, sizeof(int) * (size_t)nnz_lower,
+                           hipMemcpyHostToDevice, stream()));
+    PSP_HIP(hipMemcpyAsync(S->val, val_host, sizeof(double) * (size_t)nnz_lower,
+                           hipMemcpyHostToDevice, stream()));
+  }
+  if (n)
+    PSP_HIP(hipMemcpyAsync(S->diag, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
+                           stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  *out = S;
+  return PSP_OK;
+}
+
+int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out) {
+  if (!out || nx < 1 || ny < 1 || nz < 0) return fail(PSP_EINVAL, "psp_sss_poisson: bad grid");
+  const long n = (long)nx * ny * (nz > 0 ? nz : 1);
+  if (n > 0x7fffffffL) return fail(PSP_EINVAL, "psp_sss_poisson: n exceeds 32-bit indices");
+  const long nnzl = poisson_lower_prefix(n, nx, ny, nz);
+  PSP_TRY(ensure_device());
+  psp_sss *S = new psp_sss();
+  S->n = (int)n;
+  S->nnz_lower = (int)nnzl;
+  int rc = psp_csr_poisson(nx, ny, nz, &S->full);
+  if (rc != PSP_OK) {
+    delete S;
+    return rc;
+  }
+  hipError_t e1 = hipMalloc((void **)&S->ind, sizeof(int) * ((size_t)n + 1));
+  hipError_t e2 = hipMalloc((void **)&S->col, sizeof(int) * (size_t)(nnzl ? nnzl : 1));
+  hipError_t e3 = hipMalloc((void **)&S->val, sizeof(double) * (size_t)(nnzl ? nnzl : 1));
+  hipError_t e4 = hipMalloc((void **)&S->diag, sizeof(double) * (size_t)n);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    psp_sss_destroy(S);
+    return fail(PSP_ENOMEM, "psp_sss_poisson: device allocation failed");
+  }
+  int grid = (int)std::min<long>((n + 1 + 255) / 256, 8192);
+  hipLaunchKernelGGL(poisson_sss_kernel, dim3(grid), dim3(256), 0, stream(), nx, ny, nz, n, S->ind,
+                     S->col, S->val, S->diag);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  *out = S;
+  return PSP_OK;
+}
+
+int psp_sss_destroy(psp_sss_t *S) {
+  if (!S) return PSP_OK;
+  psp_csr_destroy(S->full);
+  (void)hipFree(S->ind);
+  (void)hipFree(S->col);
+  (void)hipFree(S->val);
+  (void)hipFree(S->diag);
+  delete S;
+  return PSP_OK;
+}
+
+int psp_sss_shape(const psp_sss_t *S, int *n, int *nnz_reported) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_shape: NULL handle");
+  if (n) *n = S->n;
+  if (nnz_reported) *nnz_reported = S->nnz_lower + S->n;  // sss_mat.c:155
+  return PSP_OK;
+}
+
+int psp_sss_download(const psp_sss_t *S, int *ind_host, int *col_host, double *val_host,
+                     double *diag_host) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_download: NULL handle");
+  if (ind_host)
+    PSP_HIP(hipMemcpyAsync(ind_host, S->ind, sizeof(int) * ((size_t)S->n + 1),
+                           hipMemcpyDeviceToHost, stream()));
+  if (col_host && S->nnz_lower)
+    PSP_HIP(hipMemcpyAsync(col_host, S->col, sizeof(int) * (size_t)S->nnz_lower,
+                           hipMemcpyDeviceToHost, stream()));
+  if (val_host && S->nnz_lower)
+    PSP_HIP(hipMemcpyAsync(val_host, S->val, sizeof(double) * (size_t)S->nnz_lower,
+                           hipMemcpyDeviceToHost, stream()));
+  if (diag_host && S->n)
+    PSP_HIP(hipMemcpyAsync(diag_host, S->diag, sizeof(double) * (size_t)S->n,
+                           hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_sss_getitem(const psp_sss_t *S, int i, int j, double *value) {
+  if (!S || !value) return fail(PSP_EINVAL, "psp_sss_getitem: NULL argument");
+  if (i < 0 || j < 0 || i >= S->n || j >= S->n)
+    return fail(PSP_EINVAL, "psp_sss_getitem: indices out of range");
+  if (i == j) {
+    PSP_HIP(hipMemcpy(value, S->diag + i, sizeof(double), hipMemcpyDeviceToHost));
+    return PSP_OK;
+  }
+  if (i < j) std::swap(i, j);
+  int lohi[2];
+  PSP_HIP(hipMemcpy(lohi, S->ind + i, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  *value = 0.0;
+  const int len = lohi[1] - lohi[0];
+  if (len > 0) {
+    std::vector<int> c((size_t)len);
+    PSP_HIP(hipMemcpy(c.data(), S->col + lohi[0], sizeof(int) * (size_t)len, hipMemcpyDeviceToHost));
+    for (int k = 0; k < len; ++k)
+      if (c[k] == j) {
+        PSP_HIP(hipMemcpy(value, S->val + lohi[0] + k, sizeof(double), hipMemcpyDeviceToHost));
+        break;
+      }
+  }
+  return PSP_OK;
+}
+
+int psp_sss_matvec_dev(psp_sss_t *S, const double *x_dev, double *y_dev) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_matvec_dev: NULL handle");
+  return psp_csr_matvec_dev(S->full, x_dev, y_dev);
+}
+
+int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, double *y_host,
+                          ptrdiff_t incy) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_matvec: NULL handle");
+  return psp_csr_matvec_stride(S->full, x_host, incx, y_host, incy);
+}
+
+int psp_sss_matvec(psp_sss_t *S, const double *x_host, double *y_host) {
+  return psp_sss_matvec_stride(S, x_host, 1, y_host, 1);
+}
+
+int64_t psp_sss_device_bytes(const psp_sss_t *S) {
+  if (!S) return 0;
+  return psp_csr_device_bytes(S->full) + (int64_t)sizeof(int) * (S->n + 1) +
+         (int64_t)(sizeof(int) + sizeof(double)) * S->nnz_lower + (int64_t)sizeof(double) * S->n;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// psp_internal.h -- shared declarations inside libpysparse_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "pysparse_hip.h"
+
+namespace psp {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+hipStream_t stream();
+int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
+
+#define PSP_HIP(call)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return psp::fail(e_ == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "%s: %s (%s:%d)", \
+                       #call, hipGetErrorString(e_), __FILE__, __LINE__);                \
+  } while (0)
+
+#define PSP_TRY(call)        \
+  do {                       \
+    int rc_ = (call);        \
+    if (rc_ != PSP_OK)       \
+      return rc_;            \
+  } while (0)
+
+#define PSP_LAUNCH_CHECK() PSP_HIP(hipGetLastError())
+
+// Reductions: every reducing kernel is launched with at most kMaxParts blocks; block b
+// leaves its partial sums in partials[slot*kMaxParts + b]; a one-block finishing kernel
+// adds them in index order.  Fixed grid + fixed order => bitwise reproducible results.
+constexpr int kMaxParts = 2048;
+constexpr int kSlots = 4;
+
+struct Workspace {
+  double *partials = nullptr;   // kSlots * kMaxParts doubles (device)
+  double *scal_dev = nullptr;   // 16 doubles (device)
+  double *scal_host = nullptr;  // 16 doubles (pinned host)
+  int num_cu = 0;
+  int device = -1;
+};
+int workspace(Workspace **out);
+
+// grid for streaming n-element vector kernels (256 threads, 2 doubles per lane per step)
+inline int vec_grid(const Workspace &w, long n) {
+  long want = (n + 511) / 512;
+  long cap = (long)w.num_cu * 8;
+  if (cap > kMaxParts) cap = kMaxParts;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+// finish: out_dev[j] = sum_b partials[j*kMaxParts + b], j < nvals, b < nparts
+int finish_partials(const double *partials, int nparts, int nvals, double *out_dev);
+// copy k scalars device -> host (synchronises the stream)
+int fetch_scalars(const double *src_dev, int k, double *dst_host);
+
+}  // namespace psp
+
+struct psp_csr {
+  int nrows = 0, ncols = 0, nnz = 0;
+  int *ind = nullptr;     // nrows + 1
+  int *col = nullptr;     // padded to a multiple of 4 entries (+4)
+  double *val = nullptr;  // same padding
+  size_t padded = 0;
+  int rows_per_chunk = 0;  // SpMV work decomposition (see psp_csr.hip)
+  int nchunks = 0;
+  int variant = -1;  // kernel variant override, -1 = default
+  int max_row_nnz = 0;
+};
+
+struct psp_sss {
+  int n = 0, nnz_lower = 0;
+  int *ind = nullptr;
+  int *col = nullptr;
+  double *val = nullptr;
+  double *diag = nullptr;
+  psp_csr *full = nullptr;  // expanded full-CSR device mirror used by matvec
+};
+
+enum psp_op_kind { PSP_OP_CSR = 1, PSP_OP_SSS = 2, PSP_OP_JACOBI = 3, PSP_OP_CALLBACK = 4 };
+
+struct psp_op {
+  int kind = 0;
+  int n = 0;
+  psp_csr *csr = nullptr;
+  psp_sss *sss = nullptr;
+  psp_jacobi *jac = nullptr;
+  psp_host_apply_fn fn = nullptr;
+  void *ctx = nullptr;
+  // pinned staging for callback operators
+  double *hx = nullptr, *hy = nullptr;
+};
+
+struct psp_jacobi {
+  int n = 0;
+  double omega = 1.0;
+  int steps = 1;
+  double *dinv = nullptr;
+  double *temp = nullptr;  // steps > 1
+  psp_op A;                // operator for the extra sweeps (kind == 0 when absent)
+};
+
+namespace psp {
+// y = op(x) on device vectors; y must not alias x
+int op_apply(const psp_op *op, const double *x_dev, double *y_dev);
+// the csr that a native operator multiplies with (csr, or sss->full); nullptr otherwise
+inline psp_csr *op_native_csr(const psp_op *op) {
+  if (!op) return nullptr;
+  if (op->kind == PSP_OP_CSR) return op->csr;
+  if (op->kind == PSP_OP_SSS) return op->sss->full;
+  return nullptr;
+}
+int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
+                    double *partials, int *nparts);
+int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+}  // namespace psp

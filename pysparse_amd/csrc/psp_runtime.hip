@@ -1,0 +1,212 @@
+// psp_runtime.hip -- device selection, stream, memory, events, reduction workspace.
+#include <cstring>
+#include <mutex>
+
+#include "psp_internal.h"
+
+namespace psp {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static int g_device = 0;
+static int g_dev_state = 0;  // 0 unknown, 1 ok, -1 none
+static Workspace g_ws;
+static std::mutex g_mu;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+const char *last_error() { return g_err.c_str(); }
+
+hipStream_t stream() { return g_stream; }
+
+int ensure_device() {
+  if (g_dev_state == 1) return PSP_OK;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0) {
+    g_dev_state = -1;
+    return fail(PSP_ENODEV,
+                "no HIP device available (%s); libpysparse_hip has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (g_device >= cnt)
+    return fail(PSP_ENODEV, "device %d requested but only %d visible", g_device, cnt);
+  PSP_HIP(hipSetDevice(g_device));
+  g_dev_state = 1;
+  return PSP_OK;
+}
+
+int workspace(Workspace **out) {
+  PSP_TRY(ensure_device());
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ws.device != g_device) {
+    if (g_ws.partials) {
+      (void)hipFree(g_ws.partials);
+      (void)hipFree(g_ws.scal_dev);
+      (void)hipHostFree(g_ws.scal_host);
+      g_ws = Workspace();
+    }
+    hipDeviceProp_t prop;
+    PSP_HIP(hipGetDeviceProperties(&prop, g_device));
+    g_ws.num_cu = prop.multiProcessorCount;
+    PSP_HIP(hipMalloc((void **)&g_ws.partials, sizeof(double) * kSlots * kMaxParts));
+    PSP_HIP(hipMalloc((void **)&g_ws.scal_dev, sizeof(double) * 16));
+    PSP_HIP(hipHostMalloc((void **)&g_ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
+    g_ws.device = g_device;
+  }
+  *out = &g_ws;
+  return PSP_OK;
+}
+
+// one block: thread t adds partials t, t+256, ... in order, then a fixed tree
+__global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ partials,
+                                                     int nparts, int nvals,
+                                                     double *__restrict__ out) {
+  __shared__ double sh[256];
+  for (int j = 0; j < nvals; ++j) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * kMaxParts + b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = sh[0];
+    __syncthreads();
+  }
+}
+
+int finish_partials(const double *partials, int nparts, int nvals, double *out_dev) {
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), partials, nparts, nvals,
+                     out_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int fetch_scalars(const double *src_dev, int k, double *dst_host) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  PSP_HIP(hipMemcpyAsync(w->scal_host, src_dev, sizeof(double) * k, hipMemcpyDeviceToHost,
+                         stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  memcpy(dst_host, w->scal_host, sizeof(double) * k);
+  return PSP_OK;
+}
+
+}  // namespace psp
+
+using namespace psp;
+
+extern "C" {
+
+const char *psp_last_error(void) { return psp::last_error(); }
+const char *psp_version(void) { return "pysparse_hip 0.1 (gfx950)"; }
+
+int psp_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+int psp_set_device(int device) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+    return fail(PSP_ENODEV, "no HIP device available; libpysparse_hip has no CPU fallback");
+  if (device < 0 || device >= cnt)
+    return fail(PSP_EINVAL, "device %d out of range (0..%d)", device, cnt - 1);
+  PSP_HIP(hipSetDevice(device));
+  g_device = device;
+  g_dev_state = 1;
+  return PSP_OK;
+}
+
+int psp_set_stream(void *hip_stream) {
+  g_stream = (hipStream_t)hip_stream;
+  return PSP_OK;
+}
+
+int psp_synchronize(void) {
+  PSP_TRY(ensure_device());
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes) {
+  PSP_TRY(ensure_device());
+  hipDeviceProp_t prop;
+  PSP_HIP(hipGetDeviceProperties(&prop, g_device));
+  if (name && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return PSP_OK;
+}
+
+int psp_malloc(void **dev, size_t bytes) {
+  if (!dev) return fail(PSP_EINVAL, "psp_malloc: NULL out pointer");
+  PSP_TRY(ensure_device());
+  PSP_HIP(hipMalloc(dev, bytes ? bytes : 8));
+  return PSP_OK;
+}
+
+int psp_free(void *dev) {
+  if (!dev) return PSP_OK;
+  PSP_HIP(hipFree(dev));
+  return PSP_OK;
+}
+
+int psp_memcpy_h2d(void *dev, const void *host, size_t bytes) {
+  PSP_TRY(ensure_device());
+  PSP_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_memcpy_d2h(void *host, const void *dev, size_t bytes) {
+  PSP_TRY(ensure_device());
+  PSP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_memset(void *dev, int byte, size_t bytes) {
+  PSP_TRY(ensure_device());
+  PSP_HIP(hipMemsetAsync(dev, byte, bytes, stream()));
+  return PSP_OK;
+}
+
+int psp_event_create(void **event) {
+  PSP_TRY(ensure_device());
+  hipEvent_t e;
+  PSP_HIP(hipEventCreate(&e));
+  *event = (void *)e;
+  return PSP_OK;
+}
+
+int psp_event_destroy(void *event) {
+  if (event) PSP_HIP(hipEventDestroy((hipEvent_t)event));
+  return PSP_OK;
+}
+
+int psp_event_record(void *event) {
+  PSP_HIP(hipEventRecord((hipEvent_t)event, stream()));
+  return PSP_OK;
+}
+
+int psp_event_elapsed_ms(void *start, void *stop, float *ms) {
+  PSP_HIP(hipEventSynchronize((hipEvent_t)stop));
+  PSP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,606 @@
+// psp_solvers.hip -- operator protocol, Jacobi, and the device-resident PCG / MINRES loops.
+//
+// Control flow (scalars, exit tests, info codes) follows the reference line by line:
+//   PCG     pysparse/itsolvers/src/pcg.c:22-171
+//   MINRES  pysparse/itsolvers/src/minres.c:43-200
+//   Jacobi  pysparse/precon/src/preconmodule.c:35-54, 352-412
+// All n-vectors live in HBM for the whole solve.  Per iteration the host reads back the
+// 1-3 reduced scalars it needs to take the reference's branches (alpha, beta, exit tests)
+// in IEEE double exactly as the C code does; nothing else crosses PCIe.
+//
+// Two inner loops share the kernels of psp_vec.hip:
+//   fused    A is a native csr/sss matrix and K is None or jacobi(steps=1):
+//            z = dinv.*r is never stored; p.q is an epilogue of the SpMV; x/r update,
+//            stagnation scan, ||r||^2 and the next rho are one pass.
+//            HBM traffic per iteration: 12 nnz + 108 n bytes.
+//   generic  any other operator pair (host callbacks = user-defined Python matvec/precon,
+//            jacobi with steps > 1): same kernels with an explicit z vector; callback
+//            operators are bridged with one D2H + one H2D copy per application.
+#include <cmath>
+#include <vector>
+
+#include "psp_internal.h"
+
+using namespace psp;
+
+namespace psp {
+int k_dot(long n, const double *x, const double *y, double *partials, int *nparts);
+int k_residual(long n, const double *b, double *r, const double *dinv, double *partials, int *nparts);
+int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p);
+int k_xr_update(long n, double alpha, const double *p, const double *q, const double *dinv,
+                double *x, double *r, double *partials, int *nparts);
+int k_jacobi_first(long n, const double *x, const double *dinv, double *y);
+int k_jacobi_sweep(long n, const double *x, const double *dinv, const double *temp, double *y);
+int k_dinv(long n, const double *diag, double omega, double *dinv, double *partials, int *nparts);
+int k_scale_div(long n, const double *y, double beta, double *v);
+int k_lanczos(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old,
+              const double *dinv, double *y, double *partials, int *nparts);
+int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old);
+int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, double *w,
+                double *w_old, double *x);
+}  // namespace psp
+
+extern "C" int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev);
+
+namespace {
+
+struct DevVecs {
+  std::vector<double *> ptrs;
+  ~DevVecs() {
+    for (double *p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  int alloc(size_t n, double **out) {
+    double *p = nullptr;
+    hipError_t e = hipMalloc((void **)&p, sizeof(double) * (n ? n : 1));
+    if (e != hipSuccess)
+      return fail(PSP_ENOMEM, "solver work vector (%zu doubles): %s", n, hipGetErrorString(e));
+    ptrs.push_back(p);
+    *out = p;
+    return PSP_OK;
+  }
+};
+
+// reduce `nvals` slots of the workspace partials and bring them to the host
+int reduce_fetch(Workspace *w, int nparts, int nvals, double *host) {
+  PSP_TRY(finish_partials(w->partials, nparts, nvals, w->scal_dev));
+  return fetch_scalars(w->scal_dev, nvals, host);
+}
+
+// the dinv array when K is a native single-step Jacobi, else nullptr
+const double *fused_dinv(const psp_op *K) {
+  if (K && K->kind == PSP_OP_JACOBI && K->jac->steps == 1) return K->jac->dinv;
+  return nullptr;
+}
+
+}  // namespace
+
+namespace psp {
+
+int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y) {
+  PSP_TRY(k_jacobi_first(K->n, x, K->dinv, y));
+  for (int step = 1; step < K->steps; ++step) {
+    if (K->A.kind == 0) return fail(PSP_EINVAL, "jacobi: steps > 1 needs the matrix operator");
+    PSP_HIP(hipMemcpyAsync(K->temp, y, sizeof(double) * (size_t)K->n, hipMemcpyDeviceToDevice,
+                           stream()));
+    PSP_TRY(op_apply(&K->A, K->temp, y));
+    PSP_TRY(k_jacobi_sweep(K->n, x, K->dinv, K->temp, y));
+  }
+  return PSP_OK;
+}
+
+int op_apply(const psp_op *op, const double *x_dev, double *y_dev) {
+  switch (op->kind) {
+    case PSP_OP_CSR:
+      return psp_csr_matvec_dev(op->csr, x_dev, y_dev);
+    case PSP_OP_SSS:
+      return psp_sss_matvec_dev(op->sss, x_dev, y_dev);
+    case PSP_OP_JACOBI:
+      return jacobi_apply_dev(op->jac, x_dev, y_dev);
+    case PSP_OP_CALLBACK: {
+      // SpMatrix_Matvec / SpMatrix_Precon (spmatrixmodule.c:169-248): the callee sees host
+      // arrays, so bridge the device vectors through pinned staging buffers
+      const size_t bytes = sizeof(double) * (size_t)op->n;
+      PSP_HIP(hipMemcpyAsync(op->hx, x_dev, bytes, hipMemcpyDeviceToHost, stream()));
+      PSP_HIP(hipStreamSynchronize(stream()));
+      if (op->fn(op->ctx, op->n, op->hx, op->hy) != 0)
+        return fail(PSP_ECALLBACK, "operator callback reported failure");
+      PSP_HIP(hipMemcpyAsync(y_dev, op->hy, bytes, hipMemcpyHostToDevice, stream()));
+      return PSP_OK;
+    }
+  }
+  return fail(PSP_EINVAL, "op_apply: unknown operator kind %d", op->kind);
+}
+
+}  // namespace psp
+
+// ====================================================================== PCG
+
+static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
+                      double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  DevVecs mem;
+  double *r, *p, *q, *z = nullptr;
+  PSP_TRY(mem.alloc(n, &r));
+  PSP_TRY(mem.alloc(n, &p));
+  PSP_TRY(mem.alloc(n, &q));
+
+  psp_csr *Acsr = op_native_csr(A);
+  const double *dinv = fused_dinv(K);
+  const bool fused = Acsr != nullptr && (K == nullptr || dinv != nullptr);
+  if (!fused && K) PSP_TRY(mem.alloc(n, &z));
+
+  double s[4];
+  int np;
+
+  // n2b = ||b||  (pcg.c:57)
+  PSP_TRY(k_dot(n, b, b, w->partials, &np));
+  PSP_TRY(reduce_fetch(w, np, 1, s));
+  const double n2b = sqrt(s[0]);
+  if (n2b == 0.0) {  // pcg.c:58-67
+    PSP_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    *info = 0;
+    *relres = 0.0;
+    *iter = 0;
+    return PSP_OK;
+  }
+
+  *info = -1;  // pcg.c:70
+  const double tolb = tol * n2b;
+
+  // r = b - A x, normr (pcg.c:72-75); the fused form also yields rho = r.z for iteration 1
+  PSP_TRY(op_apply(A, x, r));
+  PSP_TRY(k_residual(n, b, r, fused ? dinv : nullptr, w->partials, &np));
+  PSP_TRY(reduce_fetch(w, np, 2, s));
+  double normr = sqrt(s[0]);
+  double rho_next = s[1];
+  if (hist) hist[0] = normr;
+
+  if (normr <= tolb) {  // pcg.c:77-84
+    *info = 0;
+    *relres = normr / n2b;
+    *iter = 0;
+    return PSP_OK;
+  }
+
+  double rho = 1.0, rho1, beta = 0.0, alpha, pq;
+  int stag = 0;
+  int it;
+  for (it = 1; it <= maxit; ++it) {  // pcg.c:91
+    const double *zsrc = r;           // vector the p-update reads z from
+    const double *zdinv = dinv;       // fused: z = dinv.*r formed on the fly
+    if (!fused) {
+      zdinv = nullptr;
+      if (K) {  // pcg.c:93-94
+        PSP_TRY(op_apply(K, r, z));
+        zsrc = z;
+      }
+      // rho = r.z (pcg.c:100); without K, z == r (pcg.c:96)
+      PSP_TRY(k_dot(n, r, zsrc, w->partials, &np));
+      PSP_TRY(reduce_fetch(w, np, 1, s));
+      rho_next = s[0];
+    }
+    rho1 = rho;
+    rho = rho_next;
+    if (rho == 0.0) {  // pcg.c:101-104
+      *info = -2;
+      break;
+    }
+    if (it == 1) {
+      PSP_TRY(k_pupdate(n, zsrc, zdinv, 0.0, true, p));  // pcg.c:106
+    } else {
+      beta = rho / rho1;
+      if (beta == 0.0) {  // pcg.c:109-112
+        *info = -6;
+        break;
+      }
+      PSP_TRY(k_pupdate(n, zsrc, zdinv, beta, false, p));  // pcg.c:113-114
+    }
+
+    // q = A p, pq = p.q (pcg.c:116-117)
+    if (Acsr) {
+      PSP_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np));
+    } else {
+      PSP_TRY(op_apply(A, p, q));
+      PSP_TRY(k_dot(n, p, q, w->partials, &np));
+    }
+    PSP_TRY(reduce_fetch(w, np, 1, s));
+    pq = s[0];
+    if (pq == 0.0) {  // pcg.c:118-120
+      *info = -6;
+      break;
+    }
+    alpha = rho / pq;
+    if (alpha == 0.0) stag = 1;  // pcg.c:124-125
+
+    // stagnation scan, x += alpha p, r -= alpha q, normr (pcg.c:127-152)
+    PSP_TRY(k_xr_update(n, alpha, p, q, fused ? dinv : nullptr, x, r, w->partials, &np));
+    PSP_TRY(reduce_fetch(w, np, 3, s));
+    if (stag == 0) stag = (s[2] == 0.0);
+    normr = sqrt(s[0]);
+    rho_next = s[1];
+    if (hist) hist[it] = normr;
+
+    if (normr <= tolb) {  // pcg.c:154-157
+      *info = 0;
+      break;
+    }
+    if (stag == 1) {  // pcg.c:159-162
+      *info = -5;
+      break;
+    }
+  }
+  *iter = it;  // pcg.c:165: maxit + 1 when the loop ran out
+  *relres = normr / n2b;
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+// ====================================================================== MINRES
+
+static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
+                         double errtol, int it_max, int *info, int *iter, double *relres,
+                         double *hist) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  DevVecs mem;
+  double *v_hat_old, *v_hat, *y = nullptr, *wv, *w_old, *v, *av;
+  PSP_TRY(mem.alloc(n, &v_hat_old));
+  PSP_TRY(mem.alloc(n, &v_hat));
+  PSP_TRY(mem.alloc(n, &wv));
+  PSP_TRY(mem.alloc(n, &w_old));
+  PSP_TRY(mem.alloc(n, &v));
+  PSP_TRY(mem.alloc(n, &av));
+  if (K) PSP_TRY(mem.alloc(n, &y));
+
+  psp_csr *Acsr = op_native_csr(A);
+  const double *dinv = fused_dinv(K);
+  const bool kfused = (K == nullptr) || dinv != nullptr;  // y = K v_hat can ride in the update
+  const size_t bytes = sizeof(double) * (size_t)n;
+  double s[4];
+  int np;
+
+  *iter = 0;
+  PSP_HIP(hipMemsetAsync(v_hat_old, 0, bytes, stream()));  // minres.c:63-65
+  // v_hat = b - A x; norm_r0 (minres.c:67-71); fused: also v_hat . (dinv.*v_hat)
+  PSP_TRY(op_apply(A, x, v_hat));
+  PSP_TRY(k_residual(n, b, v_hat, kfused ? dinv : nullptr, w->partials, &np));
+  PSP_TRY(reduce_fetch(w, np, 2, s));
+  const double norm_r0 = sqrt(s[0]);
+  double beta = s[1];
+  if (K) {  // y = K v_hat (minres.c:73-76)
+    PSP_TRY(op_apply(K, v_hat, y));
+    if (!kfused) {
+      PSP_TRY(k_dot(n, v_hat, y, w->partials, &np));  // minres.c:78
+      PSP_TRY(reduce_fetch(w, np, 1, s));
+      beta = s[0];
+    }
+  }
+  if (beta < 0.0) {  // minres.c:79-80
+    *info = -3;
+    PSP_HIP(hipStreamSynchronize(stream()));
+    return PSP_OK;
+  }
+  beta = sqrt(beta);
+  double beta_old = 1.0;
+  double c = 1.0, c_old = 1.0, s_ = 0.0, s_old = 0.0, c_oold, s_oold;
+  PSP_HIP(hipMemsetAsync(wv, 0, bytes, stream()));  // minres.c:86-90
+  PSP_HIP(hipMemsetAsync(w_old, 0, bytes, stream()));
+  double eta = beta;
+  double norm_rmr = norm_r0;
+  if (hist) hist[0] = norm_rmr;
+
+  while (true) {
+    if (*iter >= it_max || norm_rmr < errtol * norm_r0) break;  // minres.c:114 (strict <)
+    *iter += 1;
+
+    // v = y / beta (minres.c:123-124); y = v_hat is implied: the update below keeps the
+    // old v_hat in v_hat_old directly (minres.c:125,135)
+    PSP_TRY(k_scale_div(n, K ? y : v_hat, beta, v));
+    // Av = A v, alpha = v.Av (minres.c:127-129)
+    if (Acsr) {
+      PSP_TRY(csr_spmv_launch(Acsr, v, av, v, w->partials, &np));
+    } else {
+      PSP_TRY(op_apply(A, v, av));
+      PSP_TRY(k_dot(n, v, av, w->partials, &np));
+    }
+    PSP_TRY(reduce_fetch(w, np, 1, s));
+    const double alpha = s[0];
+    const double dconst1 = alpha / beta, dconst2 = beta / beta_old;  // minres.c:131
+    // v_hat = Av - c1 v_hat - c2 v_hat_old; v_hat_old = old v_hat; y = K v_hat; beta^2
+    if (kfused) {
+      PSP_TRY(k_lanczos(n, av, dconst1, dconst2, v_hat, v_hat_old, dinv, y, w->partials, &np));
+    } else {
+      PSP_TRY(k_lanczos_plain(n, av, dconst1, dconst2, v_hat, v_hat_old));
+      PSP_TRY(op_apply(K, v_hat, y));  // minres.c:137-140
+      PSP_TRY(k_dot(n, v_hat, y, w->partials, &np));
+    }
+    PSP_TRY(reduce_fetch(w, np, 1, s));
+    beta_old = beta;
+    beta = s[0];  // minres.c:143
+    if (beta < 0.0) {
+      *info = -3;
+      PSP_HIP(hipStreamSynchronize(stream()));
+      return PSP_OK;
+    }
+    beta = sqrt(beta);
+
+    // QR factorisation + Givens rotation (minres.c:151-164)
+    c_oold = c_old;
+    c_old = c;
+    s_oold = s_old;
+    s_old = s_;
+    const double r1_hat = c_old * alpha - c_oold * s_old * beta_old;
+    const double r1 = sqrt(r1_hat * r1_hat + beta * beta);
+    const double r2 = s_old * alpha + c_oold * c_old * beta_old;
+    const double r3 = s_oold * beta_old;
+    if (r1 == 0.0) {
+      *info = -6;
+      PSP_HIP(hipStreamSynchronize(stream()));
+      return PSP_OK;
+    }
+    c = r1_hat / r1;
+    s_ = beta / r1;
+
+    // w, x update (minres.c:172-180)
+    PSP_TRY(k_minres_wx(n, v, r1, r2, r3, c * eta, wv, w_old, x));
+    eta = -s_ * eta;
+    norm_rmr *= fabs(s_);  // minres.c:192
+    if (hist) hist[*iter] = norm_rmr;
+  }
+
+  *relres = norm_rmr / norm_r0;  // minres.c:195
+  *info = (norm_rmr < errtol * norm_r0) ? 0 : -1;
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+// ====================================================================== C ABI
+
+static int check_solver_args(const psp_op *A, const psp_op *K, int n, const void *x, const void *b,
+                             int *info, int *iter, double *relres) {
+  if (!A || !x || !b || !info || !iter || !relres) return fail(PSP_EINVAL, "solver: NULL argument");
+  if (n <= 0) return fail(PSP_EINVAL, "solver: n must be positive");
+  if (A->n != n) return fail(PSP_EINVAL, "solver: operator order %d != n %d", A->n, n);
+  if (K && K->n != n) return fail(PSP_EINVAL, "solver: preconditioner order %d != n %d", K->n, n);
+  return PSP_OK;
+}
+
+extern "C" {
+
+int psp_op_from_csr(psp_csr_t *A, psp_op_t **out) {
+  if (!A || !out) return fail(PSP_EINVAL, "psp_op_from_csr: NULL argument");
+  if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
+  psp_op *op = new psp_op();
+  op->kind = PSP_OP_CSR;
+  op->n = A->nrows;
+  op->csr = A;
+  *out = op;
+  return PSP_OK;
+}
+
+int psp_op_from_sss(psp_sss_t *A, psp_op_t **out) {
+  if (!A || !out) return fail(PSP_EINVAL, "psp_op_from_sss: NULL argument");
+  psp_op *op = new psp_op();
+  op->kind = PSP_OP_SSS;
+  op->n = A->n;
+  op->sss = A;
+  *out = op;
+  return PSP_OK;
+}
+
+int psp_op_from_jacobi(psp_jacobi_t *K, psp_op_t **out) {
+  if (!K || !out) return fail(PSP_EINVAL, "psp_op_from_jacobi: NULL argument");
+  psp_op *op = new psp_op();
+  op->kind = PSP_OP_JACOBI;
+  op->n = K->n;
+  op->jac = K;
+  *out = op;
+  return PSP_OK;
+}
+
+int psp_op_from_callback(int n, psp_host_apply_fn fn, void *ctx, psp_op_t **out) {
+  if (!fn || !out || n <= 0) return fail(PSP_EINVAL, "psp_op_from_callback: bad argument");
+  PSP_TRY(ensure_device());
+  psp_op *op = new psp_op();
+  op->kind = PSP_OP_CALLBACK;
+  op->n = n;
+  op->fn = fn;
+  op->ctx = ctx;
+  hipError_t e1 = hipHostMalloc((void **)&op->hx, sizeof(double) * (size_t)n, hipHostMallocDefault);
+  hipError_t e2 = hipHostMalloc((void **)&op->hy, sizeof(double) * (size_t)n, hipHostMallocDefault);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    psp_op_destroy(op);
+    return fail(PSP_ENOMEM, "psp_op_from_callback: pinned staging allocation failed");
+  }
+  *out = op;
+  return PSP_OK;
+}
+
+int psp_op_destroy(psp_op_t *op) {
+  if (!op) return PSP_OK;
+  if (op->hx) (void)hipHostFree(op->hx);
+  if (op->hy) (void)hipHostFree(op->hy);
+  delete op;
+  return PSP_OK;
+}
+
+// ---------------------------------------------------------------- jacobi
+
+static int jacobi_from_diag_dev(int n, double *diag_dev_owned, double omega, int steps,
+                                const psp_op *A, psp_jacobi_t **out) {
+  // diag_dev_owned is turned into dinv in place
+  Workspace *w;
+  int rc = workspace(&w);
+  int np = 0;
+  double nsing = 0.0;
+  if (rc == PSP_OK) rc = k_dinv(n, diag_dev_owned, omega, diag_dev_owned, w->partials, &np);
+  if (rc == PSP_OK) rc = finish_partials(w->partials, np, 1, w->scal_dev);
+  if (rc == PSP_OK) rc = fetch_scalars(w->scal_dev, 1, &nsing);
+  if (rc == PSP_OK && nsing != 0.0)
+    rc = fail(PSP_ESINGULAR, "diagonal element close to zero");  // preconmodule.c:395-397
+  if (rc != PSP_OK) {
+    (void)hipFree(diag_dev_owned);
+    return rc;
+  }
+  psp_jacobi *K = new psp_jacobi();
+  K->n = n;
+  K->omega = omega;
+  K->steps = steps;
+  K->dinv = diag_dev_owned;
+  if (A) K->A = *A;
+  if (steps > 1) {
+    if (hipMalloc((void **)&K->temp, sizeof(double) * (size_t)n) != hipSuccess) {
+      psp_jacobi_destroy(K);
+      return fail(PSP_ENOMEM, "jacobi: temp allocation failed");
+    }
+  }
+  *out = K;
+  return PSP_OK;
+}
+
+int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **out) {
+  if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_csr: NULL argument");
+  if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
+  if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  PSP_TRY(ensure_device());
+  double *d;
+  PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(A->nrows ? A->nrows : 1)));
+  int rc = psp_csr_diagonal_dev(A, d);
+  if (rc != PSP_OK) {
+    (void)hipFree(d);
+    return rc;
+  }
+  psp_op op;
+  op.kind = PSP_OP_CSR;
+  op.n = A->nrows;
+  op.csr = A;
+  return jacobi_from_diag_dev(A->nrows, d, omega, steps, &op, out);
+}
+
+int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **out) {
+  if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_sss: NULL argument");
+  if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  PSP_TRY(ensure_device());
+  double *d;
+  PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(A->n ? A->n : 1)));
+  hipError_t e = hipMemcpyAsync(d, A->diag, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToDevice,
+                                stream());
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return fail(PSP_ENODEV, "jacobi: %s", hipGetErrorString(e));
+  }
+  psp_op op;
+  op.kind = PSP_OP_SSS;
+  op.n = A->n;
+  op.sss = A;
+  return jacobi_from_diag_dev(A->n, d, omega, steps, &op, out);
+}
+
+int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int steps,
+                           const psp_op_t *A_or_null, psp_jacobi_t **out) {
+  if (!diag_host || !out || n <= 0) return fail(PSP_EINVAL, "psp_jacobi_create_diag: bad argument");
+  if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  if (steps > 1 && !A_or_null)
+    return fail(PSP_EINVAL, "jacobi: steps > 1 needs the matrix operator");
+  PSP_TRY(ensure_device());
+  double *d;
+  PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)n));
+  hipError_t e = hipMemcpyAsync(d, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
+                                stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(stream());
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return fail(PSP_ENODEV, "jacobi: %s", hipGetErrorString(e));
+  }
+  return jacobi_from_diag_dev(n, d, omega, steps, A_or_null, out);
+}
+
+int psp_jacobi_destroy(psp_jacobi_t *K) {
+  if (!K) return PSP_OK;
+  (void)hipFree(K->dinv);
+  if (K->temp) (void)hipFree(K->temp);
+  delete K;
+  return PSP_OK;
+}
+
+int psp_jacobi_shape(const psp_jacobi_t *K, int *n) {
+  if (!K || !n) return fail(PSP_EINVAL, "psp_jacobi_shape: NULL argument");
+  *n = K->n;
+  return PSP_OK;
+}
+
+int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev) {
+  if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_jacobi_precon_dev: NULL argument");
+  return jacobi_apply_dev(K, x_dev, y_dev);
+}
+
+int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
+  if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
+  PSP_TRY(ensure_device());
+  DevVecs mem;
+  double *x, *y;
+  PSP_TRY(mem.alloc(K->n, &x));
+  PSP_TRY(mem.alloc(K->n, &y));
+  const size_t bytes = sizeof(double) * (size_t)K->n;
+  PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_TRY(jacobi_apply_dev(K, x, y));
+  PSP_HIP(hipMemcpyAsync(y_host, y, bytes, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+// ---------------------------------------------------------------- solvers
+
+int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, const double *b_dev,
+                double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
+  PSP_TRY(ensure_device());
+  return pcg_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
+}
+
+int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+            double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
+  PSP_TRY(ensure_device());
+  DevVecs mem;
+  double *x, *b;
+  PSP_TRY(mem.alloc(n, &x));
+  PSP_TRY(mem.alloc(n, &b));
+  const size_t bytes = sizeof(double) * (size_t)n;
+  PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_HIP(hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_TRY(pcg_device(A, K, n, x, b, tol, maxit, info, iter, relres, hist_host));
+  PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
+                   const double *b_dev, double tol, int maxit, int *info, int *iter,
+                   double *relres, double *hist_host) {
+  PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
+  PSP_TRY(ensure_device());
+  return minres_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
+}
+
+int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+               double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
+  PSP_TRY(ensure_device());
+  DevVecs mem;
+  double *x, *b;
+  PSP_TRY(mem.alloc(n, &x));
+  PSP_TRY(mem.alloc(n, &b));
+  const size_t bytes = sizeof(double) * (size_t)n;
+  PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_HIP(hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_TRY(minres_device(A, K, n, x, b, tol, maxit, info, iter, relres, hist_host));
+  PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+}  // extern "C"

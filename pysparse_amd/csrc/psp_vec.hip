@@ -1,0 +1,560 @@
+// psp_vec.hip -- the fp64 vector kernels of the Krylov loops (the reference's BLAS-1 calls
+// and hand loops in pysparse/itsolvers/src/pcg.c and minres.c), fused so that every
+// vector is streamed as few times as the data dependencies allow.
+//
+// All kernels: 256-thread workgroups, grid-stride over the vector with 16-byte-per-lane
+// accesses (8-byte when a pointer is not 16-byte aligned or n is odd), per-lane partial
+// sums -> wave shuffle -> LDS -> one slot per workgroup; a one-block finishing kernel adds
+// the slots in index order (bitwise reproducible, no atomics).  Per-element arithmetic
+// follows the reference expression order; the library is built with -ffp-contract=off.
+#include "psp_internal.h"
+
+using namespace psp;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int V>
+struct alignas(8 * V) Pack {
+  double v[V];
+};
+
+template <int V>
+__device__ __forceinline__ Pack<V> ld(const double *p, long i) {
+  return *reinterpret_cast<const Pack<V> *>(p + i);
+}
+template <int V>
+__device__ __forceinline__ void st(double *p, long i, const Pack<V> &x) {
+  *reinterpret_cast<Pack<V> *>(p + i) = x;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// sums NV per-thread values over the block; thread 0 stores them to partials[j*kMaxParts + block]
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *partials) {
+  __shared__ double sh[NV][4];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double s = wave_sum(v[j]);
+    if ((threadIdx.x & 63) == 0) sh[j][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      partials[(size_t)j * kMaxParts + blockIdx.x] = sh[j][0] + sh[j][1] + sh[j][2] + sh[j][3];
+  }
+}
+
+#define PSP_VEC_LOOP(i, n)                                                        \
+  for (long i = ((long)blockIdx.x * kBlock + threadIdx.x) * V; i < (n);           \
+       i += (long)gridDim.x * kBlock * V)
+
+// ---- dot: pcg.c:100,117  minres.c:78,129,143
+template <int V>
+__global__ __launch_bounds__(kBlock) void dot_kernel(long n, const double *__restrict__ x,
+                                                     const double *__restrict__ y,
+                                                     double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> a = ld<V>(x, i), b = ld<V>(y, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[0] += a.v[u] * b.v[u];
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+// ---- r = b - r; partials {r.r, r.z}, z = dinv.*r or r: pcg.c:73-75 (+ :93-100 fused)
+template <int V, bool PRE>
+__global__ __launch_bounds__(kBlock) void residual_kernel(long n, const double *__restrict__ b,
+                                                          double *__restrict__ r,
+                                                          const double *__restrict__ dinv,
+                                                          double *__restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> bb = ld<V>(b, i);
+    Pack<V> rr = ld<V>(r, i);
+    Pack<V> dd;
+    if constexpr (PRE) dd = ld<V>(dinv, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      const double t = bb.v[u] - rr.v[u];
+      rr.v[u] = t;
+      acc[0] += t * t;
+      if constexpr (PRE) {
+        const double z = t * dd.v[u];
+        acc[1] += t * z;
+      }
+    }
+    st<V>(r, i, rr);
+  }
+  if constexpr (!PRE) acc[1] = acc[0];
+  block_reduce_store<2>(acc, partials);
+}
+
+// ---- p = z + beta*p (pcg.c:113-114) or p = z (pcg.c:106); z = dinv.*r or r
+template <int V, bool PRE, bool FIRST>
+__global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *__restrict__ r,
+                                                         const double *__restrict__ dinv,
+                                                         double beta, double *__restrict__ p) {
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> z = ld<V>(r, i);
+    if constexpr (PRE) {
+      const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dd.v[u];
+    }
+    if constexpr (!FIRST) {
+      const Pack<V> pp = ld<V>(p, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] + beta * pp.v[u];
+    }
+    st<V>(p, i, z);
+  }
+}
+
+// ---- stagnation scan + x += alpha p, r -= alpha q (pcg.c:127-143); partials
+//      {r.r, r.z, nonstag}: nonstag = 1 for a workgroup whose local dmax has 1 + dmax != 1
+template <int V, bool PRE>
+__global__ __launch_bounds__(kBlock) void xr_update_kernel(
+    long n, double alpha, const double *__restrict__ p, const double *__restrict__ q,
+    const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r,
+    double *__restrict__ partials) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  double dmax = 0.0;
+  const double malpha = -alpha;
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> pp = ld<V>(p, i), qq = ld<V>(q, i);
+    Pack<V> xx = ld<V>(x, i), rr = ld<V>(r, i);
+    Pack<V> dd;
+    if constexpr (PRE) dd = ld<V>(dinv, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      if (xx.v[u] != 0.0) {
+        const double ddum = fabs(alpha * pp.v[u] / xx.v[u]);
+        if (ddum > dmax) dmax = ddum;
+      } else if (pp.v[u] != 0.0) {
+        // the reference ASSIGNS dmax = 1.0 here (pcg.c:136); for the test 1+dmax == 1
+        // that is equivalent to max(dmax, 1.0)
+        if (1.0 > dmax) dmax = 1.0;
+      }
+      xx.v[u] = xx.v[u] + alpha * pp.v[u];    // daxpy, pcg.c:141
+      const double t = rr.v[u] + malpha * qq.v[u];  // daxpy with -alpha, pcg.c:142-143
+      rr.v[u] = t;
+      acc[0] += t * t;
+      if constexpr (PRE) {
+        const double z = t * dd.v[u];
+        acc[1] += t * z;
+      }
+    }
+    st<V>(x, i, xx);
+    st<V>(r, i, rr);
+  }
+  if constexpr (!PRE) acc[1] = acc[0];
+  // block max of dmax
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(dmax, off, 64);
+    if (o > dmax) dmax = o;
+  }
+  acc[2] = ((threadIdx.x & 63) == 0 && (1.0 + dmax != 1.0)) ? 1.0 : 0.0;
+  block_reduce_store<3>(acc, partials);
+}
+
+// ---- Jacobi: y = x.*dinv (preconmodule.c:41-42)
+template <int V>
+__global__ __launch_bounds__(kBlock) void jacobi_first_kernel(long n, const double *__restrict__ x,
+                                                              const double *__restrict__ dinv,
+                                                              double *__restrict__ y) {
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> a = ld<V>(x, i);
+    const Pack<V> d = ld<V>(dinv, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) a.v[u] = a.v[u] * d.v[u];
+    st<V>(y, i, a);
+  }
+}
+
+// ---- Jacobi sweep: y = (x - y).*dinv + temp (preconmodule.c:50-51)
+template <int V>
+__global__ __launch_bounds__(kBlock) void jacobi_sweep_kernel(long n, const double *__restrict__ x,
+                                                              const double *__restrict__ dinv,
+                                                              const double *__restrict__ temp,
+                                                              double *__restrict__ y) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> a = ld<V>(x, i), d = ld<V>(dinv, i), t = ld<V>(temp, i);
+    Pack<V> yy = ld<V>(y, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) yy.v[u] = (a.v[u] - yy.v[u]) * d.v[u] + t.v[u];
+    st<V>(y, i, yy);
+  }
+}
+
+// ---- dinv = omega / diag with the singularity test 1 + d == 1 (preconmodule.c:395-400);
+//      partial = number of singular entries
+template <int V>
+__global__ __launch_bounds__(kBlock) void dinv_kernel(long n, const double *__restrict__ diag,
+                                                      double omega, double *__restrict__ dinv,
+                                                      double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> d = ld<V>(diag, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      if (1.0 + d.v[u] == 1.0) acc[0] += 1.0;
+      d.v[u] = omega / d.v[u];
+    }
+    st<V>(dinv, i, d);
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+// ---- MINRES: v = y / beta (minres.c:123-124)
+template <int V>
+__global__ __launch_bounds__(kBlock) void scale_div_kernel(long n, const double *__restrict__ y,
+                                                           double beta, double *__restrict__ v) {
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> a = ld<V>(y, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) a.v[u] = a.v[u] / beta;
+    st<V>(v, i, a);
+  }
+}
+
+// ---- MINRES Lanczos update (minres.c:131-143):
+//      t = v_hat; v_hat = av - c1*v_hat - c2*v_hat_old; v_hat_old = t;
+//      y = dinv.*v_hat (PRE && y != nullptr) ; partial {v_hat . y}
+template <int V, bool PRE>
+__global__ __launch_bounds__(kBlock) void lanczos_kernel(
+    long n, const double *__restrict__ av, double c1, double c2, double *__restrict__ v_hat,
+    double *__restrict__ v_hat_old, const double *__restrict__ dinv, double *__restrict__ y,
+    double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> a = ld<V>(av, i);
+    Pack<V> vh = ld<V>(v_hat, i), vo = ld<V>(v_hat_old, i);
+    Pack<V> dd, yy;
+    if constexpr (PRE) dd = ld<V>(dinv, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      const double t = vh.v[u];
+      const double nv = a.v[u] - c1 * t - c2 * vo.v[u];
+      vo.v[u] = t;
+      vh.v[u] = nv;
+      if constexpr (PRE) {
+        yy.v[u] = nv * dd.v[u];
+        acc[0] += nv * yy.v[u];
+      } else {
+        acc[0] += nv * nv;
+      }
+    }
+    st<V>(v_hat, i, vh);
+    st<V>(v_hat_old, i, vo);
+    if constexpr (PRE) st<V>(y, i, yy);
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+// ---- same recurrence without the preconditioner/dot (generic path: K applied afterwards)
+template <int V>
+__global__ __launch_bounds__(kBlock) void lanczos_plain_kernel(long n, const double *__restrict__ av,
+                                                               double c1, double c2,
+                                                               double *__restrict__ v_hat,
+                                                               double *__restrict__ v_hat_old) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> a = ld<V>(av, i);
+    Pack<V> vh = ld<V>(v_hat, i), vo = ld<V>(v_hat_old, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      const double t = vh.v[u];
+      vh.v[u] = a.v[u] - c1 * t - c2 * vo.v[u];
+      vo.v[u] = t;
+    }
+    st<V>(v_hat, i, vh);
+    st<V>(v_hat_old, i, vo);
+  }
+}
+
+// ---- MINRES update (minres.c:172-180): tmp = w; w = (v - r3*w_old - r2*tmp)/r1;
+//      w_old = tmp; x += c_eta*w
+template <int V>
+__global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double *__restrict__ v,
+                                                           double r1, double r2, double r3,
+                                                           double c_eta, double *__restrict__ w,
+                                                           double *__restrict__ w_old,
+                                                           double *__restrict__ x) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> vv = ld<V>(v, i);
+    Pack<V> ww = ld<V>(w, i), wo = ld<V>(w_old, i), xx = ld<V>(x, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      const double tmp = ww.v[u];
+      const double nw = (vv.v[u] - r3 * wo.v[u] - r2 * tmp) / r1;
+      ww.v[u] = nw;
+      wo.v[u] = tmp;
+      xx.v[u] += c_eta * nw;
+    }
+    st<V>(w, i, ww);
+    st<V>(w_old, i, wo);
+    st<V>(x, i, xx);
+  }
+}
+
+// ---- halo packing
+__global__ void gather_kernel(int count, const int *__restrict__ idx, const double *__restrict__ v,
+                              double *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    out[i] = v[idx[i]];
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename... P>
+inline bool can_vec2(long n, P... ptrs) {
+  return (n % 2 == 0) && (aligned16(ptrs) && ...);
+}
+
+}  // namespace
+
+namespace psp {
+
+// Launch helpers (device pointers, library stream).  `partials` = slot base in the workspace.
+
+int k_dot(long n, const double *x, const double *y, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x, y))
+    hipLaunchKernelGGL(dot_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, x, y, partials);
+  else
+    hipLaunchKernelGGL(dot_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, x, y, partials);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_residual(long n, const double *b, double *r, const double *dinv, double *partials,
+               int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  const bool v2 = dinv ? can_vec2(n, b, r, dinv) : can_vec2(n, b, r);
+#define L(V, PRE)                                                                              \
+  hipLaunchKernelGGL((residual_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, b, r, \
+                     dinv, partials)
+  if (dinv) { if (v2) L(2, true); else L(1, true); }
+  else { if (v2) L(2, false); else L(1, false); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  const bool v2 = dinv ? can_vec2(n, r, p, dinv) : can_vec2(n, r, p);
+#define L(V, PRE, FIRST)                                                                  \
+  hipLaunchKernelGGL((pupdate_kernel<V, PRE, FIRST>), dim3(grid), dim3(kBlock), 0, stream(), n, \
+                     r, dinv, beta, p)
+  if (dinv) {
+    if (first) { if (v2) L(2, true, true); else L(1, true, true); }
+    else { if (v2) L(2, true, false); else L(1, true, false); }
+  } else {
+    if (first) { if (v2) L(2, false, true); else L(1, false, true); }
+    else { if (v2) L(2, false, false); else L(1, false, false); }
+  }
+#undef L
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_xr_update(long n, double alpha, const double *p, const double *q, const double *dinv,
+                double *x, double *r, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  const bool v2 = dinv ? can_vec2(n, p, q, x, r, dinv) : can_vec2(n, p, q, x, r);
+#define L(V, PRE)                                                                          \
+  hipLaunchKernelGGL((xr_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
+                     alpha, p, q, dinv, x, r, partials)
+  if (dinv) { if (v2) L(2, true); else L(1, true); }
+  else { if (v2) L(2, false); else L(1, false); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_jacobi_first(long n, const double *x, const double *dinv, double *y) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x, dinv, y))
+    hipLaunchKernelGGL(jacobi_first_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, x, dinv, y);
+  else
+    hipLaunchKernelGGL(jacobi_first_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, x, dinv, y);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_jacobi_sweep(long n, const double *x, const double *dinv, const double *temp, double *y) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x, dinv, temp, y))
+    hipLaunchKernelGGL(jacobi_sweep_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, x, dinv,
+                       temp, y);
+  else
+    hipLaunchKernelGGL(jacobi_sweep_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, x, dinv,
+                       temp, y);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_dinv(long n, const double *diag, double omega, double *dinv, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, diag, dinv))
+    hipLaunchKernelGGL(dinv_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, diag, omega, dinv,
+                       partials);
+  else
+    hipLaunchKernelGGL(dinv_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, diag, omega, dinv,
+                       partials);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_scale_div(long n, const double *y, double beta, double *v) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, y, v))
+    hipLaunchKernelGGL(scale_div_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v);
+  else
+    hipLaunchKernelGGL(scale_div_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_lanczos(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old,
+              const double *dinv, double *y, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  const bool v2 = dinv ? can_vec2(n, av, v_hat, v_hat_old, dinv, y) : can_vec2(n, av, v_hat, v_hat_old);
+#define L(V, PRE)                                                                              \
+  hipLaunchKernelGGL((lanczos_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, av, c1, \
+                     c2, v_hat, v_hat_old, dinv, y, partials)
+  if (dinv) { if (v2) L(2, true); else L(1, true); }
+  else { if (v2) L(2, false); else L(1, false); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_hat,
+                    double *v_hat_old) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, av, v_hat, v_hat_old))
+    hipLaunchKernelGGL(lanczos_plain_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, av, c1,
+                       c2, v_hat, v_hat_old);
+  else
+    hipLaunchKernelGGL(lanczos_plain_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, av, c1,
+                       c2, v_hat, v_hat_old);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, double *w_,
+                double *w_old, double *x) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, v, w_, w_old, x))
+    hipLaunchKernelGGL(minres_wx_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, v, r1, r2, r3,
+                       c_eta, w_, w_old, x);
+  else
+    hipLaunchKernelGGL(minres_wx_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, v, r1, r2, r3,
+                       c_eta, w_, w_old, x);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+}  // namespace psp
+
+// ------------------------------------------------------------------ C ABI: phase kernels
+
+extern "C" {
+
+int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_dot(n, x_dev, y_dev, w->partials, &np));
+  return finish_partials(w->partials, np, 1, out_dev);
+}
+
+int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv_dev,
+                   double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_residual(n, b_dev, r_dev, dinv_dev, w->partials, &np));
+  return finish_partials(w->partials, np, 2, out_dev);
+}
+
+int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double beta, int first,
+                  double *p_dev) {
+  return k_pupdate(n, r_dev, dinv_dev, beta, first != 0, p_dev);
+}
+
+int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
+                         double *out_dev) {
+  if (!A || !p_dev || !q_dev || !out_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: NULL");
+  if (p_offset < 0 || p_offset + A->nrows > A->ncols)
+    return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: owned rows do not fit the column space");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np = 0;
+  if (A->nrows == 0) {
+    PSP_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), stream()));
+    return PSP_OK;
+  }
+  PSP_TRY(csr_spmv_launch(A, p_dev, q_dev, p_dev + p_offset, w->partials, &np));
+  return finish_partials(w->partials, np, 1, out_dev);
+}
+
+int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,
+                    const double *dinv_dev, double *x_dev, double *r_dev, double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_xr_update(n, alpha, p_dev, q_dev, dinv_dev, x_dev, r_dev, w->partials, &np));
+  return finish_partials(w->partials, np, 3, out_dev);
+}
+
+int psp_k_gather(int count, const int *idx_dev, const double *v_dev, double *send_dev) {
+  PSP_TRY(ensure_device());
+  if (count <= 0) return PSP_OK;
+  int grid = (count + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, stream(), count, idx_dev, v_dev,
+                     send_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pysparse_hip.h declares,
+and the product fails loudly (no CPU fallback) when there is no GPU."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pysparse_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(psp_[a-z0-9_]+)\s*\(", src)) - {"psp_host_apply_fn"})
+
+
+def test_header_symbols_are_exported():
+    from pysparse_amd import _capi
+    L = _capi.lib()
+    names = declared_symbols()
+    assert len(names) > 50
+    for name in names:
+        assert hasattr(L, name), name
+    assert sorted(_capi.SYMBOLS) == names
+    assert b"gfx950" in L.psp_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    from pysparse_amd import _capi, device
+    if device.device_count() > 0:
+        pytest.skip("a GPU is present")
+    import numpy as np
+    with pytest.raises(_capi.PspError, match="no HIP device"):
+        device.DeviceCSR.poisson(4, 4)
+    with pytest.raises(_capi.PspError, match="no HIP device"):
+        device.DeviceCSR.from_arrays((1, 1), np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32),
+                                     np.array([1.0]))

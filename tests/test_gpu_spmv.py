@@ -1,0 +1,179 @@
+"""GPU parity: csr_mat / sss_mat matvec through the C ABI vs the CPU oracle.
+
+Bar: indptr/indices/values bit-exact; y bit-exact (the kernel adds each row's rounded
+products left to right exactly like csr_mat.c:49-54 / sss_mat.c:45-55)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rng_vec(n, seed=0):
+    return np.random.default_rng(seed).standard_normal(n)
+
+
+def random_csr(O, m, n, seed, max_row, empty_frac=0.1, long_rows=()):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_row + 1, size=m)
+    lens[rng.random(m) < empty_frac] = 0
+    for r, L in long_rows:
+        lens[r] = min(L, n)
+    ind = np.zeros(m + 1, dtype=np.int32)
+    np.cumsum(lens, out=ind[1:])
+    col = np.empty(ind[-1], dtype=np.int32)
+    for i in range(m):
+        col[ind[i]:ind[i + 1]] = np.sort(rng.choice(n, size=lens[i], replace=False))
+    val = rng.standard_normal(ind[-1])
+    return O.CSR((m, n), val, col, ind)
+
+
+@pytest.mark.parametrize("grid", [(3, 3, 0), (100, 100, 0), (37, 53, 0), (16, 16, 16), (33, 20, 17), (1, 1, 1),
+                                  (7, 1, 0), (129, 65, 3)])
+def test_poisson_generator_structure_bit_exact(oracle, grid):
+    from pysparse_amd.device import DeviceCSR, DeviceSSS
+    A = oracle.poisson_csr(*grid)
+    D = DeviceCSR.poisson(*grid)
+    ind, col, val = D.download()
+    assert D.shape == A.shape and D.nnz == A.nnz
+    assert np.array_equal(ind, A.ind) and np.array_equal(col, A.col) and np.array_equal(val, A.val)
+    S = oracle.poisson_sss(*grid)
+    DS = DeviceSSS.poisson(*grid)
+    sind, scol, sval, sdiag = DS.download()
+    assert DS.nnz == S.nnz
+    assert np.array_equal(sind, S.ind) and np.array_equal(scol, S.col)
+    assert np.array_equal(sval, S.val) and np.array_equal(sdiag, S.diag)
+
+
+def test_poisson_slab_matches_global_rows(oracle):
+    from pysparse_amd.device import DeviceCSR
+    nx, ny, nz = 12, 10, 9
+    A = oracle.poisson_csr(nx, ny, nz)
+    n = A.shape[0]
+    nxy = nx * ny
+    lo, hi = 3 * nxy, 7 * nxy
+    shift = lo - nxy
+    D = DeviceCSR.poisson_slab(nx, ny, nz, lo, hi, shift, (hi - lo) + 2 * nxy)
+    ind, col, val = D.download()
+    assert np.array_equal(ind, A.ind[lo:hi + 1] - A.ind[lo])
+    assert np.array_equal(col, A.col[A.ind[lo]:A.ind[hi]] - shift)
+    assert np.array_equal(val, A.val[A.ind[lo]:A.ind[hi]])
+    assert n == nx * ny * nz
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 16, 20, 28])
+@pytest.mark.parametrize("grid", [(100, 100, 0), (64, 64, 64), (41, 29, 13)])
+def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
+    from pysparse_amd.device import DeviceCSR
+    A = oracle.poisson_csr(*grid)
+    D = DeviceCSR.poisson(*grid)
+    D.set_variant(variant)
+    n = A.shape[0]
+    x = rng_vec(n)
+    y_ref = np.empty(n)
+    A.matvec(x, y_ref)
+    y = np.full(n, np.nan)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 6, 16])
+@pytest.mark.parametrize("case", ["ragged", "long", "wide", "tiny", "all_empty", "one_huge_row"])
+def test_csr_matvec_bit_exact_irregular(oracle, case, variant):
+    from pysparse_amd.device import DeviceCSR
+    if case == "ragged":
+        A = random_csr(oracle, 5000, 4000, 1, 40)
+    elif case == "long":  # rows longer than one LDS tile, and rows crossing tile boundaries
+        A = random_csr(oracle, 300, 20000, 2, 64, long_rows=((5, 9000), (6, 4096), (7, 4100), (150, 12000)))
+    elif case == "wide":
+        A = random_csr(oracle, 50, 100000, 3, 3000)
+    elif case == "tiny":
+        A = random_csr(oracle, 3, 2, 4, 2, empty_frac=0.0)
+    elif case == "all_empty":
+        A = oracle.CSR((1000, 10), np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(1001, dtype=np.int32))
+    else:
+        A = random_csr(oracle, 4, 50000, 5, 1, long_rows=((2, 50000),))
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    D.set_variant(variant)
+    x = rng_vec(A.shape[1], 7)
+    y_ref = np.empty(A.shape[0])
+    A.matvec(x, y_ref)
+    y = np.full(A.shape[0], np.nan)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+    ind, col, val = D.download()
+    assert np.array_equal(ind, A.ind) and np.array_equal(col, A.col) and np.array_equal(val, A.val)
+
+
+def test_csr_matvec_strided_views(oracle):
+    from pysparse_amd.device import DeviceCSR
+    A = random_csr(oracle, 700, 900, 11, 20)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    xb = rng_vec(2 * 900, 3)
+    yb = np.zeros(3 * 700)
+    x, y = xb[::2], yb[1::3]
+    y_ref = np.empty(700)
+    A.matvec(np.ascontiguousarray(x), y_ref)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+    assert np.all(yb[0::3] == 0) and np.all(yb[2::3] == 0)
+    with pytest.raises(ValueError):
+        D.matvec(np.zeros(5), y)
+    with pytest.raises(ValueError):
+        D.matvec(x.astype(np.float32), y)
+
+
+def test_csr_matvec_transp(oracle):
+    from pysparse_amd.device import DeviceCSR
+    A = random_csr(oracle, 3000, 2000, 12, 30)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    x = rng_vec(3000, 5)
+    y_ref = np.empty(2000)
+    A.matvec_transp(x, y_ref)
+    y = np.full(2000, np.nan)
+    D.matvec_transp(x, y)
+    # scatter order is not fixed on the GPU (fp64 atomics): tolerance, not bit equality
+    assert np.allclose(y, y_ref, rtol=1e-12, atol=1e-12 * np.abs(y_ref).max())
+
+
+@pytest.mark.parametrize("which", ["poisson2d", "poisson3d", "tendigit", "random"])
+def test_sss_matvec_bit_exact(oracle, which):
+    from pysparse_amd.device import DeviceSSS
+    if which == "poisson2d":
+        S = oracle.poisson_sss(60, 45)
+    elif which == "poisson3d":
+        S = oracle.poisson_sss(20, 21, 22)
+    elif which == "tendigit":
+        S = oracle.tendigit_sss(20000)
+    else:
+        rng = np.random.default_rng(9)
+        n = 3000
+        lens = np.minimum(rng.integers(0, 25, size=n), np.arange(n))
+        ind = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(lens, out=ind[1:])
+        col = np.concatenate([np.sort(rng.choice(i, size=lens[i], replace=False)) for i in range(n)] +
+                             [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+        S = oracle.SSS(n, rng.standard_normal(ind[-1]), rng.standard_normal(n), col, ind)
+    D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    assert D.nnz == S.nnz
+    x = rng_vec(S.n, 21)
+    y_ref = np.full(S.n, 123.0)  # the reference assigns y[i]; garbage must not leak in
+    S.matvec(x, y_ref)
+    y = np.full(S.n, np.nan)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+    ind, col, val, diag = D.download()
+    assert np.array_equal(ind, S.ind) and np.array_equal(col, S.col)
+    assert np.array_equal(val, S.val) and np.array_equal(diag, S.diag)
+    for (i, j) in ((0, 0), (S.n - 1, 0), (5, 3), (3, 5), (S.n - 1, S.n - 2)):
+        assert D[i, j] == S.getitem(i, j)
+
+
+def test_create_rejects_malformed(oracle):
+    from pysparse_amd.device import DeviceCSR
+    from pysparse_amd._capi import PspError
+    ind = np.array([0, 2, 3], dtype=np.int32)
+    val = np.ones(3)
+    with pytest.raises(PspError):
+        DeviceCSR.from_arrays((2, 2), ind, np.array([0, 1, 2], dtype=np.int32), val)  # col out of range
+    with pytest.raises(PspError):
+        DeviceCSR.from_arrays((2, 2), np.array([0, 3, 2], dtype=np.int32), np.array([0, 1, 1], dtype=np.int32), val)
