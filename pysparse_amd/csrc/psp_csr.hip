@@ -17,6 +17,7 @@
 // HBM traffic per call: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "psp_internal.h"
@@ -189,6 +190,158 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_stream(
   }
 }
 
+// ------------------------------------------------------------------ wave-level pipeline
+//
+// Same algorithm with ONE WAVEFRONT per chunk (tile of WT nonzeros) and no workgroup
+// barrier: the four waves of a workgroup run decoupled, each with a private LDS slice.
+// The loop is software-pipelined one chunk deep: while chunk i's x gathers return and its
+// rows are reduced, the val/col/row-bound loads of chunk i+1 are already in flight, so
+// every wave keeps HBM requests outstanding all the time (vmcnt waits only for the older
+// gathers, never for the younger prefetch).  Requires every chunk to fit one tile, i.e.
+// max row length <= WT/2 (the launcher falls back to csr_spmv_stream otherwise).
+template <int WT>
+struct WaveStage {
+  static constexpr int STEPS = WT / 256;
+  i4v c[STEPS];
+  d2v v0[STEPS], v1[STEPS];
+  int r0, r1, s, e;
+  int lo0, hi0, lo1, hi1;
+};
+
+template <int WT, bool NT>
+__device__ __forceinline__ void wave_issue(WaveStage<WT> &S, int chunk, int lane,
+                                           const int2 *__restrict__ tab,
+                                           const int *__restrict__ ind,
+                                           const int *__restrict__ col,
+                                           const double *__restrict__ val) {
+  const int2 c0 = tab[chunk];
+  const int2 c1 = tab[chunk + 1];
+  S.r0 = c0.x;
+  S.r1 = c1.x;
+  S.s = c0.y;
+  S.e = c1.y;
+  const int ts = S.s & ~3;
+#pragma unroll
+  for (int st = 0; st < WaveStage<WT>::STEPS; ++st) {
+    int k = ts + (st * 64 + lane) * 4;
+    k = (k < S.e) ? k : ts;
+    S.c[st] = ldg<NT>(reinterpret_cast<const i4v *>(col + k));
+    S.v0[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
+    S.v1[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k + 2));
+  }
+  const int ra = S.r0 + lane, rb = ra + 64;
+  S.lo0 = S.hi0 = S.lo1 = S.hi1 = 0;
+  if (ra < S.r1) {
+    S.lo0 = ind[ra];
+    S.hi0 = ind[ra + 1];
+  }
+  if (rb < S.r1) {
+    S.lo1 = ind[rb];
+    S.hi1 = ind[rb + 1];
+  }
+}
+
+template <int WT, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_spmv_wave(
+    int nchunks, int map_mode, const int2 *__restrict__ tab, const int *__restrict__ ind,
+    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+  constexpr int STEPS = WT / 256;
+  __shared__ double prod_all[4 * WT];
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *prod = prod_all + wid * WT;
+  const int nwaves = gridDim.x * 4;
+  // chunk visited by this wave in sweep `it`
+  int base, stride;
+  if (map_mode == 0) {
+    base = (int)blockIdx.x * 4 + wid;  // neighbouring chunks run at the same time chip-wide
+    stride = nwaves;
+  } else {
+    const int W = nwaves >> 3;  // waves per XCD: each XCD sweeps a contiguous stripe
+    base = ((int)blockIdx.x & 7) * W + ((int)blockIdx.x >> 3) * 4 + wid;
+    stride = nwaves;
+  }
+  double dsum = 0.0;
+  int chunk = base;
+  if (chunk < nchunks) {
+    WaveStage<WT> cur;
+    wave_issue<WT, NT>(cur, chunk, lane, tab, ind, col, val);
+    while (true) {
+      // x gathers of the current chunk (addresses = the col values just loaded)
+      double xv[STEPS][4];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        xv[st][0] = x[cur.c[st].x];
+        xv[st][1] = x[cur.c[st].y];
+        xv[st][2] = x[cur.c[st].z];
+        xv[st][3] = x[cur.c[st].w];
+      }
+      // prefetch the next chunk behind them
+      const int next = chunk + stride;
+      const bool has_next = next < nchunks;
+      WaveStage<WT> nxt;
+      if (has_next) wave_issue<WT, NT>(nxt, next, lane, tab, ind, col, val);
+
+      const int ts = cur.s & ~3;
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int off = (st * 64 + lane) * 4;
+        d2v p0, p1;
+        p0.x = cur.v0[st].x * xv[st][0];
+        p0.y = cur.v0[st].y * xv[st][1];
+        p1.x = cur.v1[st].x * xv[st][2];
+        p1.y = cur.v1[st].y * xv[st][3];
+        *reinterpret_cast<d2v *>(&prod[off]) = p0;
+        *reinterpret_cast<d2v *>(&prod[off + 2]) = p1;
+      }
+      // LDS operations of one wave execute in order; the fence only stops the compiler
+      // from moving the reads above the writes
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      int m = 0;
+      for (int r = cur.r0 + lane; r < cur.r1; r += 64, ++m) {
+        int lo, hi;
+        if (m == 0) {
+          lo = cur.lo0;
+          hi = cur.hi0;
+        } else if (m == 1) {
+          lo = cur.lo1;
+          hi = cur.hi1;
+        } else {
+          lo = ind[r];
+          hi = ind[r + 1];
+        }
+        double acc = 0.0;
+        for (int k = lo; k < hi; k += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int idx = k + u - ts;
+            idx = idx < WT ? idx : WT - 1;
+            v[u] = prod[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < hi) ? v[u] : 0.0;
+        }
+        y[r] = acc;
+        if (dotv) dsum += dotv[r] * acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!has_next) break;
+      cur = nxt;
+      chunk = next;
+    }
+  }
+  if (partials) {
+    const double t = block_sum(dsum, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
 // y = A^T x: scatter with fp64 HBM atomics (csr_mat.c:74-88).  Not on the Krylov path.
 __global__ void csr_spmv_transp_kernel(int nrows, const int *__restrict__ ind,
                                        const int *__restrict__ col,
@@ -306,6 +459,7 @@ struct Variant {
   int tile, vec;
   bool nt;
   int map_mode;
+  bool wave;
 };
 
 Variant decode_variant(int v) {
@@ -318,6 +472,12 @@ Variant decode_variant(int v) {
   r.tile = (v & 4) ? 2048 : 4096;
   r.nt = (v & 8) != 0;
   r.map_mode = (v & 16) ? 1 : 0;
+  // bit 5: wave-level pipelined kernel, tile 512 (bit 2 set) or 1024 nonzeros per wave
+  r.wave = (v & 32) != 0;
+  if (r.wave) {
+    r.tile = (v & 4) ? 512 : 1024;
+    r.vec = 4;
+  }
   return r;
 }
 
@@ -360,7 +520,7 @@ static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
 namespace psp {
 
 struct CsrExtra {
-  ChunkTable t[2];
+  std::map<int, ChunkTable> t;
 };
 
 }  // namespace psp
@@ -390,7 +550,7 @@ static int finalize_csr(psp_csr *A) {
 static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
-  ChunkTable &t = ex.t[tile == 4096 ? 0 : 1];
+  ChunkTable &t = ex.t[tile];
   if (t.tab == nullptr) {
     int target = tile - 3 - A->max_row_nnz;
     if (target < tile / 2) target = tile / 2;  // very long rows: chunks spill into more tiles
@@ -421,9 +581,32 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
                     double *partials, int *nparts) {
   Workspace *w;
   PSP_TRY(workspace(&w));
-  const Variant v = decode_variant(A->variant);
+  Variant v = decode_variant(A->variant);
+  if (v.wave && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
+    v.wave = false;
+    v.tile = 2048;
+  }
   ChunkTable *t;
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
+  if (v.wave) {
+    // 4 waves per workgroup, one chunk per wave at a time; residency is VGPR-bound
+    const int per_cu = v.tile == 512 ? 5 : 3;
+    int grid = std::min((t->nchunks + 3) / 4, std::min(w->num_cu * per_cu, kMaxParts));
+    if (v.map_mode == 1) {
+      grid = grid / 8 * 8;
+      if (grid < 8) grid = 8;
+    }
+    if (grid < 1) grid = 1;
+#define PSP_WCASE(WT, NT)                                                                       \
+  hipLaunchKernelGGL((csr_spmv_wave<WT, NT>), dim3(grid), dim3(kBlock), 0, stream(), t->nchunks, \
+                     v.map_mode, t->tab, A->ind, A->col, A->val, x, y, dotv, partials)
+    if (v.tile == 512) { if (v.nt) PSP_WCASE(512, true); else PSP_WCASE(512, false); }
+    else { if (v.nt) PSP_WCASE(1024, true); else PSP_WCASE(1024, false); }
+#undef PSP_WCASE
+    PSP_LAUNCH_CHECK();
+    if (nparts) *nparts = grid;
+    return PSP_OK;
+  }
   // persistent grid: as many workgroups as stay resident (LDS: 32 KiB -> 5/CU, 16 KiB -> 8/CU)
   const int per_cu = v.tile == 4096 ? 5 : 8;
   int grid = std::min(t->nchunks, std::min(w->num_cu * per_cu, kMaxParts));
@@ -568,7 +751,7 @@ int psp_csr_destroy(psp_csr_t *A) {
     auto it = g_extra.find(A);
     if (it != g_extra.end()) {
       for (auto &t : it->second.t)
-        if (t.tab) (void)hipFree(t.tab);
+        if (t.second.tab) (void)hipFree(t.second.tab);
       g_extra.erase(it);
     }
   }

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kBlock) void xr_update_kernel(
   double acc[3] = {0.0, 0.0, 0.0};
   double dmax = 0.0;
   const double malpha = -alpha;
+  const bool upd = alpha != 0.0;
   PSP_VEC_LOOP(i, n) {
     const Pack<V> pp = ld<V>(p, i), qq = ld<V>(q, i);
     Pack<V> xx = ld<V>(x, i), rr = ld<V>(r, i);
@@ -144,8 +145,10 @@ __global__ __launch_bounds__(kBlock) void xr_update_kernel(
         // that is equivalent to max(dmax, 1.0)
         if (1.0 > dmax) dmax = 1.0;
       }
-      xx.v[u] = xx.v[u] + alpha * pp.v[u];    // daxpy, pcg.c:141
-      const double t = rr.v[u] + malpha * qq.v[u];  // daxpy with -alpha, pcg.c:142-143
+      // daxpy (pcg.c:141-143) returns without touching y when the scalar is zero
+      // (netlib/OpenBLAS quick return), which matters when p or q hold inf/NaN
+      if (upd) xx.v[u] = xx.v[u] + alpha * pp.v[u];
+      const double t = upd ? rr.v[u] + malpha * qq.v[u] : rr.v[u];
       rr.v[u] = t;
       acc[0] += t * t;
       if constexpr (PRE) {

@@ -153,7 +153,7 @@ def test_special_exits(oracle, golden, p2d):
 
 def test_stagnation_and_breakdown_codes(oracle):
     """-5 (stagnation) and -6/-2 (zero scalars) against the oracle on crafted inputs."""
-    from pysparse_amd.device import DeviceCSR, pcg
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg
     n = 64
     ind = np.arange(n + 1, dtype=np.int32)
     col = np.arange(n, dtype=np.int32)
@@ -167,16 +167,92 @@ def test_stagnation_and_breakdown_codes(oracle):
     ro = oracle.pcg(A, b, xo, 1e-10, 50)
     rd = pcg(D, b, xd, 1e-10, 50)
     assert ro[:2] == rd[:2] and ro[0] == -6
-    # huge x0, tiny correction: 1 + |alpha p / x| == 1 -> stagnation -5
-    val = np.linspace(1.0, 2.0, n)
+    # alpha == 0 -> stag = 1 -> -5 (pcg.c:124-125,159-162): q = A p overflows to inf, so
+    # pq = inf and alpha = rho/inf = 0 while rho stays finite thanks to a tiny preconditioner
+    val = np.full(n, 1e300)
     A = oracle.CSR((n, n), val, col, ind)
     D = DeviceCSR.from_arrays((n, n), ind, col, val)
-    x0 = np.full(n, 1e30)
-    b = val * x0 + 1.0
-    xo, xd = x0.copy(), x0.copy()
-    ro = oracle.pcg(A, b, xo, 1e-300, 50)
-    rd = pcg(D, b, xd, 1e-300, 50)
-    assert ro[:2] == rd[:2] and ro[0] == -5
+    b = np.full(n, 1e150)
+
+    class HugeDiag:
+        shape = (n, n)
+
+        def __getitem__(self, ij):
+            return 1e100
+
+    xo, xd = np.zeros(n), np.zeros(n)
+    with np.errstate(all="ignore"):
+        ro = oracle.pcg(A, b, xo, 1e-10, 50, np.full(n, 1e-100))
+    rd = pcg(D, b, xd, 1e-10, 50, DeviceJacobi(HugeDiag()))
+    assert ro[:2] == rd[:2] == (-5, 1)
+    assert rd[2] == ro[2] == 1.0  # daxpy quick return for alpha == 0 leaves r untouched
+    # rho == 0 -> -2 (pcg.c:101-104): indefinite preconditioner with r.z == 0
+    val = np.ones(n)
+    A = oracle.CSR((n, n), val, col, ind)
+    D = DeviceCSR.from_arrays((n, n), ind, col, val)
+    dinv = np.ones(n)
+    dinv[n // 2:] = -1.0
+
+    class SignDiag:
+        shape = (n, n)
+
+        def __getitem__(self, ij):
+            return 1.0 if ij[0] < n // 2 else -1.0
+
+    b = np.ones(n)
+    xo, xd = np.zeros(n), np.zeros(n)
+    ro = oracle.pcg(A, b, xo, 1e-10, 50, dinv)
+    rd = pcg(D, b, xd, 1e-10, 50, DeviceJacobi(SignDiag()))
+    assert ro[:2] == rd[:2] == (-2, 1)
+
+
+def test_stagnation_scan_kernel():
+    """pcg.c:127-139 on crafted vectors through psp_k_xr_update: out[2] != 0 <=> 1 + dmax != 1."""
+    import ctypes as C
+    from pysparse_amd.device import DeviceBuffer
+    from pysparse_amd._capi import check, lib
+
+    def scan(alpha, p, x):
+        dmax = 0.0
+        for pi, xi in zip(p, x):
+            if xi != 0.0:
+                d = abs(alpha * pi / xi)
+                if d > dmax:
+                    dmax = d
+            elif pi != 0.0:
+                dmax = 1.0
+        return 1.0 + dmax != 1.0
+
+    n = 1000
+    rng = np.random.default_rng(3)
+    cases = []
+    x = rng.standard_normal(n) + 3.0
+    cases.append((1.0, x * 1e-17, x))                      # every update below eps/2: stagnated
+    p = x * 1e-17
+    p[777] = x[777] * 1e-15
+    cases.append((1.0, p, x))                              # one component still moves
+    xz = x.copy()
+    xz[5] = 0.0
+    pz = x * 1e-18
+    cases.append((1.0, pz, xz))                            # x_i == 0 with p_i != 0 -> dmax = 1
+    pz2 = pz.copy()
+    pz2[5] = 0.0
+    cases.append((1.0, pz2, xz))                           # x_i == 0 and p_i == 0: ignored
+    cases.append((2.0 ** -53, x.copy(), x))                # |alpha p/x| == 2^-53 exactly: tie rounds to 1
+    cases.append((2.0 ** -53 * (1 + 2.0 ** -52), x.copy(), x))
+    for alpha, p, x0 in cases:
+        q = rng.standard_normal(n)
+        r = rng.standard_normal(n)
+        dp, dq = DeviceBuffer.from_host(p), DeviceBuffer.from_host(q)
+        dx, dr = DeviceBuffer.from_host(x0), DeviceBuffer.from_host(r)
+        out = DeviceBuffer(4)
+        check(lib().psp_k_xr_update(n, alpha, dp.ptr, dq.ptr, None, dx.ptr, dr.ptr, out.ptr))
+        o = out.download()
+        assert (o[2] != 0.0) == scan(alpha, p, x0)
+        assert np.array_equal(dx.download(), x0 + alpha * p)
+        r_new = r + (-alpha) * q
+        assert np.array_equal(dr.download(), r_new)
+        assert abs(o[0] - np.dot(r_new, r_new)) <= 1e-13 * o[0] and o[1] == o[0]
 
 
 def test_jacobi_object(oracle, p2d):
