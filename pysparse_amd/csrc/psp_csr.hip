@@ -16,6 +16,7 @@
 //     reduced by wave shuffles + LDS, one slot per workgroup, finished in fixed order.
 // HBM traffic per call: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -86,9 +87,10 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 template <int TILE, int VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void csr_spmv_stream(
-    int nchunks, int map_mode, const int2 *__restrict__ tab, const int *__restrict__ ind,
-    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+    int nchunks, int map_mode, int colmask, const int2 *__restrict__ tab,
+    const int *__restrict__ ind, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ dotv,
+    double *__restrict__ partials) {
   static_assert(TILE % (kBlock * VEC) == 0, "tile must be a whole number of steps");
   constexpr int STEPS = TILE / (kBlock * VEC);
   __shared__ double prod[TILE];
@@ -129,23 +131,23 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_stream(
           const d2v v0 = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
           const d2v v1 = ldg<NT>(reinterpret_cast<const d2v *>(val + k + 2));
           d2v p0, p1;
-          p0.x = v0.x * x[c.x];
-          p0.y = v0.y * x[c.y];
-          p1.x = v1.x * x[c.z];
-          p1.y = v1.y * x[c.w];
+          p0.x = v0.x * x[c.x & colmask];
+          p0.y = v0.y * x[c.y & colmask];
+          p1.x = v1.x * x[c.z & colmask];
+          p1.y = v1.y * x[c.w & colmask];
           *reinterpret_cast<d2v *>(&prod[off]) = p0;
           *reinterpret_cast<d2v *>(&prod[off + 2]) = p1;
         } else if constexpr (VEC == 2) {
           const i2v c = ldg<NT>(reinterpret_cast<const i2v *>(col + k));
           const d2v v0 = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
           d2v p0;
-          p0.x = v0.x * x[c.x];
-          p0.y = v0.y * x[c.y];
+          p0.x = v0.x * x[c.x & colmask];
+          p0.y = v0.y * x[c.y & colmask];
           *reinterpret_cast<d2v *>(&prod[off]) = p0;
         } else {
           const int c = ldg<NT>(col + k);
           const double v0 = ldg<NT>(val + k);
-          prod[off] = v0 * x[c];
+          prod[off] = v0 * x[c & colmask];
         }
       }
       __syncthreads();
@@ -243,9 +245,10 @@ __device__ __forceinline__ void wave_issue(WaveStage<WT> &S, int chunk, int lane
 
 template <int WT, bool NT>
 __global__ __launch_bounds__(kBlock) void csr_spmv_wave(
-    int nchunks, int map_mode, const int2 *__restrict__ tab, const int *__restrict__ ind,
-    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+    int nchunks, int map_mode, int colmask, const int2 *__restrict__ tab,
+    const int *__restrict__ ind, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ dotv,
+    double *__restrict__ partials) {
   constexpr int STEPS = WT / 256;
   __shared__ double prod_all[4 * WT];
   __shared__ double red[4];
@@ -273,10 +276,10 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave(
       double xv[STEPS][4];
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
-        xv[st][0] = x[cur.c[st].x];
-        xv[st][1] = x[cur.c[st].y];
-        xv[st][2] = x[cur.c[st].z];
-        xv[st][3] = x[cur.c[st].w];
+        xv[st][0] = x[cur.c[st].x & colmask];
+        xv[st][1] = x[cur.c[st].y & colmask];
+        xv[st][2] = x[cur.c[st].z & colmask];
+        xv[st][3] = x[cur.c[st].w & colmask];
       }
       // prefetch the next chunk behind them
       const int next = chunk + stride;
@@ -460,6 +463,7 @@ struct Variant {
   bool nt;
   int map_mode;
   bool wave;
+  bool full_grid;
 };
 
 Variant decode_variant(int v) {
@@ -473,6 +477,8 @@ Variant decode_variant(int v) {
   r.nt = (v & 8) != 0;
   r.map_mode = (v & 16) ? 1 : 0;
   // bit 5: wave-level pipelined kernel, tile 512 (bit 2 set) or 1024 nonzeros per wave
+  // bit 6: one chunk per workgroup/wave (no persistent loop)
+  r.full_grid = (v & 64) != 0;
   r.wave = (v & 32) != 0;
   if (r.wave) {
     r.tile = (v & 4) ? 512 : 1024;
@@ -570,11 +576,21 @@ static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out) {
 
 namespace psp {
 
+// tuning aid: PSP_SPMV_COLMASK=<int> ANDs every gathered column index (wrong results, used
+// only to price the x gathers); default -1 leaves indices untouched
+static int colmask() {
+  static const int m = [] {
+    const char *e = getenv("PSP_SPMV_COLMASK");
+    return e ? atoi(e) : -1;
+  }();
+  return m;
+}
+
 template <int TILE, int VEC, bool NT>
 static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab, const psp_csr *A,
                            const double *x, double *y, const double *dotv, double *partials) {
   hipLaunchKernelGGL((csr_spmv_stream<TILE, VEC, NT>), dim3(grid), dim3(kBlock), 0, stream(),
-                     nchunks, map_mode, tab, A->ind, A->col, A->val, x, y, dotv, partials);
+                     nchunks, map_mode, colmask(), tab, A->ind, A->col, A->val, x, y, dotv, partials);
 }
 
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
@@ -592,6 +608,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     // 4 waves per workgroup, one chunk per wave at a time; residency is VGPR-bound
     const int per_cu = v.tile == 512 ? 5 : 3;
     int grid = std::min((t->nchunks + 3) / 4, std::min(w->num_cu * per_cu, kMaxParts));
+    if (v.full_grid && !partials) grid = (t->nchunks + 3) / 4;
     if (v.map_mode == 1) {
       grid = grid / 8 * 8;
       if (grid < 8) grid = 8;
@@ -599,7 +616,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     if (grid < 1) grid = 1;
 #define PSP_WCASE(WT, NT)                                                                       \
   hipLaunchKernelGGL((csr_spmv_wave<WT, NT>), dim3(grid), dim3(kBlock), 0, stream(), t->nchunks, \
-                     v.map_mode, t->tab, A->ind, A->col, A->val, x, y, dotv, partials)
+                     v.map_mode, colmask(), t->tab, A->ind, A->col, A->val, x, y, dotv, partials)
     if (v.tile == 512) { if (v.nt) PSP_WCASE(512, true); else PSP_WCASE(512, false); }
     else { if (v.nt) PSP_WCASE(1024, true); else PSP_WCASE(1024, false); }
 #undef PSP_WCASE
@@ -610,6 +627,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   // persistent grid: as many workgroups as stay resident (LDS: 32 KiB -> 5/CU, 16 KiB -> 8/CU)
   const int per_cu = v.tile == 4096 ? 5 : 8;
   int grid = std::min(t->nchunks, std::min(w->num_cu * per_cu, kMaxParts));
+  if (v.full_grid && !partials) grid = t->nchunks;
   if (v.map_mode == 1) {
     grid = grid / 8 * 8;
     if (grid < 8) grid = 8;
