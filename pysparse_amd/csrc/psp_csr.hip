@@ -345,6 +345,131 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave(
   }
 }
 
+// ------------------------------------------------------------------ one chunk per wave, no loop
+//
+// The fastest form measured on MI355X (profiles/): the grid holds ONE WAVE PER CHUNK and the
+// hardware dispatcher, not a persistent loop, walks the matrix -- waves start in address
+// order, which keeps the HBM request stream nearly linear, and a CU always has fresh waves
+// to cover the tab -> val/col -> x-gather dependency chain.  WPB waves share a workgroup
+// only to share its LDS allocation and the dot-product epilogue.
+//   LAYOUT 0: each lane loads 4 consecutive nonzeros per step (16-byte col, 2x16-byte val)
+//   LAYOUT 1: each lane loads 1 nonzero per step (4-byte col, 8-byte val): the x gather of
+//             one instruction then covers 64 consecutive nonzeros (~9 stencil rows) and
+//             touches about half as many cache lines
+template <int WT, int WPB, int LAYOUT, bool NT>
+__global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
+    int nchunks, int colmask, const int2 *__restrict__ tab, const int *__restrict__ ind,
+    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+  __shared__ double prod_all[WPB * WT];
+  __shared__ double red[WPB];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *prod = prod_all + wid * WT;
+  const int chunk = (int)blockIdx.x * WPB + wid;
+  double dsum = 0.0;
+  if (chunk < nchunks) {
+    const int2 c0 = tab[chunk];
+    const int2 c1 = tab[chunk + 1];
+    const int r0 = c0.x, r1 = c1.x, s = c0.y, e = c1.y;
+    const int ts = s & ~3;
+    // row bounds of the first two passes, issued together with the stream loads
+    const int ra = r0 + lane, rb = ra + 64;
+    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if constexpr (LAYOUT == 0) {
+      constexpr int STEPS = WT / 256;
+      i4v c[STEPS];
+      d2v v0[STEPS], v1[STEPS];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        int k = ts + (st * 64 + lane) * 4;
+        k = (k < e) ? k : ts;
+        c[st] = ldg<NT>(reinterpret_cast<const i4v *>(col + k));
+        v0[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
+        v1[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k + 2));
+      }
+      if (ra < r1) { lo0 = ind[ra]; hi0 = ind[ra + 1]; }
+      if (rb < r1) { lo1 = ind[rb]; hi1 = ind[rb + 1]; }
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int off = (st * 64 + lane) * 4;
+        d2v p0, p1;
+        p0.x = v0[st].x * x[c[st].x & colmask];
+        p0.y = v0[st].y * x[c[st].y & colmask];
+        p1.x = v1[st].x * x[c[st].z & colmask];
+        p1.y = v1[st].y * x[c[st].w & colmask];
+        *reinterpret_cast<d2v *>(&prod[off]) = p0;
+        *reinterpret_cast<d2v *>(&prod[off + 2]) = p1;
+      }
+    } else {
+      constexpr int STEPS = WT / 64;
+      int c[STEPS];
+      double v[STEPS];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        int k = ts + st * 64 + lane;
+        k = (k < e) ? k : ts;
+        c[st] = ldg<NT>(col + k);
+        v[st] = ldg<NT>(val + k);
+      }
+      if (ra < r1) { lo0 = ind[ra]; hi0 = ind[ra + 1]; }
+      if (rb < r1) { lo1 = ind[rb]; hi1 = ind[rb + 1]; }
+      double xv[STEPS];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) xv[st] = x[c[st] & colmask];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) prod[st * 64 + lane] = v[st] * xv[st];
+    }
+    // LDS operations of one wave execute in order; the fence only pins the compiler
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    int m = 0;
+    for (int r = ra; r < r1; r += 64, ++m) {
+      int lo, hi;
+      if (m == 0) { lo = lo0; hi = hi0; }
+      else if (m == 1) { lo = lo1; hi = hi1; }
+      else { lo = ind[r]; hi = ind[r + 1]; }
+      double acc = 0.0;
+      for (int k = lo; k < hi; k += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          int idx = k + u - ts;
+          idx = idx < WT ? idx : WT - 1;
+          t[u] = prod[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (k + u < hi) ? t[u] : 0.0;
+      }
+      y[r] = acc;
+      if (dotv) dsum += dotv[r] * acc;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < WPB; ++i) t += red[i];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
+// first-level fold of per-workgroup dot partials when the grid is larger than the
+// workspace slots: out[b] = in[b] + in[b+nout] + ... (fixed order)
+__global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
+                                                            double *__restrict__ out, int nout) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nout) return;
+  double s = 0.0;
+  for (int i = b; i < nin; i += nout) s += in[i];
+  out[b] = s;
+}
+
 // y = A^T x: scatter with fp64 HBM atomics (csr_mat.c:74-88).  Not on the Krylov path.
 __global__ void csr_spmv_transp_kernel(int nrows, const int *__restrict__ ind,
                                        const int *__restrict__ col,
@@ -458,18 +583,22 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
+constexpr int kDefaultVariant = 128 + 16;  // w1, tile 1024, layout 0, 8 waves per workgroup
+
 struct Variant {
   int tile, vec;
   bool nt;
   int map_mode;
   bool wave;
   bool full_grid;
+  bool w1;
+  int layout, wpb;
 };
 
 Variant decode_variant(int v) {
   // bits 0-1: vec (0 -> 4, 1 -> 2, 2 -> 1); bit 2: tile 2048 instead of 4096;
   // bit 3: non-temporal val/col loads; bit 4: XCD-striped chunk order
-  if (v < 0) v = 0;
+  if (v < 0) v = kDefaultVariant;
   Variant r;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
@@ -484,6 +613,14 @@ Variant decode_variant(int v) {
     r.tile = (v & 4) ? 512 : 1024;
     r.vec = 4;
   }
+  // bit 7: one chunk per wave, non-persistent (csr_spmv_w1).  bit 0: layout (0: 4 nonzeros
+  // per lane per load, 1: one); bit 2: tile 512 instead of 1024; bits 4-5: waves per
+  // workgroup 4 / 8 / 16; bit 3: non-temporal loads
+  r.w1 = (v & 128) != 0;
+  r.layout = v & 1;
+  r.wpb = 4 << ((v >> 4) & 3);
+  if (r.wpb > 16) r.wpb = 16;
+  if (r.w1) r.tile = (v & 4) ? 512 : 1024;
   return r;
 }
 
@@ -527,6 +664,8 @@ namespace psp {
 
 struct CsrExtra {
   std::map<int, ChunkTable> t;
+  double *big_partials = nullptr;  // one slot per workgroup of the full-grid SpMV
+  int big_cap = 0;
 };
 
 }  // namespace psp
@@ -598,12 +737,53 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   Workspace *w;
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
-  if (v.wave && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
-    v.wave = false;
+  if ((v.wave || v.w1) && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
+    v.wave = v.w1 = false;
     v.tile = 2048;
+    v.vec = 4;
+    v.map_mode = 0;
+    v.full_grid = false;
   }
   ChunkTable *t;
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
+  if (v.w1) {
+    const int grid = (t->nchunks + v.wpb - 1) / v.wpb;
+    double *pbuf = partials;
+    psp::CsrExtra *ex = nullptr;
+    if (partials && grid > kMaxParts) {
+      std::lock_guard<std::mutex> lk(g_extra_mu);
+      ex = &g_extra[A];
+      if (ex->big_cap < grid) {
+        if (ex->big_partials) (void)hipFree(ex->big_partials);
+        ex->big_partials = nullptr;
+        ex->big_cap = 0;
+        PSP_HIP(hipMalloc((void **)&ex->big_partials, sizeof(double) * (size_t)grid));
+        ex->big_cap = grid;
+      }
+      pbuf = ex->big_partials;
+    }
+#define PSP_W1(WT, WPB, LAY, NT)                                                                 \
+  hipLaunchKernelGGL((csr_spmv_w1<WT, WPB, LAY, NT>), dim3(grid), dim3(64 * WPB), 0, stream(),    \
+                     t->nchunks, colmask(), t->tab, A->ind, A->col, A->val, x, y, dotv, pbuf)
+#define PSP_W1_NT(WT, WPB, LAY) do { if (v.nt) PSP_W1(WT, WPB, LAY, true); else PSP_W1(WT, WPB, LAY, false); } while (0)
+#define PSP_W1_LAY(WT, WPB) do { if (v.layout) PSP_W1_NT(WT, WPB, 1); else PSP_W1_NT(WT, WPB, 0); } while (0)
+#define PSP_W1_WPB(WT) do { if (v.wpb == 4) PSP_W1_LAY(WT, 4); else if (v.wpb == 8) PSP_W1_LAY(WT, 8); else PSP_W1_LAY(WT, 16); } while (0)
+    if (v.tile == 512) PSP_W1_WPB(512); else PSP_W1_WPB(1024);
+#undef PSP_W1_WPB
+#undef PSP_W1_LAY
+#undef PSP_W1_NT
+#undef PSP_W1
+    PSP_LAUNCH_CHECK();
+    int np = grid;
+    if (pbuf != partials) {
+      np = 1024;
+      hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 256), dim3(256), 0, stream(), pbuf, grid,
+                         partials, np);
+      PSP_LAUNCH_CHECK();
+    }
+    if (nparts) *nparts = np;
+    return PSP_OK;
+  }
   if (v.wave) {
     // 4 waves per workgroup, one chunk per wave at a time; residency is VGPR-bound
     const int per_cu = v.tile == 512 ? 5 : 3;
@@ -770,6 +950,7 @@ int psp_csr_destroy(psp_csr_t *A) {
     if (it != g_extra.end()) {
       for (auto &t : it->second.t)
         if (t.second.tab) (void)hipFree(t.second.tab);
+      if (it->second.big_partials) (void)hipFree(it->second.big_partials);
       g_extra.erase(it);
     }
   }
