@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave(
 //             touches about half as many cache lines
 template <int WT, int WPB, int LAYOUT, bool NT>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
-    int nchunks, int colmask, const int2 *__restrict__ tab, const int *__restrict__ ind,
+    int nchunks, int colmask, int stripe, const int2 *__restrict__ tab, const int *__restrict__ ind,
     const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
   __shared__ double prod_all[WPB * WT];
@@ -366,7 +366,18 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *prod = prod_all + wid * WT;
-  const int chunk = (int)blockIdx.x * WPB + wid;
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+  // share an L2; observed, used for speed only).  With stripe > 0 the k-th workgroup of
+  // XCD j takes position ((k / stripe) * 8 + j) * stripe + k % stripe, i.e. every XCD walks
+  // contiguous stripes of `stripe` workgroups while the eight of them stay on adjacent
+  // stripes -- the x entries of neighbouring grid lines are then re-used in that XCD's L2
+  // instead of being fetched once per XCD.
+  int vb = (int)blockIdx.x;
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int chunk = vb * WPB + wid;
   double dsum = 0.0;
   if (chunk < nchunks) {
     const int2 c0 = tab[chunk];
@@ -583,7 +594,7 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
-constexpr int kDefaultVariant = 128 + 16;  // w1, tile 1024, layout 0, 8 waves per workgroup
+constexpr int kDefaultVariant = 128;  // csr_spmv_w1, tile 1024, layout 0, 4 waves per workgroup  // w1, tile 1024, layout 0, 8 waves per workgroup
 
 struct Variant {
   int tile, vec;
@@ -593,6 +604,7 @@ struct Variant {
   bool full_grid;
   bool w1;
   int layout, wpb;
+  int stripe;
 };
 
 Variant decode_variant(int v) {
@@ -600,6 +612,9 @@ Variant decode_variant(int v) {
   // bit 3: non-temporal val/col loads; bit 4: XCD-striped chunk order
   if (v < 0) v = kDefaultVariant;
   Variant r;
+  // bits 8-19: workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order)
+  r.stripe = (v >> 8) & 0xfff;
+  v &= 0xff;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
   r.tile = (v & 4) ? 2048 : 4096;
@@ -725,6 +740,15 @@ static int colmask() {
   return m;
 }
 
+// workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order); PSP_SPMV_STRIPE overrides
+static int spmv_stripe() {
+  static const int m = [] {
+    const char *e = getenv("PSP_SPMV_STRIPE");
+    return e ? atoi(e) : -1;
+  }();
+  return m;
+}
+
 template <int TILE, int VEC, bool NT>
 static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab, const psp_csr *A,
                            const double *x, double *y, const double *dotv, double *partials) {
@@ -747,7 +771,9 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   ChunkTable *t;
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
   if (v.w1) {
-    const int grid = (t->nchunks + v.wpb - 1) / v.wpb;
+    int grid = (t->nchunks + v.wpb - 1) / v.wpb;
+    const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+    if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
     double *pbuf = partials;
     psp::CsrExtra *ex = nullptr;
     if (partials && grid > kMaxParts) {
@@ -764,7 +790,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     }
 #define PSP_W1(WT, WPB, LAY, NT)                                                                 \
   hipLaunchKernelGGL((csr_spmv_w1<WT, WPB, LAY, NT>), dim3(grid), dim3(64 * WPB), 0, stream(),    \
-                     t->nchunks, colmask(), t->tab, A->ind, A->col, A->val, x, y, dotv, pbuf)
+                     t->nchunks, colmask(), stripe, t->tab, A->ind, A->col, A->val, x, y, dotv, pbuf)
 #define PSP_W1_NT(WT, WPB, LAY) do { if (v.nt) PSP_W1(WT, WPB, LAY, true); else PSP_W1(WT, WPB, LAY, false); } while (0)
 #define PSP_W1_LAY(WT, WPB) do { if (v.layout) PSP_W1_NT(WT, WPB, 1); else PSP_W1_NT(WT, WPB, 0); } while (0)
 #define PSP_W1_WPB(WT) do { if (v.wpb == 4) PSP_W1_LAY(WT, 4); else if (v.wpb == 8) PSP_W1_LAY(WT, 8); else PSP_W1_LAY(WT, 16); } while (0)
