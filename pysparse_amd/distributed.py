@@ -1,0 +1,347 @@
+"""Row-range partitioned SpMV + Jacobi-PCG over the GPUs of one node.
+
+The reference is single-process; this is the MI355X-native extension of its PCG
+(pysparse/itsolvers/src/pcg.c:22-171) to N ranks, one process per GPU:
+
+  * rows of A and the matching slices of x, b, r, q, dinv are split into contiguous row
+    ranges; each rank stores its row block with column indices renumbered into a local
+    "extended" vector  [ghost_lo | owned | ghost_hi]  (ghosts sorted by global index, so a
+    banded operator keeps its global ordering and the SpMV kernel needs no change);
+  * before every q = A p the ghost entries of p are exchanged with the neighbouring ranks
+    (RCCL send/recv through torch.distributed, point-to-point over xGMI);
+  * the three sum reductions and the stagnation test of one PCG iteration are packed into
+    TWO all-reduces:  #1 {p.q}  and  #2 {r.r, r.z, number of non-stagnated ranks}.
+
+All arithmetic on vectors is done by a *backend*: HipBackend calls the HIP kernels of
+libpysparse_hip.so through the C ABI on torch CUDA tensors (the product path); the CPU
+gloo tests inject an oracle-backed stand-in (tests/test_distributed_cpu.py) so that the
+partition, halo and reduction logic of this file is exercised at world_size 2 without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+try:  # torch is plumbing here: device memory, streams and torch.distributed
+    import torch
+    import torch.distributed as dist
+except ImportError:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def row_range(n_global, world, rank):
+    """Contiguous, balanced row ranges: rank r owns [lo, hi)."""
+    base, rem = divmod(n_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def slab_range(n_planes, plane_rows, world, rank):
+    """Row range made of whole grid planes (z-slabs for 3-D, y-lines for 2-D)."""
+    lo, hi = row_range(n_planes, world, rank)
+    return lo * plane_rows, hi * plane_rows
+
+
+class HaloPlan:
+    """Who sends which entries to whom.  `recv[q]` = slice of the extended vector filled
+    by rank q; `send[q]` = owned-local indices (or a slice) this rank sends to q."""
+
+    def __init__(self, n_owned, ghost_lo, ghost_hi):
+        self.n_owned = n_owned
+        self.ghost_lo = ghost_lo  # number of ghost entries below the owned block
+        self.ghost_hi = ghost_hi
+        self.p_offset = ghost_lo
+        self.n_ext = ghost_lo + n_owned + ghost_hi
+        self.recv = {}  # rank -> (start, stop) in the extended vector
+        self.send = {}  # rank -> (start, stop) in OWNED coordinates, or an index tensor
+
+
+def poisson_halo_plan(nx, ny, nz, world, rank):
+    """Slab partition of the 5-/7-point operator: ghosts are the `reach` rows just below
+    and above the owned block (reach = one grid plane / line), clipped at the boundary."""
+    three_d = nz > 0
+    planes = nz if three_d else ny
+    plane_rows = nx * ny if three_d else nx
+    if planes < world:
+        raise ValueError("fewer grid planes than ranks")
+    lo, hi = slab_range(planes, plane_rows, world, rank)
+    n = plane_rows * planes
+    reach = plane_rows
+    g_lo = min(reach, lo)
+    g_hi = min(reach, n - hi)
+    plan = HaloPlan(hi - lo, g_lo, g_hi)
+    plan.row_lo, plan.row_hi, plan.n_global = lo, hi, n
+    if g_lo:  # lower neighbour owns [lo - reach, lo)
+        plan.recv[rank - 1] = (0, g_lo)
+        plan.send[rank - 1] = (0, reach)  # my first plane is its ghost_hi
+    if g_hi:
+        plan.recv[rank + 1] = (g_lo + plan.n_owned, plan.n_ext)
+        plan.send[rank + 1] = (plan.n_owned - reach, plan.n_owned)
+    return plan
+
+
+def general_halo_plan(n_global, row_lo, row_hi, col_global, world, rank, all_gather_object):
+    """Partition of an arbitrary CSR row block (host arrays, small/medium problems): the
+    ghost set is the sorted set of referenced off-rank columns; send lists are exchanged
+    once at setup.  Returns (plan, col_local)."""
+    col_global = np.asarray(col_global, dtype=np.int64)
+    needed = np.unique(col_global)
+    g_lo_ids = needed[needed < row_lo]
+    g_hi_ids = needed[needed >= row_hi]
+    plan = HaloPlan(row_hi - row_lo, len(g_lo_ids), len(g_hi_ids))
+    plan.row_lo, plan.row_hi, plan.n_global = row_lo, row_hi, n_global
+    ext_ids = np.concatenate([g_lo_ids, np.arange(row_lo, row_hi, dtype=np.int64), g_hi_ids])
+    col_local = np.searchsorted(ext_ids, col_global).astype(np.int32)
+    ranges = all_gather_object((row_lo, row_hi))
+    ghosts = np.concatenate([g_lo_ids, g_hi_ids])
+    wanted = {}  # owner rank -> ids I need from it
+    for q, (qlo, qhi) in enumerate(ranges):
+        if q == rank:
+            continue
+        ids = ghosts[(ghosts >= qlo) & (ghosts < qhi)]
+        if len(ids):
+            wanted[q] = ids
+            start = int(np.searchsorted(ext_ids, ids[0]))
+            plan.recv[q] = (start, start + len(ids))
+    everyone = all_gather_object(wanted)
+    for q, w in enumerate(everyone):
+        if q != rank and rank in w:
+            plan.send[q] = (w[rank] - row_lo).astype(np.int32)  # owned-local indices
+    return plan, col_local
+
+
+# ----------------------------------------------------------------------------- backends
+
+class HipBackend:
+    """Vectors = torch CUDA float64 tensors; kernels = libpysparse_hip.so via the C ABI."""
+
+    def __init__(self, device_index):
+        from . import _capi
+        self._capi = _capi
+        self.L = _capi.lib()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        _capi.check(self.L.psp_set_device(device_index))
+        # enqueue our kernels on torch's current stream so that collectives order with them
+        _capi.check(self.L.psp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._scal = torch.zeros(8, dtype=torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def index_tensor(self, idx):
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+
+    def _p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def dot(self, x, y):
+        out = self._scal[:1]
+        self._capi.check(self.L.psp_k_dot(x.numel(), self._p(x), self._p(y), self._p(out)))
+        return out
+
+    def residual(self, b, r, dinv):
+        out = self._scal[:2]
+        self._capi.check(self.L.psp_k_residual(r.numel(), self._p(b), self._p(r),
+                                               self._p(dinv) if dinv is not None else None, self._p(out)))
+        return out
+
+    def pupdate(self, r, dinv, beta, first, p_owned):
+        self._capi.check(self.L.psp_k_pupdate(r.numel(), self._p(r), self._p(dinv) if dinv is not None else None,
+                                              float(beta), int(first), self._p(p_owned)))
+
+    def matvec_dot(self, A, p_ext, p_offset, q):
+        out = self._scal[:1]
+        self._capi.check(self.L.psp_k_csr_matvec_dot(A._h, self._p(p_ext), int(p_offset), self._p(q), self._p(out)))
+        return out
+
+    def matvec(self, A, p_ext, q):
+        self._capi.check(self.L.psp_csr_matvec_dev(A._h, self._p(p_ext), self._p(q)))
+
+    def xr_update(self, alpha, p_owned, q, dinv, x, r):
+        out = self._scal[:3]
+        self._capi.check(self.L.psp_k_xr_update(x.numel(), float(alpha), self._p(p_owned), self._p(q),
+                                                self._p(dinv) if dinv is not None else None, self._p(x),
+                                                self._p(r), self._p(out)))
+        return out
+
+    def gather(self, idx, v, out):
+        self._capi.check(self.L.psp_k_gather(idx.numel(), self._p(idx), self._p(v), self._p(out)))
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+
+class Comm:
+    """torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allreduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def exchange(self, sends, recvs):
+        """sends/recvs: lists of (peer, tensor).  One grouped RCCL send/recv batch."""
+        if not sends and not recvs:
+            return
+        ops = [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
+        ops += [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+class SingleComm:
+    """world_size 1 without a process group."""
+    rank, world = 0, 1
+
+    def allreduce_sum(self, t):
+        return t
+
+    def all_gather_object(self, obj):
+        return [obj]
+
+    def exchange(self, sends, recvs):
+        assert not sends and not recvs
+
+    def barrier(self):
+        pass
+
+
+# ----------------------------------------------------------------------------- operator
+
+class DistCSR:
+    """Row block of a CSR matrix + its halo plan.  `A_local` is a device csr handle whose
+    column space is the extended vector."""
+
+    def __init__(self, A_local, plan, comm, backend):
+        self.A, self.plan, self.comm, self.be = A_local, plan, comm, backend
+        self.n_local = plan.n_owned
+        self.n_global = plan.n_global
+        self._send_idx = {}
+        self._send_buf = {}
+        for q, s in plan.send.items():
+            if not isinstance(s, tuple):
+                self._send_idx[q] = backend.index_tensor(s)
+                self._send_buf[q] = backend.zeros(len(s))
+
+    @classmethod
+    def poisson(cls, nx, ny, nz, comm, backend, make_local):
+        """make_local(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local) -> csr handle."""
+        plan = poisson_halo_plan(nx, ny, nz, comm.world, comm.rank)
+        A = make_local(nx, ny, nz, plan.row_lo, plan.row_hi, plan.row_lo - plan.ghost_lo, plan.n_ext)
+        return cls(A, plan, comm, backend)
+
+    def new_ext(self):
+        return self.be.zeros(self.plan.n_ext)
+
+    def owned(self, v_ext):
+        o = self.plan.p_offset
+        return v_ext[o:o + self.n_local]
+
+    def halo_exchange(self, v_ext):
+        """Fill the ghost entries of v_ext from the neighbours' owned entries."""
+        if self.comm.world == 1:
+            return
+        own = self.owned(v_ext)
+        sends, recvs = [], []
+        for q, s in sorted(self.plan.send.items()):
+            if isinstance(s, tuple):
+                sends.append((q, own[s[0]:s[1]]))
+            else:
+                self.be.gather(self._send_idx[q], own, self._send_buf[q])
+                sends.append((q, self._send_buf[q]))
+        for q, (a, b) in sorted(self.plan.recv.items()):
+            recvs.append((q, v_ext[a:b]))
+        self.comm.exchange(sends, recvs)
+
+    def matvec(self, v_ext, y):
+        """y = A v for the owned rows; v_ext's owned part must be current."""
+        self.halo_exchange(v_ext)
+        self.be.matvec(self.A, v_ext, y)
+
+
+def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
+    """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices.
+
+    Same control flow as Itsolvers_pcg_kernel (pcg.c:57-166) with K = None (dinv is None)
+    or K = jacobi(steps=1) given by its local dinv slice; every rank returns the same
+    triple.  x is updated in place."""
+    be, comm = A.be, A.comm
+    n = A.n_local
+    r, q = be.zeros(n), be.zeros(n)
+    p_ext = A.new_ext()
+    p = A.owned(p_ext)
+
+    s = comm.allreduce_sum(be.dot(b, b).clone()).tolist()
+    n2b = float(np.sqrt(s[0]))
+    if n2b == 0.0:  # pcg.c:58-67
+        x.zero_()
+        return 0, 0, 0.0
+    info = -1
+    tolb = tol * n2b
+    # r = b - A x (pcg.c:72-75); also rho = r.z for the first iteration
+    p.copy_(x)
+    A.matvec(p_ext, r)
+    s = comm.allreduce_sum(be.residual(b, r, dinv).clone()).tolist()
+    normr = float(np.sqrt(s[0]))
+    rho_next = s[1]
+    if hist is not None:
+        hist.append(normr)
+    if normr <= tolb:  # pcg.c:77-84
+        return 0, 0, normr / n2b
+    rho = 1.0
+    stag = 0
+    it = 1
+    while it <= maxit:
+        rho1, rho = rho, rho_next
+        if rho == 0.0:  # pcg.c:101-104
+            info = -2
+            break
+        if it == 1:
+            be.pupdate(r, dinv, 0.0, True, p)
+        else:
+            beta = rho / rho1
+            if beta == 0.0:  # pcg.c:109-112
+                info = -6
+                break
+            be.pupdate(r, dinv, beta, False, p)
+        A.halo_exchange(p_ext)
+        pq = comm.allreduce_sum(be.matvec_dot(A.A, p_ext, A.plan.p_offset, q).clone()).tolist()[0]  # all-reduce #1
+        if pq == 0.0:  # pcg.c:118-120
+            info = -6
+            break
+        alpha = rho / pq
+        if alpha == 0.0:
+            stag = 1
+        s = comm.allreduce_sum(be.xr_update(alpha, p, q, dinv, x, r).clone()).tolist()  # all-reduce #2
+        if stag == 0:
+            stag = 1 if s[2] == 0.0 else 0  # every rank's local 1 + dmax == 1
+        normr = float(np.sqrt(s[0]))
+        rho_next = s[1]
+        if hist is not None:
+            hist.append(normr)
+        if normr <= tolb:  # pcg.c:154-157
+            info = 0
+            break
+        if stag == 1:  # pcg.c:159-162
+            info = -5
+            break
+        it += 1
+    return info, it, normr / n2b

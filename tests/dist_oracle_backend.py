@@ -1,0 +1,68 @@
+"""CPU stand-in for pysparse_amd.distributed.HipBackend used ONLY by the gloo tests: the
+same method set on torch CPU tensors, arithmetic delegated to the oracle / numpy.  It lets
+world_size-2 tests drive the product's partition + halo + reduction logic without a GPU."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+class OracleBackend:
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+
+    def index_tensor(self, idx):
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32).copy())
+
+    def dot(self, x, y):
+        return torch.tensor([float(np.dot(x.numpy(), y.numpy()))], dtype=torch.float64)
+
+    def residual(self, b, r, dinv):
+        rn = r.numpy()
+        rn[:] = b.numpy() - rn
+        z = rn * dinv.numpy() if dinv is not None else rn
+        return torch.tensor([float(np.dot(rn, rn)), float(np.dot(rn, z))], dtype=torch.float64)
+
+    def pupdate(self, r, dinv, beta, first, p_owned):
+        z = r.numpy() * dinv.numpy() if dinv is not None else r.numpy()
+        pn = p_owned.numpy()
+        pn[:] = z if first else z + beta * pn
+
+    def matvec(self, A, p_ext, q):
+        A.matvec(np.ascontiguousarray(p_ext.numpy()), q.numpy())
+
+    def matvec_dot(self, A, p_ext, p_offset, q):
+        self.matvec(A, p_ext, q)
+        n = q.numel()
+        return torch.tensor([float(np.dot(p_ext.numpy()[p_offset:p_offset + n], q.numpy()))], dtype=torch.float64)
+
+    def xr_update(self, alpha, p, q, dinv, x, r):
+        pn, qn, xn, rn = p.numpy(), q.numpy(), x.numpy(), r.numpy()
+        dmax = 0.0
+        with np.errstate(all="ignore"):
+            nz = xn != 0.0
+            if nz.any():
+                dmax = float(np.nanmax(np.abs(alpha * pn[nz] / xn[nz]), initial=0.0))
+            if ((~nz) & (pn != 0.0)).any():
+                dmax = max(dmax, 1.0)
+        if alpha != 0.0:
+            xn += alpha * pn
+            rn += (-alpha) * qn
+        z = rn * dinv.numpy() if dinv is not None else rn
+        return torch.tensor([float(np.dot(rn, rn)), float(np.dot(rn, z)), 1.0 if 1.0 + dmax != 1.0 else 0.0],
+                            dtype=torch.float64)
+
+    def gather(self, idx, v, out):
+        out.numpy()[:] = v.numpy()[idx.numpy()]
+
+    def synchronize(self):
+        pass
+
+
+def local_poisson_from_oracle(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local):
+    A = O.poisson_csr(nx, ny, nz)
+    a, b = A.ind[row_lo], A.ind[row_hi]
+    return O.CSR((row_hi - row_lo, ncols_local), A.val[a:b], A.col[a:b] - col_shift, A.ind[row_lo:row_hi + 1] - a)

@@ -1,0 +1,139 @@
+"""world_size 2 and 3 gloo tests (CPU) of the row-partitioned SpMV / PCG driver
+(pysparse_amd/distributed.py): partition plan, halo exchange and the two all-reduces per
+iteration, with the vector arithmetic supplied by an oracle-backed stand-in."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import oracle as O
+        from pysparse_amd import distributed as D
+        from dist_oracle_backend import OracleBackend, local_poisson_from_oracle
+        be, comm = OracleBackend(), D.Comm()
+        out = {}
+        if case[0] == "poisson":
+            nx, ny, nz = case[1]
+            G = O.poisson_csr(nx, ny, nz)
+            A = D.DistCSR.poisson(nx, ny, nz, comm, be, local_poisson_from_oracle)
+        else:  # general CSR with irregular coupling across the partition
+            rng = np.random.default_rng(5)
+            n = 300
+            S = O.tendigit_sss(n)  # log-spaced bands: ghosts are scattered index sets
+            G = O.sss_to_csr(S)
+            lo, hi = D.row_range(n, world, rank)
+            a, b_ = G.ind[lo], G.ind[hi]
+            plan, col_local = D.general_halo_plan(n, lo, hi, G.col[a:b_], world, rank, comm.all_gather_object)
+            A_loc = O.CSR((hi - lo, plan.n_ext), G.val[a:b_], col_local, G.ind[lo:hi + 1] - a)
+            A = D.DistCSR(A_loc, plan, comm, be)
+        n = G.shape[0]
+        lo, hi = A.plan.row_lo, A.plan.row_hi
+        # ---- distributed SpMV == rows [lo, hi) of the global SpMV (bit-exact: same row order)
+        xg = np.random.default_rng(1).standard_normal(n)
+        yg = np.empty(n)
+        G.matvec(xg, yg)
+        v = A.new_ext()
+        A.owned(v).copy_(torch.from_numpy(xg[lo:hi].copy()))
+        y = be.zeros(hi - lo)
+        A.matvec(v, y)
+        out["spmv_ok"] = bool(np.array_equal(y.numpy(), yg[lo:hi]))
+        # ---- distributed PCG == oracle PCG on the global system
+        bg = np.empty(n)
+        G.matvec(np.ones(n), bg)
+        dinv_g = O.jacobi_dinv(G.diagonal())
+        res = {}
+        for name, dg in (("none", None), ("jacobi", dinv_g)):
+            xo = np.zeros(n)
+            ref = O.pcg(G, bg, xo, 1e-9, 500, dg)
+            x = be.zeros(hi - lo)
+            hist = []
+            got = D.dist_pcg(A, be.from_numpy(bg[lo:hi]), x, 1e-9, 500,
+                             be.from_numpy(dg[lo:hi]) if dg is not None else None, hist)
+            err = float(np.abs(x.numpy() - xo[lo:hi]).max() / np.abs(xo).max())
+            res[name] = (ref, got, err, len(hist))
+        out["pcg"] = res
+        # maxit exhausted -> iter = maxit + 1; zero rhs -> (0, 0, 0.0)
+        x = be.zeros(hi - lo)
+        out["maxit"] = D.dist_pcg(A, be.from_numpy(bg[lo:hi]), x, 1e-30, 3)
+        x = be.from_numpy(np.ones(hi - lo))
+        out["zero"] = D.dist_pcg(A, be.zeros(hi - lo), x, 1e-9, 10) + (float(x.abs().max()),)
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def _run(world, case):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    return results
+
+
+@pytest.mark.parametrize("world,case", [(2, ("poisson", (6, 5, 8))), (3, ("poisson", (5, 4, 7))),
+                                        (2, ("poisson", (16, 9, 0))), (2, ("general",)), (3, ("general",))])
+def test_row_partitioned_spmv_and_pcg(world, case):
+    results = _run(world, case)
+    assert len(results) == world
+    for rank, out in results.items():
+        assert "error" not in out, out.get("error")
+        assert out["spmv_ok"]
+        for name, (ref, got, err, nhist) in out["pcg"].items():
+            assert tuple(got[:2]) == tuple(ref[:2]), (name, ref, got)
+            # the recurred ||r|| at the exit iteration sits at the rounding floor of the recurrence
+            assert abs(got[2] - ref[2]) <= (1e-6 if case[0] == "poisson" else 0.1) * ref[2]
+            assert err < 1e-12
+            assert nhist == got[1] + 1
+        assert tuple(out["maxit"][:2]) == (-1, 4)
+        assert out["zero"] == (0, 0, 0.0, 0.0)
+    # every rank reports the same triple
+    r0 = results[0]["pcg"]["jacobi"][1]
+    assert all(results[r]["pcg"]["jacobi"][1] == r0 for r in results)
+
+
+def test_partition_helpers():
+    sys.path.insert(0, ROOT)
+    from pysparse_amd import distributed as D
+    n = 103
+    covered = []
+    for r in range(8):
+        lo, hi = D.row_range(n, 8, r)
+        covered.extend(range(lo, hi))
+    assert covered == list(range(n))
+    # 1024^3 over 8 ranks: 128 planes each, 2^27 rows, halo = one plane on each inner side
+    for r in range(8):
+        p = D.poisson_halo_plan(1024, 1024, 1024, 8, r)
+        assert p.n_owned == 2 ** 27 and p.n_global == 2 ** 30
+        assert p.ghost_lo == (0 if r == 0 else 2 ** 20) and p.ghost_hi == (0 if r == 7 else 2 ** 20)
+        assert sorted(p.recv) == sorted(p.send) == [q for q in (r - 1, r + 1) if 0 <= q < 8]
+    with pytest.raises(ValueError):
+        D.poisson_halo_plan(4, 4, 2, 4, 0)
