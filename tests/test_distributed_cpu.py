@@ -41,6 +41,7 @@ def _worker(rank, world, port, case, q):
             rng = np.random.default_rng(5)
             n = 300
             S = O.tendigit_sss(n)  # log-spaced bands: ghosts are scattered index sets
+            S.diag[:] = 40.0 + rng.random(n)  # diagonally dominant: rounding is not amplified
             G = O.sss_to_csr(S)
             lo, hi = D.row_range(n, world, rank)
             a, b_ = G.ind[lo], G.ind[hi]
