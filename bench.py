@@ -207,7 +207,9 @@ def main():
         K = dev.DeviceJacobi(A)
         aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
         bb = dev.DeviceBuffer(n_loc)
-        A.matvec_dev(dev.DeviceBuffer.from_host(np.ones(n_loc)).ptr, bb.ptr)
+        ones_b = dev.DeviceBuffer.from_host(np.ones(n_loc))  # must outlive the asynchronous launch
+        A.matvec_dev(ones_b.ptr, bb.ptr)
+        sync()
         pcg_t = []
         for k in (k1, k2):
             xb.zero()
