@@ -122,6 +122,12 @@ def main():
             raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
         a.gpus = world
 
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        # torch first: its bundled HIP runtime must be the one libpysparse_hip.so binds to --
+        # two HIP runtimes in one process do not both see the GPU
+        import torch
+        import torch.distributed as dist
     from pysparse_amd import _capi, device as dev
     L, check = _capi.lib(), _capi.check
 
@@ -133,10 +139,7 @@ def main():
         nx = ny = 1024
         nz = 128 * world
 
-    use_dist = world > 1 or a.force_dist
     if use_dist:
-        import torch
-        import torch.distributed as dist
         from pysparse_amd import distributed as D
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")

@@ -1,5 +1,9 @@
 """ctypes binding of libpysparse_hip.so (include/pysparse_hip.h).
 
+Process rule: when PyTorch is used in the same process, `import torch` BEFORE the first call
+of lib() -- the library then binds to the HIP runtime bundled with torch (same SONAME); the
+other order loads two HIP runtimes and the second one to initialise sees no device.
+
 Used by bench.py, the GPU tests and the multi-GPU driver; the drop-in extension modules
 (pysparse_amd.sparse.spmatrix, .itsolvers.krylov, .precon.precon) link the same library
 directly from C.  There is no CPU fallback: every compute call raises when no GPU is

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch (when present) must load its HIP runtime before libpysparse_hip.so does
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
