@@ -123,7 +123,7 @@ def main():
         a.gpus = world
 
     use_dist = world > 1 or a.force_dist
-    if use_dist:
+    if use_dist or os.environ.get("PSP_IMPORT_TORCH"):
         # torch first: its bundled HIP runtime must be the one libpysparse_hip.so binds to --
         # two HIP runtimes in one process do not both see the GPU
         import torch

@@ -358,9 +358,10 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave(
 //             touches about half as many cache lines
 template <int WT, int WPB, int LAYOUT, bool NT>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
-    int nchunks, int colmask, int stripe, const int2 *__restrict__ tab, const int *__restrict__ ind,
-    const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials) {
+    int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
+    const int *__restrict__ ind, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ dotv,
+    double *__restrict__ partials) {
   __shared__ double prod_all[WPB * WT];
   __shared__ double red[WPB];
   const int lane = threadIdx.x & 63;
@@ -380,12 +381,14 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
   const int chunk = vb * WPB + wid;
   double dsum = 0.0;
   if (chunk < nchunks) {
+    // The chunk's nonzeros lie in the window [kb, kb + WT) with kb = chunk*target known
+    // WITHOUT the chunk table, so the val/col stream is issued first and the table / row
+    // bounds (needed only by the reduce phase) load behind it: two dependent memory
+    // levels (val+col -> x gather) instead of three.
+    const int kb = chunk * target;
     const int2 c0 = tab[chunk];
     const int2 c1 = tab[chunk + 1];
-    const int r0 = c0.x, r1 = c1.x, s = c0.y, e = c1.y;
-    const int ts = s & ~3;
-    // row bounds of the first two passes, issued together with the stream loads
-    const int ra = r0 + lane, rb = ra + 64;
+    const int ra_base = c0.x, r1 = c1.x;
     int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
     if constexpr (LAYOUT == 0) {
       constexpr int STEPS = WT / 256;
@@ -393,12 +396,13 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
       d2v v0[STEPS], v1[STEPS];
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
-        int k = ts + (st * 64 + lane) * 4;
-        k = (k < e) ? k : ts;
+        int k = kb + (st * 64 + lane) * 4;
+        k = (k < kmax) ? k : kmax;  // the last window may run past the (padded) arrays
         c[st] = ldg<NT>(reinterpret_cast<const i4v *>(col + k));
         v0[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k));
         v1[st] = ldg<NT>(reinterpret_cast<const d2v *>(val + k + 2));
       }
+      const int ra = ra_base + lane, rb = ra + 64;
       if (ra < r1) { lo0 = ind[ra]; hi0 = ind[ra + 1]; }
       if (rb < r1) { lo1 = ind[rb]; hi1 = ind[rb + 1]; }
 #pragma unroll
@@ -418,11 +422,12 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
       double v[STEPS];
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
-        int k = ts + st * 64 + lane;
-        k = (k < e) ? k : ts;
+        int k = kb + st * 64 + lane;
+        k = (k < kmax + 3) ? k : kmax + 3;
         c[st] = ldg<NT>(col + k);
         v[st] = ldg<NT>(val + k);
       }
+      const int ra = ra_base + lane, rb = ra + 64;
       if (ra < r1) { lo0 = ind[ra]; hi0 = ind[ra + 1]; }
       if (rb < r1) { lo1 = ind[rb]; hi1 = ind[rb + 1]; }
       double xv[STEPS];
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
     __builtin_amdgcn_wave_barrier();
 
     int m = 0;
-    for (int r = ra; r < r1; r += 64, ++m) {
+    for (int r = ra_base + lane; r < r1; r += 64, ++m) {
       int lo, hi;
       if (m == 0) { lo = lo0; hi = hi0; }
       else if (m == 1) { lo = lo1; hi = hi1; }
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
         double t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          int idx = k + u - ts;
+          int idx = k + u - kb;
           idx = idx < WT ? idx : WT - 1;
           t[u] = prod[idx];
         }
@@ -670,6 +675,7 @@ int alloc_csr(int nrows, int ncols, long nnz, psp_csr **out) {
 // chunk tables are cached per (matrix, tile) in the handle
 struct ChunkTable {
   int tile = 0;
+  int target = 0;
   int nchunks = 0;
   int2 *tab = nullptr;
 };
@@ -712,11 +718,14 @@ static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out) {
   psp::CsrExtra &ex = g_extra[A];
   ChunkTable &t = ex.t[tile];
   if (t.tab == nullptr) {
-    int target = tile - 3 - A->max_row_nnz;
+    // chunk c holds the rows that START in nonzeros [c*target, (c+1)*target); with
+    // target <= tile - max_row it never needs more than `tile` nonzeros from c*target on
+    int target = (tile - A->max_row_nnz) & ~3;
     if (target < tile / 2) target = tile / 2;  // very long rows: chunks spill into more tiles
     long nch = ((long)A->nnz + target - 1) / target;
     if (nch < 1) nch = 1;
     t.tile = tile;
+    t.target = target;
     t.nchunks = (int)nch;
     PSP_HIP(hipMalloc((void **)&t.tab, sizeof(int2) * (nch + 1)));
     int grid = (int)((nch + 1 + 255) / 256);
@@ -790,7 +799,8 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     }
 #define PSP_W1(WT, WPB, LAY, NT)                                                                 \
   hipLaunchKernelGGL((csr_spmv_w1<WT, WPB, LAY, NT>), dim3(grid), dim3(64 * WPB), 0, stream(),    \
-                     t->nchunks, colmask(), stripe, t->tab, A->ind, A->col, A->val, x, y, dotv, pbuf)
+                     t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, A->ind,  \
+                     A->col, A->val, x, y, dotv, pbuf)
 #define PSP_W1_NT(WT, WPB, LAY) do { if (v.nt) PSP_W1(WT, WPB, LAY, true); else PSP_W1(WT, WPB, LAY, false); } while (0)
 #define PSP_W1_LAY(WT, WPB) do { if (v.layout) PSP_W1_NT(WT, WPB, 1); else PSP_W1_NT(WT, WPB, 0); } while (0)
 #define PSP_W1_WPB(WT) do { if (v.wpb == 4) PSP_W1_LAY(WT, 4); else if (v.wpb == 8) PSP_W1_LAY(WT, 8); else PSP_W1_LAY(WT, 16); } while (0)
