@@ -599,7 +599,7 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
-constexpr int kDefaultVariant = 128;  // csr_spmv_w1, tile 1024, layout 0, 4 waves per workgroup  // w1, tile 1024, layout 0, 8 waves per workgroup
+constexpr int kDefaultVariant = 128 + (32 << 8);  // csr_spmv_w1: tile 1024, layout 0, 4 waves per workgroup, XCD stripe 32
 
 struct Variant {
   int tile, vec;
@@ -812,7 +812,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     PSP_LAUNCH_CHECK();
     int np = grid;
     if (pbuf != partials) {
-      np = 1024;
+      np = kFold;
       hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 256), dim3(256), 0, stream(), pbuf, grid,
                          partials, np);
       PSP_LAUNCH_CHECK();
@@ -823,7 +823,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   if (v.wave) {
     // 4 waves per workgroup, one chunk per wave at a time; residency is VGPR-bound
     const int per_cu = v.tile == 512 ? 5 : 3;
-    int grid = std::min((t->nchunks + 3) / 4, std::min(w->num_cu * per_cu, kMaxParts));
+    int grid = std::min((t->nchunks + 3) / 4, std::min(w->num_cu * per_cu, 2048));
     if (v.full_grid && !partials) grid = (t->nchunks + 3) / 4;
     if (v.map_mode == 1) {
       grid = grid / 8 * 8;
@@ -842,7 +842,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   }
   // persistent grid: as many workgroups as stay resident (LDS: 32 KiB -> 5/CU, 16 KiB -> 8/CU)
   const int per_cu = v.tile == 4096 ? 5 : 8;
-  int grid = std::min(t->nchunks, std::min(w->num_cu * per_cu, kMaxParts));
+  int grid = std::min(t->nchunks, std::min(w->num_cu * per_cu, 2048));
   if (v.full_grid && !partials) grid = t->nchunks;
   if (v.map_mode == 1) {
     grid = grid / 8 * 8;

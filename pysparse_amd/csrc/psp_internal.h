@@ -32,14 +32,20 @@ int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usa
 
 #define PSP_LAUNCH_CHECK() PSP_HIP(hipGetLastError())
 
-// Reductions: every reducing kernel is launched with at most kMaxParts blocks; block b
-// leaves its partial sums in partials[slot*kMaxParts + b]; a one-block finishing kernel
-// adds them in index order.  Fixed grid + fixed order => bitwise reproducible results.
-constexpr int kMaxParts = 2048;
+// Reductions: every reducing kernel is launched with at most kMaxParts workgroups;
+// workgroup b leaves its partial sums in partials[slot*kMaxParts + b]; the finishing step
+// (a fixed-order fold to 1024 values when there are more, then one workgroup) adds them
+// in index order.  Fixed grid + fixed order => bitwise reproducible results, no atomics.
+constexpr int kMaxParts = 1 << 18;
 constexpr int kSlots = 4;
+constexpr int kFold = 1024;
+// streaming vector kernels: one workgroup per contiguous span of kVecSpan elements
+// (non-persistent grids measured faster than grid-stride loops on MI355X, profiles/)
+constexpr int kVecSpan = 1024;
 
 struct Workspace {
   double *partials = nullptr;   // kSlots * kMaxParts doubles (device)
+  double *folded = nullptr;     // kSlots * kFold doubles (device)
   double *scal_dev = nullptr;   // 16 doubles (device)
   double *scal_host = nullptr;  // 16 doubles (pinned host)
   int num_cu = 0;
@@ -47,13 +53,12 @@ struct Workspace {
 };
 int workspace(Workspace **out);
 
-// grid for streaming n-element vector kernels (256 threads, 2 doubles per lane per step)
-inline int vec_grid(const Workspace &w, long n) {
-  long want = (n + 511) / 512;
-  long cap = (long)w.num_cu * 8;
-  if (cap > kMaxParts) cap = kMaxParts;
+// grid for streaming n-element vector kernels: one workgroup per span (capped; the kernels
+// loop over spans beyond the cap)
+inline int vec_grid(const Workspace &, long n) {
+  long want = (n + kVecSpan - 1) / kVecSpan;
   if (want < 1) want = 1;
-  return (int)(want < cap ? want : cap);
+  return (int)(want < kMaxParts ? want : kMaxParts);
 }
 
 // finish: out_dev[j] = sum_b partials[j*kMaxParts + b], j < nvals, b < nparts

@@ -50,6 +50,7 @@ int workspace(Workspace **out) {
   if (g_ws.device != g_device) {
     if (g_ws.partials) {
       (void)hipFree(g_ws.partials);
+      (void)hipFree(g_ws.folded);
       (void)hipFree(g_ws.scal_dev);
       (void)hipHostFree(g_ws.scal_host);
       g_ws = Workspace();
@@ -58,6 +59,7 @@ int workspace(Workspace **out) {
     PSP_HIP(hipGetDeviceProperties(&prop, g_device));
     g_ws.num_cu = prop.multiProcessorCount;
     PSP_HIP(hipMalloc((void **)&g_ws.partials, sizeof(double) * kSlots * kMaxParts));
+    PSP_HIP(hipMalloc((void **)&g_ws.folded, sizeof(double) * kSlots * kFold));
     PSP_HIP(hipMalloc((void **)&g_ws.scal_dev, sizeof(double) * 16));
     PSP_HIP(hipHostMalloc((void **)&g_ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
     g_ws.device = g_device;
@@ -66,14 +68,24 @@ int workspace(Workspace **out) {
   return PSP_OK;
 }
 
-// one block: thread t adds partials t, t+256, ... in order, then a fixed tree
+// fold: out[j*kFold + t] = sum over b == t (mod kFold) of in[j*stride + b], ascending b
+__global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ in, int nparts,
+                                                   double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // < kFold
+  const int j = blockIdx.y;
+  double s = 0.0;
+  for (int b = t; b < nparts; b += kFold) s += in[(size_t)j * kMaxParts + b];
+  out[(size_t)j * kFold + t] = s;
+}
+
+// one block: thread t adds parts t, t+256, ... in order, then a fixed tree
 __global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ partials,
-                                                     int nparts, int nvals,
+                                                     int nparts, int nvals, int stride,
                                                      double *__restrict__ out) {
   __shared__ double sh[256];
   for (int j = 0; j < nvals; ++j) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * kMaxParts + b];
+    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * stride + b];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -86,8 +98,18 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ 
 }
 
 int finish_partials(const double *partials, int nparts, int nvals, double *out_dev) {
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), partials, nparts, nvals,
-                     out_dev);
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  if (nparts > 2 * kFold) {
+    hipLaunchKernelGGL(fold_kernel, dim3(kFold / 256, nvals), dim3(256), 0, stream(), partials,
+                       nparts, w->folded);
+    PSP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), w->folded, kFold, nvals,
+                       kFold, out_dev);
+  } else {
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), partials, nparts, nvals,
+                       kMaxParts, out_dev);
+  }
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

@@ -52,9 +52,12 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *part
   }
 }
 
-#define PSP_VEC_LOOP(i, n)                                                        \
-  for (long i = ((long)blockIdx.x * kBlock + threadIdx.x) * V; i < (n);           \
-       i += (long)gridDim.x * kBlock * V)
+// workgroup b streams the contiguous span [b*kVecSpan, (b+1)*kVecSpan) (and b + grid, ...):
+// kVecSpan / (256*V) independent 8*V-byte accesses per lane
+#define PSP_VEC_LOOP(i, n)                                                             \
+  for (long span_ = (long)blockIdx.x * kVecSpan; span_ < (n); span_ += (long)gridDim.x * kVecSpan) \
+    _Pragma("unroll") for (int u_ = 0; u_ < kVecSpan / (kBlock * V); ++u_)              \
+      for (long i = span_ + ((long)u_ * kBlock + threadIdx.x) * V; i < (n); i = (n))
 
 // ---- dot: pcg.c:100,117  minres.c:78,129,143
 template <int V>
