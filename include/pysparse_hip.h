@@ -71,6 +71,9 @@ int psp_free(void *dev);
 int psp_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int psp_memcpy_d2h(void *host, const void *dev, size_t bytes);
 int psp_memset(void *dev, int byte, size_t bytes);
+/* release the cached solver work vectors (the library keeps the last few GB-sized scratch
+ * vectors between solves because hipMalloc/hipFree of them costs milliseconds) */
+int psp_trim(void);
 int psp_event_create(void **event);
 int psp_event_destroy(void *event);
 int psp_event_record(void *event);                       /* on the library stream */
