@@ -1,0 +1,118 @@
+/*
+ * pysparse_amd.itsolvers.krylov -- info, iter, relres = pcg|minres(A, b, x, tol, maxit[, K])
+ *
+ * Python-3 counterpart of ItSolvers_pcg / ItSolvers_minres
+ * (pysparse/itsolvers/src/itsolversmodule.c:32-118, :217-305).  The loops themselves
+ * (pcg.c:22-171, minres.c:43-200) run device-resident in libpysparse_hip.so; this file only
+ * parses arguments the way the reference does, turns A and K into operators and builds the
+ * result tuple.  Native operands keep the whole solve on the GPU with the GIL released;
+ * duck-typed Python operators are called back once per application with the GIL held.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+
+#include <string.h>
+
+#include "psp_pyops.h"
+
+typedef int (*solver_fn)(const psp_op_t *, const psp_op_t *, int, double *, const double *, double,
+                         int, int *, int *, double *, double *);
+
+static PyObject *run_solver(PyObject *args, solver_fn fn, int check_positive_shape) {
+  PyObject *amat, *bo, *xo, *precon = Py_None;
+  PyArrayObject *b = NULL, *x = NULL;
+  double tol, relres = 0.0;
+  int maxit, info = 0, iter = 0, n = 0, nk = 0, rc;
+  PyOpRef aref, kref;
+  PyObject *result = NULL;
+  int have_a = 0, have_k = 0;
+
+  if (!PyArg_ParseTuple(args, "OOOdi|O", &amat, &bo, &xo, &tol, &maxit, &precon)) return NULL;
+
+  /* check shape of matrix object (itsolversmodule.c:65-67 / :245-250) */
+  if (pyop_acquire(amat, 0, &aref, &n)) return NULL;
+  have_a = 1;
+  if (check_positive_shape && n <= 0) {
+    PyErr_SetString(PyExc_ValueError, "invalid matrix shape");
+    goto done;
+  }
+
+  /* x and b as contiguous double arrays (itsolversmodule.c:70-82): x is solved in place only
+   * when it already is one; any other input is converted and the copy discarded */
+  x = (PyArrayObject *)PyArray_FROM_OTF(xo, NPY_DOUBLE, NPY_ARRAY_CARRAY);
+  if (x == NULL) {
+    PyErr_SetString(PyExc_ValueError, "Unable to convert x to double array");
+    goto done;
+  }
+  b = (PyArrayObject *)PyArray_FROM_OTF(bo, NPY_DOUBLE, NPY_ARRAY_IN_ARRAY);
+  if (b == NULL) {
+    PyErr_SetString(PyExc_ValueError, "Unable to convert b to double array");
+    goto done;
+  }
+  if (PyArray_NDIM(x) != 1 || PyArray_NDIM(b) != 1 || PyArray_DIM(x, 0) != PyArray_DIM(b, 0) ||
+      PyArray_DIM(x, 0) != n) {
+    PyErr_SetString(PyExc_ValueError, "incompatible operand shapes");
+    goto done;
+  }
+  if (precon != Py_None) {
+    if (pyop_acquire(precon, 1, &kref, &nk)) goto done;
+    have_k = 1;
+    if (nk != n) {
+      PyErr_SetString(PyExc_ValueError, "incompatible operand shapes");
+      goto done;
+    }
+  }
+
+  if (aref.is_callback || (have_k && kref.is_callback)) {
+    rc = fn(aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
+            (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres, NULL);
+  } else {
+    Py_BEGIN_ALLOW_THREADS
+    rc = fn(aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
+            (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres, NULL);
+    Py_END_ALLOW_THREADS
+  }
+  if (PyErr_Occurred()) goto done; /* a callback raised (itsolversmodule.c:114-115) */
+  if (rc != PSP_OK) {
+    PyErr_SetString(rc == PSP_ENOMEM ? PyExc_MemoryError
+                                     : (rc == PSP_EINVAL ? PyExc_ValueError : PyExc_RuntimeError),
+                    psp_last_error());
+    goto done;
+  }
+  result = Py_BuildValue("iid", info, iter, relres);
+done:
+  if (have_k) pyop_release(&kref);
+  if (have_a) pyop_release(&aref);
+  Py_XDECREF(x);
+  Py_XDECREF(b);
+  return result;
+}
+
+static PyObject *ItSolvers_pcg(PyObject *self, PyObject *args) { return run_solver(args, psp_pcg, 0); }
+
+static PyObject *ItSolvers_minres(PyObject *self, PyObject *args) {
+  return run_solver(args, psp_minres, 1);
+}
+
+static PyMethodDef krylov_methods[] = {
+    {"pcg", ItSolvers_pcg, METH_VARARGS,
+     "info, iter, relres = pcg(A, b, x, tol, maxit[, K])\n\nPreconditioned Conjugate Gradient method."},
+    {"minres", ItSolvers_minres, METH_VARARGS,
+     "info, iter, relres = minres(A, b, x, tol, maxit[, K])\n\nMinimal Residual method."},
+    {NULL, NULL, 0, NULL}};
+
+/* itsolversmodule.c:625-646 */
+static const char krylov_doc[] =
+    "Iterative solvers on MI355X.  info >= 0: converged; -1: maxit reached; -2: ill-conditioned\n"
+    "preconditioner; -3: preconditioner not SPD (minres); -5: stagnation; -6: breakdown.";
+
+static struct PyModuleDef krylov_module = {PyModuleDef_HEAD_INIT, "krylov", krylov_doc, -1,
+                                           krylov_methods, NULL, NULL, NULL, NULL};
+
+PyMODINIT_FUNC PyInit_krylov(void) {
+  import_array();
+  if (import_spmatrix() < 0) return NULL;
+  return PyModule_Create(&krylov_module);
+}

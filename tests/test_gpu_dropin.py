@@ -1,0 +1,245 @@
+"""GPU: the drop-in extension modules (pysparse.sparse.spmatrix, pysparse.itsolvers.krylov,
+pysparse.precon.precon) driven the way the reference's own scripts drive them."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_spmatrix_host import poisson2d, poisson2d_sym  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "ref_pcg.json")) as f:
+        return json.load(f), np.load(os.path.join(golden_dir, "ref_iterates.npz"))
+
+
+@pytest.fixture(scope="module")
+def L100():
+    return poisson2d(100)
+
+
+def test_demo_pcg_script_flow(golden, L100, tmp_path):
+    """examples/demo_pcg.py:47-98: A = ll_mat_from_mtx; b = A*e; pcg with None and jacobi(A, 1.0, 1)."""
+    from pysparse.sparse import spmatrix
+    from pysparse.itsolvers.krylov import pcg
+    from pysparse.precon import precon
+    cases, its = golden
+    # through a MatrixMarket file, like the script
+    Ls = poisson2d_sym(100)
+    sind, scol, sval, sdiag = Ls.to_sss_arrays()
+    p = tmp_path / "poi2d_100.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (10000, 10000, len(sval) + 10000))
+        for i in range(10000):
+            for k in range(sind[i], sind[i + 1]):
+                f.write("%d %d %.17g\n" % (i + 1, scol[k] + 1, sval[k]))
+            f.write("%d %d %.17g\n" % (i + 1, i + 1, sdiag[i]))
+    A = spmatrix.ll_mat_from_mtx(str(p))
+    (m, n) = A.shape
+    assert m == n == 10000 and A.nnz == 29800
+    e = np.ones(n, "d")
+    b = np.empty(n, "d")
+    A.matvec(e, b)
+    tol = 1.0e-6
+    x = np.zeros(n, "d")
+    info, it, relres = pcg(A, b, x, tol, 2 * n)
+    g = cases["G1_none"]
+    assert (info, it) == (g["info"], g["iter"]) == (0, 160)
+    assert abs(relres - g["relres"]) < 1e-9 * g["relres"]
+    assert abs(np.linalg.norm(x - e, ord=np.inf) - g["err_inf"]) < 1e-12
+    assert np.abs(x - its["G1_none"]).max() < 1e-12
+    x = np.zeros(n, "d")
+    M = precon.jacobi(A, 1.0, 1)
+    assert M.shape == (n, n)
+    info, it, relres = pcg(A, b, x, tol, 2 * n, M)
+    g = cases["G1_jacobi"]
+    assert (info, it) == (g["info"], g["iter"])
+    assert np.abs(x - its["G1_jacobi"]).max() < 1e-12
+
+
+def test_poisson_test_script_flow(golden, L100):
+    """examples/poisson_test.py:50-124 with x0 = 0: pcg on S = L.to_sss(), A = L.to_csr() and L itself."""
+    from pysparse.itsolvers.krylov import pcg
+    cases, its = golden
+    L = L100
+    A, S = L.to_csr(), L.to_sss()
+    n = 10000
+    assert L.nnz == 49600 and A.nnz == 49600 and S.nnz == 19800 + n  # sss reports lower + n
+    assert A.shape == S.shape == L.shape == (n, n)
+    b = np.ones(n, "d")
+    g = cases["G2"]
+    for M in (S, A, L):
+        x = np.zeros(n, "d")
+        info, it, relres = pcg(M, b, x, 1e-8, 2000)
+        assert (info, it) == (g["info"], g["iter"]) == (0, 187)
+        assert np.abs(x - its["G2"]).max() / np.abs(its["G2"]).max() < 1e-12
+        r = np.empty(n, "d")
+        M.matvec(x, r)
+        assert np.linalg.norm(b - r) <= 1.001e-8 * np.linalg.norm(b) * 1.1
+
+
+def test_types_attributes_and_matvec_bit_exact(oracle, L100):
+    from pysparse.sparse import spmatrix
+    L = L100
+    A, S = L.to_csr(), L.to_sss()
+    assert isinstance(A, spmatrix.CSRMatType) and isinstance(S, spmatrix.SSSMatType)
+    O = oracle.poisson_csr(100, 100)
+    ind, col, val = A.to_arrays()
+    assert np.array_equal(ind, O.ind) and np.array_equal(col, O.col) and np.array_equal(val, O.val)
+    x = np.random.default_rng(0).standard_normal(10000)
+    y_ref = np.empty(10000)
+    O.matvec(x, y_ref)
+    for M in (A, S, L, spmatrix.poisson_csr(100, 100), spmatrix.poisson_sss(100, 100),
+              spmatrix.csr_from_arrays(O.ind, O.col, O.val, (10000, 10000))):
+        y = np.full(10000, np.nan)
+        M.matvec(x, y)
+        assert np.array_equal(y, y_ref)
+        y2 = np.full(10000, np.nan)
+        M.matvec_transp(x, y2)  # symmetric operator
+        assert np.allclose(y2, y_ref, rtol=1e-12, atol=1e-12)
+    # strided NumPy views (spmatrix.h:38-54)
+    xb, yb = np.zeros(20000), np.zeros(30000)
+    xb[::2] = x
+    A.matvec(xb[::2], yb[::3])
+    assert np.array_equal(yb[::3], y_ref)
+    # sss_mat[i,j] (intended behaviour of sss_mat.c:14-28)
+    assert S[5, 5] == 4.0 and S[5, 4] == -1.0 and S[4, 5] == -1.0 and S[5, 7] == 0.0
+    with pytest.raises(IndexError, match="slices not supported"):
+        S[0:2, 1]
+    # modifying the ll_mat invalidates its device mirror
+    L2 = poisson2d(5)
+    y5 = np.empty(25)
+    L2.matvec(np.ones(25), y5)
+    L2[0, 0] = 10.0
+    y5b = np.empty(25)
+    L2.matvec(np.ones(25), y5b)
+    assert y5b[0] == y5[0] + 6.0 and np.array_equal(y5b[1:], y5[1:])
+
+
+def test_jacobi_object_and_python_operators(oracle, L100):
+    """precon.rst:15-24 protocol: any object with shape + precon(x, y); and
+    examples/fixme/pysparse_test.py:143-151 style diag_prec."""
+    from pysparse.itsolvers.krylov import pcg, minres
+    from pysparse.precon import precon
+    L = L100
+    A = L.to_csr()
+    n = 10000
+    O = oracle.poisson_csr(100, 100)
+    b = np.ones(n)
+    K = precon.jacobi(A, 0.9, 2)  # extension: jacobi on a csr_mat (diagonal read on the device)
+    x = np.random.default_rng(3).standard_normal(n)
+    y = np.empty(n)
+    K.precon(x, y)
+    dinv = oracle.jacobi_dinv(O.diagonal(), 0.9)
+    t = x * dinv
+    tmp = np.empty(n)
+    O.matvec(t, tmp)
+    assert np.array_equal(y, (x - tmp) * dinv + t)
+    with pytest.raises(ValueError, match="contiguous"):
+        K.precon(np.zeros(2 * n)[::2], y)
+
+    class diag_prec:
+        def __init__(self, A):
+            self.shape = A.shape
+            self.dinv = np.array([1.0 / A[i, i] for i in range(A.shape[0])])
+
+        def precon(self, x, y):
+            np.multiply(x, self.dinv, y)
+
+    xo = np.zeros(n)
+    ref = oracle.pcg(O, b, xo, 1e-9, 2000, oracle.jacobi_dinv(O.diagonal()))
+    for Kp in (diag_prec(L), precon.jacobi(L), precon.jacobi(A), precon.jacobi(L.to_sss())):
+        x = np.zeros(n)
+        got = pcg(A, b, x, 1e-9, 2000, Kp)
+        assert got[:2] == ref[:2]
+        assert np.abs(x - xo).max() / np.abs(xo).max() < 1e-12
+
+    class PyMat:
+        shape = (n, n)
+
+        def matvec(self, x, y):
+            O.matvec(np.ascontiguousarray(x), y)
+
+    x = np.zeros(n)
+    got = pcg(PyMat(), b, x, 1e-9, 2000, precon.jacobi(A))
+    assert got[:2] == ref[:2]
+
+    class Boom:
+        shape = (n, n)
+
+        def matvec(self, x, y):
+            raise ZeroDivisionError("boom")
+
+    with pytest.raises(ZeroDivisionError):
+        pcg(Boom(), b, np.zeros(n), 1e-9, 10)
+    # singular diagonal
+    Z = poisson2d(3)
+    Z[4, 4] = 1e-30
+    with pytest.raises(ValueError, match="close to zero"):
+        precon.jacobi(Z)
+    # minres through the module, SSS operator
+    xo = np.zeros(n)
+    refm = oracle.minres(O, b, xo, 1e-8, 2000)
+    x = np.zeros(n)
+    got = minres(L.to_sss(), b, x, 1e-8, 2000)
+    assert got[:2] == refm[:2] and np.abs(x - xo).max() / np.abs(xo).max() < 1e-12
+    # x given as a list: solved on a converted copy and discarded (itsolversmodule.c:70-76)
+    xi = [0.0] * n
+    info, it, rr = pcg(A, b, xi, 1e-6, 500)
+    assert info == 0 and xi == [0.0] * n
+
+
+def test_itsolver_wrappers(golden, L100):
+    from pysparse.itsolvers import Pcg, Minres
+    cases, its = golden
+    A = L100.to_csr()
+    n = 10000
+    s = Pcg(A)
+    x = np.full(n, 7.0)  # solve() zeroes the initial guess (itsolvers_util.py:41)
+    s.solve(np.ones(n), x, 1e-8, 2000)
+    assert (s.lastInfo, s.lastIterations, s.nofCalled) == (0, 187, 1)
+    assert np.abs(x - its["G2"]).max() / np.abs(its["G2"]).max() < 1e-12
+    with pytest.raises(RuntimeError):  # info < 0 raises (itsolvers_util.py:49-50)
+        s.solve(np.ones(n), x, 1e-30, 5)
+    assert s.totalIterations == 187 + 6
+    m = Minres(A)
+    m.solve(np.ones(n), x, 1e-8, 2000)
+    assert m.lastInfo == 0
+
+
+def test_tendigit_script_flow(golden_dir):
+    """examples/tendigit.py:26-49 with x0 = 0 and K = jacobi instead of ssor."""
+    from pysparse.sparse import spmatrix
+    from pysparse.itsolvers.krylov import minres
+    from pysparse.precon import precon
+    n = 2000  # the element-wise Python assembly loop of the script, at a size that stays quick
+    sieve = np.ones(20000, dtype=bool)
+    sieve[:2] = False
+    for p in range(2, 142):
+        if sieve[p]:
+            sieve[p * p::p] = False
+    primes = np.flatnonzero(sieve)[:n]
+    A = spmatrix.ll_mat_sym(n, n * 8)
+    d = 1
+    while d < n:
+        for i in range(d, n):
+            A[i, i - d] = 1.0
+        d *= 2
+    for i in range(n):
+        A[i, i] = 1.0 * primes[i]
+    S = A.to_sss()
+    K = precon.jacobi(S)
+    b = np.zeros(n)
+    b[0] = 1.0
+    x = np.zeros(n)
+    info, it, relres = minres(S, b, x, 1e-16, n, K)
+    assert info == 0
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    ind, col, val = A.to_csr_arrays()
+    xs = spla.spsolve(sp.csr_matrix((val, col, ind), shape=(n, n)).tocsc(), b)
+    assert abs(x[0] - xs[0]) < 1e-14 and np.abs(x - xs).max() < 1e-13

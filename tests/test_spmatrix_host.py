@@ -1,0 +1,241 @@
+"""CPU: host logic of the drop-in extension modules -- the ll_mat feeder (sorted insertion,
+conversions), argument checking and error behaviour -- against the oracle's restatement of
+ll_mat.c and the golden structure fixtures.  No compute call is made: anything that would
+need the GPU must fail loudly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pysparse.sparse import spmatrix
+from pysparse.itsolvers import krylov
+from pysparse.precon import precon
+
+
+def poisson2d(n):  # pysparse/tools/poisson.py:22-37
+    L = spmatrix.ll_mat(n * n, n * n, 5 * n * n - 4 * n)
+    for i in range(n):
+        for j in range(n):
+            k = i + n * j
+            L[k, k] = 4
+            if i > 0:
+                L[k, k - 1] = -1
+            if i < n - 1:
+                L[k, k + 1] = -1
+            if j > 0:
+                L[k, k - n] = -1
+            if j < n - 1:
+                L[k, k + n] = -1
+    return L
+
+
+def poisson2d_sym(n):  # pysparse/tools/poisson.py:39-50
+    L = spmatrix.ll_mat_sym(n * n, 3 * n * n - 2 * n)
+    for i in range(n):
+        for j in range(n):
+            k = i + n * j
+            L[k, k] = 4
+            if i > 0:
+                L[k, k - 1] = -1
+            if j > 0:
+                L[k, k - n] = -1
+    return L
+
+
+def test_module_surface():
+    for name in ("ll_mat", "ll_mat_sym", "ll_mat_from_mtx", "LLMatType", "CSRMatType", "SSSMatType", "error", "_C_API"):
+        assert hasattr(spmatrix, name)
+    assert callable(krylov.pcg) and callable(krylov.minres) and callable(precon.jacobi)
+    assert "pcg(A, b, x, tol, maxit" in krylov.pcg.__doc__
+
+
+def test_create_entries_negative_index():
+    # test/test_spmatrix.py:17-65
+    A = spmatrix.ll_mat(5, 7)
+    assert A.shape == (5, 7) and A.nnz == 0 and A.issym == 0
+    A[0, 0] = 1.5
+    A[4, 6] = -2
+    A[-1, -2] = 3.0
+    assert A[0, 0] == 1.5 and A[4, 6] == -2.0 and A[4, 5] == 3.0 and A[-1, -1] == -2.0
+    assert A[2, 3] == 0.0 and A.nnz == 3
+    A[0, 0] = 0  # assigning zero deletes the entry (ll_mat.c:336-352)
+    assert A.nnz == 2 and A[0, 0] == 0.0
+    Z = spmatrix.ll_mat(3, 3, 10, 1)  # storeZeros
+    Z[1, 1] = 0.0
+    assert Z.nnz == 1
+    for bad in ((5, 0), (0, 7), (-6, 0)):
+        with pytest.raises(IndexError):
+            A[bad] = 1.0
+        with pytest.raises(IndexError):
+            A[bad]
+    with pytest.raises(IndexError):
+        A[0:2, 0]
+    S = spmatrix.ll_mat_sym(4)
+    S[2, 1] = 5.0
+    assert S[1, 2] == 5.0 and S.issym == 1
+    with pytest.raises(IndexError, match="upper triangle"):
+        S[1, 2] = 1.0
+
+
+def test_poisson_structure_invariants(oracle, golden_dir):
+    # nnz formulas asserted by the reference's own tests: test/test_spmatrix.py:77-78
+    with open(os.path.join(golden_dir, "structure.json")) as f:
+        gold = json.load(f)
+    for n in (3, 4, 5, 6):
+        L, Ls = poisson2d(n), poisson2d_sym(n)
+        assert L.nnz == n * (5 * n - 4) and Ls.nnz == n * (3 * n - 2)
+        g = gold["poisson2d_%d" % n]
+        for M in (L, Ls):  # general == symmetric builder after expansion (:79-82)
+            ind, col, val = M.to_csr_arrays()
+            assert ind.tolist() == g["csr"]["ind"] and col.tolist() == g["csr"]["col"]
+            assert val.tolist() == g["csr"]["val"]
+            sind, scol, sval, sdiag = M.to_sss_arrays()
+            assert sind.tolist() == g["sss"]["ind"] and scol.tolist() == g["sss"]["col"]
+            assert sval.tolist() == g["sss"]["val"] and sdiag.tolist() == g["sss"]["diag"]
+        # ||A||_1 == ||A||_inf == 8 for n >= 3 (test/test_spmatrix.py:186-187)
+        ind, col, val = L.to_csr_arrays()
+        rows = np.repeat(np.arange(n * n), np.diff(ind))
+        assert np.bincount(col, weights=np.abs(val)).max() == 8.0
+        assert np.bincount(rows, weights=np.abs(val)).max() == 8.0
+    # direct generator of the oracle == element-wise ll_mat route
+    D = oracle.poisson_csr(6, 6)
+    ind, col, val = poisson2d(6).to_csr_arrays()
+    assert np.array_equal(ind, D.ind) and np.array_equal(col, D.col) and np.array_equal(val, D.val)
+
+
+def test_random_insertion_order_matches_oracle(oracle):
+    rng = np.random.default_rng(0)
+    for sym in (False, True):
+        n = 40
+        A = spmatrix.ll_mat_sym(n, 5) if sym else spmatrix.ll_mat(n, n, 5)
+        R = oracle.LL(n, n, 5, sym=sym)
+        for _ in range(1500):
+            i, j = int(rng.integers(n)), int(rng.integers(n))
+            if sym and i < j:
+                i, j = j, i
+            v = float(rng.choice([0.0, 1.0, -2.5, rng.standard_normal()]))
+            A[i, j] = v
+            R[i, j] = v
+        assert A.nnz == R.nnz
+        C = R.to_csr()
+        ind, col, val = A.to_csr_arrays()
+        assert np.array_equal(ind, C.ind) and np.array_equal(col, C.col) and np.array_equal(val, C.val)
+        S = R.to_sss()
+        sind, scol, sval, sdiag = A.to_sss_arrays()
+        assert np.array_equal(sind, S.ind) and np.array_equal(scol, S.col)
+        assert np.array_equal(sval, S.val) and np.array_equal(sdiag, S.diag)
+        for _ in range(50):
+            i, j = int(rng.integers(n)), int(rng.integers(n))
+            assert A[i, j] == R[i, j]
+
+
+def test_put_semantics():
+    # ll_mat.c:2482-2495: a.put(b, id1, id2): a[id1[i], id2[i]] = b[i]; scalar b broadcasts;
+    # id2 defaults to id1; symmetric matrices store into the lower triangle
+    A = spmatrix.ll_mat(6, 6)
+    A.put([1.0, 2.0, 3.0], [0, 1, 2], [3, 4, 5])
+    assert A[0, 3] == 1.0 and A[1, 4] == 2.0 and A[2, 5] == 3.0
+    A.put(7.0, np.arange(6))
+    assert all(A[i, i] == 7.0 for i in range(6))
+    A.put(np.array([9, 8]), np.array([5, 4]), np.array([0, 0]))
+    assert A[5, 0] == 9.0 and A[4, 0] == 8.0
+    S = spmatrix.ll_mat_sym(5)
+    S.put([1.5, 2.5], [0, 3], [4, 1])
+    assert S[4, 0] == 1.5 and S[0, 4] == 1.5 and S[3, 1] == 2.5
+    with pytest.raises(IndexError):
+        A.put([1.0], [6], [0])
+    A.update_add_at([1.0, 1.0], [0, 0], [0, 0])
+    assert A[0, 0] == 9.0
+
+
+def test_from_mtx(tmp_path):
+    p = tmp_path / "m.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% comment\n3 3 4\n1 1 2.0\n2 1 -1\n3 3 5e0\n3 2 0.25\n")
+    A = spmatrix.ll_mat_from_mtx(str(p))
+    assert A.issym == 1 and A.shape == (3, 3) and A.nnz == 4
+    assert A[0, 1] == -1.0 and A[2, 1] == 0.25
+    ind, col, val = A.to_csr_arrays()  # symmetric storage expands to the full matrix
+    assert ind.tolist() == [0, 2, 4, 6] and col.tolist() == [0, 1, 0, 2, 1, 2]
+    g = tmp_path / "g.mtx"
+    g.write_text("%%MatrixMarket matrix coordinate real general\n2 3 2\n1 3 1.0\n2 1 2.0\n")
+    B = spmatrix.ll_mat_from_mtx(str(g))
+    assert B.issym == 0 and B.shape == (2, 3) and B[0, 2] == 1.0
+    bad = tmp_path / "b.mtx"
+    bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(spmatrix.error):
+        spmatrix.ll_mat_from_mtx(str(bad))
+    with pytest.raises(IOError):
+        spmatrix.ll_mat_from_mtx(str(tmp_path / "missing.mtx"))
+    oob = tmp_path / "o.mtx"
+    oob.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(IndexError):
+        spmatrix.ll_mat_from_mtx(str(oob))
+
+
+def test_vector_argument_checks_and_loud_failure_without_gpu():
+    A = poisson2d(3)
+    x, y = np.zeros(9), np.zeros(9)
+    with pytest.raises(ValueError, match="arg 1 must be a 1-dimensional double array"):
+        A.matvec(np.zeros(8), y)
+    with pytest.raises(ValueError, match="arg 2 must be a 1-dimensional double array"):
+        A.matvec(x, np.zeros(9, dtype=np.float32))
+    with pytest.raises(TypeError):
+        A.matvec([0.0] * 9, y)
+    if spmatrix.device_count() == 0:
+        # no CPU fallback anywhere on the product path
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            A.matvec(x, y)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            A.to_csr()
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            A.to_sss()
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            spmatrix.poisson_csr(4, 4)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            krylov.pcg(A, np.ones(9), x, 1e-8, 10)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            precon.jacobi(A)
+
+
+def test_solver_argument_errors():
+    class NotSquare:
+        shape = (3, 4)
+
+    class NoShape:
+        pass
+
+    class BadShape:
+        shape = (3,)
+
+    b = np.ones(3)
+    with pytest.raises(ValueError, match="not square"):
+        krylov.pcg(NotSquare(), b, b.copy(), 1e-8, 10)
+    with pytest.raises(AttributeError):
+        krylov.pcg(NoShape(), b, b.copy(), 1e-8, 10)
+    with pytest.raises(ValueError, match="invalid matrix shape"):
+        krylov.minres(BadShape(), b, b.copy(), 1e-8, 10)
+    with pytest.raises(TypeError):
+        krylov.pcg(NotSquare(), b, b.copy(), 1e-8)  # maxit missing
+
+
+def test_c_api_capsule_slots():
+    import ctypes
+    cap = spmatrix._C_API
+    ctypes.pythonapi.PyCapsule_GetName.restype = ctypes.c_char_p
+    ctypes.pythonapi.PyCapsule_GetName.argtypes = [ctypes.py_object]
+    assert ctypes.pythonapi.PyCapsule_GetName(cap) == b"pysparse_amd.sparse.spmatrix._C_API"
+    ctypes.pythonapi.PyCapsule_GetPointer.restype = ctypes.c_void_p
+    ctypes.pythonapi.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+    table = ctypes.cast(ctypes.pythonapi.PyCapsule_GetPointer(cap, b"pysparse_amd.sparse.spmatrix._C_API"),
+                        ctypes.POINTER(ctypes.c_void_p * 16)).contents
+    assert all(table[i] for i in range(16))  # 16 slots as in spmatrix_api.h:10-72
+    assert table[0] == id(spmatrix.LLMatType) and table[1] == id(spmatrix.CSRMatType)
+    assert table[2] == id(spmatrix.SSSMatType)
+
+
+def test_itsolver_wrappers_exist():
+    from pysparse.itsolvers import Pcg, Minres, ItSolver
+    with pytest.raises(NotImplementedError):
+        ItSolver(None).solve(np.ones(2), np.ones(2), 1e-8, 5)
+    assert Pcg(None).name == "pcg" and Minres(None).name == "minres"
