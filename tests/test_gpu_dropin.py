@@ -33,7 +33,7 @@ def test_demo_pcg_script_flow(golden, L100, tmp_path):
     sind, scol, sval, sdiag = Ls.to_sss_arrays()
     p = tmp_path / "poi2d_100.mtx"
     with open(p, "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (10000, 10000, len(sval) + 10000))
+        f.write("%%%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (10000, 10000, len(sval) + 10000))
         for i in range(10000):
             for k in range(sind[i], sind[i + 1]):
                 f.write("%d %d %.17g\n" % (i + 1, scol[k] + 1, sval[k]))
