@@ -475,6 +475,132 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
   }
 }
 
+// ------------------------------------------------------------------ w2: no dependent loads
+//
+// csr_spmv_w1 still reads `ind` for its row bounds, and that address depends on the chunk
+// table: tab -> ind is a chain of two memory latencies that the reduce phase has to wait
+// for (in-kernel stamps: ~12.6 k cycles from wave start to "everything landed" against
+// ~4.6 k for the val/col stream alone, profiles/).  w2 replaces `ind` by a per-chunk table
+// of 16-bit row offsets relative to the chunk's window, stored at a FIXED stride
+// (rowoff[chunk*E + i] = ind[r0+i] - chunk*target, padded with the chunk's end offset), so
+// every load of a wave -- val, col, row offsets, table entry -- is issued at wave start
+// and the only dependent level left is col -> x.  HBM traffic: 2*E bytes per chunk (384 B
+// for the 7-point operator, ~2.6 B/row) instead of 4 B/row of `ind`.
+template <int NP>
+__global__ __launch_bounds__(256) void build_rowoff_kernel(int nchunks, int target,
+                                                           const int2 *__restrict__ tab,
+                                                           const int *__restrict__ ind,
+                                                           unsigned short *__restrict__ rowoff) {
+  constexpr int E = 64 * NP;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunk = (int)(gid / E), i = (int)(gid % E);
+  if (chunk >= nchunks) return;
+  const int r0 = tab[chunk].x, r1 = tab[chunk + 1].x;
+  const int r = r0 + i < r1 ? r0 + i : r1;
+  rowoff[gid] = (unsigned short)(ind[r] - chunk * target);
+}
+
+__global__ void max_chunk_rows_kernel(int nchunks, const int2 *__restrict__ tab, int *__restrict__ out) {
+  int m = 0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x)
+    m = max(m, tab[c + 1].x - tab[c].x);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+template <int WT, int NP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
+    int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
+    const unsigned short *__restrict__ rowoff, const int *__restrict__ col,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials) {
+  constexpr int STEPS = WT / 256;
+  constexpr int E = 64 * NP;
+  __shared__ double prod_all[WPB * WT];
+  __shared__ double red[WPB];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *prod = prod_all + wid * WT;
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int chunk = vb * WPB + wid;
+  double dsum = 0.0;
+  if (chunk < nchunks) {
+    const int kb = chunk * target;
+    // --- every load of this wave, none depends on another
+    i4v c[STEPS];
+    d2v v0[STEPS], v1[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      int k = kb + (st * 64 + lane) * 4;
+      k = (k < kmax) ? k : kmax;
+      c[st] = *reinterpret_cast<const i4v *>(col + k);
+      v0[st] = *reinterpret_cast<const d2v *>(val + k);
+      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
+    }
+    const unsigned short *ro = rowoff + (size_t)chunk * E;
+    int lo[NP], hi[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      lo[m] = ro[i];
+      hi[m] = ro[i + 1 < E ? i + 1 : E - 1];
+    }
+    const int r0 = tab[chunk].x;
+    const int nr = tab[chunk + 1].x - r0;
+    // --- x gathers (the one dependent level), products into the wave's LDS slice
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int off = (st * 64 + lane) * 4;
+      d2v p0, p1;
+      p0.x = v0[st].x * x[c[st].x & colmask];
+      p0.y = v0[st].y * x[c[st].y & colmask];
+      p1.x = v1[st].x * x[c[st].z & colmask];
+      p1.y = v1[st].y * x[c[st].w & colmask];
+      *reinterpret_cast<d2v *>(&prod[off]) = p0;
+      *reinterpret_cast<d2v *>(&prod[off + 2]) = p1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- one lane per row, products added left to right (reference order, csr_mat.c:49-54)
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      if (i < nr) {
+        double acc = 0.0;
+        for (int k = lo[m]; k < hi[m]; k += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int idx = k + u;
+            idx = idx < WT ? idx : WT - 1;
+            t[u] = prod[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
+        }
+        y[r0 + i] = acc;
+        if (dotv) dsum += dotv[r0 + i] * acc;
+      }
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < WPB; ++i) t += red[i];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
 // first-level fold of per-workgroup dot partials when the grid is larger than the
 // workspace slots: out[b] = in[b] + in[b+nout] + ... (fixed order)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
@@ -607,7 +733,7 @@ struct Variant {
   int map_mode;
   bool wave;
   bool full_grid;
-  bool w1;
+  bool w1, w2;
   int layout, wpb;
   int stripe;
 };
@@ -637,6 +763,8 @@ Variant decode_variant(int v) {
   // per lane per load, 1: one); bit 2: tile 512 instead of 1024; bits 4-5: waves per
   // workgroup 4 / 8 / 16; bit 3: non-temporal loads
   r.w1 = (v & 128) != 0;
+  // bit 1 (with bit 7): csr_spmv_w2, row offsets from the fixed-stride table instead of ind
+  r.w2 = r.w1 && (v & 2) != 0;
   r.layout = v & 1;
   r.wpb = 4 << ((v >> 4) & 3);
   if (r.wpb > 16) r.wpb = 16;
@@ -678,6 +806,10 @@ struct ChunkTable {
   int target = 0;
   int nchunks = 0;
   int2 *tab = nullptr;
+  // csr_spmv_w2: 16-bit row offsets at a fixed stride of 64*np entries per chunk
+  int max_rows = -1;  // most rows in one chunk (-1: not computed yet)
+  int np = 0;         // passes of 64 rows (0: chunk too tall for w2)
+  unsigned short *rowoff = nullptr;
 };
 static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
 
@@ -737,6 +869,41 @@ static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out) {
   return PSP_OK;
 }
 
+// row-offset table of csr_spmv_w2 (built on first use)
+static int ensure_rowoff(const psp_csr *A, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (t->max_rows >= 0) return PSP_OK;
+  int *d_max;
+  PSP_HIP(hipMalloc((void **)&d_max, sizeof(int)));
+  PSP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), stream()));
+  hipLaunchKernelGGL(max_chunk_rows_kernel, dim3(std::min((t->nchunks + 255) / 256, 2048)), dim3(256),
+                     0, stream(), t->nchunks, t->tab, d_max);
+  PSP_LAUNCH_CHECK();
+  int mr = 0;
+  PSP_HIP(hipMemcpyAsync(&mr, d_max, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_max));
+  t->max_rows = mr;
+  const int np = (mr + 1 + 63) / 64;  // + 1: the end offset of the last row
+  if (np > 4) {
+    t->np = 0;  // many short/empty rows: stay with the ind-based kernel
+    return PSP_OK;
+  }
+  const int npp = np < 2 ? 2 : np;
+  const size_t entries = (size_t)t->nchunks * 64 * npp;
+  PSP_HIP(hipMalloc((void **)&t->rowoff, sizeof(unsigned short) * entries));
+  const int grid = (int)((entries + 255) / 256);
+  if (npp == 2)
+    hipLaunchKernelGGL(build_rowoff_kernel<2>, dim3(grid), dim3(256), 0, stream(), t->nchunks, t->target, t->tab, A->ind, t->rowoff);
+  else if (npp == 3)
+    hipLaunchKernelGGL(build_rowoff_kernel<3>, dim3(grid), dim3(256), 0, stream(), t->nchunks, t->target, t->tab, A->ind, t->rowoff);
+  else
+    hipLaunchKernelGGL(build_rowoff_kernel<4>, dim3(grid), dim3(256), 0, stream(), t->nchunks, t->target, t->tab, A->ind, t->rowoff);
+  PSP_LAUNCH_CHECK();
+  t->np = npp;
+  return PSP_OK;
+}
+
 namespace psp {
 
 // tuning aid: PSP_SPMV_COLMASK=<int> ANDs every gathered column index (wrong results, used
@@ -771,7 +938,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
   if ((v.wave || v.w1) && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
-    v.wave = v.w1 = false;
+    v.wave = v.w1 = v.w2 = false;
     v.tile = 2048;
     v.vec = 4;
     v.map_mode = 0;
@@ -797,6 +964,23 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       }
       pbuf = ex->big_partials;
     }
+    if (v.w2) {
+      PSP_TRY(ensure_rowoff(A, t));
+      if (t->np == 0) v.w2 = false;
+    }
+    if (v.w2) {
+      if (v.wpb > 8) v.wpb = 8;
+#define PSP_W2(WT, NP, WPB)                                                                       \
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, WPB>), dim3(grid), dim3(64 * WPB), 0, stream(), t->nchunks, \
+                     colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, A->col,  \
+                     A->val, x, y, dotv, pbuf)
+#define PSP_W2_WPB(WT, NP) do { if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
+#define PSP_W2_NP(WT) do { if (t->np == 2) PSP_W2_WPB(WT, 2); else if (t->np == 3) PSP_W2_WPB(WT, 3); else PSP_W2_WPB(WT, 4); } while (0)
+      if (v.tile == 512) PSP_W2_NP(512); else PSP_W2_NP(1024);
+#undef PSP_W2_NP
+#undef PSP_W2_WPB
+#undef PSP_W2
+    } else {
 #define PSP_W1(WT, WPB, LAY, NT)                                                                 \
   hipLaunchKernelGGL((csr_spmv_w1<WT, WPB, LAY, NT>), dim3(grid), dim3(64 * WPB), 0, stream(),    \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, A->ind,  \
@@ -809,6 +993,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
 #undef PSP_W1_LAY
 #undef PSP_W1_NT
 #undef PSP_W1
+    }
     PSP_LAUNCH_CHECK();
     int np = grid;
     if (pbuf != partials) {
@@ -984,8 +1169,10 @@ int psp_csr_destroy(psp_csr_t *A) {
     std::lock_guard<std::mutex> lk(g_extra_mu);
     auto it = g_extra.find(A);
     if (it != g_extra.end()) {
-      for (auto &t : it->second.t)
+      for (auto &t : it->second.t) {
         if (t.second.tab) (void)hipFree(t.second.tab);
+        if (t.second.rowoff) (void)hipFree(t.second.rowoff);
+      }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
       g_extra.erase(it);
     }
