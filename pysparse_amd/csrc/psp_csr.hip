@@ -725,7 +725,7 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
-constexpr int kDefaultVariant = 128 + (32 << 8);  // csr_spmv_w1: tile 1024, layout 0, 4 waves per workgroup, XCD stripe 32
+constexpr int kDefaultVariant = 128 + 2 + 4 + (32 << 8);  // csr_spmv_w2: tile 512, 4 waves per workgroup, XCD stripe 32
 
 struct Variant {
   int tile, vec;
