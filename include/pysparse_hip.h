@@ -218,6 +218,13 @@ int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double bet
  * the first p_offset.. rows' worth are the owned ones: out = sum p[p_offset+i]*q[i] */
 int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
                          double *out_dev);
+/* y := A x split around a halo exchange: rows [row_a, row_b) reference no ghost entry of x
+ * and are multiplied first; wait(ctx) must return once the ghost entries have arrived (in
+ * stream order); the remaining rows follow.  dot_out_dev != NULL additionally leaves
+ * sum x[x_offset+i]*y[i] there (the fused p.q of pcg.c:116-117). */
+typedef int (*psp_wait_fn)(void *ctx);
+int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, double *y_dev,
+                             int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev);
 /* stagnation scan + x += alpha p, r -= alpha q (pcg.c:127-143) and
  * out = { r.r, r.z (z = dinv.*r), nonstag } where nonstag != 0 iff 1 + dmax != 1 */
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,

@@ -31,8 +31,10 @@ psp_jacobi_shape psp_jacobi_precon psp_jacobi_precon_dev
 psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_callback psp_op_destroy
 psp_pcg psp_pcg_dev psp_minres psp_minres_dev
 psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
+psp_k_csr_matvec_overlap
 """.split()
 
+WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
@@ -108,6 +110,7 @@ def _declare(L):
         "psp_k_dot": [i, vp, vp, vp], "psp_k_residual": [i, vp, vp, vp, vp],
         "psp_k_pupdate": [i, vp, vp, d, i, vp], "psp_k_csr_matvec_dot": [vp, vp, i, vp, vp],
         "psp_k_xr_update": [i, d, vp, vp, vp, vp, vp, vp], "psp_k_gather": [i, vp, vp, vp],
+        "psp_k_csr_matvec_overlap": [vp, vp, i, vp, i, i, WAIT_FN, vp, vp],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

@@ -511,7 +511,7 @@ __global__ void max_chunk_rows_kernel(int nchunks, const int2 *__restrict__ tab,
 
 template <int WT, int NP, int WPB>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
-    int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
+    int chunk0, int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
     const unsigned short *__restrict__ rowoff, const int *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     const int k = vb >> 3;
     vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
   }
-  const int chunk = vb * WPB + wid;
+  const int chunk = chunk0 + vb * WPB + wid;  // chunks [chunk0, nchunks) belong to this launch
   double dsum = 0.0;
   if (chunk < nchunks) {
     const int kb = chunk * target;
@@ -815,8 +815,13 @@ static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
 
 namespace psp {
 
+struct SplitInfo {
+  int tile, ca, cb;
+};
+
 struct CsrExtra {
   std::map<int, ChunkTable> t;
+  std::map<std::pair<int, int>, SplitInfo> split;  // (row_a, row_b) -> interior chunk range
   double *big_partials = nullptr;  // one slot per workgroup of the full-grid SpMV
   int big_cap = 0;
 };
@@ -971,9 +976,9 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     if (v.w2) {
       if (v.wpb > 8) v.wpb = 8;
 #define PSP_W2(WT, NP, WPB)                                                                       \
-  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, WPB>), dim3(grid), dim3(64 * WPB), 0, stream(), t->nchunks, \
-                     colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, A->col,  \
-                     A->val, x, y, dotv, pbuf)
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, WPB>), dim3(grid), dim3(64 * WPB), 0, stream(), 0,      \
+                     t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
+                     A->col, A->val, x, y, dotv, pbuf)
 #define PSP_W2_WPB(WT, NP) do { if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
 #define PSP_W2_NP(WT) do { if (t->np == 2) PSP_W2_WPB(WT, 2); else if (t->np == 3) PSP_W2_WPB(WT, 3); else PSP_W2_WPB(WT, 4); } while (0)
       if (v.tile == 512) PSP_W2_NP(512); else PSP_W2_NP(1024);
@@ -1048,6 +1053,124 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
 #undef PSP_CASE
   PSP_LAUNCH_CHECK();
   if (nparts) *nparts = grid;
+  return PSP_OK;
+}
+
+// ---- SpMV split around a halo exchange (multi-GPU): the chunks whose rows lie inside
+// [row_a, row_b) touch no ghost entry and are launched first; wait() blocks until the ghost
+// entries of x have arrived (on the library's stream); then the remaining chunks run.  Every
+// row is computed exactly once; dot partials of the three launches go to consecutive slots.
+static int chunk_lower_bound(const ChunkTable *t, int row, int *out) {
+  // first chunk c with tab[c].x >= row (binary search over the device table, a few 8-byte reads)
+  int lo = 0, hi = t->nchunks;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    int2 e;
+    PSP_HIP(hipMemcpy(&e, t->tab + mid, sizeof(int2), hipMemcpyDeviceToHost));
+    if (e.x >= row)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  *out = lo;
+  return PSP_OK;
+}
+
+template <int WT, int NP>
+static void launch_w2_range(const psp_csr *A, const ChunkTable *t, int stripe, int c0, int c1,
+                            const double *x, double *y, const double *dotv, double *pbuf, int *grid_out) {
+  int grid = (c1 - c0 + 3) / 4;
+  if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
+  *grid_out = grid;
+  if (c1 <= c0) {
+    *grid_out = 0;
+    return;
+  }
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4>), dim3(grid), dim3(256), 0, stream(), c0, c1, colmask(),
+                     stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, A->col, A->val, x, y,
+                     dotv, pbuf);
+}
+
+int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
+                     double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
+                     void *ctx) {
+  Variant v = decode_variant(A->variant);
+  ChunkTable *t = nullptr;
+  bool ok = v.w2 && A->max_row_nnz <= v.tile / 2 && row_a < row_b;
+  if (ok) {
+    PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
+    PSP_TRY(ensure_rowoff(A, t));
+    ok = t->np != 0;
+  }
+  if (!ok) {  // no split possible with this kernel variant: exchange first, then everything
+    if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+    return csr_spmv_launch(A, x, y, dotv, partials, nparts);
+  }
+  // interior chunk range [ca, cb): all rows >= row_a and < row_b
+  psp::CsrExtra *ex;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    ex = &g_extra[A];
+  }
+  int ca, cb;
+  auto key = std::make_pair(row_a, row_b);
+  auto it = ex->split.find(key);
+  if (it != ex->split.end() && it->second.tile == v.tile) {
+    ca = it->second.ca;
+    cb = it->second.cb;
+  } else {
+    PSP_TRY(chunk_lower_bound(t, row_a, &ca));
+    PSP_TRY(chunk_lower_bound(t, row_b, &cb));  // first chunk starting at/after row_b ...
+    // ... the chunk before it may straddle row_b: it is interior only if it ends at row_b
+    if (cb > 0) {
+      int2 e;
+      PSP_HIP(hipMemcpy(&e, t->tab + cb, sizeof(int2), hipMemcpyDeviceToHost));
+      if (e.x > row_b) cb -= 1;
+    }
+    if (cb < ca) cb = ca;
+    ex->split[key] = {v.tile, ca, cb};
+  }
+  const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+  const int per = 8 * (stripe > 0 ? stripe : 1) + 4;
+  const long cap_needed = (long)(t->nchunks + 3) / 4 + 3L * per;
+  double *pbuf = nullptr;
+  if (partials) {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    if (ex->big_cap < cap_needed) {
+      if (ex->big_partials) (void)hipFree(ex->big_partials);
+      ex->big_partials = nullptr;
+      ex->big_cap = 0;
+      PSP_HIP(hipMalloc((void **)&ex->big_partials, sizeof(double) * (size_t)cap_needed));
+      ex->big_cap = (int)cap_needed;
+    }
+    pbuf = ex->big_partials;
+  }
+  int g1 = 0, g2 = 0, g3 = 0;
+#define PSP_RANGE(C0, C1, OFF, G)                                                              \
+  do {                                                                                         \
+    if (v.tile == 512) {                                                                       \
+      if (t->np == 2) launch_w2_range<512, 2>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else if (t->np == 3) launch_w2_range<512, 3>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else launch_w2_range<512, 4>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+    } else {                                                                                   \
+      if (t->np == 2) launch_w2_range<1024, 2>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else if (t->np == 3) launch_w2_range<1024, 3>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else launch_w2_range<1024, 4>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+    }                                                                                          \
+    PSP_LAUNCH_CHECK();                                                                        \
+  } while (0)
+  PSP_RANGE(ca, cb, 0, g1);
+  if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+  PSP_RANGE(0, ca, g1, g2);
+  PSP_RANGE(cb, t->nchunks, g1 + g2, g3);
+#undef PSP_RANGE
+  if (partials) {
+    const int total = g1 + g2 + g3;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 256), dim3(256), 0, stream(), pbuf, total,
+                       partials, kFold);
+    PSP_LAUNCH_CHECK();
+    if (nparts) *nparts = kFold;
+  }
   return PSP_OK;
 }
 

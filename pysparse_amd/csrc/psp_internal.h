@@ -124,5 +124,8 @@ inline psp_csr *op_native_csr(const psp_op *op) {
 }
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
                     double *partials, int *nparts);
+int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
+                     double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
+                     void *ctx);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
 }  // namespace psp

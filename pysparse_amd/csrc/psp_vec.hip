@@ -543,6 +543,25 @@ int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double
   return finish_partials(w->partials, np, 1, out_dev);
 }
 
+int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, double *y_dev,
+                             int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
+  if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: NULL");
+  if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
+    return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: row range / offset out of bounds");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np = 0;
+  if (A->nrows == 0) {
+    if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+    if (dot_out_dev) PSP_HIP(hipMemsetAsync(dot_out_dev, 0, sizeof(double), stream()));
+    return PSP_OK;
+  }
+  PSP_TRY(csr_spmv_overlap(A, x_dev, y_dev, dot_out_dev ? x_dev + x_offset : nullptr,
+                           dot_out_dev ? w->partials : nullptr, &np, row_a, row_b, wait, ctx));
+  if (dot_out_dev) return finish_partials(w->partials, np, 1, dot_out_dev);
+  return PSP_OK;
+}
+
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,
                     const double *dinv_dev, double *x_dev, double *r_dev, double *out_dev) {
   Workspace *w;

@@ -54,6 +54,9 @@ class HaloPlan:
         self.n_ext = ghost_lo + n_owned + ghost_hi
         self.recv = {}  # rank -> (start, stop) in the extended vector
         self.send = {}  # rank -> (start, stop) in OWNED coordinates, or an index tensor
+        # owned rows [interior[0], interior[1]) reference no ghost entry: they can be
+        # multiplied while the halo exchange is still in flight
+        self.interior = (0, n_owned)
 
 
 def poisson_halo_plan(nx, ny, nz, world, rank):
@@ -77,13 +80,15 @@ def poisson_halo_plan(nx, ny, nz, world, rank):
     if g_hi:
         plan.recv[rank + 1] = (g_lo + plan.n_owned, plan.n_ext)
         plan.send[rank + 1] = (plan.n_owned - reach, plan.n_owned)
+    plan.interior = (reach if g_lo else 0, plan.n_owned - reach if g_hi else plan.n_owned)
     return plan
 
 
-def general_halo_plan(n_global, row_lo, row_hi, col_global, world, rank, all_gather_object):
+def general_halo_plan(n_global, row_lo, row_hi, col_global, world, rank, all_gather_object, ind=None):
     """Partition of an arbitrary CSR row block (host arrays, small/medium problems): the
     ghost set is the sorted set of referenced off-rank columns; send lists are exchanged
-    once at setup.  Returns (plan, col_local)."""
+    once at setup.  `ind` (local row pointers) lets the plan find the ghost-free row range
+    used to overlap the exchange with the SpMV.  Returns (plan, col_local)."""
     col_global = np.asarray(col_global, dtype=np.int64)
     needed = np.unique(col_global)
     g_lo_ids = needed[needed < row_lo]
@@ -103,6 +108,17 @@ def general_halo_plan(n_global, row_lo, row_hi, col_global, world, rank, all_gat
             wanted[q] = ids
             start = int(np.searchsorted(ext_ids, ids[0]))
             plan.recv[q] = (start, start + len(ids))
+    # widest run of rows whose columns are all owned (overlaps the exchange with the SpMV)
+    if ind is not None and len(col_global):
+        ind_local = np.asarray(ind, dtype=np.int64)
+        is_ghost = ((col_global < row_lo) | (col_global >= row_hi)).astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(is_ghost)])
+        touches = csum[ind_local[1:]] - csum[ind_local[:-1]]
+        bad = np.flatnonzero(touches > 0)
+        if len(bad):
+            edges = np.concatenate([[-1], bad, [row_hi - row_lo]])
+            k = int(np.argmax(np.diff(edges)))
+            plan.interior = (int(edges[k] + 1), int(edges[k + 1]))
     everyone = all_gather_object(wanted)
     for q, w in enumerate(everyone):
         if q != rank and rank in w:
@@ -161,6 +177,28 @@ class HipBackend:
     def matvec(self, A, p_ext, q):
         self._capi.check(self.L.psp_csr_matvec_dev(A._h, self._p(p_ext), self._p(q)))
 
+    def matvec_overlap(self, A, p_ext, p_offset, q, interior, wait, want_dot):
+        """q = A p with the rows of `interior` launched before wait() (the halo exchange)
+        returns; optionally the fused p.q."""
+        out = self._scal[:1] if want_dot else None
+        err = []
+
+        def _wait(ctx):
+            try:
+                wait()
+                return 0
+            except BaseException as e:  # noqa: BLE001 - re-raised below
+                err.append(e)
+                return 1
+
+        cb = self._capi.WAIT_FN(_wait)
+        rc = self.L.psp_k_csr_matvec_overlap(A._h, self._p(p_ext), int(p_offset), self._p(q), int(interior[0]),
+                                             int(interior[1]), cb, None, self._p(out) if want_dot else None)
+        if err:
+            raise err[0]
+        self._capi.check(rc)
+        return out
+
     def xr_update(self, alpha, p_owned, q, dinv, x, r):
         out = self._scal[:3]
         self._capi.check(self.L.psp_k_xr_update(x.numel(), float(alpha), self._p(p_owned), self._p(q),
@@ -202,6 +240,19 @@ class Comm:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
+    def exchange_start(self, sends, recvs):
+        """Post the grouped send/recv batch; returns wait() that completes it (stream order)."""
+        if not sends and not recvs:
+            return lambda: None
+        ops = [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
+        ops += [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
+        works = dist.batch_isend_irecv(ops)
+
+        def wait():
+            for w in works:
+                w.wait()
+        return wait
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)
@@ -219,6 +270,10 @@ class SingleComm:
 
     def exchange(self, sends, recvs):
         assert not sends and not recvs
+
+    def exchange_start(self, sends, recvs):
+        assert not sends and not recvs
+        return lambda: None
 
     def barrier(self):
         pass
@@ -255,10 +310,7 @@ class DistCSR:
         o = self.plan.p_offset
         return v_ext[o:o + self.n_local]
 
-    def halo_exchange(self, v_ext):
-        """Fill the ghost entries of v_ext from the neighbours' owned entries."""
-        if self.comm.world == 1:
-            return
+    def _halo_ops(self, v_ext):
         own = self.owned(v_ext)
         sends, recvs = [], []
         for q, s in sorted(self.plan.send.items()):
@@ -269,12 +321,27 @@ class DistCSR:
                 sends.append((q, self._send_buf[q]))
         for q, (a, b) in sorted(self.plan.recv.items()):
             recvs.append((q, v_ext[a:b]))
+        return sends, recvs
+
+    def halo_exchange(self, v_ext):
+        """Fill the ghost entries of v_ext from the neighbours' owned entries."""
+        if self.comm.world == 1:
+            return
+        sends, recvs = self._halo_ops(v_ext)
         self.comm.exchange(sends, recvs)
 
-    def matvec(self, v_ext, y):
-        """y = A v for the owned rows; v_ext's owned part must be current."""
-        self.halo_exchange(v_ext)
-        self.be.matvec(self.A, v_ext, y)
+    def matvec(self, v_ext, y, want_dot=False):
+        """y = A v for the owned rows; v_ext's owned part must be current.  The ghost
+        exchange is started first and overlapped with the rows that need no ghost entry.
+        want_dot: also return the device scalar sum v_owned[i]*y[i]."""
+        if self.comm.world == 1:
+            if want_dot:
+                return self.be.matvec_dot(self.A, v_ext, self.plan.p_offset, y)
+            self.be.matvec(self.A, v_ext, y)
+            return None
+        sends, recvs = self._halo_ops(v_ext)
+        wait = self.comm.exchange_start(sends, recvs)
+        return self.be.matvec_overlap(self.A, v_ext, self.plan.p_offset, y, self.plan.interior, wait, want_dot)
 
 
 def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
@@ -322,8 +389,7 @@ def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
                 info = -6
                 break
             be.pupdate(r, dinv, beta, False, p)
-        A.halo_exchange(p_ext)
-        pq = comm.allreduce_sum(be.matvec_dot(A.A, p_ext, A.plan.p_offset, q).clone()).tolist()[0]  # all-reduce #1
+        pq = comm.allreduce_sum(A.matvec(p_ext, q, want_dot=True).clone()).tolist()[0]  # all-reduce #1
         if pq == 0.0:  # pcg.c:118-120
             info = -6
             break

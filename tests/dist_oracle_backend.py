@@ -39,6 +39,20 @@ class OracleBackend:
         n = q.numel()
         return torch.tensor([float(np.dot(p_ext.numpy()[p_offset:p_offset + n], q.numpy()))], dtype=torch.float64)
 
+    def matvec_overlap(self, A, p_ext, p_offset, q, interior, wait, want_dot):
+        # rows of `interior` must not depend on ghost entries: multiply them BEFORE the
+        # exchange completes and check that the result survives unchanged afterwards
+        n = q.numel()
+        before = q.numpy().copy()
+        A.matvec(np.ascontiguousarray(p_ext.numpy()), before)
+        wait()
+        self.matvec(A, p_ext, q)
+        lo, hi = interior
+        assert np.array_equal(before[lo:hi], q.numpy()[lo:hi]), "interior rows touched ghost entries"
+        if want_dot:
+            return torch.tensor([float(np.dot(p_ext.numpy()[p_offset:p_offset + n], q.numpy()))], dtype=torch.float64)
+        return None
+
     def xr_update(self, alpha, p, q, dinv, x, r):
         pn, qn, xn, rn = p.numpy(), q.numpy(), x.numpy(), r.numpy()
         dmax = 0.0

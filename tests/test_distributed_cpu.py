@@ -45,7 +45,8 @@ def _worker(rank, world, port, case, q):
             G = O.sss_to_csr(S)
             lo, hi = D.row_range(n, world, rank)
             a, b_ = G.ind[lo], G.ind[hi]
-            plan, col_local = D.general_halo_plan(n, lo, hi, G.col[a:b_], world, rank, comm.all_gather_object)
+            plan, col_local = D.general_halo_plan(n, lo, hi, G.col[a:b_], world, rank, comm.all_gather_object,
+                                                     ind=G.ind[lo:hi + 1] - a)
             A_loc = O.CSR((hi - lo, plan.n_ext), G.val[a:b_], col_local, G.ind[lo:hi + 1] - a)
             A = D.DistCSR(A_loc, plan, comm, be)
         n = G.shape[0]

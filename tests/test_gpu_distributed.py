@@ -77,6 +77,22 @@ def _worker(rank, world, port, q):
                 for (p, t), (_, h) in zip(recvs, hr):
                     t.copy_(h)
 
+            def exchange_start(self, sends, recvs):
+                # start the host-staged transfer now, finish it inside wait(): the interior
+                # SpMV launch sits between the two, like with the RCCL transport
+                torch.cuda.synchronize()
+                hs = [(p, t.cpu()) for p, t in sends]
+                hr = [(p, torch.empty(t.shape, dtype=t.dtype)) for p, t in recvs]
+                ops = [dist.P2POp(dist.irecv, t, p) for p, t in hr] + [dist.P2POp(dist.isend, t, p) for p, t in hs]
+                works = dist.batch_isend_irecv(ops) if ops else []
+
+                def wait():
+                    for w in works:
+                        w.wait()
+                    for (p, t), (_, h) in zip(recvs, hr):
+                        t.copy_(h)
+                return wait
+
         be = D.HipBackend(0)
         comm = HostStagedComm()
         nx, ny, nz = 48, 40, 24
