@@ -509,7 +509,7 @@ __global__ void max_chunk_rows_kernel(int nchunks, const int2 *__restrict__ tab,
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-template <int WT, int NP, int WPB>
+template <int WT, int NP, int WPB, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     int chunk0, int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
     const unsigned short *__restrict__ rowoff, const int *__restrict__ col,
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     for (int st = 0; st < STEPS; ++st) {
       int k = kb + (st * 64 + lane) * 4;
       k = (k < kmax) ? k : kmax;
-      c[st] = *reinterpret_cast<const i4v *>(col + k);
-      v0[st] = *reinterpret_cast<const d2v *>(val + k);
-      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
+      c[st] = ldg<NTL>(reinterpret_cast<const i4v *>(col + k));
+      v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k));
+      v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k + 2));
     }
     const unsigned short *ro = rowoff + (size_t)chunk * E;
     int lo[NP], hi[NP];
@@ -583,7 +583,10 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
         }
-        y[r0 + i] = acc;
+        if constexpr (NTS)
+          __builtin_nontemporal_store(acc, &y[r0 + i]);
+        else
+          y[r0 + i] = acc;
         if (dotv) dsum += dotv[r0 + i] * acc;
       }
     }
@@ -725,7 +728,8 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
-constexpr int kDefaultVariant = 128 + 2 + 4 + (32 << 8);  // csr_spmv_w2: tile 512, 4 waves per workgroup, XCD stripe 32
+// csr_spmv_w2: tile 1024, 4 waves per workgroup, non-temporal y stores, XCD stripe 32
+constexpr int kDefaultVariant = 128 + 2 + 64 + (32 << 8);
 
 struct Variant {
   int tile, vec;
@@ -763,7 +767,8 @@ Variant decode_variant(int v) {
   // per lane per load, 1: one); bit 2: tile 512 instead of 1024; bits 4-5: waves per
   // workgroup 4 / 8 / 16; bit 3: non-temporal loads
   r.w1 = (v & 128) != 0;
-  // bit 1 (with bit 7): csr_spmv_w2, row offsets from the fixed-stride table instead of ind
+  // bit 1 (with bit 7): csr_spmv_w2, row offsets from the fixed-stride table instead of ind;
+  // for w2, bit 6 = non-temporal stores of y (+1..2 %), bit 3 = non-temporal val/col loads (-13 %)
   r.w2 = r.w1 && (v & 2) != 0;
   r.layout = v & 1;
   r.wpb = 4 << ((v >> 4) & 3);
@@ -979,11 +984,21 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, WPB>), dim3(grid), dim3(64 * WPB), 0, stream(), 0,      \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
                      A->col, A->val, x, y, dotv, pbuf)
-#define PSP_W2_WPB(WT, NP) do { if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
+#define PSP_W2_NT(WT, NP)                                                                          \
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, true, false>), dim3(grid), dim3(256), 0, stream(), 0,  \
+                     t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
+                     A->col, A->val, x, y, dotv, pbuf)
+#define PSP_W2_NS(WT, NP)                                                                          \
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, false, true>), dim3(grid), dim3(256), 0, stream(), 0,  \
+                     t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
+                     A->col, A->val, x, y, dotv, pbuf)
+#define PSP_W2_WPB(WT, NP) do { if (v.nt) PSP_W2_NT(WT, NP); else if (v.full_grid) PSP_W2_NS(WT, NP); else if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
 #define PSP_W2_NP(WT) do { if (t->np == 2) PSP_W2_WPB(WT, 2); else if (t->np == 3) PSP_W2_WPB(WT, 3); else PSP_W2_WPB(WT, 4); } while (0)
       if (v.tile == 512) PSP_W2_NP(512); else PSP_W2_NP(1024);
 #undef PSP_W2_NP
 #undef PSP_W2_WPB
+#undef PSP_W2_NT
+#undef PSP_W2_NS
 #undef PSP_W2
     } else {
 #define PSP_W1(WT, WPB, LAY, NT)                                                                 \
