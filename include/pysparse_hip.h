@@ -200,6 +200,20 @@ int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
                    const double *b_dev, double tol, int maxit, int *info, int *iter,
                    double *relres, double *hist_host);
 
+/* The four other Krylov kernels of the reference's `krylov` module on the same operator
+ * protocol, unfused: cgs (pysparse/itsolvers/src/cgs.c:14-110,
+ * wrapper itsolversmodule.c:503-586), bicgstab (bicgstab.c:233-320, :125-216), qmrs
+ * (qmrs.c:29-154, :410-496; the initial guess is ignored), gmres(dim)
+ * (gmres.c:62-175, :313-403; *relres is the true residual reduction). */
+int psp_cgs(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+            double tol, int maxit, int *info, int *iter, double *relres);
+int psp_bicgstab(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+                 double tol, int maxit, int *info, int *iter, double *relres);
+int psp_qmrs(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+             double tol, int maxit, int *info, int *iter, double *relres);
+int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+              double tol, int maxit, int dim, int *info, int *iter, double *relres);
+
 /* ------------------------------------------ solver phase kernels (device pointers)
  * The building blocks of the loops above, exported so that the row-partitioned
  * multi-GPU driver (pysparse_amd/distributed.py) can interleave them with RCCL

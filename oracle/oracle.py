@@ -81,6 +81,9 @@ def _declare(L):
     L.orc_minres_sss.restype = C.c_int
     L.orc_minres_sss.argtypes = [C.c_int, _dp, _dp, _ip, _ip, C.c_void_p, C.c_int, _dp, _dp, C.c_double,
                                  C.c_int, ipt, dpt, C.c_void_p]
+    L.orc_krylov_more.restype = C.c_int
+    L.orc_krylov_more.argtypes = [C.c_int, C.c_int, _dp, C.c_void_p, _ip, _ip, C.c_void_p, _dp, _dp, C.c_double,
+                                  C.c_int, C.c_int, ipt, dpt]
     # ll_mat feeder restatement
     L.orc_ll_new.restype = C.c_void_p
     L.orc_ll_new.argtypes = [C.c_int] * 5
@@ -326,6 +329,18 @@ def minres(A, b, x, tol, maxit, dinv=None, steps=1, hist=False):
         info = L.orc_minres_sss(n, A.val, A.diag, A.col, A.ind, _opt(dinv), steps, x, b, tol, maxit,
                                 C.byref(it), C.byref(rr), _opt(h))
     return (info, it.value, rr.value, h) if hist else (info, it.value, rr.value)
+
+
+_MORE = {"cgs": 0, "bicgstab": 1, "qmrs": 2, "gmres": 3}
+
+
+def krylov_more(solver, A, b, x, tol, maxit, dinv=None, dim=20):
+    """cgs / bicgstab / qmrs / gmres restatements (parity UNPINNED, see pysparse_oracle.c)."""
+    n = A.shape[0]
+    it, rr = C.c_int(0), C.c_double(0.0)
+    info = lib().orc_krylov_more(_MORE[solver], n, A.val, _opt(A.diag) if isinstance(A, SSS) else None, A.col, A.ind,
+                                 _opt(dinv), x, b, tol, maxit, dim, C.byref(it), C.byref(rr))
+    return info, it.value, rr.value
 
 
 # ----------------------------------------------------------------------------- compiled reference

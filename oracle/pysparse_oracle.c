@@ -805,6 +805,331 @@ ORC_API long orc_poisson_sss(int nx, int ny, int nz, double *val, double *diag, 
   return r;
 }
 
+/* ============================================================================
+ * The four other Krylov kernels of pysparse/itsolvers.
+ *
+ * Parity status of THIS block: UNPINNED.  The reference ships no compilable copy of
+ * these kernels (bicgstab.c, cgs.c, qmrs.c, gmres.c need the Python-2 C API) and no
+ * golden vectors for them; the functions below restate the published loops line by
+ * line and are checked only against each other, against PCG on SPD systems and
+ * against direct solves (tests/test_oracle_krylov_more.py).
+ * ==========================================================================*/
+
+ORC_API void orc_dscal(int n, double a, double *x) {
+  int i;
+  for (i = 0; i < n; i++)
+    x[i] = a * x[i];
+}
+
+/* pysparse/itsolvers/src/cgs.c:14-110.  work = 8n.  Returns info (0 / -1; -100 callback). */
+ORC_API int orc_cgs(int n, const double *b, double *x, int maxit, double tol, double *work,
+                    int *iter, double *res, orc_matvec_fn matvec, void *mctx,
+                    orc_precon_fn precon, void *pctx) {
+  double *r0 = work, *r = work + n, *p = work + 2 * (long)n, *q = work + 3 * (long)n,
+         *u = work + 4 * (long)n, *v = work + 5 * (long)n, *tmp = work + 6 * (long)n,
+         *tmp2 = work + 7 * (long)n;
+  double alpha, beta, rho, rho_new, tol_sq = tol * tol, bnrm_sq, ddummy;
+  *iter = 0;
+  if (matvec(mctx, n, x, tmp)) return -100;
+  orc_dcopy(n, b, r0);
+  orc_daxpy(n, -1.0, tmp, r0);
+  orc_dcopy(n, r0, r);
+  orc_dcopy(n, r0, u);
+  orc_dcopy(n, r0, p);
+  rho = orc_ddot(n, r0, r0);
+  bnrm_sq = orc_ddot(n, b, b);
+  if (rho < bnrm_sq * tol_sq) {
+    *res = sqrt(rho / bnrm_sq);
+    return 0;
+  }
+  for (; *iter < maxit; (*iter)++) {
+    if (precon) {
+      if (precon(pctx, n, p, tmp)) return -100;
+      if (matvec(mctx, n, tmp, v)) return -100;
+    } else if (matvec(mctx, n, p, v))
+      return -100;
+    alpha = rho / orc_ddot(n, v, r0);
+    ddummy = -alpha;
+    orc_dcopy(n, u, q);
+    orc_daxpy(n, ddummy, v, q);
+    orc_dcopy(n, u, tmp);
+    orc_daxpy(n, 1.0, q, tmp);
+    if (precon) {
+      if (precon(pctx, n, tmp, tmp2)) return -100;
+    } else
+      orc_dcopy(n, tmp, tmp2);
+    orc_daxpy(n, alpha, tmp2, x);
+    if (matvec(mctx, n, tmp2, tmp)) return -100;
+    orc_daxpy(n, ddummy, tmp, r);
+    *res = orc_ddot(n, r, r);
+    if (*res < bnrm_sq * tol_sq) {
+      *res = sqrt(*res / bnrm_sq);
+      return 0;
+    }
+    rho_new = orc_ddot(n, r, r0);
+    beta = rho_new / rho;
+    rho = rho_new;
+    orc_dcopy(n, r, u);
+    orc_daxpy(n, beta, q, u);
+    orc_dcopy(n, q, tmp);
+    orc_daxpy(n, beta, p, tmp);
+    orc_dcopy(n, u, p);
+    orc_daxpy(n, beta, tmp, p);
+  }
+  *res = sqrt(*res / bnrm_sq);
+  return -1;
+}
+
+/* pysparse/itsolvers/src/bicgstab.c:233-320 (Itsolvers_bicgstab_kernel).  work = 8n.
+ * *info starts at -6 and keeps it on the early returns (rho == 0, omega == 0), where the
+ * module ignores the kernel's return value (itsolversmodule.c:185-196). */
+ORC_API int orc_bicgstab(int n, double *x, const double *b, double tol, int maxit, int *iter,
+                         double *relres, int *info, double *work, orc_matvec_fn matvec,
+                         void *mctx, orc_precon_fn precon, void *pctx) {
+  double *r = work, *rhat = work + n, *p = work + 2 * (long)n, *phat = work + 3 * (long)n,
+         *v = work + 4 * (long)n, *s = work + 5 * (long)n, *shat = work + 6 * (long)n,
+         *t = work + 7 * (long)n;
+  double alpha = 0.0, omega = 0.0, rho_im1, rho_im2 = 0.0, beta = 0.0, res, res0, n2b;
+  int i;
+  *info = -6;
+  n2b = orc_dnrm2(n, b);
+  if (n2b == 0.0) {
+    for (i = 0; i < n; i++) x[i] = 0.0;
+    *info = 0;
+    *relres = 0.0;
+    *iter = 0;
+    return 0;
+  }
+  if (matvec(mctx, n, x, r)) return -100;
+  for (i = 0; i < n; i++) r[i] = b[i] + -r[i];
+  res0 = orc_dnrm2(n, r);
+  orc_dcopy(n, r, rhat);
+  *iter = 0;
+  do {
+    (*iter)++;
+    rho_im1 = orc_ddot(n, rhat, r);
+    if (rho_im1 == 0.0) return -1;
+    if (*iter == 1) {
+      orc_dcopy(n, r, p);
+    } else {
+      beta = (rho_im1 / rho_im2) * (alpha / omega);
+      for (i = 0; i < n; i++) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+    }
+    if (precon) {
+      if (precon(pctx, n, p, phat)) return -100;
+    } else
+      orc_dcopy(n, p, phat);
+    if (matvec(mctx, n, phat, v)) return -100;
+    alpha = rho_im1 / orc_ddot(n, rhat, v);
+    for (i = 0; i < n; i++) s[i] = r[i] + (-alpha) * v[i];
+    if (precon) {
+      if (precon(pctx, n, s, shat)) return -100;
+    } else
+      orc_dcopy(n, s, shat);
+    if (matvec(mctx, n, shat, t)) return -100;
+    omega = orc_ddot(n, t, s) / orc_ddot(n, t, t);
+    for (i = 0; i < n; i++) x[i] = x[i] + alpha * phat[i] + omega * shat[i];
+    for (i = 0; i < n; i++) r[i] = s[i] - omega * t[i];
+    res = orc_dnrm2(n, r);
+    if (omega == 0.0) return -1;
+    rho_im2 = rho_im1;
+  } while ((res / res0 > tol) && (*iter < maxit));
+  *relres = res / res0;
+  *info = (*relres >= tol) ? -1 : 0;
+  return 0;
+}
+
+/* pysparse/itsolvers/src/qmrs.c:29-154.  work = 6n.  The initial guess is ignored (x := 0).
+ * Returns info (0, -1, -2, -6; -100 callback). */
+ORC_API int orc_qmrs(int n, const double *b, double *x, double *work, double tol, int maxit,
+                     int *iter, double *err, orc_matvec_fn matvec, void *mctx,
+                     orc_precon_fn precon, void *pctx) {
+  double *wrk1 = work, *p = work + n, *d = work + 2 * (long)n, *v1 = work + 3 * (long)n,
+         *t = work + 4 * (long)n, *g = work + 5 * (long)n;
+  double beta, res_init, delta, theta, c0, c1, theta0, cc, xi1, rho1inv, tau, eta0, eps0, rho0,
+      rho1, d1;
+  int i;
+  orc_dcopy(n, b, v1);
+  rho0 = orc_dnrm2(n, v1);
+  tau = rho0;
+  for (i = 0; i < n; ++i) {
+    v1[i] /= rho0;
+    p[i] = 0.0;
+    g[i] = 0.0;
+    d[i] = 0.0;
+    x[i] = 0.0;
+  }
+  c0 = 1.0;
+  eps0 = 1.0;
+  xi1 = 1.0;
+  theta0 = 0.0;
+  eta0 = -1.0;
+  res_init = rho0;
+  *err = 1.0;
+  *iter = 0;
+  while (*err > tol && *iter < maxit) {
+    ++(*iter);
+    if (eps0 == 0.0) return -6;
+    if (precon) {
+      if (precon(pctx, n, v1, wrk1)) return -100;
+    } else
+      orc_dcopy(n, v1, wrk1);
+    delta = orc_ddot(n, wrk1, v1);
+    if (delta == 0.0) return -2;
+    cc = xi1 * (delta / eps0);
+    for (i = 0; i < n; ++i) {
+      p[i] = v1[i] - p[i] * cc;
+      g[i] = wrk1[i] - g[i] * cc;
+    }
+    if (matvec(mctx, n, g, t)) return -100;
+    eps0 = orc_ddot(n, g, t);
+    beta = eps0 / delta;
+    for (i = 0; i < n; ++i) v1[i] = t[i] - v1[i] * beta;
+    rho1 = orc_dnrm2(n, v1);
+    xi1 = rho1;
+    if (c0 * fabs(beta) == 0.0) return -6;
+    theta = rho1 / (c0 * fabs(beta));
+    c1 = 1.0 / sqrt(theta * theta + 1.0);
+    if (beta * (c0 * c0) == 0.0) return -6;
+    eta0 = -eta0 * rho0 * (c1 * c1) / (beta * (c0 * c0));
+    tau = tau * theta * c1;
+    if (rho1 == 0.0) return -6;
+    d1 = theta0 * c1;
+    cc = d1 * d1;
+    rho1inv = 1.0 / rho1;
+    for (i = 0; i < n; ++i) {
+      d[i] = p[i] * eta0 + d[i] * cc;
+      x[i] += d[i];
+      v1[i] *= rho1inv;
+    }
+    if (xi1 == 0.0) return -6;
+    rho0 = rho1;
+    *err = tau / res_init;
+    c0 = c1;
+    theta0 = theta;
+  }
+  if (precon) {
+    if (precon(pctx, n, x, wrk1)) return -100;
+    orc_dcopy(n, wrk1, x);
+  }
+  return (*err < tol) ? 0 : -1;
+}
+
+static void orc_gen_rot(double dx, double dy, double *cs, double *sn) { /* gmres.c:40-55 */
+  if (dy == 0.0) {
+    *cs = 1.0;
+    *sn = 0.0;
+  } else if (fabs(dy) > fabs(dx)) {
+    double temp = dx / dy;
+    *sn = 1.0 / sqrt(1.0 + temp * temp);
+    *cs = temp * *sn;
+  } else {
+    double temp = dy / dx;
+    *cs = 1.0 / sqrt(1.0 + temp * temp);
+    *sn = temp * *cs;
+  }
+}
+static void orc_app_rot(double *dx, double *dy, double cs, double sn) { /* gmres.c:56-61 */
+  double temp = cs * *dx + sn * *dy;
+  *dy = -sn * *dx + cs * *dy;
+  *dx = temp;
+}
+
+/* pysparse/itsolvers/src/gmres.c:62-175: restarted GMRES(dim), right preconditioning.
+ * Returns 0 (-100 callback); *relres is the TRUE residual reduction at exit. */
+ORC_API int orc_gmres(int n, double errtol, int it_max, int *it, double *relres, int dim,
+                      double *x, const double *b, orc_matvec_fn matvec, void *mctx,
+                      orc_precon_fn precon, void *pctx) {
+  int m1 = dim + 1, i, j, k, iter = 0, rc = 0;
+  double beta, resid0 = 0.0, n2b, rel_resid = 0.0;
+  double *H = (double *)malloc(sizeof(double) * dim * (dim + 1));
+  double *s = (double *)malloc(sizeof(double) * (dim + 1));
+  double *cs = (double *)malloc(sizeof(double) * dim), *sn = (double *)malloc(sizeof(double) * dim);
+  double *V = (double *)malloc(sizeof(double) * (size_t)n * (dim + 1));
+  double *W = (double *)malloc(sizeof(double) * (size_t)n * dim);
+#define OV(i) (&V[(size_t)(i) * n])
+#define OW(i) (&W[(size_t)(i) * n])
+#define OH(i, j) (H[(j) * m1 + (i)])
+  n2b = orc_dnrm2(n, b);
+  if (n2b == 0.0) {
+    for (i = 0; i < n; i++) x[i] = 0.0;
+    *relres = 0.0;
+    *it = 0;
+    goto done;
+  }
+  do {
+    if (matvec(mctx, n, x, OV(0))) { rc = -100; goto done; }
+    orc_daxpy(n, -1.0, b, OV(0));
+    beta = sqrt(orc_ddot(n, OV(0), OV(0)));
+    orc_dscal(n, -1.0 / beta, OV(0));
+    if (iter == 0) resid0 = beta;
+    for (i = 1; i < dim + 1; i++) s[i] = 0.0;
+    s[0] = beta;
+    i = -1;
+    do {
+      i++;
+      iter++;
+      if (precon) {
+        if (precon(pctx, n, OV(i), OW(i))) { rc = -100; goto done; }
+      } else
+        orc_dcopy(n, OV(i), OW(i));
+      if (matvec(mctx, n, OW(i), OV(i + 1))) { rc = -100; goto done; }
+      for (k = 0; k <= i; k++) {
+        OH(k, i) = orc_ddot(n, OV(i + 1), OV(k));
+        orc_daxpy(n, -OH(k, i), OV(k), OV(i + 1));
+      }
+      OH(i + 1, i) = sqrt(orc_ddot(n, OV(i + 1), OV(i + 1)));
+      orc_dscal(n, 1.0 / OH(i + 1, i), OV(i + 1));
+      for (k = 0; k < i; k++) orc_app_rot(&OH(k, i), &OH(k + 1, i), cs[k], sn[k]);
+      orc_gen_rot(OH(i, i), OH(i + 1, i), &cs[i], &sn[i]);
+      orc_app_rot(&OH(i, i), &OH(i + 1, i), cs[i], sn[i]);
+      orc_app_rot(&s[i], &s[i + 1], cs[i], sn[i]);
+      rel_resid = fabs(s[i + 1]) / resid0;
+      if (rel_resid <= errtol) break;
+    } while (i + 1 < dim && iter + 1 <= it_max);
+    for (j = i; j >= 0; j--) {
+      s[j] /= OH(j, j);
+      for (k = j - 1; k >= 0; k--) s[k] -= OH(k, j) * s[j];
+    }
+    for (j = 0; j <= i; j++) orc_daxpy(n, s[j], OW(j), x);
+  } while (rel_resid > errtol && iter + 1 <= it_max);
+  if (matvec(mctx, n, x, OV(0))) { rc = -100; goto done; }
+  orc_daxpy(n, -1.0, b, OV(0));
+  beta = sqrt(orc_ddot(n, OV(0), OV(0)));
+  *it = iter;
+  *relres = beta / resid0;
+done:
+#undef OV
+#undef OW
+#undef OH
+  free(H); free(s); free(cs); free(sn); free(V); free(W);
+  return rc;
+}
+
+/* generic driver: solver = 0 cgs, 1 bicgstab, 2 qmrs, 3 gmres; operator CSR (da == NULL) or SSS */
+ORC_API int orc_krylov_more(int solver, int n, const double *va, const double *da, const int *ja,
+                            const int *ia, const double *dinv, double *x, const double *b,
+                            double tol, int maxit, int dim, int *iter, double *relres) {
+  orc_csr_t Ac = {n, n, va, ja, ia};
+  orc_sss_t As = {n, va, da, ja, ia};
+  orc_matvec_fn mv = da ? orc_sss_matvec_cb : orc_csr_matvec_cb;
+  void *mctx = da ? (void *)&As : (void *)&Ac;
+  orc_jacobi_t K = {n, dinv, 1, NULL, mv, mctx};
+  orc_precon_fn pc = dinv ? orc_jacobi_apply : NULL;
+  double *work = (double *)malloc(sizeof(double) * 8 * (size_t)n);
+  int info = 0;
+  if (solver == 0)
+    info = orc_cgs(n, b, x, maxit, tol, work, iter, relres, mv, mctx, pc, &K);
+  else if (solver == 1) {
+    orc_bicgstab(n, x, b, tol, maxit, iter, relres, &info, work, mv, mctx, pc, &K);
+  } else if (solver == 2)
+    info = orc_qmrs(n, b, x, work, tol, maxit, iter, relres, mv, mctx, pc, &K);
+  else
+    info = orc_gmres(n, tol, maxit, iter, relres, dim, x, b, mv, mctx, pc, &K);
+  free(work);
+  return info;
+}
+
 /* --------------------------------------- bound shims for the compiled reference */
 
 /* examples/poisson_test/pcg.c takes context-free callbacks

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpysparse_hip.so")
+LIB_PATH = os.environ.get("PSP_LIB_OVERRIDE") or os.path.join(HERE, "libpysparse_hip.so")  # override: A/B builds
 
 # every symbol include/pysparse_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = """
@@ -29,7 +29,7 @@ psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
 psp_jacobi_create_csr psp_jacobi_create_sss psp_jacobi_create_diag psp_jacobi_destroy
 psp_jacobi_shape psp_jacobi_precon psp_jacobi_precon_dev
 psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_callback psp_op_destroy
-psp_pcg psp_pcg_dev psp_minres psp_minres_dev
+psp_pcg psp_pcg_dev psp_minres psp_minres_dev psp_cgs psp_bicgstab psp_qmrs psp_gmres
 psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
 psp_k_csr_matvec_overlap
 """.split()
@@ -107,6 +107,8 @@ def _declare(L):
         "psp_pcg_dev": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
         "psp_minres": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
         "psp_minres_dev": [vp, vp, i, vp, vp, d, i, pi, pi, pd, vp],
+        "psp_cgs": [vp, vp, i, vp, vp, d, i, pi, pi, pd], "psp_bicgstab": [vp, vp, i, vp, vp, d, i, pi, pi, pd],
+        "psp_qmrs": [vp, vp, i, vp, vp, d, i, pi, pi, pd], "psp_gmres": [vp, vp, i, vp, vp, d, i, i, pi, pi, pd],
         "psp_k_dot": [i, vp, vp, vp], "psp_k_residual": [i, vp, vp, vp, vp],
         "psp_k_pupdate": [i, vp, vp, d, i, vp], "psp_k_csr_matvec_dot": [vp, vp, i, vp, vp],
         "psp_k_xr_update": [i, d, vp, vp, vp, vp, vp, vp], "psp_k_gather": [i, vp, vp, vp],

@@ -17,6 +17,7 @@
 //            jacobi with steps > 1): same kernels with an explicit z vector; callback
 //            operators are bridged with one D2H + one H2D copy per application.
 #include <cmath>
+#include <initializer_list>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -40,6 +41,8 @@ int k_lanczos(long n, const double *av, double c1, double c2, double *v_hat, dou
 int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old);
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, double *w,
                 double *w_old, double *x);
+int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
+int k_scal(long n, double a, double *x);
 }  // namespace psp
 
 extern "C" int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev);
@@ -407,6 +410,331 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   return PSP_OK;
 }
 
+// ====================================================================== cgs / bicgstab / qmrs / gmres
+//
+// the four other kernels of pysparse/itsolvers on the same
+// operator protocol and the same device vector ops.  Unfused on purpose: each BLAS-1 call /
+// hand loop of the reference is one kernel with the reference's rounding order, the scalar
+// recurrences run on the host in IEEE double like the C code.  (Parity: checked against the
+// oracle restatement, which for these four solvers is itself unpinned -- DESIGN.md section 7.)
+
+namespace {
+
+struct Blas {
+  Workspace *w;
+  long n;
+  int dot(const double *x, const double *y, double *out) {
+    int np;
+    PSP_TRY(k_dot(n, x, y, w->partials, &np));
+    return reduce_fetch(w, np, 1, out);
+  }
+  int nrm2(const double *x, double *out) {
+    PSP_TRY(dot(x, x, out));
+    *out = sqrt(*out);
+    return PSP_OK;
+  }
+  int copy(const double *x, double *y) {
+    PSP_HIP(hipMemcpyAsync(y, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+    return PSP_OK;
+  }
+  int axpy(double a, const double *x, double *y) {  // y = y + a*x; netlib quick return for a == 0
+    if (a == 0.0) return PSP_OK;
+    return k_lin2(n, 1.0, y, a, x, y);
+  }
+  int zero(double *x) {
+    PSP_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, stream()));
+    return PSP_OK;
+  }
+};
+
+int apply_or_copy(const psp_op *K, long n, const double *x, double *y) {
+  if (K) return op_apply(K, x, y);
+  PSP_HIP(hipMemcpyAsync(y, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  return PSP_OK;
+}
+
+}  // namespace
+
+// pysparse/itsolvers/src/cgs.c:14-110
+static int cgs_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol,
+                      int maxit, int *info, int *iter, double *res) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  Blas B{w, n};
+  DevVecs mem;
+  double *r0, *r, *p, *q, *u, *v, *tmp, *tmp2;
+  for (double **pp : {&r0, &r, &p, &q, &u, &v, &tmp, &tmp2}) PSP_TRY(mem.alloc(n, pp));
+  const double tol_sq = tol * tol;
+  double alpha, beta, rho, rho_new, bnrm_sq, d;
+  *iter = 0;
+  PSP_TRY(op_apply(A, x, tmp));
+  PSP_TRY(B.copy(b, r0));
+  PSP_TRY(B.axpy(-1.0, tmp, r0));
+  PSP_TRY(B.copy(r0, r));
+  PSP_TRY(B.copy(r0, u));
+  PSP_TRY(B.copy(r0, p));
+  PSP_TRY(B.dot(r0, r0, &rho));
+  PSP_TRY(B.dot(b, b, &bnrm_sq));
+  if (rho < bnrm_sq * tol_sq) {
+    *res = sqrt(rho / bnrm_sq);
+    *info = 0;
+    return PSP_OK;
+  }
+  for (; *iter < maxit; (*iter)++) {
+    if (K) {
+      PSP_TRY(op_apply(K, p, tmp));
+      PSP_TRY(op_apply(A, tmp, v));
+    } else {
+      PSP_TRY(op_apply(A, p, v));
+    }
+    PSP_TRY(B.dot(v, r0, &d));
+    alpha = rho / d;
+    const double ddummy = -alpha;
+    PSP_TRY(B.copy(u, q));
+    PSP_TRY(B.axpy(ddummy, v, q));
+    PSP_TRY(B.copy(u, tmp));
+    PSP_TRY(B.axpy(1.0, q, tmp));
+    PSP_TRY(apply_or_copy(K, n, tmp, tmp2));
+    PSP_TRY(B.axpy(alpha, tmp2, x));
+    PSP_TRY(op_apply(A, tmp2, tmp));
+    PSP_TRY(B.axpy(ddummy, tmp, r));
+    PSP_TRY(B.dot(r, r, res));
+    if (*res < bnrm_sq * tol_sq) {
+      *res = sqrt(*res / bnrm_sq);
+      *info = 0;
+      return PSP_OK;
+    }
+    PSP_TRY(B.dot(r, r0, &rho_new));
+    beta = rho_new / rho;
+    rho = rho_new;
+    PSP_TRY(B.copy(r, u));
+    PSP_TRY(B.axpy(beta, q, u));
+    PSP_TRY(B.copy(q, tmp));
+    PSP_TRY(B.axpy(beta, p, tmp));
+    PSP_TRY(B.copy(u, p));
+    PSP_TRY(B.axpy(beta, tmp, p));
+  }
+  *res = sqrt(*res / bnrm_sq);
+  *info = -1;
+  return PSP_OK;
+}
+
+// pysparse/itsolvers/src/bicgstab.c:233-320
+static int bicgstab_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
+                           double tol, int maxit, int *info, int *iter, double *relres) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  Blas B{w, n};
+  DevVecs mem;
+  double *r, *rhat, *p, *phat, *v, *s, *shat, *t;
+  for (double **pp : {&r, &rhat, &p, &phat, &v, &s, &shat, &t}) PSP_TRY(mem.alloc(n, pp));
+  double alpha = 0.0, omega = 0.0, rho_im1, rho_im2 = 0.0, beta, res, res0, n2b, d1, d2;
+  *info = -6;
+  PSP_TRY(B.nrm2(b, &n2b));
+  if (n2b == 0.0) {
+    PSP_TRY(B.zero(x));
+    *info = 0;
+    *relres = 0.0;
+    *iter = 0;
+    return PSP_OK;
+  }
+  PSP_TRY(op_apply(A, x, r));
+  PSP_TRY(k_lin2(n, 1.0, b, -1.0, r, r));  // r = b + -r
+  PSP_TRY(B.nrm2(r, &res0));
+  PSP_TRY(B.copy(r, rhat));
+  *iter = 0;
+  do {
+    (*iter)++;
+    PSP_TRY(B.dot(rhat, r, &rho_im1));
+    if (rho_im1 == 0.0) return PSP_OK;  // info stays -6 (the module ignores the kernel's -1)
+    if (*iter == 1) {
+      PSP_TRY(B.copy(r, p));
+    } else {
+      beta = (rho_im1 / rho_im2) * (alpha / omega);
+      PSP_TRY(k_lin2(n, 1.0, p, -omega, v, t));  // t is free here: p - omega*v
+      PSP_TRY(k_lin2(n, 1.0, r, beta, t, p));    // p = r + beta*(p - omega*v)
+    }
+    PSP_TRY(apply_or_copy(K, n, p, phat));
+    PSP_TRY(op_apply(A, phat, v));
+    PSP_TRY(B.dot(rhat, v, &d1));
+    alpha = rho_im1 / d1;
+    PSP_TRY(k_lin2(n, 1.0, r, -alpha, v, s));  // v_plus_cw(n, r, v, -alpha, s)
+    PSP_TRY(apply_or_copy(K, n, s, shat));
+    PSP_TRY(op_apply(A, shat, t));
+    PSP_TRY(B.dot(t, s, &d1));
+    PSP_TRY(B.dot(t, t, &d2));
+    omega = d1 / d2;
+    PSP_TRY(k_lin2(n, 1.0, x, alpha, phat, x));  // x = x + alpha*phat ...
+    PSP_TRY(k_lin2(n, 1.0, x, omega, shat, x));  // ... + omega*shat
+    PSP_TRY(k_lin2(n, 1.0, s, -omega, t, r));    // r = s - omega*t
+    PSP_TRY(B.nrm2(r, &res));
+    if (omega == 0.0) return PSP_OK;
+    rho_im2 = rho_im1;
+  } while ((res / res0 > tol) && (*iter < maxit));
+  *relres = res / res0;
+  *info = (*relres >= tol) ? -1 : 0;
+  return PSP_OK;
+}
+
+// pysparse/itsolvers/src/qmrs.c:29-154
+static int qmrs_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol,
+                       int maxit, int *info, int *iter, double *err) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  Blas B{w, n};
+  DevVecs mem;
+  double *wrk1, *p, *d, *v1, *t, *g;
+  for (double **pp : {&wrk1, &p, &d, &v1, &t, &g}) PSP_TRY(mem.alloc(n, pp));
+  double beta, res_init, delta, theta, c0, c1, theta0, cc, xi1, rho1inv, tau, eta0, eps0, rho0, rho1, d1;
+  PSP_TRY(B.copy(b, v1));
+  PSP_TRY(B.nrm2(v1, &rho0));
+  tau = rho0;
+  PSP_TRY(k_scale_div(n, v1, rho0, v1));
+  PSP_TRY(B.zero(p));
+  PSP_TRY(B.zero(g));
+  PSP_TRY(B.zero(d));
+  PSP_TRY(B.zero(x));
+  c0 = 1.0;
+  eps0 = 1.0;
+  xi1 = 1.0;
+  theta0 = 0.0;
+  eta0 = -1.0;
+  res_init = rho0;
+  *err = 1.0;
+  *iter = 0;
+#define QMRS_RET(code) do { *info = (code); PSP_HIP(hipStreamSynchronize(stream())); return PSP_OK; } while (0)
+  while (*err > tol && *iter < maxit) {
+    ++(*iter);
+    if (eps0 == 0.0) QMRS_RET(-6);
+    PSP_TRY(apply_or_copy(K, n, v1, wrk1));
+    PSP_TRY(B.dot(wrk1, v1, &delta));
+    if (delta == 0.0) QMRS_RET(-2);
+    cc = xi1 * (delta / eps0);
+    PSP_TRY(k_lin2(n, 1.0, v1, -cc, p, p));    // p = v1 - p*cc
+    PSP_TRY(k_lin2(n, 1.0, wrk1, -cc, g, g));  // g = wrk1 - g*cc
+    PSP_TRY(op_apply(A, g, t));
+    PSP_TRY(B.dot(g, t, &eps0));
+    beta = eps0 / delta;
+    PSP_TRY(k_lin2(n, 1.0, t, -beta, v1, v1));  // v1 = t - v1*beta
+    PSP_TRY(B.nrm2(v1, &rho1));
+    xi1 = rho1;
+    if (c0 * fabs(beta) == 0.0) QMRS_RET(-6);
+    theta = rho1 / (c0 * fabs(beta));
+    c1 = 1.0 / sqrt(theta * theta + 1.0);
+    if (beta * (c0 * c0) == 0.0) QMRS_RET(-6);
+    eta0 = -eta0 * rho0 * (c1 * c1) / (beta * (c0 * c0));
+    tau = tau * theta * c1;
+    if (rho1 == 0.0) QMRS_RET(-6);
+    d1 = theta0 * c1;
+    cc = d1 * d1;
+    rho1inv = 1.0 / rho1;
+    PSP_TRY(k_lin2(n, eta0, p, cc, d, d));  // d = p*eta0 + d*cc
+    PSP_TRY(k_lin2(n, 1.0, x, 1.0, d, x));  // x += d
+    PSP_TRY(k_scal(n, rho1inv, v1));        // v1 *= rho1inv
+    if (xi1 == 0.0) QMRS_RET(-6);
+    rho0 = rho1;
+    *err = tau / res_init;
+    c0 = c1;
+    theta0 = theta;
+  }
+#undef QMRS_RET
+  if (K) {
+    PSP_TRY(op_apply(K, x, wrk1));
+    PSP_TRY(B.copy(wrk1, x));
+  }
+  *info = (*err < tol) ? 0 : -1;
+  return PSP_OK;
+}
+
+// pysparse/itsolvers/src/gmres.c:62-175 (rotations :40-61)
+static void gen_rot(double dx, double dy, double *cs, double *sn) {
+  if (dy == 0.0) {
+    *cs = 1.0;
+    *sn = 0.0;
+  } else if (fabs(dy) > fabs(dx)) {
+    const double temp = dx / dy;
+    *sn = 1.0 / sqrt(1.0 + temp * temp);
+    *cs = temp * *sn;
+  } else {
+    const double temp = dy / dx;
+    *cs = 1.0 / sqrt(1.0 + temp * temp);
+    *sn = temp * *cs;
+  }
+}
+static void app_rot(double *dx, double *dy, double cs, double sn) {
+  const double temp = cs * *dx + sn * *dy;
+  *dy = -sn * *dx + cs * *dy;
+  *dx = temp;
+}
+
+static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
+                        double errtol, int it_max, int dim, int *info, int *it, double *relres) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  Blas B{w, n};
+  if (dim < 1) return fail(PSP_EINVAL, "gmres: dim must be >= 1");
+  DevVecs mem;
+  std::vector<double *> V(dim + 1), W(dim);
+  for (int i = 0; i <= dim; ++i) PSP_TRY(mem.alloc(n, &V[i]));
+  for (int i = 0; i < dim; ++i) PSP_TRY(mem.alloc(n, &W[i]));
+  const int m1 = dim + 1;
+  std::vector<double> H((size_t)dim * m1), s(m1), cs(dim), sn(dim);
+#define GH(i, j) (H[(size_t)(j) * m1 + (i)])
+  int i, j, k, iter = 0;
+  double beta, resid0 = 0.0, n2b, rel_resid = 0.0, d;
+  *info = 0;
+  PSP_TRY(B.nrm2(b, &n2b));
+  if (n2b == 0.0) {
+    PSP_TRY(B.zero(x));
+    *relres = 0.0;
+    *it = 0;
+    return PSP_OK;
+  }
+  do {
+    PSP_TRY(op_apply(A, x, V[0]));
+    PSP_TRY(B.axpy(-1.0, b, V[0]));
+    PSP_TRY(B.dot(V[0], V[0], &d));
+    beta = sqrt(d);
+    PSP_TRY(k_scal(n, -1.0 / beta, V[0]));
+    if (iter == 0) resid0 = beta;
+    for (i = 1; i < dim + 1; i++) s[i] = 0.0;
+    s[0] = beta;
+    i = -1;
+    do {
+      i++;
+      iter++;
+      PSP_TRY(apply_or_copy(K, n, V[i], W[i]));
+      PSP_TRY(op_apply(A, W[i], V[i + 1]));
+      for (k = 0; k <= i; k++) {
+        PSP_TRY(B.dot(V[i + 1], V[k], &d));
+        GH(k, i) = d;
+        PSP_TRY(B.axpy(-GH(k, i), V[k], V[i + 1]));
+      }
+      PSP_TRY(B.dot(V[i + 1], V[i + 1], &d));
+      GH(i + 1, i) = sqrt(d);
+      PSP_TRY(k_scal(n, 1.0 / GH(i + 1, i), V[i + 1]));
+      for (k = 0; k < i; k++) app_rot(&GH(k, i), &GH(k + 1, i), cs[k], sn[k]);
+      gen_rot(GH(i, i), GH(i + 1, i), &cs[i], &sn[i]);
+      app_rot(&GH(i, i), &GH(i + 1, i), cs[i], sn[i]);
+      app_rot(&s[i], &s[i + 1], cs[i], sn[i]);
+      rel_resid = fabs(s[i + 1]) / resid0;
+      if (rel_resid <= errtol) break;
+    } while (i + 1 < dim && iter + 1 <= it_max);
+    for (j = i; j >= 0; j--) {
+      s[j] /= GH(j, j);
+      for (k = j - 1; k >= 0; k--) s[k] -= GH(k, j) * s[j];
+    }
+    for (j = 0; j <= i; j++) PSP_TRY(B.axpy(s[j], W[j], x));
+  } while (rel_resid > errtol && iter + 1 <= it_max);
+#undef GH
+  PSP_TRY(op_apply(A, x, V[0]));
+  PSP_TRY(B.axpy(-1.0, b, V[0]));
+  PSP_TRY(B.dot(V[0], V[0], &d));
+  *it = iter;
+  *relres = sqrt(d) / resid0;
+  return PSP_OK;
+}
+
 // ====================================================================== C ABI
 
 static int check_solver_args(const psp_op *A, const psp_op *K, int n, const void *x, const void *b,
@@ -653,6 +981,48 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
   PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));
   PSP_HIP(hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, stream()));
   PSP_TRY(minres_device(A, K, n, x, b, tol, maxit, info, iter, relres, hist_host));
+  PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+// ---------------------------------------------------------------- cgs / bicgstab / qmrs / gmres
+
+#define PSP_HOST_SOLVER(NAME, CALL)                                                              \
+  int NAME(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,    \
+           double tol, int maxit, int *info, int *iter, double *relres) {                        \
+    PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));                     \
+    PSP_TRY(ensure_device());                                                                    \
+    DevVecs mem;                                                                                 \
+    double *x, *b;                                                                               \
+    PSP_TRY(mem.alloc(n, &x));                                                                   \
+    PSP_TRY(mem.alloc(n, &b));                                                                   \
+    const size_t bytes = sizeof(double) * (size_t)n;                                             \
+    PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));                  \
+    PSP_HIP(hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, stream()));                  \
+    PSP_TRY(CALL);                                                                               \
+    PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));                  \
+    PSP_HIP(hipStreamSynchronize(stream()));                                                     \
+    return PSP_OK;                                                                               \
+  }
+
+PSP_HOST_SOLVER(psp_cgs, cgs_device(A, K, n, x, b, tol, maxit, info, iter, relres))
+PSP_HOST_SOLVER(psp_bicgstab, bicgstab_device(A, K, n, x, b, tol, maxit, info, iter, relres))
+PSP_HOST_SOLVER(psp_qmrs, qmrs_device(A, K, n, x, b, tol, maxit, info, iter, relres))
+#undef PSP_HOST_SOLVER
+
+int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
+              double tol, int maxit, int dim, int *info, int *iter, double *relres) {
+  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
+  PSP_TRY(ensure_device());
+  DevVecs mem;
+  double *x, *b;
+  PSP_TRY(mem.alloc(n, &x));
+  PSP_TRY(mem.alloc(n, &b));
+  const size_t bytes = sizeof(double) * (size_t)n;
+  PSP_HIP(hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_HIP(hipMemcpyAsync(b, b_host, bytes, hipMemcpyHostToDevice, stream()));
+  PSP_TRY(gmres_device(A, K, n, x, b, tol, maxit, dim, info, iter, relres));
   PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
   return PSP_OK;

@@ -24,9 +24,24 @@ template <int V>
 __device__ __forceinline__ Pack<V> ld(const double *p, long i) {
   return *reinterpret_cast<const Pack<V> *>(p + i);
 }
+typedef double d2nt __attribute__((ext_vector_type(2)));
+
+// vector results are written once and next read after >= 1 GB of other traffic: store them
+// non-temporally when PSP_VEC_NT_STORE is set (A/B: profiles/)
 template <int V>
 __device__ __forceinline__ void st(double *p, long i, const Pack<V> &x) {
+#ifdef PSP_VEC_NT_STORE
+  if constexpr (V == 2) {
+    d2nt t;
+    t.x = x.v[0];
+    t.y = x.v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<d2nt *>(p + i));
+  } else {
+    __builtin_nontemporal_store(x.v[0], p + i);
+  }
+#else
   *reinterpret_cast<Pack<V> *>(p + i) = x;
+#endif
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -312,6 +327,31 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double 
   }
 }
 
+// ---- z = a*x + b*y (separate roundings, as the reference's daxpy / hand loops); z may
+//      alias x or y.  Building block of the unfused cgs / bicgstab / qmrs / gmres loops.
+template <int V>
+__global__ __launch_bounds__(kBlock) void lin2_kernel(long n, double a, const double *x, double b,
+                                                      const double *y, double *z) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> xx = ld<V>(x, i), yy = ld<V>(y, i);
+    Pack<V> zz;
+#pragma unroll
+    for (int u = 0; u < V; ++u) zz.v[u] = a * xx.v[u] + b * yy.v[u];
+    st<V>(z, i, zz);
+  }
+}
+
+// ---- x = a*x (dscal)
+template <int V>
+__global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> xx = ld<V>(x, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) xx.v[u] = a * xx.v[u];
+    st<V>(x, i, xx);
+  }
+}
+
 // ---- halo packing
 __global__ void gather_kernel(int count, const int *__restrict__ idx, const double *__restrict__ v,
                               double *__restrict__ out) {
@@ -480,6 +520,30 @@ int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_ha
   else
     hipLaunchKernelGGL(lanczos_plain_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, av, c1,
                        c2, v_hat, v_hat_old);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_lin2(long n, double a, const double *x, double b, const double *y, double *z) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x, y, z))
+    hipLaunchKernelGGL(lin2_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, a, x, b, y, z);
+  else
+    hipLaunchKernelGGL(lin2_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, a, x, b, y, z);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_scal(long n, double a, double *x) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x))
+    hipLaunchKernelGGL(scal_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, a, x);
+  else
+    hipLaunchKernelGGL(scal_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, a, x);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

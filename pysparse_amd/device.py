@@ -352,6 +352,48 @@ def minres(A, b, x, tol, maxit, K=None, hist=False):
     return _solve(lib().psp_minres, A, b, x, tol, maxit, K, hist)
 
 
+def _solve_more(name, A, b, x, tol, maxit, K, dim=None):
+    aop = _Op(A, "matvec")
+    kop = _Op(K, "precon") if K is not None else None
+    n = int(A.shape[0])
+    xw = x if (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous
+               and x.ndim == 1) else np.ascontiguousarray(x, dtype=np.float64)
+    bw = np.ascontiguousarray(b, dtype=np.float64)
+    if xw.ndim != 1 or bw.ndim != 1 or xw.shape[0] != bw.shape[0] or xw.shape[0] != n:
+        raise ValueError("incompatible operand shapes")
+    info, it, rr = C.c_int(0), C.c_int(0), C.c_double(0.0)
+    fn = getattr(lib(), "psp_" + name)
+    args = [aop._h, kop._h if kop else None, n, _ptr(xw), _ptr(bw), float(tol), int(maxit)]
+    if dim is not None:
+        args.append(int(dim))
+    rc = fn(*args, C.byref(info), C.byref(it), C.byref(rr))
+    for op in (aop, kop):
+        if op is not None and op.exc is not None:
+            raise op.exc
+    check(rc)
+    return info.value, it.value, rr.value
+
+
+def cgs(A, b, x, tol, maxit, K=None):
+    """info, iter, relres = cgs(A, b, x, tol, maxit[, K]) -- itsolversmodule.c:503-586."""
+    return _solve_more("cgs", A, b, x, tol, maxit, K)
+
+
+def bicgstab(A, b, x, tol, maxit, K=None):
+    """info, iter, relres = bicgstab(A, b, x, tol, maxit[, K]) -- itsolversmodule.c:125-216."""
+    return _solve_more("bicgstab", A, b, x, tol, maxit, K)
+
+
+def qmrs(A, b, x, tol, maxit, K=None):
+    """info, iter, relres = qmrs(A, b, x, tol, maxit[, K]) -- itsolversmodule.c:410-496."""
+    return _solve_more("qmrs", A, b, x, tol, maxit, K)
+
+
+def gmres(A, b, x, tol, maxit, K=None, dim=20):
+    """info, iter, relres = gmres(A, b, x, tol, maxit[, K[, dim]]) -- itsolversmodule.c:313-403."""
+    return _solve_more("gmres", A, b, x, tol, maxit, K, dim)
+
+
 def device_count():
     return lib().psp_device_count()
 

@@ -5,7 +5,7 @@ build: `solve()` zeroes x first (:41), keeps the counters nofCalled / totalItera
 lastIterations / lastInfo (:24-27,43-46) and raises on info < 0 (:49-50)."""
 from . import krylov
 
-__all__ = ["ItSolver", "Pcg", "Minres"]
+__all__ = ["ItSolver", "Pcg", "Minres", "Qmrs", "Cgs", "Bicgstab", "Gmres"]
 
 
 class ItSolver:
@@ -50,3 +50,31 @@ class Minres(ItSolver):
         ItSolver.__init__(self, matrix, **kwargs)
         self.name = "minres"
         self.itsolver = krylov.minres
+
+
+class Qmrs(ItSolver):
+    def __init__(self, matrix, **kwargs):
+        ItSolver.__init__(self, matrix, **kwargs)
+        self.name = "qmrs"
+        self.itsolver = krylov.qmrs
+
+
+class Cgs(ItSolver):
+    def __init__(self, matrix, **kwargs):
+        ItSolver.__init__(self, matrix, **kwargs)
+        self.name = "cgs"
+        self.itsolver = krylov.cgs
+
+
+class Bicgstab(ItSolver):
+    def __init__(self, matrix, **kwargs):
+        ItSolver.__init__(self, matrix, **kwargs)
+        self.name = "bicgstab"
+        self.itsolver = krylov.bicgstab
+
+
+class Gmres(ItSolver):
+    def __init__(self, matrix, **kwargs):
+        ItSolver.__init__(self, matrix, **kwargs)
+        self.name = "gmres"
+        self.itsolver = krylov.gmres

@@ -20,6 +20,23 @@
 typedef int (*solver_fn)(const psp_op_t *, const psp_op_t *, int, double *, const double *, double,
                          int, int *, int *, double *, double *);
 
+typedef int (*solver_fn10)(const psp_op_t *, const psp_op_t *, int, double *, const double *, double,
+                           int, int *, int *, double *);
+static solver_fn10 g_fn10; /* solver without history argument, set by the thin wrappers below */
+static int g_gmres_dim;
+
+static int call_fn10(const psp_op_t *A, const psp_op_t *K, int n, double *x, const double *b,
+                     double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
+  (void)hist;
+  return g_fn10(A, K, n, x, b, tol, maxit, info, iter, relres);
+}
+
+static int call_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x, const double *b,
+                      double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
+  (void)hist;
+  return psp_gmres(A, K, n, x, b, tol, maxit, g_gmres_dim, info, iter, relres);
+}
+
 static PyObject *run_solver(PyObject *args, solver_fn fn, int check_positive_shape) {
   PyObject *amat, *bo, *xo, *precon = Py_None;
   PyArrayObject *b = NULL, *x = NULL;
@@ -96,7 +113,48 @@ static PyObject *ItSolvers_minres(PyObject *self, PyObject *args) {
   return run_solver(args, psp_minres, 1);
 }
 
+/* the module is single-threaded under the GIL up to the point where run_solver releases it,
+ * and the selector variables are read before that */
+static PyObject *ItSolvers_cgs(PyObject *self, PyObject *args) {
+  g_fn10 = psp_cgs;
+  return run_solver(args, call_fn10, 1);
+}
+static PyObject *ItSolvers_bicgstab(PyObject *self, PyObject *args) {
+  g_fn10 = psp_bicgstab;
+  return run_solver(args, call_fn10, 0);
+}
+static PyObject *ItSolvers_qmrs(PyObject *self, PyObject *args) {
+  g_fn10 = psp_qmrs;
+  return run_solver(args, call_fn10, 1);
+}
+/* gmres(A, b, x, tol, maxit[, K[, dim=20]]): itsolversmodule.c:313-403 */
+static PyObject *ItSolvers_gmres(PyObject *self, PyObject *args) {
+  Py_ssize_t na = PyTuple_GET_SIZE(args);
+  PyObject *core, *res;
+  g_gmres_dim = 20;
+  if (na == 7) {
+    g_gmres_dim = (int)PyLong_AsLong(PyTuple_GET_ITEM(args, 6));
+    if (PyErr_Occurred()) return NULL;
+    core = PyTuple_GetSlice(args, 0, 6);
+  } else {
+    core = args;
+    Py_INCREF(core);
+  }
+  if (core == NULL) return NULL;
+  res = run_solver(core, call_gmres, 1);
+  Py_DECREF(core);
+  return res;
+}
+
 static PyMethodDef krylov_methods[] = {
+    {"cgs", ItSolvers_cgs, METH_VARARGS,
+     "info, iter, relres = cgs(A, b, x, tol, maxit[, K])\n\nConjugate Gradient Squared method."},
+    {"bicgstab", ItSolvers_bicgstab, METH_VARARGS,
+     "info, iter, relres = bicgstab(A, b, x, tol, maxit[, K])\n\nStabilized BiConjugate Gradient method."},
+    {"qmrs", ItSolvers_qmrs, METH_VARARGS,
+     "info, iter, relres = qmrs(A, b, x, tol, maxit[, K])\n\nQuasi-Minimal Residual Smoothing method."},
+    {"gmres", ItSolvers_gmres, METH_VARARGS,
+     "info, iter, relres = gmres(A, b, x, tol, maxit[, K[, dim]])\n\nGMRES(dim) of Saad and Schultz."},
     {"pcg", ItSolvers_pcg, METH_VARARGS,
      "info, iter, relres = pcg(A, b, x, tol, maxit[, K])\n\nPreconditioned Conjugate Gradient method."},
     {"minres", ItSolvers_minres, METH_VARARGS,

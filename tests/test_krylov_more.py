@@ -1,0 +1,120 @@
+"""cgs / bicgstab / qmrs / gmres.
+
+CPU part: the oracle restatements agree with PCG / a direct solve (their parity against the
+reference is UNPINNED: no compilable reference kernel or golden vector exists for them).
+GPU part: the device loops reproduce the oracle's info / iteration counts and iterates."""
+import numpy as np
+import pytest
+
+SOLVERS = ("cgs", "bicgstab", "qmrs", "gmres")
+
+
+def nonsym_csr(oracle, n, seed):
+    """diagonally dominant non-symmetric tridiagonal-plus-band matrix"""
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        ent = {i: 8.0 + rng.random()}
+        for off in (-7, -1, 1, 5):
+            j = i + off
+            if 0 <= j < n:
+                ent[j] = rng.standard_normal()
+        for j in sorted(ent):
+            rows.append(i), cols.append(j), vals.append(ent[j])
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=ind[1:])
+    return oracle.CSR((n, n), np.array(vals), np.array(cols, dtype=np.int32), ind)
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_oracle_more_solvers_reach_the_pcg_solution(oracle, solver):
+    A = oracle.poisson_csr(24, 20)
+    n = A.shape[0]
+    b = np.random.default_rng(2).standard_normal(n)
+    xp = np.zeros(n)
+    assert oracle.pcg(A, b, xp, 1e-12, 4000)[0] == 0
+    for dinv in (None, oracle.jacobi_dinv(A.diagonal())):
+        x = np.full(n, 0.5) if solver != "qmrs" else np.zeros(n)
+        info, it, rr = oracle.krylov_more(solver, A, b, x, 1e-11, 4000, dinv, dim=25)
+        assert info == 0 and 0 < it < 4000
+        assert np.abs(x - xp).max() / np.abs(xp).max() < 1e-8
+
+
+@pytest.mark.parametrize("solver", ("cgs", "bicgstab", "gmres"))
+def test_oracle_more_solvers_nonsymmetric(oracle, solver):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    A = nonsym_csr(oracle, 400, 3)
+    b = np.ones(400)
+    xs = spla.spsolve(sp.csr_matrix((A.val, A.col, A.ind), shape=A.shape).tocsc(), b)
+    x = np.zeros(400)
+    info, it, rr = oracle.krylov_more(solver, A, b, x, 1e-12, 2000, oracle.jacobi_dinv(A.diagonal()), dim=30)
+    assert info == 0 and np.abs(x - xs).max() / np.abs(xs).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_gpu_more_solvers_match_oracle(oracle, solver):
+    from pysparse_amd import device as dev
+    fn = getattr(dev, solver)
+    cases = [(oracle.poisson_csr(40, 32), True), (oracle.poisson_csr(12, 11, 10), True)]
+    if solver != "qmrs":
+        cases.append((nonsym_csr(oracle, 3000, 5), False))
+    for A, sym in cases:
+        n = A.shape[0]
+        D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+        b = np.random.default_rng(7).standard_normal(n)
+        for use_k in (False, True):
+            dinv = oracle.jacobi_dinv(A.diagonal()) if use_k else None
+            K = dev.DeviceJacobi(D) if use_k else None
+            kw = {"dim": 15} if solver == "gmres" else {}
+            xo = np.full(n, 0.25)
+            ro = oracle.krylov_more(solver, A, b, xo, 1e-10, 3000, dinv, **kw)
+            x = np.full(n, 0.25)
+            r = fn(D, b, x, 1e-10, 3000, K, **kw)
+            assert r[:2] == ro[:2], (solver, r, ro)
+            assert abs(r[2] - ro[2]) <= 1e-6 * abs(ro[2]) + 1e-18
+            assert np.abs(x - xo).max() / np.abs(xo).max() < 1e-11
+    # maxit exhausted
+    A = oracle.poisson_csr(40, 32)
+    n = A.shape[0]
+    D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    b = np.ones(n)
+    xo, x = np.zeros(n), np.zeros(n)
+    kw = {"dim": 4} if solver == "gmres" else {}
+    ro = oracle.krylov_more(solver, A, b, xo, 1e-14, 6, None, **kw)
+    r = fn(D, b, x, 1e-14, 6, None, **kw)
+    assert r[:2] == ro[:2] and np.abs(x - xo).max() <= 1e-12 * np.abs(xo).max()
+
+
+@pytest.mark.gpu
+def test_gpu_more_solvers_through_the_module(oracle):
+    """pysparse.itsolvers.krylov.{cgs,bicgstab,qmrs,gmres} and the ItSolver wrappers
+    (itsolvers_util.py:154-178 runs all six on poisson2d_sym(100))."""
+    from pysparse.itsolvers import krylov, Qmrs, Cgs, Bicgstab, Gmres
+    from pysparse.sparse import spmatrix
+    from pysparse.precon import precon
+    A = spmatrix.poisson_csr(50, 50)
+    O = oracle.poisson_csr(50, 50)
+    n = 2500
+    b = np.ones(n)
+    K = precon.jacobi(A)
+    dinv = oracle.jacobi_dinv(O.diagonal())
+    for name in SOLVERS:
+        xo = np.zeros(n)
+        ro = oracle.krylov_more(name, O, b, xo, 1e-9, 2000, dinv, dim=20)
+        x = np.zeros(n)
+        r = getattr(krylov, name)(A, b, x, 1e-9, 2000, K)
+        assert r[:2] == ro[:2] and np.abs(x - xo).max() / np.abs(xo).max() < 1e-11
+    x = np.zeros(n)
+    r = krylov.gmres(A, b, x, 1e-9, 2000, None, 35)
+    xo = np.zeros(n)
+    assert r[:2] == oracle.krylov_more("gmres", O, b, xo, 1e-9, 2000, None, dim=35)[:2]
+    for cls in (Qmrs, Cgs, Bicgstab, Gmres):
+        s = cls(A)
+        x = np.ones(n)
+        s.solve(b, x, 1e-8, 2000, K)
+        assert s.lastInfo == 0 and s.nofCalled == 1
+        r = np.empty(n)
+        A.matvec(x, r)
+        assert np.linalg.norm(b - r) < 1e-6 * np.linalg.norm(b)
