@@ -604,15 +604,18 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
   }
 }
 
-// first-level fold of per-workgroup dot partials when the grid is larger than the
-// workspace slots: out[b] = in[b] + in[b+nout] + ... (fixed order)
+// first-level fold of per-workgroup dot partials when they do not sit in the workspace
+// slots: out[o] = sum of in[o], in[o+nout], ... ; 16 lanes per output, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
                                                             double *__restrict__ out, int nout) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nout) return;
+  const int o = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int g = threadIdx.x & 15;
   double s = 0.0;
-  for (int i = b; i < nin; i += nout) s += in[i];
-  out[b] = s;
+  if (o < nout)
+    for (long i = o + (long)nout * g; i < nin; i += (long)nout * 16) s += in[i];
+#pragma unroll
+  for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 16);
+  if (g == 0 && o < nout) out[o] = s;
 }
 
 // y = A^T x: scatter with fp64 HBM atomics (csr_mat.c:74-88).  Not on the Krylov path.
@@ -1018,7 +1021,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     int np = grid;
     if (pbuf != partials) {
       np = kFold;
-      hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 256), dim3(256), 0, stream(), pbuf, grid,
+      hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
                          partials, np);
       PSP_LAUNCH_CHECK();
     }
@@ -1181,7 +1184,7 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
 #undef PSP_RANGE
   if (partials) {
     const int total = g1 + g2 + g3;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 256), dim3(256), 0, stream(), pbuf, total,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), pbuf, total,
                        partials, kFold);
     PSP_LAUNCH_CHECK();
     if (nparts) *nparts = kFold;

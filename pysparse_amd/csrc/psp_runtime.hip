@@ -68,14 +68,20 @@ int workspace(Workspace **out) {
   return PSP_OK;
 }
 
-// fold: out[j*kFold + t] = sum over b == t (mod kFold) of in[j*stride + b], ascending b
+// fold: out[j*kFold + o] = sum over b == o (mod kFold) of in[j*kMaxParts + b].  16 lanes share
+// one output: lane g adds b = o + kFold*(g + 16*i) in ascending i, then a fixed xor-tree over
+// the 16 lanes -- same order every run.  64 workgroups per value keep the 1-3 MB of partials
+// of a 2^27-element reduction from being read by only four workgroups (70 us -> ~10 us).
 __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ in, int nparts,
                                                    double *__restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // < kFold
+  const int o = blockIdx.x * 16 + (threadIdx.x >> 4);  // < kFold
+  const int g = threadIdx.x & 15;
   const int j = blockIdx.y;
   double s = 0.0;
-  for (int b = t; b < nparts; b += kFold) s += in[(size_t)j * kMaxParts + b];
-  out[(size_t)j * kFold + t] = s;
+  for (long b = o + (long)kFold * g; b < nparts; b += (long)kFold * 16) s += in[(size_t)j * kMaxParts + b];
+#pragma unroll
+  for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 16);
+  if (g == 0) out[(size_t)j * kFold + o] = s;
 }
 
 // one block: thread t adds parts t, t+256, ... in order, then a fixed tree
@@ -101,7 +107,7 @@ int finish_partials(const double *partials, int nparts, int nvals, double *out_d
   Workspace *w;
   PSP_TRY(workspace(&w));
   if (nparts > 2 * kFold) {
-    hipLaunchKernelGGL(fold_kernel, dim3(kFold / 256, nvals), dim3(256), 0, stream(), partials,
+    hipLaunchKernelGGL(fold_kernel, dim3(kFold / 16, nvals), dim3(256), 0, stream(), partials,
                        nparts, w->folded);
     PSP_LAUNCH_CHECK();
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), w->folded, kFold, nvals,
