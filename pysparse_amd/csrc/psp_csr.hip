@@ -731,8 +731,9 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // ------------------------------------------------------------------ host helpers
 
-// csr_spmv_w2: tile 1024, 4 waves per workgroup, non-temporal y stores, XCD stripe 32
-constexpr int kDefaultVariant = 128 + 2 + 64 + (32 << 8);
+// csr_spmv_w2: tile 1024, 4 waves per workgroup, non-temporal y stores, XCD stripe 64
+// (profiles/r1_spmv_w2_sweep.txt: stripes 48/64/96 within 0.5 %, 0 and >= 192 about 1-3 % slower)
+constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8);
 
 struct Variant {
   int tile, vec;
