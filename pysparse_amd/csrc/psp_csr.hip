@@ -514,9 +514,10 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     int chunk0, int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
     const unsigned short *__restrict__ rowoff, const int *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ dotv, double *__restrict__ partials) {
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
   constexpr int STEPS = WT / 256;
   constexpr int E = 64 * NP;
+  if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
   __shared__ double prod_all[WPB * WT];
   __shared__ double red[WPB];
   const int lane = threadIdx.x & 63;
@@ -946,8 +947,17 @@ static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab,
                      nchunks, map_mode, colmask(), tab, A->ind, A->col, A->val, x, y, dotv, partials);
 }
 
+bool csr_spmv_has_skip(const psp_csr *A) {
+  Variant v = decode_variant(A->variant);
+  if (!v.w2 || A->max_row_nnz > v.tile / 2) return false;
+  ChunkTable *t;
+  if (get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t) != PSP_OK) return false;
+  if (ensure_rowoff(A, t) != PSP_OK) return false;
+  return t->np != 0;
+}
+
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
-                    double *partials, int *nparts) {
+                    double *partials, int *nparts, const int *skip) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
@@ -987,15 +997,15 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
 #define PSP_W2(WT, NP, WPB)                                                                       \
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, WPB>), dim3(grid), dim3(64 * WPB), 0, stream(), 0,      \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
-                     A->col, A->val, x, y, dotv, pbuf)
+                     A->col, A->val, x, y, dotv, pbuf, skip)
 #define PSP_W2_NT(WT, NP)                                                                          \
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, true, false>), dim3(grid), dim3(256), 0, stream(), 0,  \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
-                     A->col, A->val, x, y, dotv, pbuf)
+                     A->col, A->val, x, y, dotv, pbuf, skip)
 #define PSP_W2_NS(WT, NP)                                                                          \
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, false, true>), dim3(grid), dim3(256), 0, stream(), 0,  \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
-                     A->col, A->val, x, y, dotv, pbuf)
+                     A->col, A->val, x, y, dotv, pbuf, skip)
 #define PSP_W2_WPB(WT, NP) do { if (v.nt) PSP_W2_NT(WT, NP); else if (v.full_grid) PSP_W2_NS(WT, NP); else if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
 #define PSP_W2_NP(WT) do { if (t->np == 2) PSP_W2_WPB(WT, 2); else if (t->np == 3) PSP_W2_WPB(WT, 3); else PSP_W2_WPB(WT, 4); } while (0)
       if (v.tile == 512) PSP_W2_NP(512); else PSP_W2_NP(1024);
@@ -1107,7 +1117,7 @@ static void launch_w2_range(const psp_csr *A, const ChunkTable *t, int stripe, i
   }
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4>), dim3(grid), dim3(256), 0, stream(), c0, c1, colmask(),
                      stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, A->col, A->val, x, y,
-                     dotv, pbuf);
+                     dotv, pbuf, (const int *)nullptr);
 }
 
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,

@@ -113,6 +113,14 @@ struct psp_jacobi {
 };
 
 namespace psp {
+// Device-resident scalar state of the asynchronous PCG loop (psp_solvers.hip): the kernels
+// of one iteration read alpha / beta / status from here instead of from host arguments, so
+// the host can enqueue many iterations without synchronising.
+struct PcgDev {
+  double rho, rho1, alpha, beta, normr, tolb, n2b, relres;
+  int status;  // 0 running, 1 finished (every later kernel is a no-op)
+  int info, iter, stag;
+};
 // y = op(x) on device vectors; y must not alias x
 int op_apply(const psp_op *op, const double *x_dev, double *y_dev);
 // the csr that a native operator multiplies with (csr, or sss->full); nullptr otherwise
@@ -123,7 +131,9 @@ inline psp_csr *op_native_csr(const psp_op *op) {
   return nullptr;
 }
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
-                    double *partials, int *nparts);
+                    double *partials, int *nparts, const int *skip = nullptr);
+// true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
+bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx);

@@ -16,7 +16,10 @@
 //   generic  any other operator pair (host callbacks = user-defined Python matvec/precon,
 //            jacobi with steps > 1): same kernels with an explicit z vector; callback
 //            operators are bridged with one D2H + one H2D copy per application.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <mutex>
 #include <utility>
@@ -29,9 +32,10 @@ using namespace psp;
 namespace psp {
 int k_dot(long n, const double *x, const double *y, double *partials, int *nparts);
 int k_residual(long n, const double *b, double *r, const double *dinv, double *partials, int *nparts);
-int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p);
+int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p,
+              const PcgDev *st = nullptr);
 int k_xr_update(long n, double alpha, const double *p, const double *q, const double *dinv,
-                double *x, double *r, double *partials, int *nparts);
+                double *x, double *r, double *partials, int *nparts, const PcgDev *st = nullptr);
 int k_jacobi_first(long n, const double *x, const double *dinv, double *y);
 int k_jacobi_sweep(long n, const double *x, const double *dinv, const double *temp, double *y);
 int k_dinv(long n, const double *diag, double omega, double *dinv, double *partials, int *nparts);
@@ -169,6 +173,154 @@ int op_apply(const psp_op *op, const double *x_dev, double *y_dev) {
 
 // ====================================================================== PCG
 
+// ---------------------------------------------------------------------- asynchronous PCG
+//
+// Same algorithm and the same kernels as pcg_device's fused path, but alpha, beta and the
+// exit tests of pcg.c:100-162 are evaluated by one-thread kernels on the device, and a
+// `status` word turns every later launch into a no-op once the loop has ended.  The host
+// enqueues kBatch iterations, then reads the 96-byte state once: two host round trips per
+// ITERATION become one per BATCH (matters when an iteration is shorter than ~1 ms).
+
+__device__ __forceinline__ void pcg_finish(PcgDev *st, int code, int iter) {
+  st->status = 1;
+  st->info = code;
+  st->iter = iter;
+  st->relres = st->normr / st->n2b;  // pcg.c:166
+}
+
+// after q = A p and the p.q reduction: pcg.c:117-125
+__global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal, int it) {
+  if (st->status) return;
+  const double pq = scal[0];
+  if (pq == 0.0) {
+    pcg_finish(st, -6, it);
+    return;
+  }
+  const double alpha = st->rho / pq;
+  st->alpha = alpha;
+  if (alpha == 0.0) st->stag = 1;
+}
+
+// after the x/r update and its reductions: pcg.c:127-162 for iteration `it`, then the head
+// of iteration it+1 (pcg.c:99-112)
+__global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, int it, int maxit,
+                              double *__restrict__ hist) {
+  if (st->status) return;
+  if (st->stag == 0) st->stag = (scal[2] == 0.0) ? 1 : 0;
+  const double normr = sqrt(scal[0]);
+  st->normr = normr;
+  if (hist) hist[it] = normr;
+  if (normr <= st->tolb) {
+    pcg_finish(st, 0, it);
+  } else if (st->stag == 1) {
+    pcg_finish(st, -5, it);
+  } else if (it == maxit) {
+    pcg_finish(st, -1, maxit + 1);  // pcg.c:165: the loop ran out
+  } else {
+    const double rho1 = st->rho, rho = scal[1];
+    st->rho1 = rho1;
+    st->rho = rho;
+    if (rho == 0.0) {
+      pcg_finish(st, -2, it + 1);
+    } else {
+      const double beta = rho / rho1;
+      if (beta == 0.0)
+        pcg_finish(st, -6, it + 1);
+      else
+        st->beta = beta;
+    }
+  }
+}
+
+static int pcg_async_enabled() {
+  static const int on = [] {
+    const char *e = getenv("PSP_PCG_ASYNC");
+    return e ? atoi(e) : 1;
+  }();
+  return on;
+}
+
+// runs iterations 1..maxit; on entry r = b - A x, rho0 = r.z != 0, normr0 > tolb
+static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
+                          double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
+                          int *info, int *iter, double *relres, double *hist) {
+  constexpr int kBatch = 16;
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  PcgDev *st = nullptr;
+  PcgDev *hst = nullptr;
+  double *hist_dev = nullptr;
+  PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
+  hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
+  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
+  if (e != hipSuccess) {
+    (void)hipFree(st);
+    if (hst) (void)hipHostFree(hst);
+    return fail(PSP_ENOMEM, "pcg: state allocation failed: %s", hipGetErrorString(e));
+  }
+  int rc = PSP_OK;
+  if (hist_dev) (void)hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)maxit + 1), stream());  // NaN
+  memset(hst, 0, sizeof(PcgDev));
+  hst->rho = rho0;
+  hst->rho1 = 1.0;
+  hst->normr = normr0;
+  hst->tolb = tolb;
+  hst->n2b = n2b;
+#define PCG_TRY(call)            \
+  do {                           \
+    rc = (call);                 \
+    if (rc != PSP_OK) goto done; \
+  } while (0)
+#define PCG_HIP(call)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      rc = fail(PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_));              \
+      goto done;                                                                  \
+    }                                                                             \
+  } while (0)
+  PCG_HIP(hipMemcpyAsync(st, hst, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
+  {
+    int it = 1, np;
+    while (true) {
+      const int last = std::min(maxit, it + kBatch - 1);
+      for (; it <= last; ++it) {
+        PCG_TRY(k_pupdate(n, r, dinv, 0.0, it == 1, p, st));
+        PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
+        PCG_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
+        hipLaunchKernelGGL(pcg_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev, it);
+        PCG_TRY(k_xr_update(n, 0.0, p, q, dinv, x, r, w->partials, &np, st));
+        PCG_TRY(finish_partials(w->partials, np, 3, w->scal_dev + 4));
+        hipLaunchKernelGGL(pcg_scalar_xr, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, it, maxit,
+                           hist_dev);
+      }
+      PCG_HIP(hipGetLastError());
+      PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
+      PCG_HIP(hipStreamSynchronize(stream()));
+      if (hst->status || it > maxit) break;
+    }
+    if (!hst->status) {  // cannot happen: the last iteration always finishes the state
+      rc = fail(PSP_ENODEV, "pcg: asynchronous loop ended without a status");
+      goto done;
+    }
+    *info = hst->info;
+    *iter = hst->iter;
+    *relres = hst->relres;
+    if (hist) {
+      const int cnt = std::min(hst->iter, maxit);
+      if (cnt >= 1)
+        PCG_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    }
+  }
+done:
+#undef PCG_TRY
+#undef PCG_HIP
+  (void)hipFree(st);
+  (void)hipHostFree(hst);
+  if (hist_dev) (void)hipFree(hist_dev);
+  return rc;
+}
+
 static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
                       double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
   Workspace *w;
@@ -216,6 +368,17 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
     *relres = normr / n2b;
     *iter = 0;
     return PSP_OK;
+  }
+
+  if (fused && maxit >= 1 && pcg_async_enabled() && csr_spmv_has_skip(Acsr)) {
+    if (rho_next == 0.0) {  // pcg.c:101-104 in iteration 1
+      *info = -2;
+      *iter = 1;
+      *relres = normr / n2b;
+      return PSP_OK;
+    }
+    return pcg_async_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter,
+                          relres, hist);
   }
 
   double rho = 1.0, rho1, beta = 0.0, alpha, pq;

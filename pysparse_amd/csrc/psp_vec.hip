@@ -120,7 +120,12 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(long n, const double *
 template <int V, bool PRE, bool FIRST>
 __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *__restrict__ r,
                                                          const double *__restrict__ dinv,
-                                                         double beta, double *__restrict__ p) {
+                                                         double beta, double *__restrict__ p,
+                                                         const PcgDev *__restrict__ dstate) {
+  if (dstate) {  // asynchronous loop: scalars live on the device
+    if (dstate->status) return;
+    beta = dstate->beta;
+  }
   PSP_VEC_LOOP(i, n) {
     Pack<V> z = ld<V>(r, i);
     if constexpr (PRE) {
@@ -143,7 +148,11 @@ template <int V, bool PRE>
 __global__ __launch_bounds__(kBlock) void xr_update_kernel(
     long n, double alpha, const double *__restrict__ p, const double *__restrict__ q,
     const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r,
-    double *__restrict__ partials) {
+    double *__restrict__ partials, const PcgDev *__restrict__ dstate) {
+  if (dstate) {
+    if (dstate->status) return;
+    alpha = dstate->alpha;
+  }
   double acc[3] = {0.0, 0.0, 0.0};
   double dmax = 0.0;
   const double malpha = -alpha;
@@ -402,14 +411,15 @@ int k_residual(long n, const double *b, double *r, const double *dinv, double *p
   return PSP_OK;
 }
 
-int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p) {
+int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p,
+              const PcgDev *dstate) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   const bool v2 = dinv ? can_vec2(n, r, p, dinv) : can_vec2(n, r, p);
 #define L(V, PRE, FIRST)                                                                  \
   hipLaunchKernelGGL((pupdate_kernel<V, PRE, FIRST>), dim3(grid), dim3(kBlock), 0, stream(), n, \
-                     r, dinv, beta, p)
+                     r, dinv, beta, p, dstate)
   if (dinv) {
     if (first) { if (v2) L(2, true, true); else L(1, true, true); }
     else { if (v2) L(2, true, false); else L(1, true, false); }
@@ -423,14 +433,14 @@ int k_pupdate(long n, const double *r, const double *dinv, double beta, bool fir
 }
 
 int k_xr_update(long n, double alpha, const double *p, const double *q, const double *dinv,
-                double *x, double *r, double *partials, int *nparts) {
+                double *x, double *r, double *partials, int *nparts, const PcgDev *dstate) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   const bool v2 = dinv ? can_vec2(n, p, q, x, r, dinv) : can_vec2(n, p, q, x, r);
 #define L(V, PRE)                                                                          \
   hipLaunchKernelGGL((xr_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
-                     alpha, p, q, dinv, x, r, partials)
+                     alpha, p, q, dinv, x, r, partials, dstate)
   if (dinv) { if (v2) L(2, true); else L(1, true); }
   else { if (v2) L(2, false); else L(1, false); }
 #undef L
@@ -588,7 +598,7 @@ int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv
 
 int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double beta, int first,
                   double *p_dev) {
-  return k_pupdate(n, r_dev, dinv_dev, beta, first != 0, p_dev);
+  return k_pupdate(n, r_dev, dinv_dev, beta, first != 0, p_dev, nullptr);
 }
 
 int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
@@ -631,7 +641,7 @@ int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_de
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
-  PSP_TRY(k_xr_update(n, alpha, p_dev, q_dev, dinv_dev, x_dev, r_dev, w->partials, &np));
+  PSP_TRY(k_xr_update(n, alpha, p_dev, q_dev, dinv_dev, x_dev, r_dev, w->partials, &np, nullptr));
   return finish_partials(w->partials, np, 3, out_dev);
 }
 
