@@ -265,7 +265,7 @@ def main():
             "pcg_effective_GBps": pcg_bytes(n_tot, nnz_tot) / pcg_s_per_iter / 1e9,
             "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k},
             "roofline": {
-                "bound": "hbm", "kernel": "csr_spmv_w1", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": "csr_spmv_w2", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes(n_loc, nnz_loc), "avg_launch_ms": kern_ms,
             },

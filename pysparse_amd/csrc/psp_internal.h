@@ -41,7 +41,7 @@ constexpr int kSlots = 4;
 constexpr int kFold = 1024;
 // streaming vector kernels: one workgroup per contiguous span of kVecSpan elements
 // (non-persistent grids measured faster than grid-stride loops on MI355X, profiles/)
-constexpr int kVecSpan = 1024;
+constexpr int kVecSpan = 512;  // one 16-byte access per lane per array: measured best (profiles/)
 
 struct Workspace {
   double *partials = nullptr;   // kSlots * kMaxParts doubles (device)

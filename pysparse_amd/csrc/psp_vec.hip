@@ -142,39 +142,72 @@ __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *_
   }
 }
 
-// ---- stagnation scan + x += alpha p, r -= alpha q (pcg.c:127-143); partials
-//      {r.r, r.z, nonstag}: nonstag = 1 for a workgroup whose local dmax has 1 + dmax != 1
-template <int V, bool PRE>
-__global__ __launch_bounds__(kBlock) void xr_update_kernel(
-    long n, double alpha, const double *__restrict__ p, const double *__restrict__ q,
-    const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r,
-    double *__restrict__ partials, const PcgDev *__restrict__ dstate) {
+// ---- pcg.c:127-152 as TWO streaming kernels.  One fused pass over x, p, r, q, dinv (7 HBM
+//      streams) measured 1.39 ms at n = 2^27; the two passes below (3 and 4 streams, the same
+//      56 n bytes in total) take 0.54 + 0.74 ms (profiles/r1_vec_kernels.txt).
+//      x_update: stagnation scan (:127-139) + x += alpha p (:141); partial slot 2 = nonstag
+//      (1 for a workgroup whose local dmax has 1 + dmax != 1)
+template <int V>
+__global__ __launch_bounds__(kBlock) void x_update_kernel(long n, double alpha,
+                                                          const double *__restrict__ p,
+                                                          double *__restrict__ x,
+                                                          double *__restrict__ partials,
+                                                          const PcgDev *__restrict__ dstate) {
   if (dstate) {
     if (dstate->status) return;
     alpha = dstate->alpha;
   }
-  double acc[3] = {0.0, 0.0, 0.0};
   double dmax = 0.0;
+  const bool upd = alpha != 0.0;
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> pp = ld<V>(p, i);
+    Pack<V> xx = ld<V>(x, i);
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      // pcg.c:128-137, branch-free: x != 0 -> ddum = |alpha*p/x| (a NaN never replaces dmax,
+      // like `if (ddum > dmax)`); x == 0 and p != 0 -> the reference ASSIGNS dmax = 1.0, which
+      // for the test 1 + dmax == 1 is equivalent to max(dmax, 1.0)
+      const double quot = fabs(alpha * pp.v[u] / xx.v[u]);
+      const double ddum = (xx.v[u] != 0.0) ? quot : ((pp.v[u] != 0.0) ? 1.0 : 0.0);
+      dmax = (ddum > dmax) ? ddum : dmax;
+      // daxpy (pcg.c:141) returns without touching y when the scalar is zero (netlib /
+      // OpenBLAS quick return), which matters when p holds inf/NaN
+      if (upd) xx.v[u] = xx.v[u] + alpha * pp.v[u];
+    }
+    st<V>(x, i, xx);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(dmax, off, 64);
+    if (o > dmax) dmax = o;
+  }
+  double acc[1];
+  acc[0] = ((threadIdx.x & 63) == 0 && (1.0 + dmax != 1.0)) ? 1.0 : 0.0;
+  block_reduce_store<1>(acc, partials + 2 * (size_t)kMaxParts);
+}
+
+//      r_update: r -= alpha q (:142-143); partial slots 0, 1 = {r.r, r.z}, z = dinv.*r or r
+template <int V, bool PRE>
+__global__ __launch_bounds__(kBlock) void r_update_kernel(long n, double alpha,
+                                                          const double *__restrict__ q,
+                                                          const double *__restrict__ dinv,
+                                                          double *__restrict__ r,
+                                                          double *__restrict__ partials,
+                                                          const PcgDev *__restrict__ dstate) {
+  if (dstate) {
+    if (dstate->status) return;
+    alpha = dstate->alpha;
+  }
+  double acc[2] = {0.0, 0.0};
   const double malpha = -alpha;
   const bool upd = alpha != 0.0;
   PSP_VEC_LOOP(i, n) {
-    const Pack<V> pp = ld<V>(p, i), qq = ld<V>(q, i);
-    Pack<V> xx = ld<V>(x, i), rr = ld<V>(r, i);
+    const Pack<V> qq = ld<V>(q, i);
+    Pack<V> rr = ld<V>(r, i);
     Pack<V> dd;
     if constexpr (PRE) dd = ld<V>(dinv, i);
 #pragma unroll
     for (int u = 0; u < V; ++u) {
-      if (xx.v[u] != 0.0) {
-        const double ddum = fabs(alpha * pp.v[u] / xx.v[u]);
-        if (ddum > dmax) dmax = ddum;
-      } else if (pp.v[u] != 0.0) {
-        // the reference ASSIGNS dmax = 1.0 here (pcg.c:136); for the test 1+dmax == 1
-        // that is equivalent to max(dmax, 1.0)
-        if (1.0 > dmax) dmax = 1.0;
-      }
-      // daxpy (pcg.c:141-143) returns without touching y when the scalar is zero
-      // (netlib/OpenBLAS quick return), which matters when p or q hold inf/NaN
-      if (upd) xx.v[u] = xx.v[u] + alpha * pp.v[u];
       const double t = upd ? rr.v[u] + malpha * qq.v[u] : rr.v[u];
       rr.v[u] = t;
       acc[0] += t * t;
@@ -183,18 +216,10 @@ __global__ __launch_bounds__(kBlock) void xr_update_kernel(
         acc[1] += t * z;
       }
     }
-    st<V>(x, i, xx);
     st<V>(r, i, rr);
   }
   if constexpr (!PRE) acc[1] = acc[0];
-  // block max of dmax
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(dmax, off, 64);
-    if (o > dmax) dmax = o;
-  }
-  acc[2] = ((threadIdx.x & 63) == 0 && (1.0 + dmax != 1.0)) ? 1.0 : 0.0;
-  block_reduce_store<3>(acc, partials);
+  block_reduce_store<2>(acc, partials);
 }
 
 // ---- Jacobi: y = x.*dinv (preconmodule.c:41-42)
@@ -437,10 +462,17 @@ int k_xr_update(long n, double alpha, const double *p, const double *q, const do
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
-  const bool v2 = dinv ? can_vec2(n, p, q, x, r, dinv) : can_vec2(n, p, q, x, r);
-#define L(V, PRE)                                                                          \
-  hipLaunchKernelGGL((xr_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
-                     alpha, p, q, dinv, x, r, partials, dstate)
+  if (can_vec2(n, p, x))
+    hipLaunchKernelGGL(x_update_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, alpha, p, x,
+                       partials, dstate);
+  else
+    hipLaunchKernelGGL(x_update_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, alpha, p, x,
+                       partials, dstate);
+  PSP_LAUNCH_CHECK();
+  const bool v2 = dinv ? can_vec2(n, q, r, dinv) : can_vec2(n, q, r);
+#define L(V, PRE)                                                                         \
+  hipLaunchKernelGGL((r_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
+                     alpha, q, dinv, r, partials, dstate)
   if (dinv) { if (v2) L(2, true); else L(1, true); }
   else { if (v2) L(2, false); else L(1, false); }
 #undef L

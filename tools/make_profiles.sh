@@ -32,14 +32,14 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
     for c, v in acc.items():
         vals[c] = sum(v) / len(v)
 with open(os.path.join(out, "spmv_pmc_summary.txt"), "w") as g:
-    g.write("# rocprofv3 --pmc averages per launch, csr_spmv_w1, 7-pt Poisson 512^3 (tools/prof_spmv.py)\n")
+    g.write("# rocprofv3 --pmc averages per launch, csr_spmv_w2 (default variant), 7-pt Poisson 512^3 (tools/prof_spmv.py)\n")
     for c in sorted(vals):
         g.write("%-36s %18.1f\n" % (c, vals[c]))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports exactly half of the bytes of a
     # wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE (KB) is exact
     hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    json.dump({"kernel": "csr_spmv_w1", "workload": "7-pt Poisson 512^3", "FETCH_SIZE_KB": vals["FETCH_SIZE"],
+    json.dump({"kernel": "csr_spmv_w2", "workload": "7-pt Poisson 512^3", "FETCH_SIZE_KB": vals["FETCH_SIZE"],
                "WRITE_SIZE_KB": vals["WRITE_SIZE"], "fetch_correction": 2.0,
                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 13939769348,
                "note": "L2<->fabric request bytes (Infinity-Cache hits included), not DRAM-only"},
