@@ -486,6 +486,18 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w1(
 // every load of a wave -- val, col, row offsets, table entry -- is issued at wave start
 // and the only dependent level left is col -> x.  HBM traffic: 2*E bytes per chunk (384 B
 // for the 7-point operator, ~2.6 B/row) instead of 4 B/row of `ind`.
+// interleave col/val into 768-byte tiles of 64 nonzeros (see csr_spmv_w2<..., PACKED>)
+__global__ __launch_bounds__(256) void pack_kernel(long count, const int *__restrict__ col,
+                                                   const double *__restrict__ val,
+                                                   char *__restrict__ packed) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) {
+    char *tile = packed + (size_t)(k >> 6) * 768;
+    const int o = (int)(k & 63);
+    *reinterpret_cast<int *>(tile + o * 4) = col[k];
+    *reinterpret_cast<double *>(tile + 256 + o * 8) = val[k];
+  }
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void build_rowoff_kernel(int nchunks, int target,
                                                            const int2 *__restrict__ tab,
@@ -509,7 +521,9 @@ __global__ void max_chunk_rows_kernel(int nchunks, const int2 *__restrict__ tab,
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-template <int WT, int NP, int WPB, bool NTL = false, bool NTS = false>
+// PACKED: val/col come from ONE interleaved stream (tiles of 64 nonzeros: 256 B of column
+// indices followed by 512 B of values) instead of two arrays -- fewer concurrent HBM streams
+template <int WT, int NP, int WPB, bool NTL = false, bool NTS = false, bool PACKED = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     int chunk0, int nchunks, int colmask, int stripe, int target, int kmax, const int2 *__restrict__ tab,
     const unsigned short *__restrict__ rowoff, const int *__restrict__ col,
@@ -539,9 +553,17 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
     for (int st = 0; st < STEPS; ++st) {
       int k = kb + (st * 64 + lane) * 4;
       k = (k < kmax) ? k : kmax;
-      c[st] = ldg<NTL>(reinterpret_cast<const i4v *>(col + k));
-      v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k));
-      v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k + 2));
+      if constexpr (PACKED) {
+        const char *tile = reinterpret_cast<const char *>(val) + (size_t)(k >> 6) * 768;
+        const int o = k & 63;
+        c[st] = *reinterpret_cast<const i4v *>(tile + o * 4);
+        v0[st] = *reinterpret_cast<const d2v *>(tile + 256 + o * 8);
+        v1[st] = *reinterpret_cast<const d2v *>(tile + 256 + o * 8 + 16);
+      } else {
+        c[st] = ldg<NTL>(reinterpret_cast<const i4v *>(col + k));
+        v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k));
+        v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k + 2));
+      }
     }
     const unsigned short *ro = rowoff + (size_t)chunk * E;
     int lo[NP], hi[NP];
@@ -834,6 +856,7 @@ struct CsrExtra {
   std::map<std::pair<int, int>, SplitInfo> split;  // (row_a, row_b) -> interior chunk range
   double *big_partials = nullptr;  // one slot per workgroup of the full-grid SpMV
   int big_cap = 0;
+  char *packed = nullptr;          // interleaved col/val tiles (PACKED variants)
 };
 
 }  // namespace psp
@@ -919,6 +942,22 @@ static int ensure_rowoff(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+static int ensure_packed(const psp_csr *A, char **out) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  psp::CsrExtra &ex = g_extra[A];
+  if (ex.packed == nullptr) {
+    const size_t ntiles = (A->padded + 63) / 64 + 1;
+    PSP_HIP(hipMalloc((void **)&ex.packed, ntiles * 768));
+    PSP_HIP(hipMemsetAsync(ex.packed, 0, ntiles * 768, stream()));
+    const int grid = (int)std::min<size_t>((A->padded + 255) / 256, 65536);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, stream(), (long)A->padded, A->col, A->val,
+                       ex.packed);
+    PSP_LAUNCH_CHECK();
+  }
+  *out = ex.packed;
+  return PSP_OK;
+}
+
 namespace psp {
 
 // tuning aid: PSP_SPMV_COLMASK=<int> ANDs every gathered column index (wrong results, used
@@ -992,6 +1031,8 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       PSP_TRY(ensure_rowoff(A, t));
       if (t->np == 0) v.w2 = false;
     }
+    char *packed = nullptr;
+    if (v.w2 && v.layout == 1) PSP_TRY(ensure_packed(A, &packed));
     if (v.w2) {
       if (v.wpb > 8) v.wpb = 8;
 #define PSP_W2(WT, NP, WPB)                                                                       \
@@ -1006,13 +1047,18 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, false, true>), dim3(grid), dim3(256), 0, stream(), 0,  \
                      t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
                      A->col, A->val, x, y, dotv, pbuf, skip)
-#define PSP_W2_WPB(WT, NP) do { if (v.nt) PSP_W2_NT(WT, NP); else if (v.full_grid) PSP_W2_NS(WT, NP); else if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
+#define PSP_W2_PK(WT, NP)                                                                          \
+  hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4, false, true, true>), dim3(grid), dim3(256), 0, stream(), 0, \
+                     t->nchunks, colmask(), stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, \
+                     A->col, reinterpret_cast<const double *>(packed), x, y, dotv, pbuf, skip)
+#define PSP_W2_WPB(WT, NP) do { if (packed) PSP_W2_PK(WT, NP); else if (v.nt) PSP_W2_NT(WT, NP); else if (v.full_grid) PSP_W2_NS(WT, NP); else if (v.wpb == 4) PSP_W2(WT, NP, 4); else PSP_W2(WT, NP, 8); } while (0)
 #define PSP_W2_NP(WT) do { if (t->np == 2) PSP_W2_WPB(WT, 2); else if (t->np == 3) PSP_W2_WPB(WT, 3); else PSP_W2_WPB(WT, 4); } while (0)
       if (v.tile == 512) PSP_W2_NP(512); else PSP_W2_NP(1024);
 #undef PSP_W2_NP
 #undef PSP_W2_WPB
 #undef PSP_W2_NT
 #undef PSP_W2_NS
+#undef PSP_W2_PK
 #undef PSP_W2
     } else {
 #define PSP_W1(WT, WPB, LAY, NT)                                                                 \
@@ -1326,6 +1372,7 @@ int psp_csr_destroy(psp_csr_t *A) {
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
       }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
+      if (it->second.packed) (void)hipFree(it->second.packed);
       g_extra.erase(it);
     }
   }
