@@ -13,6 +13,7 @@ namespace psp {
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 hipStream_t stream();
+hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
 
 #define PSP_HIP(call)                                                                    \
@@ -120,6 +121,8 @@ struct PcgDev {
   double rho, rho1, alpha, beta, normr, tolb, n2b, relres;
   int status;  // 0 running, 1 finished (every later kernel is a no-op)
   int info, iter, stag;
+  int it;      // iteration the enqueued kernels are working on (1-based), advanced on the device
+  int maxit;
 };
 // y = op(x) on device vectors; y must not alias x
 int op_apply(const psp_op *op, const double *x_dev, double *y_dev);

@@ -26,6 +26,11 @@ int fail(int code, const char *fmt, ...) {
 const char *last_error() { return g_err.c_str(); }
 
 hipStream_t stream() { return g_stream; }
+hipStream_t swap_stream(hipStream_t s) {
+  hipStream_t old = g_stream;
+  g_stream = s;
+  return old;
+}
 
 int ensure_device() {
   if (g_dev_state == 1) return PSP_OK;

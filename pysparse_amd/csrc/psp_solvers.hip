@@ -189,11 +189,11 @@ __device__ __forceinline__ void pcg_finish(PcgDev *st, int code, int iter) {
 }
 
 // after q = A p and the p.q reduction: pcg.c:117-125
-__global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal, int it) {
+__global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
   if (st->status) return;
   const double pq = scal[0];
   if (pq == 0.0) {
-    pcg_finish(st, -6, it);
+    pcg_finish(st, -6, st->it);
     return;
   }
   const double alpha = st->rho / pq;
@@ -203,9 +203,9 @@ __global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal, int i
 
 // after the x/r update and its reductions: pcg.c:127-162 for iteration `it`, then the head
 // of iteration it+1 (pcg.c:99-112)
-__global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, int it, int maxit,
-                              double *__restrict__ hist) {
+__global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
   if (st->status) return;
+  const int it = st->it;
   if (st->stag == 0) st->stag = (scal[2] == 0.0) ? 1 : 0;
   const double normr = sqrt(scal[0]);
   st->normr = normr;
@@ -214,12 +214,13 @@ __global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, int i
     pcg_finish(st, 0, it);
   } else if (st->stag == 1) {
     pcg_finish(st, -5, it);
-  } else if (it == maxit) {
-    pcg_finish(st, -1, maxit + 1);  // pcg.c:165: the loop ran out
+  } else if (it == st->maxit) {
+    pcg_finish(st, -1, it + 1);  // pcg.c:165: the loop ran out
   } else {
     const double rho1 = st->rho, rho = scal[1];
     st->rho1 = rho1;
     st->rho = rho;
+    st->it = it + 1;
     if (rho == 0.0) {
       pcg_finish(st, -2, it + 1);
     } else {
@@ -240,16 +241,48 @@ static int pcg_async_enabled() {
   return on;
 }
 
-// runs iterations 1..maxit; on entry r = b - A x, rho0 = r.z != 0, normr0 > tolb
+static int pcg_graph_enabled() {
+  static const int on = [] {
+    const char *e = getenv("PSP_PCG_GRAPH");
+    return e ? atoi(e) : 1;
+  }();
+  return on;
+}
+
+// one batch = kBatch iterations' worth of launches on the library stream; every kernel takes
+// its scalars (and the iteration number) from the device state, so all batches are identical
+static int pcg_enqueue_batch(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
+                             double *q, PcgDev *st, double *hist_dev, int batch) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  for (int i = 0; i < batch; ++i) {
+    PSP_TRY(k_pupdate(n, r, dinv, 0.0, false, p, st));
+    PSP_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
+    PSP_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
+    hipLaunchKernelGGL(pcg_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev);
+    PSP_TRY(k_xr_update(n, 0.0, p, q, dinv, x, r, w->partials, &np, st));
+    PSP_TRY(finish_partials(w->partials, np, 3, w->scal_dev + 4));
+    hipLaunchKernelGGL(pcg_scalar_xr, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, hist_dev);
+  }
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+// runs iterations 1..maxit; on entry r = b - A x, rho0 = r.z != 0, normr0 > tolb.
+// The first batch is launched directly (it also performs the lazy table builds of the SpMV);
+// when more batches are needed the batch is captured ONCE into a hipGraph and replayed.
 static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
                           double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
                           int *info, int *iter, double *relres, double *hist) {
   constexpr int kBatch = 16;
-  Workspace *w;
-  PSP_TRY(workspace(&w));
   PcgDev *st = nullptr;
   PcgDev *hst = nullptr;
   double *hist_dev = nullptr;
+  hipStream_t own = nullptr, prev = nullptr;
+  bool swapped = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
   PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
   hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
   if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
@@ -259,62 +292,82 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
     return fail(PSP_ENOMEM, "pcg: state allocation failed: %s", hipGetErrorString(e));
   }
   int rc = PSP_OK;
-  if (hist_dev) (void)hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)maxit + 1), stream());  // NaN
+#define PCG_TRY(call)            \
+  do {                           \
+    rc = (call);                 \
+    if (rc != PSP_OK) goto done; \
+  } while (0)
+#define PCG_HIP(call)                                                \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) {                                          \
+      rc = fail(PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_)); \
+      goto done;                                                     \
+    }                                                                \
+  } while (0)
+  if (hist_dev) PCG_HIP(hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)maxit + 1), stream()));  // NaN
   memset(hst, 0, sizeof(PcgDev));
   hst->rho = rho0;
   hst->rho1 = 1.0;
   hst->normr = normr0;
   hst->tolb = tolb;
   hst->n2b = n2b;
-#define PCG_TRY(call)            \
-  do {                           \
-    rc = (call);                 \
-    if (rc != PSP_OK) goto done; \
-  } while (0)
-#define PCG_HIP(call)                                                             \
-  do {                                                                            \
-    hipError_t e_ = (call);                                                       \
-    if (e_ != hipSuccess) {                                                       \
-      rc = fail(PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_));              \
-      goto done;                                                                  \
-    }                                                                             \
-  } while (0)
+  hst->it = 1;
+  hst->maxit = maxit;
   PCG_HIP(hipMemcpyAsync(st, hst, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
-  {
-    int it = 1, np;
-    while (true) {
-      const int last = std::min(maxit, it + kBatch - 1);
-      for (; it <= last; ++it) {
-        PCG_TRY(k_pupdate(n, r, dinv, 0.0, it == 1, p, st));
-        PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
-        PCG_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
-        hipLaunchKernelGGL(pcg_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev, it);
-        PCG_TRY(k_xr_update(n, 0.0, p, q, dinv, x, r, w->partials, &np, st));
-        PCG_TRY(finish_partials(w->partials, np, 3, w->scal_dev + 4));
-        hipLaunchKernelGGL(pcg_scalar_xr, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, it, maxit,
-                           hist_dev);
+  PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, std::min(kBatch, maxit)));
+  PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
+  PCG_HIP(hipStreamSynchronize(stream()));
+  if (!hst->status) {
+    // more batches: replay a captured graph (capture needs a non-null stream)
+    bool use_graph = pcg_graph_enabled() != 0;
+    if (use_graph) {
+      if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) {
+        prev = swap_stream(own);
+        swapped = true;
+        if (hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int brc = pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, kBatch);
+          const hipError_t ce = hipStreamEndCapture(own, &graph);
+          if (brc != PSP_OK || ce != hipSuccess || graph == nullptr ||
+              hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            exec = nullptr;
+          }
+        }
+        if (exec == nullptr) {  // capture not possible here: fall back to direct launches
+          (void)hipGetLastError();
+          swap_stream(prev);
+          swapped = false;
+        }
       }
-      PCG_HIP(hipGetLastError());
+      use_graph = exec != nullptr;
+    }
+    while (!hst->status) {
+      if (use_graph)
+        PCG_HIP(hipGraphLaunch(exec, stream()));
+      else
+        PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, kBatch));
       PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
       PCG_HIP(hipStreamSynchronize(stream()));
-      if (hst->status || it > maxit) break;
     }
-    if (!hst->status) {  // cannot happen: the last iteration always finishes the state
-      rc = fail(PSP_ENODEV, "pcg: asynchronous loop ended without a status");
-      goto done;
-    }
-    *info = hst->info;
-    *iter = hst->iter;
-    *relres = hst->relres;
-    if (hist) {
-      const int cnt = std::min(hst->iter, maxit);
-      if (cnt >= 1)
-        PCG_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
-    }
+  }
+  *info = hst->info;
+  *iter = hst->iter;
+  *relres = hst->relres;
+  if (hist) {
+    const int cnt = std::min(hst->iter, maxit);
+    if (cnt >= 1)
+      PCG_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
   }
 done:
 #undef PCG_TRY
 #undef PCG_HIP
+  if (swapped) {
+    (void)hipStreamSynchronize(own);
+    swap_stream(prev);
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  if (own) (void)hipStreamDestroy(own);
   (void)hipFree(st);
   (void)hipHostFree(hst);
   if (hist_dev) (void)hipFree(hist_dev);

@@ -116,15 +116,18 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(long n, const double *
   block_reduce_store<2>(acc, partials);
 }
 
-// ---- p = z + beta*p (pcg.c:113-114) or p = z (pcg.c:106); z = dinv.*r or r
+// ---- p = z + beta*p (pcg.c:113-114) or p = z (pcg.c:106); z = dinv.*r or r.
+//      With a device state the "first iteration" decision is taken on the device (it == 1).
 template <int V, bool PRE, bool FIRST>
 __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *__restrict__ r,
                                                          const double *__restrict__ dinv,
                                                          double beta, double *__restrict__ p,
                                                          const PcgDev *__restrict__ dstate) {
+  bool first = FIRST;
   if (dstate) {  // asynchronous loop: scalars live on the device
     if (dstate->status) return;
     beta = dstate->beta;
+    first = dstate->it == 1;
   }
   PSP_VEC_LOOP(i, n) {
     Pack<V> z = ld<V>(r, i);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *_
 #pragma unroll
       for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dd.v[u];
     }
-    if constexpr (!FIRST) {
+    if (!first) {
       const Pack<V> pp = ld<V>(p, i);
 #pragma unroll
       for (int u = 0; u < V; ++u) z.v[u] = z.v[u] + beta * pp.v[u];

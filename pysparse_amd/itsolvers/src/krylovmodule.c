@@ -17,27 +17,22 @@
 
 #include "psp_pyops.h"
 
-typedef int (*solver_fn)(const psp_op_t *, const psp_op_t *, int, double *, const double *, double,
-                         int, int *, int *, double *, double *);
+/* which kernel run_solver dispatches to */
+enum { SOLVER_PCG, SOLVER_MINRES, SOLVER_CGS, SOLVER_BICGSTAB, SOLVER_QMRS, SOLVER_GMRES };
 
-typedef int (*solver_fn10)(const psp_op_t *, const psp_op_t *, int, double *, const double *, double,
-                           int, int *, int *, double *);
-static solver_fn10 g_fn10; /* solver without history argument, set by the thin wrappers below */
-static int g_gmres_dim;
-
-static int call_fn10(const psp_op_t *A, const psp_op_t *K, int n, double *x, const double *b,
-                     double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
-  (void)hist;
-  return g_fn10(A, K, n, x, b, tol, maxit, info, iter, relres);
+static int dispatch(int which, int gmres_dim, const psp_op_t *A, const psp_op_t *K, int n, double *x,
+                    const double *b, double tol, int maxit, int *info, int *iter, double *relres) {
+  switch (which) {
+    case SOLVER_PCG: return psp_pcg(A, K, n, x, b, tol, maxit, info, iter, relres, NULL);
+    case SOLVER_MINRES: return psp_minres(A, K, n, x, b, tol, maxit, info, iter, relres, NULL);
+    case SOLVER_CGS: return psp_cgs(A, K, n, x, b, tol, maxit, info, iter, relres);
+    case SOLVER_BICGSTAB: return psp_bicgstab(A, K, n, x, b, tol, maxit, info, iter, relres);
+    case SOLVER_QMRS: return psp_qmrs(A, K, n, x, b, tol, maxit, info, iter, relres);
+    default: return psp_gmres(A, K, n, x, b, tol, maxit, gmres_dim, info, iter, relres);
+  }
 }
 
-static int call_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x, const double *b,
-                      double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
-  (void)hist;
-  return psp_gmres(A, K, n, x, b, tol, maxit, g_gmres_dim, info, iter, relres);
-}
-
-static PyObject *run_solver(PyObject *args, solver_fn fn, int check_positive_shape) {
+static PyObject *run_solver(PyObject *args, int which, int gmres_dim, int check_positive_shape) {
   PyObject *amat, *bo, *xo, *precon = Py_None;
   PyArrayObject *b = NULL, *x = NULL;
   double tol, relres = 0.0;
@@ -83,12 +78,12 @@ static PyObject *run_solver(PyObject *args, solver_fn fn, int check_positive_sha
   }
 
   if (aref.is_callback || (have_k && kref.is_callback)) {
-    rc = fn(aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
-            (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres, NULL);
+    rc = dispatch(which, gmres_dim, aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
+                  (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres);
   } else {
     Py_BEGIN_ALLOW_THREADS
-    rc = fn(aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
-            (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres, NULL);
+    rc = dispatch(which, gmres_dim, aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
+                  (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres);
     Py_END_ALLOW_THREADS
   }
   if (PyErr_Occurred()) goto done; /* a callback raised (itsolversmodule.c:114-115) */
@@ -107,33 +102,30 @@ done:
   return result;
 }
 
-static PyObject *ItSolvers_pcg(PyObject *self, PyObject *args) { return run_solver(args, psp_pcg, 0); }
+static PyObject *ItSolvers_pcg(PyObject *self, PyObject *args) {
+  return run_solver(args, SOLVER_PCG, 0, 0);
+}
 
 static PyObject *ItSolvers_minres(PyObject *self, PyObject *args) {
-  return run_solver(args, psp_minres, 1);
+  return run_solver(args, SOLVER_MINRES, 0, 1);
 }
 
-/* the module is single-threaded under the GIL up to the point where run_solver releases it,
- * and the selector variables are read before that */
 static PyObject *ItSolvers_cgs(PyObject *self, PyObject *args) {
-  g_fn10 = psp_cgs;
-  return run_solver(args, call_fn10, 1);
+  return run_solver(args, SOLVER_CGS, 0, 1);
 }
 static PyObject *ItSolvers_bicgstab(PyObject *self, PyObject *args) {
-  g_fn10 = psp_bicgstab;
-  return run_solver(args, call_fn10, 0);
+  return run_solver(args, SOLVER_BICGSTAB, 0, 0);
 }
 static PyObject *ItSolvers_qmrs(PyObject *self, PyObject *args) {
-  g_fn10 = psp_qmrs;
-  return run_solver(args, call_fn10, 1);
+  return run_solver(args, SOLVER_QMRS, 0, 1);
 }
 /* gmres(A, b, x, tol, maxit[, K[, dim=20]]): itsolversmodule.c:313-403 */
 static PyObject *ItSolvers_gmres(PyObject *self, PyObject *args) {
   Py_ssize_t na = PyTuple_GET_SIZE(args);
   PyObject *core, *res;
-  g_gmres_dim = 20;
+  int dim = 20;
   if (na == 7) {
-    g_gmres_dim = (int)PyLong_AsLong(PyTuple_GET_ITEM(args, 6));
+    dim = (int)PyLong_AsLong(PyTuple_GET_ITEM(args, 6));
     if (PyErr_Occurred()) return NULL;
     core = PyTuple_GetSlice(args, 0, 6);
   } else {
@@ -141,7 +133,7 @@ static PyObject *ItSolvers_gmres(PyObject *self, PyObject *args) {
     Py_INCREF(core);
   }
   if (core == NULL) return NULL;
-  res = run_solver(core, call_gmres, 1);
+  res = run_solver(core, SOLVER_GMRES, dim, 1);
   Py_DECREF(core);
   return res;
 }
