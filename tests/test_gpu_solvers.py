@@ -375,3 +375,27 @@ def test_minres_poisson_vs_oracle(oracle, p2d):
     x = np.zeros(n)
     info, it, relres = minres(D, b, x, 1e-14, 5)
     assert (info, it) == (-1, 5) == oracle.minres(A, b, np.zeros(n), 1e-14, 5)[:2]
+
+
+def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
+    """host-scalar loop (PSP_PCG_ASYNC=0), device-scalar loop (default) and its hipGraph replay
+    (PSP_PCG_GRAPH=1) are the same algorithm: identical info / iteration counts / iterates."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);"
+        "from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg;"
+        "D = DeviceCSR.poisson(100, 100); n = 10000; x = np.zeros(n);"
+        "r = pcg(D, np.ones(n), x, 1e-8, 2000, DeviceJacobi(D), hist=True);"
+        "print(json.dumps([r[0], r[1], r[2], float(x[0]), float(x[n // 2]), float(np.nansum(r[3]))]))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    cases, _ = golden
+    for o in outs:
+        assert (o[0], o[1]) == (0, cases["G2"]["iter"])
+    assert outs[0] == outs[1] == outs[2]  # bitwise: same kernels, same reduction order
