@@ -805,7 +805,8 @@ Variant decode_variant(int v) {
 }
 
 int alloc_csr(int nrows, int ncols, long nnz, psp_csr **out) {
-  if (nrows < 0 || ncols < 0 || nnz < 0 || nnz > 0x7fffffffL)
+  // the kernels index nonzeros with 32-bit ints up to one tile past nnz
+  if (nrows < 0 || ncols < 0 || nnz < 0 || nnz > 0x7fffffffL - 8192)
     return fail(PSP_EINVAL, "csr: invalid shape (%d x %d, nnz %ld)", nrows, ncols, nnz);
   PSP_TRY(ensure_device());
   psp_csr *A = new psp_csr();
