@@ -532,8 +532,10 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
   constexpr int STEPS = WT / 256;
   constexpr int E = 64 * NP;
   if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
+  // exactly 32 KiB for 4 waves x 1024 products: five workgroups fit the CU's 160 KiB (a separate
+  // array for the dot partials would cost the fifth)
   __shared__ double prod_all[WPB * WT];
-  __shared__ double red[WPB];
+  double *red = prod_all;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *prod = prod_all + wid * WT;
@@ -616,6 +618,231 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
   }
   if (partials) {
     dsum = wave_sum(dsum);
+    __syncthreads();  // red[] lives in wave 0's slice: every wave must be done with its rows
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < WPB; ++i) t += red[i];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ w3: x staged in LDS
+//
+// What holds csr_spmv_w2 at ~70 % is not HBM but the per-CU L1: every x gather instruction
+// touches ~20 cache lines (counters: TCP busy 92 %, a third of the cycles in pending-miss
+// stalls).  w3 takes the gathers off the L1.  Per chunk the builder below lists the
+// distinct 128-byte blocks of x (16 doubles) that the chunk's nonzeros reference -- for a
+// banded operator a handful of short windows -- and rewrites the chunk's column indices as
+// 16-bit offsets into that list.  The wave then
+//   1. issues the val stream, the 16-bit columns, the row offsets and the block list
+//      (all independent, fixed-stride addresses),
+//   2. loads the listed x blocks with fully coalesced 16-byte-per-lane loads (8 lanes per
+//      block, 8 blocks per instruction) and parks them in its LDS slice,
+//   3. gathers x from LDS, overwrites the slice with the rounded products, and
+//   4. reduces rows left to right exactly like w2 (same products, same order => the
+//      same bits as csr_mat.c:49-54).
+// HBM traffic per nonzero drops from 12 to 10 bytes (+ 4*NB bytes of block list per
+// chunk), L1 requests per chunk from ~400 lines to ~150.  Matrices whose chunks reference
+// more than NB blocks stay on w2.
+typedef unsigned short us4v __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, int write,
+                                                      const int2 *__restrict__ tab,
+                                                      const int *__restrict__ col,
+                                                      int *__restrict__ blist,
+                                                      unsigned short *__restrict__ col16,
+                                                      int *__restrict__ maxblocks) {
+  constexpr int WT = 1024;
+  constexpr int kNone = 0x7fffffff;
+  __shared__ int keys[WT];
+  __shared__ int ulist[WT];
+  const int chunk = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (chunk >= nchunks) return;
+  const int s = tab[chunk].y, e = tab[chunk + 1].y;
+  const long kb = (long)chunk * target;
+  for (int i = lane; i < WT; i += 64) {
+    const long k = kb + i;
+    keys[i] = (k >= s && k < e) ? (col[k] >> 4) : kNone;
+  }
+  __syncthreads();
+  // bitonic sort of the 1024 block ids
+  for (int size = 2; size <= WT; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < WT / 2; t += 64) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const bool up = (i & size) == 0;
+        const int a = keys[i], b = keys[j];
+        if ((a > b) == up) {
+          keys[i] = b;
+          keys[j] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // distinct ids, in ascending order
+  int count = 0;
+  for (int base = 0; base < WT; base += 64) {
+    const int i = base + lane;
+    const int k = keys[i];
+    const bool flag = k != kNone && (i == 0 || k != keys[i - 1]);
+    const unsigned long long bal = __ballot(flag);
+    const int pos = count + __popcll(bal & ((1ull << lane) - 1ull));
+    if (flag) ulist[pos] = k;
+    count += __popcll(bal);
+  }
+  __syncthreads();
+  if (lane == 0) atomicMax(maxblocks, count);
+  if (!write || count > NB) return;
+  for (int i = lane; i < NB; i += 64)
+    blist[(size_t)chunk * NB + i] = count ? ulist[i < count ? i : count - 1] : 0;
+  for (int i = lane; i < WT; i += 64) {
+    const long k = kb + i;
+    unsigned short v = 0;
+    if (k >= s && k < e) {
+      const int c = col[k];
+      const int b = c >> 4;
+      int lo = 0, hi = count - 1;  // b is in ulist[0, count)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ulist[mid] < b)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      v = (unsigned short)(lo * 16 + (c & 15));
+    }
+    col16[(size_t)chunk * WT + i] = v;
+  }
+}
+
+template <int NP, int NB, int WPB, bool NTS>
+__global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
+    int chunk0, int nchunks, int stripe, int target, int kmax, int ncols,
+    const int2 *__restrict__ tab, const unsigned short *__restrict__ rowoff,
+    const unsigned short *__restrict__ col16, const int *__restrict__ blist,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+  constexpr int WT = 1024;
+  constexpr int STEPS = WT / 256;
+  constexpr int E = 64 * NP;
+  constexpr int XW = NB * 16;             // doubles in the x window
+  constexpr int LW = XW > WT ? XW : WT;   // the products overwrite the window
+  constexpr int XL = NB / 8;              // 16-byte x loads per lane
+  static_assert(NB == 32 || NB == 64 || NB == 128, "block list is read one or two entries per lane");
+  if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
+  __shared__ double lds_all[WPB * LW];  // 32 KiB at NB <= 64: five workgroups per CU
+  double *red = lds_all;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *buf = lds_all + wid * LW;
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int chunk = chunk0 + vb * WPB + wid;  // chunks [chunk0, nchunks) belong to this launch
+  double dsum = 0.0;
+  if (chunk < nchunks) {
+    const int kb = chunk * target;
+    // --- independent loads: values, 16-bit columns, row offsets, block list, table entry
+    d2v v0[STEPS], v1[STEPS];
+    us4v c[STEPS];
+    const unsigned short *cp = col16 + (size_t)chunk * WT;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      int k = kb + (st * 64 + lane) * 4;
+      k = (k < kmax) ? k : kmax;
+      v0[st] = *reinterpret_cast<const d2v *>(val + k);
+      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
+      c[st] = *reinterpret_cast<const us4v *>(cp + (st * 64 + lane) * 4);
+    }
+    const int *bl = blist + (size_t)chunk * NB;
+    const int blk0 = bl[NB == 32 ? (lane & 31) : lane];
+    int blk1 = 0;
+    if constexpr (NB == 128) blk1 = bl[64 + lane];
+    const unsigned short *ro = rowoff + (size_t)chunk * E;
+    int lo[NP], hi[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      lo[m] = ro[i];
+      hi[m] = ro[i + 1 < E ? i + 1 : E - 1];
+    }
+    const int r0 = tab[chunk].x;
+    const int nr = tab[chunk + 1].x - r0;
+    // --- the chunk's x blocks: 8 lanes per 128-byte block, 8 blocks per load instruction
+    d2v xw[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int src = (j & 7) * 8 + (lane >> 3);
+      const int b = __shfl((NB == 128 && j >= 8) ? blk1 : blk0, src, 64);
+      const long e0 = (long)b * 16 + (lane & 7) * 2;
+      if (e0 + 1 < ncols) {
+        xw[j] = *reinterpret_cast<const d2v *>(x + e0);
+      } else {  // the block that holds the end of x
+        xw[j].x = e0 < ncols ? x[e0] : 0.0;
+        xw[j].y = 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < XL; ++j) *reinterpret_cast<d2v *>(&buf[(j * 64 + lane) * 2]) = xw[j];
+    // LDS operations of one wave execute in order; the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- gathers from LDS, then the products take the window's place
+    d2v p0[STEPS], p1[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      p0[st].x = v0[st].x * buf[c[st].x];
+      p0[st].y = v0[st].y * buf[c[st].y];
+      p1[st].x = v1[st].x * buf[c[st].z];
+      p1[st].y = v1[st].y * buf[c[st].w];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int off = (st * 64 + lane) * 4;
+      *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
+      *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- one lane per row, products added left to right (reference order, csr_mat.c:49-54)
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      if (i < nr) {
+        double acc = 0.0;
+        for (int k = lo[m]; k < hi[m]; k += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int idx = k + u;
+            idx = idx < WT ? idx : WT - 1;
+            t[u] = buf[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
+        }
+        if constexpr (NTS)
+          __builtin_nontemporal_store(acc, &y[r0 + i]);
+        else
+          y[r0 + i] = acc;
+        if (dotv) dsum += dotv[r0 + i] * acc;
+      }
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    __syncthreads();  // red[] lives in wave 0's slice: every wave must be done with its rows
     if (lane == 0) red[wid] = dsum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -756,7 +983,10 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 
 // csr_spmv_w2: tile 1024, 4 waves per workgroup, non-temporal y stores, XCD stripe 64
 // (profiles/r1_spmv_w2_sweep.txt: stripes 48/64/96 within 0.5 %, 0 and >= 192 about 1-3 % slower)
-constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8);
+// bit 20: csr_spmv_w3 (x windows staged in LDS, 16-bit chunk-local columns) where the matrix
+// qualifies (profiles/r1_spmv_w3*.txt)
+constexpr int kW3Bit = 1 << 20;
+constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8) + kW3Bit;
 
 struct Variant {
   int tile, vec;
@@ -767,6 +997,7 @@ struct Variant {
   bool w1, w2;
   int layout, wpb;
   int stripe;
+  bool w3;
 };
 
 Variant decode_variant(int v) {
@@ -776,6 +1007,7 @@ Variant decode_variant(int v) {
   Variant r;
   // bits 8-19: workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order)
   r.stripe = (v >> 8) & 0xfff;
+  const bool w3bit = (v & kW3Bit) != 0;
   v &= 0xff;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
@@ -801,6 +1033,8 @@ Variant decode_variant(int v) {
   r.wpb = 4 << ((v >> 4) & 3);
   if (r.wpb > 16) r.wpb = 16;
   if (r.w1) r.tile = (v & 4) ? 512 : 1024;
+  // w3 rides on the w2 tables (tile 1024, 4 waves per workgroup)
+  r.w3 = w3bit && r.w2 && r.tile == 1024 && r.layout == 0;
   return r;
 }
 
@@ -843,6 +1077,12 @@ struct ChunkTable {
   int max_rows = -1;  // most rows in one chunk (-1: not computed yet)
   int np = 0;         // passes of 64 rows (0: chunk too tall for w2)
   unsigned short *rowoff = nullptr;
+  // csr_spmv_w3: per chunk the 128-byte x blocks it references (fixed stride nb) and the
+  // chunk's columns as 16-bit offsets into that list (fixed stride 1024)
+  int nb = -1;        // -1: not examined yet, 0: some chunk needs too many blocks
+  int max_blocks = 0;
+  int *blist = nullptr;
+  unsigned short *col16 = nullptr;
 };
 static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
 
@@ -943,6 +1183,66 @@ static int ensure_rowoff(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+// block lists + 16-bit columns of csr_spmv_w3 (built on first use; needs the w2 tables)
+static int w3_nb_cap() {
+  static const int cap = [] {
+    const char *e = getenv("PSP_SPMV_W3_NB");  // largest block list tried (32 / 64 / 128), 0 = never
+    return e ? atoi(e) : 64;
+  }();
+  return cap;
+}
+
+static int ensure_w3(const psp_csr *A, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (t->nb >= 0) return PSP_OK;
+  t->nb = 0;
+  if (t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
+  int *d_max;
+  PSP_HIP(hipMalloc((void **)&d_max, sizeof(int)));
+  PSP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), stream()));
+  // pass 1: most distinct x blocks referenced by one chunk
+  hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
+                     0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
+  PSP_LAUNCH_CHECK();
+  int mb = 0;
+  PSP_HIP(hipMemcpyAsync(&mb, d_max, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  t->max_blocks = mb;
+  const int cap = w3_nb_cap();
+  int nb = 0;
+  if (mb <= 32 && cap >= 32) nb = 32;
+  else if (mb <= 64 && cap >= 64) nb = 64;
+  else if (mb <= 128 && cap >= 128) nb = 128;
+  if (nb == 0) {
+    PSP_HIP(hipFree(d_max));
+    return PSP_OK;
+  }
+  hipError_t e1 = hipMalloc((void **)&t->blist, sizeof(int) * (size_t)t->nchunks * nb);
+  hipError_t e2 = hipMalloc((void **)&t->col16, sizeof(unsigned short) * (size_t)t->nchunks * 1024);
+  if (e1 != hipSuccess || e2 != hipSuccess) {  // no room for the extra tables: stay on w2
+    (void)hipGetLastError();
+    if (e1 == hipSuccess) (void)hipFree(t->blist);
+    if (e2 == hipSuccess) (void)hipFree(t->col16);
+    t->blist = nullptr;
+    t->col16 = nullptr;
+    (void)hipFree(d_max);
+    return PSP_OK;
+  }
+  // pass 2: write the tables
+#define PSP_BUILD_W3(NB)                                                                          \
+  hipLaunchKernelGGL(build_w3_kernel<NB>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks,     \
+                     t->target, 1, t->tab, A->col, t->blist, t->col16, d_max)
+  if (nb == 32) PSP_BUILD_W3(32);
+  else if (nb == 64) PSP_BUILD_W3(64);
+  else PSP_BUILD_W3(128);
+#undef PSP_BUILD_W3
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_max));
+  t->nb = nb;
+  return PSP_OK;
+}
+
 static int ensure_packed(const psp_csr *A, char **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
@@ -985,6 +1285,37 @@ static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab,
                            const double *x, double *y, const double *dotv, double *partials) {
   hipLaunchKernelGGL((csr_spmv_stream<TILE, VEC, NT>), dim3(grid), dim3(kBlock), 0, stream(),
                      nchunks, map_mode, colmask(), tab, A->ind, A->col, A->val, x, y, dotv, partials);
+}
+
+// csr_spmv_w3 over chunks [c0, c1) (the whole matrix: 0, nchunks)
+template <int NP, int NB>
+static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
+                            int c1, const double *x, double *y, const double *dotv, double *pbuf,
+                            const int *skip) {
+  if (nts)
+    hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
+                       t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
+                       A->val, x, y, dotv, pbuf, skip);
+  else
+    hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, false>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
+                       t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
+                       A->val, x, y, dotv, pbuf, skip);
+}
+
+template <int NP>
+static void launch_w3_np(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
+                         int c1, const double *x, double *y, const double *dotv, double *pbuf,
+                         const int *skip) {
+  if (t->nb == 32) launch_w3_np_nb<NP, 32>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else if (t->nb == 64) launch_w3_np_nb<NP, 64>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else launch_w3_np_nb<NP, 128>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+}
+
+static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0, int c1,
+                      const double *x, double *y, const double *dotv, double *pbuf, const int *skip) {
+  if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
 }
 
 bool csr_spmv_has_skip(const psp_csr *A) {
@@ -1031,6 +1362,22 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     if (v.w2) {
       PSP_TRY(ensure_rowoff(A, t));
       if (t->np == 0) v.w2 = false;
+    }
+    if (v.w2 && v.w3) {
+      PSP_TRY(ensure_w3(A, t));
+      if (t->nb > 0) {
+        launch_w3(A, t, v.full_grid, grid, stripe, 0, t->nchunks, x, y, dotv, pbuf, skip);
+        PSP_LAUNCH_CHECK();
+        int np = grid;
+        if (pbuf != partials) {
+          np = kFold;
+          hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
+                             partials, np);
+          PSP_LAUNCH_CHECK();
+        }
+        if (nparts) *nparts = np;
+        return PSP_OK;
+      }
     }
     char *packed = nullptr;
     if (v.w2 && v.layout == 1) PSP_TRY(ensure_packed(A, &packed));
@@ -1153,13 +1500,17 @@ static int chunk_lower_bound(const ChunkTable *t, int row, int *out) {
 }
 
 template <int WT, int NP>
-static void launch_w2_range(const psp_csr *A, const ChunkTable *t, int stripe, int c0, int c1,
+static void launch_w2_range(const psp_csr *A, const ChunkTable *t, bool w3, int stripe, int c0, int c1,
                             const double *x, double *y, const double *dotv, double *pbuf, int *grid_out) {
   int grid = (c1 - c0 + 3) / 4;
   if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
   *grid_out = grid;
   if (c1 <= c0) {
     *grid_out = 0;
+    return;
+  }
+  if (w3) {
+    launch_w3(A, t, false, grid, stripe, c0, c1, x, y, dotv, pbuf, nullptr);
     return;
   }
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4>), dim3(grid), dim3(256), 0, stream(), c0, c1, colmask(),
@@ -1177,6 +1528,11 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
     PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
     PSP_TRY(ensure_rowoff(A, t));
     ok = t->np != 0;
+  }
+  bool w3 = false;
+  if (ok && v.w3) {
+    PSP_TRY(ensure_w3(A, t));
+    w3 = t->nb > 0;
   }
   if (!ok) {  // no split possible with this kernel variant: exchange first, then everything
     if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
@@ -1225,13 +1581,13 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
 #define PSP_RANGE(C0, C1, OFF, G)                                                              \
   do {                                                                                         \
     if (v.tile == 512) {                                                                       \
-      if (t->np == 2) launch_w2_range<512, 2>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else if (t->np == 3) launch_w2_range<512, 3>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else launch_w2_range<512, 4>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      if (t->np == 2) launch_w2_range<512, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else if (t->np == 3) launch_w2_range<512, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else launch_w2_range<512, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
     } else {                                                                                   \
-      if (t->np == 2) launch_w2_range<1024, 2>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else if (t->np == 3) launch_w2_range<1024, 3>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else launch_w2_range<1024, 4>(A, t, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      if (t->np == 2) launch_w2_range<1024, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else if (t->np == 3) launch_w2_range<1024, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      else launch_w2_range<1024, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
     }                                                                                          \
     PSP_LAUNCH_CHECK();                                                                        \
   } while (0)
@@ -1371,6 +1727,8 @@ int psp_csr_destroy(psp_csr_t *A) {
       for (auto &t : it->second.t) {
         if (t.second.tab) (void)hipFree(t.second.tab);
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
+        if (t.second.blist) (void)hipFree(t.second.blist);
+        if (t.second.col16) (void)hipFree(t.second.col16);
       }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
       if (it->second.packed) (void)hipFree(it->second.packed);
