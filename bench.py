@@ -242,11 +242,16 @@ def main():
         value = spmv_bytes(n_tot, nnz_tot) / (wall / a.steps) / 1e9
         kern_ms = ev_ms / a.steps
         achieved = spmv_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
+        kernel = (A.A if use_dist else A).kernel_info()[0]
+        # HBM traffic of one launch from the committed rocprofv3 --pmc passes of the same kernel
+        # on the same workload (tools/make_profiles.sh; counters cannot be read in-process)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r1_spmv_pmc.json")
         if os.path.exists(pmc) and world == 1 and not a.grid:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("kernel") == kernel:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
         out = {
@@ -265,7 +270,7 @@ def main():
             "pcg_effective_GBps": pcg_bytes(n_tot, nnz_tot) / pcg_s_per_iter / 1e9,
             "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k},
             "roofline": {
-                "bound": "hbm", "kernel": "csr_spmv_w2", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes(n_loc, nnz_loc), "avg_launch_ms": kern_ms,
             },

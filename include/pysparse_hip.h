@@ -119,6 +119,14 @@ int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev);
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev);
 /* kernel tuning knob for A/B measurements: variant < 0 restores the default */
 int psp_csr_set_variant(psp_csr_t *A, int variant);
+/* workgroup schedule of the SpMV (tuning / tests; results never depend on it): strip_rows < 0
+ * automatic (plane-sweeping order for wide-band operators such as the 7-point stencil), 0 natural
+ * row order, > 0 plane-sweeping with that many rows per strip regardless of the matrix size */
+int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
+/* which kernel y := A x runs for this handle (builds its tables if needed): name, and
+ * info[4] = {x blocks per chunk list (w3), most x blocks one chunk references, schedule active,
+ * half band width used by the schedule} */
+int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
 /* bytes of device memory held by the handle */
 int64_t psp_csr_device_bytes(const psp_csr_t *A);
 

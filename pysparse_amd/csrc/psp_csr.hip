@@ -728,7 +728,8 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const int2 *__restrict__ tab, const unsigned short *__restrict__ rowoff,
     const unsigned short *__restrict__ col16, const int *__restrict__ blist,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
+    const int *__restrict__ perm) {
   constexpr int WT = 1024;
   constexpr int STEPS = WT / 256;
   constexpr int E = 64 * NP;
@@ -743,13 +744,15 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *buf = lds_all + wid * LW;
   int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
-  if (stripe > 0) {
+  if (perm) {
+    vb = perm[vb];  // plane-sweeping schedule (build_schedule); < 0: padding slot
+  } else if (stripe > 0) {
     const int k = vb >> 3;
     vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
   }
   const int chunk = chunk0 + vb * WPB + wid;  // chunks [chunk0, nchunks) belong to this launch
   double dsum = 0.0;
-  if (chunk < nchunks) {
+  if (vb >= 0 && chunk < nchunks) {
     const int kb = chunk * target;
     // --- independent loads: values, 16-bit columns, row offsets, block list, table entry
     d2v v0[STEPS], v1[STEPS];
@@ -998,6 +1001,7 @@ struct Variant {
   int layout, wpb;
   int stripe;
   bool w3;
+  bool sched;
 };
 
 Variant decode_variant(int v) {
@@ -1008,6 +1012,7 @@ Variant decode_variant(int v) {
   // bits 8-19: workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order)
   r.stripe = (v >> 8) & 0xfff;
   const bool w3bit = (v & kW3Bit) != 0;
+  const bool nosched = (v & (1 << 21)) != 0;
   v &= 0xff;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
@@ -1035,6 +1040,7 @@ Variant decode_variant(int v) {
   if (r.w1) r.tile = (v & 4) ? 512 : 1024;
   // w3 rides on the w2 tables (tile 1024, 4 waves per workgroup)
   r.w3 = w3bit && r.w2 && r.tile == 1024 && r.layout == 0;
+  r.sched = r.w3 && !nosched;  // bit 21: keep the natural order + XCD stripes
   return r;
 }
 
@@ -1083,6 +1089,11 @@ struct ChunkTable {
   int max_blocks = 0;
   int *blist = nullptr;
   unsigned short *col16 = nullptr;
+  // plane-sweeping workgroup schedule (build_schedule): launch slot -> workgroup, or absent
+  int sched_state = -1;  // -1 not examined, 0 none (natural order + XCD stripes), 1 present
+  int sched_grid = 0;
+  int *perm = nullptr;
+  int half_band = 0;
 };
 static int get_chunk_table(psp_csr *A, int tile, ChunkTable **out);
 
@@ -1243,6 +1254,113 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+// ---- plane-sweeping schedule -------------------------------------------------------------
+// A banded operator whose half band width D is large (the 7-point stencil: D = nx*ny rows)
+// touches every x line from three places D rows apart; in row order those are ~2*D*88 bytes
+// of streaming apart, far more than an XCD's 4 MiB L2, so the line is fetched over the fabric
+// three times (counters: 13.2 GB read per launch at 512^3 against 11.2 GB of distinct bytes,
+// and w3 runs AT the fabric's streaming rate, so those bytes are time).  The schedule makes
+// each XCD own "strips" -- the rows whose index modulo D falls in one interval of ~8 K rows --
+// and walk a strip period by period (plane by plane): the three uses of a line then fall
+// within two strip-planes (~1.5 MiB of streaming) of the same L2.  It is a permutation of
+// workgroups only (launch slot -> workgroup, dealt so that slot % 8, the XCD, owns whole
+// strips); any value of D gives correct results, a poor one only a poor order.
+__global__ void band_kernel(int nrows, const int *__restrict__ ind, const int *__restrict__ col,
+                            int *__restrict__ out) {
+  int lo = 0x7fffffff, hi = -0x7fffffff;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    const int a = ind[r], b = ind[r + 1];
+    if (b > a) {  // columns ascend within a row
+      lo = min(lo, col[a] - r);
+      hi = max(hi, col[b - 1] - r);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_down(lo, off, 64));
+    hi = max(hi, __shfl_down(hi, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(out, lo);
+    atomicMax(out + 1, hi);
+  }
+}
+
+static int sched_strip_rows() {
+  static const int v = [] {
+    // rows per strip-plane; 0 = natural order.  Default OFF: measured on MI355X at 512^3 the
+    // schedule cuts fabric reads from 13.2 to 11.3 GB per launch (L2 hits 29 M -> 44 M) and is
+    // 0.5-10 % SLOWER -- the re-fetches it removes were Infinity-Cache hits, and DRAM bytes, not
+    // fabric bytes, bound the kernel (profiles/r1_spmv_w3_schedule.txt)
+    const char *e = getenv("PSP_SPMV_STRIP_ROWS");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+static int ensure_schedule(const psp_csr *A, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (t->sched_state >= 0) return PSP_OK;
+  t->sched_state = 0;
+  const bool forced = A->sched_strip_rows >= 0;  // psp_csr_set_schedule: no size heuristics
+  const int strip_rows = forced ? A->sched_strip_rows : sched_strip_rows();
+  const int nwg = (t->nchunks + 3) / 4;
+  if (strip_rows <= 0 || A->nrows < 1 || (!forced && nwg < 4096)) return PSP_OK;
+  int *d_band;
+  PSP_HIP(hipMalloc((void **)&d_band, 2 * sizeof(int)));
+  const int init[2] = {0x7fffffff, -0x7fffffff};
+  PSP_HIP(hipMemcpyAsync(d_band, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  hipLaunchKernelGGL(band_kernel, dim3(std::min((A->nrows + 255) / 256, 4096)), dim3(256), 0, stream(),
+                     A->nrows, A->ind, A->col, d_band);
+  PSP_LAUNCH_CHECK();
+  int band[2];
+  PSP_HIP(hipMemcpyAsync(band, d_band, sizeof(band), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_band));
+  if (band[1] < band[0]) return PSP_OK;
+  // half the span of (col - row): independent of a constant column shift (ghost-extended slabs)
+  const long D = ((long)band[1] - band[0]) / 2;
+  t->half_band = (int)D;
+  // worth it only when the natural order cannot keep a period in one L2 (D rows * ~88 B >> 1 MiB)
+  // and the matrix spans several periods
+  if (D < 1 || (!forced && (D < 4L * strip_rows || D > A->nrows / 3))) return PSP_OK;
+  long nstrips = (D + strip_rows / 2) / strip_rows;
+  nstrips = (nstrips + 7) / 8 * 8;  // whole strips per XCD
+  const double w = (double)D / (double)nstrips;
+  // first row of every workgroup (4 consecutive chunks)
+  std::vector<int2> tab((size_t)t->nchunks + 1);
+  PSP_HIP(hipMemcpy(tab.data(), t->tab, sizeof(int2) * tab.size(), hipMemcpyDeviceToHost));
+  struct Key {
+    int strip, period, wg;
+  };
+  std::vector<Key> keys((size_t)nwg);
+  for (int g = 0; g < nwg; ++g) {
+    const long r0 = tab[(size_t)g * 4].x;
+    long strip = (long)((double)(r0 % D) / w);
+    if (strip >= nstrips) strip = nstrips - 1;
+    keys[g] = {(int)strip, (int)(r0 / D), g};
+  }
+  std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+    if (a.strip != b.strip) return a.strip < b.strip;
+    if (a.period != b.period) return a.period < b.period;
+    return a.wg < b.wg;
+  });
+  // XCD j (= slot % 8) walks the j-th eighth of the sorted list
+  const int per = (nwg + 7) / 8;
+  const int grid = per * 8;
+  std::vector<int> perm((size_t)grid, -1);
+  for (int j = 0; j < 8; ++j)
+    for (int p = 0; p < per; ++p) {
+      const long src = (long)j * per + p;
+      if (src < nwg) perm[(size_t)p * 8 + j] = keys[(size_t)src].wg;
+    }
+  PSP_HIP(hipMalloc((void **)&t->perm, sizeof(int) * (size_t)grid));
+  PSP_HIP(hipMemcpy(t->perm, perm.data(), sizeof(int) * (size_t)grid, hipMemcpyHostToDevice));
+  t->sched_grid = grid;
+  t->sched_state = 1;
+  return PSP_OK;
+}
+
 static int ensure_packed(const psp_csr *A, char **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
@@ -1291,31 +1409,32 @@ static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab,
 template <int NP, int NB>
 static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
                             int c1, const double *x, double *y, const double *dotv, double *pbuf,
-                            const int *skip) {
+                            const int *skip, const int *perm) {
   if (nts)
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip);
+                       A->val, x, y, dotv, pbuf, skip, perm);
   else
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, false>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip);
+                       A->val, x, y, dotv, pbuf, skip, perm);
 }
 
 template <int NP>
 static void launch_w3_np(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
                          int c1, const double *x, double *y, const double *dotv, double *pbuf,
-                         const int *skip) {
-  if (t->nb == 32) launch_w3_np_nb<NP, 32>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
-  else if (t->nb == 64) launch_w3_np_nb<NP, 64>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
-  else launch_w3_np_nb<NP, 128>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+                         const int *skip, const int *perm) {
+  if (t->nb == 32) launch_w3_np_nb<NP, 32>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+  else if (t->nb == 64) launch_w3_np_nb<NP, 64>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+  else launch_w3_np_nb<NP, 128>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
 }
 
 static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0, int c1,
-                      const double *x, double *y, const double *dotv, double *pbuf, const int *skip) {
-  if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
-  else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
-  else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+                      const double *x, double *y, const double *dotv, double *pbuf, const int *skip,
+                      const int *perm = nullptr) {
+  if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+  else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+  else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
 }
 
 bool csr_spmv_has_skip(const psp_csr *A) {
@@ -1342,9 +1461,27 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   ChunkTable *t;
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
   if (v.w1) {
+    if (v.w3) v.wpb = 4;
     int grid = (t->nchunks + v.wpb - 1) / v.wpb;
     const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
     if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
+    if (v.w2) {
+      PSP_TRY(ensure_rowoff(A, t));
+      if (t->np == 0) v.w2 = false;
+    }
+    bool use_w3 = false;
+    const int *perm = nullptr;
+    if (v.w2 && v.w3) {
+      PSP_TRY(ensure_w3(A, t));
+      use_w3 = t->nb > 0;
+      if (use_w3 && v.sched) {
+        PSP_TRY(ensure_schedule(A, t));
+        if (t->sched_state == 1) {
+          perm = t->perm;
+          grid = t->sched_grid;
+        }
+      }
+    }
     double *pbuf = partials;
     psp::CsrExtra *ex = nullptr;
     if (partials && grid > kMaxParts) {
@@ -1359,25 +1496,18 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       }
       pbuf = ex->big_partials;
     }
-    if (v.w2) {
-      PSP_TRY(ensure_rowoff(A, t));
-      if (t->np == 0) v.w2 = false;
-    }
-    if (v.w2 && v.w3) {
-      PSP_TRY(ensure_w3(A, t));
-      if (t->nb > 0) {
-        launch_w3(A, t, v.full_grid, grid, stripe, 0, t->nchunks, x, y, dotv, pbuf, skip);
+    if (use_w3) {
+      launch_w3(A, t, v.full_grid, grid, stripe, 0, t->nchunks, x, y, dotv, pbuf, skip, perm);
+      PSP_LAUNCH_CHECK();
+      int np = grid;
+      if (pbuf != partials) {
+        np = kFold;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
+                           partials, np);
         PSP_LAUNCH_CHECK();
-        int np = grid;
-        if (pbuf != partials) {
-          np = kFold;
-          hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
-                             partials, np);
-          PSP_LAUNCH_CHECK();
-        }
-        if (nparts) *nparts = np;
-        return PSP_OK;
       }
+      if (nparts) *nparts = np;
+      return PSP_OK;
     }
     char *packed = nullptr;
     if (v.w2 && v.layout == 1) PSP_TRY(ensure_packed(A, &packed));
@@ -1729,6 +1859,7 @@ int psp_csr_destroy(psp_csr_t *A) {
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
         if (t.second.blist) (void)hipFree(t.second.blist);
         if (t.second.col16) (void)hipFree(t.second.col16);
+        if (t.second.perm) (void)hipFree(t.second.perm);
       }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
       if (it->second.packed) (void)hipFree(it->second.packed);
@@ -1829,6 +1960,58 @@ int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t i
 
 int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host) {
   return psp_csr_matvec_transp_stride(A, x_host, 1, y_host, 1);
+}
+
+int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
+  if (!A) return fail(PSP_EINVAL, "psp_csr_set_schedule: NULL handle");
+  A->sched_strip_rows = strip_rows;
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  auto it = g_extra.find(A);
+  if (it != g_extra.end())
+    for (auto &t : it->second.t) {  // rebuilt on the next product
+      if (t.second.perm) (void)hipFree(t.second.perm);
+      t.second.perm = nullptr;
+      t.second.sched_state = -1;
+    }
+  return PSP_OK;
+}
+
+int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
+  if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
+  Variant v = decode_variant(A->variant);
+  const char *k = "csr_spmv_stream";
+  int vals[4] = {0, 0, 0, 0};
+  if (A->nrows > 0 && (v.wave || v.w1) && A->max_row_nnz <= v.tile / 2) {
+    k = v.wave ? "csr_spmv_wave" : "csr_spmv_w1";
+    if (v.w2) {
+      ChunkTable *t;
+      PSP_TRY(get_chunk_table(A, v.tile, &t));
+      PSP_TRY(ensure_rowoff(A, t));
+      if (t->np != 0) {
+        k = "csr_spmv_w2";
+        if (v.w3) {
+          PSP_TRY(ensure_w3(A, t));
+          vals[1] = t->max_blocks;
+          if (t->nb > 0) {
+            k = "csr_spmv_w3";
+            vals[0] = t->nb;
+            if (v.sched) {
+              PSP_TRY(ensure_schedule(A, t));
+              vals[2] = t->sched_state == 1;
+              vals[3] = t->half_band;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (name && name_cap > 0) {
+    strncpy(name, k, (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (info)
+    for (int i = 0; i < 4; ++i) info[i] = vals[i];
+  return PSP_OK;
 }
 
 int psp_csr_set_variant(psp_csr_t *A, int variant) {

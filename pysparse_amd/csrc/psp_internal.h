@@ -79,6 +79,7 @@ struct psp_csr {
   int nchunks = 0;
   int variant = -1;  // kernel variant override, -1 = default
   int max_row_nnz = 0;
+  int sched_strip_rows = -1;  // psp_csr_set_schedule: -1 automatic, 0 off, > 0 forced strip width
 };
 
 struct psp_sss {

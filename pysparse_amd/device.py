@@ -132,6 +132,17 @@ class DeviceCSR:
     def set_variant(self, v):
         check(lib().psp_csr_set_variant(self._h, int(v)))
 
+    def set_schedule(self, strip_rows):
+        check(lib().psp_csr_set_schedule(self._h, int(strip_rows)))
+
+    def kernel_info(self):
+        """(kernel name, {nb, max_blocks, scheduled, half_band}) of the product y = A x."""
+        name = C.create_string_buffer(64)
+        info = (C.c_int * 4)()
+        check(lib().psp_csr_kernel_info(self._h, name, 64, info))
+        return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
+                                     "half_band": info[3]}
+
     @property
     def device_bytes(self):
         return lib().psp_csr_device_bytes(self._h)

@@ -212,3 +212,89 @@ def test_matvec_overlap_split_is_bit_exact(oracle, grid):
     bad = _capi.WAIT_FN(lambda ctx: 1)
     dy = DeviceBuffer(n)
     assert L.psp_k_csr_matvec_overlap(D._h, dx.ptr, 0, dy.ptr, 0, n, bad, None, None) != 0
+
+
+def banded_csr(O, m, n, seed, half_band, max_row, empty_frac=0.05):
+    """rows with up to max_row entries inside a band around the diagonal (few x blocks per chunk)"""
+    rng = np.random.default_rng(seed)
+    ind = np.zeros(m + 1, dtype=np.int32)
+    cols = []
+    for i in range(m):
+        c = min(i * n // max(m, 1), n - 1)
+        lo, hi = max(0, c - half_band), min(n, c + half_band + 1)
+        L = 0 if rng.random() < empty_frac else int(rng.integers(1, min(max_row, hi - lo) + 1))
+        cols.append(np.sort(rng.choice(np.arange(lo, hi), size=L, replace=False)))
+        ind[i + 1] = ind[i] + L
+    col = np.concatenate(cols).astype(np.int32) if cols else np.zeros(0, dtype=np.int32)
+    val = rng.standard_normal(ind[-1])
+    return O.CSR((m, n), val, col, ind)
+
+
+@pytest.mark.parametrize("shape", [(3000, 3001, 40, 9), (5000, 4999, 150, 12), (2000, 13, 6, 5), (4000, 4007, 300, 30),
+                                   (800, 100000, 20, 7)])
+def test_csr_matvec_w3_banded_bit_exact(oracle, shape):
+    """csr_spmv_w3 (x blocks staged in LDS, 16-bit chunk-local columns): odd / short x (the block
+    holding the end of x), ragged and empty rows; the same matrix through w2 gives the same bits"""
+    from pysparse_amd.device import DeviceCSR
+    m, n, hb, mr = shape
+    A = banded_csr(oracle, m, n, 21, hb, mr)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    x = rng_vec(n, 3)
+    y_ref = np.empty(m)
+    A.matvec(x, y_ref)
+    name, info = D.kernel_info()
+    if name != "csr_spmv_w1":  # w1: some chunk holds more than 255 (short) rows, no 16-bit row table
+        if info["max_blocks"] <= 64:
+            assert name == "csr_spmv_w3" and info["nb"] in (32, 64)
+        else:
+            assert name == "csr_spmv_w2"
+    y = np.full(m, np.nan)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+    D.set_variant(16578)  # w2
+    assert D.kernel_info()[0] in ("csr_spmv_w2", "csr_spmv_w1")
+    y2 = np.full(m, np.nan)
+    D.matvec(x, y2)
+    assert np.array_equal(y2, y_ref)
+
+
+@pytest.mark.parametrize("grid,strip", [((40, 40, 30), 256), ((64, 64, 20), 1024), ((30, 20, 50), 100), ((300, 300, 0), 900)])
+def test_csr_matvec_plane_sweeping_schedule_bit_exact(oracle, grid, strip):
+    """the plane-sweeping workgroup order is a permutation only: every row exactly once, same bits"""
+    from pysparse_amd.device import DeviceCSR
+    A = oracle.poisson_csr(*grid)
+    D = DeviceCSR.poisson(*grid)
+    n = A.shape[0]
+    x = rng_vec(n, 9)
+    y_ref = np.empty(n)
+    A.matvec(x, y_ref)
+    for s in (strip, 0, -1):
+        D.set_schedule(s)
+        name, info = D.kernel_info()
+        assert name == "csr_spmv_w3"
+        assert info["scheduled"] == (s > 0)
+        if s > 0:
+            assert info["half_band"] == (grid[0] * grid[1] if grid[2] else grid[0])
+        y = np.full(n, np.nan)
+        D.matvec(x, y)
+        assert np.array_equal(y, y_ref)
+
+
+def test_csr_matvec_schedule_on_ghost_extended_slab(oracle):
+    """row slab with shifted columns (the multi-GPU local block): band half width is shift-independent"""
+    from pysparse_amd.device import DeviceCSR
+    nx, ny, nz = 24, 20, 40
+    A = oracle.poisson_csr(nx, ny, nz)
+    nxy = nx * ny
+    lo, hi = 5 * nxy, 33 * nxy
+    shift = lo - nxy
+    D = DeviceCSR.poisson_slab(nx, ny, nz, lo, hi, shift, (hi - lo) + 2 * nxy)
+    D.set_schedule(128)
+    name, info = D.kernel_info()
+    assert name == "csr_spmv_w3" and info["scheduled"] and info["half_band"] == nxy
+    xg = rng_vec(A.shape[0], 4)
+    yg = np.empty(A.shape[0])
+    A.matvec(xg, yg)
+    y = np.full(hi - lo, np.nan)
+    D.matvec(np.ascontiguousarray(xg[shift:shift + (hi - lo) + 2 * nxy]), y)
+    assert np.array_equal(y, yg[lo:hi])

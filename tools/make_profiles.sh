@@ -28,21 +28,23 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
     for r in csv.DictReader(open(f)):
         if "csr_spmv" in r.get("Kernel_Name", ""):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            kname = r["Kernel_Name"].split("(")[0]
+            kname = [w for w in r["Kernel_Name"].replace("<", " ").replace("(", " ").replace(":", " ").split() if w.startswith("csr_spmv")][0]
     for c, v in acc.items():
         vals[c] = sum(v) / len(v)
 with open(os.path.join(out, "spmv_pmc_summary.txt"), "w") as g:
-    g.write("# rocprofv3 --pmc averages per launch, csr_spmv_w2 (default variant), 7-pt Poisson 512^3 (tools/prof_spmv.py)\n")
+    g.write("# rocprofv3 --pmc averages per launch, %s (default variant), 7-pt Poisson 512^3 (tools/prof_spmv.py)\n" % kname)
     for c in sorted(vals):
         g.write("%-36s %18.1f\n" % (c, vals[c]))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports exactly half of the bytes of a
     # wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE (KB) is exact
     hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    json.dump({"kernel": "csr_spmv_w2", "workload": "7-pt Poisson 512^3", "FETCH_SIZE_KB": vals["FETCH_SIZE"],
+    json.dump({"kernel": kname, "workload": "7-pt Poisson 512^3", "FETCH_SIZE_KB": vals["FETCH_SIZE"],
                "WRITE_SIZE_KB": vals["WRITE_SIZE"], "fetch_correction": 2.0,
                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 13939769348,
-               "note": "L2<->fabric request bytes (Infinity-Cache hits included), not DRAM-only"},
+               "note": "L2<->fabric request bytes (Infinity-Cache hits included), not DRAM-only; "
+                       "distinct DRAM bytes of csr_spmv_w3 per launch: val 8 + col16 2 per nonzero, "
+                       "block list 256 + row offsets 2*64*np per chunk, x and y once"},
               open(os.path.join(out, "spmv_pmc.json"), "w"), indent=1)
 PY
 cat $OUT/bench.json; head -6 $OUT/bench_kernel_stats.csv | cut -c1-220; cat $OUT/spmv_pmc_summary.txt
