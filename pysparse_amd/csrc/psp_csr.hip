@@ -857,6 +857,154 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
   }
 }
 
+// ------------------------------------------------------------------ w4: offset-structured rows
+//
+// After w3 the SpMV is bound by distinct DRAM bytes, and for a stencil operator a fifth of
+// those are column indices that carry almost no information: every row's columns are
+// row + o for o in a small set of offsets (7 for the 7-point operator, whatever the grid or
+// the slab shift).  w4 is for matrices with at most 16 distinct values of col - row whose rows
+// store their columns strictly ascending.  Built once from the CSR arrays (lossless):
+//   * offs[NO]   the distinct offsets, ascending;
+//   * mask[r]    16 bits: which offsets row r stores (bit order = storage order, because
+//                ascending offsets are ascending columns);
+//   * valT       the values in blocks of 128 rows, offset-major inside a block
+//                (valT[(block*NO + o)*128 + i] = A[r, r + offs[o]], zero where not stored).
+// The kernel is then a pure streaming kernel: each lane owns two consecutive rows, loads
+// their NO value pairs and the NO x pairs with 16-byte accesses that are consecutive across
+// the wave, and adds the stored products in offset order -- the reference's left-to-right
+// order (csr_mat.c:49-54), separate multiply and add, entries that are not stored are not
+// touched (the mask decides, not the zero padding) => bit-identical to the CPU loop.
+// No LDS, no dependent loads, no column indices: DRAM bytes per row 8*NO + 2 (+ x, y).
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // x pairs: 8-byte aligned
+
+constexpr int kDiaRows = 128;      // rows per block (one wave: two rows per lane)
+constexpr int kDiaMaxOffs = 16;
+constexpr int kDiaEmpty = -0x7fffffff - 1;
+
+struct DiaOffs {
+  int o[kDiaMaxOffs];
+};
+
+// distinct values of col - row into a 64-slot open-addressing table; *overflow when there
+// are more than the table (and so certainly more than 16) or a row is not strictly ascending
+__global__ void dia_offsets_kernel(int nrows, const int *__restrict__ ind, const int *__restrict__ col,
+                                   int *table, int *overflow) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+    if (*(volatile int *)overflow) return;
+    int prev = -1;
+    for (int k = ind[r]; k < ind[r + 1]; ++k) {
+      const int c = col[k];
+      if (c <= prev) {
+        *overflow = 1;  // unsorted or repeated columns: storage order is not offset order
+        return;
+      }
+      prev = c;
+      const int o = c - r;
+      unsigned h = ((unsigned)o * 2654435761u) >> 26;
+      int probes = 0;
+      for (; probes < 64; ++probes, h = (h + 1) & 63) {
+        int v = *(volatile int *)(table + h);
+        if (v == o) break;
+        if (v == kDiaEmpty) {
+          v = atomicCAS(table + h, kDiaEmpty, o);
+          if (v == kDiaEmpty || v == o) break;
+        }
+      }
+      if (probes == 64) {
+        *overflow = 1;
+        return;
+      }
+    }
+  }
+}
+
+__global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__restrict__ ind,
+                                 const int *__restrict__ col, const double *__restrict__ val,
+                                 double *__restrict__ valT, unsigned short *__restrict__ mask) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    const long blk = r / kDiaRows;
+    const int i = (int)(r % kDiaRows);
+    unsigned m = 0;
+    for (int k = ind[r]; k < ind[r + 1]; ++k) {
+      const int o = col[k] - (int)r;
+      int b = 0;
+      while (b < no - 1 && offs.o[b] != o) ++b;
+      m |= 1u << b;
+      valT[((size_t)blk * no + b) * kDiaRows + i] = val[k];
+    }
+    mask[r] = (unsigned short)m;
+  }
+}
+
+template <int NO>
+__global__ __launch_bounds__(256) void csr_spmv_w4(
+    int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
+    const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int blk = blk0 + vb * 4 + wid;  // blocks [blk0, blk1) belong to this launch
+  const long r = (long)blk * kDiaRows + 2 * lane;
+  double dsum = 0.0;
+  if (blk < blk1 && r < nrows) {
+    // the mask array is padded to a whole block: both halves are always readable
+    const unsigned mm = *reinterpret_cast<const unsigned *>(mask + r);
+    const unsigned m0 = mm & 0xffffu, m1 = mm >> 16;
+    const double *vp = valT + (size_t)blk * NO * kDiaRows + 2 * lane;
+    d2v v[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) v[o] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vp + o * kDiaRows));
+    d2v xv[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const long c = r + offs.o[o];
+      if (c >= 0 && c + 1 < ncols) {
+        const d2u t = *reinterpret_cast<const d2u *>(x + c);
+        xv[o].x = t.x;
+        xv[o].y = t.y;
+      } else {  // the ends of x: load only what a stored entry can reference
+        xv[o].x = (c >= 0 && c < ncols) ? x[c] : 0.0;
+        xv[o].y = (c + 1 >= 0 && c + 1 < ncols) ? x[c + 1] : 0.0;
+      }
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const double t0 = a0 + v[o].x * xv[o].x;
+      const double t1 = a1 + v[o].y * xv[o].y;
+      a0 = ((m0 >> o) & 1u) ? t0 : a0;
+      a1 = ((m1 >> o) & 1u) ? t1 : a1;
+    }
+    if (r + 1 < nrows) {
+      d2u outu;
+      outu.x = a0;
+      outu.y = a1;
+      __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
+      if (dotv) {
+        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        dsum += u.x * a0;
+        dsum += u.y * a1;
+      }
+    } else {
+      y[r] = a0;
+      if (dotv) dsum += dotv[r] * a0;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
 // first-level fold of per-workgroup dot partials when they do not sit in the workspace
 // slots: out[o] = sum of in[o], in[o+nout], ... ; 16 lanes per output, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
@@ -989,7 +1137,9 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 // bit 20: csr_spmv_w3 (x windows staged in LDS, 16-bit chunk-local columns) where the matrix
 // qualifies (profiles/r1_spmv_w3*.txt)
 constexpr int kW3Bit = 1 << 20;
-constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8) + kW3Bit;
+// bit 22: csr_spmv_w4 (masked offset-major layout, no column indices) where the matrix qualifies
+constexpr int kW4Bit = 1 << 22;
+constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8) + kW3Bit + kW4Bit;
 
 struct Variant {
   int tile, vec;
@@ -1002,6 +1152,7 @@ struct Variant {
   int stripe;
   bool w3;
   bool sched;
+  bool w4;
 };
 
 Variant decode_variant(int v) {
@@ -1013,6 +1164,7 @@ Variant decode_variant(int v) {
   r.stripe = (v >> 8) & 0xfff;
   const bool w3bit = (v & kW3Bit) != 0;
   const bool nosched = (v & (1 << 21)) != 0;
+  r.w4 = (v & kW4Bit) != 0;
   v &= 0xff;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
@@ -1109,6 +1261,12 @@ struct CsrExtra {
   double *big_partials = nullptr;  // one slot per workgroup of the full-grid SpMV
   int big_cap = 0;
   char *packed = nullptr;          // interleaved col/val tiles (PACKED variants)
+  // csr_spmv_w4: offset-structured layout (state -1 not examined, 0 not eligible, 1 built)
+  int dia_state = -1;
+  int dia_no = 0;
+  DiaOffs dia_offs;
+  double *dia_val = nullptr;
+  unsigned short *dia_mask = nullptr;
 };
 
 }  // namespace psp
@@ -1361,6 +1519,104 @@ static int ensure_schedule(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+// offset-structured layout of csr_spmv_w4 (built on first use)
+static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  psp::CsrExtra &ex = g_extra[A];
+  *out = &ex;
+  if (ex.dia_state >= 0) return PSP_OK;
+  ex.dia_state = 0;
+  static const bool off = [] {
+    const char *e = getenv("PSP_SPMV_W4");
+    return e && atoi(e) == 0;
+  }();
+  if (off || A->nrows < 1 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
+  int *d_tab;
+  PSP_HIP(hipMalloc((void **)&d_tab, 65 * sizeof(int)));
+  int init[65];
+  for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
+  init[64] = 0;
+  PSP_HIP(hipMemcpyAsync(d_tab, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  hipLaunchKernelGGL(dia_offsets_kernel, dim3(std::min((A->nrows + 255) / 256, 8192)), dim3(256), 0, stream(),
+                     A->nrows, A->ind, A->col, d_tab, d_tab + 64);
+  PSP_LAUNCH_CHECK();
+  int tab[65];
+  PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_tab));
+  if (tab[64]) return PSP_OK;
+  std::vector<int> offs;
+  for (int i = 0; i < 64; ++i)
+    if (tab[i] != kDiaEmpty) offs.push_back(tab[i]);
+  if (offs.empty() || (int)offs.size() > kDiaMaxOffs) return PSP_OK;
+  std::sort(offs.begin(), offs.end());
+  const int no = (int)offs.size();
+  // padding: rows without an entry at some offset still occupy a slot; refuse layouts that would
+  // move more value bytes than the CSR form moves values + indices (12 per stored entry)
+  const size_t nblk = ((size_t)A->nrows + kDiaRows - 1) / kDiaRows;
+  const double slots = (double)nblk * kDiaRows * no;
+  if (slots * 8.0 > 11.0 * (double)A->nnz) return PSP_OK;
+  for (int i = 0; i < kDiaMaxOffs; ++i) ex.dia_offs.o[i] = i < no ? offs[i] : 0;
+  const size_t nval = nblk * kDiaRows * no;
+  hipError_t e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
+  hipError_t e2 = hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * (nblk * kDiaRows + 2));
+  if (e1 != hipSuccess || e2 != hipSuccess) {  // no room: stay with the CSR kernels
+    (void)hipGetLastError();
+    if (e1 == hipSuccess) (void)hipFree(ex.dia_val);
+    if (e2 == hipSuccess) (void)hipFree(ex.dia_mask);
+    ex.dia_val = nullptr;
+    ex.dia_mask = nullptr;
+    return PSP_OK;
+  }
+  PSP_HIP(hipMemsetAsync(ex.dia_val, 0, sizeof(double) * nval, stream()));
+  PSP_HIP(hipMemsetAsync(ex.dia_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
+  hipLaunchKernelGGL(dia_build_kernel, dim3(std::min((A->nrows + 255) / 256, 65536)), dim3(256), 0, stream(),
+                     A->nrows, no, ex.dia_offs, A->ind, A->col, A->val, ex.dia_val, ex.dia_mask);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  ex.dia_no = no;
+  ex.dia_state = 1;
+  return PSP_OK;
+}
+
+// csr_spmv_w4 over row blocks [b0, b1)
+static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int b0, int b1, const double *x,
+                     double *y, const double *dotv, double *pbuf, const int *skip, int grid) {
+#define PSP_W4(NO)                                                                                   \
+  case NO:                                                                                           \
+    hipLaunchKernelGGL((csr_spmv_w4<NO>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows,       \
+                       A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf,   \
+                       skip);                                                                        \
+    break
+  switch (ex->dia_no) {
+    PSP_W4(1); PSP_W4(2); PSP_W4(3); PSP_W4(4); PSP_W4(5); PSP_W4(6); PSP_W4(7); PSP_W4(8);
+    PSP_W4(9); PSP_W4(10); PSP_W4(11); PSP_W4(12); PSP_W4(13); PSP_W4(14); PSP_W4(15); PSP_W4(16);
+    default:
+      return fail(PSP_EINVAL, "csr_spmv_w4: %d offsets", ex->dia_no);
+  }
+#undef PSP_W4
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+static int w4_grid(int nblocks, int stripe) {
+  int grid = (nblocks + 3) / 4;
+  if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
+  return grid;
+}
+
+static int ensure_big_partials(psp::CsrExtra *ex, int cap) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (ex->big_cap < cap) {
+    if (ex->big_partials) (void)hipFree(ex->big_partials);
+    ex->big_partials = nullptr;
+    ex->big_cap = 0;
+    PSP_HIP(hipMalloc((void **)&ex->big_partials, sizeof(double) * (size_t)cap));
+    ex->big_cap = cap;
+  }
+  return PSP_OK;
+}
+
 static int ensure_packed(const psp_csr *A, char **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
@@ -1439,6 +1695,11 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
 
 bool csr_spmv_has_skip(const psp_csr *A) {
   Variant v = decode_variant(A->variant);
+  if (v.w4) {
+    psp::CsrExtra *ex;
+    if (ensure_w4(A, &ex) != PSP_OK) return false;
+    if (ex->dia_state == 1) return true;
+  }
   if (!v.w2 || A->max_row_nnz > v.tile / 2) return false;
   ChunkTable *t;
   if (get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t) != PSP_OK) return false;
@@ -1451,6 +1712,30 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   Workspace *w;
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
+  if (v.w4) {
+    psp::CsrExtra *ex;
+    PSP_TRY(ensure_w4(A, &ex));
+    if (ex->dia_state == 1) {
+      const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+      const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
+      const int grid = w4_grid(nblk, stripe);
+      double *pbuf = partials;
+      if (partials && grid > kMaxParts) {
+        PSP_TRY(ensure_big_partials(ex, grid));
+        pbuf = ex->big_partials;
+      }
+      PSP_TRY(launch_w4(A, ex, stripe, 0, nblk, x, y, dotv, pbuf, skip, grid));
+      int np = grid;
+      if (pbuf != partials) {
+        np = kFold;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
+                           partials, np);
+        PSP_LAUNCH_CHECK();
+      }
+      if (nparts) *nparts = np;
+      return PSP_OK;
+    }
+  }
   if ((v.wave || v.w1) && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
     v.wave = v.w1 = v.w2 = false;
     v.tile = 2048;
@@ -1652,6 +1937,37 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx) {
   Variant v = decode_variant(A->variant);
+  if (v.w4 && row_a < row_b) {
+    psp::CsrExtra *ex;
+    PSP_TRY(ensure_w4(A, &ex));
+    if (ex->dia_state == 1) {
+      // interior = the 128-row blocks that lie inside [row_a, row_b)
+      const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
+      int ba = (row_a + kDiaRows - 1) / kDiaRows, bb = row_b / kDiaRows;
+      if (row_b >= A->nrows) bb = nblk;
+      if (bb < ba) bb = ba;
+      const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+      const int g1 = bb > ba ? w4_grid(bb - ba, stripe) : 0;
+      const int g2 = ba > 0 ? w4_grid(ba, stripe) : 0;
+      const int g3 = nblk > bb ? w4_grid(nblk - bb, stripe) : 0;
+      double *pbuf = nullptr;
+      if (partials) {
+        PSP_TRY(ensure_big_partials(ex, g1 + g2 + g3 + 8));
+        pbuf = ex->big_partials;
+      }
+      if (g1) PSP_TRY(launch_w4(A, ex, stripe, ba, bb, x, y, dotv, pbuf, nullptr, g1));
+      if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+      if (g2) PSP_TRY(launch_w4(A, ex, stripe, 0, ba, x, y, dotv, pbuf ? pbuf + g1 : nullptr, nullptr, g2));
+      if (g3) PSP_TRY(launch_w4(A, ex, stripe, bb, nblk, x, y, dotv, pbuf ? pbuf + g1 + g2 : nullptr, nullptr, g3));
+      if (partials) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), pbuf, g1 + g2 + g3,
+                           partials, kFold);
+        PSP_LAUNCH_CHECK();
+        if (nparts) *nparts = kFold;
+      }
+      return PSP_OK;
+    }
+  }
   ChunkTable *t = nullptr;
   bool ok = v.w2 && A->max_row_nnz <= v.tile / 2 && row_a < row_b;
   if (ok) {
@@ -1863,6 +2179,8 @@ int psp_csr_destroy(psp_csr_t *A) {
       }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
       if (it->second.packed) (void)hipFree(it->second.packed);
+      if (it->second.dia_val) (void)hipFree(it->second.dia_val);
+      if (it->second.dia_mask) (void)hipFree(it->second.dia_mask);
       g_extra.erase(it);
     }
   }
@@ -1981,7 +2299,17 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   Variant v = decode_variant(A->variant);
   const char *k = "csr_spmv_stream";
   int vals[4] = {0, 0, 0, 0};
-  if (A->nrows > 0 && (v.wave || v.w1) && A->max_row_nnz <= v.tile / 2) {
+  bool w4 = false;
+  if (v.w4) {
+    psp::CsrExtra *ex;
+    PSP_TRY(ensure_w4(A, &ex));
+    if (ex->dia_state == 1) {
+      w4 = true;
+      k = "csr_spmv_w4";
+      vals[0] = ex->dia_no;
+    }
+  }
+  if (!w4 && A->nrows > 0 && (v.wave || v.w1) && A->max_row_nnz <= v.tile / 2) {
     k = v.wave ? "csr_spmv_wave" : "csr_spmv_w1";
     if (v.w2) {
       ChunkTable *t;

@@ -73,12 +73,20 @@ def test_poisson_test_G2_G3_csr_and_sss(golden, p2d, name, tol):
         assert relerr(x, its[name]) < RTOL_X
 
 
+# SpMV kernel behind the solve: default (csr_spmv_w4 on the Poisson operators), w3, w2
+SPMV_KERNELS = {"w4": (-1, "csr_spmv_w4"), "w3": ((1 << 20) + 16578, "csr_spmv_w3"), "w2": (16578, "csr_spmv_w2")}
+
+
+@pytest.mark.parametrize("kern", sorted(SPMV_KERNELS))
 @pytest.mark.parametrize("k", [1, 2, 10, 50])
-def test_fixed_iteration_counts(golden, p2d, k):
+def test_fixed_iteration_counts(golden, p2d, k, kern):
     """tol = 0 never converges: exactly k iterations, info -1 and iter = k+1 (pcg.c:165)."""
-    from pysparse_amd.device import DeviceJacobi, pcg
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg
     cases, its = golden
-    A, D, _, _ = p2d
+    A = p2d[0]
+    D = DeviceCSR.poisson(100, 100)
+    D.set_variant(SPMV_KERNELS[kern][0])
+    assert D.kernel_info()[0] == SPMV_KERNELS[kern][1]
     n = A.shape[0]
     g = cases["fixed_%d" % k]
     x = np.zeros(n)
@@ -96,11 +104,14 @@ def test_fixed_iteration_counts(golden, p2d, k):
     assert abs(np.linalg.norm(x) - gj["x"]["norm2"]) <= 1e-12 * gj["x"]["norm2"]
 
 
+@pytest.mark.parametrize("kern", sorted(SPMV_KERNELS))
 @pytest.mark.parametrize("N,name", [(32, "G4"), (64, "G5")])
-def test_poisson3d_G4_G5(oracle, golden, N, name):
+def test_poisson3d_G4_G5(oracle, golden, N, name, kern):
     from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg
     cases, _ = golden
     D = DeviceCSR.poisson(N, N, N)
+    D.set_variant(SPMV_KERNELS[kern][0])
+    assert D.kernel_info()[0] == SPMV_KERNELS[kern][1]
     n = D.shape[0]
     b = np.empty(n)
     D.matvec(np.ones(n), b)

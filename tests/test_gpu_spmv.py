@@ -60,7 +60,7 @@ def test_poisson_slab_matches_global_rows(oracle):
     assert n == nx * ny * nz
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195, 1065154, 3162306])
 @pytest.mark.parametrize("grid", [(100, 100, 0), (64, 64, 64), (41, 29, 13)])
 def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
     from pysparse_amd.device import DeviceCSR
@@ -264,6 +264,7 @@ def test_csr_matvec_plane_sweeping_schedule_bit_exact(oracle, grid, strip):
     from pysparse_amd.device import DeviceCSR
     A = oracle.poisson_csr(*grid)
     D = DeviceCSR.poisson(*grid)
+    D.set_variant((1 << 20) + 16578)  # csr_spmv_w3 (the default for a stencil operator is w4)
     n = A.shape[0]
     x = rng_vec(n, 9)
     y_ref = np.empty(n)
@@ -289,6 +290,7 @@ def test_csr_matvec_schedule_on_ghost_extended_slab(oracle):
     lo, hi = 5 * nxy, 33 * nxy
     shift = lo - nxy
     D = DeviceCSR.poisson_slab(nx, ny, nz, lo, hi, shift, (hi - lo) + 2 * nxy)
+    D.set_variant((1 << 20) + 16578)
     D.set_schedule(128)
     name, info = D.kernel_info()
     assert name == "csr_spmv_w3" and info["scheduled"] and info["half_band"] == nxy
@@ -298,3 +300,88 @@ def test_csr_matvec_schedule_on_ghost_extended_slab(oracle):
     y = np.full(hi - lo, np.nan)
     D.matvec(np.ascontiguousarray(xg[shift:shift + (hi - lo) + 2 * nxy]), y)
     assert np.array_equal(y, yg[lo:hi])
+
+
+def offset_structured_csr(O, m, n, seed, offsets, keep=0.93, empty_frac=0.02):
+    """every stored column is row + o for o in `offsets` (random subsets, ragged at the ends of x)"""
+    rng = np.random.default_rng(seed)
+    offs = np.sort(np.asarray(offsets))
+    ind = np.zeros(m + 1, dtype=np.int32)
+    cols = []
+    for r in range(m):
+        c = r + offs
+        c = c[(c >= 0) & (c < n)]
+        if rng.random() < empty_frac:
+            c = c[:0]
+        else:
+            c = c[rng.random(c.size) < keep]
+        cols.append(c)
+        ind[r + 1] = ind[r] + c.size
+    col = np.concatenate(cols).astype(np.int32)
+    val = rng.standard_normal(ind[-1])
+    val[rng.random(val.size) < 0.02] = 0.0  # explicitly stored zeros stay stored entries
+    return O.CSR((m, n), val, col, ind)
+
+
+@pytest.mark.parametrize("case", [
+    (1001, 1001, (-37, -1, 0, 1, 37)), (777, 900, (0, 5, 123)), (2048, 2048, tuple(range(-8, 8))),
+    (513, 700, (-3, 0, 2, 180)), (128, 128, (0,)), (127, 131, (0, 2, 4)), (1290, 1290, (-128, 0, 128)),
+    (4000, 4100, (100, 101, 99, 0, 37, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74))])
+def test_csr_matvec_w4_offset_structured_bit_exact(oracle, case):
+    """csr_spmv_w4 (masked offset-major layout): random subsets of <= 16 offsets, empty rows, odd row
+    counts, rectangular shapes, stored zeros; NaN / Inf in x reach exactly the rows that store an
+    entry there; w3 / w2 on the same matrix give the same bits"""
+    from pysparse_amd.device import DeviceCSR
+    m, n, offs = case
+    A = offset_structured_csr(oracle, m, n, 5, offs)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    name, info = D.kernel_info()
+    assert name == "csr_spmv_w4" and info["nb"] <= len(offs)
+    x = rng_vec(n, 8)
+    if n > 4:
+        x[n // 3] = np.nan
+        x[n // 2] = np.inf
+        x[n - 1] = -np.inf
+    y_ref = np.empty(m)
+    A.matvec(x, y_ref)
+    y = np.full(m, 123.0)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref, equal_nan=True)
+    assert np.array_equal(np.signbit(y), np.signbit(y_ref))
+    for variant in ((1 << 20) + 16578, 16578, 0):
+        D.set_variant(variant)
+        assert D.kernel_info()[0] != "csr_spmv_w4"
+        y2 = np.full(m, 123.0)
+        D.matvec(x, y2)
+        assert np.array_equal(y2, y_ref, equal_nan=True)
+    ind, col, val = D.download()
+    assert np.array_equal(ind, A.ind) and np.array_equal(col, A.col) and np.array_equal(val, A.val)
+
+
+def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
+    """unsorted columns (storage order is not offset order), more than 16 offsets, too much padding"""
+    from pysparse_amd.device import DeviceCSR
+    n = 500
+    ind = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
+    col = np.empty(2 * n, dtype=np.int32)
+    col[0::2] = np.minimum(np.arange(n) + 1, n - 1)
+    col[1::2] = np.arange(n) - (np.arange(n) == n - 1)  # second column smaller than the first
+    val = rng_vec(2 * n, 1)
+    A = oracle.CSR((n, n), val, col, ind)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    assert D.kernel_info()[0] != "csr_spmv_w4"
+    x = rng_vec(n, 2)
+    y_ref, y = np.empty(n), np.empty(n)
+    A.matvec(x, y_ref)
+    D.matvec(x, y)
+    assert np.array_equal(y, y_ref)
+    B = offset_structured_csr(oracle, 600, 600, 3, tuple(range(-10, 10)))  # 20 offsets
+    assert DeviceCSR.from_arrays(B.shape, B.ind, B.col, B.val).kernel_info()[0] != "csr_spmv_w4"
+    Cm = offset_structured_csr(oracle, 3000, 3000, 4, tuple(range(0, 160, 10)), keep=0.1)  # 90 % padding
+    DC = DeviceCSR.from_arrays(Cm.shape, Cm.ind, Cm.col, Cm.val)
+    assert DC.kernel_info()[0] != "csr_spmv_w4"
+    y_ref, y = np.empty(3000), np.empty(3000)
+    xx = rng_vec(3000, 6)
+    Cm.matvec(xx, y_ref)
+    DC.matvec(xx, y)
+    assert np.array_equal(y, y_ref)
