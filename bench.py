@@ -32,6 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3-6.8 achievable)
+W3_VARIANT = (1 << 20) + 128 + 64 + 2 + (64 << 8)  # csr_spmv_w3 (general banded CSR), see psp_csr.hip
+
+
+def dram_model_bytes(kernel, info, n, nnz):
+    """distinct bytes one launch has to move from/to DRAM: x and y once,
+    plus the matrix stream of the kernel that ran"""
+    if kernel == "csr_spmv_w4":   # values in padded offset-major blocks of 128 rows + 16-bit row masks
+        rows = (n + 127) // 128 * 128
+        return 8 * rows * info["nb"] + 2 * n + 16 * n
+    if kernel == "csr_spmv_w3":   # val 8 + col16 2 per nonzero; per chunk of ~1016 nonzeros: block list + row offsets
+        chunks = nnz / 1016.0
+        return int(10 * nnz * (1024 / 1016.0) + chunks * (4 * info["nb"] + 2 * 256 + 16) + 16 * n)
+    return 12 * nnz + 20 * n + 4
 
 
 def spmv_bytes(n, nnz):
@@ -189,6 +202,27 @@ def main():
     sync()
     wall = time.perf_counter() - t0
 
+    # ---- beside it (N = 1): the general-CSR kernel on the same operator.  The default kernel for
+    # a stencil operator (csr_spmv_w4) reads no column indices at all, so its rate in CSR-model
+    # bytes can exceed the HBM line; csr_spmv_w3 is what an arbitrary banded csr_mat gets.
+    general = None
+    if not use_dist and a.variant < 0:
+        kern0, info0 = A.kernel_info()
+        if kern0 == "csr_spmv_w4":
+            A.set_variant(W3_VARIANT)
+            for _ in range(3):
+                step()
+            sync()
+            ev.start()
+            for _ in range(a.steps):
+                step()
+            g_ms = ev.stop_ms() / a.steps
+            sync()
+            general = {"kernel": A.kernel_info()[0], "avg_launch_ms": g_ms,
+                       "achieved": spmv_bytes(n_loc, nnz_loc) / (g_ms * 1e-3) / 1e9}
+            general["frac"] = general["achieved"] / HBM_PEAK_GBPS
+            A.set_variant(-1)
+
     # ---- Jacobi-PCG iterations/s on the same operator (b = A*ones, x0 = 0, tol = 0 so that
     # exactly k iterations run; the setup -- ||b||, r = b - A x0 -- is inside the timed
     # region, i.e. the rate is slightly conservative)
@@ -242,7 +276,7 @@ def main():
         value = spmv_bytes(n_tot, nnz_tot) / (wall / a.steps) / 1e9
         kern_ms = ev_ms / a.steps
         achieved = spmv_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
-        kernel = (A.A if use_dist else A).kernel_info()[0]
+        kernel, kinfo = (A.A if use_dist else A).kernel_info()
         # HBM traffic of one launch from the committed rocprofv3 --pmc passes of the same kernel
         # on the same workload (tools/make_profiles.sh; counters cannot be read in-process)
         traffic = None
@@ -273,8 +307,15 @@ def main():
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": spmv_bytes(n_loc, nnz_loc), "avg_launch_ms": kern_ms,
+                # what the kernel that ran has to move (its own index format), and that rate
+                "dram_model_bytes_per_launch": dram_model_bytes(kernel, kinfo, n_loc, nnz_loc),
+                "dram_model_GBps": dram_model_bytes(kernel, kinfo, n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9,
+                "note": "achieved = CSR-model bytes (12 nnz + 20 n + 4) / avg launch time; "
+                        "csr_spmv_w4/w3 move fewer bytes than that model (no / 16-bit column indices)",
             },
         }
+        if general is not None:
+            out["roofline_general_csr"] = general
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

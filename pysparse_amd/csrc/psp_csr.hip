@@ -936,7 +936,7 @@ __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__r
   }
 }
 
-template <int NO>
+template <int NO, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(256) void csr_spmv_w4(
     int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
     const double *vp = valT + (size_t)blk * NO * kDiaRows + 2 * lane;
     d2v v[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) v[o] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vp + o * kDiaRows));
+    for (int o = 0; o < NO; ++o) v[o] = ldg<NTL>(reinterpret_cast<const d2v *>(vp + o * kDiaRows));
     d2v xv[NO];
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
@@ -986,7 +986,10 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
       d2u outu;
       outu.x = a0;
       outu.y = a1;
-      __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
+      if constexpr (NTS)
+        __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
+      else
+        *reinterpret_cast<d2u *>(y + r) = outu;
       if (dotv) {
         const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
         dsum += u.x * a0;
@@ -1582,11 +1585,16 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
 // csr_spmv_w4 over row blocks [b0, b1)
 static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int b0, int b1, const double *x,
                      double *y, const double *dotv, double *pbuf, const int *skip, int grid) {
+  const int flags = (A->variant >= 0 ? A->variant : 0) >> 23 & 3;  // A/B knobs: bit 23 plain val loads, 24 plain y stores
+#define PSP_W4_F(NO, NTL, NTS)                                                                       \
+  hipLaunchKernelGGL((csr_spmv_w4<NO, NTL, NTS>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows, \
+                     A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf, skip)
 #define PSP_W4(NO)                                                                                   \
   case NO:                                                                                           \
-    hipLaunchKernelGGL((csr_spmv_w4<NO>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows,       \
-                       A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf,   \
-                       skip);                                                                        \
+    if (flags == 0) PSP_W4_F(NO, true, true);                                                        \
+    else if (flags == 1) PSP_W4_F(NO, false, true);                                                  \
+    else if (flags == 2) PSP_W4_F(NO, true, false);                                                  \
+    else PSP_W4_F(NO, false, false);                                                                 \
     break
   switch (ex->dia_no) {
     PSP_W4(1); PSP_W4(2); PSP_W4(3); PSP_W4(4); PSP_W4(5); PSP_W4(6); PSP_W4(7); PSP_W4(8);
@@ -1595,6 +1603,7 @@ static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int 
       return fail(PSP_EINVAL, "csr_spmv_w4: %d offsets", ex->dia_no);
   }
 #undef PSP_W4
+#undef PSP_W4_F
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
@@ -1652,6 +1661,13 @@ static int spmv_stripe() {
     return e ? atoi(e) : -1;
   }();
   return m;
+}
+
+// XCD stripe of w4 in workgroups of 512 rows: 32 measured best at 512^3 (0: -0.5 %, 64: -2 %,
+// 256: -4 %; profiles/r1_spmv_w4_knobs.txt); an explicit variant or PSP_SPMV_STRIPE overrides
+static int w4_stripe(const psp_csr *A, const Variant &v) {
+  if (spmv_stripe() >= 0) return spmv_stripe();
+  return A->variant < 0 ? 32 : v.stripe;
 }
 
 template <int TILE, int VEC, bool NT>
@@ -1716,7 +1732,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
     if (ex->dia_state == 1) {
-      const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+      const int stripe = w4_stripe(A, v);
       const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
       const int grid = w4_grid(nblk, stripe);
       double *pbuf = partials;
@@ -1946,7 +1962,7 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
       int ba = (row_a + kDiaRows - 1) / kDiaRows, bb = row_b / kDiaRows;
       if (row_b >= A->nrows) bb = nblk;
       if (bb < ba) bb = ba;
-      const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
+      const int stripe = w4_stripe(A, v);
       const int g1 = bb > ba ? w4_grid(bb - ba, stripe) : 0;
       const int g2 = ba > 0 ? w4_grid(ba, stripe) : 0;
       const int g3 = nblk > bb ? w4_grid(nblk - bb, stripe) : 0;
