@@ -286,6 +286,8 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
   bool swapped = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  int enqueued = 0;  // iterations launched so far (never more than maxit: a no-op launch of a
+                     // 512^3 grid still costs ~55 us)
   PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
   hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
   if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
@@ -318,7 +320,8 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
   hst->it = 1;
   hst->maxit = maxit;
   PCG_HIP(hipMemcpyAsync(st, hst, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
-  PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, std::min(kBatch, maxit)));
+  enqueued = std::min(kBatch, maxit);
+  PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, enqueued));
   PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
   PCG_HIP(hipStreamSynchronize(stream()));
   if (!hst->status) {
@@ -345,10 +348,13 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
       use_graph = exec != nullptr;
     }
     while (!hst->status) {
-      if (use_graph)
+      if (use_graph) {
         PCG_HIP(hipGraphLaunch(exec, stream()));
-      else
-        PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, kBatch));
+      } else {
+        const int batch = std::max(1, std::min(kBatch, maxit - enqueued));
+        PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, batch));
+        enqueued += batch;
+      }
       PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
       PCG_HIP(hipStreamSynchronize(stream()));
     }
