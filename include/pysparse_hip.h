@@ -144,6 +144,11 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
 int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out);
 int psp_sss_destroy(psp_sss_t *A);
 /* n, and nnz as the reference reports it: strict-lower count + n (sss_mat.c:155) */
+/* which kernel y := S x runs (sss_spmv_w4 for offset-structured matrices: the strict lower triangle
+ * only, half the traffic of the mirrored product; otherwise the csr kernels on the full mirror),
+ * and the A/B knob -- same meaning as psp_csr_kernel_info / psp_csr_set_variant */
+int psp_sss_kernel_info(psp_sss_t *A, char *name, int name_cap, int *info);
+int psp_sss_set_variant(psp_sss_t *A, int variant);
 int psp_sss_shape(const psp_sss_t *A, int *n, int *nnz_reported);
 int psp_sss_download(const psp_sss_t *A, int *ind_host, int *col_host, double *val_host,
                      double *diag_host);

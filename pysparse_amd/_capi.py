@@ -26,6 +26,7 @@ psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_cs
 psp_csr_set_schedule psp_csr_kernel_info psp_csr_device_bytes
 psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
 psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
+psp_sss_kernel_info psp_sss_set_variant
 psp_jacobi_create_csr psp_jacobi_create_sss psp_jacobi_create_diag psp_jacobi_destroy
 psp_jacobi_shape psp_jacobi_precon psp_jacobi_precon_dev
 psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_callback psp_op_destroy
@@ -98,6 +99,7 @@ def _declare(L):
         "psp_sss_download": [vp, vp, vp, vp, vp], "psp_sss_getitem": [vp, i, i, pd],
         "psp_sss_matvec": [vp, vp, vp], "psp_sss_matvec_stride": [vp, vp, pt, vp, pt],
         "psp_sss_matvec_dev": [vp, vp, vp],
+        "psp_sss_kernel_info": [vp, C.c_char_p, i, pi], "psp_sss_set_variant": [vp, i],
         "psp_jacobi_create_csr": [vp, d, i, pvp], "psp_jacobi_create_sss": [vp, d, i, pvp],
         "psp_jacobi_create_diag": [i, vp, d, i, vp, pvp], "psp_jacobi_destroy": [vp],
         "psp_jacobi_shape": [vp, pi], "psp_jacobi_precon": [vp, vp, vp],

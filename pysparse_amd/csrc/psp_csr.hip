@@ -961,17 +961,29 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
     d2v v[NO];
 #pragma unroll
     for (int o = 0; o < NO; ++o) v[o] = ldg<NTL>(reinterpret_cast<const d2v *>(vp + o * kDiaRows));
+    // x pairs: every load is issued unconditionally from a clamped address (a bounds-check branch
+    // per load makes the compiler wait for all earlier loads before each one -- seven sequential
+    // round trips); the lanes at the two ends of x repair their pairs afterwards
     d2v xv[NO];
+    const long cmax = (long)ncols - 2;  // ncols >= 2 (ensure_w4)
+    bool edge = false;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       const long c = r + offs.o[o];
-      if (c >= 0 && c + 1 < ncols) {
-        const d2u t = *reinterpret_cast<const d2u *>(x + c);
-        xv[o].x = t.x;
-        xv[o].y = t.y;
-      } else {  // the ends of x: load only what a stored entry can reference
-        xv[o].x = (c >= 0 && c < ncols) ? x[c] : 0.0;
-        xv[o].y = (c + 1 >= 0 && c + 1 < ncols) ? x[c + 1] : 0.0;
+      const long cc = c < 0 ? 0 : (c > cmax ? cmax : c);
+      const d2u t = *reinterpret_cast<const d2u *>(x + cc);
+      xv[o].x = t.x;
+      xv[o].y = t.y;
+      edge |= cc != c;
+    }
+    if (edge) {  // load only what a stored entry can reference
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const long c = r + offs.o[o];
+        if (c < 0 || c > cmax) {
+          xv[o].x = (c >= 0 && c < ncols) ? x[c] : 0.0;
+          xv[o].y = (c + 1 >= 0 && c + 1 < ncols) ? x[c + 1] : 0.0;
+        }
       }
     }
     double a0 = 0.0, a1 = 0.0;
@@ -990,6 +1002,172 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
         __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
       else
         *reinterpret_cast<d2u *>(y + r) = outu;
+      if (dotv) {
+        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        dsum += u.x * a0;
+        dsum += u.y * a1;
+      }
+    } else {
+      y[r] = a0;
+      if (dotv) dsum += dotv[r] * a0;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// ------------------------------------------------------------------ sss_spmv_w4: symmetric skyline
+//
+// sss_matvec (sss_mat.c:45-55) for offset-structured matrices, at HALF the matrix traffic of the
+// mirrored-CSR product: only the strict lower triangle is stored (offset-major blocks of 128
+// rows, like csr_spmv_w4) and it is read twice -- as row r's lower entries L[r, r+o] and, at the
+// shifted rows r-o, as the mirrored upper entries A[r, r-o] = L[r-o, r] (the second read of a
+// block hits in L2 / Infinity Cache; DRAM sees the values once).  Summation order per row is
+// the reference's: lower entries by ascending column, then the diagonal term, then the
+// mirrored entries by ascending row (sss_mat.c:52 adds them as the sweep reaches row r-o).
+// mask[r]: bits 0-7 = lower offsets row r stores, bits 8-15 = rows r-o_j that store offset o_j.
+struct SssOffs {
+  int o[8];  // strictly negative, ascending
+};
+
+__global__ void sss_lowmask_kernel(int n, int nol, SssOffs offs, const int *__restrict__ ind,
+                                   const int *__restrict__ col, const double *__restrict__ val,
+                                   double *__restrict__ valL, unsigned char *__restrict__ low) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+    const long blk = r / kDiaRows;
+    const int i = (int)(r % kDiaRows);
+    unsigned m = 0;
+    for (int k = ind[r]; k < ind[r + 1]; ++k) {
+      const int o = col[k] - (int)r;
+      int b = 0;
+      while (b < nol - 1 && offs.o[b] != o) ++b;
+      m |= 1u << b;
+      valL[((size_t)blk * nol + b) * kDiaRows + i] = val[k];
+    }
+    low[r] = (unsigned char)m;
+  }
+}
+
+__global__ void sss_mask_kernel(int n, int nol, SssOffs offs, const unsigned char *__restrict__ low,
+                                unsigned short *__restrict__ mask) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+    unsigned m = low[r];
+    for (int j = 0; j < nol; ++j) {
+      const long ru = r - offs.o[j];
+      if (ru < n && ((low[ru] >> j) & 1u)) m |= 1u << (8 + j);
+    }
+    mask[r] = (unsigned short)m;
+  }
+}
+
+template <int NOL>
+__global__ __launch_bounds__(256) void sss_spmv_w4(
+    int n, int stripe, SssOffs offs, const double *__restrict__ valL, const double *__restrict__ diag,
+    const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const long blk = (long)vb * 4 + wid;
+  const long r = blk * kDiaRows + 2 * lane;
+  double dsum = 0.0;
+  if (r < n) {
+    const bool two = r + 1 < n;
+    const unsigned mm = *reinterpret_cast<const unsigned *>(mask + r);  // padded to a whole block
+    const unsigned m0 = mm & 0xffffu, m1 = mm >> 16;
+    // All loads are issued unconditionally from clamped addresses (see csr_spmv_w4); the lanes at
+    // the ends of x repair their pairs afterwards.  valL is padded to whole blocks (npad rows).
+    const long npad = ((long)n + kDiaRows - 1) / kDiaRows * kDiaRows;
+    const long xmax = (long)n - 2;  // n >= 2 (ensure_sss_w4)
+    bool edge = !two;
+    // lower entries of rows r, r+1 and the x they multiply
+    d2v vl[NOL], xl[NOL];
+    const double *vp = valL + (size_t)blk * NOL * kDiaRows + 2 * lane;
+#pragma unroll
+    for (int j = 0; j < NOL; ++j) {
+      vl[j] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vp + j * kDiaRows));
+      const long c = r + offs.o[j];  // < r
+      const long cc = c < 0 ? 0 : c;
+      const d2u t = *reinterpret_cast<const d2u *>(x + cc);
+      xl[j].x = t.x;
+      xl[j].y = t.y;
+      edge |= c < 0;
+    }
+    // diagonal
+    d2v dg, x0;
+    {
+      const long rd = r > xmax ? xmax : r;
+      const d2u t = *reinterpret_cast<const d2u *>(diag + rd);
+      const d2u u = *reinterpret_cast<const d2u *>(x + rd);
+      dg.x = t.x; dg.y = t.y; x0.x = u.x; x0.y = u.y;
+    }
+    // mirrored entries: L[ru, ru + o_j] with ru = r - o_j (> r), times x[ru]
+    d2v vu[NOL], xu[NOL];
+#pragma unroll
+    for (int j = 0; j < NOL; ++j) {
+      const long ru = r - offs.o[j];
+      const long v0 = ru < npad ? ru : npad - 1, v1 = ru + 1 < npad ? ru + 1 : npad - 1;
+      vu[j].x = valL[((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows)];
+      vu[j].y = valL[((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows)];
+      const long xr = ru > xmax ? xmax : ru;
+      const d2u t = *reinterpret_cast<const d2u *>(x + xr);
+      xu[j].x = t.x;
+      xu[j].y = t.y;
+      edge |= ru > xmax;
+    }
+    if (edge) {
+#pragma unroll
+      for (int j = 0; j < NOL; ++j) {
+        const long c = r + offs.o[j];
+        if (c < 0) {
+          xl[j].x = 0.0;
+          xl[j].y = c + 1 >= 0 ? x[c + 1] : 0.0;
+        }
+        const long ru = r - offs.o[j];
+        if (ru > xmax) {
+          xu[j].x = ru < n ? x[ru] : 0.0;
+          xu[j].y = 0.0;
+        }
+      }
+      if (!two) {
+        dg.x = diag[r];
+        dg.y = 0.0;
+        x0.x = x[r];
+        x0.y = 0.0;
+      }
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NOL; ++j) {  // lower entries, ascending column
+      const double t0 = a0 + vl[j].x * xl[j].x;
+      const double t1 = a1 + vl[j].y * xl[j].y;
+      a0 = ((m0 >> j) & 1u) ? t0 : a0;
+      a1 = ((m1 >> j) & 1u) ? t1 : a1;
+    }
+    a0 = a0 + dg.x * x0.x;  // sss_mat.c:54: y[i] = s + diag[i]*x[i], always
+    a1 = a1 + dg.y * x0.y;
+#pragma unroll
+    for (int j = NOL - 1; j >= 0; --j) {  // mirrored entries, ascending row r - o_j
+      const double t0 = a0 + vu[j].x * xu[j].x;
+      const double t1 = a1 + vu[j].y * xu[j].y;
+      a0 = ((m0 >> (8 + j)) & 1u) ? t0 : a0;
+      a1 = ((m1 >> (8 + j)) & 1u) ? t1 : a1;
+    }
+    if (two) {
+      d2u outu;
+      outu.x = a0;
+      outu.y = a1;
+      __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
       if (dotv) {
         const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
         dsum += u.x * a0;
@@ -1533,7 +1711,7 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
     const char *e = getenv("PSP_SPMV_W4");
     return e && atoi(e) == 0;
   }();
-  if (off || A->nrows < 1 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
+  if (off || A->nrows < 1 || A->ncols < 2 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
   int *d_tab;
   PSP_HIP(hipMalloc((void **)&d_tab, 65 * sizeof(int)));
   int init[65];
@@ -1626,6 +1804,90 @@ static int ensure_big_partials(psp::CsrExtra *ex, int cap) {
   return PSP_OK;
 }
 
+// sss_spmv_w4 tables of a symmetric-skyline handle (built on first use)
+static std::mutex g_sss_mu;
+static int ensure_sss_w4(psp_sss *S) {
+  std::lock_guard<std::mutex> lk(g_sss_mu);
+  if (S->w4_state >= 0) return PSP_OK;
+  S->w4_state = 0;
+  static const bool off = [] {
+    const char *e = getenv("PSP_SSS_W4");
+    return e && atoi(e) == 0;
+  }();
+  if (off || S->n < 2 || S->nnz_lower < 1) return PSP_OK;
+  int *d_tab;
+  PSP_HIP(hipMalloc((void **)&d_tab, 65 * sizeof(int)));
+  int init[65];
+  for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
+  init[64] = 0;
+  PSP_HIP(hipMemcpyAsync(d_tab, init, sizeof(init), hipMemcpyHostToDevice, stream()));
+  hipLaunchKernelGGL(dia_offsets_kernel, dim3(std::min((S->n + 255) / 256, 8192)), dim3(256), 0, stream(), S->n,
+                     S->ind, S->col, d_tab, d_tab + 64);
+  PSP_LAUNCH_CHECK();
+  int tab[65];
+  PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(d_tab));
+  if (tab[64]) return PSP_OK;
+  std::vector<int> offs;
+  for (int i = 0; i < 64; ++i)
+    if (tab[i] != kDiaEmpty) offs.push_back(tab[i]);
+  if (offs.empty() || offs.size() > 8) return PSP_OK;
+  std::sort(offs.begin(), offs.end());
+  const int nol = (int)offs.size();
+  const size_t nblk = ((size_t)S->n + kDiaRows - 1) / kDiaRows;
+  // padded lower values must stay below what the mirrored product streams for them
+  if ((double)nblk * kDiaRows * nol * 8.0 > 11.0 * (double)S->nnz_lower) return PSP_OK;
+  SssOffs so;
+  for (int i = 0; i < 8; ++i) so.o[i] = i < nol ? offs[i] : -1;
+  const size_t nval = nblk * kDiaRows * nol;
+  unsigned char *low = nullptr;
+  hipError_t e1 = hipMalloc((void **)&S->w4_val, sizeof(double) * nval);
+  hipError_t e2 = hipMalloc((void **)&S->w4_mask, sizeof(unsigned short) * (nblk * kDiaRows + 2));
+  hipError_t e3 = hipMalloc((void **)&low, (size_t)S->n);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    (void)hipGetLastError();
+    if (e1 == hipSuccess) (void)hipFree(S->w4_val);
+    if (e2 == hipSuccess) (void)hipFree(S->w4_mask);
+    if (e3 == hipSuccess) (void)hipFree(low);
+    S->w4_val = nullptr;
+    S->w4_mask = nullptr;
+    return PSP_OK;
+  }
+  PSP_HIP(hipMemsetAsync(S->w4_val, 0, sizeof(double) * nval, stream()));
+  PSP_HIP(hipMemsetAsync(S->w4_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
+  const int grid = std::min((S->n + 255) / 256, 65536);
+  hipLaunchKernelGGL(sss_lowmask_kernel, dim3(grid), dim3(256), 0, stream(), S->n, nol, so, S->ind, S->col,
+                     S->val, S->w4_val, low);
+  hipLaunchKernelGGL(sss_mask_kernel, dim3(grid), dim3(256), 0, stream(), S->n, nol, so, low, S->w4_mask);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(low));
+  for (int i = 0; i < 8; ++i) S->w4_offs[i] = so.o[i];
+  S->w4_nol = nol;
+  S->w4_state = 1;
+  return PSP_OK;
+}
+
+static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *y, const double *dotv,
+                         double *pbuf, const int *skip, int grid) {
+  SssOffs so;
+  for (int i = 0; i < 8; ++i) so.o[i] = S->w4_offs[i];
+#define PSP_SW4(NOL)                                                                                 \
+  case NOL:                                                                                          \
+    hipLaunchKernelGGL((sss_spmv_w4<NOL>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,      \
+                       S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip);                      \
+    break
+  switch (S->w4_nol) {
+    PSP_SW4(1); PSP_SW4(2); PSP_SW4(3); PSP_SW4(4); PSP_SW4(5); PSP_SW4(6); PSP_SW4(7); PSP_SW4(8);
+    default:
+      return fail(PSP_EINVAL, "sss_spmv_w4: %d offsets", S->w4_nol);
+  }
+#undef PSP_SW4
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
 static int ensure_packed(const psp_csr *A, char **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
@@ -1711,6 +1973,11 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
 
 bool csr_spmv_has_skip(const psp_csr *A) {
   Variant v = decode_variant(A->variant);
+  if (v.w4 && A->sym_owner) {
+    psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
+    if (ensure_sss_w4(S) != PSP_OK) return false;
+    if (S->w4_state == 1) return true;
+  }
   if (v.w4) {
     psp::CsrExtra *ex;
     if (ensure_w4(A, &ex) != PSP_OK) return false;
@@ -1728,6 +1995,35 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   Workspace *w;
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
+  if (v.w4 && A->sym_owner) {  // the full mirror of an sss_mat: multiply with the lower triangle only
+    psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
+    PSP_TRY(ensure_sss_w4(S));
+    if (S->w4_state == 1) {
+      const int stripe = w4_stripe(A, v);
+      const int nblk = (S->n + kDiaRows - 1) / kDiaRows;
+      const int grid = w4_grid(nblk, stripe);
+      double *pbuf = partials;
+      if (partials && grid > kMaxParts) {
+        psp::CsrExtra *ex;
+        {
+          std::lock_guard<std::mutex> lk(g_extra_mu);
+          ex = &g_extra[A];
+        }
+        PSP_TRY(ensure_big_partials(ex, grid));
+        pbuf = ex->big_partials;
+      }
+      PSP_TRY(launch_sss_w4(S, stripe, x, y, dotv, pbuf, skip, grid));
+      int np = grid;
+      if (pbuf != partials) {
+        np = kFold;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid,
+                           partials, np);
+        PSP_LAUNCH_CHECK();
+      }
+      if (nparts) *nparts = np;
+      return PSP_OK;
+    }
+  }
   if (v.w4) {
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
@@ -2316,7 +2612,16 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   const char *k = "csr_spmv_stream";
   int vals[4] = {0, 0, 0, 0};
   bool w4 = false;
-  if (v.w4) {
+  if (v.w4 && A->sym_owner) {
+    psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
+    PSP_TRY(ensure_sss_w4(S));
+    if (S->w4_state == 1) {
+      w4 = true;
+      k = "sss_spmv_w4";
+      vals[0] = S->w4_nol;
+    }
+  }
+  if (!w4 && v.w4) {
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
     if (ex->dia_state == 1) {
@@ -2446,6 +2751,7 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
     PSP_HIP(hipMemcpyAsync(S->diag, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
                            stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
+  S->full->sym_owner = S;
   *out = S;
   return PSP_OK;
 }
@@ -2477,6 +2783,7 @@ int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out) {
                      S->col, S->val, S->diag);
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(stream()));
+  S->full->sym_owner = S;
   *out = S;
   return PSP_OK;
 }
@@ -2484,6 +2791,8 @@ int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out) {
 int psp_sss_destroy(psp_sss_t *S) {
   if (!S) return PSP_OK;
   psp_csr_destroy(S->full);
+  if (S->w4_val) (void)hipFree(S->w4_val);
+  if (S->w4_mask) (void)hipFree(S->w4_mask);
   (void)hipFree(S->ind);
   (void)hipFree(S->col);
   (void)hipFree(S->val);
@@ -2556,6 +2865,16 @@ int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, do
 
 int psp_sss_matvec(psp_sss_t *S, const double *x_host, double *y_host) {
   return psp_sss_matvec_stride(S, x_host, 1, y_host, 1);
+}
+
+int psp_sss_kernel_info(psp_sss_t *S, char *name, int name_cap, int *info) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_kernel_info: NULL handle");
+  return psp_csr_kernel_info(S->full, name, name_cap, info);
+}
+
+int psp_sss_set_variant(psp_sss_t *S, int variant) {
+  if (!S) return fail(PSP_EINVAL, "psp_sss_set_variant: NULL handle");
+  return psp_csr_set_variant(S->full, variant);
 }
 
 int64_t psp_sss_device_bytes(const psp_sss_t *S) {

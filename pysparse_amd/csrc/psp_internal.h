@@ -80,6 +80,7 @@ struct psp_csr {
   int variant = -1;  // kernel variant override, -1 = default
   int max_row_nnz = 0;
   int sched_strip_rows = -1;  // psp_csr_set_schedule: -1 automatic, 0 off, > 0 forced strip width
+  const struct psp_sss *sym_owner = nullptr;  // set on the full mirror of an sss_mat (sss_spmv_w4)
 };
 
 struct psp_sss {
@@ -89,6 +90,13 @@ struct psp_sss {
   double *val = nullptr;
   double *diag = nullptr;
   psp_csr *full = nullptr;  // expanded full-CSR device mirror used by matvec
+  // sss_spmv_w4: offset-major values of the strict lower triangle + row masks (psp_csr.hip);
+  // state -1 not examined, 0 not eligible, 1 built
+  int w4_state = -1;
+  int w4_nol = 0;
+  int w4_offs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double *w4_val = nullptr;
+  unsigned short *w4_mask = nullptr;
 };
 
 enum psp_op_kind { PSP_OP_CSR = 1, PSP_OP_SSS = 2, PSP_OP_JACOBI = 3, PSP_OP_CALLBACK = 4 };

@@ -194,6 +194,19 @@ class DeviceSSS:
 
     matvec_transp = matvec  # sss_mat.c:108
 
+    def matvec_dev(self, x_ptr, y_ptr):
+        check(lib().psp_sss_matvec_dev(self._h, x_ptr, y_ptr))
+
+    def set_variant(self, v):
+        check(lib().psp_sss_set_variant(self._h, int(v)))
+
+    def kernel_info(self):
+        name = C.create_string_buffer(64)
+        info = (C.c_int * 4)()
+        check(lib().psp_sss_kernel_info(self._h, name, 64, info))
+        return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
+                                     "half_band": info[3]}
+
     def __getitem__(self, ij):
         if not (isinstance(ij, tuple) and len(ij) == 2 and all(isinstance(t, (int, np.integer)) for t in ij)):
             raise IndexError("slices not supported")

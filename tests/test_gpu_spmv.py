@@ -385,3 +385,60 @@ def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
     Cm.matvec(xx, y_ref)
     DC.matvec(xx, y)
     assert np.array_equal(y, y_ref)
+
+
+def offset_structured_sss(O, n, seed, lower_offsets, keep=0.93):
+    rng = np.random.default_rng(seed)
+    offs = np.sort(np.asarray(lower_offsets))
+    ind = np.zeros(n + 1, dtype=np.int32)
+    cols = []
+    for r in range(n):
+        c = r + offs
+        c = c[c >= 0]
+        c = c[rng.random(c.size) < keep]
+        cols.append(c)
+        ind[r + 1] = ind[r] + c.size
+    col = np.concatenate(cols).astype(np.int32)
+    diag = rng.standard_normal(n)
+    diag[rng.random(n) < 0.05] = 0.0
+    return O.SSS(n, rng.standard_normal(ind[-1]), diag, col, ind)
+
+
+@pytest.mark.parametrize("case", [("poisson", (60, 45, 0)), ("poisson", (20, 21, 22)), ("poisson", (33, 7, 5)),
+                                  ("poisson", (128, 128, 0)), ("random", (1001, (-37, -2, -1))),
+                                  ("random", (2049, (-64, -1))), ("random", (1300, (-129,))),
+                                  ("random", (5000, (-700, -699, -31, -30, -5, -3, -2, -1)))])
+def test_sss_matvec_w4_lower_only_bit_exact(oracle, case):
+    """sss_spmv_w4: only the strict lower triangle is stored / streamed; per-row order = sss_mat.c:45-55
+    (lower by column, diagonal, mirrored entries by row); odd and even shifts, odd n, NaN / Inf in x;
+    the mirrored-CSR kernels on the same handle give the same bits"""
+    from pysparse_amd.device import DeviceSSS
+    kind, arg = case
+    if kind == "poisson":
+        S = oracle.poisson_sss(*arg)
+        D = DeviceSSS.poisson(*arg)
+    else:
+        S = offset_structured_sss(oracle, arg[0], 17, arg[1])
+        D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    name, info = D.kernel_info()
+    assert name == "sss_spmv_w4", (name, info)
+    for seed, special in ((1, False), (2, True)):
+        x = rng_vec(S.n, seed)
+        if special and S.n > 8:
+            x[S.n // 3] = np.nan
+            x[S.n // 2] = np.inf
+            x[S.n - 1] = -np.inf
+            x[0] = np.inf
+        y_ref = np.full(S.n, 123.0)
+        S.matvec(x, y_ref)
+        D.set_variant(-1)
+        y = np.full(S.n, 321.0)
+        D.matvec(x, y)
+        assert np.array_equal(y, y_ref, equal_nan=True)
+        for variant in ((1 << 20) + 16578, 16578):  # mirrored full CSR through w3 / w2
+            D.set_variant(variant)
+            assert D.kernel_info()[0] != "sss_spmv_w4"
+            y2 = np.full(S.n, 321.0)
+            D.matvec(x, y2)
+            assert np.array_equal(y2, y_ref, equal_nan=True)
+    D.set_variant(-1)

@@ -15,9 +15,10 @@ ap.add_argument("--grid", default="512,512,512")
 ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--pcg", type=int, default=0, help="also run this many Jacobi-PCG iterations")
+ap.add_argument("--sss", action="store_true", help="symmetric-skyline operator (sss_spmv_w4 by default)")
 a = ap.parse_args()
 nx, ny, nz = (int(t) for t in a.grid.split(","))
-A = dev.DeviceCSR.poisson(nx, ny, nz)
+A = dev.DeviceSSS.poisson(nx, ny, nz) if a.sss else dev.DeviceCSR.poisson(nx, ny, nz)
 A.set_variant(a.variant)
 n = A.shape[0]
 x = dev.DeviceBuffer.from_host(np.random.default_rng(0).standard_normal(n))
@@ -34,4 +35,4 @@ if a.pcg:
     info, it, rr = C.c_int(), C.c_int(), C.c_double()
     check(lib().psp_pcg_dev(aop._h, kop._h, n, x.ptr, b.ptr, 0.0, a.pcg, C.byref(info), C.byref(it), C.byref(rr), None))
     print("pcg", info.value, it.value, rr.value)
-print("done", n, A.nnz)
+print("done", n, A.nnz, A.kernel_info())
