@@ -1064,7 +1064,7 @@ __global__ void sss_mask_kernel(int n, int nol, SssOffs offs, const unsigned cha
   }
 }
 
-template <int NOL>
+template <int NOL, int FLAGS = 0>
 __global__ __launch_bounds__(256) void sss_spmv_w4(
     int n, int stripe, SssOffs offs, const double *__restrict__ valL, const double *__restrict__ diag,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     const double *vp = valL + (size_t)blk * NOL * kDiaRows + 2 * lane;
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {
-      vl[j] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vp + j * kDiaRows));
+      vl[j] = ldg<(FLAGS & 1) != 0>(reinterpret_cast<const d2v *>(vp + j * kDiaRows));  // plain: the line is usually in L2 already (shifted read), NT costs 6 %
       const long c = r + offs.o[j];  // < r
       const long cc = c < 0 ? 0 : c;
       const d2u t = *reinterpret_cast<const d2u *>(x + cc);
@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     for (int j = 0; j < NOL; ++j) {
       const long ru = r - offs.o[j];
       const long v0 = ru < npad ? ru : npad - 1, v1 = ru + 1 < npad ? ru + 1 : npad - 1;
-      vu[j].x = valL[((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows)];
-      vu[j].y = valL[((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows)];
+      vu[j].x = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows));
+      vu[j].y = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows));
       const long xr = ru > xmax ? xmax : ru;
       const d2u t = *reinterpret_cast<const d2u *>(x + xr);
       xu[j].x = t.x;
@@ -1873,10 +1873,16 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
                          double *pbuf, const int *skip, int grid) {
   SssOffs so;
   for (int i = 0; i < 8; ++i) so.o[i] = S->w4_offs[i];
+  const int flags = (S->full->variant >= 0 ? S->full->variant : 0) >> 23 & 3;  // A/B: 1 NT lower loads (-6 %), 2 NT shifted loads (-25 %); profiles/r1_sss_spmv_w4_timing.txt
+#define PSP_SW4_F(NOL, F)                                                                            \
+  hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
+                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip)
 #define PSP_SW4(NOL)                                                                                 \
   case NOL:                                                                                          \
-    hipLaunchKernelGGL((sss_spmv_w4<NOL>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,      \
-                       S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip);                      \
+    if (flags == 0) PSP_SW4_F(NOL, 0);                                                               \
+    else if (flags == 1) PSP_SW4_F(NOL, 1);                                                          \
+    else if (flags == 2) PSP_SW4_F(NOL, 2);                                                          \
+    else PSP_SW4_F(NOL, 3);                                                                          \
     break
   switch (S->w4_nol) {
     PSP_SW4(1); PSP_SW4(2); PSP_SW4(3); PSP_SW4(4); PSP_SW4(5); PSP_SW4(6); PSP_SW4(7); PSP_SW4(8);
@@ -1884,6 +1890,7 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
       return fail(PSP_EINVAL, "sss_spmv_w4: %d offsets", S->w4_nol);
   }
 #undef PSP_SW4
+#undef PSP_SW4_F
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

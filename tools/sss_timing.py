@@ -22,7 +22,11 @@ n = S.n
 nnz_lower = S.nnz - n
 x = dev.DeviceBuffer.from_host(np.random.default_rng(0).standard_normal(n))
 y = dev.DeviceBuffer(n)
-variants = {"default": -1, "mirror_w3": (1 << 20) + 16578, "mirror_w2": 16578}
+B = (1 << 22) + (1 << 20) + 194
+variants = {"default": -1, "s32_f0": B + (32 << 8), "s32_ntlow": B + (32 << 8) + (1 << 23),
+            "s32_ntshift": B + (32 << 8) + (2 << 23), "s32_both": B + (32 << 8) + (3 << 23),
+            "s0": B, "s16": B + (16 << 8), "s64": B + (64 << 8), "s128": B + (128 << 8),
+            "mirror_w3": (1 << 20) + 16578, "mirror_w2": 16578}
 times = {k: [] for k in variants}
 names = {}
 ref = None
