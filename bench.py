@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--pcg-iters", type=int, default=40)
     ap.add_argument("--grid", default="", help="override the grid, e.g. 256,256,256 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sss", action="store_true", help="skip the sss_mat leg (N = 1)")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed driver even at world size 1 (plumbing check)")
@@ -260,6 +261,38 @@ def main():
             res = (info.value, it.value, rr.value)
     pcg_s_per_iter = pcg_t / k
 
+    # ---- beside it (N = 1): the same operator as an sss_mat (examples/poisson_test.py solves with
+    # S = L.to_sss()): y = S x from the strict lower triangle only, and Jacobi-PCG on it
+    sss = None
+    if not use_dist and not a.no_sss:
+        S = dev.DeviceSSS.poisson(nx, ny, nz)
+        for _ in range(3):
+            S.matvec_dev(xb.ptr, yb.ptr)
+        sync()
+        ev.start()
+        for _ in range(a.steps):
+            S.matvec_dev(xb.ptr, yb.ptr)
+        s_ms = ev.stop_ms() / a.steps
+        sync()
+        nnz_lower = S.nnz - n_loc
+        KS = dev.DeviceJacobi(S)
+        sop, ksop = dev._Op(S, "matvec"), dev._Op(KS, "precon")
+        for kk in (2, k):
+            xb.zero()
+            info, it, rr = C.c_int(), C.c_int(), C.c_double()
+            sync()
+            t = time.perf_counter()
+            check(L.psp_pcg_dev(sop._h, ksop._h, n_loc, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it),
+                                C.byref(rr), None))
+            sync()
+            s_pcg_t = time.perf_counter() - t
+        sss = {"kernel": S.kernel_info()[0], "spmv_ms": s_ms,
+               # B_sss = 12 nnz_lower + 28 n + 4
+               "spmv_GBps_sss_model": (12 * nnz_lower + 28 * n_loc + 4) / (s_ms * 1e-3) / 1e9,
+               "pcg_iters_per_s": k / s_pcg_t, "pcg_check": {"info": info.value, "iter": it.value, "relres": rr.value}}
+        sss["frac_sss_model"] = sss["spmv_GBps_sss_model"] / HBM_PEAK_GBPS
+        del S, KS, sop, ksop
+
     # ---- MAX over ranks
     if use_dist:
         t = torch.tensor([wall, ev_ms, pcg_s_per_iter], dtype=torch.float64, device="cuda")
@@ -316,6 +349,8 @@ def main():
         }
         if general is not None:
             out["roofline_general_csr"] = general
+        if sss is not None:
+            out["sss_mat"] = sss
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
