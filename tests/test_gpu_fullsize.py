@@ -1,0 +1,234 @@
+"""GPU parity at BASELINE.json's FULL sizes (C2 4096^2, C3 512^3, one rank's slab of C4 1024^3),
+through properties that need no CPU oracle at that size:
+
+  * exact row sums: A*ones is 0 in the interior and the number of missing neighbours on the
+    boundary (small integers, so the comparison is exact);
+  * every SpMV kernel (w4 / w3 / w2, and the sss_mat product from the lower triangle only) gives
+    the SAME BITS for a random x -- the small-size tests pin each of them to the oracle bit for bit;
+  * symmetry (A x).z == x.(A z) and linearity to rounding;
+  * Jacobi-PCG: the recurred residual norm the solver reports equals ||b - A x|| recomputed from
+    the returned x (pcg.c:146-153 keeps the recurred one), identical iteration counts and iterates
+    <= 1e-12 apart whichever kernel multiplies; the 2-D config run to convergence recovers x = 1.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W3 = (1 << 20) + 16578
+W2 = 16578
+
+
+def missing_neighbours(nx, ny, nz):
+    shape = (nz, ny, nx) if nz else (ny, nx)
+    e = np.zeros(shape)
+    for ax in range(len(shape)):
+        sl_lo = [slice(None)] * len(shape)
+        sl_hi = [slice(None)] * len(shape)
+        sl_lo[ax], sl_hi[ax] = 0, -1
+        e[tuple(sl_lo)] += 1
+        e[tuple(sl_hi)] += 1
+    return e.ravel()
+
+
+def dev_dot(L, check, n, a, b, out):
+    check(L.psp_k_dot(n, a.ptr, b.ptr, out.ptr))
+    return float(out.download()[0])
+
+
+@pytest.mark.parametrize("grid", [(4096, 4096, 0), (512, 512, 512)])
+def test_fullsize_spmv_properties(grid):
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    nx, ny, nz = grid
+    A = dev.DeviceCSR.poisson(nx, ny, nz)
+    n = A.shape[0]
+    stencil = 7 if nz else 5
+    faces = 2 * (nx * ny + ny * nz + nx * nz) if nz else 2 * (nx + ny)
+    assert n == nx * ny * max(nz, 1) and A.nnz == stencil * n - faces  # test_spmatrix.py:77-78 extended to 3-D
+    assert A.kernel_info()[0] == "csr_spmv_w4"
+
+    ones = dev.DeviceBuffer.from_host(np.ones(n))
+    y = dev.DeviceBuffer(n)
+    A.matvec_dev(ones.ptr, y.ptr)
+    assert np.array_equal(y.download(), missing_neighbours(nx, ny, nz))
+    del ones
+
+    rng = np.random.default_rng(5)
+    xh = rng.standard_normal(n)
+    x = dev.DeviceBuffer.from_host(xh)
+    A.matvec_dev(x.ptr, y.ptr)
+    y_w4 = y.download()
+    for variant, name in ((W3, "csr_spmv_w3"), (W2, "csr_spmv_w2")):
+        A.set_variant(variant)
+        assert A.kernel_info()[0] == name
+        y.zero()
+        A.matvec_dev(x.ptr, y.ptr)
+        assert np.array_equal(y.download(), y_w4), name
+    A.set_variant(-1)
+
+    # spot rows against the definition (corners, edges, interior), exact
+    nxy = nx * ny
+    for k in sorted({k for k in (0, 1, nx - 1, nx, nxy - 1, nxy, n // 2 + nx // 3, n - nxy - 1, n - nx, n - 1) if 0 <= k < n}):
+        i, j, l = k % nx, (k // nx) % ny, k // nxy
+        s = 0.0
+        if nz and l > 0:
+            s += -1.0 * xh[k - nxy]
+        if j > 0:
+            s += -1.0 * xh[k - nx]
+        if i > 0:
+            s += -1.0 * xh[k - 1]
+        s += (6.0 if nz else 4.0) * xh[k]
+        if i < nx - 1:
+            s += -1.0 * xh[k + 1]
+        if j < ny - 1:
+            s += -1.0 * xh[k + nx]
+        if nz and l < nz - 1:
+            s += -1.0 * xh[k + nxy]
+        assert y_w4[k] == s, k
+
+    # sss_mat: same operator from the strict lower triangle; same per-row order => same bits
+    S = dev.DeviceSSS.poisson(nx, ny, nz)
+    assert S.kernel_info()[0] == "sss_spmv_w4"
+    y.zero()
+    S.matvec_dev(x.ptr, y.ptr)
+    assert np.array_equal(y.download(), y_w4)
+    del S
+
+    # symmetry and linearity, to rounding
+    z = dev.DeviceBuffer.from_host(rng.standard_normal(n))
+    az = dev.DeviceBuffer(n)
+    A.matvec_dev(z.ptr, az.ptr)
+    A.matvec_dev(x.ptr, y.ptr)
+    out = dev.DeviceBuffer(4)
+    ax_z = dev_dot(L, check, n, y, z, out)
+    x_az = dev_dot(L, check, n, x, az, out)
+    scale = np.sqrt(dev_dot(L, check, n, y, y, out) * dev_dot(L, check, n, z, z, out))
+    assert abs(ax_z - x_az) <= 1e-12 * scale
+    azh = az.download()
+    comb = dev.DeviceBuffer.from_host(2.5 * xh - 0.75 * z.download())
+    A.matvec_dev(comb.ptr, az.ptr)
+    lin = az.download() - (2.5 * y_w4 - 0.75 * azh)
+    assert np.abs(lin).max() <= 64 * np.finfo(float).eps * (np.abs(y_w4).max() + np.abs(azh).max())
+
+
+def _pcg_dev(L, check, dev, A, K, n, x, b, tol, maxit):
+    aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
+    info, it, rr = C.c_int(), C.c_int(), C.c_double()
+    check(L.psp_pcg_dev(aop._h, kop._h, n, x.ptr, b.ptr, tol, maxit, C.byref(info), C.byref(it), C.byref(rr), None))
+    check(L.psp_synchronize())
+    return info.value, it.value, rr.value
+
+
+def test_fullsize_pcg_512_fixed_iterations_consistent_across_kernels():
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    nx = ny = nz = 512
+    A = dev.DeviceCSR.poisson(nx, ny, nz)
+    n = A.shape[0]
+    K = dev.DeviceJacobi(A)
+    ones = dev.DeviceBuffer.from_host(np.ones(n))
+    b = dev.DeviceBuffer(n)
+    A.matvec_dev(ones.ptr, b.ptr)  # b = A*ones (demo_pcg.py:57-58)
+    del ones
+    out = dev.DeviceBuffer(4)
+    n2b = np.sqrt(dev_dot(L, check, n, b, b, out))
+    r = dev.DeviceBuffer(n)
+    results = {}
+    for name, variant in (("w4", -1), ("w3", W3)):
+        A.set_variant(variant)
+        x = dev.DeviceBuffer(n)
+        x.zero()
+        info, it, relres = _pcg_dev(L, check, dev, A, K, n, x, b, 0.0, 25)
+        assert (info, it) == (-1, 26)  # tol = 0: the loop runs out, iter = maxit + 1 (pcg.c:165)
+        # true residual of the returned iterate against the recurred norm the solver kept
+        A.matvec_dev(x.ptr, r.ptr)
+        check(L.psp_k_residual(n, b.ptr, r.ptr, None, out.ptr))
+        true_rel = np.sqrt(float(out.download()[0])) / n2b
+        assert abs(true_rel - relres) <= 1e-10 * relres
+        results[name] = (relres, x.download())
+        del x
+    A.set_variant(-1)
+    S = dev.DeviceSSS.poisson(nx, ny, nz)
+    KS = dev.DeviceJacobi(S)
+    x = dev.DeviceBuffer(n)
+    x.zero()
+    info, it, relres = _pcg_dev(L, check, dev, S, KS, n, x, b, 0.0, 25)
+    assert (info, it) == (-1, 26)
+    results["sss"] = (relres, x.download())
+    ref_rr, ref_x = results["w4"]
+    assert 0 < ref_rr < 0.2  # 25 Jacobi-PCG iterations take the residual well below ||b||
+    for name in ("w3", "sss"):
+        rr, xs = results[name]
+        # same products in the same per-row order: only the dot-product partial order differs
+        assert abs(rr - ref_rr) <= 1e-12 * ref_rr, name
+        assert np.abs(xs - ref_x).max() <= 1e-12 * np.abs(ref_x).max(), name
+
+
+def test_fullsize_pcg_4096sq_converges_to_ones():
+    """C2: 2-D 5-pt 4096^2, b = A*ones, Jacobi-PCG to 1e-8 (the demo_pcg.py flow at full size)."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    A = dev.DeviceCSR.poisson(4096, 4096)
+    n = A.shape[0]
+    K = dev.DeviceJacobi(A)
+    ones = dev.DeviceBuffer.from_host(np.ones(n))
+    b = dev.DeviceBuffer(n)
+    A.matvec_dev(ones.ptr, b.ptr)
+    x = dev.DeviceBuffer(n)
+    x.zero()
+    info, it, relres = _pcg_dev(L, check, dev, A, K, n, x, b, 1e-8, 40000)
+    assert info == 0 and relres <= 1e-8
+    assert 2000 < it < 30000  # O(N) iterations for the N x N grid (G1: 160 at N = 100, tol 1e-6)
+    xs = x.download()
+    assert np.abs(xs - 1.0).max() < 0.1  # error <= cond * relres ~ 7e6 * 1e-8, far from tight
+    # the recurred residual is the true one
+    r = dev.DeviceBuffer(n)
+    out = dev.DeviceBuffer(4)
+    n2b = np.sqrt(dev_dot(L, check, n, b, b, out))
+    A.matvec_dev(x.ptr, r.ptr)
+    check(L.psp_k_residual(n, b.ptr, r.ptr, None, out.ptr))  # r := b - A x, out[0] = r.r
+    true_rel = np.sqrt(float(out.download()[0])) / n2b
+    assert abs(true_rel - relres) <= 1e-4 * relres  # thousands of recurrence steps apart
+
+
+def test_fullsize_slab_of_1024_cubed():
+    """C4: the row block one of 8 ranks owns (128 z-planes of 1024^3 = 2^27 rows, ghost-extended
+    columns): interior rank => every row sum is 0 except nothing (all six neighbours exist inside
+    the global grid in z; x/y faces are boundary)."""
+    from pysparse_amd import device as dev
+    nx = ny = 1024
+    nz = 1024
+    nxy = nx * ny
+    lo, hi = 3 * 128 * nxy, 4 * 128 * nxy  # rank 3 of 8
+    shift = lo - nxy
+    ncols = (hi - lo) + 2 * nxy
+    A = dev.DeviceCSR.poisson_slab(nx, ny, nz, lo, hi, shift, ncols)
+    assert A.shape == (1 << 27, ncols) and A.nnz == 938999808  # interior ranks
+    assert A.kernel_info()[0] == "csr_spmv_w4"
+    ones = dev.DeviceBuffer.from_host(np.ones(ncols))
+    y = dev.DeviceBuffer(hi - lo)
+    A.matvec_dev(ones.ptr, y.ptr)
+    e2 = missing_neighbours(nx, ny, 0)  # x/y faces only: the z neighbours are ghosts that exist
+    yh = y.download().reshape(128, nxy)
+    assert np.array_equal(yh, np.broadcast_to(e2, (128, nxy)))
+    xh = np.random.default_rng(2).standard_normal(ncols)
+    x = dev.DeviceBuffer.from_host(xh)
+    A.matvec_dev(x.ptr, y.ptr)
+    y4 = y.download()
+    A.set_variant(W3)
+    assert A.kernel_info()[0] == "csr_spmv_w3"
+    y.zero()
+    A.matvec_dev(x.ptr, y.ptr)
+    assert np.array_equal(y.download(), y4)
+    k = 77 * nxy + 513 * nx + 100  # an interior row, against the definition
+    g = k + nxy  # its position in the extended vector
+    s = 0.0
+    for c, v in ((g - nxy, -1.0), (g - nx, -1.0), (g - 1, -1.0), (g, 6.0), (g + 1, -1.0), (g + nx, -1.0), (g + nxy, -1.0)):
+        s += v * xh[c]
+    assert y4[k] == s
