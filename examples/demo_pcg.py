@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Python-3 counterpart of the reference's examples/demo_pcg.py:23-100 on the MI355X modules:
-per MatrixMarket problem, b = A*e and three... two PCG solves (no preconditioner, Jacobi);
-prints n, nnz, iter, relres, ||x-e||_inf, info, setup and solve seconds.  The SSOR column of
-the reference script is outside this build's scope.
+per MatrixMarket problem, b = A*e and three PCG solves (no preconditioner, Jacobi,
+SSOR on A.to_sss()); prints n, nnz, iter, relres, ||x-e||_inf, info, setup and solve seconds.
 
   python examples/demo_pcg.py problem.mtx [problem2.mtx ...]
   python examples/demo_pcg.py --poisson 100        # generate poisson2d_sym(100) on the fly
@@ -60,6 +59,15 @@ def test_pcg(problems, tol=1.0e-6):
         x = np.zeros(n, "d")
         t = time.perf_counter()
         M = precon.jacobi(A, 1.0, 1)
+        t_m = time.perf_counter() - t
+        t = time.perf_counter()
+        info, it, relres = pcg(A, b, x, tol, 2 * n, M)
+        t_solve = time.perf_counter() - t
+        err = np.linalg.norm(x - e, ord=np.inf)
+        print("%10s  %8s  %9s  %6d  %8.1e  %8.1e  %4d  %6.2f  %6.2f" % ("", "", "", it, relres, err, info, t_m, t_solve))
+        x = np.zeros(n, "d")
+        t = time.perf_counter()
+        M = precon.ssor(A.to_sss(), 1.0, 1)  # demo_pcg.py:84-86
         t_m = time.perf_counter() - t
         t = time.perf_counter()
         info, it, relres = pcg(A, b, x, tol, 2 * n, M)

@@ -48,6 +48,7 @@ extern "C" {
 typedef struct psp_csr psp_csr_t;       /* device mirror of CSRMatObject, csr_mat.h:6-13     */
 typedef struct psp_sss psp_sss_t;       /* device mirror of SSSMatObject, sss_mat.h:6-14     */
 typedef struct psp_jacobi psp_jacobi_t; /* device mirror of JacobiObject, preconmodule.c:11-19 */
+typedef struct psp_ssor psp_ssor_t;     /* device mirror of SSORObject, preconmodule.c:21-31   */
 typedef struct psp_op psp_op_t;         /* "anything with shape + matvec / precon":
                                            the operator protocol of spmatrixmodule.c:169-248 */
 
@@ -181,6 +182,21 @@ int psp_jacobi_shape(const psp_jacobi_t *K, int *n);
 int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host);
 int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev);
 
+/* --------------------------------------------------------------------- ssor */
+
+/* replaces newSSORObject (preconmodule.c:414-459): `steps` symmetric Gauss-Seidel (omega == 1,
+ * symgs_kernel :149-193) or SSOR (ssor_kernel :95-143) steps with a zero initial guess on an
+ * sss_mat.  The triangular sweeps are level-scheduled; every row performs the reference's
+ * operations in the reference's order, so results are bit-identical to the sequential loops.
+ * The handle borrows A (keep it alive). */
+int psp_ssor_create(psp_sss_t *A, double omega, int steps, psp_ssor_t **out);
+int psp_ssor_destroy(psp_ssor_t *K);
+/* n and the number of dependency levels of the forward / backward sweep */
+int psp_ssor_info(const psp_ssor_t *K, int *n, int *levels_forward, int *levels_backward);
+/* y := K x.  SSOR_precon, preconmodule.c:199-223 */
+int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host);
+int psp_ssor_precon_dev(psp_ssor_t *K, const double *x_dev, double *y_dev);
+
 /* --------------------------------------------------------- operator protocol */
 
 /* Host callback operator: the C image of SpMatrix_Matvec / SpMatrix_Precon
@@ -191,6 +207,7 @@ typedef int (*psp_host_apply_fn)(void *ctx, int n, const double *x_host, double 
 int psp_op_from_csr(psp_csr_t *A, psp_op_t **out);
 int psp_op_from_sss(psp_sss_t *A, psp_op_t **out);
 int psp_op_from_jacobi(psp_jacobi_t *K, psp_op_t **out);
+int psp_op_from_ssor(psp_ssor_t *K, psp_op_t **out);
 int psp_op_from_callback(int n, psp_host_apply_fn fn, void *ctx, psp_op_t **out);
 int psp_op_destroy(psp_op_t *op);
 

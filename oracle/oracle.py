@@ -81,6 +81,13 @@ def _declare(L):
     L.orc_minres_sss.restype = C.c_int
     L.orc_minres_sss.argtypes = [C.c_int, _dp, _dp, _ip, _ip, C.c_void_p, C.c_int, _dp, _dp, C.c_double,
                                  C.c_int, ipt, dpt, C.c_void_p]
+    L.orc_symgs.restype = None
+    L.orc_symgs.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+    L.orc_ssor.restype = None
+    L.orc_ssor.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_double, C.c_int]
+    L.orc_pcg_sss_ssor.restype = C.c_int
+    L.orc_pcg_sss_ssor.argtypes = [C.c_int, _dp, _dp, _ip, _ip, C.c_double, C.c_int, _dp, _dp, C.c_double,
+                                   C.c_int, ipt, dpt, ipt, C.c_void_p]
     L.orc_krylov_more.restype = C.c_int
     L.orc_krylov_more.argtypes = [C.c_int, C.c_int, _dp, C.c_void_p, _ip, _ip, C.c_void_p, _dp, _dp, C.c_double,
                                   C.c_int, C.c_int, ipt, dpt]
@@ -299,6 +306,27 @@ def jacobi_dinv(diag, omega=1.0):
     if rc:
         raise ValueError("diagonal element close to zero")
     return dinv
+
+
+def ssor_apply(S, x, y, omega=1.0, steps=1):
+    """y = K x for precon.ssor(S, omega, steps) (preconmodule.c:95-223); y is also read when steps == 0."""
+    n = S.n
+    L = lib()
+    if omega == 1.0:
+        L.orc_symgs(n, np.ascontiguousarray(x), y, np.empty(n), S.val, S.diag, S.col, S.ind, steps)
+    else:
+        L.orc_ssor(n, np.ascontiguousarray(x), y, np.empty(n), np.empty(n), S.val, S.diag, S.col, S.ind,
+                   omega, steps)
+
+
+def pcg_ssor(S, b, x, tol, maxit, omega=1.0, steps=1, hist=False):
+    """pcg(S, b, x, tol, maxit, precon.ssor(S, omega, steps)) on the CPU."""
+    it, fl, rr = C.c_int(0), C.c_int(0), C.c_double(0.0)
+    h = np.full(maxit + 2, np.nan) if hist else None
+    rc = lib().orc_pcg_sss_ssor(S.n, S.val, S.diag, S.col, S.ind, omega, steps, x, b, tol, maxit,
+                                C.byref(it), C.byref(rr), C.byref(fl), _opt(h))
+    assert rc == 0
+    return (fl.value, it.value, rr.value, h) if hist else (fl.value, it.value, rr.value)
 
 
 def pcg(A, b, x, tol, maxit, dinv=None, steps=1, hist=False):

@@ -258,6 +258,101 @@ ORC_API int orc_jacobi_apply(void *ctx, int n, const double *x, double *y) {
   return 0;
 }
 
+/* -------------------------------------------------------------------- SSOR */
+
+/* pysparse/precon/src/preconmodule.c:149-193 (symgs_kernel, omega == 1): `steps` symmetric
+ * Gauss-Seidel steps with zero initial guess on the SSS arrays; x is the output, y an n-vector
+ * of work space.  Parity status of the two SSOR routines: UNPINNED at the bit level (no
+ * compilable reference and no golden vector for them exists); tests pin them by identity
+ * against dense triangular solves (tests/test_oracle_golden.py). */
+ORC_API void orc_symgs(int n, const double *b, double *x, double *y, const double *va,
+                       const double *da, const int *ja, const int *ia, int steps) {
+  double s;
+  int step, i, j, k;
+  for (k = 0; k < n; k++) /* :164-165 */
+    y[k] = 0.0;
+  for (step = 0; step < steps; step++) {
+    for (i = 0; i < n; i++) { /* :171-179 */
+      s = 0.0;
+      for (k = ia[i]; k < ia[i + 1]; k++) {
+        j = ja[k];
+        s += va[k] * x[j];
+      }
+      x[i] = (b[i] - y[i] - s) / da[i];
+      y[i] = s;
+    }
+    for (k = 0; k < n; k++) { /* :182-185 */
+      x[k] = y[k];
+      y[k] = 0.0;
+    }
+    for (i = n - 1; i >= 0; i--) { /* :186-193 */
+      x[i] = (b[i] - x[i] - y[i]) / da[i];
+      s = x[i];
+      for (k = ia[i]; k < ia[i + 1]; k++) {
+        j = ja[k];
+        y[j] += va[k] * s;
+      }
+    }
+  }
+}
+
+/* preconmodule.c:95-143 (ssor_kernel, omega != 1); h and temp are n-vectors of work space */
+ORC_API void orc_ssor(int n, const double *b, double *x, double *h, double *temp, const double *va,
+                      const double *da, const int *ja, const int *ia, double omega, int steps) {
+  double s;
+  int step, i, j, k;
+  for (step = 0; step < steps; step++) {
+    if (step == 0) /* :110-115 */
+      for (i = 0; i < n; i++)
+        temp[i] = omega * b[i];
+    else
+      for (i = 0; i < n; i++)
+        temp[i] = (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];
+    for (i = 0; i < n; i++) { /* :117-125 */
+      s = 0.0;
+      for (k = ia[i]; k < ia[i + 1]; k++) {
+        j = ja[k];
+        s -= va[k] * x[j];
+      }
+      h[i] = omega * s;
+      x[i] = (temp[i] + h[i]) / da[i];
+    }
+    for (i = 0; i < n; i++) { /* :128-131 */
+      temp[i] = (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];
+      h[i] = 0.0;
+    }
+    for (i = n - 1; i >= 0; i--) { /* :132-140 */
+      h[i] = omega * h[i];
+      x[i] = (temp[i] + h[i]) / da[i];
+      s = x[i];
+      for (k = ia[i]; k < ia[i + 1]; k++) {
+        j = ja[k];
+        h[j] -= va[k] * s;
+      }
+    }
+  }
+}
+
+typedef struct {
+  int n;
+  const double *va, *da;
+  const int *ja, *ia;
+  double omega;
+  int steps;
+  double *temp, *temp2;
+} orc_ssor_t;
+
+/* SSOR_precon, preconmodule.c:199-223 */
+ORC_API int orc_ssor_apply(void *ctx, int n, const double *x, double *y) {
+  const orc_ssor_t *K = (const orc_ssor_t *)ctx;
+  (void)n;
+  if (K->omega == 1.0)
+    orc_symgs(K->n, x, y, K->temp, K->va, K->da, K->ja, K->ia, K->steps);
+  else
+    orc_ssor(K->n, x, y, K->temp, K->temp2, K->va, K->da, K->ja, K->ia, K->omega, K->steps);
+  return 0;
+}
+
 /* --------------------------------------------------------------------- PCG */
 
 /* pysparse/itsolvers/src/pcg.c:22-171 (Itsolvers_pcg_kernel).  work = 4n doubles
@@ -1128,6 +1223,22 @@ ORC_API int orc_krylov_more(int solver, int n, const double *va, const double *d
     info = orc_gmres(n, tol, maxit, iter, relres, dim, x, b, mv, mctx, pc, &K);
   free(work);
   return info;
+}
+
+/* PCG on an SSS operator with the SSOR preconditioner (examples/demo_pcg.py:78-98, third column) */
+ORC_API int orc_pcg_sss_ssor(int n, const double *va, const double *da, const int *ja, const int *ia,
+                             double omega, int steps, double *x, const double *b, double tol, int maxit,
+                             int *iter, double *relres, int *flag, double *hist) {
+  orc_sss_t As = {n, va, da, ja, ia};
+  orc_ssor_t K = {n, va, da, ja, ia, omega, steps, NULL, NULL};
+  double *work = (double *)malloc(sizeof(double) * 6 * (size_t)(n > 0 ? n : 1));
+  int rc;
+  if (!work) return -2;
+  K.temp = work + 4 * (size_t)n;
+  K.temp2 = work + 5 * (size_t)n;
+  rc = orc_pcg(n, x, b, tol, maxit, iter, relres, flag, work, orc_sss_matvec_cb, &As, orc_ssor_apply, &K, hist);
+  free(work);
+  return rc;
 }
 
 /* --------------------------------------- bound shims for the compiled reference */

@@ -99,7 +99,7 @@ struct psp_sss {
   unsigned short *w4_mask = nullptr;
 };
 
-enum psp_op_kind { PSP_OP_CSR = 1, PSP_OP_SSS = 2, PSP_OP_JACOBI = 3, PSP_OP_CALLBACK = 4 };
+enum psp_op_kind { PSP_OP_CSR = 1, PSP_OP_SSS = 2, PSP_OP_JACOBI = 3, PSP_OP_CALLBACK = 4, PSP_OP_SSOR = 5 };
 
 struct psp_op {
   int kind = 0;
@@ -107,6 +107,7 @@ struct psp_op {
   psp_csr *csr = nullptr;
   psp_sss *sss = nullptr;
   psp_jacobi *jac = nullptr;
+  psp_ssor *ssor = nullptr;
   psp_host_apply_fn fn = nullptr;
   void *ctx = nullptr;
   // pinned staging for callback operators
@@ -150,4 +151,5 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+int ssor_apply_dev(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip
 }  // namespace psp

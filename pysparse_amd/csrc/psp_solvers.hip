@@ -154,6 +154,8 @@ int op_apply(const psp_op *op, const double *x_dev, double *y_dev) {
       return psp_sss_matvec_dev(op->sss, x_dev, y_dev);
     case PSP_OP_JACOBI:
       return jacobi_apply_dev(op->jac, x_dev, y_dev);
+    case PSP_OP_SSOR:
+      return ssor_apply_dev(op->ssor, x_dev, y_dev);
     case PSP_OP_CALLBACK: {
       // SpMatrix_Matvec / SpMatrix_Precon (spmatrixmodule.c:169-248): the callee sees host
       // arrays, so bridge the device vectors through pinned staging buffers
@@ -1005,6 +1007,18 @@ int psp_op_from_jacobi(psp_jacobi_t *K, psp_op_t **out) {
   op->kind = PSP_OP_JACOBI;
   op->n = K->n;
   op->jac = K;
+  *out = op;
+  return PSP_OK;
+}
+
+int psp_op_from_ssor(psp_ssor_t *K, psp_op_t **out) {
+  if (!K || !out) return fail(PSP_EINVAL, "psp_op_from_ssor: NULL argument");
+  int n = 0;
+  PSP_TRY(psp_ssor_info(K, &n, nullptr, nullptr));
+  psp_op *op = new psp_op();
+  op->kind = PSP_OP_SSOR;
+  op->n = n;
+  op->ssor = K;
   *out = op;
   return PSP_OK;
 }

@@ -255,6 +255,8 @@ class _Op:
             check(lib().psp_op_from_sss(obj._h, C.byref(h)))
         elif isinstance(obj, DeviceJacobi):
             check(lib().psp_op_from_jacobi(obj._h, C.byref(h)))
+        elif isinstance(obj, DeviceSSOR):
+            check(lib().psp_op_from_ssor(obj._h, C.byref(h)))
         else:
             # duck-typed operator: shape + matvec/precon (spmatrixmodule.c:86-132, :169-248)
             shape = obj.shape
@@ -334,6 +336,44 @@ class DeviceJacobi:
     def close(self):
         if getattr(self, "_h", None):
             lib().psp_jacobi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceSSOR:
+    """precon.ssor(A, omega=1.0, steps=1) on an sss_mat (preconmodule.c:414-459, :95-223)."""
+
+    def __init__(self, A, omega=1.0, steps=1):
+        if not isinstance(A, DeviceSSS):
+            raise TypeError("ssor() argument 1 must be sss_mat")  # "O!" with SSSMatType, preconmodule.c:499
+        h = C.c_void_p()
+        check(lib().psp_ssor_create(A._h, float(omega), int(steps), C.byref(h)))
+        self._A = A  # the handle borrows the matrix
+        self._h = h
+        self.shape = (A.n, A.n)
+        lf, lb = C.c_int(), C.c_int()
+        check(lib().psp_ssor_info(h, None, C.byref(lf), C.byref(lb)))
+        self.levels = (lf.value, lb.value)
+
+    def precon(self, x, y):
+        n = self.shape[0]
+        for k, a in ((1, x), (2, y)):
+            if (not isinstance(a, np.ndarray) or a.ndim != 1 or a.dtype != np.float64 or a.shape[0] != n
+                    or not a.flags.c_contiguous):
+                raise ValueError("arg %d must be a contiguous 1-dimensional double array of appropriate size." % k)
+        check(lib().psp_ssor_precon(self._h, _ptr(x), _ptr(y)))
+
+    def precon_dev(self, x_ptr, y_ptr):
+        check(lib().psp_ssor_precon_dev(self._h, x_ptr, y_ptr))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().psp_ssor_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,0 +1,125 @@
+"""GPU parity: precon.ssor on an sss_mat (level-scheduled sweeps) vs the CPU oracle's sequential
+sweeps (preconmodule.c:95-223).  Every row performs the reference's operations in the reference's
+order, so the bar is bit equality."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rng_vec(n, seed=0):
+    return np.random.default_rng(seed).standard_normal(n)
+
+
+def random_sss(O, n, seed, max_lower=12):
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.integers(0, max_lower + 1, size=n), np.arange(n))
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=ind[1:])
+    col = np.concatenate([np.sort(rng.choice(i, size=lens[i], replace=False)) for i in range(n)] +
+                         [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    val = 0.1 * rng.standard_normal(ind[-1])
+    diag = 4.0 + rng.random(n)  # diagonally dominant enough to keep the sweeps tame
+    return O.SSS(n, val, diag, col, ind)
+
+
+def cases(oracle, which):
+    from pysparse_amd.device import DeviceSSS
+    if which == "poisson2d":
+        S = oracle.poisson_sss(37, 29)
+    elif which == "poisson3d":
+        S = oracle.poisson_sss(13, 11, 9)
+    elif which == "tendigit":
+        S = oracle.tendigit_sss(3000)
+    elif which == "diagonal":  # no off-diagonal entry: one level in each direction
+        S = oracle.SSS(50, np.zeros(0), 2.0 + np.arange(50.0), np.zeros(0, dtype=np.int32), np.zeros(51, dtype=np.int32))
+    else:
+        S = random_sss(oracle, 2500, 11)
+    return S, DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.0, 2), (1.4, 1), (0.8, 3), (1.0, 0), (1.2, 0)])
+@pytest.mark.parametrize("which", ["poisson2d", "poisson3d", "tendigit", "diagonal", "random"])
+def test_ssor_precon_bit_exact(oracle, which, omega, steps):
+    from pysparse_amd.device import DeviceSSOR
+    S, D = cases(oracle, which)
+    K = DeviceSSOR(D, omega, steps)
+    assert K.shape == (S.n, S.n)
+    x = rng_vec(S.n, 5)
+    y_ref = np.full(S.n, 3.25)
+    oracle.ssor_apply(S, x, y_ref, omega, steps)
+    y = np.full(S.n, 3.25)
+    K.precon(x, y)
+    assert np.array_equal(y, y_ref)
+    if which == "poisson2d":
+        assert K.levels == (37 + 29 - 1, 37 + 29 - 1)  # hyperplanes i + j = const
+    if which == "diagonal":
+        assert K.levels == (1, 1)
+    with pytest.raises(ValueError):
+        K.precon(x[:-1], y)
+    with pytest.raises(ValueError):
+        K.precon(x, y[::2])
+
+
+def test_ssor_requires_sss(oracle):
+    from pysparse_amd.device import DeviceCSR, DeviceSSOR
+    with pytest.raises(TypeError):
+        DeviceSSOR(DeviceCSR.poisson(5, 5))
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.3, 1), (1.0, 2)])
+@pytest.mark.parametrize("grid", [(100, 100, 0), (24, 24, 24)])
+def test_pcg_with_ssor_matches_oracle(oracle, grid, omega, steps):
+    """demo_pcg.py's third column: pcg(A, b, x, tol, maxit, ssor(S, omega, steps)), b = A*e"""
+    from pysparse_amd.device import DeviceSSOR, DeviceSSS, pcg
+    S = oracle.poisson_sss(*grid)
+    D = DeviceSSS.poisson(*grid)
+    n = S.n
+    b = np.empty(n)
+    S.matvec(np.ones(n), b)
+    xo = np.zeros(n)
+    info_o, it_o, rr_o, hist_o = oracle.pcg_ssor(S, b, xo, 1e-8, 2 * n, omega, steps, hist=True)
+    xs = np.zeros(n)
+    info, it, rr, hist = pcg(D, b, xs, 1e-8, 2 * n, DeviceSSOR(D, omega, steps), hist=True)
+    assert (info, it) == (info_o, it_o) and info == 0
+    assert abs(rr - rr_o) <= 1e-9 * rr_o
+    assert np.allclose(hist[:it + 1], hist_o[:it + 1], rtol=1e-9, atol=0)
+    assert np.abs(xs - xo).max() <= 1e-12 * np.abs(xo).max()
+    # SSOR beats Jacobi on the Poisson operator (the reason for demo_pcg.py's third column)
+    xj = np.zeros(n)
+    _, it_j, _ = oracle.pcg(S, b, xj, 1e-8, 2 * n, oracle.jacobi_dinv(S.diag))
+    assert it < it_j
+
+
+def test_dropin_module_ssor(oracle):
+    """pysparse.precon.precon.ssor through the extension modules, the way demo_pcg.py:84-98 uses it"""
+    from pysparse.sparse import spmatrix
+    from pysparse.itsolvers.krylov import pcg
+    from pysparse.precon import precon
+    n1 = 60
+    S = spmatrix.poisson_sss(n1, n1)
+    n = n1 * n1
+    assert S.shape == (n, n)
+    K = precon.ssor(S)  # omega = 1.0, steps = 1
+    assert K.shape == (n, n)
+    So = oracle.poisson_sss(n1, n1)
+    x = rng_vec(n, 1)
+    y, y_ref = np.zeros(n), np.zeros(n)
+    K.precon(x, y)
+    oracle.ssor_apply(So, x, y_ref, 1.0, 1)
+    assert np.array_equal(y, y_ref)
+    K2 = precon.ssor(S, 1.5, 2)
+    K2.precon(x, y)
+    oracle.ssor_apply(So, x, y_ref, 1.5, 2)
+    assert np.array_equal(y, y_ref)
+    with pytest.raises(TypeError):
+        precon.ssor(spmatrix.poisson_csr(n1, n1))  # "O!" with SSSMatType (preconmodule.c:499)
+    with pytest.raises(ValueError):
+        K.precon(x[:-1], y)
+    b = np.empty(n)
+    S.matvec(np.ones(n), b)
+    xs, xo = np.zeros(n), np.zeros(n)
+    res = pcg(S, b, xs, 1e-6, 2 * n, K)
+    ref = oracle.pcg_ssor(So, b, xo, 1e-6, 2 * n, 1.0, 1)
+    assert res[:2] == ref[:2] and abs(res[2] - ref[2]) <= 1e-9 * ref[2]
+    assert np.abs(xs - xo).max() <= 1e-12 * np.abs(xo).max()

@@ -143,3 +143,30 @@ def test_minres_exits(oracle):
     info, it, rr = oracle.minres(A, b, np.zeros(n), 1e-8, 500)
     xp = np.zeros(n)
     assert info == 0 and oracle.pcg(A, b, xp, 1e-10, 500)[0] == 0
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.0, 3), (1.3, 1), (0.7, 2)])
+def test_oracle_ssor_identity_against_triangular_solves(oracle, omega, steps):
+    """orc_symgs / orc_ssor (preconmodule.c:95-193) have no compilable reference and no golden vector:
+    pinned by the iteration they implement, x <- x + w (D + w L)^-1 (b - A x) forward then the same
+    with L^T backward, written with SciPy triangular solves (agreement to rounding, not bits)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    S = oracle.poisson_sss(9, 8, 7)
+    n = S.n
+    A = oracle.sss_to_csr(S)
+    M = sp.csr_matrix((A.val, A.col, A.ind), shape=(n, n))
+    Lo = sp.tril(M, -1).tocsr()
+    D = sp.diags(M.diagonal())
+    b = np.random.default_rng(3).standard_normal(n)
+    y = np.full(n, 7.0)
+    oracle.ssor_apply(S, b, y, omega, steps)
+    x = np.zeros(n)
+    for _ in range(steps):
+        x = x + spl.spsolve_triangular((D / omega + Lo).tocsr(), b - M @ x, lower=True)
+        x = x + spl.spsolve_triangular((D / omega + Lo.T).tocsr(), b - M @ x, lower=False)
+    assert np.abs(y - x).max() <= 1e-13 * np.abs(x).max()
+    # steps = 0 leaves y untouched (for omega == 1 the kernel still does nothing to x)
+    y0 = np.full(n, 5.0)
+    oracle.ssor_apply(S, b, y0, omega, 0)
+    assert np.all(y0 == 5.0)
