@@ -221,6 +221,20 @@ def test_fullsize_slab_of_1024_cubed():
     x = dev.DeviceBuffer.from_host(xh)
     A.matvec_dev(x.ptr, y.ptr)
     y4 = y.download()
+    # the multi-GPU product: interior rows first, the two ghost-touching plane ranges after the halo
+    # wait -- same bits, and the fused dot equals the separate one to rounding
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    out = dev.DeviceBuffer(4)
+    for variant in (-1, W3):
+        A.set_variant(variant)
+        y.zero()
+        from pysparse_amd._capi import WAIT_FN
+        check(L.psp_k_csr_matvec_overlap(A._h, x.ptr, nxy, y.ptr, nxy, (hi - lo) - nxy, WAIT_FN(0), None, out.ptr))
+        assert np.array_equal(y.download(), y4), variant
+        fused = float(out.download()[0])
+        sep = float(np.dot(xh[nxy:nxy + (hi - lo)], y4))
+        assert abs(fused - sep) <= 1e-10 * abs(sep)
     A.set_variant(W3)
     assert A.kernel_info()[0] == "csr_spmv_w3"
     y.zero()
