@@ -254,6 +254,12 @@ int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const
  * collectives issued through torch.distributed.  Each reduction leaves its result(s) in
  * out_dev[0..k) on the device (no host synchronisation). */
 
+/* Tell the vector kernels that v_dev[0..n) holds ONE value everywhere (checked on the device; a
+ * vector that does not is simply not registered): psp_k_residual / psp_k_pupdate / psp_k_xr_update
+ * then form z = dinv.*r as r_i * c without streaming dinv -- same product, 8 bytes per row less.
+ * The vector must not change until psp_k_unhint.  precon.jacobi registers its own dinv. */
+int psp_k_hint_constant(const double *v_dev, int n);
+int psp_k_unhint(const double *v_dev);
 /* out[0] = sum x_i*y_i */
 int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev);
 /* r := b - r (pcg.c:73-74); out = { r.r, r.z } with z = dinv.*r (dinv may be NULL: z = r) */

@@ -150,6 +150,11 @@ bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx);
+// constant-vector registry (psp_vec.hip): the PCG vector kernels skip the dinv stream when the
+// preconditioner's dinv holds one value everywhere
+int dinv_register(const double *v, long n);
+void dinv_unregister(const double *v);
+bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip
 }  // namespace psp

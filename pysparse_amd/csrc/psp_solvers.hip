@@ -1067,6 +1067,7 @@ static int jacobi_from_diag_dev(int n, double *diag_dev_owned, double omega, int
     (void)hipFree(diag_dev_owned);
     return rc;
   }
+  (void)dinv_register(diag_dev_owned, n);  // constant diagonal: z = r .* dinv needs no dinv stream
   psp_jacobi *K = new psp_jacobi();
   K->n = n;
   K->omega = omega;
@@ -1142,6 +1143,7 @@ int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int ste
 
 int psp_jacobi_destroy(psp_jacobi_t *K) {
   if (!K) return PSP_OK;
+  dinv_unregister(K->dinv);
   (void)hipFree(K->dinv);
   if (K->temp) (void)hipFree(K->temp);
   delete K;

@@ -7,6 +7,11 @@
 // sums -> wave shuffle -> LDS -> one slot per workgroup; a one-block finishing kernel adds
 // the slots in index order (bitwise reproducible, no atomics).  Per-element arithmetic
 // follows the reference expression order; the library is built with -ffp-contract=off.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
 #include "psp_internal.h"
 
 using namespace psp;
@@ -89,38 +94,44 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(long n, const double *__res
 }
 
 // ---- r = b - r; partials {r.r, r.z}, z = dinv.*r or r: pcg.c:73-75 (+ :93-100 fused)
-template <int V, bool PRE>
+// PRE: 0 no preconditioner, 1 dinv array, 2 dinv is the constant dc everywhere (same product
+// r_i * dinv_i, one 8-byte stream less)
+template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void residual_kernel(long n, const double *__restrict__ b,
                                                           double *__restrict__ r,
-                                                          const double *__restrict__ dinv,
+                                                          const double *__restrict__ dinv, double dc,
                                                           double *__restrict__ partials) {
   double acc[2] = {0.0, 0.0};
   PSP_VEC_LOOP(i, n) {
     const Pack<V> bb = ld<V>(b, i);
     Pack<V> rr = ld<V>(r, i);
     Pack<V> dd;
-    if constexpr (PRE) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 1) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) dd.v[u] = dc;
+    }
 #pragma unroll
     for (int u = 0; u < V; ++u) {
       const double t = bb.v[u] - rr.v[u];
       rr.v[u] = t;
       acc[0] += t * t;
-      if constexpr (PRE) {
+      if constexpr (PRE != 0) {
         const double z = t * dd.v[u];
         acc[1] += t * z;
       }
     }
     st<V>(r, i, rr);
   }
-  if constexpr (!PRE) acc[1] = acc[0];
+  if constexpr (PRE == 0) acc[1] = acc[0];
   block_reduce_store<2>(acc, partials);
 }
 
 // ---- p = z + beta*p (pcg.c:113-114) or p = z (pcg.c:106); z = dinv.*r or r.
 //      With a device state the "first iteration" decision is taken on the device (it == 1).
-template <int V, bool PRE, bool FIRST>
+template <int V, int PRE, bool FIRST>
 __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *__restrict__ r,
-                                                         const double *__restrict__ dinv,
+                                                         const double *__restrict__ dinv, double dc,
                                                          double beta, double *__restrict__ p,
                                                          const PcgDev *__restrict__ dstate) {
   bool first = FIRST;
@@ -131,10 +142,14 @@ __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *_
   }
   PSP_VEC_LOOP(i, n) {
     Pack<V> z = ld<V>(r, i);
-    if constexpr (PRE) {
+    if constexpr (PRE == 1) {
       const Pack<V> dd = ld<V>(dinv, i);
 #pragma unroll
       for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dd.v[u];
+    }
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dc;
     }
     if (!first) {
       const Pack<V> pp = ld<V>(p, i);
@@ -190,10 +205,10 @@ __global__ __launch_bounds__(kBlock) void x_update_kernel(long n, double alpha,
 }
 
 //      r_update: r -= alpha q (:142-143); partial slots 0, 1 = {r.r, r.z}, z = dinv.*r or r
-template <int V, bool PRE>
+template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void r_update_kernel(long n, double alpha,
                                                           const double *__restrict__ q,
-                                                          const double *__restrict__ dinv,
+                                                          const double *__restrict__ dinv, double dc,
                                                           double *__restrict__ r,
                                                           double *__restrict__ partials,
                                                           const PcgDev *__restrict__ dstate) {
@@ -208,20 +223,24 @@ __global__ __launch_bounds__(kBlock) void r_update_kernel(long n, double alpha,
     const Pack<V> qq = ld<V>(q, i);
     Pack<V> rr = ld<V>(r, i);
     Pack<V> dd;
-    if constexpr (PRE) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 1) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) dd.v[u] = dc;
+    }
 #pragma unroll
     for (int u = 0; u < V; ++u) {
       const double t = upd ? rr.v[u] + malpha * qq.v[u] : rr.v[u];
       rr.v[u] = t;
       acc[0] += t * t;
-      if constexpr (PRE) {
+      if constexpr (PRE != 0) {
         const double z = t * dd.v[u];
         acc[1] += t * z;
       }
     }
     st<V>(r, i, rr);
   }
-  if constexpr (!PRE) acc[1] = acc[0];
+  if constexpr (PRE == 0) acc[1] = acc[0];
   block_reduce_store<2>(acc, partials);
 }
 
@@ -405,7 +424,68 @@ inline bool can_vec2(long n, P... ptrs) {
 
 }  // namespace
 
+namespace {
+
+__global__ void not_constant_kernel(long n, const double *__restrict__ v, int *__restrict__ flag) {
+  const double c = v[0];
+  int bad = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    bad |= v[i] != c;  // NaN != NaN: a vector holding NaN is never "constant"
+  if (bad) atomicOr(flag, 1);
+}
+
+// device vectors known to hold one value everywhere (Jacobi dinv of a constant-diagonal operator):
+// pointer -> (length, value).  Entries are added by dinv_register and removed by dinv_unregister;
+// the owner guarantees the vector does not change in between.
+struct ConstVec {
+  long n;
+  double c;
+};
+std::unordered_map<const double *, ConstVec> g_const;
+std::mutex g_const_mu;
+
+}  // namespace
+
 namespace psp {
+
+int dinv_register(const double *v, long n) {
+  static const bool off = [] {
+    const char *e = getenv("PSP_DINV_CONST");
+    return e && atoi(e) == 0;
+  }();
+  if (off || !v || n < 1) return PSP_OK;
+  int *flag;
+  PSP_HIP(hipMalloc((void **)&flag, sizeof(int)));
+  PSP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+  hipLaunchKernelGGL(not_constant_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, stream(),
+                     n, v, flag);
+  PSP_LAUNCH_CHECK();
+  int bad = 1;
+  double c = 0.0;
+  PSP_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipMemcpyAsync(&c, v, sizeof(double), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  PSP_HIP(hipFree(flag));
+  std::lock_guard<std::mutex> lk(g_const_mu);
+  if (bad)
+    g_const.erase(v);
+  else
+    g_const[v] = {n, c};
+  return PSP_OK;
+}
+
+void dinv_unregister(const double *v) {
+  std::lock_guard<std::mutex> lk(g_const_mu);
+  g_const.erase(v);
+}
+
+bool dinv_constant(const double *v, long n, double *c) {
+  std::lock_guard<std::mutex> lk(g_const_mu);
+  auto it = g_const.find(v);
+  if (it == g_const.end() || it->second.n != n) return false;
+  *c = it->second.c;
+  return true;
+}
 
 // Launch helpers (device pointers, library stream).  `partials` = slot base in the workspace.
 
@@ -427,12 +507,15 @@ int k_residual(long n, const double *b, double *r, const double *dinv, double *p
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
-  const bool v2 = dinv ? can_vec2(n, b, r, dinv) : can_vec2(n, b, r);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, b, r, dinv) : can_vec2(n, b, r);
 #define L(V, PRE)                                                                              \
   hipLaunchKernelGGL((residual_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, b, r, \
-                     dinv, partials)
-  if (dinv) { if (v2) L(2, true); else L(1, true); }
-  else { if (v2) L(2, false); else L(1, false); }
+                     dinv, dc, partials)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
 #undef L
   PSP_LAUNCH_CHECK();
   *nparts = grid;
@@ -444,16 +527,21 @@ int k_pupdate(long n, const double *r, const double *dinv, double beta, bool fir
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
-  const bool v2 = dinv ? can_vec2(n, r, p, dinv) : can_vec2(n, r, p);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, r, p, dinv) : can_vec2(n, r, p);
 #define L(V, PRE, FIRST)                                                                  \
   hipLaunchKernelGGL((pupdate_kernel<V, PRE, FIRST>), dim3(grid), dim3(kBlock), 0, stream(), n, \
-                     r, dinv, beta, p, dstate)
-  if (dinv) {
-    if (first) { if (v2) L(2, true, true); else L(1, true, true); }
-    else { if (v2) L(2, true, false); else L(1, true, false); }
+                     r, dinv, dc, beta, p, dstate)
+  if (cst) {
+    if (first) { if (v2) L(2, 2, true); else L(1, 2, true); }
+    else { if (v2) L(2, 2, false); else L(1, 2, false); }
+  } else if (dinv) {
+    if (first) { if (v2) L(2, 1, true); else L(1, 1, true); }
+    else { if (v2) L(2, 1, false); else L(1, 1, false); }
   } else {
-    if (first) { if (v2) L(2, false, true); else L(1, false, true); }
-    else { if (v2) L(2, false, false); else L(1, false, false); }
+    if (first) { if (v2) L(2, 0, true); else L(1, 0, true); }
+    else { if (v2) L(2, 0, false); else L(1, 0, false); }
   }
 #undef L
   PSP_LAUNCH_CHECK();
@@ -472,12 +560,15 @@ int k_xr_update(long n, double alpha, const double *p, const double *q, const do
     hipLaunchKernelGGL(x_update_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, alpha, p, x,
                        partials, dstate);
   PSP_LAUNCH_CHECK();
-  const bool v2 = dinv ? can_vec2(n, q, r, dinv) : can_vec2(n, q, r);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, q, r, dinv) : can_vec2(n, q, r);
 #define L(V, PRE)                                                                         \
   hipLaunchKernelGGL((r_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
-                     alpha, q, dinv, r, partials, dstate)
-  if (dinv) { if (v2) L(2, true); else L(1, true); }
-  else { if (v2) L(2, false); else L(1, false); }
+                     alpha, q, dinv, dc, r, partials, dstate)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
 #undef L
   PSP_LAUNCH_CHECK();
   *nparts = grid;
@@ -620,6 +711,16 @@ int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev) 
   int np;
   PSP_TRY(k_dot(n, x_dev, y_dev, w->partials, &np));
   return finish_partials(w->partials, np, 1, out_dev);
+}
+
+int psp_k_hint_constant(const double *v_dev, int n) {
+  if (!v_dev || n < 1) return fail(PSP_EINVAL, "psp_k_hint_constant: bad argument");
+  return dinv_register(v_dev, n);
+}
+
+int psp_k_unhint(const double *v_dev) {
+  dinv_unregister(v_dev);
+  return PSP_OK;
 }
 
 int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv_dev,

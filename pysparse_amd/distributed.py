@@ -209,6 +209,12 @@ class HipBackend:
     def gather(self, idx, v, out):
         self._capi.check(self.L.psp_k_gather(idx.numel(), self._p(idx), self._p(v), self._p(out)))
 
+    def hint_constant(self, v):
+        self._capi.check(self.L.psp_k_hint_constant(self._p(v), v.numel()))
+
+    def unhint(self, v):
+        self._capi.check(self.L.psp_k_unhint(self._p(v)))
+
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
@@ -345,6 +351,20 @@ class DistCSR:
 
 
 def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
+    """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices; see
+    _dist_pcg.  A dinv slice that holds one value everywhere (constant-diagonal operator) is
+    announced to the vector kernels for the duration of the solve (psp_k_hint_constant)."""
+    hint = getattr(A.be, "hint_constant", None) if dinv is not None else None
+    if hint is not None:
+        hint(dinv)
+    try:
+        return _dist_pcg(A, b, x, tol, maxit, dinv, hist)
+    finally:
+        if hint is not None:
+            A.be.unhint(dinv)
+
+
+def _dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices.
 
     Same control flow as Itsolvers_pcg_kernel (pcg.c:57-166) with K = None (dinv is None)

@@ -410,3 +410,55 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     for o in outs:
         assert (o[0], o[1]) == (0, cases["G2"]["iter"])
     assert outs[0] == outs[1] == outs[2]  # bitwise: same kernels, same reduction order
+
+
+def test_pcg_jacobi_constant_and_variable_diagonal(oracle):
+    """precon.jacobi registers a dinv that holds one value everywhere (constant-diagonal operator) so
+    the vector kernels form z = r*c without streaming dinv; a variable diagonal takes the array path.
+    Same products either way: iteration counts identical to the oracle, iterates <= 1e-12."""
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg
+    A = oracle.poisson_csr(40, 30, 20)
+    n = A.shape[0]
+    for variable in (False, True):
+        val = A.val.copy()
+        if variable:  # bump the diagonal entries by a smooth, row-dependent amount (stays SPD)
+            rows = np.repeat(np.arange(n), np.diff(A.ind))
+            dmask = A.col == rows
+            val[dmask] += 0.5 + 0.4 * np.sin(np.arange(n) * 0.01)
+        B = oracle.CSR(A.shape, val, A.col, A.ind)
+        D = DeviceCSR.from_arrays(B.shape, B.ind, B.col, B.val)
+        b = np.empty(n)
+        B.matvec(np.ones(n), b)
+        xo, xs = np.zeros(n), np.zeros(n)
+        ref = oracle.pcg(B, b, xo, 1e-10, 2000, oracle.jacobi_dinv(B.diagonal()), hist=True)
+        res = pcg(D, b, xs, 1e-10, 2000, DeviceJacobi(D), hist=True)
+        assert res[:2] == ref[:2] and res[0] == 0
+        assert np.allclose(res[3][:res[1] + 1], ref[3][:ref[1] + 1], rtol=1e-9, atol=0)
+        assert np.abs(xs - xo).max() <= 1e-12 * np.abs(xo).max()
+
+
+def test_hint_constant_abi():
+    """psp_k_hint_constant on caller-owned vectors (the multi-GPU driver's dinv slice): a constant vector
+    and a non-constant one give the same residual reductions as the unhinted call"""
+    import ctypes as C
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    n = 100003
+    rng = np.random.default_rng(3)
+    bh, rh = rng.standard_normal(n), rng.standard_normal(n)
+    for dh in (np.full(n, 1.0 / 6.0), 1.0 / (4.0 + rng.random(n))):
+        b, d = dev.DeviceBuffer.from_host(bh), dev.DeviceBuffer.from_host(dh)
+        outs = []
+        for hinted in (False, True):
+            r = dev.DeviceBuffer.from_host(rh)
+            out = dev.DeviceBuffer(4)
+            if hinted:
+                check(L.psp_k_hint_constant(d.ptr, n))
+            check(L.psp_k_residual(n, b.ptr, r.ptr, d.ptr, out.ptr))
+            outs.append((out.download()[:2].copy(), r.download()))
+            if hinted:
+                check(L.psp_k_unhint(d.ptr))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        t = bh - rh
+        assert abs(outs[0][0][1] - np.dot(t, t * dh)) <= 1e-12 * abs(np.dot(t, t * dh))
