@@ -1186,6 +1186,127 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
   }
 }
 
+// ---- csr_spmv_w4 with the PCG p-update folded in (pcg.c:105-117 in one pass):
+//   p_new = z + beta*p_old (z = r, r.*dinv or r*dc; first iteration: p_new = z),  q = A p_new,
+//   partial sums of p_new.q.  p_new is formed on the fly at every neighbour position from r and
+//   p_old (the same two rounded operations as pupdate_kernel, so the same bits) and written once for
+//   the lane's own rows; p_old and p_new are different buffers.  Saves the separate pass that
+//   writes p and the SpMV's read of it (8 bytes per row).  Square operators only (x = p has nrows
+//   entries).
+template <int NO, int PRE>
+__global__ __launch_bounds__(256) void csr_spmv_w4_pf(
+    int nrows, int stripe, DiaOffs offs, const double *__restrict__ valT,
+    const unsigned short *__restrict__ mask, const double *__restrict__ r, const double *__restrict__ dinv,
+    double dc, const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ q,
+    double beta, int first, double *__restrict__ partials, const psp::PcgDev *__restrict__ dstate) {
+  if (dstate) {  // asynchronous loop: scalars live on the device
+    if (dstate->status) return;
+    beta = dstate->beta;
+    first = dstate->it == 1;
+  }
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int vb = (int)blockIdx.x;
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int blk = vb * 4 + wid;
+  const long row = (long)blk * kDiaRows + 2 * lane;
+  double dsum = 0.0;
+  if (row < nrows) {
+    const unsigned mm = *reinterpret_cast<const unsigned *>(mask + row);
+    const unsigned m0 = mm & 0xffffu, m1 = mm >> 16;
+    const double *vp = valT + (size_t)blk * NO * kDiaRows + 2 * lane;
+    d2v v[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) v[o] = ldg<true>(reinterpret_cast<const d2v *>(vp + o * kDiaRows));
+    const long cmax = (long)nrows - 2;  // nrows >= 2
+    // own rows (stored to p_new) and the neighbour pairs: every load unconditional, clamped
+    const long rc = row > cmax ? cmax : row;
+    d2u rr[NO + 1], pp[NO + 1], dd[NO + 1];
+    bool edge = rc != row;
+#pragma unroll
+    for (int o = 0; o <= NO; ++o) {
+      const long c = o < NO ? row + offs.o[o] : row;
+      const long cc = c < 0 ? 0 : (c > cmax ? cmax : c);
+      rr[o] = *reinterpret_cast<const d2u *>(r + cc);
+      if (!first) pp[o] = *reinterpret_cast<const d2u *>(p_old + cc);
+      if constexpr (PRE == 1) dd[o] = *reinterpret_cast<const d2u *>(dinv + cc);
+      edge |= cc != c;
+    }
+    if (edge) {
+#pragma unroll
+      for (int o = 0; o <= NO; ++o) {
+        const long c = o < NO ? row + offs.o[o] : row;
+        if (c < 0 || c > cmax) {
+          const bool i0 = c >= 0 && c < nrows, i1 = c + 1 >= 0 && c + 1 < nrows;
+          rr[o].x = i0 ? r[c] : 0.0;
+          rr[o].y = i1 ? r[c + 1] : 0.0;
+          if (!first) {
+            pp[o].x = i0 ? p_old[c] : 0.0;
+            pp[o].y = i1 ? p_old[c + 1] : 0.0;
+          }
+          if constexpr (PRE == 1) {
+            dd[o].x = i0 ? dinv[c] : 0.0;
+            dd[o].y = i1 ? dinv[c + 1] : 0.0;
+          }
+        }
+      }
+    }
+    // p_new at the NO neighbour pairs and at the own pair (index NO)
+    d2v pn[NO + 1];
+#pragma unroll
+    for (int o = 0; o <= NO; ++o) {
+      double z0 = rr[o].x, z1 = rr[o].y;
+      if constexpr (PRE == 1) {
+        z0 = z0 * dd[o].x;
+        z1 = z1 * dd[o].y;
+      }
+      if constexpr (PRE == 2) {
+        z0 = z0 * dc;
+        z1 = z1 * dc;
+      }
+      if (!first) {
+        z0 = z0 + beta * pp[o].x;
+        z1 = z1 + beta * pp[o].y;
+      }
+      pn[o].x = z0;
+      pn[o].y = z1;
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const double t0 = a0 + v[o].x * pn[o].x;
+      const double t1 = a1 + v[o].y * pn[o].y;
+      a0 = ((m0 >> o) & 1u) ? t0 : a0;
+      a1 = ((m1 >> o) & 1u) ? t1 : a1;
+    }
+    if (row + 1 < nrows) {
+      d2u outq, outp;
+      outq.x = a0;
+      outq.y = a1;
+      outp.x = pn[NO].x;
+      outp.y = pn[NO].y;
+      __builtin_nontemporal_store(outq, reinterpret_cast<d2u *>(q + row));
+      *reinterpret_cast<d2u *>(p_new + row) = outp;
+      dsum += pn[NO].x * a0;
+      dsum += pn[NO].y * a1;
+    } else {
+      q[row] = a0;
+      p_new[row] = pn[NO].x;
+      dsum += pn[NO].x * a0;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
 // first-level fold of per-workgroup dot partials when they do not sit in the workspace
 // slots: out[o] = sum of in[o], in[o+nout], ... ; 16 lanes per output, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
@@ -1976,6 +2097,63 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
   if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
   else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
   else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+}
+
+// q = A (z + beta p_old) with p_new written on the way (csr_spmv_w4_pf); *available = 0 when the
+// operator has no w4 layout (the caller then runs pupdate + csr_spmv_launch)
+int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old,
+                           double *p_new, double *q, double beta, bool first, double *partials, int *nparts,
+                           const PcgDev *dstate, int *available) {
+  *available = 0;
+  // OFF by default: measured at 512^3 it changes nothing (296 / 298 iterations/s with, 291 / 299
+  // without, alternating processes) -- the 8 bytes per row of DRAM traffic it saves are paid
+  // back by reading two arrays instead of one at every neighbour position.  PSP_PCG_PFUSED=1 enables.
+  static const bool on = [] {
+    const char *e = getenv("PSP_PCG_PFUSED");
+    return e ? atoi(e) != 0 : false;
+  }();
+  Variant v = decode_variant(A->variant);
+  if (!on || !v.w4 || A->sym_owner || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1 || ex->dia_no > 8) return PSP_OK;  // register budget: up to 8 offsets
+  const int stripe = w4_stripe(A, v);
+  const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
+  const int grid = w4_grid(nblk, stripe);
+  double *pbuf = partials;
+  if (partials && grid > kMaxParts) {
+    PSP_TRY(ensure_big_partials(ex, grid));
+    pbuf = ex->big_partials;
+  }
+  double dc = 0.0;
+  const int pre = !dinv ? 0 : (dinv_constant(dinv, A->nrows, &dc) ? 2 : 1);
+#define PSP_PF(NO, PRE)                                                                             \
+  hipLaunchKernelGGL((csr_spmv_w4_pf<NO, PRE>), dim3(grid), dim3(256), 0, stream(), A->nrows, stripe, \
+                     ex->dia_offs, ex->dia_val, ex->dia_mask, r, dinv, dc, p_old, p_new, q, beta,     \
+                     first ? 1 : 0, pbuf, dstate)
+#define PSP_PF_NO(NO)                                                                               \
+  case NO:                                                                                          \
+    if (pre == 0) PSP_PF(NO, 0);                                                                    \
+    else if (pre == 1) PSP_PF(NO, 1);                                                               \
+    else PSP_PF(NO, 2);                                                                             \
+    break
+  switch (ex->dia_no) {
+    PSP_PF_NO(1); PSP_PF_NO(2); PSP_PF_NO(3); PSP_PF_NO(4); PSP_PF_NO(5); PSP_PF_NO(6); PSP_PF_NO(7); PSP_PF_NO(8);
+    default:
+      return PSP_OK;
+  }
+#undef PSP_PF_NO
+#undef PSP_PF
+  PSP_LAUNCH_CHECK();
+  int np = grid;
+  if (pbuf != partials) {
+    np = kFold;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid, partials, np);
+    PSP_LAUNCH_CHECK();
+  }
+  if (nparts) *nparts = np;
+  *available = 1;
+  return PSP_OK;
 }
 
 bool csr_spmv_has_skip(const psp_csr *A) {

@@ -145,6 +145,11 @@ inline psp_csr *op_native_csr(const psp_op *op) {
 }
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
                     double *partials, int *nparts, const int *skip = nullptr);
+// PCG: p_new = z + beta p_old and q = A p_new (+ p_new.q partials) in one pass over a w4 operator;
+// *available = 0 when A has no such layout (nothing was launched)
+int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old,
+                           double *p_new, double *q, double beta, bool first, double *partials, int *nparts,
+                           const PcgDev *dstate, int *available);
 // true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
 bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,

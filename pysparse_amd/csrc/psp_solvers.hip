@@ -256,14 +256,23 @@ static int pcg_graph_enabled() {
 
 // one batch = kBatch iterations' worth of launches on the library stream; every kernel takes
 // its scalars (and the iteration number) from the device state, so all batches are identical
-static int pcg_enqueue_batch(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
-                             double *q, PcgDev *st, double *hist_dev, int batch) {
+// p / p2: the direction vector ping-pongs between two buffers when the p-update is folded into
+// the SpMV (csr_spmv_w4_pf reads p_old while it writes p_new); *p is always the current one
+static int pcg_enqueue_batch(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double **pp,
+                             double **pp2, double *q, PcgDev *st, double *hist_dev, int batch) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
   for (int i = 0; i < batch; ++i) {
-    PSP_TRY(k_pupdate(n, r, dinv, 0.0, false, p, st));
-    PSP_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
+    int fusedp = 0;
+    PSP_TRY(csr_spmv_pfused_launch(Acsr, r, dinv, *pp, *pp2, q, 0.0, false, w->partials, &np, st, &fusedp));
+    if (fusedp) {
+      std::swap(*pp, *pp2);
+    } else {
+      PSP_TRY(k_pupdate(n, r, dinv, 0.0, false, *pp, st));
+      PSP_TRY(csr_spmv_launch(Acsr, *pp, q, *pp, w->partials, &np, &st->status));
+    }
+    double *p = *pp;
     PSP_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
     hipLaunchKernelGGL(pcg_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev);
     PSP_TRY(k_xr_update(n, 0.0, p, q, dinv, x, r, w->partials, &np, st));
@@ -278,7 +287,7 @@ static int pcg_enqueue_batch(psp_csr *Acsr, const double *dinv, int n, double *x
 // The first batch is launched directly (it also performs the lazy table builds of the SpMV);
 // when more batches are needed the batch is captured ONCE into a hipGraph and replayed.
 static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
-                          double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
+                          double *p2, double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
                           int *info, int *iter, double *relres, double *hist) {
   constexpr int kBatch = 16;
   PcgDev *st = nullptr;
@@ -323,7 +332,7 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
   hst->maxit = maxit;
   PCG_HIP(hipMemcpyAsync(st, hst, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
   enqueued = std::min(kBatch, maxit);
-  PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, enqueued));
+  PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, &p, &p2, q, st, hist_dev, enqueued));
   PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
   PCG_HIP(hipStreamSynchronize(stream()));
   if (!hst->status) {
@@ -334,7 +343,7 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
         prev = swap_stream(own);
         swapped = true;
         if (hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int brc = pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, kBatch);
+          const int brc = pcg_enqueue_batch(Acsr, dinv, n, x, r, &p, &p2, q, st, hist_dev, kBatch);
           const hipError_t ce = hipStreamEndCapture(own, &graph);
           if (brc != PSP_OK || ce != hipSuccess || graph == nullptr ||
               hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -354,7 +363,7 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
         PCG_HIP(hipGraphLaunch(exec, stream()));
       } else {
         const int batch = std::max(1, std::min(kBatch, maxit - enqueued));
-        PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, p, q, st, hist_dev, batch));
+        PCG_TRY(pcg_enqueue_batch(Acsr, dinv, n, x, r, &p, &p2, q, st, hist_dev, batch));
         enqueued += batch;
       }
       PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
@@ -399,6 +408,8 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
   const double *dinv = fused_dinv(K);
   const bool fused = Acsr != nullptr && (K == nullptr || dinv != nullptr);
   if (!fused && K) PSP_TRY(mem.alloc(n, &z));
+  double *p2 = nullptr;  // second direction buffer of the p-update-in-SpMV path (csr_spmv_w4_pf)
+  if (fused) PSP_TRY(mem.alloc(n, &p2));
 
   double s[4];
   int np;
@@ -441,7 +452,7 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
       *relres = normr / n2b;
       return PSP_OK;
     }
-    return pcg_async_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter,
+    return pcg_async_loop(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                           relres, hist);
   }
 
@@ -468,19 +479,25 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
       *info = -2;
       break;
     }
-    if (it == 1) {
-      PSP_TRY(k_pupdate(n, zsrc, zdinv, 0.0, true, p));  // pcg.c:106
-    } else {
+    if (it > 1) {
       beta = rho / rho1;
       if (beta == 0.0) {  // pcg.c:109-112
         *info = -6;
         break;
       }
-      PSP_TRY(k_pupdate(n, zsrc, zdinv, beta, false, p));  // pcg.c:113-114
+    }
+    int fusedp = 0;
+    if (fused)  // p = z (+ beta p) and q = A p in one pass where the operator has the w4 layout
+      PSP_TRY(csr_spmv_pfused_launch(Acsr, r, dinv, p, p2, q, beta, it == 1, w->partials, &np, nullptr, &fusedp));
+    if (fusedp) {
+      std::swap(p, p2);
+    } else {
+      PSP_TRY(k_pupdate(n, zsrc, zdinv, it == 1 ? 0.0 : beta, it == 1, p));  // pcg.c:106, :113-114
     }
 
     // q = A p, pq = p.q (pcg.c:116-117)
-    if (Acsr) {
+    if (fusedp) {
+    } else if (Acsr) {
       PSP_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np));
     } else {
       PSP_TRY(op_apply(A, p, q));

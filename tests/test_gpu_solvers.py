@@ -389,8 +389,9 @@ def test_minres_poisson_vs_oracle(oracle, p2d):
 
 
 def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
-    """host-scalar loop (PSP_PCG_ASYNC=0), device-scalar loop (default) and its hipGraph replay
-    (PSP_PCG_GRAPH=1) are the same algorithm: identical info / iteration counts / iterates."""
+    """host-scalar loop (PSP_PCG_ASYNC=0), device-scalar loop (default), its hipGraph replay
+    (PSP_PCG_GRAPH=1), the p-update folded into the SpMV (PSP_PCG_PFUSED=1, both loops) and the dinv
+    stream kept (PSP_DINV_CONST=0) are the same algorithm: identical info / iteration counts / iterates."""
     import subprocess
     import sys
     code = (
@@ -401,7 +402,9 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
         "print(json.dumps([r[0], r[1], r[2], float(x[0]), float(x[n // 2]), float(np.nansum(r[3]))]))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}):
+    for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}, {"PSP_PCG_PFUSED": "1"},
+                {"PSP_PCG_PFUSED": "1", "PSP_PCG_ASYNC": "0"}, {"PSP_DINV_CONST": "0"},
+                {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
@@ -409,7 +412,7 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     cases, _ = golden
     for o in outs:
         assert (o[0], o[1]) == (0, cases["G2"]["iter"])
-    assert outs[0] == outs[1] == outs[2]  # bitwise: same kernels, same reduction order
+    assert all(o == outs[0] for o in outs)  # bitwise: same products, same reduction order
 
 
 def test_pcg_jacobi_constant_and_variable_diagonal(oracle):
