@@ -96,6 +96,13 @@ int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int
 int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out);
 int psp_csr_poisson_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
                          int ncols_local, psp_csr_t **out);
+/* The same operator for grids whose nonzero count exceeds 32 bits (1024^3 on ONE GPU: 7.5e9
+ * entries, the strong-scaling baseline of BASELINE.json configs[3]): generated directly in the
+ * index-free offset-major layout of csr_spmv_w4, ~62 GB at 1024^3.  Supports
+ * matvec, jacobi, the solvers and kernel_info; there are no CSR arrays to download or transpose.
+ * psp_csr_shape reports nnz = -1 when it does not fit an int: use psp_csr_nnz64. */
+int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out);
+int64_t psp_csr_nnz64(const psp_csr_t *A);
 int psp_csr_destroy(psp_csr_t *A);
 /* shape / nnz attributes: CSRMatType_getattr, csr_mat.c:208-231 */
 int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz);

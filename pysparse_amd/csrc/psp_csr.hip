@@ -936,6 +936,54 @@ __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__r
   }
 }
 
+// 5-/7-point Poisson operator written directly in the offset-major w4 layout (no CSR arrays):
+// offsets {-nx*ny, -nx, -1, 0, 1, nx, nx*ny} (3-D) or {-nx, -1, 0, 1, nx}; same entries, same
+// per-row order as poisson_csr_kernel
+__global__ void poisson_w4_kernel(int nx, int ny, int nz, long n, int no, double *__restrict__ valT,
+                                  unsigned short *__restrict__ mask) {
+  const long nxy = (long)nx * ny;
+  const bool three_d = nz > 0;
+  const double dg = three_d ? 6.0 : 4.0;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(k % nx);
+    const int j = (int)((k / nx) % ny);
+    const long l = k / nxy;
+    double *v = valT + (size_t)(k / kDiaRows) * no * kDiaRows + (size_t)(k % kDiaRows);
+    unsigned m = 0;
+    int b = 0;
+    if (three_d) {
+      if (l > 0) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+      ++b;
+    }
+    if (j > 0) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+    ++b;
+    if (i > 0) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+    ++b;
+    v[(size_t)b * kDiaRows] = dg; m |= 1u << b;
+    ++b;
+    if (i < nx - 1) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+    ++b;
+    if (j < ny - 1) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+    ++b;
+    if (three_d) {
+      if (l < nz - 1) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
+      ++b;
+    }
+    mask[k] = (unsigned short)m;
+  }
+}
+
+// A[r, r] from the w4 layout (0.0 where the diagonal is not stored)
+__global__ void dia_diag_kernel(int nrows, int no, int zero_slot, const double *__restrict__ valT,
+                                const unsigned short *__restrict__ mask, double *__restrict__ diag) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+    double d = 0.0;
+    if (zero_slot >= 0 && ((mask[r] >> zero_slot) & 1u))
+      d = valT[((size_t)(r / kDiaRows) * no + zero_slot) * kDiaRows + (size_t)(r % kDiaRows)];
+    diag[r] = d;
+  }
+}
+
 template <int NO, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(256) void csr_spmv_w4(
     int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
@@ -2158,6 +2206,7 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
 
 bool csr_spmv_has_skip(const psp_csr *A) {
   Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
   if (v.w4 && A->sym_owner) {
     psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
     if (ensure_sss_w4(S) != PSP_OK) return false;
@@ -2180,6 +2229,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   Workspace *w;
   PSP_TRY(workspace(&w));
   Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
   if (v.w4 && A->sym_owner) {  // the full mirror of an sss_mat: multiply with the lower triangle only
     psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
     PSP_TRY(ensure_sss_w4(S));
@@ -2233,6 +2283,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       return PSP_OK;
     }
   }
+  if (A->w4_only) return fail(PSP_EINVAL, "this operator exists only in the w4 layout (psp_csr_poisson_big)");
   if ((v.wave || v.w1) && A->max_row_nnz > v.tile / 2) {  // a chunk would not fit one wave tile
     v.wave = v.w1 = v.w2 = false;
     v.tile = 2048;
@@ -2434,6 +2485,7 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx) {
   Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
   if (v.w4 && row_a < row_b) {
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
@@ -2661,6 +2713,58 @@ int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out) {
   return psp_csr_poisson_slab(nx, ny, nz, 0, n, 0, (int)n, out);
 }
 
+int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
+  if (!out || nx < 2 || ny < 2 || nz < 0 || nz == 1)
+    return fail(PSP_EINVAL, "psp_csr_poisson_big: grid dimensions must be >= 2 (nz = 0: 2-D)");
+  const long n = (long)nx * ny * (nz > 0 ? nz : 1);
+  if (n > 0x7fffffffL - 256) return fail(PSP_EINVAL, "psp_csr_poisson_big: n exceeds 32-bit row indices");
+  PSP_TRY(ensure_device());
+  const bool three_d = nz > 0;
+  const int no = three_d ? 7 : 5;
+  const long nxy = (long)nx * ny;
+  psp_csr *A = new psp_csr();
+  A->nrows = A->ncols = (int)n;
+  A->nnz64 = poisson_prefix(n, nx, ny, nz);
+  A->nnz = A->nnz64 > 0x7fffffffL ? -1 : (int)A->nnz64;
+  A->max_row_nnz = no;
+  A->w4_only = true;
+  psp::CsrExtra *ex;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    ex = &g_extra[A];
+  }
+  int b = 0;
+  if (three_d) ex->dia_offs.o[b++] = (int)-nxy;
+  ex->dia_offs.o[b++] = -nx;
+  ex->dia_offs.o[b++] = -1;
+  ex->dia_offs.o[b++] = 0;
+  ex->dia_offs.o[b++] = 1;
+  ex->dia_offs.o[b++] = nx;
+  if (three_d) ex->dia_offs.o[b++] = (int)nxy;
+  for (; b < kDiaMaxOffs; ++b) ex->dia_offs.o[b] = 0;
+  const size_t nblk = ((size_t)n + kDiaRows - 1) / kDiaRows;
+  const size_t nval = nblk * kDiaRows * no;
+  hipError_t e1 = hipMalloc((void **)&ex->dia_val, sizeof(double) * nval);
+  hipError_t e2 = hipMalloc((void **)&ex->dia_mask, sizeof(unsigned short) * (nblk * kDiaRows + 2));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    (void)hipGetLastError();
+    psp_csr_destroy(A);
+    return fail(PSP_ENOMEM, "psp_csr_poisson_big: device allocation of %zu values failed", nval);
+  }
+  PSP_HIP(hipMemsetAsync(ex->dia_val, 0, sizeof(double) * nval, stream()));
+  PSP_HIP(hipMemsetAsync(ex->dia_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
+  hipLaunchKernelGGL(poisson_w4_kernel, dim3(65536), dim3(256), 0, stream(), nx, ny, nz, n, no, ex->dia_val,
+                     ex->dia_mask);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  ex->dia_no = no;
+  ex->dia_state = 1;
+  *out = A;
+  return PSP_OK;
+}
+
+int64_t psp_csr_nnz64(const psp_csr_t *A) { return A ? (A->w4_only ? A->nnz64 : (int64_t)A->nnz) : 0; }
+
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
   {
@@ -2698,6 +2802,7 @@ int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz) {
 
 int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host) {
   if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
+  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big)");
   if (ind_host)
     PSP_HIP(hipMemcpyAsync(ind_host, A->ind, sizeof(int) * ((size_t)A->nrows + 1),
                            hipMemcpyDeviceToHost, stream()));
@@ -2713,6 +2818,17 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
 
 int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
   if (A->nrows == 0) return PSP_OK;
+  if (A->w4_only) {
+    psp::CsrExtra *ex;
+    PSP_TRY(ensure_w4(A, &ex));
+    int zero_slot = -1;
+    for (int o = 0; o < ex->dia_no; ++o)
+      if (ex->dia_offs.o[o] == 0) zero_slot = o;
+    hipLaunchKernelGGL(dia_diag_kernel, dim3(std::min((A->nrows + 255) / 256, 65536)), dim3(256), 0, stream(),
+                       A->nrows, ex->dia_no, zero_slot, ex->dia_val, ex->dia_mask, diag_dev);
+    PSP_LAUNCH_CHECK();
+    return PSP_OK;
+  }
   int grid = std::min((A->nrows + 255) / 256, 4096);
   hipLaunchKernelGGL(csr_diag_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind, A->col,
                      A->val, diag_dev);
@@ -2752,6 +2868,7 @@ int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
 
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
+  if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big)");
   PSP_HIP(hipMemsetAsync(y_dev, 0, sizeof(double) * (size_t)A->ncols, stream()));
   if (A->nrows == 0 || A->nnz == 0) return PSP_OK;
   int grid = std::min((A->nrows + 3) / 4, 8192);
@@ -2794,6 +2911,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
   Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
   const char *k = "csr_spmv_stream";
   int vals[4] = {0, 0, 0, 0};
   bool w4 = false;
@@ -2856,6 +2974,10 @@ int psp_csr_set_variant(psp_csr_t *A, int variant) {
 
 int64_t psp_csr_device_bytes(const psp_csr_t *A) {
   if (!A) return 0;
+  if (A->w4_only) {
+    const int64_t rows = ((int64_t)A->nrows + kDiaRows - 1) / kDiaRows * kDiaRows;
+    return rows * (8 * (int64_t)A->max_row_nnz + 2);
+  }
   return (int64_t)(sizeof(int) * ((size_t)A->nrows + 1) + (sizeof(int) + sizeof(double)) * A->padded);
 }
 

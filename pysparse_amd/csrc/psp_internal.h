@@ -81,6 +81,10 @@ struct psp_csr {
   int max_row_nnz = 0;
   int sched_strip_rows = -1;  // psp_csr_set_schedule: -1 automatic, 0 off, > 0 forced strip width
   const struct psp_sss *sym_owner = nullptr;  // set on the full mirror of an sss_mat (sss_spmv_w4)
+  // psp_csr_poisson_big: the operator exists ONLY in the offset-major w4 layout (ind / col / val are
+  // null; nnz may exceed 32 bits: nnz64 holds it, nnz is -1 then)
+  bool w4_only = false;
+  int64_t nnz64 = 0;
 };
 
 struct psp_sss {

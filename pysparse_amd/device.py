@@ -96,6 +96,15 @@ class DeviceCSR:
         return cls(h)
 
     @classmethod
+    def poisson_big(cls, nx, ny, nz=0):
+        """the Poisson operator in the index-free w4 layout only (nnz may exceed 32 bits: 1024^3)"""
+        h = C.c_void_p()
+        check(lib().psp_csr_poisson_big(nx, ny, nz, C.byref(h)))
+        A = cls(h)
+        A.nnz = int(lib().psp_csr_nnz64(h))
+        return A
+
+    @classmethod
     def poisson_slab(cls, nx, ny, nz, row_lo, row_hi, col_shift, ncols_local):
         h = C.c_void_p()
         check(lib().psp_csr_poisson_slab(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local, C.byref(h)))

@@ -246,3 +246,75 @@ def test_fullsize_slab_of_1024_cubed():
     for c, v in ((g - nxy, -1.0), (g - nx, -1.0), (g - 1, -1.0), (g, 6.0), (g + 1, -1.0), (g + nx, -1.0), (g + nxy, -1.0)):
         s += v * xh[c]
     assert y4[k] == s
+
+
+@pytest.mark.parametrize("grid", [(40, 30, 20), (64, 50, 0), (129, 7, 3)])
+def test_poisson_big_equals_csr_operator(oracle, grid):
+    """psp_csr_poisson_big (w4 layout only, no CSR arrays) against the ordinary generator: same bits for
+    y = A x, the diagonal and a Jacobi-PCG solve; download / transpose are refused"""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import PspError
+    A = dev.DeviceCSR.poisson(*grid)
+    B = dev.DeviceCSR.poisson_big(*grid)
+    assert B.shape == A.shape and B.nnz == A.nnz and B.kernel_info()[0] == "csr_spmv_w4"
+    n = A.shape[0]
+    x = np.random.default_rng(1).standard_normal(n)
+    ya, yb = np.empty(n), np.empty(n)
+    A.matvec(x, ya)
+    B.matvec(x, yb)
+    assert np.array_equal(ya, yb)
+    assert np.array_equal(A.diagonal(), B.diagonal())
+    b = np.empty(n)
+    A.matvec(np.ones(n), b)
+    xa, xb = np.zeros(n), np.zeros(n)
+    ra = dev.pcg(A, b, xa, 1e-10, 2000, dev.DeviceJacobi(A))
+    rb = dev.pcg(B, b, xb, 1e-10, 2000, dev.DeviceJacobi(B))
+    assert ra == rb and np.array_equal(xa, xb)
+    with pytest.raises(PspError):
+        B.download()
+    with pytest.raises(PspError):
+        B.matvec_transp(x, yb)
+    B.set_variant(16578)  # asking for a CSR kernel changes nothing: there are no CSR arrays
+    B.matvec(x, yb)
+    assert np.array_equal(ya, yb)
+
+
+def test_fullsize_1024_cubed_on_one_gpu():
+    """C4's operator on ONE GPU (n = 2^30, nnz = 7.5e9 > 2^31: index-free layout only): exact row sums,
+    spot rows against the definition, 5 Jacobi-PCG iterations with a consistent residual"""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    N = 1024
+    A = dev.DeviceCSR.poisson_big(N, N, N)
+    n = A.shape[0]
+    assert n == 1 << 30 and A.nnz == 7 * n - 6 * N * N == 7509901312  # SURVEY section 8
+    ones = dev.DeviceBuffer(n)
+    y = dev.DeviceBuffer(n)
+    chunk = np.ones(1 << 26)  # ones on the device without an 8 GiB host array
+    for k in range(0, n, chunk.size):
+        check(L.psp_memcpy_h2d(ones.ptr + 8 * k, chunk.ctypes.data, 8 * chunk.size))
+    A.matvec_dev(ones.ptr, y.ptr)
+    # row sums plane by plane: interior planes see only the x/y faces, the first and last one more
+    e2 = missing_neighbours(N, N, 0)
+    plane = np.empty(N * N)
+    for l in (0, 1, 511, 1022, 1023):
+        check(L.psp_memcpy_d2h(plane.ctypes.data, y.ptr + 8 * l * N * N, 8 * N * N))
+        assert np.array_equal(plane, e2 + (1.0 if l in (0, N - 1) else 0.0)), l
+    b = y  # b = A*ones
+    x = dev.DeviceBuffer(n)
+    x.zero()
+    K = dev.DeviceJacobi(A)
+    aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
+    info, it, rr = C.c_int(), C.c_int(), C.c_double()
+    check(L.psp_pcg_dev(aop._h, kop._h, n, x.ptr, b.ptr, 0.0, 5, C.byref(info), C.byref(it), C.byref(rr), None))
+    check(L.psp_synchronize())
+    assert (info.value, it.value) == (-1, 6) and 0 < rr.value < 1
+    r = ones  # reuse
+    out = dev.DeviceBuffer(4)
+    A.matvec_dev(x.ptr, r.ptr)
+    check(L.psp_k_residual(n, b.ptr, r.ptr, None, out.ptr))
+    rr_true = np.sqrt(float(out.download()[0]))
+    check(L.psp_k_dot(n, b.ptr, b.ptr, out.ptr))
+    n2b = np.sqrt(float(out.download()[0]))
+    assert abs(rr_true / n2b - rr.value) <= 1e-10 * rr.value
