@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""A second stand-in for BASELINE config C5 (Emilia_923: unstructured FEM, 3 dof per node, ~44 nnz/row),
+closer to it than the log-spaced K1 pattern: a 68 x 68 x 67 node grid, 3 unknowns per node, every node
+coupled to itself, its 6 face and 8 corner neighbours (45 nnz/row, n = 929 424), node numbers shuffled
+inside groups of --shuffle consecutive nodes to mimic an unstructured ordering.  sss_mat product
+through each applicable kernel + Jacobi-MINRES."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pysparse_amd import device as dev  # noqa: E402
+from pysparse_amd._capi import check, lib  # noqa: E402
+from tools.spmv_sweep import time_launches  # noqa: E402
+
+
+def fem_sss(gx, gy, gz, shuffle, seed=0):
+    rng = np.random.default_rng(seed)
+    nn = gx * gy * gz
+    ids = np.arange(nn, dtype=np.int64)
+    if shuffle > 1:  # local renumbering
+        for a in range(0, nn, shuffle):
+            b = min(nn, a + shuffle)
+            ids[a:b] = a + rng.permutation(b - a)
+    i = np.arange(nn) % gx
+    j = (np.arange(nn) // gx) % gy
+    k = np.arange(nn) // (gx * gy)
+    nb = [(0, 0, 0)] + [(s, 0, 0) for s in (-1, 1)] + [(0, s, 0) for s in (-1, 1)] + [(0, 0, s) for s in (-1, 1)]
+    nb += [(a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)]
+    rows, cols, vals = [], [], []
+    for (di, dj, dk) in nb:
+        ok = (i + di >= 0) & (i + di < gx) & (j + dj >= 0) & (j + dj < gy) & (k + dk >= 0) & (k + dk < gz)
+        p = np.nonzero(ok)[0]
+        q = p + di + gx * (dj + gy * dk)
+        P, Q = ids[p], ids[q]
+        for d in range(3):
+            for e in range(3):
+                r, c = 3 * P + d, 3 * Q + e
+                lower = c < r
+                rr, cc = r[lower], c[lower]
+                rows.append(rr)
+                cols.append(cc)
+                vals.append(-(0.05 + 0.01 * ((rr * 7 + cc * 13) % 10)))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    n = 3 * nn
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=ind[1:])
+    diag = 10.0 + rng.random(n)
+    return n, ind, cols.astype(np.int32), vals, diag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shuffle", type=int, default=32)
+    ap.add_argument("--grid", default="68,68,67")
+    a = ap.parse_args()
+    gx, gy, gz = (int(t) for t in a.grid.split(","))
+    L = lib()
+    n, ind, col, val, diag = fem_sss(gx, gy, gz, a.shuffle)
+    nl = len(col)
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    x = dev.DeviceBuffer.from_host(np.random.default_rng(1).standard_normal(n))
+    y = dev.DeviceBuffer(n)
+    res = {"n": n, "nnz_lower": nl, "nnz_per_row_full": (2 * nl + n) / n, "shuffle": a.shuffle,
+           "w3_nb_cap": os.environ.get("PSP_SPMV_W3_NB", "64")}
+    ref = None
+    for name, variant in (("default", -1), ("w2", 16578)):
+        S.set_variant(variant)
+        kern, info = S.kernel_info()
+        f = lambda: S.matvec_dev(x.ptr, y.ptr)  # noqa: E731
+        time_launches(f, 5)
+        yh = y.download()
+        if ref is None:
+            ref = yh
+        assert np.array_equal(ref, yh)
+        t = min(time_launches(f, 30) for _ in range(3))
+        res[name] = {"kernel": kern, "info": info, "spmv_ms": t,
+                     "GBps_sss_model": (12 * nl + 28 * n + 4) / t / 1e6,
+                     "GBps_csr_model": (12 * (2 * nl + n) + 20 * n + 4) / t / 1e6}
+    S.set_variant(-1)
+    b = np.zeros(n)
+    b[0] = 1.0
+    xh = np.zeros(n)
+    t0 = time.perf_counter()
+    r = dev.minres(S, b, xh, 1e-10, 2000, dev.DeviceJacobi(S))
+    res["minres"] = {"info": r[0], "iter": r[1], "relres": r[2], "seconds_incl_pcie": time.perf_counter() - t0}
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
