@@ -243,3 +243,29 @@ def test_tendigit_script_flow(golden_dir):
     ind, col, val = A.to_csr_arrays()
     xs = spla.spsolve(sp.csr_matrix((val, col, ind), shape=(n, n)).tocsc(), b)
     assert abs(x[0] - xs[0]) < 1e-14 and np.abs(x - xs).max() < 1e-13
+
+
+def test_pysparse_matrix_products_on_gpu(oracle, L100):
+    """A*x (pysparseMatrix.py:224-272), x*A and the solvers driven with the wrapped ll_mat"""
+    from pysparse.sparse.pysparseMatrix import PysparseMatrix
+    from pysparse.itsolvers.krylov import pcg
+    from pysparse.precon import precon
+    from pysparse.tools import poisson
+    A = PysparseMatrix(matrix=L100)
+    n = A.getShape()[0]
+    R = oracle.poisson_csr(100, 100)
+    x = np.random.default_rng(4).standard_normal(n)
+    y_ref = np.empty(n)
+    R.matvec(x, y_ref)
+    assert np.array_equal(A * x, y_ref) and np.array_equal(A.matvec(x), y_ref)
+    assert np.allclose(x * A, y_ref, rtol=1e-12, atol=1e-12)  # symmetric operator: A^T x = A x (atomics: tolerance)
+    S = PysparseMatrix(matrix=poisson.poisson2d_sym(30))
+    xs = np.random.default_rng(5).standard_normal(900)
+    ys = np.empty(900)
+    oracle.poisson_csr(30, 30).matvec(xs, ys)
+    assert np.array_equal(S * xs, ys)
+    b = A * np.ones(n)
+    xsol, xo = np.zeros(n), np.zeros(n)
+    res = pcg(A.getMatrix(), b, xsol, 1e-8, 2 * n, precon.jacobi(A.getMatrix()))
+    ref = oracle.pcg(R, b, xo, 1e-8, 2 * n, oracle.jacobi_dinv(R.diagonal()))
+    assert res[:2] == ref[:2] and np.abs(xsol - xo).max() <= 1e-12 * np.abs(xo).max()

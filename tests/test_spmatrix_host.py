@@ -239,3 +239,84 @@ def test_itsolver_wrappers_exist():
     with pytest.raises(NotImplementedError):
         ItSolver(None).solve(np.ones(2), np.ones(2), 1e-8, 5)
     assert Pcg(None).name == "pcg" and Minres(None).name == "minres"
+
+
+def test_tools_poisson_builders(oracle):
+    """pysparse.tools.poisson / poisson_vec (pysparse/tools/poisson.py, poisson_vec.py): element-wise,
+    vectorised (ll_mat.put) and block-built forms give the structures the oracle generates; the nnz
+    formulas are the ones test/test_spmatrix.py:77-78 asserts"""
+    from pysparse.tools import poisson, poisson_vec, cputime
+    for n in (2, 3, 7):
+        R2, R3 = oracle.poisson_csr(n, n), oracle.poisson_csr(n, n, n)
+        for L, R in ((poisson.poisson2d(n), R2), (poisson_vec.poisson2d_vec(n), R2),
+                     (poisson.poisson3d(n), R3), (poisson_vec.poisson3d_vec(n), R3)):
+            ind, col, val = L.to_csr_arrays()
+            assert np.array_equal(ind, R.ind) and np.array_equal(col, R.col) and np.array_equal(val, R.val)
+        assert poisson.poisson2d(n).nnz == n * (5 * n - 4)
+        S2, S3 = oracle.poisson_sss(n, n), oracle.poisson_sss(n, n, n)
+        for L, S in ((poisson.poisson2d_sym(n), S2), (poisson.poisson2d_sym_blk(n), S2),
+                     (poisson_vec.poisson2d_sym_vec(n), S2), (poisson.poisson3d_sym(n), S3),
+                     (poisson_vec.poisson3d_sym_vec(n), S3)):
+            ind, col, val, diag = L.to_sss_arrays()
+            assert np.array_equal(ind, S.ind) and np.array_equal(col, S.col)
+            assert np.array_equal(val, S.val) and np.array_equal(diag, S.diag)
+        assert poisson.poisson2d_sym(n).nnz == n * (3 * n - 2)
+        # the symmetric ll_mat expands to the same full CSR as the general one (ll_mat.c:1586-1625)
+        ind, col, val = poisson.poisson2d_sym(n).to_csr_arrays()
+        assert np.array_equal(ind, R2.ind) and np.array_equal(col, R2.col) and np.array_equal(val, R2.val)
+        ind, col, val = poisson.poisson1d(n).to_csr_arrays()
+        assert list(np.diff(ind)) == ([2] + [3] * (n - 2) + [2] if n > 1 else [1])
+        i1, c1, v1 = poisson_vec.poisson1d_vec(n).to_csr_arrays()
+        assert np.array_equal(ind, i1) and np.array_equal(col, c1) and np.array_equal(val, v1)
+    assert cputime() >= 0.0
+
+
+def test_pysparse_matrix_host_operations(tmp_path):
+    """PysparseMatrix (pysparse/sparse/pysparseMatrix.py:61-545): construction keywords, copy, +, -,
+    scalar and matrix products, scaling, put / take / addAt, find, dense and MatrixMarket export,
+    identity and spdiags -- host-side, checked against dense NumPy"""
+    from pysparse.sparse import spmatrix
+    from pysparse.sparse.pysparseMatrix import PysparseIdentityMatrix, PysparseMatrix, PysparseSpDiagsMatrix
+    A = PysparseMatrix(matrix=poisson2d(4))
+    dense = A.getNumpyArray()
+    assert A.getShape() == (16, 16) and A.getNnz() == 4 * (5 * 4 - 4) and not A.isSymmetric()
+    assert np.array_equal(A.copy().getNumpyArray(), dense)
+    eye = PysparseIdentityMatrix(16)
+    assert eye.isSymmetric() and np.array_equal(eye.getNumpyArray(), np.eye(16))
+    assert np.array_equal((A + eye).getNumpyArray(), dense + np.eye(16))
+    assert np.array_equal((A - 2.0 * eye).getNumpyArray(), dense - 2 * np.eye(16))
+    assert np.array_equal((-A).getNumpyArray(), -dense) and np.array_equal((A * 0.5).getNumpyArray(), 0.5 * dense)
+    assert np.allclose((A * A).getNumpyArray(), dense @ dense)
+    S = PysparseMatrix(matrix=poisson2d_sym(4))
+    assert S.isSymmetric() and np.array_equal(S.getNumpyArray(), dense)
+    T = S + S
+    assert T.isSymmetric() and np.array_equal(T.getNumpyArray(), 2 * dense)
+    assert np.array_equal((S + A).getNumpyArray(), 2 * dense) and not (S + A).isSymmetric()
+    assert np.array_equal(S.takeDiagonal(), 4 * np.ones(16))
+    assert S.take([1], [0])[0] == -1 and S.take([0], [1])[0] == -1 and S.take([0], [5])[0] == 0
+    v, r, c = A.find()
+    assert v.size == A.getNnz() and np.array_equal(dense[r, c], v)
+    B = A.copy()
+    B.row_scale(np.arange(1.0, 17.0))
+    assert np.array_equal(B.getNumpyArray(), np.diag(np.arange(1.0, 17.0)) @ dense)
+    B.col_scale(np.full(16, 2.0))
+    assert np.array_equal(B.getNumpyArray(), 2 * np.diag(np.arange(1.0, 17.0)) @ dense)
+    B.addAtDiagonal(np.ones(16))
+    B.put(7.0, [0], [3])
+    B.addAt([1.5], [0], [3])
+    assert B[0, 3] == 8.5 and B[0, 0] == 2 * 4 + 1
+    B[2, 2] = -3.0
+    assert B[2, 2] == -3.0
+    M = PysparseSpDiagsMatrix(5, [np.arange(1.0, 6.0), -np.ones(5), -np.ones(5)], [0, 1, -1])
+    assert np.array_equal(M.getNumpyArray(), np.diag(np.arange(1.0, 6.0)) - np.eye(5, k=1) - np.eye(5, k=-1))
+    Z = PysparseMatrix(size=6, symmetric=True, sizeHint=10)
+    assert Z.isSymmetric() and Z.getShape() == (6, 6) and Z.getNnz() == 0
+    with pytest.raises(ValueError):
+        PysparseMatrix(size=3, nrow=4, ncol=3)
+    with pytest.raises(TypeError):
+        A + PysparseIdentityMatrix(3)
+    p = tmp_path / "s.mtx"
+    S.exportMmf(str(p))
+    L = spmatrix.ll_mat_from_mtx(str(p))
+    assert L.issym and L.nnz == S.getNnz()
+    assert np.array_equal(PysparseMatrix(matrix=L).getNumpyArray(), dense)
