@@ -134,7 +134,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
 /* which kernel y := A x runs for this handle (builds its tables if needed): name, and
  * info[4] = {w3: x blocks per chunk list / w4: number of distinct col-row offsets,
  * most x blocks one chunk references (w3), schedule active, half band width used by the schedule}.
- * csr_spmv_w4: offset-structured operators (<= 16 distinct col - row, ascending columns), values in
+ * csr_spmv_w4: offset-structured operators (<= 32 distinct col - row, ascending columns), values in
  *   offset-major blocks + 16-bit row masks; csr_spmv_w3: banded CSR, x staged in LDS, 16-bit
  *   chunk-local columns; csr_spmv_w2 / w1 / stream: any CSR.  All add each row's products left
  *   to right (csr_mat.c:49-54), so the choice never changes a bit of y. */

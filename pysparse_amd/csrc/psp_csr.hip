@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // x pairs: 8-byte aligned
 
 constexpr int kDiaRows = 128;      // rows per block (one wave: two rows per lane)
-constexpr int kDiaMaxOffs = 16;
+constexpr int kDiaMaxOffs = 32;  // 1..16: 16-bit row masks (csr_spmv_w4), 17..32: 32-bit (csr_spmv_w4x)
 constexpr int kDiaEmpty = -0x7fffffff - 1;
 
 struct DiaOffs {
@@ -918,9 +918,10 @@ __global__ void dia_offsets_kernel(int nrows, const int *__restrict__ ind, const
   }
 }
 
+template <typename MaskT>
 __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__restrict__ ind,
                                  const int *__restrict__ col, const double *__restrict__ val,
-                                 double *__restrict__ valT, unsigned short *__restrict__ mask) {
+                                 double *__restrict__ valT, MaskT *__restrict__ mask) {
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
     const long blk = r / kDiaRows;
     const int i = (int)(r % kDiaRows);
@@ -932,7 +933,7 @@ __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__r
       m |= 1u << b;
       valT[((size_t)blk * no + b) * kDiaRows + i] = val[k];
     }
-    mask[r] = (unsigned short)m;
+    mask[r] = (MaskT)m;
   }
 }
 
@@ -1212,6 +1213,93 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
       a1 = ((m1 >> (8 + j)) & 1u) ? t1 : a1;
     }
     if (two) {
+      d2u outu;
+      outu.x = a0;
+      outu.y = a1;
+      __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
+      if (dotv) {
+        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        dsum += u.x * a0;
+        dsum += u.y * a1;
+      }
+    } else {
+      y[r] = a0;
+      if (dotv) dsum += dotv[r] * a0;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// csr_spmv_w4 for 17..32 offsets (27-point stencils): 32-bit row masks, and the offsets are taken in
+// groups of 8 so that the value / x pairs of one group, not of all offsets, are live at a time
+template <int NO>
+__global__ __launch_bounds__(256) void csr_spmv_w4x(
+    int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
+    const unsigned *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int vb = (int)blockIdx.x;
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int blk = blk0 + vb * 4 + wid;
+  const long r = (long)blk * kDiaRows + 2 * lane;
+  double dsum = 0.0;
+  if (blk < blk1 && r < nrows) {
+    const uint2 mm = *reinterpret_cast<const uint2 *>(mask + r);  // padded to a whole block
+    const unsigned m0 = mm.x, m1 = mm.y;
+    const double *vp = valT + (size_t)blk * NO * kDiaRows + 2 * lane;
+    const long cmax = (long)ncols - 2;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < NO; g += 8) {
+      constexpr int G = 8;
+      d2v v[G], xv[G];
+      bool edge = false;
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (g + u < NO) {
+          v[u] = ldg<true>(reinterpret_cast<const d2v *>(vp + (g + u) * kDiaRows));
+          const long c = r + offs.o[g + u];
+          const long cc = c < 0 ? 0 : (c > cmax ? cmax : c);
+          const d2u t = *reinterpret_cast<const d2u *>(x + cc);
+          xv[u].x = t.x;
+          xv[u].y = t.y;
+          edge |= cc != c;
+        }
+      }
+      if (edge) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < NO) {
+            const long c = r + offs.o[g + u];
+            if (c < 0 || c > cmax) {
+              xv[u].x = (c >= 0 && c < ncols) ? x[c] : 0.0;
+              xv[u].y = (c + 1 >= 0 && c + 1 < ncols) ? x[c + 1] : 0.0;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (g + u < NO) {
+          const double t0 = a0 + v[u].x * xv[u].x;
+          const double t1 = a1 + v[u].y * xv[u].y;
+          a0 = ((m0 >> (g + u)) & 1u) ? t0 : a0;
+          a1 = ((m1 >> (g + u)) & 1u) ? t1 : a1;
+        }
+      }
+    }
+    if (r + 1 < nrows) {
       d2u outu;
       outu.x = a0;
       outu.y = a1;
@@ -1616,7 +1704,8 @@ struct CsrExtra {
   int dia_no = 0;
   DiaOffs dia_offs;
   double *dia_val = nullptr;
-  unsigned short *dia_mask = nullptr;
+  unsigned short *dia_mask = nullptr;  // dia_no <= 16
+  unsigned *dia_mask32 = nullptr;      // dia_no > 16
 };
 
 }  // namespace psp
@@ -1908,20 +1997,31 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   if (slots * 8.0 > 11.0 * (double)A->nnz) return PSP_OK;
   for (int i = 0; i < kDiaMaxOffs; ++i) ex.dia_offs.o[i] = i < no ? offs[i] : 0;
   const size_t nval = nblk * kDiaRows * no;
+  const bool m32 = no > 16;
+  const size_t nmask = nblk * kDiaRows + 2;
   hipError_t e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
-  hipError_t e2 = hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * (nblk * kDiaRows + 2));
+  hipError_t e2 = m32 ? hipMalloc((void **)&ex.dia_mask32, sizeof(unsigned) * nmask)
+                      : hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * nmask);
   if (e1 != hipSuccess || e2 != hipSuccess) {  // no room: stay with the CSR kernels
     (void)hipGetLastError();
     if (e1 == hipSuccess) (void)hipFree(ex.dia_val);
-    if (e2 == hipSuccess) (void)hipFree(ex.dia_mask);
+    if (e2 == hipSuccess) (void)hipFree(m32 ? (void *)ex.dia_mask32 : (void *)ex.dia_mask);
     ex.dia_val = nullptr;
     ex.dia_mask = nullptr;
+    ex.dia_mask32 = nullptr;
     return PSP_OK;
   }
   PSP_HIP(hipMemsetAsync(ex.dia_val, 0, sizeof(double) * nval, stream()));
-  PSP_HIP(hipMemsetAsync(ex.dia_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
-  hipLaunchKernelGGL(dia_build_kernel, dim3(std::min((A->nrows + 255) / 256, 65536)), dim3(256), 0, stream(),
-                     A->nrows, no, ex.dia_offs, A->ind, A->col, A->val, ex.dia_val, ex.dia_mask);
+  const int bgrid = std::min((A->nrows + 255) / 256, 65536);
+  if (m32) {
+    PSP_HIP(hipMemsetAsync(ex.dia_mask32, 0, sizeof(unsigned) * nmask, stream()));
+    hipLaunchKernelGGL(dia_build_kernel<unsigned>, dim3(bgrid), dim3(256), 0, stream(), A->nrows, no, ex.dia_offs,
+                       A->ind, A->col, A->val, ex.dia_val, ex.dia_mask32);
+  } else {
+    PSP_HIP(hipMemsetAsync(ex.dia_mask, 0, sizeof(unsigned short) * nmask, stream()));
+    hipLaunchKernelGGL(dia_build_kernel<unsigned short>, dim3(bgrid), dim3(256), 0, stream(), A->nrows, no,
+                       ex.dia_offs, A->ind, A->col, A->val, ex.dia_val, ex.dia_mask);
+  }
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(stream()));
   ex.dia_no = no;
@@ -1946,6 +2046,15 @@ static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int 
   switch (ex->dia_no) {
     PSP_W4(1); PSP_W4(2); PSP_W4(3); PSP_W4(4); PSP_W4(5); PSP_W4(6); PSP_W4(7); PSP_W4(8);
     PSP_W4(9); PSP_W4(10); PSP_W4(11); PSP_W4(12); PSP_W4(13); PSP_W4(14); PSP_W4(15); PSP_W4(16);
+#define PSP_W4X(NO)                                                                                  \
+  case NO:                                                                                           \
+    hipLaunchKernelGGL((csr_spmv_w4x<NO>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows,      \
+                       A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask32, x, y, dotv, pbuf, \
+                       skip);                                                                        \
+    break
+    PSP_W4X(17); PSP_W4X(18); PSP_W4X(19); PSP_W4X(20); PSP_W4X(21); PSP_W4X(22); PSP_W4X(23); PSP_W4X(24);
+    PSP_W4X(25); PSP_W4X(26); PSP_W4X(27); PSP_W4X(28); PSP_W4X(29); PSP_W4X(30); PSP_W4X(31); PSP_W4X(32);
+#undef PSP_W4X
     default:
       return fail(PSP_EINVAL, "csr_spmv_w4: %d offsets", ex->dia_no);
   }
@@ -2782,6 +2891,7 @@ int psp_csr_destroy(psp_csr_t *A) {
       if (it->second.packed) (void)hipFree(it->second.packed);
       if (it->second.dia_val) (void)hipFree(it->second.dia_val);
       if (it->second.dia_mask) (void)hipFree(it->second.dia_mask);
+      if (it->second.dia_mask32) (void)hipFree(it->second.dia_mask32);
       g_extra.erase(it);
     }
   }

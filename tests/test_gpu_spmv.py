@@ -326,7 +326,12 @@ def offset_structured_csr(O, m, n, seed, offsets, keep=0.93, empty_frac=0.02):
 @pytest.mark.parametrize("case", [
     (1001, 1001, (-37, -1, 0, 1, 37)), (777, 900, (0, 5, 123)), (2048, 2048, tuple(range(-8, 8))),
     (513, 700, (-3, 0, 2, 180)), (128, 128, (0,)), (127, 131, (0, 2, 4)), (1290, 1290, (-128, 0, 128)),
-    (4000, 4100, (100, 101, 99, 0, 37, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74))])
+    (4000, 4100, (100, 101, 99, 0, 37, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74)),
+    # 17..32 offsets: csr_spmv_w4x (32-bit row masks, offsets in groups of 8)
+    (3001, 3001, tuple(range(-8, 9))), (5000, 5000, tuple(range(-16, 16))),
+    # the 27-point stencil of a 12 x 11 x 10 grid
+    (1320, 1320, tuple(sorted(di + 12 * dj + 132 * dk for di in (-1, 0, 1) for dj in (-1, 0, 1) for dk in (-1, 0, 1)))),
+    (2049, 2100, tuple(range(0, 290, 10)))])
 def test_csr_matvec_w4_offset_structured_bit_exact(oracle, case):
     """csr_spmv_w4 (masked offset-major layout): random subsets of <= 16 offsets, empty rows, odd row
     counts, rectangular shapes, stored zeros; NaN / Inf in x reach exactly the rows that store an
@@ -359,7 +364,7 @@ def test_csr_matvec_w4_offset_structured_bit_exact(oracle, case):
 
 
 def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
-    """unsorted columns (storage order is not offset order), more than 16 offsets, too much padding"""
+    """unsorted columns (storage order is not offset order), more than 32 offsets, too much padding"""
     from pysparse_amd.device import DeviceCSR
     n = 500
     ind = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
@@ -375,7 +380,7 @@ def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
     A.matvec(x, y_ref)
     D.matvec(x, y)
     assert np.array_equal(y, y_ref)
-    B = offset_structured_csr(oracle, 600, 600, 3, tuple(range(-10, 10)))  # 20 offsets
+    B = offset_structured_csr(oracle, 600, 600, 3, tuple(range(-20, 20)))  # 40 offsets
     assert DeviceCSR.from_arrays(B.shape, B.ind, B.col, B.val).kernel_info()[0] != "csr_spmv_w4"
     Cm = offset_structured_csr(oracle, 3000, 3000, 4, tuple(range(0, 160, 10)), keep=0.1)  # 90 % padding
     DC = DeviceCSR.from_arrays(Cm.shape, Cm.ind, Cm.col, Cm.val)
