@@ -1,0 +1,116 @@
+"""GPU: randomized structure stress of y = A x -- every applicable kernel (default selection, w3, w2,
+stream) must give the oracle's bits on hundreds of small random matrices: offset-structured (w4 / w4x
+eligible) with random offset sets, banded (w3 eligible), scattered, tiny and rectangular shapes, empty
+rows / columns, rows longer than a tile.  Seeds are fixed: failures are reproducible."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W3, W2, STREAM = (1 << 20) + 16578, 16578, 0
+
+
+def make_matrix(O, rng):
+    kind = rng.choice(["offsets", "offsets", "banded", "scattered", "tiny", "longrow"])
+    if kind == "tiny":
+        m, n = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    elif kind == "longrow":
+        m, n = int(rng.integers(2, 40)), int(rng.integers(3000, 9000))
+    else:
+        m = int(rng.integers(1, 3000))
+        n = m if rng.random() < 0.5 else int(rng.integers(1, 3000))
+    rows = []
+    if kind == "offsets":
+        k = int(rng.integers(1, 33))
+        span = int(rng.choice([3, 40, 1000, 5000]))
+        offs = np.unique(rng.integers(-span, span + 1, size=k))
+        keep = rng.choice([0.5, 0.9, 1.0])
+        for r in range(m):
+            c = r + offs
+            c = c[(c >= 0) & (c < n)]
+            rows.append(c[rng.random(c.size) < keep] if rng.random() > 0.03 else c[:0])
+    elif kind == "banded":
+        hb = int(rng.integers(1, 200))
+        mr = int(rng.integers(1, 30))
+        for r in range(m):
+            ctr = min(r * n // max(m, 1), n - 1)
+            lo, hi = max(0, ctr - hb), min(n, ctr + hb + 1)
+            L = int(rng.integers(0, min(mr, hi - lo) + 1))
+            rows.append(np.sort(rng.choice(np.arange(lo, hi), size=L, replace=False)))
+    elif kind == "longrow":
+        for r in range(m):
+            L = int(rng.choice([0, 5, 600, 2500, n]))
+            rows.append(np.sort(rng.choice(n, size=min(L, n), replace=False)))
+    else:
+        mr = int(rng.integers(1, 12))
+        for r in range(m):
+            L = int(rng.integers(0, min(mr, n) + 1))
+            rows.append(np.sort(rng.choice(n, size=L, replace=False)))
+    ind = np.zeros(m + 1, dtype=np.int32)
+    np.cumsum([len(c) for c in rows], out=ind[1:])
+    col = (np.concatenate(rows) if ind[-1] else np.zeros(0)).astype(np.int32)
+    val = rng.standard_normal(ind[-1])
+    return kind, O.CSR((m, n), val, col, ind)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_random_structures_all_kernels_bit_exact(oracle, block):
+    from pysparse_amd.device import DeviceCSR
+    rng = np.random.default_rng(1000 + block)
+    seen = {}
+    for t in range(40):
+        kind, A = make_matrix(oracle, rng)
+        m, n = A.shape
+        D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+        x = rng.standard_normal(n)
+        y_ref = np.full(m, 7.0)
+        A.matvec(x, y_ref)
+        for variant in (-1, W3, W2, STREAM):
+            D.set_variant(variant)
+            name = D.kernel_info()[0]
+            y = np.full(m, -3.0)
+            D.matvec(x, y)
+            assert np.array_equal(y, y_ref), (block, t, kind, A.shape, A.nnz, variant, name)
+            if variant == -1:
+                seen[name] = seen.get(name, 0) + 1
+        yt_ref = np.empty(n)
+        A.matvec_transp(rng.standard_normal(m) * 0 + 1.0, yt_ref)
+        yt = np.empty(n)
+        D.matvec_transp(np.ones(m), yt)
+        assert np.allclose(yt, yt_ref, rtol=1e-12, atol=1e-12 * (np.abs(yt_ref).max() + 1))
+    assert len(seen) >= 2, seen  # the selection really visits several kernels
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_symmetric_structures_sss_bit_exact(oracle, block):
+    from pysparse_amd.device import DeviceSSS
+    rng = np.random.default_rng(2000 + block)
+    for t in range(30):
+        n = int(rng.integers(2, 2500))
+        structured = rng.random() < 0.6
+        rows = []
+        if structured:
+            k = int(rng.integers(1, 9))
+            offs = -np.unique(rng.integers(1, int(rng.choice([3, 60, 1500])) + 1, size=k))
+            keep = rng.choice([0.7, 1.0])
+            for r in range(n):
+                c = np.sort(r + offs)
+                c = c[c >= 0]
+                rows.append(c[rng.random(c.size) < keep])
+        else:
+            for r in range(n):
+                L = int(rng.integers(0, min(8, r) + 1))
+                rows.append(np.sort(rng.choice(r, size=L, replace=False)) if L else np.zeros(0, dtype=np.int64))
+        ind = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum([len(c) for c in rows], out=ind[1:])
+        col = (np.concatenate(rows) if ind[-1] else np.zeros(0)).astype(np.int32)
+        S = oracle.SSS(n, rng.standard_normal(ind[-1]), rng.standard_normal(n), col, ind)
+        D = DeviceSSS.from_arrays(n, S.ind, S.col, S.val, S.diag)
+        x = rng.standard_normal(n)
+        y_ref = np.full(n, 1.5)
+        S.matvec(x, y_ref)
+        for variant in (-1, W3, W2):
+            D.set_variant(variant)
+            y = np.full(n, -2.5)
+            D.matvec(x, y)
+            assert np.array_equal(y, y_ref), (block, t, n, structured, variant, D.kernel_info())
