@@ -722,7 +722,12 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
   }
 }
 
-template <int NP, int NB, int WPB, bool NTS>
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+
+// PAIRS: each lane takes 2 consecutive nonzeros per step (8 steps) instead of 4 (4 steps): every
+// value load instruction then covers 1 KB contiguous -- 8 cache lines instead of the 16 that the two
+// half-loads of the 4-wide form touch twice
+template <int NP, int NB, int WPB, bool NTS, bool NTL = false, bool PAIRS = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     int chunk0, int nchunks, int stripe, int target, int kmax, int ncols,
     const int2 *__restrict__ tab, const unsigned short *__restrict__ rowoff,
@@ -760,11 +765,22 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const unsigned short *cp = col16 + (size_t)chunk * WT;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      int k = kb + (st * 64 + lane) * 4;
-      k = (k < kmax) ? k : kmax;
-      v0[st] = *reinterpret_cast<const d2v *>(val + k);
-      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
-      c[st] = *reinterpret_cast<const us4v *>(cp + (st * 64 + lane) * 4);
+      if constexpr (PAIRS) {  // v0 = nonzeros (2 st) * 128 + 2 lane .. +1, v1 = the same in the next 128
+        int k0 = kb + (2 * st) * 128 + 2 * lane, k1 = k0 + 128;
+        k0 = (k0 < kmax + 2) ? k0 : kmax + 2;
+        k1 = (k1 < kmax + 2) ? k1 : kmax + 2;
+        v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k0));
+        v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k1));
+        const us2v c0 = ldg<NTL>(reinterpret_cast<const us2v *>(cp + (2 * st) * 128 + 2 * lane));
+        const us2v c1 = ldg<NTL>(reinterpret_cast<const us2v *>(cp + (2 * st + 1) * 128 + 2 * lane));
+        c[st].x = c0.x; c[st].y = c0.y; c[st].z = c1.x; c[st].w = c1.y;
+      } else {
+        int k = kb + (st * 64 + lane) * 4;
+        k = (k < kmax) ? k : kmax;
+        v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k));
+        v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k + 2));
+        c[st] = ldg<NTL>(reinterpret_cast<const us4v *>(cp + (st * 64 + lane) * 4));
+      }
     }
     const int *bl = blist + (size_t)chunk * NB;
     const int blk0 = bl[NB == 32 ? (lane & 31) : lane];
@@ -812,9 +828,14 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      const int off = (st * 64 + lane) * 4;
-      *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
-      *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+      if constexpr (PAIRS) {
+        *reinterpret_cast<d2v *>(&buf[(2 * st) * 128 + 2 * lane]) = p0[st];
+        *reinterpret_cast<d2v *>(&buf[(2 * st + 1) * 128 + 2 * lane]) = p1[st];
+      } else {
+        const int off = (st * 64 + lane) * 4;
+        *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
+        *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2224,12 +2245,27 @@ static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab,
                      nchunks, map_mode, colmask(), tab, A->ind, A->col, A->val, x, y, dotv, partials);
 }
 
+// A/B knobs of the w3 kernel
+// Form of the w3 value / column stream: 1 NT loads, 2 pair layout, 3 both.  Default = both: the
+// pair layout alone changes nothing (2.075 vs 2.080 ms at 512^3), NT loads on the 4-wide form cost
+// 13 % (each line is touched by two load instructions), together they give 2 % (2.038 ms).
+// Variant bits 25-26 select the other three forms for A/B (stored value XOR 3).
+static int w3_ab(const psp_csr *A) { return (A->variant >= 0 ? (A->variant >> 25) & 3 : 0) ^ 3; }
+
 // csr_spmv_w3 over chunks [c0, c1) (the whole matrix: 0, nchunks)
 template <int NP, int NB>
 static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
                             int c1, const double *x, double *y, const double *dotv, double *pbuf,
                             const int *skip, const int *perm) {
-  if (nts)
+#define PSP_W3_AB(NTL, PAIRS)                                                                          \
+  hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, NTL, PAIRS>), dim3(grid), dim3(256), 0, stream(), c0, c1, \
+                     stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
+                     A->val, x, y, dotv, pbuf, skip, perm)
+  const int ab = w3_ab(A);
+  if (nts && ab == 1) PSP_W3_AB(true, false);
+  else if (nts && ab == 2) PSP_W3_AB(false, true);
+  else if (nts && ab == 3) PSP_W3_AB(true, true);
+  else if (nts)
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
                        A->val, x, y, dotv, pbuf, skip, perm);

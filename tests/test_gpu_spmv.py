@@ -60,7 +60,7 @@ def test_poisson_slab_matches_global_rows(oracle):
     assert n == nx * ny * nz
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195, 1065154, 3162306])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195, 1065154, 3162306, 34619586, 68174018, 101728450])
 @pytest.mark.parametrize("grid", [(100, 100, 0), (64, 64, 64), (41, 29, 13)])
 def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
     from pysparse_amd.device import DeviceCSR
@@ -76,7 +76,8 @@ def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
     assert np.array_equal(y, y_ref)
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 6, 16, 32, 36, 52, 68, 128, 129, 130, 132, 133, 134, 149, 150, 164, 195])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 6, 16, 32, 36, 52, 68, 128, 129, 130, 132, 133, 134, 149, 150, 164, 195,
+                                     1065154, 34619586, 68174018, 101728450])
 @pytest.mark.parametrize("case", ["ragged", "long", "wide", "tiny", "all_empty", "one_huge_row"])
 def test_csr_matvec_bit_exact_irregular(oracle, case, variant):
     from pysparse_amd.device import DeviceCSR
@@ -251,11 +252,13 @@ def test_csr_matvec_w3_banded_bit_exact(oracle, shape):
     y = np.full(m, np.nan)
     D.matvec(x, y)
     assert np.array_equal(y, y_ref)
-    D.set_variant(16578)  # w2
-    assert D.kernel_info()[0] in ("csr_spmv_w2", "csr_spmv_w1")
-    y2 = np.full(m, np.nan)
-    D.matvec(x, y2)
-    assert np.array_equal(y2, y_ref)
+    for v in (16578, 1065154, 34619586, 68174018, 101728450):  # w2; w3 4-wide; w3 NT / pairs / both
+        D.set_variant(v)
+        if v == 16578:
+            assert D.kernel_info()[0] in ("csr_spmv_w2", "csr_spmv_w1")
+        y2 = np.full(m, np.nan)
+        D.matvec(x, y2)
+        assert np.array_equal(y2, y_ref), v
 
 
 @pytest.mark.parametrize("grid,strip", [((40, 40, 30), 256), ((64, 64, 20), 1024), ((30, 20, 50), 100), ((300, 300, 0), 900)])

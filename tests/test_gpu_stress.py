@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 W3, W2, STREAM = (1 << 20) + 16578, 16578, 0
+W3_VARIANTS = (W3, W3 + (1 << 25), W3 + (2 << 25), W3 + (3 << 25))
 
 
 def make_matrix(O, rng):
@@ -65,7 +66,7 @@ def test_random_structures_all_kernels_bit_exact(oracle, block):
         x = rng.standard_normal(n)
         y_ref = np.full(m, 7.0)
         A.matvec(x, y_ref)
-        for variant in (-1, W3, W2, STREAM):
+        for variant in (-1, W2, STREAM) + W3_VARIANTS:
             D.set_variant(variant)
             name = D.kernel_info()[0]
             y = np.full(m, -3.0)
