@@ -40,10 +40,10 @@ int k_jacobi_first(long n, const double *x, const double *dinv, double *y);
 int k_jacobi_sweep(long n, const double *x, const double *dinv, const double *temp, double *y);
 int k_dinv(long n, const double *diag, double omega, double *dinv, double *partials, int *nparts);
 int k_scale_div(long n, const double *y, double beta, double *v);
-int k_lanczos(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old,
+int k_lanczos(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old,
               const double *dinv, double *y, double *partials, int *nparts);
-int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old);
-int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, double *w,
+int k_lanczos_plain(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old);
+int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w,
                 double *w_old, double *x);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
@@ -607,10 +607,13 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
     const double alpha = s[0];
     const double dconst1 = alpha / beta, dconst2 = beta / beta_old;  // minres.c:131
     // v_hat = Av - c1 v_hat - c2 v_hat_old; v_hat_old = old v_hat; y = K v_hat; beta^2
+    // (the kernels write the new v_hat over v_hat_old; swapping the names is "v_hat_old = old v_hat")
     if (kfused) {
       PSP_TRY(k_lanczos(n, av, dconst1, dconst2, v_hat, v_hat_old, dinv, y, w->partials, &np));
+      std::swap(v_hat, v_hat_old);
     } else {
       PSP_TRY(k_lanczos_plain(n, av, dconst1, dconst2, v_hat, v_hat_old));
+      std::swap(v_hat, v_hat_old);
       PSP_TRY(op_apply(K, v_hat, y));  // minres.c:137-140
       PSP_TRY(k_dot(n, v_hat, y, w->partials, &np));
     }
@@ -642,7 +645,8 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
     s_ = beta / r1;
 
     // w, x update (minres.c:172-180)
-    PSP_TRY(k_minres_wx(n, v, r1, r2, r3, c * eta, wv, w_old, x));
+    PSP_TRY(k_minres_wx(n, v, r1, r2, r3, c * eta, wv, w_old, x));  // new w lands in w_old's buffer
+    std::swap(wv, w_old);
     eta = -s_ * eta;
     norm_rmr *= fabs(s_);  // minres.c:192
     if (hist) hist[*iter] = norm_rmr;

@@ -307,33 +307,37 @@ __global__ __launch_bounds__(kBlock) void scale_div_kernel(long n, const double 
 // ---- MINRES Lanczos update (minres.c:131-143):
 //      t = v_hat; v_hat = av - c1*v_hat - c2*v_hat_old; v_hat_old = t;
 //      y = dinv.*v_hat (PRE && y != nullptr) ; partial {v_hat . y}
-template <int V, bool PRE>
+template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void lanczos_kernel(
-    long n, const double *__restrict__ av, double c1, double c2, double *__restrict__ v_hat,
-    double *__restrict__ v_hat_old, const double *__restrict__ dinv, double *__restrict__ y,
+    long n, const double *__restrict__ av, double c1, double c2, const double *__restrict__ v_hat,
+    double *__restrict__ v_hat_old, const double *__restrict__ dinv, double dc, double *__restrict__ y,
     double *__restrict__ partials) {
+  // The new v_hat is written over v_hat_old (its old value is consumed here) and the caller swaps the
+  // two names: "v_hat_old = old v_hat" (minres.c:125,135) then costs no store.  PRE as in residual_kernel.
   double acc[1] = {0.0};
   PSP_VEC_LOOP(i, n) {
     const Pack<V> a = ld<V>(av, i);
-    Pack<V> vh = ld<V>(v_hat, i), vo = ld<V>(v_hat_old, i);
+    const Pack<V> vh = ld<V>(v_hat, i);
+    Pack<V> vo = ld<V>(v_hat_old, i);
     Pack<V> dd, yy;
-    if constexpr (PRE) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 1) dd = ld<V>(dinv, i);
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) dd.v[u] = dc;
+    }
 #pragma unroll
     for (int u = 0; u < V; ++u) {
-      const double t = vh.v[u];
-      const double nv = a.v[u] - c1 * t - c2 * vo.v[u];
-      vo.v[u] = t;
-      vh.v[u] = nv;
-      if constexpr (PRE) {
+      const double nv = a.v[u] - c1 * vh.v[u] - c2 * vo.v[u];
+      vo.v[u] = nv;
+      if constexpr (PRE != 0) {
         yy.v[u] = nv * dd.v[u];
         acc[0] += nv * yy.v[u];
       } else {
         acc[0] += nv * nv;
       }
     }
-    st<V>(v_hat, i, vh);
     st<V>(v_hat_old, i, vo);
-    if constexpr (PRE) st<V>(y, i, yy);
+    if constexpr (PRE != 0) st<V>(y, i, yy);
   }
   block_reduce_store<1>(acc, partials);
 }
@@ -342,42 +346,35 @@ __global__ __launch_bounds__(kBlock) void lanczos_kernel(
 template <int V>
 __global__ __launch_bounds__(kBlock) void lanczos_plain_kernel(long n, const double *__restrict__ av,
                                                                double c1, double c2,
-                                                               double *__restrict__ v_hat,
+                                                               const double *__restrict__ v_hat,
                                                                double *__restrict__ v_hat_old) {
-  PSP_VEC_LOOP(i, n) {
+  PSP_VEC_LOOP(i, n) {  // new v_hat over v_hat_old; the caller swaps the names
     const Pack<V> a = ld<V>(av, i);
-    Pack<V> vh = ld<V>(v_hat, i), vo = ld<V>(v_hat_old, i);
+    const Pack<V> vh = ld<V>(v_hat, i);
+    Pack<V> vo = ld<V>(v_hat_old, i);
 #pragma unroll
-    for (int u = 0; u < V; ++u) {
-      const double t = vh.v[u];
-      vh.v[u] = a.v[u] - c1 * t - c2 * vo.v[u];
-      vo.v[u] = t;
-    }
-    st<V>(v_hat, i, vh);
+    for (int u = 0; u < V; ++u) vo.v[u] = a.v[u] - c1 * vh.v[u] - c2 * vo.v[u];
     st<V>(v_hat_old, i, vo);
   }
 }
 
 // ---- MINRES update (minres.c:172-180): tmp = w; w = (v - r3*w_old - r2*tmp)/r1;
-//      w_old = tmp; x += c_eta*w
+//      w_old = tmp; x += c_eta*w.  The new w is written over w_old and the caller swaps the names.
 template <int V>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double *__restrict__ v,
                                                            double r1, double r2, double r3,
-                                                           double c_eta, double *__restrict__ w,
+                                                           double c_eta, const double *__restrict__ w,
                                                            double *__restrict__ w_old,
                                                            double *__restrict__ x) {
   PSP_VEC_LOOP(i, n) {
-    const Pack<V> vv = ld<V>(v, i);
-    Pack<V> ww = ld<V>(w, i), wo = ld<V>(w_old, i), xx = ld<V>(x, i);
+    const Pack<V> vv = ld<V>(v, i), ww = ld<V>(w, i);
+    Pack<V> wo = ld<V>(w_old, i), xx = ld<V>(x, i);
 #pragma unroll
     for (int u = 0; u < V; ++u) {
-      const double tmp = ww.v[u];
-      const double nw = (vv.v[u] - r3 * wo.v[u] - r2 * tmp) / r1;
-      ww.v[u] = nw;
-      wo.v[u] = tmp;
+      const double nw = (vv.v[u] - r3 * wo.v[u] - r2 * ww.v[u]) / r1;
+      wo.v[u] = nw;
       xx.v[u] += c_eta * nw;
     }
-    st<V>(w, i, ww);
     st<V>(w_old, i, wo);
     st<V>(x, i, xx);
   }
@@ -628,24 +625,28 @@ int k_scale_div(long n, const double *y, double beta, double *v) {
   return PSP_OK;
 }
 
-int k_lanczos(long n, const double *av, double c1, double c2, double *v_hat, double *v_hat_old,
+int k_lanczos(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old,
               const double *dinv, double *y, double *partials, int *nparts) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
-  const bool v2 = dinv ? can_vec2(n, av, v_hat, v_hat_old, dinv, y) : can_vec2(n, av, v_hat, v_hat_old);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, av, v_hat, v_hat_old, y) : can_vec2(n, av, v_hat, v_hat_old, dinv, y))
+                       : can_vec2(n, av, v_hat, v_hat_old);
 #define L(V, PRE)                                                                              \
   hipLaunchKernelGGL((lanczos_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, av, c1, \
-                     c2, v_hat, v_hat_old, dinv, y, partials)
-  if (dinv) { if (v2) L(2, true); else L(1, true); }
-  else { if (v2) L(2, false); else L(1, false); }
+                     c2, v_hat, v_hat_old, dinv, dc, y, partials)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
 #undef L
   PSP_LAUNCH_CHECK();
   *nparts = grid;
   return PSP_OK;
 }
 
-int k_lanczos_plain(long n, const double *av, double c1, double c2, double *v_hat,
+int k_lanczos_plain(long n, const double *av, double c1, double c2, const double *v_hat,
                     double *v_hat_old) {
   Workspace *w;
   PSP_TRY(workspace(&w));
@@ -684,7 +685,7 @@ int k_scal(long n, double a, double *x) {
   return PSP_OK;
 }
 
-int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, double *w_,
+int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w_,
                 double *w_old, double *x) {
   Workspace *w;
   PSP_TRY(workspace(&w));
