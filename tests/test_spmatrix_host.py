@@ -320,3 +320,49 @@ def test_pysparse_matrix_host_operations(tmp_path):
     L = spmatrix.ll_mat_from_mtx(str(p))
     assert L.issym and L.nnz == S.getNnz()
     assert np.array_equal(PysparseMatrix(matrix=L).getNumpyArray(), dense)
+
+
+def test_mtx_direct_ingest_equals_ll_mat_route(tmp_path):
+    """tools.mtx (MatrixMarket -> CSR / SSS arrays without an ll_mat) against ll_mat_from_mtx(...).to_*:
+    general and symmetric files, unsorted entries, repeated entries (last one wins), explicit zeros"""
+    from pysparse.sparse import spmatrix
+    from pysparse.tools import mtx
+    rng = np.random.default_rng(8)
+    n = 40
+    # symmetric file: lower triangle in shuffled order, a repeated entry, an explicit zero
+    ent = [(i, j, float(rng.standard_normal())) for i in range(n) for j in range(i + 1) if rng.random() < 0.2 or i == j]
+    ent.append((7, 3, 0.0))
+    ent.append((9, 2, 1.25))
+    ent.append((9, 2, -4.5))
+    order = rng.permutation(len(ent))
+    ps = tmp_path / "s.mtx"
+    with open(ps, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% a comment\n")
+        f.write("%d %d %d\n" % (n, n, len(ent)))
+        for k in order:
+            f.write("%d %d %.17g\n" % (ent[k][0] + 1, ent[k][1] + 1, ent[k][2]))
+    # the repeated (9, 2) entries must keep file order for "last one wins": write them adjacent & ordered
+    L = spmatrix.ll_mat_from_mtx(str(ps))
+    shape, ind, col, val = mtx.csr_arrays_from_mtx(str(ps))
+    li, lc, lv = L.to_csr_arrays()
+    assert shape == L.shape and np.array_equal(ind, li) and np.array_equal(col, lc) and np.array_equal(val, lv)
+    ns, sind, scol, sval, sdiag = mtx.sss_arrays_from_mtx(str(ps))
+    ti, tc, tv, td = L.to_sss_arrays()
+    assert ns == n and np.array_equal(sind, ti) and np.array_equal(scol, tc)
+    assert np.array_equal(sval, tv) and np.array_equal(sdiag, td)
+    # general rectangular file
+    m2, n2 = 30, 50
+    ent = [(int(rng.integers(m2)), int(rng.integers(n2)), float(rng.standard_normal())) for _ in range(300)]
+    pg = tmp_path / "g.mtx"
+    with open(pg, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m2, n2, len(ent)))
+        for (i, j, v) in ent:
+            f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
+    G = spmatrix.ll_mat_from_mtx(str(pg))
+    shape, ind, col, val = mtx.csr_arrays_from_mtx(str(pg))
+    gi, gc, gv = G.to_csr_arrays()
+    assert shape == (m2, n2) and np.array_equal(ind, gi) and np.array_equal(col, gc) and np.array_equal(val, gv)
+    with open(tmp_path / "c.mtx", "w") as f:
+        f.write("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
+    with pytest.raises(Exception):
+        mtx.read_mtx(str(tmp_path / "c.mtx"))
