@@ -355,7 +355,8 @@ def test_mtx_direct_ingest_equals_ll_mat_route(tmp_path):
     ent = [(int(rng.integers(m2)), int(rng.integers(n2)), float(rng.standard_normal())) for _ in range(300)]
     pg = tmp_path / "g.mtx"
     with open(pg, "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m2, n2, len(ent)))
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write("%d %d %d\n" % (m2, n2, len(ent)))
         for (i, j, v) in ent:
             f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
     G = spmatrix.ll_mat_from_mtx(str(pg))
