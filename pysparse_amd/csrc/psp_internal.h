@@ -137,6 +137,14 @@ struct PcgDev {
   int info, iter, stag;
   int it;      // iteration the enqueued kernels are working on (1-based), advanced on the device
   int maxit;
+  // lazy x-update loop (pcg_async_loop_lazy): x += alpha_x * p of the last finished iteration is
+  // applied by the NEXT iteration's p-update pass (or by the final pass after the loop)
+  int xpend;       // an x update (and its stagnation scan) is pending
+  int stag0;       // alpha == 0 in the pending iteration (pcg.c:124-125)
+  int head_rho0;   // deferred exits of the iteration about to start: rho == 0 (pcg.c:101-104) ...
+  int head_beta0;  // ... and beta == 0 (pcg.c:109-112); they come AFTER the pending stagnation test
+  int pend_maxit;  // the loop ran out at it == maxit: -5 or -1 is decided by the final scan
+  double alpha_x;
 };
 // y = op(x) on device vectors; y must not alias x
 int op_apply(const psp_op *op, const double *x_dev, double *y_dev);

@@ -34,6 +34,12 @@ int k_dot(long n, const double *x, const double *y, double *partials, int *npart
 int k_residual(long n, const double *b, double *r, const double *dinv, double *partials, int *nparts);
 int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p,
               const PcgDev *st = nullptr);
+int k_px_update(long n, const double *r, const double *dinv, double *p, double *x, double *partials,
+                int *nparts, const PcgDev *dstate);
+int k_x_update(long n, double alpha, const double *p, double *x, double *partials, int *nparts,
+               const PcgDev *dstate);
+int k_r_update(long n, double alpha, const double *q, const double *dinv, double *r, double *partials,
+               int *nparts, const PcgDev *dstate);
 int k_xr_update(long n, double alpha, const double *p, const double *q, const double *dinv,
                 double *x, double *r, double *partials, int *nparts, const PcgDev *st = nullptr);
 int k_jacobi_first(long n, const double *x, const double *dinv, double *y);
@@ -394,6 +400,177 @@ done:
   return rc;
 }
 
+// ---------------------------------------------------------------------- lazy x-update loop
+//
+// The x update of iteration k (x += alpha_k p_k, pcg.c:141) and its stagnation scan (:127-139) read
+// p_k; so does the p update of iteration k+1 (:113-114).  Doing both in one pass (px_update_kernel)
+// saves one read of p per iteration (146 n -> 138 n bytes with a constant Jacobi diagonal).  The
+// price is bookkeeping: whether iteration k stagnated (flag -5, :159-162) is then only known inside
+// iteration k+1, so
+//   * the convergence test of iteration k (:154-157) still ends the loop at once (it comes first in
+//     the reference too); the pending x update is applied by a final pass after the loop;
+//   * otherwise iteration k+1 starts; right after its px pass the scalar kernel looks at the scan of
+//     iteration k: stagnated -> finish with -5 / iter k / the residual of iteration k (x is x_k by
+//     then, exactly what the reference returns); the exits at the head of iteration k+1 (rho == 0,
+//     beta == 0, :101-112) are evaluated after that, in the reference's order;
+//   * when the loop runs out (k == maxit) the final pass does the scan and picks -5 or -1 (:159-165).
+// Same kernels' arithmetic, same reduction order: bitwise identical to the other loops (tested).
+
+__global__ void pcg_lazy_scalar_x(PcgDev *st, const double *__restrict__ scal) {
+  if (st->status) return;
+  if (st->xpend) {  // iteration it-1: pcg.c:159-162
+    const int stag = st->stag0 || scal[0] == 0.0;
+    st->xpend = 0;
+    if (stag) {
+      st->stag = 1;
+      pcg_finish(st, -5, st->it - 1);
+      return;
+    }
+  }
+  if (st->head_rho0) {  // pcg.c:101-104 of iteration it
+    pcg_finish(st, -2, st->it);
+    return;
+  }
+  if (st->head_beta0) pcg_finish(st, -6, st->it);  // pcg.c:109-112
+}
+
+__global__ void pcg_lazy_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
+  if (st->status) return;
+  const double pq = scal[0];
+  if (pq == 0.0) {  // pcg.c:118-120 (x holds the updates through it-1)
+    pcg_finish(st, -6, st->it);
+    return;
+  }
+  const double alpha = st->rho / pq;
+  st->alpha = alpha;
+  st->alpha_x = alpha;
+  st->stag0 = alpha == 0.0 ? 1 : 0;
+  st->xpend = 1;
+}
+
+__global__ void pcg_lazy_scalar_r(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
+  if (st->status) return;
+  const int it = st->it;
+  const double normr = sqrt(scal[0]);
+  st->normr = normr;
+  if (hist) hist[it] = normr;
+  if (normr <= st->tolb) {
+    pcg_finish(st, 0, it);  // x update of iteration it still pending: final pass
+  } else if (it == st->maxit) {
+    st->pend_maxit = 1;     // -5 or -1: decided by the scan of the final pass
+    st->status = 1;
+  } else {
+    const double rho1 = st->rho, rho = scal[1];
+    st->rho1 = rho1;
+    st->rho = rho;
+    st->it = it + 1;
+    st->head_rho0 = rho == 0.0 ? 1 : 0;
+    st->head_beta0 = 0;
+    if (rho != 0.0) {
+      const double beta = rho / rho1;
+      st->beta = beta;
+      st->head_beta0 = beta == 0.0 ? 1 : 0;
+    }
+  }
+}
+
+static int pcg_lazy_enabled() {
+  static const int on = [] {
+    const char *e = getenv("PSP_PCG_LAZYX");
+    return e ? atoi(e) : 1;
+  }();
+  return on;
+}
+
+static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
+                               double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
+                               int *info, int *iter, double *relres, double *hist) {
+  constexpr int kBatch = 16;
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  PcgDev *st = nullptr, *hst = nullptr;
+  double *hist_dev = nullptr;
+  PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
+  hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
+  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
+  if (e != hipSuccess) {
+    (void)hipFree(st);
+    if (hst) (void)hipHostFree(hst);
+    return fail(PSP_ENOMEM, "pcg: state allocation failed: %s", hipGetErrorString(e));
+  }
+  int rc = PSP_OK;
+  int enqueued = 0, np = 0;
+  double *stag_parts = w->partials + 2 * (size_t)kMaxParts;  // slot 2: the scan's partials
+#define PCG_TRY(call)            \
+  do {                           \
+    rc = (call);                 \
+    if (rc != PSP_OK) goto done; \
+  } while (0)
+#define PCG_HIP(call)                                                \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) {                                          \
+      rc = fail(PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_)); \
+      goto done;                                                     \
+    }                                                                \
+  } while (0)
+  if (hist_dev) PCG_HIP(hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)maxit + 1), stream()));
+  memset(hst, 0, sizeof(PcgDev));
+  hst->rho = rho0;
+  hst->rho1 = 1.0;
+  hst->normr = normr0;
+  hst->tolb = tolb;
+  hst->n2b = n2b;
+  hst->it = 1;
+  hst->maxit = maxit;
+  PCG_HIP(hipMemcpyAsync(st, hst, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
+  do {
+    const int batch = std::max(1, std::min(kBatch, maxit - enqueued));
+    for (int i = 0; i < batch; ++i) {
+      PCG_TRY(k_px_update(n, r, dinv, p, x, w->partials, &np, st));
+      PCG_TRY(finish_partials(stag_parts, np, 1, w->scal_dev + 8));
+      hipLaunchKernelGGL(pcg_lazy_scalar_x, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 8);
+      PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
+      PCG_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
+      hipLaunchKernelGGL(pcg_lazy_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev);
+      PCG_TRY(k_r_update(n, 0.0, q, dinv, r, w->partials, &np, st));
+      PCG_TRY(finish_partials(w->partials, np, 2, w->scal_dev + 4));
+      hipLaunchKernelGGL(pcg_lazy_scalar_r, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, hist_dev);
+    }
+    PCG_HIP(hipGetLastError());
+    enqueued += batch;
+    PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
+    PCG_HIP(hipStreamSynchronize(stream()));
+  } while (!hst->status);
+  if (hst->xpend) {  // the x update (and scan) of the last iteration
+    double s[1];
+    PCG_TRY(k_x_update(n, hst->alpha_x, p, x, w->partials, &np, nullptr));
+    PCG_TRY(finish_partials(stag_parts, np, 1, w->scal_dev + 8));
+    PCG_TRY(fetch_scalars(w->scal_dev + 8, 1, s));
+    if (hst->pend_maxit) {
+      const bool stag = hst->stag0 || s[0] == 0.0;
+      hst->info = stag ? -5 : -1;               // pcg.c:159-165
+      hst->iter = stag ? maxit : maxit + 1;
+      hst->relres = hst->normr / hst->n2b;
+    }
+  }
+  *info = hst->info;
+  *iter = hst->iter;
+  *relres = hst->relres;
+  if (hist) {
+    const int cnt = std::min(hst->iter, maxit);
+    if (cnt >= 1)
+      PCG_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+done:
+#undef PCG_TRY
+#undef PCG_HIP
+  (void)hipFree(st);
+  (void)hipHostFree(hst);
+  if (hist_dev) (void)hipFree(hist_dev);
+  return rc;
+}
+
 static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
                       double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
   Workspace *w;
@@ -452,6 +629,9 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
       *relres = normr / n2b;
       return PSP_OK;
     }
+    if (pcg_lazy_enabled() && !pcg_graph_enabled())
+      return pcg_async_loop_lazy(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter,
+                                 relres, hist);
     return pcg_async_loop(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                           relres, hist);
   }

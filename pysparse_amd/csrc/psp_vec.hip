@@ -160,6 +160,60 @@ __global__ __launch_bounds__(kBlock) void pupdate_kernel(long n, const double *_
   }
 }
 
+// ---- lazy x-update (pcg_async_loop_lazy): ONE pass does the x update + stagnation scan of the
+//      iteration that just finished (pcg.c:127-141, exactly x_update_kernel's arithmetic) and the
+//      p update of the iteration that starts (pcg.c:105-115, pupdate_kernel's) -- they share the
+//      read of p: 40 n bytes instead of 24 n + 24 n.  Scalars come from the device state.
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void px_update_kernel(long n, const double *__restrict__ r,
+                                                           const double *__restrict__ dinv, double dc,
+                                                           double *__restrict__ p, double *__restrict__ x,
+                                                           double *__restrict__ partials,
+                                                           const PcgDev *__restrict__ dstate) {
+  if (dstate->status) return;
+  const double beta = dstate->beta, alpha = dstate->alpha_x;
+  const bool first = dstate->it == 1, xp = dstate->xpend != 0;
+  const bool upd = alpha != 0.0;
+  double dmax = 0.0;
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> pp = ld<V>(p, i);  // garbage in iteration 1: neither use below reads it then
+    Pack<V> z = ld<V>(r, i);
+    if (xp) {
+      Pack<V> xx = ld<V>(x, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) {
+        const double quot = fabs(alpha * pp.v[u] / xx.v[u]);
+        const double ddum = (xx.v[u] != 0.0) ? quot : ((pp.v[u] != 0.0) ? 1.0 : 0.0);
+        dmax = (ddum > dmax) ? ddum : dmax;
+        if (upd) xx.v[u] = xx.v[u] + alpha * pp.v[u];
+      }
+      st<V>(x, i, xx);
+    }
+    if constexpr (PRE == 1) {
+      const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dd.v[u];
+    }
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] * dc;
+    }
+    if (!first) {
+#pragma unroll
+      for (int u = 0; u < V; ++u) z.v[u] = z.v[u] + beta * pp.v[u];
+    }
+    st<V>(p, i, z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(dmax, off, 64);
+    if (o > dmax) dmax = o;
+  }
+  double acc[1];
+  acc[0] = ((threadIdx.x & 63) == 0 && (1.0 + dmax != 1.0)) ? 1.0 : 0.0;
+  block_reduce_store<1>(acc, partials + 2 * (size_t)kMaxParts);
+}
+
 // ---- pcg.c:127-152 as TWO streaming kernels.  One fused pass over x, p, r, q, dinv (7 HBM
 //      streams) measured 1.39 ms at n = 2^27; the two passes below (3 and 4 streams, the same
 //      56 n bytes in total) take 0.54 + 0.74 ms (profiles/r1_vec_kernels.txt).
@@ -542,6 +596,61 @@ int k_pupdate(long n, const double *r, const double *dinv, double beta, bool fir
   }
 #undef L
   PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_px_update(long n, const double *r, const double *dinv, double *p, double *x, double *partials,
+                int *nparts, const PcgDev *dstate) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, r, p, x, dinv) : can_vec2(n, r, p, x);
+#define L(V, PRE)                                                                          \
+  hipLaunchKernelGGL((px_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, \
+                     dinv, dc, p, x, partials, dstate)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+// the two halves of k_xr_update on their own (lazy loop: r update per iteration, x update at the end)
+int k_x_update(long n, double alpha, const double *p, double *x, double *partials, int *nparts,
+               const PcgDev *dstate) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, p, x))
+    hipLaunchKernelGGL(x_update_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, alpha, p, x, partials, dstate);
+  else
+    hipLaunchKernelGGL(x_update_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, alpha, p, x, partials, dstate);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_r_update(long n, double alpha, const double *q, const double *dinv, double *r, double *partials,
+               int *nparts, const PcgDev *dstate) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, q, r, dinv) : can_vec2(n, q, r);
+#define L(V, PRE)                                                                         \
+  hipLaunchKernelGGL((r_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, \
+                     alpha, q, dinv, dc, r, partials, dstate)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
   return PSP_OK;
 }
 

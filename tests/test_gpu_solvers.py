@@ -390,8 +390,9 @@ def test_minres_poisson_vs_oracle(oracle, p2d):
 
 def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     """host-scalar loop (PSP_PCG_ASYNC=0), device-scalar loop (default), its hipGraph replay
-    (PSP_PCG_GRAPH=1), the p-update folded into the SpMV (PSP_PCG_PFUSED=1, both loops) and the dinv
-    stream kept (PSP_DINV_CONST=0) are the same algorithm: identical info / iteration counts / iterates."""
+    (PSP_PCG_GRAPH=1), the p-update folded into the SpMV (PSP_PCG_PFUSED=1, both loops), the dinv
+    stream kept (PSP_DINV_CONST=0) and the eager x update (PSP_PCG_LAZYX=0; default: x update folded into
+    the next p-update pass) are the same algorithm: identical info / iteration counts / iterates."""
     import subprocess
     import sys
     code = (
@@ -404,7 +405,8 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     outs = []
     for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}, {"PSP_PCG_PFUSED": "1"},
                 {"PSP_PCG_PFUSED": "1", "PSP_PCG_ASYNC": "0"}, {"PSP_DINV_CONST": "0"},
-                {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}):
+                {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}, {"PSP_PCG_LAZYX": "0"},
+                {"PSP_PCG_LAZYX": "0", "PSP_PCG_PFUSED": "1"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
@@ -465,3 +467,35 @@ def test_hint_constant_abi():
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         t = bh - rh
         assert abs(outs[0][0][1] - np.dot(t, t * dh)) <= 1e-12 * abs(np.dot(t, t * dh))
+
+
+def test_pcg_lazy_x_update_exit_semantics_match_eager_loop():
+    """The lazy x-update loop learns about the stagnation of iteration k only inside iteration k+1 and
+    when the loop runs out; every truncation point must still give the eager loop's (info, iter,
+    relres, x) bit for bit: tol = 0 on a small SPD system for maxit = 1 .. beyond the iteration where
+    the updates stagnate (-5), plus a converging run and the variable-diagonal Jacobi path."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);"
+        "from pysparse_amd.device import DeviceCSR, DeviceJacobi, pcg;"
+        "D = DeviceCSR.poisson(12, 12); n = 144; out = [];\n"
+        "b = np.random.default_rng(0).standard_normal(n)\n"
+        "for K in (None, DeviceJacobi(D)):\n"
+        "    for maxit in list(range(1, 140)) + [1000]:\n"
+        "        x = np.zeros(n); r = pcg(D, b, x, 0.0, maxit, K)\n"
+        "        out.append([r[0], r[1], r[2].hex(), x.tobytes().hex()[:64], float(np.abs(x).sum()).hex()])\n"
+        "x = np.zeros(n); r = pcg(D, b, x, 1e-9, 500, DeviceJacobi(D)); out.append([r[0], r[1], r[2].hex(), float(x.sum()).hex()])\n"
+        "print(json.dumps(out))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "1"}, {"PSP_PCG_ASYNC": "0"}):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2]
+    infos = {o[0] for o in outs[1][:-1]}
+    assert -5 in infos and -1 in infos  # the sweep really crosses the stagnation point
+    k5 = min(o[1] for o in outs[1][:-1] if o[0] == -5)
+    assert k5 > 3  # stagnation after several iterations, not a crafted first-iteration case
