@@ -391,8 +391,8 @@ def test_minres_poisson_vs_oracle(oracle, p2d):
 def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     """host-scalar loop (PSP_PCG_ASYNC=0), device-scalar loop (default), its hipGraph replay
     (PSP_PCG_GRAPH=1), the p-update folded into the SpMV (PSP_PCG_PFUSED=1, both loops), the dinv
-    stream kept (PSP_DINV_CONST=0) and the eager x update (PSP_PCG_LAZYX=0; default: x update folded into
-    the next p-update pass) are the same algorithm: identical info / iteration counts / iterates."""
+    stream kept (PSP_DINV_CONST=0) and the lazy x update (PSP_PCG_LAZYX=2 forces it at this size; it is
+    the default from 2^25 unknowns on: x update folded into the next p-update pass) are the same algorithm: identical info / iteration counts / iterates."""
     import subprocess
     import sys
     code = (
@@ -405,8 +405,8 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     outs = []
     for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}, {"PSP_PCG_PFUSED": "1"},
                 {"PSP_PCG_PFUSED": "1", "PSP_PCG_ASYNC": "0"}, {"PSP_DINV_CONST": "0"},
-                {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}, {"PSP_PCG_LAZYX": "0"},
-                {"PSP_PCG_LAZYX": "0", "PSP_PCG_PFUSED": "1"}):
+                {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}, {"PSP_PCG_LAZYX": "2"},
+                {"PSP_PCG_LAZYX": "2", "PSP_DINV_CONST": "0"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
@@ -489,7 +489,7 @@ def test_pcg_lazy_x_update_exit_semantics_match_eager_loop():
         "print(json.dumps(out))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "1"}, {"PSP_PCG_ASYNC": "0"}):
+    for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "2"}, {"PSP_PCG_ASYNC": "0"}):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
