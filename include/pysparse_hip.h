@@ -65,6 +65,8 @@ int psp_set_stream(void *hip_stream);
 int psp_synchronize(void);
 /* name, CU count and HBM bytes of the current device */
 int psp_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+/* free / total device memory right now (leak checks; psp_trim() first to drop the solver scratch pool) */
+int psp_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 
 /* device memory + timing hooks used by bench.py and the tests */
 int psp_malloc(void **dev, size_t bytes);

@@ -185,6 +185,15 @@ int psp_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_b
   return PSP_OK;
 }
 
+int psp_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+  PSP_TRY(ensure_device());
+  size_t f = 0, t = 0;
+  PSP_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return PSP_OK;
+}
+
 int psp_malloc(void **dev, size_t bytes) {
   if (!dev) return fail(PSP_EINVAL, "psp_malloc: NULL out pointer");
   PSP_TRY(ensure_device());

@@ -115,3 +115,51 @@ def test_random_symmetric_structures_sss_bit_exact(oracle, block):
             y = np.full(n, -2.5)
             D.matvec(x, y)
             assert np.array_equal(y, y_ref), (block, t, n, structured, variant, D.kernel_info())
+
+
+def test_no_device_memory_leak_across_handle_lifecycles(oracle):
+    """create / use / destroy every kind of handle (csr with each kernel's side tables, sss, jacobi,
+    ssor, the solvers' scratch) repeatedly: free device memory returns to where it started"""
+    import ctypes as C
+    import gc
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+
+    def free_bytes():
+        gc.collect()
+        check(L.psp_synchronize())
+        check(L.psp_trim())
+        f, t = C.c_int64(), C.c_int64()
+        check(L.psp_mem_info(C.byref(f), C.byref(t)))
+        return f.value
+
+    def cycle():
+        A = dev.DeviceCSR.poisson(96, 96, 96)
+        n = A.shape[0]
+        x, y = np.ones(n), np.empty(n)
+        for v in (-1, (1 << 20) + 16578, 16578, 0):  # w4, w3, w2, stream tables
+            A.set_variant(v)
+            A.matvec(x, y)
+        A.set_variant((1 << 20) + 16578)
+        A.set_schedule(512)
+        A.matvec(x, y)
+        A.set_variant(-1)
+        S = dev.DeviceSSS.poisson(96, 96, 96)
+        S.matvec(x, y)
+        b = y.copy()
+        xs = np.zeros(n)
+        dev.pcg(A, b, xs, 1e-6, 200, dev.DeviceJacobi(A))
+        dev.pcg(S, b, xs, 1e-6, 50, dev.DeviceSSOR(S))
+        dev.minres(S, b, xs, 1e-6, 200, dev.DeviceJacobi(S))
+        B = dev.DeviceCSR.poisson_big(64, 64, 64)
+        B.matvec(np.ones(B.shape[0]), np.empty(B.shape[0]))
+        R = oracle.poisson_csr(20, 20)
+        dev.DeviceCSR.from_arrays(R.shape, R.ind, R.col, R.val).matvec_transp(np.ones(400), np.empty(400))
+
+    cycle()  # first use builds process-lifetime things (workspace, pinned scalars)
+    f0 = free_bytes()
+    for _ in range(3):
+        cycle()
+    f1 = free_bytes()
+    assert abs(f1 - f0) <= 8 << 20, (f0, f1)  # allocator granularity, not a leak of any table (tens of MB each)
