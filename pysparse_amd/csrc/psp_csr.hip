@@ -1010,7 +1010,10 @@ template <int NO, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(256) void csr_spmv_w4(
     int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
+    int use_div, double xdiv) {
+  // use_div: multiply with x ./ xdiv instead of x (MINRES: v = y / beta formed on the fly,
+  // minres.c:123-124 -- the same correctly rounded division as the separate pass)
   if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
@@ -1056,6 +1059,13 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
         }
       }
     }
+    if (use_div) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        xv[o].x = xv[o].x / xdiv;
+        xv[o].y = xv[o].y / xdiv;
+      }
+    }
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
@@ -1073,13 +1083,17 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
       else
         *reinterpret_cast<d2u *>(y + r) = outu;
       if (dotv) {
-        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        if (use_div) {
+          u.x = u.x / xdiv;
+          u.y = u.y / xdiv;
+        }
         dsum += u.x * a0;
         dsum += u.y * a1;
       }
     } else {
       y[r] = a0;
-      if (dotv) dsum += dotv[r] * a0;
+      if (dotv) dsum += (use_div ? dotv[r] / xdiv : dotv[r]) * a0;
     }
   }
   if (partials) {
@@ -1138,7 +1152,8 @@ template <int NOL, int FLAGS = 0>
 __global__ __launch_bounds__(256) void sss_spmv_w4(
     int n, int stripe, SssOffs offs, const double *__restrict__ valL, const double *__restrict__ diag,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
+    int use_div, double xdiv) {
   if (skip && *skip) return;
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
@@ -1216,6 +1231,17 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
         x0.y = 0.0;
       }
     }
+    if (use_div) {  // x ./ xdiv (see csr_spmv_w4)
+#pragma unroll
+      for (int j = 0; j < NOL; ++j) {
+        xl[j].x = xl[j].x / xdiv;
+        xl[j].y = xl[j].y / xdiv;
+        xu[j].x = xu[j].x / xdiv;
+        xu[j].y = xu[j].y / xdiv;
+      }
+      x0.x = x0.x / xdiv;
+      x0.y = x0.y / xdiv;
+    }
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {  // lower entries, ascending column
@@ -1239,13 +1265,17 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
       outu.y = a1;
       __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
       if (dotv) {
-        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        if (use_div) {
+          u.x = u.x / xdiv;
+          u.y = u.y / xdiv;
+        }
         dsum += u.x * a0;
         dsum += u.y * a1;
       }
     } else {
       y[r] = a0;
-      if (dotv) dsum += dotv[r] * a0;
+      if (dotv) dsum += (use_div ? dotv[r] / xdiv : dotv[r]) * a0;
     }
   }
   if (partials) {
@@ -2052,11 +2082,14 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
 
 // csr_spmv_w4 over row blocks [b0, b1)
 static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int b0, int b1, const double *x,
-                     double *y, const double *dotv, double *pbuf, const int *skip, int grid) {
+                     double *y, const double *dotv, double *pbuf, const int *skip, int grid, int use_div = 0,
+                     double xdiv = 1.0) {
+  if (use_div && ex->dia_no > 16) return fail(PSP_EINVAL, "csr_spmv_w4x has no scaled form");
   const int flags = (A->variant >= 0 ? A->variant : 0) >> 23 & 3;  // A/B knobs: bit 23 plain val loads, 24 plain y stores
 #define PSP_W4_F(NO, NTL, NTS)                                                                       \
   hipLaunchKernelGGL((csr_spmv_w4<NO, NTL, NTS>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows, \
-                     A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf, skip)
+                     A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf, skip,  \
+                     use_div, xdiv)
 #define PSP_W4(NO)                                                                                   \
   case NO:                                                                                           \
     if (flags == 0) PSP_W4_F(NO, true, true);                                                        \
@@ -2169,13 +2202,13 @@ static int ensure_sss_w4(psp_sss *S) {
 }
 
 static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *y, const double *dotv,
-                         double *pbuf, const int *skip, int grid) {
+                         double *pbuf, const int *skip, int grid, int use_div = 0, double xdiv = 1.0) {
   SssOffs so;
   for (int i = 0; i < 8; ++i) so.o[i] = S->w4_offs[i];
   const int flags = (S->full->variant >= 0 ? S->full->variant : 0) >> 23 & 3;  // A/B: 1 NT lower loads (-6 %), 2 NT shifted loads (-25 %); profiles/r1_sss_spmv_w4_timing.txt
 #define PSP_SW4_F(NOL, F)                                                                            \
   hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
-                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip)
+                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv)
 #define PSP_SW4(NOL)                                                                                 \
   case NOL:                                                                                          \
     if (flags == 0) PSP_SW4_F(NOL, 0);                                                               \
@@ -2290,6 +2323,56 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
   if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
   else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
   else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+}
+
+// y = A (x ./ xdiv) and the partials of (x ./ xdiv) . y, for the two index-free layouts only
+// (MINRES: v = y / beta is never materialised); *available = 0 otherwise (nothing launched)
+int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,
+                           int *nparts, int *available) {
+  *available = 0;
+  static const bool on = [] {
+    const char *e = getenv("PSP_MINRES_SCALED");
+    return e ? atoi(e) != 0 : true;
+  }();
+  Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
+  if (!on || !v.w4 || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  const int stripe = w4_stripe(A, v);
+  const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
+  const int grid = w4_grid(nblk, stripe);
+  psp::CsrExtra *ex;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    ex = &g_extra[A];
+  }
+  bool sss = false;
+  if (A->sym_owner) {
+    psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
+    PSP_TRY(ensure_sss_w4(S));
+    sss = S->w4_state == 1;
+  }
+  if (!sss) {
+    PSP_TRY(ensure_w4(A, &ex));
+    if (ex->dia_state != 1 || ex->dia_no > 16) return PSP_OK;
+  }
+  double *pbuf = partials;
+  if (partials && grid > kMaxParts) {
+    PSP_TRY(ensure_big_partials(ex, grid));
+    pbuf = ex->big_partials;
+  }
+  if (sss)
+    PSP_TRY(launch_sss_w4(A->sym_owner, stripe, x, y, x, pbuf, nullptr, grid, 1, xdiv));
+  else
+    PSP_TRY(launch_w4(A, ex, stripe, 0, nblk, x, y, x, pbuf, nullptr, grid, 1, xdiv));
+  int np = grid;
+  if (pbuf != partials) {
+    np = kFold;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid, partials, np);
+    PSP_LAUNCH_CHECK();
+  }
+  if (nparts) *nparts = np;
+  *available = 1;
+  return PSP_OK;
 }
 
 // q = A (z + beta p_old) with p_new written on the way (csr_spmv_w4_pf); *available = 0 when the

@@ -162,6 +162,9 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
 int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old,
                            double *p_new, double *q, double beta, bool first, double *partials, int *nparts,
                            const PcgDev *dstate, int *available);
+// MINRES: y = A (x ./ xdiv) + partials of (x ./ xdiv) . y on the index-free layouts; *available = 0 otherwise
+int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,
+                           int *nparts, int *available);
 // true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
 bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,

@@ -50,7 +50,7 @@ int k_lanczos(long n, const double *av, double c1, double c2, const double *v_ha
               const double *dinv, double *y, double *partials, int *nparts);
 int k_lanczos_plain(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old);
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w,
-                double *w_old, double *x);
+                double *w_old, double *x, bool scaled = false, double vdiv = 1.0);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
 }  // namespace psp
@@ -738,6 +738,10 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   psp_csr *Acsr = op_native_csr(A);
   const double *dinv = fused_dinv(K);
   const bool kfused = (K == nullptr) || dinv != nullptr;  // y = K v_hat can ride in the update
+  // scaled mode (index-free SpMV layouts): v = y / beta is never stored; the unnormalised vector of
+  // the iteration must then survive the Lanczos update, so y ping-pongs between two buffers
+  double *y2 = nullptr;
+  if (K && kfused && Acsr) PSP_TRY(mem.alloc(n, &y2));
   const size_t bytes = sizeof(double) * (size_t)n;
   double s[4];
   int np;
@@ -778,9 +782,15 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
 
     // v = y / beta (minres.c:123-124); y = v_hat is implied: the update below keeps the
     // old v_hat in v_hat_old directly (minres.c:125,135)
-    PSP_TRY(k_scale_div(n, K ? y : v_hat, beta, v));
+    const double *vsrc = K ? y : v_hat;  // unnormalised Lanczos vector of this iteration
+    const double vdiv = beta;
+    int scaled = 0;
+    if (Acsr && kfused && (!K || y2))
+      PSP_TRY(csr_spmv_scaled_launch(Acsr, vsrc, vdiv, av, w->partials, &np, &scaled));
+    if (!scaled) PSP_TRY(k_scale_div(n, vsrc, beta, v));
     // Av = A v, alpha = v.Av (minres.c:127-129)
-    if (Acsr) {
+    if (scaled) {
+    } else if (Acsr) {
       PSP_TRY(csr_spmv_launch(Acsr, v, av, v, w->partials, &np));
     } else {
       PSP_TRY(op_apply(A, v, av));
@@ -792,8 +802,11 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
     // v_hat = Av - c1 v_hat - c2 v_hat_old; v_hat_old = old v_hat; y = K v_hat; beta^2
     // (the kernels write the new v_hat over v_hat_old; swapping the names is "v_hat_old = old v_hat")
     if (kfused) {
-      PSP_TRY(k_lanczos(n, av, dconst1, dconst2, v_hat, v_hat_old, dinv, y, w->partials, &np));
+      // scaled mode: the new y goes to the other buffer (vsrc = old y is still needed by the w update)
+      double *ynew = (scaled && K) ? y2 : y;
+      PSP_TRY(k_lanczos(n, av, dconst1, dconst2, v_hat, v_hat_old, dinv, ynew, w->partials, &np));
       std::swap(v_hat, v_hat_old);
+      if (scaled && K) std::swap(y, y2);
     } else {
       PSP_TRY(k_lanczos_plain(n, av, dconst1, dconst2, v_hat, v_hat_old));
       std::swap(v_hat, v_hat_old);
@@ -828,7 +841,8 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
     s_ = beta / r1;
 
     // w, x update (minres.c:172-180)
-    PSP_TRY(k_minres_wx(n, v, r1, r2, r3, c * eta, wv, w_old, x));  // new w lands in w_old's buffer
+    // new w lands in w_old's buffer; scaled: v = vsrc / vdiv on the fly (vsrc is v_hat_old resp. y2 now)
+    PSP_TRY(k_minres_wx(n, scaled ? vsrc : v, r1, r2, r3, c * eta, wv, w_old, x, scaled != 0, vdiv));
     std::swap(wv, w_old);
     eta = -s_ * eta;
     norm_rmr *= fabs(s_);  // minres.c:192

@@ -414,17 +414,20 @@ __global__ __launch_bounds__(kBlock) void lanczos_plain_kernel(long n, const dou
 
 // ---- MINRES update (minres.c:172-180): tmp = w; w = (v - r3*w_old - r2*tmp)/r1;
 //      w_old = tmp; x += c_eta*w.  The new w is written over w_old and the caller swaps the names.
-template <int V>
+template <int V, bool SCALED>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double *__restrict__ v,
-                                                           double r1, double r2, double r3,
+                                                           double vdiv, double r1, double r2, double r3,
                                                            double c_eta, const double *__restrict__ w,
                                                            double *__restrict__ w_old,
                                                            double *__restrict__ x) {
+  // SCALED: v holds the unnormalised Lanczos vector and v / vdiv is formed here (minres.c:123-124)
   PSP_VEC_LOOP(i, n) {
-    const Pack<V> vv = ld<V>(v, i), ww = ld<V>(w, i);
+    Pack<V> vv = ld<V>(v, i);
+    const Pack<V> ww = ld<V>(w, i);
     Pack<V> wo = ld<V>(w_old, i), xx = ld<V>(x, i);
 #pragma unroll
     for (int u = 0; u < V; ++u) {
+      if constexpr (SCALED) vv.v[u] = vv.v[u] / vdiv;
       const double nw = (vv.v[u] - r3 * wo.v[u] - r2 * ww.v[u]) / r1;
       wo.v[u] = nw;
       xx.v[u] += c_eta * nw;
@@ -795,16 +798,17 @@ int k_scal(long n, double a, double *x) {
 }
 
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w_,
-                double *w_old, double *x) {
+                double *w_old, double *x, bool scaled, double vdiv) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
-  if (can_vec2(n, v, w_, w_old, x))
-    hipLaunchKernelGGL(minres_wx_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, v, r1, r2, r3,
-                       c_eta, w_, w_old, x);
-  else
-    hipLaunchKernelGGL(minres_wx_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, v, r1, r2, r3,
-                       c_eta, w_, w_old, x);
+  const bool v2 = can_vec2(n, v, w_, w_old, x);
+#define L(V, S)                                                                                   \
+  hipLaunchKernelGGL((minres_wx_kernel<V, S>), dim3(grid), dim3(kBlock), 0, stream(), n, v, vdiv, r1, \
+                     r2, r3, c_eta, w_, w_old, x)
+  if (scaled) { if (v2) L(2, true); else L(1, true); }
+  else { if (v2) L(2, false); else L(1, false); }
+#undef L
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
