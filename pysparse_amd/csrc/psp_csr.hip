@@ -1,20 +1,27 @@
 // psp_csr.hip -- csr_mat / sss_mat device containers and the SpMV kernels.
 //
-// The hot kernel is csr_spmv_stream.  Reference loop: pysparse/sparse/src/csr_mat.c:49-54
+// Reference loop: pysparse/sparse/src/csr_mat.c:49-54
 //     for i: s = 0; for k in [ia[i], ia[i+1]): s += va[k]*x[ja[k]]; y[i] = s
-// 5-7 nonzeros per row (Poisson) means one wavefront per row would idle 57+ lanes and
-// uncoalesce val/col, so the work is cut by NONZEROS, not rows:
-//   * a "chunk" is a run of whole rows holding at most ~TILE nonzeros (table built once
-//     per matrix); a 256-thread workgroup takes one chunk at a time (persistent grid);
-//   * stream phase: the workgroup reads val/col of the chunk with 16-byte-per-lane
-//     coalesced loads, gathers x[col] (L1/L2/Infinity-Cache hits for banded operators),
-//     and parks the rounded products val*x in an LDS tile;
-//   * reduce phase: one lane per row adds that row's products from LDS left to right,
-//     i.e. in exactly the reference's order with separate multiply and add (the library
-//     is built with -ffp-contract=off), so y is bit-identical to the CPU loop;
-//   * optional epilogue: per-workgroup partial of sum u[i]*y[i] (the PCG p.q product)
-//     reduced by wave shuffles + LDS, one slot per workgroup, finished in fixed order.
-// HBM traffic per call: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
+// Every kernel in this file adds each row's separately rounded products left to right (the
+// library is built with -ffp-contract=off), so y is bit-identical to that loop whichever kernel
+// runs.  csr_spmv_launch picks, per matrix:
+//     csr_spmv_w4 / w4x   offset-structured operators (<= 32 distinct col - row): values in
+//                         offset-major blocks + row masks, no column indices, no LDS
+//     sss_spmv_w4         the same for sss_mat, strict lower triangle only (read twice, shifted)
+//     csr_spmv_w3         banded CSR: x blocks staged in LDS, 16-bit chunk-local columns
+//     csr_spmv_w2 / w1    any CSR with short rows: one wavefront per chunk of ~1024 nonzeros,
+//                         products parked in LDS, one lane per row adds them
+//     csr_spmv_stream     rows longer than half a tile (workgroup-wide tiles, carried sums)
+// Contents, in order:
+//     chunk table builder; csr_spmv_stream; csr_spmv_wave (persistent, ablation); csr_spmv_w1;
+//     csr_spmv_w2 (+ row-offset table); csr_spmv_w3 (+ build_w3_kernel);
+//     w4 family: dia_offsets / dia_build kernels, poisson_w4_kernel, csr_spmv_w4, sss_spmv_w4,
+//       csr_spmv_w4x, csr_spmv_w4_pf (PCG p-update folded in);
+//     fold / transpose / diagonal kernels; Poisson generators;
+//     host side: variant decoding, per-handle side tables (ChunkTable, CsrExtra) and their ensure_*
+//       builders, the plane-sweeping schedule, csr_spmv_launch and friends, the halo-overlap split;
+//     C ABI: psp_csr_*, psp_sss_*.
+// HBM traffic in the CSR model: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
