@@ -1501,6 +1501,38 @@ __global__ __launch_bounds__(256) void csr_spmv_w4_pf(
   }
 }
 
+// y = A^T x on the w4 layout, without atomics and in the reference's order.  csr_matvec_transp_kernel
+// (csr_mat.c:74-88) zeroes y and sweeps the rows in ascending order, adding va[k]*x[i] to y[ja[k]]:
+// y[c] therefore receives its terms by ascending row i = c - o, i.e. by DESCENDING offset.  A lane
+// owns two columns and gathers A[c - o, c] = valT[row c - o][o] for o = last .. first -- same terms,
+// same order, bit-identical to the CPU loop (the scatter kernel with fp64 atomics is only correct
+// to rounding and not reproducible).
+template <int NO>
+__global__ __launch_bounds__(256) void csr_spmv_w4_transp(
+    int nrows, int ncols, DiaOffs offs, const double *__restrict__ valT, const unsigned short *__restrict__ mask,
+    const double *__restrict__ x, double *__restrict__ y) {
+  const long c = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (c >= ncols) return;
+  const long npad = ((long)nrows + kDiaRows - 1) / kDiaRows * kDiaRows;
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int o = NO - 1; o >= 0; --o) {
+    // rows that hold column c / c + 1 at this offset; clamped loads, the mask (0 in the padding) decides
+    const long i0 = c - offs.o[o], i1 = i0 + 1;
+    const bool in0 = i0 >= 0 && i0 < nrows, in1 = i1 >= 0 && i1 < nrows && c + 1 < ncols;
+    const long j0 = i0 < 0 ? 0 : (i0 >= npad ? npad - 1 : i0), j1 = i1 < 0 ? 0 : (i1 >= npad ? npad - 1 : i1);
+    const double v0 = valT[((size_t)(j0 / kDiaRows) * NO + o) * kDiaRows + (size_t)(j0 % kDiaRows)];
+    const double v1 = valT[((size_t)(j1 / kDiaRows) * NO + o) * kDiaRows + (size_t)(j1 % kDiaRows)];
+    const unsigned m0 = mask[j0], m1 = mask[j1];
+    const double x0 = x[in0 ? i0 : 0], x1 = x[in1 ? i1 : 0];
+    const double t0 = a0 + v0 * x0, t1 = a1 + v1 * x1;
+    a0 = (in0 && ((m0 >> o) & 1u)) ? t0 : a0;
+    a1 = (in1 && ((m1 >> o) & 1u)) ? t1 : a1;
+  }
+  y[c] = a0;
+  if (c + 1 < ncols) y[c + 1] = a1;
+}
+
 // first-level fold of per-workgroup dot partials when they do not sit in the workspace
 // slots: out[o] = sum of in[o], in[o+nout], ... ; 16 lanes per output, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
@@ -2231,6 +2263,33 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
 #undef PSP_SW4
 #undef PSP_SW4_F
   PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+// y = A^T x through csr_spmv_w4_transp; *available = 0 when A has no 16-bit-mask w4 layout
+static int launch_w4_transp(const psp_csr *A, const double *x, double *y, int *available) {
+  *available = 0;
+  Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
+  if (!v.w4 || A->nrows < 1 || A->ncols < 1) return PSP_OK;
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1 || ex->dia_no > 16) return PSP_OK;
+  const int grid = (int)(((long)A->ncols + 511) / 512);
+#define PSP_W4T(NO)                                                                                 \
+  case NO:                                                                                          \
+    hipLaunchKernelGGL((csr_spmv_w4_transp<NO>), dim3(grid), dim3(256), 0, stream(), A->nrows, A->ncols, \
+                       ex->dia_offs, ex->dia_val, ex->dia_mask, x, y);                               \
+    break
+  switch (ex->dia_no) {
+    PSP_W4T(1); PSP_W4T(2); PSP_W4T(3); PSP_W4T(4); PSP_W4T(5); PSP_W4T(6); PSP_W4T(7); PSP_W4T(8);
+    PSP_W4T(9); PSP_W4T(10); PSP_W4T(11); PSP_W4T(12); PSP_W4T(13); PSP_W4T(14); PSP_W4T(15); PSP_W4T(16);
+    default:
+      return PSP_OK;
+  }
+#undef PSP_W4T
+  PSP_LAUNCH_CHECK();
+  *available = 1;
   return PSP_OK;
 }
 
@@ -3104,6 +3163,11 @@ int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
 
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
+  {  // offset-structured operators: exact gather in the reference's order, no atomics
+    int done = 0;
+    PSP_TRY(launch_w4_transp(A, x_dev, y_dev, &done));
+    if (done) return PSP_OK;
+  }
   if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big)");
   PSP_HIP(hipMemsetAsync(y_dev, 0, sizeof(double) * (size_t)A->ncols, stream()));
   if (A->nrows == 0 || A->nnz == 0) return PSP_OK;

@@ -251,7 +251,7 @@ def test_fullsize_slab_of_1024_cubed():
 @pytest.mark.parametrize("grid", [(40, 30, 20), (64, 50, 0), (129, 7, 3)])
 def test_poisson_big_equals_csr_operator(oracle, grid):
     """psp_csr_poisson_big (w4 layout only, no CSR arrays) against the ordinary generator: same bits for
-    y = A x, the diagonal and a Jacobi-PCG solve; download / transpose are refused"""
+    y = A x, y = A^T x, the diagonal and a Jacobi-PCG solve; download is refused"""
     from pysparse_amd import device as dev
     from pysparse_amd._capi import PspError
     A = dev.DeviceCSR.poisson(*grid)
@@ -272,8 +272,11 @@ def test_poisson_big_equals_csr_operator(oracle, grid):
     assert ra == rb and np.array_equal(xa, xb)
     with pytest.raises(PspError):
         B.download()
-    with pytest.raises(PspError):
-        B.matvec_transp(x, yb)
+    ta, tb, to = np.empty(n), np.empty(n), np.empty(n)
+    A.matvec_transp(x, ta)  # both through csr_spmv_w4_transp: exact, no atomics
+    B.matvec_transp(x, tb)
+    oracle.poisson_csr(*grid).matvec_transp(x, to)
+    assert np.array_equal(ta, to) and np.array_equal(tb, to)
     B.set_variant(16578)  # asking for a CSR kernel changes nothing: there are no CSR arrays
     B.matvec(x, yb)
     assert np.array_equal(ya, yb)

@@ -450,3 +450,30 @@ def test_sss_matvec_w4_lower_only_bit_exact(oracle, case):
             D.matvec(x, y2)
             assert np.array_equal(y2, y_ref, equal_nan=True)
     D.set_variant(-1)
+
+
+@pytest.mark.parametrize("case", [(1001, 1001, (-37, -1, 0, 1, 37)), (777, 900, (0, 5, 123)), (900, 777, (-123, -5, 0)),
+                                  (2048, 2048, tuple(range(-8, 8))), (513, 700, (-3, 0, 2, 180)), (127, 131, (0, 2, 4)),
+                                  (3, 2, (0,)), (4000, 4100, (100, 101, 99, 0, 37, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74))])
+def test_csr_matvec_transp_w4_exact(oracle, case):
+    """y = A^T x on offset-structured matrices: a gather over the w4 layout in the reference's
+    accumulation order (ascending row), so bit-identical to csr_matvec_transp_kernel (csr_mat.c:74-88)
+    and reproducible -- unlike the atomics scatter used for irregular matrices"""
+    from pysparse_amd.device import DeviceCSR
+    m, n, offs = case
+    A = offset_structured_csr(oracle, m, n, 11, offs, keep=0.95 if m > 10 else 1.0, empty_frac=0.0 if m < 10 else 0.02)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    if D.kernel_info()[0] != "csr_spmv_w4":
+        pytest.skip("layout refused (padding)")
+    x = rng_vec(m, 3)
+    if m > 8:
+        x[m // 2] = np.inf
+        x[m // 3] = np.nan
+    y_ref = np.full(n, 5.0)
+    A.matvec_transp(x, y_ref)
+    y = np.full(n, -5.0)
+    D.matvec_transp(x, y)
+    assert np.array_equal(y, y_ref, equal_nan=True)
+    y2 = np.full(n, -5.0)
+    D.matvec_transp(x, y2)
+    assert np.array_equal(y, y2, equal_nan=True)  # reproducible
