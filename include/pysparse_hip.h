@@ -120,9 +120,10 @@ int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host);
 /* element strides of non-contiguous NumPy views: csr_matvec_kernel_stride, csr_mat.c:58-72 */
 int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
                           ptrdiff_t incy);
-/* y := A^T x.  CSRMat_matvec_transp, csr_mat.c:114-133 (kernel :74-88).  Offset-structured matrices:
- * exact gather in the reference's accumulation order (bit-identical); otherwise an fp64-atomics
- * scatter (equal to rounding, summation order not fixed). */
+/* y := A^T x.  CSRMat_matvec_transp, csr_mat.c:114-133 (kernel :74-88).  Every y[c] adds its terms by
+ * ascending row like the reference's scatter loop, so the result is bit-identical: offset-structured
+ * matrices gather over the w4 layout, all others multiply with A^T kept as a second CSR matrix (built
+ * on the first call, + one matrix of device memory). */
 int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host);
 int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
                                  double *y_host, ptrdiff_t incy);

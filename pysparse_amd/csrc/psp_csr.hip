@@ -22,6 +22,8 @@
 //       builders, the plane-sweeping schedule, csr_spmv_launch and friends, the halo-overlap split;
 //     C ABI: psp_csr_*, psp_sss_*.
 // HBM traffic in the CSR model: 12*nnz + 4*(n+1) + 8*n (y) + 8*n (x, once) = 12 nnz + 20 n + 4.
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1533,6 +1535,40 @@ __global__ __launch_bounds__(256) void csr_spmv_w4_transp(
   if (c + 1 < ncols) y[c + 1] = a1;
 }
 
+// ---- A^T as a CSR matrix (built once per handle for matvec_transp on irregular matrices):
+// rows_of_nonzeros expands ind to one row id per nonzero; a STABLE radix sort of (column, position)
+// then lists the nonzeros of each column by ascending row -- the order in which
+// csr_matvec_transp_kernel (csr_mat.c:80-87) adds them into y[column].
+__global__ void iota_int_kernel(int n, int *__restrict__ v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+
+__global__ void rows_of_nonzeros_kernel(int nrows, const int *__restrict__ ind, int *__restrict__ rows) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < nrows; r += nwaves)
+    for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) rows[k] = r;
+}
+
+__global__ void transp_gather_kernel(int nnz, const int *__restrict__ perm, const int *__restrict__ rows,
+                                     const double *__restrict__ val, int *__restrict__ col_t,
+                                     double *__restrict__ val_t) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x) {
+    const int src = perm[k];
+    col_t[k] = rows[src];
+    val_t[k] = val[src];
+  }
+}
+
+// ind_t[c] = first position whose (sorted) column is >= c
+__global__ void transp_ptr_kernel(int nnz, int ncols, const int *__restrict__ sorted_cols, int *__restrict__ ind_t) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= nnz; k += gridDim.x * blockDim.x) {
+    const int lo = k == 0 ? 0 : sorted_cols[k - 1] + 1;  // columns (prev, cur] start at k
+    const int hi = k == nnz ? ncols : sorted_cols[k];
+    for (int c = lo; c <= hi; ++c) ind_t[c] = k;
+  }
+}
+
 // first-level fold of per-workgroup dot partials when they do not sit in the workspace
 // slots: out[o] = sum of in[o], in[o+nout], ... ; 16 lanes per output, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ in, int nin,
@@ -1545,20 +1581,6 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__rest
 #pragma unroll
   for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 16);
   if (g == 0 && o < nout) out[o] = s;
-}
-
-// y = A^T x: scatter with fp64 HBM atomics (csr_mat.c:74-88).  Not on the Krylov path.
-__global__ void csr_spmv_transp_kernel(int nrows, const int *__restrict__ ind,
-                                       const int *__restrict__ col,
-                                       const double *__restrict__ val,
-                                       const double *__restrict__ x, double *__restrict__ y) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int r = wave; r < nrows; r += nwaves) {
-    const double xi = x[r];
-    for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) atomicAdd(&y[col[k]], val[k] * xi);
-  }
 }
 
 __global__ void csr_diag_kernel(int nrows, const int *__restrict__ ind,
@@ -1796,6 +1818,7 @@ struct CsrExtra {
   double *dia_val = nullptr;
   unsigned short *dia_mask = nullptr;  // dia_no <= 16
   unsigned *dia_mask32 = nullptr;      // dia_no > 16
+  psp_csr *transposed = nullptr;       // A^T as its own handle (matvec_transp on irregular matrices)
 };
 
 }  // namespace psp
@@ -2290,6 +2313,75 @@ static int launch_w4_transp(const psp_csr *A, const double *x, double *y, int *a
 #undef PSP_W4T
   PSP_LAUNCH_CHECK();
   *available = 1;
+  return PSP_OK;
+}
+
+// A^T as a CSR handle of its own, cached on A (irregular matrices; w4 matrices use csr_spmv_w4_transp)
+static int ensure_transposed(const psp_csr *A, psp_csr **out) {
+  psp::CsrExtra *ex;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    ex = &g_extra[A];
+    if (ex->transposed) {
+      *out = ex->transposed;
+      return PSP_OK;
+    }
+  }
+  psp_csr *T = nullptr;
+  PSP_TRY(alloc_csr(A->ncols, A->nrows, A->nnz, &T));
+  const int nnz = A->nnz;
+  int rc = PSP_OK;
+  int *rows = nullptr, *pos = nullptr, *keys = nullptr, *perm = nullptr;
+  void *tmp = nullptr;
+#define TR_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      rc = fail(e_ == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "%s: %s", #call,       \
+                hipGetErrorString(e_));                                                    \
+      goto done;                                                                           \
+    }                                                                                      \
+  } while (0)
+  if (nnz > 0) {
+    const size_t ib = sizeof(int) * (size_t)nnz;
+    TR_HIP(hipMalloc((void **)&rows, ib));
+    TR_HIP(hipMalloc((void **)&pos, ib));
+    TR_HIP(hipMalloc((void **)&keys, ib));
+    TR_HIP(hipMalloc((void **)&perm, ib));
+    const int g = std::min((nnz + 255) / 256, 65536);
+    hipLaunchKernelGGL(rows_of_nonzeros_kernel, dim3(std::min((A->nrows + 3) / 4, 65536)), dim3(256), 0, stream(),
+                       A->nrows, A->ind, rows);
+    hipLaunchKernelGGL(iota_int_kernel, dim3(g), dim3(256), 0, stream(), nnz, pos);
+    int bits = 1;
+    while (bits < 31 && (1L << bits) < A->ncols) ++bits;
+    size_t bytes = 0;
+    TR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, A->col, keys, pos, perm, nnz, 0, bits, stream()));
+    TR_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
+    TR_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, A->col, keys, pos, perm, nnz, 0, bits, stream()));  // stable
+    hipLaunchKernelGGL(transp_gather_kernel, dim3(g), dim3(256), 0, stream(), nnz, perm, rows, A->val, T->col, T->val);
+    hipLaunchKernelGGL(transp_ptr_kernel, dim3(g), dim3(256), 0, stream(), nnz, A->ncols, keys, T->ind);
+    TR_HIP(hipGetLastError());
+  } else {
+    TR_HIP(hipMemsetAsync(T->ind, 0, sizeof(int) * ((size_t)A->ncols + 1), stream()));
+  }
+  TR_HIP(hipStreamSynchronize(stream()));
+  rc = finalize_csr(T);
+done:
+#undef TR_HIP
+  (void)hipFree(rows);
+  (void)hipFree(pos);
+  (void)hipFree(keys);
+  (void)hipFree(perm);
+  (void)hipFree(tmp);
+  if (rc != PSP_OK) {
+    psp_csr_destroy(T);
+    return rc;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    g_extra[A].transposed = T;
+  }
+  *out = T;
   return PSP_OK;
 }
 
@@ -3061,10 +3153,12 @@ int64_t psp_csr_nnz64(const psp_csr_t *A) { return A ? (A->w4_only ? A->nnz64 : 
 
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
+  psp_csr *transposed = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_extra_mu);
     auto it = g_extra.find(A);
     if (it != g_extra.end()) {
+      transposed = it->second.transposed;
       for (auto &t : it->second.t) {
         if (t.second.tab) (void)hipFree(t.second.tab);
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
@@ -3080,6 +3174,7 @@ int psp_csr_destroy(psp_csr_t *A) {
       g_extra.erase(it);
     }
   }
+  if (transposed) psp_csr_destroy(transposed);  // outside the lock: it has side tables of its own
   (void)hipFree(A->ind);
   (void)hipFree(A->col);
   (void)hipFree(A->val);
@@ -3169,13 +3264,13 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
     if (done) return PSP_OK;
   }
   if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big)");
-  PSP_HIP(hipMemsetAsync(y_dev, 0, sizeof(double) * (size_t)A->ncols, stream()));
-  if (A->nrows == 0 || A->nnz == 0) return PSP_OK;
-  int grid = std::min((A->nrows + 3) / 4, 8192);
-  hipLaunchKernelGGL(csr_spmv_transp_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind,
-                     A->col, A->val, x_dev, y_dev);
-  PSP_LAUNCH_CHECK();
-  return PSP_OK;
+  if (A->ncols == 0) return PSP_OK;
+  // irregular matrices: multiply with A^T stored as CSR (built once): every y[c] adds its terms by
+  // ascending row, the order of csr_matvec_transp_kernel (csr_mat.c:80-87) -- exact, no atomics
+  psp_csr *T;
+  PSP_TRY(ensure_transposed(A, &T));
+  T->variant = A->variant;
+  return csr_spmv_launch(T, x_dev, y_dev, nullptr, nullptr, nullptr);
 }
 
 int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,

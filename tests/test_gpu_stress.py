@@ -74,11 +74,14 @@ def test_random_structures_all_kernels_bit_exact(oracle, block):
             assert np.array_equal(y, y_ref), (block, t, kind, A.shape, A.nnz, variant, name)
             if variant == -1:
                 seen[name] = seen.get(name, 0) + 1
-        yt_ref = np.empty(n)
-        A.matvec_transp(rng.standard_normal(m) * 0 + 1.0, yt_ref)
-        yt = np.empty(n)
-        D.matvec_transp(np.ones(m), yt)
-        assert np.allclose(yt, yt_ref, rtol=1e-12, atol=1e-12 * (np.abs(yt_ref).max() + 1))
+        xt = rng.standard_normal(m)
+        yt_ref = np.full(n, 9.0)
+        A.matvec_transp(xt, yt_ref)
+        for variant in (-1, W2):
+            D.set_variant(variant)
+            yt = np.full(n, -9.0)
+            D.matvec_transp(xt, yt)
+            assert np.array_equal(yt, yt_ref), (block, t, kind, A.shape, variant)
     assert len(seen) >= 2, seen  # the selection really visits several kernels
 
 
