@@ -291,6 +291,17 @@ int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double
 typedef int (*psp_wait_fn)(void *ctx);
 int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, double *y_dev,
                              int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev);
+/* The same update as psp_k_xr_update in the "lazy x" arrangement: the x update and
+ * stagnation scan of the iteration that just finished ride in the p update of the next one.
+ *   px: if xpend: scan + x += alpha_x p (p = previous direction); then p := z + beta p (first: p := z);
+ *       out[0] = nonstag (meaningful when xpend)
+ *   r : r -= alpha q; out = { r.r, r.z }
+ *   x : the pending x update on its own (after the loop); out[0] = nonstag */
+int psp_k_px_update(int n, const double *r_dev, const double *dinv_dev, double beta, int first, double alpha_x,
+                    int xpend, double *p_dev, double *x_dev, double *out_dev);
+int psp_k_r_update(int n, double alpha, const double *q_dev, const double *dinv_dev, double *r_dev,
+                   double *out_dev);
+int psp_k_x_update(int n, double alpha, const double *p_dev, double *x_dev, double *out_dev);
 /* stagnation scan + x += alpha p, r -= alpha q (pcg.c:127-143) and
  * out = { r.r, r.z (z = dinv.*r), nonstag } where nonstag != 0 iff 1 + dmax != 1 */
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,

@@ -33,7 +33,7 @@ psp_ssor_create psp_ssor_destroy psp_ssor_info psp_ssor_precon psp_ssor_precon_d
 psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_ssor psp_op_from_callback psp_op_destroy
 psp_pcg psp_pcg_dev psp_minres psp_minres_dev psp_cgs psp_bicgstab psp_qmrs psp_gmres
 psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
-psp_k_csr_matvec_overlap psp_k_hint_constant psp_k_unhint
+psp_k_csr_matvec_overlap psp_k_hint_constant psp_k_unhint psp_k_px_update psp_k_r_update psp_k_x_update
 """.split()
 
 WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -121,6 +121,8 @@ def _declare(L):
         "psp_k_xr_update": [i, d, vp, vp, vp, vp, vp, vp], "psp_k_gather": [i, vp, vp, vp],
         "psp_k_csr_matvec_overlap": [vp, vp, i, vp, i, i, WAIT_FN, vp, vp],
         "psp_k_hint_constant": [vp, i], "psp_k_unhint": [vp],
+        "psp_k_px_update": [i, vp, vp, d, i, d, i, vp, vp, vp], "psp_k_r_update": [i, d, vp, vp, vp, vp],
+        "psp_k_x_update": [i, d, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

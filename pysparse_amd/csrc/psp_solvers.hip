@@ -35,7 +35,8 @@ int k_residual(long n, const double *b, double *r, const double *dinv, double *p
 int k_pupdate(long n, const double *r, const double *dinv, double beta, bool first, double *p,
               const PcgDev *st = nullptr);
 int k_px_update(long n, const double *r, const double *dinv, double *p, double *x, double *partials,
-                int *nparts, const PcgDev *dstate);
+                int *nparts, const PcgDev *dstate, double beta = 0.0, double alpha = 0.0, bool first = false,
+                bool xpend = false);
 int k_x_update(long n, double alpha, const double *p, double *x, double *partials, int *nparts,
                const PcgDev *dstate);
 int k_r_update(long n, double alpha, const double *q, const double *dinv, double *r, double *partials,

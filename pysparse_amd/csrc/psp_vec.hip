@@ -169,10 +169,16 @@ __global__ __launch_bounds__(kBlock) void px_update_kernel(long n, const double 
                                                            const double *__restrict__ dinv, double dc,
                                                            double *__restrict__ p, double *__restrict__ x,
                                                            double *__restrict__ partials,
-                                                           const PcgDev *__restrict__ dstate) {
-  if (dstate->status) return;
-  const double beta = dstate->beta, alpha = dstate->alpha_x;
-  const bool first = dstate->it == 1, xp = dstate->xpend != 0;
+                                                           const PcgDev *__restrict__ dstate, double beta,
+                                                           double alpha, int first_, int xpend_) {
+  bool first = first_ != 0, xp = xpend_ != 0;
+  if (dstate) {  // asynchronous loop: scalars live on the device; otherwise they are the arguments
+    if (dstate->status) return;
+    beta = dstate->beta;
+    alpha = dstate->alpha_x;
+    first = dstate->it == 1;
+    xp = dstate->xpend != 0;
+  }
   const bool upd = alpha != 0.0;
   double dmax = 0.0;
   PSP_VEC_LOOP(i, n) {
@@ -603,7 +609,7 @@ int k_pupdate(long n, const double *r, const double *dinv, double beta, bool fir
 }
 
 int k_px_update(long n, const double *r, const double *dinv, double *p, double *x, double *partials,
-                int *nparts, const PcgDev *dstate) {
+                int *nparts, const PcgDev *dstate, double beta, double alpha, bool first, bool xpend) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -612,7 +618,7 @@ int k_px_update(long n, const double *r, const double *dinv, double *p, double *
   const bool v2 = dinv && !cst ? can_vec2(n, r, p, x, dinv) : can_vec2(n, r, p, x);
 #define L(V, PRE)                                                                          \
   hipLaunchKernelGGL((px_update_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, \
-                     dinv, dc, p, x, partials, dstate)
+                     dinv, dc, p, x, partials, dstate, beta, alpha, first ? 1 : 0, xpend ? 1 : 0)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -884,6 +890,33 @@ int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, do
                            dot_out_dev ? w->partials : nullptr, &np, row_a, row_b, wait, ctx));
   if (dot_out_dev) return finish_partials(w->partials, np, 1, dot_out_dev);
   return PSP_OK;
+}
+
+int psp_k_px_update(int n, const double *r_dev, const double *dinv_dev, double beta, int first, double alpha_x,
+                    int xpend, double *p_dev, double *x_dev, double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_px_update(n, r_dev, dinv_dev, p_dev, x_dev, w->partials, &np, nullptr, beta, alpha_x, first != 0,
+                      xpend != 0));
+  return finish_partials(w->partials + 2 * (size_t)kMaxParts, np, 1, out_dev);
+}
+
+int psp_k_r_update(int n, double alpha, const double *q_dev, const double *dinv_dev, double *r_dev,
+                   double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_r_update(n, alpha, q_dev, dinv_dev, r_dev, w->partials, &np, nullptr));
+  return finish_partials(w->partials, np, 2, out_dev);
+}
+
+int psp_k_x_update(int n, double alpha, const double *p_dev, double *x_dev, double *out_dev) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_x_update(n, alpha, p_dev, x_dev, w->partials, &np, nullptr));
+  return finish_partials(w->partials + 2 * (size_t)kMaxParts, np, 1, out_dev);
 }
 
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,

@@ -69,6 +69,42 @@ class OracleBackend:
         return torch.tensor([float(np.dot(rn, rn)), float(np.dot(rn, z)), 1.0 if 1.0 + dmax != 1.0 else 0.0],
                             dtype=torch.float64)
 
+    @staticmethod
+    def _scan(alpha, pn, xn):
+        dmax = 0.0
+        with np.errstate(all="ignore"):
+            nz = xn != 0.0
+            if nz.any():
+                dmax = float(np.nanmax(np.abs(alpha * pn[nz] / xn[nz]), initial=0.0))
+            if ((~nz) & (pn != 0.0)).any():
+                dmax = max(dmax, 1.0)
+        return 1.0 if 1.0 + dmax != 1.0 else 0.0
+
+    def px_update(self, r, dinv, beta, first, alpha_x, xpend, p_owned, x):
+        pn, xn = p_owned.numpy(), x.numpy()
+        flag = 0.0
+        if xpend:
+            flag = self._scan(alpha_x, pn, xn)
+            if alpha_x != 0.0:
+                xn += alpha_x * pn
+        z = r.numpy() * dinv.numpy() if dinv is not None else r.numpy()
+        pn[:] = z if first else z + beta * pn
+        return torch.tensor([flag], dtype=torch.float64)
+
+    def r_update(self, alpha, q, dinv, r):
+        rn = r.numpy()
+        if alpha != 0.0:
+            rn += (-alpha) * q.numpy()
+        z = rn * dinv.numpy() if dinv is not None else rn
+        return torch.tensor([float(np.dot(rn, rn)), float(np.dot(rn, z))], dtype=torch.float64)
+
+    def x_update(self, alpha, p_owned, x):
+        pn, xn = p_owned.numpy(), x.numpy()
+        flag = self._scan(alpha, pn, xn)
+        if alpha != 0.0:
+            xn += alpha * pn
+        return torch.tensor([flag], dtype=torch.float64)
+
     def gather(self, idx, v, out):
         out.numpy()[:] = v.numpy()[idx.numpy()]
 

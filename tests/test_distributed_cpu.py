@@ -75,6 +75,19 @@ def _worker(rank, world, port, case, q):
             err = float(np.abs(x.numpy() - xo[lo:hi]).max() / np.abs(xo).max())
             res[name] = (ref, got, err, len(hist))
         out["pcg"] = res
+        # lazy x-update loop (default) against the eager one: every truncation point of a run that
+        # crosses its stagnation (tol = 0) gives the same (info, iter, relres, x), bit for bit
+        bl = be.from_numpy(bg[lo:hi])
+        dl = be.from_numpy(dinv_g[lo:hi])
+        same, infos = True, set()
+        for maxit in list(range(1, 60, 3)) + [400]:
+            xe, xl = be.zeros(hi - lo), be.zeros(hi - lo)
+            re_ = D._dist_pcg(A, bl, xe, 0.0, maxit, dl)
+            rl = D._dist_pcg_lazy(A, bl, xl, 0.0, maxit, dl)
+            infos.add(rl[0])
+            same = same and tuple(re_) == tuple(rl) and bool(np.array_equal(xe.numpy(), xl.numpy()))
+        out["lazy_equals_eager"] = same
+        out["lazy_infos"] = sorted(infos)
         # maxit exhausted -> iter = maxit + 1; zero rhs -> (0, 0, 0.0)
         x = be.zeros(hi - lo)
         out["maxit"] = D.dist_pcg(A, be.from_numpy(bg[lo:hi]), x, 1e-30, 3)
@@ -115,6 +128,8 @@ def test_row_partitioned_spmv_and_pcg(world, case):
             assert abs(got[2] - ref[2]) <= (1e-6 if case[0] == "poisson" else 0.1) * ref[2]
             assert err < 1e-12
             assert nhist == got[1] + 1
+        assert out["lazy_equals_eager"], out["lazy_infos"]
+        assert -1 in out["lazy_infos"] and (-5 in out["lazy_infos"] or case[0] != "poisson")
         assert tuple(out["maxit"][:2]) == (-1, 4)
         assert out["zero"] == (0, 0, 0.0, 0.0)
     # every rank reports the same triple
