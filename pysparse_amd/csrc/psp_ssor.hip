@@ -35,6 +35,7 @@ struct psp_ssor {
   psp_sss *S = nullptr;  // borrowed; the Python object keeps the matrix alive
   int *rows_f = nullptr, *rows_b = nullptr;  // rows sorted by (level, row)
   std::vector<int> ptr_f, ptr_b;             // level l = rows[ptr[l] .. ptr[l+1])
+  int *dptr_f = nullptr, *dptr_b = nullptr;  // the same on the device (runs of small levels)
   double *temp = nullptr;                    // y (symgs) / h (ssor)
 };
 
@@ -68,66 +69,72 @@ __global__ void level_ptr_kernel(int n, const int *__restrict__ keys, int *__res
     if (i == 0 || keys[i] != keys[i - 1]) ptr[keys[i]] = i;
 }
 
-// ---- symgs_kernel, preconmodule.c:149-193 (omega == 1)
-// forward half-step, rows of one level: s = sum_{lower} va*x[j]; x[i] = (b[i] - y[i] - s)/da[i]; y[i] = s
-__global__ void symgs_fwd_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
-                                 const int *__restrict__ col, const double *__restrict__ val,
-                                 const double *__restrict__ da, const double *__restrict__ b, double *x,
-                                 double *y) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cnt) return;
-  const int i = rows[t];
-  double s = 0.0;
-  for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s += val[k] * x[col[k]];
-  x[i] = (b[i] - y[i] - s) / da[i];
-  y[i] = s;
+// ---- one row of each sweep (KIND 0: symgs forward, 1: symgs backward, 2: ssor forward, 3: ssor backward)
+// symgs_kernel, preconmodule.c:149-193 (omega == 1):
+//   forward : s = sum_{lower} va*x[j]; x[i] = (b[i] - y[i] - s)/da[i]; y[i] = s          (:171-179)
+//   backward: x[i] holds y of the forward step ("x[k] = y[k]", :182-185), y[i] is rebuilt from the
+//             rows above in descending order, x[i] = (b[i] - x[i] - y[i]) / da[i]         (:186-193)
+// ssor_kernel, preconmodule.c:95-143 (omega != 1): temp / h as at :110-140
+template <int KIND>
+__device__ __forceinline__ void ssor_row(int i, const int *__restrict__ ind, const int *__restrict__ col,
+                                         const double *__restrict__ val, const double *__restrict__ da,
+                                         const double *__restrict__ b, double *x, double *y, double omega,
+                                         int first) {
+  if constexpr (KIND == 0) {
+    double s = 0.0;
+    for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s += val[k] * x[col[k]];
+    x[i] = (b[i] - y[i] - s) / da[i];
+    y[i] = s;
+  } else if constexpr (KIND == 1) {
+    const double yf = y[i];
+    double acc = 0.0;
+    for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc += val[k] * x[col[k]];
+    x[i] = (b[i] - yf - acc) / da[i];
+    y[i] = acc;
+  } else if constexpr (KIND == 2) {
+    const double temp = first ? omega * b[i] : (1.0 - omega) * x[i] * da[i] + y[i] + omega * b[i];
+    double s = 0.0;
+    for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s -= val[k] * x[col[k]];
+    const double hi = omega * s;
+    y[i] = hi;
+    x[i] = (temp + hi) / da[i];
+  } else {
+    const double temp = (1.0 - omega) * x[i] * da[i] + y[i] + omega * b[i];
+    double acc = 0.0;
+    for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc -= val[k] * x[col[k]];
+    const double hi = omega * acc;
+    y[i] = hi;
+    x[i] = (temp + hi) / da[i];
+  }
 }
 
-// backward half-step (:177-189): x[i] holds y of the forward step, y[i] is rebuilt from the rows
-// above in descending order, x[i] = (b[i] - x[i] - y[i]) / da[i]
-__global__ void symgs_bwd_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
-                                 const int *__restrict__ col, const double *__restrict__ val,
-                                 const double *__restrict__ da, const double *__restrict__ b, double *x,
-                                 double *y) {
+// the rows of ONE level (independent of each other)
+template <int KIND>
+__global__ void ssor_level_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
+                                  const int *__restrict__ col, const double *__restrict__ val,
+                                  const double *__restrict__ da, const double *__restrict__ b, double *x,
+                                  double *y, double omega, int first) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cnt) return;
-  const int i = rows[t];
-  const double yf = y[i];  // "x[k] = y[k]" of :178-181
-  double acc = 0.0;        // "y[k] = 0.0"
-  for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc += val[k] * x[col[k]];
-  x[i] = (b[i] - yf - acc) / da[i];
-  y[i] = acc;
+  if (t < cnt) ssor_row<KIND>(rows[t], ind, col, val, da, b, x, y, omega, first);
 }
 
-// ---- ssor_kernel, preconmodule.c:95-143 (omega != 1)
-__global__ void ssor_fwd_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
-                                const int *__restrict__ col, const double *__restrict__ val,
-                                const double *__restrict__ da, const double *__restrict__ b, double *x,
-                                double *h, double omega, int first) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cnt) return;
-  const int i = rows[t];
-  const double temp = first ? omega * b[i] : (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];  // :111-116
-  double s = 0.0;
-  for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s -= val[k] * x[col[k]];
-  const double hi = omega * s;
-  h[i] = hi;
-  x[i] = (temp + hi) / da[i];
-}
-
-__global__ void ssor_bwd_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
-                                const int *__restrict__ col, const double *__restrict__ val,
-                                const double *__restrict__ da, const double *__restrict__ b, double *x,
-                                double *h, double omega) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cnt) return;
-  const int i = rows[t];
-  const double temp = (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];  // :129-130
-  double acc = 0.0;                                                        // h[i] = 0.0, :131
-  for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc -= val[k] * x[col[k]];  // :137-140
-  const double hi = omega * acc;                                                           // :134
-  h[i] = hi;
-  x[i] = (temp + hi) / da[i];
+// a RUN of small levels [l0, l1) in one launch: a single workgroup walks them with a barrier in
+// between (stores of one level are visible to the whole workgroup after __syncthreads()).  Small
+// problems and the thin ends of big ones are launch-bound otherwise: poisson2d(100) has 199 levels
+// of at most 100 rows in each direction.
+constexpr int kSmallLevel = 256;  // measured: 2048 made poisson2d(2048) 3x slower (one CU walks 18 us levels)
+template <int KIND>
+__global__ __launch_bounds__(256) void ssor_levels_kernel(int l0, int l1, const int *__restrict__ ptr,
+                                                          const int *__restrict__ rows, const int *__restrict__ ind,
+                                                          const int *__restrict__ col, const double *__restrict__ val,
+                                                          const double *__restrict__ da, const double *__restrict__ b,
+                                                          double *x, double *y, double omega, int first) {
+  for (int l = l0; l < l1; ++l) {
+    const int a = ptr[l], e = ptr[l + 1];
+    for (int t = a + (int)threadIdx.x; t < e; t += (int)blockDim.x)
+      ssor_row<KIND>(rows[t], ind, col, val, da, b, x, y, omega, first);
+    __syncthreads();
+  }
 }
 
 // longest-path levels of the lower (dir 0) / upper (dir 1) dependency graph, rows sorted by level
@@ -207,35 +214,41 @@ done:
 
 namespace psp {
 
-int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
+template <int KIND>
+static void sweep(const psp_ssor *K, const std::vector<int> &ptr, const int *dptr, const int *rows,
+                  const double *b, double *x, double *y, int first) {
   const psp_csr *F = K->S->full;
   const double *da = K->S->diag;
+  const int nl = (int)ptr.size() - 1;
+  int l = 0;
+  while (l < nl) {
+    int e = l;  // maximal run of small levels starting at l
+    while (e < nl && ptr[e + 1] - ptr[e] <= kSmallLevel) ++e;
+    if (e - l >= 2) {
+      hipLaunchKernelGGL(ssor_levels_kernel<KIND>, dim3(1), dim3(256), 0, stream(), l, e, dptr, rows, F->ind,
+                         F->col, F->val, da, b, x, y, K->omega, first);
+      l = e;
+      continue;
+    }
+    const int a = ptr[l], cnt = ptr[l + 1] - a;
+    if (cnt > 0)
+      hipLaunchKernelGGL(ssor_level_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, stream(), cnt, rows + a,
+                         F->ind, F->col, F->val, da, b, x, y, K->omega, first);
+    ++l;
+  }
+}
+
+int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
   double *y = K->temp;
-  const int nf = (int)K->ptr_f.size() - 1, nb = (int)K->ptr_b.size() - 1;
   const bool gs = K->omega == 1.0;
   if (gs) PSP_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
   for (int step = 0; step < K->steps; ++step) {
-    for (int l = 0; l < nf; ++l) {
-      const int a = K->ptr_f[l], cnt = K->ptr_f[l + 1] - a;
-      if (cnt <= 0) continue;
-      const int grid = (cnt + 255) / 256;
-      if (gs)
-        hipLaunchKernelGGL(symgs_fwd_kernel, dim3(grid), dim3(256), 0, stream(), cnt, K->rows_f + a, F->ind,
-                           F->col, F->val, da, b, x, y);
-      else
-        hipLaunchKernelGGL(ssor_fwd_kernel, dim3(grid), dim3(256), 0, stream(), cnt, K->rows_f + a, F->ind,
-                           F->col, F->val, da, b, x, y, K->omega, step == 0 ? 1 : 0);
-    }
-    for (int l = 0; l < nb; ++l) {
-      const int a = K->ptr_b[l], cnt = K->ptr_b[l + 1] - a;
-      if (cnt <= 0) continue;
-      const int grid = (cnt + 255) / 256;
-      if (gs)
-        hipLaunchKernelGGL(symgs_bwd_kernel, dim3(grid), dim3(256), 0, stream(), cnt, K->rows_b + a, F->ind,
-                           F->col, F->val, da, b, x, y);
-      else
-        hipLaunchKernelGGL(ssor_bwd_kernel, dim3(grid), dim3(256), 0, stream(), cnt, K->rows_b + a, F->ind,
-                           F->col, F->val, da, b, x, y, K->omega);
+    if (gs) {
+      sweep<0>(K, K->ptr_f, K->dptr_f, K->rows_f, b, x, y, 0);
+      sweep<1>(K, K->ptr_b, K->dptr_b, K->rows_b, b, x, y, 0);
+    } else {
+      sweep<2>(K, K->ptr_f, K->dptr_f, K->rows_f, b, x, y, step == 0 ? 1 : 0);
+      sweep<3>(K, K->ptr_b, K->dptr_b, K->rows_b, b, x, y, 0);
     }
     PSP_LAUNCH_CHECK();
   }
@@ -261,6 +274,13 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     if (rc == PSP_OK) rc = build_schedule(S->full, 1, &K->rows_b, &K->ptr_b);
     if (rc == PSP_OK && hipMalloc((void **)&K->temp, sizeof(double) * (size_t)S->n) != hipSuccess)
       rc = fail(PSP_ENOMEM, "ssor: work vector allocation failed");
+    if (rc == PSP_OK) {
+      const size_t bf = sizeof(int) * K->ptr_f.size(), bb = sizeof(int) * K->ptr_b.size();
+      if (hipMalloc((void **)&K->dptr_f, bf) != hipSuccess || hipMalloc((void **)&K->dptr_b, bb) != hipSuccess ||
+          hipMemcpy(K->dptr_f, K->ptr_f.data(), bf, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(K->dptr_b, K->ptr_b.data(), bb, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PSP_ENOMEM, "ssor: level table allocation failed");
+    }
   } else {
     K->ptr_f.assign(1, 0);
     K->ptr_b.assign(1, 0);
@@ -277,6 +297,8 @@ int psp_ssor_destroy(psp_ssor_t *K) {
   if (!K) return PSP_OK;
   (void)hipFree(K->rows_f);
   (void)hipFree(K->rows_b);
+  (void)hipFree(K->dptr_f);
+  (void)hipFree(K->dptr_b);
   (void)hipFree(K->temp);
   delete K;
   return PSP_OK;
