@@ -64,6 +64,29 @@ inline int vec_grid(const Workspace &, long n) {
 
 // finish: out_dev[j] = sum_b partials[j*kMaxParts + b], j < nvals, b < nparts
 int finish_partials(const double *partials, int nparts, int nvals, double *out_dev);
+// its two stages separately (the solvers append their scalar recurrences to the finishing block):
+// fold_stage launches the fold when there are many partials and returns what the block reads
+int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride);
+#ifdef __HIPCC__
+// the finishing block (256 threads): thread t adds parts t, t+256, ... in order, then a fixed tree;
+// out[j] is written by thread 0 and the block is synchronised on return
+__device__ __forceinline__ void finish_block(const double *__restrict__ partials, int nparts, int nvals,
+                                             int stride, double *__restrict__ out) {
+  __shared__ double sh[256];
+  for (int j = 0; j < nvals; ++j) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * stride + b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = sh[0];
+    __syncthreads();
+  }
+}
+#endif
 // copy k scalars device -> host (synchronises the stream)
 int fetch_scalars(const double *src_dev, int k, double *dst_host);
 

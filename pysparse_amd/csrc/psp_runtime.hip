@@ -89,38 +89,38 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ in
   if (g == 0) out[(size_t)j * kFold + o] = s;
 }
 
-// one block: thread t adds parts t, t+256, ... in order, then a fixed tree
+// one block: thread t adds parts t, t+256, ... in order, then a fixed tree (finish_block, psp_internal.h)
 __global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ partials,
                                                      int nparts, int nvals, int stride,
                                                      double *__restrict__ out) {
-  __shared__ double sh[256];
-  for (int j = 0; j < nvals; ++j) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * stride + b];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[j] = sh[0];
-    __syncthreads();
-  }
+  finish_block(partials, nparts, nvals, stride, out);
 }
 
-int finish_partials(const double *partials, int nparts, int nvals, double *out_dev) {
+// first stage of a reduction over many partials: fold them to kFold values per slot; tells the
+// caller what the finishing block has to read
+int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   if (nparts > 2 * kFold) {
     hipLaunchKernelGGL(fold_kernel, dim3(kFold / 16, nvals), dim3(256), 0, stream(), partials,
                        nparts, w->folded);
     PSP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), w->folded, kFold, nvals,
-                       kFold, out_dev);
+    *src = w->folded;
+    *count = kFold;
+    *stride = kFold;
   } else {
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), partials, nparts, nvals,
-                       kMaxParts, out_dev);
+    *src = partials;
+    *count = nparts;
+    *stride = kMaxParts;
   }
+  return PSP_OK;
+}
+
+int finish_partials(const double *partials, int nparts, int nvals, double *out_dev) {
+  const double *src;
+  int count, stride;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride));
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), src, count, nvals, stride, out_dev);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

@@ -198,7 +198,7 @@ __device__ __forceinline__ void pcg_finish(PcgDev *st, int code, int iter) {
 }
 
 // after q = A p and the p.q reduction: pcg.c:117-125
-__global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
+__device__ __forceinline__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
   if (st->status) return;
   const double pq = scal[0];
   if (pq == 0.0) {
@@ -212,7 +212,7 @@ __global__ void pcg_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
 
 // after the x/r update and its reductions: pcg.c:127-162 for iteration `it`, then the head
 // of iteration it+1 (pcg.c:99-112)
-__global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
+__device__ __forceinline__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
   if (st->status) return;
   const int it = st->it;
   if (st->stag == 0) st->stag = (scal[2] == 0.0) ? 1 : 0;
@@ -241,6 +241,19 @@ __global__ void pcg_scalar_xr(PcgDev *st, const double *__restrict__ scal, doubl
     }
   }
 }
+
+// The scalar recurrences ride in the block that finishes the reduction they depend on (one launch
+// instead of finish_kernel + a one-thread kernel; the summation order is finish_block's, so the values
+// are the ones the separate kernels produced).
+enum PcgScalarOp { kOpPq = 0, kOpXr = 1, kOpLazyX = 2, kOpLazyPq = 3, kOpLazyR = 4 };
+
+template <int OP>
+__global__ __launch_bounds__(256) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                int nvals, int stride, double *__restrict__ out,
+                                                                PcgDev *st, double *__restrict__ hist);
+template <int OP>
+static int pcg_reduce_then(const double *partials, int nparts, int nvals, double *out_dev, PcgDev *st,
+                           double *hist_dev);
 
 static int pcg_async_enabled() {
   static const int on = [] {
@@ -280,11 +293,9 @@ static int pcg_enqueue_batch(psp_csr *Acsr, const double *dinv, int n, double *x
       PSP_TRY(csr_spmv_launch(Acsr, *pp, q, *pp, w->partials, &np, &st->status));
     }
     double *p = *pp;
-    PSP_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
-    hipLaunchKernelGGL(pcg_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev);
+    PSP_TRY(pcg_reduce_then<kOpPq>(w->partials, np, 1, w->scal_dev, st, nullptr));
     PSP_TRY(k_xr_update(n, 0.0, p, q, dinv, x, r, w->partials, &np, st));
-    PSP_TRY(finish_partials(w->partials, np, 3, w->scal_dev + 4));
-    hipLaunchKernelGGL(pcg_scalar_xr, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, hist_dev);
+    PSP_TRY(pcg_reduce_then<kOpXr>(w->partials, np, 3, w->scal_dev + 4, st, hist_dev));
   }
   PSP_LAUNCH_CHECK();
   return PSP_OK;
@@ -417,7 +428,7 @@ done:
 //   * when the loop runs out (k == maxit) the final pass does the scan and picks -5 or -1 (:159-165).
 // Same kernels' arithmetic, same reduction order: bitwise identical to the other loops (tested).
 
-__global__ void pcg_lazy_scalar_x(PcgDev *st, const double *__restrict__ scal) {
+__device__ __forceinline__ void pcg_lazy_scalar_x(PcgDev *st, const double *__restrict__ scal) {
   if (st->status) return;
   if (st->xpend) {  // iteration it-1: pcg.c:159-162
     const int stag = st->stag0 || scal[0] == 0.0;
@@ -435,7 +446,7 @@ __global__ void pcg_lazy_scalar_x(PcgDev *st, const double *__restrict__ scal) {
   if (st->head_beta0) pcg_finish(st, -6, st->it);  // pcg.c:109-112
 }
 
-__global__ void pcg_lazy_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
+__device__ __forceinline__ void pcg_lazy_scalar_pq(PcgDev *st, const double *__restrict__ scal) {
   if (st->status) return;
   const double pq = scal[0];
   if (pq == 0.0) {  // pcg.c:118-120 (x holds the updates through it-1)
@@ -449,7 +460,7 @@ __global__ void pcg_lazy_scalar_pq(PcgDev *st, const double *__restrict__ scal) 
   st->xpend = 1;
 }
 
-__global__ void pcg_lazy_scalar_r(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
+__device__ __forceinline__ void pcg_lazy_scalar_r(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
   if (st->status) return;
   const int it = st->it;
   const double normr = sqrt(scal[0]);
@@ -473,6 +484,34 @@ __global__ void pcg_lazy_scalar_r(PcgDev *st, const double *__restrict__ scal, d
       st->head_beta0 = beta == 0.0 ? 1 : 0;
     }
   }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                int nvals, int stride, double *__restrict__ out,
+                                                                PcgDev *st, double *__restrict__ hist) {
+  if (st->status) return;  // loop already over: nothing to reduce either
+  finish_block(src, count, nvals, stride, out);
+  if (threadIdx.x == 0) {
+    if constexpr (OP == kOpPq) pcg_scalar_pq(st, out);
+    if constexpr (OP == kOpXr) pcg_scalar_xr(st, out, hist);
+    if constexpr (OP == kOpLazyX) pcg_lazy_scalar_x(st, out);
+    if constexpr (OP == kOpLazyPq) pcg_lazy_scalar_pq(st, out);
+    if constexpr (OP == kOpLazyR) pcg_lazy_scalar_r(st, out, hist);
+  }
+}
+
+// fold (when there are many partials) + the finishing block with scalar update OP
+template <int OP>
+static int pcg_reduce_then(const double *partials, int nparts, int nvals, double *out_dev, PcgDev *st,
+                           double *hist_dev) {
+  const double *src;
+  int count, stride;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride));
+  hipLaunchKernelGGL((pcg_finish_scalar_kernel<OP>), dim3(1), dim3(256), 0, stream(), src, count, nvals, stride,
+                     out_dev, st, hist_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
 }
 
 static int pcg_lazy_enabled() {
@@ -529,14 +568,11 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
     const int batch = std::max(1, std::min(kBatch, maxit - enqueued));
     for (int i = 0; i < batch; ++i) {
       PCG_TRY(k_px_update(n, r, dinv, p, x, w->partials, &np, st));
-      PCG_TRY(finish_partials(stag_parts, np, 1, w->scal_dev + 8));
-      hipLaunchKernelGGL(pcg_lazy_scalar_x, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 8);
+      PCG_TRY(pcg_reduce_then<kOpLazyX>(stag_parts, np, 1, w->scal_dev + 8, st, nullptr));
       PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
-      PCG_TRY(finish_partials(w->partials, np, 1, w->scal_dev));
-      hipLaunchKernelGGL(pcg_lazy_scalar_pq, dim3(1), dim3(1), 0, stream(), st, w->scal_dev);
+      PCG_TRY(pcg_reduce_then<kOpLazyPq>(w->partials, np, 1, w->scal_dev, st, nullptr));
       PCG_TRY(k_r_update(n, 0.0, q, dinv, r, w->partials, &np, st));
-      PCG_TRY(finish_partials(w->partials, np, 2, w->scal_dev + 4));
-      hipLaunchKernelGGL(pcg_lazy_scalar_r, dim3(1), dim3(1), 0, stream(), st, w->scal_dev + 4, hist_dev);
+      PCG_TRY(pcg_reduce_then<kOpLazyR>(w->partials, np, 2, w->scal_dev + 4, st, hist_dev));
     }
     PCG_HIP(hipGetLastError());
     enqueued += batch;
