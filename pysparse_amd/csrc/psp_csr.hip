@@ -2681,6 +2681,9 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
   if (v.w1) {
     if (v.w3) v.wpb = 4;
+    // the NT-store / NT-load / packed forms of w2 exist with 4 waves per workgroup only: the grid must
+    // be computed for that (it was computed for 8 / 16 before: half the chunks were skipped)
+    if (v.w2 && (v.full_grid || v.nt || v.layout == 1)) v.wpb = 4;
     int grid = (t->nchunks + v.wpb - 1) / v.wpb;
     const int stripe = spmv_stripe() >= 0 ? spmv_stripe() : v.stripe;
     if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);

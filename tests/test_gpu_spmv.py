@@ -60,7 +60,8 @@ def test_poisson_slab_matches_global_rows(oracle):
     assert n == nx * ny * nz
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195, 1065154, 3162306, 34619586, 68174018, 101728450])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 5, 6, 8, 16, 20, 28, 32, 36, 44, 48, 52, 60, 68, 100, 128, 129, 130, 132, 133, 134, 141, 144, 146, 149, 150, 160, 164, 165, 8322, 8326, 8334, 8386, 8390, 16578, 16579, 195, 1065154, 3162306, 34619586, 68174018, 101728450,
+                                     16594, 16610, 210, 226, 154, 170, 147, 163])
 @pytest.mark.parametrize("grid", [(100, 100, 0), (64, 64, 64), (41, 29, 13)])
 def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
     from pysparse_amd.device import DeviceCSR
@@ -77,7 +78,7 @@ def test_csr_matvec_bit_exact_poisson(oracle, grid, variant):
 
 
 @pytest.mark.parametrize("variant", [-1, 0, 1, 2, 4, 6, 16, 32, 36, 52, 68, 128, 129, 130, 132, 133, 134, 149, 150, 164, 195,
-                                     1065154, 34619586, 68174018, 101728450])
+                                     1065154, 34619586, 68174018, 101728450, 16594, 16610, 210, 226, 154, 170, 147, 163])
 @pytest.mark.parametrize("case", ["ragged", "long", "wide", "tiny", "all_empty", "one_huge_row"])
 def test_csr_matvec_bit_exact_irregular(oracle, case, variant):
     from pysparse_amd.device import DeviceCSR

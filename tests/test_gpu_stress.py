@@ -66,7 +66,7 @@ def test_random_structures_all_kernels_bit_exact(oracle, block):
         x = rng.standard_normal(n)
         y_ref = np.full(m, 7.0)
         A.matvec(x, y_ref)
-        for variant in (-1, W2, STREAM) + W3_VARIANTS:
+        for variant in (-1, W2, STREAM, 16594, 210, 147, 129, 165) + W3_VARIANTS:  # + waves-per-workgroup / layout knobs
             D.set_variant(variant)
             name = D.kernel_info()[0]
             y = np.full(m, -3.0)

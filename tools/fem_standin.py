@@ -59,6 +59,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shuffle", type=int, default=32)
     ap.add_argument("--grid", default="68,68,67")
+    ap.add_argument("--variants", default="", help="extra kernel variants to time, comma separated")
     a = ap.parse_args()
     gx, gy, gz = (int(t) for t in a.grid.split(","))
     L = lib()
@@ -70,10 +71,12 @@ def main():
     res = {"n": n, "nnz_lower": nl, "nnz_per_row_full": (2 * nl + n) / n, "shuffle": a.shuffle,
            "w3_nb_cap": os.environ.get("PSP_SPMV_W3_NB", "64")}
     ref = None
-    for name, variant in (("default", -1), ("w2", 16578)):
+    extra = [("v%s" % v, int(v)) for v in a.variants.split(",") if v]
+    for name, variant in [("default", -1), ("w2", 16578)] + extra:
         S.set_variant(variant)
         kern, info = S.kernel_info()
         f = lambda: S.matvec_dev(x.ptr, y.ptr)  # noqa: E731
+        y.zero()
         time_launches(f, 5)
         yh = y.download()
         if ref is None:
