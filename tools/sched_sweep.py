@@ -33,6 +33,7 @@ def main():
     yref = None
     for s in strips:
         A.set_schedule(s)
+        y.zero()  # a launch that does nothing must not pass on the previous result
         time_launches(lambda: A.matvec_dev(x.ptr, y.ptr), 2)
         yh = y.download()
         if yref is None:

@@ -33,6 +33,7 @@ ref = None
 for k, v in variants.items():
     S.set_variant(v)
     names[k] = S.kernel_info()[0]
+    y.zero()
     time_launches(lambda: S.matvec_dev(x.ptr, y.ptr), 2)
     yh = y.download()
     if ref is None:

@@ -40,6 +40,7 @@ for name, variant in (("default", -1), ("w3", (1 << 20) + 16578), ("w2", 16578))
     A.set_variant(variant)
     kern, info = A.kernel_info()
     f = lambda: A.matvec_dev(x.ptr, y.ptr)  # noqa: E731
+    y.zero()
     time_launches(f, 3)
     yh = y.download()
     if ref is None:
