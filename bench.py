@@ -1,85 +1,139 @@
 #!/usr/bin/env python3
 """bench.py -- CSR SpMV GB/s (% of HBM peak) + Jacobi-PCG iterations/s, 7-pt Poisson, fp64.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
 
-A "step" is one y = A x with the full CSR operator already resident in HBM (N > 1: one
-ghost exchange of x over RCCL + the local SpMV of every rank).  W untimed warm-up steps,
-then exactly K steps between barrier + synchronize on both sides; MAX over ranks; rank 0
-prints ONE JSON line.  value = algorithmic bytes of all ranks / that time, where the
-algorithmic bytes of one SpMV are 12*nnz + 20*n + 4.
+N > 1 without a torch.distributed environment: bench.py starts its own ranks (a fresh
+`python -m torch.distributed.run --nproc-per-node N` child, before anything touches the GPU)
+and relays rank 0's JSON line; started under torch.distributed.run it is one rank of N.
 
-  N = 1   : 512^3 grid (BASELINE.json configs[2]): n = 134 217 728, nnz = 937 951 232
-  N >= 2  : 1024 x 1024 x (128*N) grid split into z-slabs of 128 planes = 2^27 rows per GPU
-            (N = 8 is the 1024^3 problem of configs[3]); weak scaling.
+A "step" is one y = A x with the operator resident in HBM (N > 1: one ghost exchange of x over
+RCCL + the local SpMV of every rank).  W untimed warm-up steps, then exactly K steps between
+barrier + synchronize on both sides; MAX over ranks; rank 0 prints ONE JSON line.
 
-Beside it (not part of `value`): Jacobi-PCG iterations/s on the same operator (b = A*ones,
-x0 = 0, fixed iteration count), the live HIP-event average of the SpMV kernel for the
-`roofline` object, and -- rank 0, N = 1 only -- the CPU oracle (oracle/, single thread,
-the reference's algorithm) timed on a bounded sample for the `cpu_baseline` object.
+  N = 1 (default)      512^3 grid (BASELINE.json configs[2]); beside it the 1024^3 operator on the
+                       same GPU (PCG iterations/s: the 1-GPU end of the strong-scaling target)
+  N > 1 (default)      --scaling strong: the fixed 1024^3 grid (configs[3]) cut into z-slabs of
+                       1024/N planes, index-free slab operator (per-rank nnz exceeds 32 bits at
+                       N = 2); rank 0 first times the whole 1024^3 problem alone (`strong_n1`)
+  --scaling weak       1024 x 1024 x 128 N grid, 2^27 rows per GPU (N = 8: the same 1024^3 problem)
+  --gpus 1 --scaling strong   the 1024^3 problem through the multi-GPU driver at world size 1
+
+`value` = bytes the SpMV kernel that ran HAS TO MOVE (its own matrix format + x once + y once,
+DESIGN.md section 3) / time, so no fraction of the 8 TB/s peak can exceed 1; the rate in CSR-model
+bytes (12 nnz + 20 n + 4) is printed beside it as `effective_csr_model_GBps`.
 """
-import argparse
-import ctypes as C
-import json
 import os
-import sys
-import time
 
-import numpy as np
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # cpu_baseline legs: ONE core, also inside OpenBLAS
+
+import argparse  # noqa: E402
+import ctypes as C  # noqa: E402
+import json  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3-6.8 achievable)
 W3_VARIANT = (1 << 20) + 128 + 64 + 2 + (64 << 8)  # csr_spmv_w3 (general banded CSR), see psp_csr.hip
+W2_VARIANT = 128 + 64 + 2 + (64 << 8)              # csr_spmv_w2 (int32 col + fp64 val streamed as stored)
+PMC_FILES = {"csr_spmv_w4": "r2_spmv_pmc.json", "csr_spmv_w3": "r2_spmv_w3_pmc.json",
+             "csr_spmv_w2": "r2_spmv_w2_pmc.json"}
 
 
-def dram_model_bytes(kernel, info, n, nnz):
-    """distinct bytes one launch has to move from/to DRAM: x and y once,
-    plus the matrix stream of the kernel that ran"""
+def csr_model_bytes(n, nnz):
+    """val 8 + col 4 per nonzero; ind 4 + y 8 + x 8 per row."""
+    return 12 * nnz + 20 * n + 4
+
+
+def kernel_bytes(kernel, info, n, nnz, nnz_lower=None):
+    """Bytes one launch of `kernel` has to move from/to DRAM: x and y once + the matrix in the
+    format that kernel streams.  Never more than the CSR model."""
     if kernel == "csr_spmv_w4":   # values in padded offset-major blocks of 128 rows + 16-bit row masks
         rows = (n + 127) // 128 * 128
         return 8 * rows * info["nb"] + 2 * n + 16 * n
+    if kernel == "sss_spmv_w4":   # strict lower triangle (offset-major), diagonal, 16-bit masks
+        rows = (n + 127) // 128 * 128
+        return 8 * rows * info["nb"] + 8 * n + 2 * n + 16 * n
     if kernel == "csr_spmv_w3":   # val 8 + col16 2 per nonzero; per chunk of ~1016 nonzeros: block list + row offsets
         chunks = nnz / 1016.0
         return int(10 * nnz * (1024 / 1016.0) + chunks * (4 * info["nb"] + 2 * 256 + 16) + 16 * n)
-    return 12 * nnz + 20 * n + 4
+    return csr_model_bytes(n, nnz)
 
 
-def spmv_bytes(n, nnz):
-    return 12 * nnz + 20 * n + 4
-
-
-def pcg_bytes(n, nnz):
-    return 12 * nnz + 108 * n  # fused lower bound per iteration
+def pcg_vector_bytes(n, lazy, const_dinv=True):
+    """vector traffic of one fused Jacobi-PCG iteration beside the SpMV:
+    lazy: px_update (r, p, x read; p, x written) + r_update (q, r read; r written) = 64 n;
+    eager: pupdate 24 n + x_update 24 n + r_update 24 n; + 16 n when dinv is streamed (twice)."""
+    return (64 if lazy else 72) * n + (0 if const_dinv else 16 * n)
 
 
 class Events:
     """HIP events on the library's stream (the stream the kernels are launched on)."""
 
-    def __init__(self, L, check):
+    def __init__(self, L, check, count=2):
         self.L, self.check = L, check
-        self.e0, self.e1 = C.c_void_p(), C.c_void_p()
-        check(L.psp_event_create(C.byref(self.e0)))
-        check(L.psp_event_create(C.byref(self.e1)))
+        self.ev = []
+        for _ in range(count):
+            e = C.c_void_p()
+            check(L.psp_event_create(C.byref(e)))
+            self.ev.append(e)
 
-    def start(self):
-        self.check(self.L.psp_event_record(self.e0))
+    def record(self, i):
+        self.check(self.L.psp_event_record(self.ev[i]))
 
-    def stop_ms(self):
-        self.check(self.L.psp_event_record(self.e1))
+    def ms(self, i, j):
         ms = C.c_float()
-        self.check(self.L.psp_event_elapsed_ms(self.e0, self.e1, C.byref(ms)))
+        self.check(self.L.psp_event_elapsed_ms(self.ev[i], self.ev[j], C.byref(ms)))
         return float(ms.value)
 
 
-def cpu_baseline(sample_n=256, spmv_reps=5, pcg_iters=10):
-    """The oracle (C restatement of csr_mat.c:49-54 + pcg.c, gcc -O2, ONE thread) on a
-    bounded sample: 7-pt Poisson sample_n^3 (same stencil, same bytes per row)."""
-    from oracle import oracle as O
-    t0 = time.time()
-    A = O.poisson_csr(sample_n, sample_n, sample_n)
+def timed_launches(step, sync, ev, count):
+    """count launches, one event between each: (average ms, median ms) per launch"""
+    sync()
+    for i in range(count):
+        ev.record(i)
+        step()
+    ev.record(count)
+    sync()
+    per = [ev.ms(i, i + 1) for i in range(count)]
+    return ev.ms(0, count) / count, float(np.median(per))
+
+
+# ------------------------------------------------------------------------------------ CPU legs
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref):
+    """oracle (C restatement of csr_mat.c:49-54 + pcg.c, gcc -O2, ONE thread) and, when it was built,
+    the compiled reference PCG (oracle/_ref/libref_pcg.so = examples/poisson_test/pcg.c unmodified)"""
+    t0 = time.perf_counter()
+    A = O.poisson_csr(*grid)
+    gen_s = time.perf_counter() - t0
     n, nnz = A.shape[0], A.nnz
     x = np.random.default_rng(0).standard_normal(n)
     y = np.empty(n)
@@ -92,51 +146,192 @@ def cpu_baseline(sample_n=256, spmv_reps=5, pcg_iters=10):
     t_spmv = float(np.median(ts))
     b = np.empty(n)
     A.matvec(np.ones(n), b)
-    dinv = O.jacobi_dinv(A.diagonal())
+    dinv = np.full(n, 1.0 / (6.0 if grid[2] else 4.0))  # jacobi(A, 1.0, 1) of the constant diagonal
     xs = np.zeros(n)
     t = time.perf_counter()
     O.pcg(A, b, xs, 0.0, pcg_iters, dinv)
     t_pcg = (time.perf_counter() - t) / (pcg_iters + 1)  # + the initial residual SpMV
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {
-        "value": spmv_bytes(n, nnz) / t_spmv / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-        "sample": "7-pt Poisson %d^3 (n=%d, nnz=%d): median of %d SpMV; %d Jacobi-PCG iterations"
-                  % (sample_n, n, nnz, spmv_reps, pcg_iters),
-        "pcg_iters_per_s": 1.0 / t_pcg, "host_cpu": model, "host_nproc": os.cpu_count(),
+    out = {"n": n, "nnz": nnz, "spmv_GBps": csr_model_bytes(n, nnz) / t_spmv / 1e9, "spmv_ms": t_spmv * 1e3,
+           "pcg_iters_per_s": 1.0 / t_pcg, "generate_s": gen_s,
+           "sample": "median of %d SpMV; %d Jacobi-PCG iterations (tol 0)" % (spmv_reps, pcg_iters)}
+    if with_ref and O.have_ref():
+        xr = np.zeros(n)
+        t = time.perf_counter()
+        O.ref_pcg(A, b, xr, 0.0, pcg_iters, dinv)
+        out["reference_pcg_iters_per_s"] = (pcg_iters + 1) / (time.perf_counter() - t)
+        out["reference_pcg_matches_port"] = bool(np.abs(xr - xs).max() <= 1e-12 * max(np.abs(xs).max(), 1e-300))
+    return out
+
+
+def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256)):
+    """`cpu_baseline` (kind "port": the oracle's SpMV -- the reference's csr_mat.c needs the Python-2
+    C API and cannot be compiled) and `cpu_baseline_reference_pcg` (kind "reference": the reference's
+    own pcg.c, compiled unmodified, driven by the oracle's CSR matvec callback).  Sizes: C2 (4096^2)
+    always; C3 (512^3, 14 GB of matrix) when host memory and the time budget allow, else 256^3."""
+    from oracle import oracle as O
+    t0 = time.time()
+    c2 = _cpu_case(O, c2_grid, 10, 10, True)
+    # C3 costs ~11x C2's generation + ~10x its per-pass time
+    predicted = 11.2 * c2["generate_s"] + 10.5 * (5 * c2["spmv_ms"] * 1e-3 + 2 * 5 / c2["pcg_iters_per_s"])
+    big = _mem_available_gb() > 48 and predicted < budget_s
+    grid3 = c3_grid if big else c3_small
+    c3 = _cpu_case(O, grid3, 3 if big else 5, 3 if big else 10, True)
+    model, nproc = _cpu_model(), os.cpu_count()
+    head = c3 if big else c2
+    base = {
+        "value": head["spmv_GBps"], "unit": "GB/s", "cores": 1, "kind": "port",
+        "sample": "CSR SpMV, 7-pt Poisson %d^3 (n=%d, nnz=%d): %s; C2 and C3 below"
+                  % (grid3[0], c3["n"], c3["nnz"], c3["sample"]) if big else
+                  "CSR SpMV, 5-pt Poisson %d^2 (n=%d, nnz=%d): %s; %d^3 skipped (host memory / time budget), "
+                  "%d^3 below" % (c2_grid[0], c2["n"], c2["nnz"], c2["sample"], c3_grid[0], c3_small[0]),
+        "pcg_iters_per_s": head["pcg_iters_per_s"], "host_cpu": model, "host_nproc": nproc,
+        "C2_poisson2d_%d" % c2_grid[0]: c2, ("C3_poisson3d_%d" % c3_grid[0] if big else "poisson3d_%d" % c3_small[0]): c3,
         "seconds": time.time() - t0,
     }
+    ref = None
+    if "reference_pcg_iters_per_s" in head:
+        ref = {"value": head["reference_pcg_iters_per_s"], "unit": "PCG iterations/s", "cores": 1,
+               "kind": "reference",
+               "sample": "examples/poisson_test/pcg.c compiled unmodified (oracle/_ref/libref_pcg.so, BLAS-1 from "
+                         "OpenBLAS with 1 thread), Jacobi-PCG on %s, %s" % (
+                             "7-pt Poisson %d^3" % c3_grid[0] if big else "5-pt Poisson %d^2" % c2_grid[0], head["sample"]),
+               "C2_poisson2d_%d" % c2_grid[0]: c2.get("reference_pcg_iters_per_s"),
+               ("C3_poisson3d_%d" % c3_grid[0] if big else "poisson3d_%d" % c3_small[0]): c3.get("reference_pcg_iters_per_s"),
+               "iterates_match_port_1e-12": bool(c2.get("reference_pcg_matches_port")
+                                                 and c3.get("reference_pcg_matches_port"))}
+    return base, ref
+
+
+def gpu_clocks():
+    """rocm-smi, called while ~1 s of SpMV launches is in flight: which clock / power state the numbers
+    of this run come from (runs land in a faster and a slower mode per box)."""
+    try:
+        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        txt = p.stdout.strip()
+        try:
+            d = json.loads(txt)
+            card = d.get("card0", d)
+            keep = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+                    keep[k] = v
+            return keep or {"raw": txt[:400]}
+        except ValueError:
+            return {"raw": txt[:400] or p.stderr.strip()[:400]}
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"error": str(e)[:200]}
+
+
+# ------------------------------------------------------------------------------------ launcher
+
+def self_launch(argv, n):
+    """N > 1 called as a plain script: start N fresh ranks BEFORE this process touches the GPU or
+    imports torch, relay their output, exit with their code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def pcg_single(L, check, dev, A, n, iters, sync):
+    """Jacobi-PCG through the library's device-resident loop: b = A*ones, x0 = 0, tol = 0 (exactly
+    `iters` iterations; ||b|| and r = b - A x0 are inside the timed region)."""
+    K = dev.DeviceJacobi(A)
+    aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
+    bb, xb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+    ones = np.ones(1 << 24)
+    for k in range(0, n, ones.size):  # chunked: n may be 2^30
+        check(L.psp_memcpy_h2d(xb.ptr + 8 * k, ones.ctypes.data, 8 * min(ones.size, n - k)))
+    A.matvec_dev(xb.ptr, bb.ptr)
+    sync()
+    for kk in (2, iters):  # first call = warm-up
+        xb.zero()
+        info, it, rr = C.c_int(), C.c_int(), C.c_double()
+        sync()
+        t = time.perf_counter()
+        check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it),
+                            C.byref(rr), None))
+        sync()
+        dt = time.perf_counter() - t
+    del aop, kop, K
+    bb.free()
+    xb.free()
+    return dt / iters, (info.value, it.value, rr.value)
+
+
+def strong_n1_leg(L, check, dev, grid, iters):
+    """the whole strong-scaling problem on ONE GPU (index-free operator, psp_csr_poisson_big): SpMV
+    time and Jacobi-PCG iterations/s -- the denominator of `vs_n1`"""
+    def sync():
+        check(L.psp_synchronize())
+    nx, ny, nz = grid
+    A = dev.DeviceCSR.poisson_big(nx, ny, nz)
+    n, nnz = A.shape[0], A.nnz
+    x, y = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+    chunk = np.random.default_rng(0).standard_normal(1 << 24)
+    for k in range(0, n, chunk.size):
+        check(L.psp_memcpy_h2d(x.ptr + 8 * k, chunk.ctypes.data, 8 * min(chunk.size, n - k)))
+    ev = Events(L, check, 12)
+    timed_launches(lambda: A.matvec_dev(x.ptr, y.ptr), sync, ev, 3)
+    avg, med = timed_launches(lambda: A.matvec_dev(x.ptr, y.ptr), sync, ev, 10)
+    kern, info = A.kernel_info()
+    x.free()
+    y.free()
+    s_per_it, chk = pcg_single(L, check, dev, A, n, iters, sync)
+    kb = kernel_bytes(kern, info, n, nnz)
+    out = {"grid": [nx, ny, nz], "n": n, "nnz": nnz, "kernel": kern, "spmv_ms": med,
+           "spmv_GBps": kb / (med * 1e-3) / 1e9, "spmv_frac_of_peak": kb / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "pcg_iters_per_s": 1.0 / s_per_it, "pcg_check": {"info": chk[0], "iter": chk[1], "relres": chk[2]},
+           "path": "psp_pcg_dev (single-GPU device-resident loop)"}
+    A.close()
+    check(L.psp_trim())
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--pcg-iters", type=int, default=40)
+    ap.add_argument("--pcg-iters", type=int, default=100)
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="auto: N = 1 -> the 512^3 single-GPU workload, N > 1 -> strong (fixed 1024^3)")
     ap.add_argument("--grid", default="", help="override the grid, e.g. 256,256,256 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sss", action="store_true", help="skip the sss_mat leg (N = 1)")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the w3 / w2 legs on the same operator (N = 1)")
+    ap.add_argument("--no-strong-n1", action="store_true", help="skip the one-GPU 1024^3 leg")
+    ap.add_argument("--no-clocks", action="store_true")
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--test-backend", default="",
+                    help="module:factory returning (backend, make_local) -- CPU dry run of the launcher and the "
+                         "row-range driver over gloo (tests/); the line it prints is marked dry_run, not a measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed driver even at world size 1 (plumbing check)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], a.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
 
-    use_dist = world > 1 or a.force_dist
+    scaling = a.scaling
+    if scaling == "auto":
+        scaling = "strong" if world > 1 else "single"
+    use_dist = world > 1 or a.force_dist or scaling != "single"
+    if a.test_backend:
+        use_dist = True
     if use_dist or os.environ.get("PSP_IMPORT_TORCH"):
         # torch first: its bundled HIP runtime must be the one libpysparse_hip.so binds to --
         # two HIP runtimes in one process do not both see the GPU (INTEGRATION.md)
@@ -147,40 +342,66 @@ def main():
 
     if a.grid:
         nx, ny, nz = (int(t) for t in a.grid.split(","))
-    elif world == 1:
+    elif scaling == "single":
         nx = ny = nz = 512
+    elif scaling == "strong":
+        nx = ny = nz = 1024
     else:
         nx = ny = 1024
         nz = 128 * world
 
+    strong_n1 = None
+    dry = bool(a.test_backend)
     if use_dist:
         from pysparse_amd import distributed as D
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        be = D.HipBackend(local_rank)
+        if dry:
+            import importlib
+            mod, fn = a.test_backend.split(":")
+            dist.init_process_group("gloo")
+            be, make_local = getattr(importlib.import_module(mod), fn)()
+            dev_sync = lambda: None  # noqa: E731
+        else:
+            torch.cuda.set_device(local_rank)
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(a.backend)
+            be = D.HipBackend(local_rank)
+            make_local = dev.DeviceCSR.poisson_big_slab if scaling == "strong" else dev.DeviceCSR.poisson_slab
+            dev_sync = torch.cuda.synchronize
         comm = D.Comm()
-        A = D.DistCSR.poisson(nx, ny, nz, comm, be, dev.DeviceCSR.poisson_slab)
-        A.A.set_variant(a.variant)
-        n_loc, nnz_loc = A.A.shape[0], A.A.nnz
+        if scaling == "strong" and world > 1 and rank == 0 and not a.no_strong_n1 and not dry:
+            # the 1-GPU end of the strong-scaling ratio, measured in this job on rank 0's GPU
+            strong_n1 = strong_n1_leg(L, check, dev, (nx, ny, nz), min(a.pcg_iters, 24))
+        comm.barrier()
+        A = D.DistCSR.poisson(nx, ny, nz, comm, be, make_local)
+        Aloc = A.A
+        if not dry:
+            Aloc.set_variant(a.variant)
+        n_loc, nnz_loc = Aloc.shape[0], Aloc.nnz
         x_ext = A.new_ext()
-        A.owned(x_ext).copy_(be.from_numpy(np.random.default_rng(rank).standard_normal(n_loc)))
+        A.owned(x_ext).copy_(be.from_numpy(np.random.default_rng(rank).standard_normal(n_loc))
+                             if n_loc <= (1 << 24) else
+                             torch.randn(n_loc, dtype=torch.float64, device=x_ext.device,
+                                         generator=torch.Generator(device=x_ext.device).manual_seed(rank)))
         y = be.zeros(n_loc)
 
         def step():
             A.matvec(x_ext, y)
 
         def sync():
-            torch.cuda.synchronize()
+            dev_sync()
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
     else:
         check(L.psp_set_device(local_rank))
         A = dev.DeviceCSR.poisson(nx, ny, nz)
         A.set_variant(a.variant)
+        Aloc = A
         n_loc, nnz_loc = A.shape[0], A.nnz
         xb = dev.DeviceBuffer.from_host(np.random.default_rng(0).standard_normal(n_loc))
         yb = dev.DeviceBuffer(n_loc)
@@ -191,48 +412,68 @@ def main():
         def sync():
             check(L.psp_synchronize())
 
-    ev = Events(L, check)
+    # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize
+    ev = None if dry else Events(L, check, a.steps + 1)
     for _ in range(a.warmup):
         step()
     sync()
     t0 = time.perf_counter()
-    ev.start()
+    if ev:
+        ev.record(0)
     for _ in range(a.steps):
         step()
-    ev_ms = ev.stop_ms()
+    if ev:
+        ev.record(1)
     sync()
     wall = time.perf_counter() - t0
+    if dry:
+        ev_ms = med_ms = wall * 1e3
+        kernel, kinfo = "test-backend", {}
+    else:
+        ev_ms = ev.ms(0, 1)
+        # per-launch median of the same K launches (SURVEY 8d protocol), outside the timed region
+        _, med_ms = timed_launches(step, sync, ev, a.steps)
+        kernel, kinfo = Aloc.kernel_info()
+    kbytes_loc = kernel_bytes(kernel, kinfo, n_loc, nnz_loc)
 
-    # ---- beside it (N = 1): the general-CSR kernel on the same operator.  The default kernel for
-    # a stencil operator (csr_spmv_w4) reads no column indices at all, so its rate in CSR-model
-    # bytes can exceed the HBM line; csr_spmv_w3 is what an arbitrary banded csr_mat gets.
-    general = None
-    if not use_dist and a.variant < 0:
-        kern0, info0 = A.kernel_info()
-        if kern0 == "csr_spmv_w4":
-            A.set_variant(W3_VARIANT)
-            for _ in range(3):
-                step()
-            sync()
-            ev.start()
-            for _ in range(a.steps):
-                step()
-            g_ms = ev.stop_ms() / a.steps
-            sync()
-            general = {"kernel": A.kernel_info()[0], "avg_launch_ms": g_ms,
-                       "achieved": spmv_bytes(n_loc, nnz_loc) / (g_ms * 1e-3) / 1e9}
-            general["frac"] = general["achieved"] / HBM_PEAK_GBPS
-            A.set_variant(-1)
+    # ---- beside it (N = 1): the other SpMV kernels on the SAME operator.  csr_spmv_w4 (default for a
+    # stencil operator) reads no column indices; csr_spmv_w3 is what an arbitrary banded csr_mat gets
+    # (16-bit chunk-local columns); csr_spmv_w2 streams int32 col + fp64 val exactly as stored.
+    kernels = None
+    if not use_dist and a.variant < 0 and not a.no_kernels:
+        kernels = []
+        for var in (W3_VARIANT, W2_VARIANT):
+            A.set_variant(var)
+            kn, ki = A.kernel_info()
+            timed_launches(step, sync, ev, 3)
+            avg, med = timed_launches(step, sync, ev, a.steps)
+            own = kernel_bytes(kn, ki, n_loc, nnz_loc)
+            kernels.append({"kernel": kn, "avg_launch_ms": avg, "median_launch_ms": med,
+                            "bytes_per_launch": own, "GBps": own / (avg * 1e-3) / 1e9,
+                            "frac": own / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "csr_model_GBps": csr_model_bytes(n_loc, nnz_loc) / (avg * 1e-3) / 1e9,
+                            "csr_model_frac": csr_model_bytes(n_loc, nnz_loc) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+        A.set_variant(-1)
 
-    # ---- Jacobi-PCG iterations/s on the same operator (b = A*ones, x0 = 0, tol = 0 so that
-    # exactly k iterations run; the setup -- ||b||, r = b - A x0 -- is inside the timed
-    # region, i.e. the rate is slightly conservative)
+    clocks = None
+    if not a.no_clocks and not dry:
+        # every rank keeps its GPU busy for ~1 s (N > 1: the steps exchange halos, so all ranks take part);
+        # rank 0 reads the clocks meanwhile
+        for _ in range(600):
+            step()
+        if rank == 0:
+            clocks = gpu_clocks()
+        sync()
+
+    # ---- Jacobi-PCG iterations/s on the same operator (b = A*ones, x0 = 0, tol = 0 so that exactly k
+    # iterations run; the setup -- ||b||, r = b - A x0 -- is inside the timed region)
     k = a.pcg_iters
     if use_dist:
         ones = A.new_ext()
         ones.fill_(1.0)
         b = be.zeros(n_loc)
         A.matvec(ones, b)
+        del ones
         dinv = be.zeros(n_loc)
         dinv.fill_(1.0 / (6.0 if nz > 0 else 4.0))  # constant diagonal of the Poisson operator
         for kk in (2, k):  # first call = warm-up
@@ -242,118 +483,131 @@ def main():
             res = D.dist_pcg(A, b, xs, 0.0, kk, dinv)
             sync()
             pcg_t = time.perf_counter() - t
+        pcg_s_per_iter = pcg_t / k
+        pcg_path = "pysparse_amd.distributed.dist_pcg (row-range driver, %s)" % D.dist_pcg_mode()
     else:
-        K = dev.DeviceJacobi(A)
-        aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
-        bb = dev.DeviceBuffer(n_loc)
-        ones_b = dev.DeviceBuffer.from_host(np.ones(n_loc))  # must outlive the asynchronous launch
-        A.matvec_dev(ones_b.ptr, bb.ptr)
-        sync()
-        for kk in (2, k):
-            xb.zero()
-            info, it, rr = C.c_int(), C.c_int(), C.c_double()
-            sync()
-            t = time.perf_counter()
-            check(L.psp_pcg_dev(aop._h, kop._h, n_loc, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it),
-                                C.byref(rr), None))
-            sync()
-            pcg_t = time.perf_counter() - t
-            res = (info.value, it.value, rr.value)
-    pcg_s_per_iter = pcg_t / k
+        pcg_s_per_iter, res = pcg_single(L, check, dev, A, n_loc, k, sync)
+        pcg_path = "psp_pcg_dev (single-GPU device-resident loop)"
 
     # ---- beside it (N = 1): the same operator as an sss_mat (examples/poisson_test.py solves with
     # S = L.to_sss()): y = S x from the strict lower triangle only, and Jacobi-PCG on it
     sss = None
     if not use_dist and not a.no_sss:
         S = dev.DeviceSSS.poisson(nx, ny, nz)
-        for _ in range(3):
+
+        def sstep():
             S.matvec_dev(xb.ptr, yb.ptr)
-        sync()
-        ev.start()
-        for _ in range(a.steps):
-            S.matvec_dev(xb.ptr, yb.ptr)
-        s_ms = ev.stop_ms() / a.steps
-        sync()
+        timed_launches(sstep, sync, ev, 3)
+        s_avg, s_med = timed_launches(sstep, sync, ev, a.steps)
         nnz_lower = S.nnz - n_loc
-        KS = dev.DeviceJacobi(S)
-        sop, ksop = dev._Op(S, "matvec"), dev._Op(KS, "precon")
-        for kk in (2, k):
-            xb.zero()
-            info, it, rr = C.c_int(), C.c_int(), C.c_double()
-            sync()
-            t = time.perf_counter()
-            check(L.psp_pcg_dev(sop._h, ksop._h, n_loc, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it),
-                                C.byref(rr), None))
-            sync()
-            s_pcg_t = time.perf_counter() - t
-        sss = {"kernel": S.kernel_info()[0], "spmv_ms": s_ms,
-               # B_sss = 12 nnz_lower + 28 n + 4
-               "spmv_GBps_sss_model": (12 * nnz_lower + 28 * n_loc + 4) / (s_ms * 1e-3) / 1e9,
-               "pcg_iters_per_s": k / s_pcg_t, "pcg_check": {"info": info.value, "iter": it.value, "relres": rr.value}}
-        sss["frac_sss_model"] = sss["spmv_GBps_sss_model"] / HBM_PEAK_GBPS
-        del S, KS, sop, ksop
+        s_per_it, s_chk = pcg_single(L, check, dev, S, n_loc, k, sync)
+        skern, sinfo = S.kernel_info()
+        sown = kernel_bytes(skern, sinfo, n_loc, 2 * nnz_lower + n_loc, nnz_lower)
+        sss = {"kernel": skern, "spmv_ms": s_avg, "median_launch_ms": s_med,
+               # B_sss = 12 nnz_lower + 28 n + 4; the kernel's own format moves `bytes_per_launch`
+               "bytes_per_launch": sown, "spmv_GBps": sown / (s_avg * 1e-3) / 1e9,
+               "frac": sown / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "sss_model_GBps": (12 * nnz_lower + 28 * n_loc + 4) / (s_avg * 1e-3) / 1e9,
+               "pcg_iters_per_s": 1.0 / s_per_it,
+               "pcg_check": {"info": s_chk[0], "iter": s_chk[1], "relres": s_chk[2]}}
+        S.close()
+        del S
+
+    # ---- N = 1 default run: the 1-GPU end of the strong-scaling target (1024^3 on this GPU)
+    if not use_dist and not a.grid and not a.no_strong_n1:
+        A.close()
+        xb.free()
+        yb.free()
+        check(L.psp_trim())
+        strong_n1 = strong_n1_leg(L, check, dev, (1024, 1024, 1024), min(k, 24))
 
     # ---- MAX over ranks
     if use_dist:
-        t = torch.tensor([wall, ev_ms, pcg_s_per_iter], dtype=torch.float64, device="cuda")
+        tdev = "cpu" if dry else "cuda"
+        t = torch.tensor([wall, ev_ms, pcg_s_per_iter, med_ms], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev_ms, pcg_s_per_iter = t.tolist()
-        tot = torch.tensor([float(n_loc), float(nnz_loc)], dtype=torch.float64, device="cuda")
+        wall, ev_ms, pcg_s_per_iter, med_ms = t.tolist()
+        tot = torch.tensor([float(n_loc), float(nnz_loc), float(kbytes_loc)], dtype=torch.float64, device=tdev)
         dist.all_reduce(tot)
-        n_tot, nnz_tot = (int(v) for v in tot.tolist())
+        n_tot, nnz_tot, kbytes_tot = (int(v) for v in tot.tolist())
     else:
-        n_tot, nnz_tot = n_loc, nnz_loc
+        n_tot, nnz_tot, kbytes_tot = n_loc, nnz_loc, kbytes_loc
 
     if rank == 0:
         ms_step = wall * 1e3 / a.steps
-        value = spmv_bytes(n_tot, nnz_tot) / (wall / a.steps) / 1e9
+        value = kbytes_tot / (wall / a.steps) / 1e9
         kern_ms = ev_ms / a.steps
-        achieved = spmv_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
-        kernel, kinfo = (A.A if use_dist else A).kernel_info()
-        # HBM traffic of one launch from the committed rocprofv3 --pmc passes of the same kernel
-        # on the same workload (tools/make_profiles.sh; counters cannot be read in-process)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_spmv_pmc.json")
-        if os.path.exists(pmc) and world == 1 and not a.grid:
+        achieved = kbytes_loc / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
+        lazy = n_loc >= (1 << 25) or use_dist
+        pcg_moved = kbytes_tot + pcg_vector_bytes(n_tot, lazy)
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(kernel, ""))
+        if os.path.isfile(pmc) and world == 1 and scaling == "single" and not a.grid:
+            # HBM-side bytes of one launch from the committed rocprofv3 --pmc passes of this kernel on this
+            # workload (tools/make_profiles.sh): counters cannot be read in-process, so this is NOT measured
+            # in this run -- `traffic_source` says where it comes from
             try:
                 rec = json.load(open(pmc))
                 if rec.get("kernel") == kernel:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/" + PMC_FILES[kernel] + " (rocprofv3 --pmc, separate run)"
             except (OSError, ValueError):
                 traffic = None
         out = {
             "metric": "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak" if scaling == "weak" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "3D Poisson 7-pt %dx%dx%d fp64 CSR (int32 indices), y = A x%s" % (
+                "workload": "3D Poisson 7-pt %dx%dx%d fp64 csr_mat (int32 indices), y = A x%s" % (
                     nx, ny, nz, "" if world == 1 else "; z-slab row partition, ghost exchange over RCCL"),
                 "n": n_tot, "nnz": nnz_tot, "rows_per_gpu": n_loc,
                 "parallelism": "1 GPU" if world == 1 else "row-range x%d" % world,
+                "scaling_mode": scaling,
             },
+            "value_basis": "bytes the kernel that ran has to move (its own matrix format + x + y once); "
+                           "effective_csr_model_GBps = the same time priced in CSR-model bytes 12 nnz + 20 n + 4",
             "pct_hbm_peak": 100.0 * value / (HBM_PEAK_GBPS * world),
+            "effective_csr_model_GBps": csr_model_bytes(n_tot, nnz_tot) / (wall / a.steps) / 1e9,
             "pcg_iters_per_s": 1.0 / pcg_s_per_iter,
-            "pcg_effective_GBps": pcg_bytes(n_tot, nnz_tot) / pcg_s_per_iter / 1e9,
-            "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k},
+            "pcg_effective_GBps": pcg_moved / pcg_s_per_iter / 1e9,
+            "pcg_pct_hbm_peak": 100.0 * pcg_moved / pcg_s_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
+            "pcg_csr_model_equiv_GBps": (12 * nnz_tot + 108 * n_tot) / pcg_s_per_iter / 1e9,
+            "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k, "path": pcg_path},
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": spmv_bytes(n_loc, nnz_loc), "avg_launch_ms": kern_ms,
-                # what the kernel that ran has to move (its own index format), and that rate
-                "dram_model_bytes_per_launch": dram_model_bytes(kernel, kinfo, n_loc, nnz_loc),
-                "dram_model_GBps": dram_model_bytes(kernel, kinfo, n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9,
-                "note": "achieved = CSR-model bytes (12 nnz + 20 n + 4) / avg launch time; "
-                        "csr_spmv_w4/w3 move fewer bytes than that model (no / 16-bit column indices)",
+                "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": kbytes_loc, "avg_launch_ms": kern_ms,
+                "median_launch_ms": med_ms,
+                "csr_model_bytes_per_launch": csr_model_bytes(n_loc, nnz_loc),
+                "csr_model_equiv_GBps": csr_model_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9,
+                "note": "achieved = bytes this kernel's format needs (csr_spmv_w4: 8 B per stored-offset slot + "
+                        "2 B row mask + x + y; no column indices) / avg launch time of the K timed launches",
             },
         }
-        if general is not None:
-            out["roofline_general_csr"] = general
+        if use_dist:
+            out["rccl_ranks"] = dist.get_world_size()  # ranks the process group actually has
+            out["backend"] = dist.get_backend()
+        if dry:
+            out["dry_run"] = "launcher / driver plumbing over gloo with " + a.test_backend + ": NOT a measurement"
+        if kernels is not None:
+            out["kernels_same_operator"] = kernels
         if sss is not None:
             out["sss_mat"] = sss
+        if strong_n1 is not None:
+            out["strong_n1"] = strong_n1
+            if use_dist and scaling == "strong" and strong_n1["grid"] == [nx, ny, nz]:
+                out["vs_n1"] = (1.0 / pcg_s_per_iter) / strong_n1["pcg_iters_per_s"]
+        if clocks is not None:
+            out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            base, ref = cpu_baseline()
+            out["cpu_baseline"] = base
+            out["cpu_baseline"]["gpu_over_cpu"] = out["effective_csr_model_GBps"] / base["value"]
+            if ref is not None:
+                out["cpu_baseline_reference_pcg"] = ref
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

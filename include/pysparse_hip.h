@@ -104,6 +104,12 @@ int psp_csr_poisson_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi,
  * matvec, jacobi, the solvers and kernel_info; there are no CSR arrays to download or transpose.
  * psp_csr_shape reports nnz = -1 when it does not fit an int: use psp_csr_nnz64. */
 int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out);
+/* Row slab [row_lo, row_hi) of the same index-free operator, columns shifted by -col_shift into a
+ * local extended vector of ncols_local entries (same meaning as psp_csr_poisson_slab): the
+ * strong-scaling legs of configs[3] at 2 and 4 GPUs hold 2^29 / 2^28 rows = 3.8e9 / 1.9e9 nonzeros
+ * per rank, beyond 32-bit CSR offsets.  psp_csr_poisson_big == slab over all rows with shift 0. */
+int psp_csr_poisson_big_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
+                             int ncols_local, psp_csr_t **out);
 int64_t psp_csr_nnz64(const psp_csr_t *A);
 int psp_csr_destroy(psp_csr_t *A);
 /* shape / nnz attributes: CSRMatType_getattr, csr_mat.c:208-231 */

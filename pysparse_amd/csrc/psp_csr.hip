@@ -969,17 +969,19 @@ __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__r
 
 // 5-/7-point Poisson operator written directly in the offset-major w4 layout (no CSR arrays):
 // offsets {-nx*ny, -nx, -1, 0, 1, nx, nx*ny} (3-D) or {-nx, -1, 0, 1, nx}; same entries, same
-// per-row order as poisson_csr_kernel
-__global__ void poisson_w4_kernel(int nx, int ny, int nz, long n, int no, double *__restrict__ valT,
-                                  unsigned short *__restrict__ mask) {
+// per-row order as poisson_csr_kernel.  Slab form: local row r is global row row_lo + r (the
+// offsets the caller puts into DiaOffs are shifted by row_lo - col_shift, nothing changes here).
+__global__ void poisson_w4_kernel(int nx, int ny, int nz, long row_lo, long nloc, int no,
+                                  double *__restrict__ valT, unsigned short *__restrict__ mask) {
   const long nxy = (long)nx * ny;
   const bool three_d = nz > 0;
   const double dg = three_d ? 6.0 : 4.0;
-  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nloc; r += (long)gridDim.x * blockDim.x) {
+    const long k = row_lo + r;
     const int i = (int)(k % nx);
     const int j = (int)((k / nx) % ny);
     const long l = k / nxy;
-    double *v = valT + (size_t)(k / kDiaRows) * no * kDiaRows + (size_t)(k % kDiaRows);
+    double *v = valT + (size_t)(r / kDiaRows) * no * kDiaRows + (size_t)(r % kDiaRows);
     unsigned m = 0;
     int b = 0;
     if (three_d) {
@@ -1000,7 +1002,7 @@ __global__ void poisson_w4_kernel(int nx, int ny, int nz, long n, int no, double
       if (l < nz - 1) { v[(size_t)b * kDiaRows] = -1.0; m |= 1u << b; }
       ++b;
     }
-    mask[k] = (unsigned short)m;
+    mask[r] = (unsigned short)m;
   }
 }
 
@@ -3102,18 +3104,30 @@ int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out) {
   return psp_csr_poisson_slab(nx, ny, nz, 0, n, 0, (int)n, out);
 }
 
-int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
+int psp_csr_poisson_big_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
+                             int ncols_local, psp_csr_t **out) {
   if (!out || nx < 2 || ny < 2 || nz < 0 || nz == 1)
     return fail(PSP_EINVAL, "psp_csr_poisson_big: grid dimensions must be >= 2 (nz = 0: 2-D)");
   const long n = (long)nx * ny * (nz > 0 ? nz : 1);
-  if (n > 0x7fffffffL - 256) return fail(PSP_EINVAL, "psp_csr_poisson_big: n exceeds 32-bit row indices");
-  PSP_TRY(ensure_device());
+  if (row_lo < 0 || row_hi > n || row_lo >= row_hi)
+    return fail(PSP_EINVAL, "psp_csr_poisson_big: bad row range");
+  const long nloc = row_hi - row_lo;
+  if (nloc > 0x7fffffffL - 256 || ncols_local < 2)
+    return fail(PSP_EINVAL, "psp_csr_poisson_big: local rows exceed 32-bit row indices");
   const bool three_d = nz > 0;
   const int no = three_d ? 7 : 5;
   const long nxy = (long)nx * ny;
+  // every local column index must land inside [0, ncols_local)
+  const long reach = three_d ? nxy : nx;
+  const long cmin = (row_lo - reach > 0 ? row_lo - reach : 0) - col_shift;
+  const long cmax = (row_hi - 1 + reach < n - 1 ? row_hi - 1 + reach : n - 1) - col_shift;
+  if (cmin < 0 || cmax >= ncols_local)
+    return fail(PSP_EINVAL, "psp_csr_poisson_big: col_shift/ncols_local do not cover the halo");
+  PSP_TRY(ensure_device());
   psp_csr *A = new psp_csr();
-  A->nrows = A->ncols = (int)n;
-  A->nnz64 = poisson_prefix(n, nx, ny, nz);
+  A->nrows = (int)nloc;
+  A->ncols = ncols_local;
+  A->nnz64 = poisson_prefix(row_hi, nx, ny, nz) - poisson_prefix(row_lo, nx, ny, nz);
   A->nnz = A->nnz64 > 0x7fffffffL ? -1 : (int)A->nnz64;
   A->max_row_nnz = no;
   A->w4_only = true;
@@ -3122,16 +3136,23 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
     std::lock_guard<std::mutex> lk(g_extra_mu);
     ex = &g_extra[A];
   }
+  // local col - local row = (global col - col_shift) - (global row - row_lo) = offset + shift
+  const long shift = row_lo - col_shift;
+  if (shift + nxy > 0x7fffffffL || shift - nxy < -0x7fffffffL) {
+    psp_csr_destroy(A);
+    return fail(PSP_EINVAL, "psp_csr_poisson_big: column shift out of range");
+  }
   int b = 0;
-  if (three_d) ex->dia_offs.o[b++] = (int)-nxy;
-  ex->dia_offs.o[b++] = -nx;
-  ex->dia_offs.o[b++] = -1;
-  ex->dia_offs.o[b++] = 0;
-  ex->dia_offs.o[b++] = 1;
-  ex->dia_offs.o[b++] = nx;
-  if (three_d) ex->dia_offs.o[b++] = (int)nxy;
+  if (three_d) ex->dia_offs.o[b++] = (int)(shift - nxy);
+  ex->dia_offs.o[b++] = (int)(shift - nx);
+  ex->dia_offs.o[b++] = (int)(shift - 1);
+  ex->dia_offs.o[b++] = (int)shift;
+  ex->dia_offs.o[b++] = (int)(shift + 1);
+  ex->dia_offs.o[b++] = (int)(shift + nx);
+  if (three_d) ex->dia_offs.o[b++] = (int)(shift + nxy);
   for (; b < kDiaMaxOffs; ++b) ex->dia_offs.o[b] = 0;
-  const size_t nblk = ((size_t)n + kDiaRows - 1) / kDiaRows;
+  A->w4_diag_slot = three_d ? 3 : 2;
+  const size_t nblk = ((size_t)nloc + kDiaRows - 1) / kDiaRows;
   const size_t nval = nblk * kDiaRows * no;
   hipError_t e1 = hipMalloc((void **)&ex->dia_val, sizeof(double) * nval);
   hipError_t e2 = hipMalloc((void **)&ex->dia_mask, sizeof(unsigned short) * (nblk * kDiaRows + 2));
@@ -3142,14 +3163,20 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
   }
   PSP_HIP(hipMemsetAsync(ex->dia_val, 0, sizeof(double) * nval, stream()));
   PSP_HIP(hipMemsetAsync(ex->dia_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
-  hipLaunchKernelGGL(poisson_w4_kernel, dim3(65536), dim3(256), 0, stream(), nx, ny, nz, n, no, ex->dia_val,
-                     ex->dia_mask);
+  hipLaunchKernelGGL(poisson_w4_kernel, dim3(65536), dim3(256), 0, stream(), nx, ny, nz, (long)row_lo, nloc, no,
+                     ex->dia_val, ex->dia_mask);
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(stream()));
   ex->dia_no = no;
   ex->dia_state = 1;
   *out = A;
   return PSP_OK;
+}
+
+int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
+  const long n = (long)nx * ny * (nz > 0 ? nz : 1);
+  if (n > 0x7fffffffL - 256) return fail(PSP_EINVAL, "psp_csr_poisson_big: n exceeds 32-bit row indices");
+  return psp_csr_poisson_big_slab(nx, ny, nz, 0, n, 0, (int)n, out);
 }
 
 int64_t psp_csr_nnz64(const psp_csr_t *A) { return A ? (A->w4_only ? A->nnz64 : (int64_t)A->nnz) : 0; }
@@ -3214,9 +3241,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
   if (A->w4_only) {
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
-    int zero_slot = -1;
-    for (int o = 0; o < ex->dia_no; ++o)
-      if (ex->dia_offs.o[o] == 0) zero_slot = o;
+    const int zero_slot = A->w4_diag_slot;  // the slot of A[r, r] (offsets are shifted on a slab)
     hipLaunchKernelGGL(dia_diag_kernel, dim3(std::min((A->nrows + 255) / 256, 65536)), dim3(256), 0, stream(),
                        A->nrows, ex->dia_no, zero_slot, ex->dia_val, ex->dia_mask, diag_dev);
     PSP_LAUNCH_CHECK();

@@ -108,6 +108,7 @@ struct psp_csr {
   // null; nnz may exceed 32 bits: nnz64 holds it, nnz is -1 then)
   bool w4_only = false;
   int64_t nnz64 = 0;
+  int w4_diag_slot = -1;  // w4_only: which offset slot holds A[r, r]
 };
 
 struct psp_sss {

@@ -105,6 +105,15 @@ class DeviceCSR:
         return A
 
     @classmethod
+    def poisson_big_slab(cls, nx, ny, nz, row_lo, row_hi, col_shift, ncols_local):
+        """row slab of the index-free operator (per-rank nnz may exceed 32 bits: 1024^3 over 2 GPUs)"""
+        h = C.c_void_p()
+        check(lib().psp_csr_poisson_big_slab(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local, C.byref(h)))
+        A = cls(h)
+        A.nnz = int(lib().psp_csr_nnz64(h))
+        return A
+
+    @classmethod
     def poisson_slab(cls, nx, ny, nz, row_lo, row_hi, col_shift, ncols_local):
         h = C.c_void_p()
         check(lib().psp_csr_poisson_slab(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local, C.byref(h)))

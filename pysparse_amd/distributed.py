@@ -372,6 +372,11 @@ class DistCSR:
         return self.be.matvec_overlap(self.A, v_ext, self.plan.p_offset, y, self.plan.interior, wait, want_dot)
 
 
+def dist_pcg_mode():
+    """which loop dist_pcg runs (bench.py prints it)"""
+    return "host scalars, lazy x update" if os.environ.get("PSP_DIST_LAZYX", "1") != "0" else "host scalars, eager"
+
+
 def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices; see
     _dist_pcg.  A dinv slice that holds one value everywhere (constant-diagonal operator) is

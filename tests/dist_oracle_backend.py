@@ -116,3 +116,8 @@ def local_poisson_from_oracle(nx, ny, nz, row_lo, row_hi, col_shift, ncols_local
     A = O.poisson_csr(nx, ny, nz)
     a, b = A.ind[row_lo], A.ind[row_hi]
     return O.CSR((row_hi - row_lo, ncols_local), A.val[a:b], A.col[a:b] - col_shift, A.ind[row_lo:row_hi + 1] - a)
+
+
+def bench_factory():
+    """bench.py --test-backend tests.dist_oracle_backend:bench_factory (dry run of the launcher over gloo)"""
+    return OracleBackend(), local_poisson_from_oracle

@@ -1,6 +1,7 @@
 """GPU: bench.py prints ONE JSON line with the driver's contract (metric / value / unit / n_gpus / steps /
 warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config) plus the
-`roofline` and `cpu_baseline` objects, on a small grid so that it runs in seconds."""
+`roofline` and `cpu_baseline` objects, on a small grid so that it runs in seconds.  No fraction of the
+HBM peak may exceed 1 by construction: every rate is bytes the kernel that ran has to move / time."""
 import json
 import os
 import subprocess
@@ -8,7 +9,6 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -20,31 +20,78 @@ def run_bench(*args):
     return json.loads(lines[0])
 
 
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+@pytest.mark.gpu
 def test_bench_json_contract_small_grid():
-    d = run_bench("--grid", "96,96,96", "--steps", "5", "--warmup", "2", "--pcg-iters", "8", "--no-cpu-baseline")
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+    d = run_bench("--grid", "96,96,96", "--steps", "5", "--warmup", "2", "--pcg-iters", "8", "--no-cpu-baseline",
+                  "--no-clocks")
+    for k in CONTRACT:
         assert k in d, k
     assert d["unit"] == "GB/s" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
     n, nnz = d["config"]["n"], d["config"]["nnz"]
     assert n == 96 ** 3 and nnz == 7 * n - 6 * 96 * 96
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["kernel"] == "csr_spmv_w4" and r["algorithmic_bytes_per_launch"] == 12 * nnz + 20 * n + 4
+    assert r["kernel"] == "csr_spmv_w4"
+    # what csr_spmv_w4 has to move: 7 offset slots of 8 B per (padded) row + 2 B mask + x + y
+    assert r["algorithmic_bytes_per_launch"] == 8 * 7 * ((n + 127) // 128 * 128) + 18 * n
+    assert r["csr_model_bytes_per_launch"] == 12 * nnz + 20 * n + 4
+    assert r["algorithmic_bytes_per_launch"] < r["csr_model_bytes_per_launch"]  # no column indices are read
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert r["dram_model_bytes_per_launch"] < r["algorithmic_bytes_per_launch"]  # no column indices are read
-    assert d["roofline_general_csr"]["kernel"] == "csr_spmv_w3"
-    assert d["sss_mat"]["kernel"] == "sss_spmv_w4"
+    # nothing is priced above the peak
+    assert r["frac"] <= 1.0 and d["pct_hbm_peak"] <= 100.0 and d["pcg_pct_hbm_peak"] <= 100.0
+    ks = {k["kernel"]: k for k in d["kernels_same_operator"]}
+    assert set(ks) == {"csr_spmv_w3", "csr_spmv_w2"}
+    assert ks["csr_spmv_w2"]["bytes_per_launch"] == 12 * nnz + 20 * n + 4  # streams the CSR arrays as stored
+    assert all(k["frac"] <= 1.0 for k in ks.values())
+    assert d["sss_mat"]["kernel"] == "sss_spmv_w4" and d["sss_mat"]["frac"] <= 1.0
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9  # tol = 0: exactly 8 iterations
     assert d["pcg_iters_per_s"] > 0 and d["value"] > 0
 
 
-def test_bench_cpu_baseline_object_small_sample(monkeypatch):
+@pytest.mark.gpu
+def test_bench_strong_path_world_size_1():
+    """--gpus 1 --scaling strong: the multi-GPU driver (index-free slab operator, RCCL process group of one rank)"""
+    d = run_bench("--gpus", "1", "--scaling", "strong", "--grid", "64,64,64", "--steps", "5", "--warmup", "2",
+                  "--pcg-iters", "8", "--no-cpu-baseline", "--no-clocks")
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["rccl_ranks"] == 1 and d["backend"] == "nccl"
+    assert d["roofline"]["kernel"] == "csr_spmv_w4" and d["roofline"]["frac"] <= 1.0
+    assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9
+
+
+def test_bench_cpu_baseline_objects_small_sample():
     sys.path.insert(0, ROOT)
     import bench
-    c = bench.cpu_baseline(sample_n=48, spmv_reps=2, pcg_iters=3)
-    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "GB/s" and c["value"] > 0
-    assert "48^3" in c["sample"] and c["pcg_iters_per_s"] > 0
+    base, ref = bench.cpu_baseline(c2_grid=(40, 40, 0), c3_grid=(24, 24, 24), c3_small=(16, 16, 16))
+    assert base["kind"] == "port" and base["cores"] == 1 and base["unit"] == "GB/s" and base["value"] > 0
+    assert base["pcg_iters_per_s"] > 0 and "C2_poisson2d_40" in base
+    if ref is not None:  # oracle/_ref is built where /root/reference exists
+        assert ref["kind"] == "reference" and ref["cores"] == 1 and ref["value"] > 0
+        assert ref["iterates_match_port_1e-12"]
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must start 2 fresh ranks by itself and
+    print ONE JSON line: launcher + row-range driver over gloo with the oracle-backed test backend."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "12,10,8",
+                          "--steps", "3", "--warmup", "1", "--pcg-iters", "5", "--no-cpu-baseline",
+                          "--test-backend", "tests.dist_oracle_backend:bench_factory"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and "dry_run" in d
+    assert d["config"]["n"] == 12 * 10 * 8 and d["config"]["rows_per_gpu"] == 12 * 10 * 4
+    assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 6

@@ -321,3 +321,54 @@ def test_fullsize_1024_cubed_on_one_gpu():
     check(L.psp_k_dot(n, b.ptr, b.ptr, out.ptr))
     n2b = np.sqrt(float(out.download()[0]))
     assert abs(rr_true / n2b - rr.value) <= 1e-10 * rr.value
+
+
+@pytest.mark.parametrize("grid,parts", [((24, 18, 12), 3), ((40, 30, 0), 4), ((33, 5, 9), 2)])
+def test_poisson_big_slab_equals_csr_slab(oracle, grid, parts):
+    """psp_csr_poisson_big_slab (index-free row slab in extended-vector coordinates: what a rank of the
+    strong-scaling runs holds) against psp_csr_poisson_slab and the oracle's global rows: same bits for
+    the product (whole and split around a halo wait), the fused dot, and the diagonal"""
+    from pysparse_amd import device as dev, distributed as D
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    nx, ny, nz = grid
+    G = oracle.poisson_csr(nx, ny, nz)
+    n = G.shape[0]
+    xg = np.random.default_rng(4).standard_normal(n)
+    yg = np.empty(n)
+    G.matvec(xg, yg)
+    for rank in range(parts):
+        plan = D.poisson_halo_plan(nx, ny, nz, parts, rank)
+        shift = plan.row_lo - plan.ghost_lo
+        A = dev.DeviceCSR.poisson_slab(nx, ny, nz, plan.row_lo, plan.row_hi, shift, plan.n_ext)
+        B = dev.DeviceCSR.poisson_big_slab(nx, ny, nz, plan.row_lo, plan.row_hi, shift, plan.n_ext)
+        assert B.shape == A.shape and B.nnz == A.nnz and B.kernel_info()[0] == "csr_spmv_w4"
+        xe = xg[shift:shift + plan.n_ext].copy()
+        ya, yb = np.empty(plan.n_owned), np.empty(plan.n_owned)
+        A.matvec(xe, ya)
+        B.matvec(xe, yb)
+        assert np.array_equal(ya, yg[plan.row_lo:plan.row_hi]) and np.array_equal(yb, ya)
+        # split product + fused dot (psp_k_csr_matvec_overlap), as the multi-GPU driver calls it
+        xd = dev.DeviceBuffer.from_host(xe)
+        yd = dev.DeviceBuffer(plan.n_owned)
+        out = dev.DeviceBuffer(2)
+        from pysparse_amd._capi import WAIT_FN
+        cb = WAIT_FN(lambda ctx: 0)
+        dots = []
+        for M in (A, B):
+            yd.zero()
+            check(L.psp_k_csr_matvec_overlap(M._h, xd.ptr, plan.p_offset, yd.ptr, plan.interior[0], plan.interior[1],
+                                             cb, None, out.ptr))
+            assert np.array_equal(yd.download(), ya)
+            dots.append(float(out.download()[0]))
+        assert dots[0] == dots[1]
+        assert abs(dots[0] - float(np.dot(xg[plan.row_lo:plan.row_hi], ya))) <= 1e-12 * abs(dots[0])
+
+
+def test_poisson_big_slab_rejects_bad_arguments():
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import PspError
+    with pytest.raises(PspError):
+        dev.DeviceCSR.poisson_big_slab(8, 8, 8, 64, 128, 64, 64 + 8)  # halo below the slab not covered
+    with pytest.raises(PspError):
+        dev.DeviceCSR.poisson_big_slab(8, 8, 8, 128, 64, 0, 512)       # empty / inverted range
