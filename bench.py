@@ -321,6 +321,12 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], a.gpus))
 
+    # ONE JSON line on stdout: RCCL / HIP print banners to file descriptor 1, so everything this process
+    # (and the libraries it loads) writes to stdout goes to stderr, and rank 0's line to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -608,7 +614,7 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = out["effective_csr_model_GBps"] / base["value"]
             if ref is not None:
                 out["cpu_baseline_reference_pcg"] = ref
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -312,8 +312,82 @@ int psp_k_x_update(int n, double alpha, const double *p_dev, double *x_dev, doub
  * out = { r.r, r.z (z = dinv.*r), nonstag } where nonstag != 0 iff 1 + dmax != 1 */
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,
                     const double *dinv_dev, double *x_dev, double *r_dev, double *out_dev);
+/* y := x .* dinv (jacobi(), preconmodule.c:41-42) on device vectors */
+int psp_k_jacobi(int n, const double *x_dev, const double *dinv_dev, double *y_dev);
 /* gather send_dev[i] = v[idx[i]] (halo packing) */
 int psp_k_gather(int count, const int *idx_dev, const double *v_dev, double *send_dev);
+
+/* ------------------------------------------ device-resident solver state for the multi-GPU driver
+ * The same loops with NO host round trip per reduction: alpha / beta / the exit tests of pcg.c:100-162
+ * (resp. the Lanczos / Givens recurrences of minres.c:129-192) live in a small device-side state; the
+ * psp_kd_* kernels read their coefficients from it and turn into no-ops once the loop has ended.  One
+ * iteration is cut at its two reductions so that an all-reduce can be issued in stream order between
+ * "finish the local partial sums" (out_dev) and "take the reference's branches on the reduced values"
+ * (psp_kd_*_scalar*).  The host enqueues a batch of iterations, then calls *_fetch once. */
+typedef struct psp_pcgstate psp_pcgstate_t;
+typedef struct {
+  int status;      /* 0 running, 1 finished */
+  int info, iter;  /* valid when finished (pend_maxit: decided by the final x update, see below) */
+  int it;          /* iteration the enqueued kernels are working on */
+  int xpend;       /* x += alpha_x p of the last finished iteration is still to be applied (psp_k_x_update) */
+  int stag0;       /* alpha == 0 in that iteration (pcg.c:124-125) */
+  int pend_maxit;  /* the loop ran out: -5 or -1 is decided by the stagnation scan of the final x update */
+  double relres, normr, n2b, alpha_x;
+} psp_pcg_status_t;
+int psp_pcgstate_create(psp_pcgstate_t **out);
+int psp_pcgstate_destroy(psp_pcgstate_t *st);
+/* state at the head of iteration 1: ||b||, tol*||b||, ||r0||, rho0 = r0.z0 (all already reduced over ranks) */
+int psp_pcgstate_init(psp_pcgstate_t *st, double n2b, double tolb, double normr0, double rho0, int maxit,
+                      int want_hist);
+int psp_pcgstate_fetch(psp_pcgstate_t *st, psp_pcg_status_t *out); /* synchronises the stream */
+int psp_pcgstate_hist(psp_pcgstate_t *st, int first, int count, double *hist_host);
+/* lazy-x arrangement, scalars from the state:
+ *   px: pending x update + scan, then p := z + beta p;  out[0] = local nonstag count
+ *   matvec_overlap: q := A p around the halo wait;       dot_out[0] = local p.q
+ *   scalar_xpq(scal = {p.q, nonstag} after the all-reduce): pcg.c:159-162 of the previous iteration,
+ *       :101-112 of this one, alpha (:117-125)
+ *   r : r -= alpha q;                                    out = local {r.r, r.z}
+ *   scalar_r(scal = {r.r, r.z} after the all-reduce): pcg.c:152-157, next rho / beta */
+int psp_kd_px_update(const psp_pcgstate_t *st, int n, const double *r_dev, const double *dinv_dev, double *p_dev,
+                     double *x_dev, double *out_dev);
+int psp_kd_csr_matvec_overlap(const psp_pcgstate_t *st, psp_csr_t *A, const double *x_dev, int x_offset,
+                              double *y_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx,
+                              double *dot_out_dev);
+int psp_kd_pcg_scalar_xpq(psp_pcgstate_t *st, const double *scal_dev);
+int psp_kd_r_update(const psp_pcgstate_t *st, int n, const double *q_dev, const double *dinv_dev, double *r_dev,
+                    double *out_dev);
+int psp_kd_pcg_scalar_r(psp_pcgstate_t *st, const double *scal_dev);
+
+typedef struct psp_minresstate psp_minresstate_t;
+typedef struct {
+  int status;  /* ended by -3 / -6 (minres.c:144-146, :160-162), or after the last w/x update */
+  int stop;    /* the loop test of minres.c:114 failed: finished once the enqueued w/x update has run */
+  int info, iter;
+  double relres;   /* written on the 0 / -1 exits only, as in the reference */
+  double norm_rmr;
+} psp_minres_status_t;
+int psp_minresstate_create(psp_minresstate_t **out);
+int psp_minresstate_destroy(psp_minresstate_t *st);
+/* state at the head of iteration 1: ||r0||, beta = sqrt(v_hat . y) (reduced over ranks), tol, maxit */
+int psp_minresstate_init(psp_minresstate_t *st, double norm_r0, double beta0, double errtol, int it_max,
+                         int want_hist);
+int psp_minresstate_fetch(psp_minresstate_t *st, psp_minres_status_t *out);
+int psp_minresstate_hist(psp_minresstate_t *st, int first, int count, double *hist_host);
+/* one iteration of minres.c:96-193 on a row block:
+ *   scale:   v := y / beta (:123-124)        matvec: Av := A v around the halo wait, dot_out = local v.Av
+ *   scalar(0, {v.Av} reduced): alpha, the Lanczos coefficients (:129-131)
+ *   lanczos: v_hat_old := Av - c1 v_hat - c2 v_hat_old (the caller swaps the names), y := dinv .* it,
+ *            out = local v_hat.y
+ *   scalar(1, {v_hat.y} reduced): beta, Givens rotation, the exits, the loop test of the next iteration
+ *   wx:      w_old := (v - r3 w_old - r2 w) / r1 (the caller swaps the names); x += c eta w (:172-180) */
+int psp_kd_minres_scale(const psp_minresstate_t *st, int n, const double *y_dev, double *v_dev);
+int psp_kd_minres_matvec(const psp_minresstate_t *st, psp_csr_t *A, const double *v_dev, int v_offset,
+                         double *av_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev);
+int psp_kd_minres_lanczos(const psp_minresstate_t *st, int n, const double *av_dev, const double *v_hat_dev,
+                          double *v_hat_old_dev, const double *dinv_dev, double *y_dev, double *out_dev);
+int psp_kd_minres_scalar(psp_minresstate_t *st, int which, const double *scal_dev);
+int psp_kd_minres_wx(const psp_minresstate_t *st, int n, const double *v_dev, const double *w_dev,
+                     double *w_old_dev, double *x_dev);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,24 @@ psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_ssor psp_op_from_
 psp_pcg psp_pcg_dev psp_minres psp_minres_dev psp_cgs psp_bicgstab psp_qmrs psp_gmres
 psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
 psp_k_csr_matvec_overlap psp_k_hint_constant psp_k_unhint psp_k_px_update psp_k_r_update psp_k_x_update
+psp_k_jacobi psp_pcgstate_create psp_pcgstate_destroy psp_pcgstate_init psp_pcgstate_fetch psp_pcgstate_hist
+psp_kd_px_update psp_kd_csr_matvec_overlap psp_kd_pcg_scalar_xpq psp_kd_r_update psp_kd_pcg_scalar_r
+psp_minresstate_create psp_minresstate_destroy psp_minresstate_init psp_minresstate_fetch psp_minresstate_hist
+psp_kd_minres_scale psp_kd_minres_matvec psp_kd_minres_lanczos psp_kd_minres_scalar psp_kd_minres_wx
 """.split()
+
+
+class PcgStatus(C.Structure):
+    """psp_pcg_status_t"""
+    _fields_ = [("status", C.c_int), ("info", C.c_int), ("iter", C.c_int), ("it", C.c_int), ("xpend", C.c_int),
+                ("stag0", C.c_int), ("pend_maxit", C.c_int), ("relres", C.c_double), ("normr", C.c_double),
+                ("n2b", C.c_double), ("alpha_x", C.c_double)]
+
+
+class MinresStatus(C.Structure):
+    """psp_minres_status_t"""
+    _fields_ = [("status", C.c_int), ("stop", C.c_int), ("info", C.c_int), ("iter", C.c_int),
+                ("relres", C.c_double), ("norm_rmr", C.c_double)]
 
 WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -124,6 +141,20 @@ def _declare(L):
         "psp_k_hint_constant": [vp, i], "psp_k_unhint": [vp],
         "psp_k_px_update": [i, vp, vp, d, i, d, i, vp, vp, vp], "psp_k_r_update": [i, d, vp, vp, vp, vp],
         "psp_k_x_update": [i, d, vp, vp, vp],
+        "psp_k_jacobi": [i, vp, vp, vp],
+        "psp_pcgstate_create": [pvp], "psp_pcgstate_destroy": [vp], "psp_pcgstate_init": [vp, d, d, d, d, i, i],
+        "psp_pcgstate_fetch": [vp, C.POINTER(PcgStatus)], "psp_pcgstate_hist": [vp, i, i, vp],
+        "psp_kd_px_update": [vp, i, vp, vp, vp, vp, vp],
+        "psp_kd_csr_matvec_overlap": [vp, vp, vp, i, vp, i, i, WAIT_FN, vp, vp],
+        "psp_kd_pcg_scalar_xpq": [vp, vp], "psp_kd_r_update": [vp, i, vp, vp, vp, vp],
+        "psp_kd_pcg_scalar_r": [vp, vp],
+        "psp_minresstate_create": [pvp], "psp_minresstate_destroy": [vp],
+        "psp_minresstate_init": [vp, d, d, d, i, i], "psp_minresstate_fetch": [vp, C.POINTER(MinresStatus)],
+        "psp_minresstate_hist": [vp, i, i, vp],
+        "psp_kd_minres_scale": [vp, i, vp, vp],
+        "psp_kd_minres_matvec": [vp, vp, vp, i, vp, i, i, WAIT_FN, vp, vp],
+        "psp_kd_minres_lanczos": [vp, i, vp, vp, vp, vp, vp, vp], "psp_kd_minres_scalar": [vp, i, vp],
+        "psp_kd_minres_wx": [vp, i, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

@@ -1022,10 +1022,11 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
     int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    int use_div, double xdiv) {
+    int use_div, double xdiv, const double *__restrict__ xdiv_dev) {
   // use_div: multiply with x ./ xdiv instead of x (MINRES: v = y / beta formed on the fly,
   // minres.c:123-124 -- the same correctly rounded division as the separate pass)
   if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
+  if (xdiv_dev) xdiv = *xdiv_dev;
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1164,8 +1165,9 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     int n, int stripe, SssOffs offs, const double *__restrict__ valL, const double *__restrict__ diag,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    int use_div, double xdiv) {
+    int use_div, double xdiv, const double *__restrict__ xdiv_dev) {
   if (skip && *skip) return;
+  if (xdiv_dev) xdiv = *xdiv_dev;
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2147,13 +2149,13 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
 // csr_spmv_w4 over row blocks [b0, b1)
 static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int b0, int b1, const double *x,
                      double *y, const double *dotv, double *pbuf, const int *skip, int grid, int use_div = 0,
-                     double xdiv = 1.0) {
+                     double xdiv = 1.0, const double *xdiv_dev = nullptr) {
   if (use_div && ex->dia_no > 16) return fail(PSP_EINVAL, "csr_spmv_w4x has no scaled form");
   const int flags = (A->variant >= 0 ? A->variant : 0) >> 23 & 3;  // A/B knobs: bit 23 plain val loads, 24 plain y stores
 #define PSP_W4_F(NO, NTL, NTS)                                                                       \
   hipLaunchKernelGGL((csr_spmv_w4<NO, NTL, NTS>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows, \
                      A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf, skip,  \
-                     use_div, xdiv)
+                     use_div, xdiv, xdiv_dev)
 #define PSP_W4(NO)                                                                                   \
   case NO:                                                                                           \
     if (flags == 0) PSP_W4_F(NO, true, true);                                                        \
@@ -2266,13 +2268,14 @@ static int ensure_sss_w4(psp_sss *S) {
 }
 
 static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *y, const double *dotv,
-                         double *pbuf, const int *skip, int grid, int use_div = 0, double xdiv = 1.0) {
+                         double *pbuf, const int *skip, int grid, int use_div = 0, double xdiv = 1.0,
+                         const double *xdiv_dev = nullptr) {
   SssOffs so;
   for (int i = 0; i < 8; ++i) so.o[i] = S->w4_offs[i];
   const int flags = (S->full->variant >= 0 ? S->full->variant : 0) >> 23 & 3;  // A/B: 1 NT lower loads (-6 %), 2 NT shifted loads (-25 %); profiles/r1_sss_spmv_w4_timing.txt
 #define PSP_SW4_F(NOL, F)                                                                            \
   hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
-                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv)
+                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv, xdiv_dev)
 #define PSP_SW4(NOL)                                                                                 \
   case NOL:                                                                                          \
     if (flags == 0) PSP_SW4_F(NOL, 0);                                                               \
@@ -2488,7 +2491,7 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
 // y = A (x ./ xdiv) and the partials of (x ./ xdiv) . y, for the two index-free layouts only
 // (MINRES: v = y / beta is never materialised); *available = 0 otherwise (nothing launched)
 int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,
-                           int *nparts, int *available) {
+                           int *nparts, int *available, const int *skip, const double *xdiv_dev) {
   *available = 0;
   static const bool on = [] {
     const char *e = getenv("PSP_MINRES_SCALED");
@@ -2521,9 +2524,9 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
     pbuf = ex->big_partials;
   }
   if (sss)
-    PSP_TRY(launch_sss_w4(A->sym_owner, stripe, x, y, x, pbuf, nullptr, grid, 1, xdiv));
+    PSP_TRY(launch_sss_w4(A->sym_owner, stripe, x, y, x, pbuf, skip, grid, 1, xdiv, xdiv_dev));
   else
-    PSP_TRY(launch_w4(A, ex, stripe, 0, nblk, x, y, x, pbuf, nullptr, grid, 1, xdiv));
+    PSP_TRY(launch_w4(A, ex, stripe, 0, nblk, x, y, x, pbuf, skip, grid, 1, xdiv, xdiv_dev));
   int np = grid;
   if (pbuf != partials) {
     np = kFold;
@@ -2855,7 +2858,8 @@ static int chunk_lower_bound(const ChunkTable *t, int row, int *out) {
 
 template <int WT, int NP>
 static void launch_w2_range(const psp_csr *A, const ChunkTable *t, bool w3, int stripe, int c0, int c1,
-                            const double *x, double *y, const double *dotv, double *pbuf, int *grid_out) {
+                            const double *x, double *y, const double *dotv, double *pbuf, int *grid_out,
+                            const int *skip) {
   int grid = (c1 - c0 + 3) / 4;
   if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
   *grid_out = grid;
@@ -2864,17 +2868,17 @@ static void launch_w2_range(const psp_csr *A, const ChunkTable *t, bool w3, int 
     return;
   }
   if (w3) {
-    launch_w3(A, t, false, grid, stripe, c0, c1, x, y, dotv, pbuf, nullptr);
+    launch_w3(A, t, false, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
     return;
   }
   hipLaunchKernelGGL((csr_spmv_w2<WT, NP, 4>), dim3(grid), dim3(256), 0, stream(), c0, c1, colmask(),
                      stripe, t->target, (int)A->padded - 4, t->tab, t->rowoff, A->col, A->val, x, y,
-                     dotv, pbuf, (const int *)nullptr);
+                     dotv, pbuf, skip);
 }
 
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
-                     void *ctx) {
+                     void *ctx, const int *skip) {
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   if (v.w4 && row_a < row_b) {
@@ -2895,10 +2899,10 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
         PSP_TRY(ensure_big_partials(ex, g1 + g2 + g3 + 8));
         pbuf = ex->big_partials;
       }
-      if (g1) PSP_TRY(launch_w4(A, ex, stripe, ba, bb, x, y, dotv, pbuf, nullptr, g1));
+      if (g1) PSP_TRY(launch_w4(A, ex, stripe, ba, bb, x, y, dotv, pbuf, skip, g1));
       if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
-      if (g2) PSP_TRY(launch_w4(A, ex, stripe, 0, ba, x, y, dotv, pbuf ? pbuf + g1 : nullptr, nullptr, g2));
-      if (g3) PSP_TRY(launch_w4(A, ex, stripe, bb, nblk, x, y, dotv, pbuf ? pbuf + g1 + g2 : nullptr, nullptr, g3));
+      if (g2) PSP_TRY(launch_w4(A, ex, stripe, 0, ba, x, y, dotv, pbuf ? pbuf + g1 : nullptr, skip, g2));
+      if (g3) PSP_TRY(launch_w4(A, ex, stripe, bb, nblk, x, y, dotv, pbuf ? pbuf + g1 + g2 : nullptr, skip, g3));
       if (partials) {
         hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), pbuf, g1 + g2 + g3,
                            partials, kFold);
@@ -2922,7 +2926,7 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
   }
   if (!ok) {  // no split possible with this kernel variant: exchange first, then everything
     if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
-    return csr_spmv_launch(A, x, y, dotv, partials, nparts);
+    return csr_spmv_launch(A, x, y, dotv, partials, nparts, skip);
   }
   // interior chunk range [ca, cb): all rows >= row_a and < row_b
   psp::CsrExtra *ex;
@@ -2967,13 +2971,13 @@ int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double 
 #define PSP_RANGE(C0, C1, OFF, G)                                                              \
   do {                                                                                         \
     if (v.tile == 512) {                                                                       \
-      if (t->np == 2) launch_w2_range<512, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else if (t->np == 3) launch_w2_range<512, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else launch_w2_range<512, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      if (t->np == 2) launch_w2_range<512, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
+      else if (t->np == 3) launch_w2_range<512, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
+      else launch_w2_range<512, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
     } else {                                                                                   \
-      if (t->np == 2) launch_w2_range<1024, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else if (t->np == 3) launch_w2_range<1024, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
-      else launch_w2_range<1024, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G); \
+      if (t->np == 2) launch_w2_range<1024, 2>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
+      else if (t->np == 3) launch_w2_range<1024, 3>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
+      else launch_w2_range<1024, 4>(A, t, w3, stripe, C0, C1, x, y, dotv, pbuf ? pbuf + (OFF) : nullptr, &G, skip); \
     }                                                                                          \
     PSP_LAUNCH_CHECK();                                                                        \
   } while (0)

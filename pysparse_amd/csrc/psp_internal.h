@@ -170,6 +170,19 @@ struct PcgDev {
   int pend_maxit;  // the loop ran out at it == maxit: -5 or -1 is decided by the final scan
   double alpha_x;
 };
+// Device-resident scalar state of the asynchronous MINRES loop (psp_solvers.hip; minres.c:96-193): the
+// Lanczos / Givens recurrences are evaluated by the thread that finishes each reduction; the vector
+// kernels read their coefficients from here.
+struct MinresDev {
+  double beta, beta_old, alpha, c, c_old, s, s_old, eta, norm_rmr, norm_r0, errtol, relres;
+  double c1, c2;             // Lanczos coefficients of the running iteration: alpha/beta, beta/beta_old
+  double r1, r2, r3, c_eta;  // its w / x update (minres.c:172-180)
+  int status;  // 1: ended by -3 / -6 (minres.c:144-146, :160-162) or after the last w/x update: all kernels no-ops
+  int stop;    // the loop test at the head of the NEXT iteration failed (minres.c:114): only the w/x update
+               // of the running iteration is still to be done
+  int skip;    // status | stop -- what the SpMV / scale / Lanczos kernels look at
+  int info, iter, it_max;
+};
 // y = op(x) on device vectors; y must not alias x
 int op_apply(const psp_op *op, const double *x_dev, double *y_dev);
 // the csr that a native operator multiplies with (csr, or sss->full); nullptr otherwise
@@ -187,13 +200,15 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
                            double *p_new, double *q, double beta, bool first, double *partials, int *nparts,
                            const PcgDev *dstate, int *available);
 // MINRES: y = A (x ./ xdiv) + partials of (x ./ xdiv) . y on the index-free layouts; *available = 0 otherwise
+// xdiv_dev != nullptr: the divisor is read from the device (asynchronous MINRES loop)
 int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,
-                           int *nparts, int *available);
+                           int *nparts, int *available, const int *skip = nullptr,
+                           const double *xdiv_dev = nullptr);
 // true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
 bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
-                     void *ctx);
+                     void *ctx, const int *skip = nullptr);
 // constant-vector registry (psp_vec.hip): the PCG vector kernels skip the dinv stream when the
 // preconditioner's dinv holds one value everywhere
 int dinv_register(const double *v, long n);

@@ -46,12 +46,12 @@ int k_xr_update(long n, double alpha, const double *p, const double *q, const do
 int k_jacobi_first(long n, const double *x, const double *dinv, double *y);
 int k_jacobi_sweep(long n, const double *x, const double *dinv, const double *temp, double *y);
 int k_dinv(long n, const double *diag, double omega, double *dinv, double *partials, int *nparts);
-int k_scale_div(long n, const double *y, double beta, double *v);
+int k_scale_div(long n, const double *y, double beta, double *v, const MinresDev *ds = nullptr);
 int k_lanczos(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old,
-              const double *dinv, double *y, double *partials, int *nparts);
+              const double *dinv, double *y, double *partials, int *nparts, const MinresDev *ds = nullptr);
 int k_lanczos_plain(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old);
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w,
-                double *w_old, double *x, bool scaled = false, double vdiv = 1.0);
+                double *w_old, double *x, bool scaled = false, double vdiv = 1.0, const MinresDev *ds = nullptr);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
 }  // namespace psp
@@ -757,6 +757,214 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
 
 // ====================================================================== MINRES
 
+// ---------------------------------------------------------------------- asynchronous MINRES
+//
+// Same kernels and the same arithmetic as the host-scalar loop in minres_device, but the Lanczos /
+// Givens recurrences of minres.c:129-192 are evaluated on the device by the thread that finishes each
+// of the two reductions, and the vector kernels read their coefficients from the MinresDev state.
+// The host enqueues kBatch iterations, then reads the state once (two host round trips per iteration
+// become one per batch: what bounds C1-sized solves).  Exit protocol:
+//   * -3 (beta^2 < 0) and -6 (r1 == 0) return BEFORE the w / x update of the iteration (minres.c:144-146,
+//     :160-162): status = 1, every later kernel is a no-op;
+//   * the loop test (minres.c:114) belongs to the head of the NEXT iteration: the scalar step that ends
+//     iteration k evaluates it and sets `stop`; the w / x update of iteration k still runs, everything
+//     after it is skipped (the next scalar step turns stop into status).
+enum MinresScalarOp { kMrAlpha = 0, kMrBeta = 1 };
+
+__device__ __forceinline__ void minres_scalar_alpha(MinresDev *st, const double *__restrict__ scal) {
+  if (st->status) return;
+  if (st->stop) {  // the update of the last iteration has run by now
+    st->status = 1;
+    return;
+  }
+  const double alpha = scal[0];  // minres.c:129
+  st->alpha = alpha;
+  st->c1 = alpha / st->beta;  // minres.c:131
+  st->c2 = st->beta / st->beta_old;
+}
+
+__device__ __forceinline__ void minres_scalar_beta(MinresDev *st, const double *__restrict__ scal,
+                                                   double *__restrict__ hist) {
+  if (st->status) return;
+  const double alpha = st->alpha;
+  const double beta_old = st->beta;
+  st->beta_old = beta_old;
+  double beta = scal[0];  // minres.c:143
+  if (beta < 0.0) {       // minres.c:144-146
+    st->status = 1;
+    st->skip = 1;
+    st->info = -3;
+    return;
+  }
+  beta = sqrt(beta);
+  st->beta = beta;
+  // QR factorisation + Givens rotation (minres.c:151-164)
+  const double c_oold = st->c_old;
+  const double c_old = st->c;
+  const double s_oold = st->s_old;
+  const double s_old = st->s;
+  st->c_old = c_old;
+  st->s_old = s_old;
+  const double r1_hat = c_old * alpha - c_oold * s_old * beta_old;
+  const double r1 = sqrt(r1_hat * r1_hat + beta * beta);
+  const double r2 = s_old * alpha + c_oold * c_old * beta_old;
+  const double r3 = s_oold * beta_old;
+  if (r1 == 0.0) {  // minres.c:160-162
+    st->status = 1;
+    st->skip = 1;
+    st->info = -6;
+    return;
+  }
+  const double c = r1_hat / r1;
+  const double s_ = beta / r1;
+  st->c = c;
+  st->s = s_;
+  st->r1 = r1;
+  st->r2 = r2;
+  st->r3 = r3;
+  st->c_eta = c * st->eta;  // minres.c:180
+  st->eta = -s_ * st->eta;
+  const double norm_rmr = st->norm_rmr * fabs(s_);  // minres.c:192
+  st->norm_rmr = norm_rmr;
+  if (hist) hist[st->iter] = norm_rmr;
+  // head of the next iteration (minres.c:114, strict <)
+  const bool conv = norm_rmr < st->errtol * st->norm_r0;
+  if (st->iter >= st->it_max || conv) {
+    st->stop = 1;
+    st->skip = 1;
+    st->relres = norm_rmr / st->norm_r0;  // minres.c:195
+    st->info = conv ? 0 : -1;
+  } else {
+    st->iter += 1;
+  }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void minres_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                   int stride, double *__restrict__ out,
+                                                                   MinresDev *st, double *__restrict__ hist) {
+  if (st->status) return;
+  finish_block(src, count, 1, stride, out);
+  if (threadIdx.x == 0) {
+    if constexpr (OP == kMrAlpha) minres_scalar_alpha(st, out);
+    if constexpr (OP == kMrBeta) minres_scalar_beta(st, out, hist);
+  }
+}
+
+template <int OP>
+static int minres_reduce_then(const double *partials, int nparts, double *out_dev, MinresDev *st, double *hist_dev) {
+  const double *src;
+  int count, stride;
+  PSP_TRY(fold_stage(partials, nparts, 1, &src, &count, &stride));
+  hipLaunchKernelGGL((minres_finish_scalar_kernel<OP>), dim3(1), dim3(256), 0, stream(), src, count, stride, out_dev,
+                     st, hist_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+static int minres_async_enabled() {
+  static const int on = [] {
+    const char *e = getenv("PSP_MINRES_ASYNC");
+    return e ? atoi(e) : 1;
+  }();
+  return on;
+}
+
+// iterations 1.. on a native operator with K = None or jacobi(steps=1); on entry the setup of
+// minres.c:62-94 is done (beta = sqrt(v_hat . y) >= 0, w = w_old = 0) and the first loop test passed
+static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n, double *x, double *v_hat,
+                             double *v_hat_old, double *y, double *y2, double *wv, double *w_old, double *v,
+                             double *av, double norm_r0, double beta0, double errtol, int it_max, int *info,
+                             int *iter, double *relres, double *hist) {
+  constexpr int kBatch = 16;
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  MinresDev *st = nullptr, *hst = nullptr;
+  double *hist_dev = nullptr;
+  PSP_HIP(hipMalloc((void **)&st, sizeof(MinresDev)));
+  hipError_t e = hipHostMalloc((void **)&hst, sizeof(MinresDev), hipHostMallocDefault);
+  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)it_max + 1));
+  if (e != hipSuccess) {
+    (void)hipFree(st);
+    if (hst) (void)hipHostFree(hst);
+    return fail(PSP_ENOMEM, "minres: state allocation failed: %s", hipGetErrorString(e));
+  }
+  int rc = PSP_OK;
+  int enqueued = 0, np = 0;
+#define MR_TRY(call)             \
+  do {                           \
+    rc = (call);                 \
+    if (rc != PSP_OK) goto done; \
+  } while (0)
+#define MR_HIP(call)                                                 \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) {                                          \
+      rc = fail(PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_)); \
+      goto done;                                                     \
+    }                                                                \
+  } while (0)
+  memset(hst, 0, sizeof(MinresDev));
+  hst->beta = beta0;
+  hst->beta_old = 1.0;
+  hst->c = 1.0;
+  hst->c_old = 1.0;
+  hst->s = 0.0;
+  hst->s_old = 0.0;
+  hst->eta = beta0;
+  hst->norm_rmr = norm_r0;
+  hst->norm_r0 = norm_r0;
+  hst->errtol = errtol;
+  hst->iter = 1;
+  hst->it_max = it_max;
+  hst->info = -1;
+  MR_HIP(hipMemcpyAsync(st, hst, sizeof(MinresDev), hipMemcpyHostToDevice, stream()));
+  do {
+    const int batch = std::max(1, std::min(kBatch, it_max - enqueued));
+    for (int i = 0; i < batch; ++i) {
+      // v = y / beta (minres.c:123-124), Av = A v, alpha = v . Av (:127-129)
+      const double *vsrc = hasK ? y : v_hat;  // unnormalised Lanczos vector of this iteration
+      int scaled = 0;
+      if (!hasK || y2)
+        MR_TRY(csr_spmv_scaled_launch(Acsr, vsrc, 1.0, av, w->partials, &np, &scaled, &st->skip, &st->beta));
+      if (!scaled) {
+        MR_TRY(k_scale_div(n, vsrc, 1.0, v, st));
+        MR_TRY(csr_spmv_launch(Acsr, v, av, v, w->partials, &np, &st->skip));
+      }
+      MR_TRY(minres_reduce_then<kMrAlpha>(w->partials, np, w->scal_dev, st, nullptr));
+      // v_hat = Av - c1 v_hat - c2 v_hat_old; y = K v_hat; beta^2 = v_hat . y (:131-143)
+      double *ynew = (scaled && hasK) ? y2 : y;
+      MR_TRY(k_lanczos(n, av, 0.0, 0.0, v_hat, v_hat_old, dinv, ynew, w->partials, &np, st));
+      std::swap(v_hat, v_hat_old);
+      if (scaled && hasK) std::swap(y, y2);
+      MR_TRY(minres_reduce_then<kMrBeta>(w->partials, np, w->scal_dev + 4, st, hist_dev));
+      // w, x update (:172-180); the new w lands in w_old's buffer
+      MR_TRY(k_minres_wx(n, scaled ? vsrc : v, 0.0, 0.0, 0.0, 0.0, wv, w_old, x, scaled != 0, 1.0, st));
+      std::swap(wv, w_old);
+    }
+    MR_HIP(hipGetLastError());
+    enqueued += batch;
+    MR_HIP(hipMemcpyAsync(hst, st, sizeof(MinresDev), hipMemcpyDeviceToHost, stream()));
+    MR_HIP(hipStreamSynchronize(stream()));
+  } while (!hst->status && !hst->stop);
+  *info = hst->info;
+  *iter = hst->iter;
+  if (hst->info == 0 || hst->info == -1) *relres = hst->relres;  // untouched on -3 / -6, as in the reference
+  if (hist) {
+    const int cnt = std::min(hst->iter, it_max);
+    if (cnt >= 1)
+      MR_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    // -3 / -6 leave the history slot of the running iteration unwritten
+  }
+done:
+#undef MR_TRY
+#undef MR_HIP
+  (void)hipFree(st);
+  (void)hipHostFree(hst);
+  if (hist_dev) (void)hipFree(hist_dev);
+  return rc;
+}
+
 static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
                          double errtol, int it_max, int *info, int *iter, double *relres,
                          double *hist) {
@@ -812,6 +1020,13 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   double eta = beta;
   double norm_rmr = norm_r0;
   if (hist) hist[0] = norm_rmr;
+
+  if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
+    if (hist)  // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
+      for (int i = 1; i <= it_max; ++i) hist[i] = hist[i];
+    return minres_async_loop(Acsr, dinv, K != nullptr, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
+                             beta, errtol, it_max, info, iter, relres, hist);
+  }
 
   while (true) {
     if (*iter >= it_max || norm_rmr < errtol * norm_r0) break;  // minres.c:114 (strict <)
@@ -1216,6 +1431,296 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
   *relres = sqrt(d) / resid0;
   return PSP_OK;
 }
+
+
+// ---------------------------------------------------------------- device-resident solver state for the
+// row-partitioned driver (pysparse_amd/distributed.py).  Same state machine as pcg_async_loop_lazy /
+// minres_async_loop, cut at the two reductions of an iteration so that an RCCL all-reduce (issued through
+// torch.distributed on the same stream) can sit between "finish the local partial sums" and "take the
+// reference's branches on the reduced values": the host enqueues whole batches of iterations and reads
+// the state once per batch -- no host round trip per reduction.
+
+struct psp_pcgstate {
+  PcgDev *dev = nullptr;
+  PcgDev *host = nullptr;  // pinned mirror
+  double *hist_dev = nullptr;
+  int hist_cap = 0;
+};
+
+struct psp_minresstate {
+  MinresDev *dev = nullptr;
+  MinresDev *host = nullptr;
+  double *hist_dev = nullptr;
+  int hist_cap = 0;
+};
+
+// {p.q, nonstag} reduced over all ranks: the stagnation verdict of the previous iteration and the exits at
+// the head of this one (pcg.c:159-162, :101-112), then alpha (pcg.c:117-125)
+__global__ void pcg_dist_scalar_xpq_kernel(PcgDev *st, const double *__restrict__ scal) {
+  pcg_lazy_scalar_x(st, scal + 1);
+  pcg_lazy_scalar_pq(st, scal);
+}
+
+// {r.r, r.z} reduced over all ranks: convergence test, next rho / beta (pcg.c:152-157, :99-112)
+__global__ void pcg_dist_scalar_r_kernel(PcgDev *st, const double *__restrict__ scal, double *__restrict__ hist) {
+  pcg_lazy_scalar_r(st, scal, hist);
+}
+
+__global__ void minres_dist_scalar_kernel(MinresDev *st, const double *__restrict__ scal, int op,
+                                          double *__restrict__ hist) {
+  if (op == kMrAlpha) minres_scalar_alpha(st, scal);
+  else minres_scalar_beta(st, scal, hist);
+}
+
+extern "C" {
+
+int psp_pcgstate_create(psp_pcgstate_t **out) {
+  if (!out) return fail(PSP_EINVAL, "psp_pcgstate_create: NULL argument");
+  PSP_TRY(ensure_device());
+  psp_pcgstate *s = new psp_pcgstate();
+  hipError_t e1 = hipMalloc((void **)&s->dev, sizeof(PcgDev));
+  hipError_t e2 = hipHostMalloc((void **)&s->host, sizeof(PcgDev), hipHostMallocDefault);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    psp_pcgstate_destroy(s);
+    return fail(PSP_ENOMEM, "psp_pcgstate_create: allocation failed");
+  }
+  *out = s;
+  return PSP_OK;
+}
+
+int psp_pcgstate_destroy(psp_pcgstate_t *s) {
+  if (!s) return PSP_OK;
+  if (s->dev) (void)hipFree(s->dev);
+  if (s->host) (void)hipHostFree(s->host);
+  if (s->hist_dev) (void)hipFree(s->hist_dev);
+  delete s;
+  return PSP_OK;
+}
+
+int psp_pcgstate_init(psp_pcgstate_t *s, double n2b, double tolb, double normr0, double rho0, int maxit,
+                      int want_hist) {
+  if (!s || maxit < 1) return fail(PSP_EINVAL, "psp_pcgstate_init: bad argument");
+  if (want_hist && s->hist_cap < maxit + 1) {
+    if (s->hist_dev) (void)hipFree(s->hist_dev);
+    s->hist_dev = nullptr;
+    s->hist_cap = 0;
+    PSP_HIP(hipMalloc((void **)&s->hist_dev, sizeof(double) * ((size_t)maxit + 1)));
+    s->hist_cap = maxit + 1;
+  }
+  if (want_hist) PSP_HIP(hipMemsetAsync(s->hist_dev, 0xff, sizeof(double) * ((size_t)maxit + 1), stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));  // the pinned mirror may still be the source of an earlier copy
+  memset(s->host, 0, sizeof(PcgDev));
+  s->host->rho = rho0;
+  s->host->rho1 = 1.0;
+  s->host->normr = normr0;
+  s->host->tolb = tolb;
+  s->host->n2b = n2b;
+  s->host->it = 1;
+  s->host->maxit = maxit;
+  PSP_HIP(hipMemcpyAsync(s->dev, s->host, sizeof(PcgDev), hipMemcpyHostToDevice, stream()));
+  return PSP_OK;
+}
+
+int psp_pcgstate_fetch(psp_pcgstate_t *s, psp_pcg_status_t *out) {
+  if (!s || !out) return fail(PSP_EINVAL, "psp_pcgstate_fetch: NULL argument");
+  PSP_HIP(hipMemcpyAsync(s->host, s->dev, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  const PcgDev *h = s->host;
+  out->status = h->status;
+  out->info = h->info;
+  out->iter = h->iter;
+  out->it = h->it;
+  out->xpend = h->xpend;
+  out->stag0 = h->stag0;
+  out->pend_maxit = h->pend_maxit;
+  out->relres = h->relres;
+  out->normr = h->normr;
+  out->n2b = h->n2b;
+  out->alpha_x = h->alpha_x;
+  return PSP_OK;
+}
+
+int psp_pcgstate_hist(psp_pcgstate_t *s, int first, int count, double *hist_host) {
+  if (!s || !hist_host || !s->hist_dev || first < 0 || count < 0 || first + count > s->hist_cap)
+    return fail(PSP_EINVAL, "psp_pcgstate_hist: bad argument");
+  if (count) PSP_HIP(hipMemcpy(hist_host, s->hist_dev + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return PSP_OK;
+}
+
+int psp_kd_px_update(const psp_pcgstate_t *s, int n, const double *r_dev, const double *dinv_dev, double *p_dev,
+                     double *x_dev, double *out_dev) {
+  if (!s || !r_dev || !p_dev || !x_dev || !out_dev) return fail(PSP_EINVAL, "psp_kd_px_update: NULL argument");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_px_update(n, r_dev, dinv_dev, p_dev, x_dev, w->partials, &np, s->dev));
+  return finish_partials(w->partials + 2 * (size_t)kMaxParts, np, 1, out_dev);
+}
+
+int psp_kd_r_update(const psp_pcgstate_t *s, int n, const double *q_dev, const double *dinv_dev, double *r_dev,
+                    double *out_dev) {
+  if (!s || !q_dev || !r_dev || !out_dev) return fail(PSP_EINVAL, "psp_kd_r_update: NULL argument");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_r_update(n, 0.0, q_dev, dinv_dev, r_dev, w->partials, &np, s->dev));
+  return finish_partials(w->partials, np, 2, out_dev);
+}
+
+int psp_kd_csr_matvec_overlap(const psp_pcgstate_t *s, psp_csr_t *A, const double *x_dev, int x_offset,
+                              double *y_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx,
+                              double *dot_out_dev) {
+  if (!s || !A || !x_dev || !y_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: NULL");
+  if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
+    return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: row range / offset out of bounds");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np = 0;
+  if (A->nrows == 0) {
+    if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+    PSP_HIP(hipMemsetAsync(dot_out_dev, 0, sizeof(double), stream()));
+    return PSP_OK;
+  }
+  PSP_TRY(csr_spmv_overlap(A, x_dev, y_dev, x_dev + x_offset, w->partials, &np, row_a, row_b, wait, ctx,
+                           &s->dev->status));
+  return finish_partials(w->partials, np, 1, dot_out_dev);
+}
+
+int psp_kd_pcg_scalar_xpq(psp_pcgstate_t *s, const double *scal_dev) {
+  if (!s || !scal_dev) return fail(PSP_EINVAL, "psp_kd_pcg_scalar_xpq: NULL argument");
+  hipLaunchKernelGGL(pcg_dist_scalar_xpq_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int psp_kd_pcg_scalar_r(psp_pcgstate_t *s, const double *scal_dev) {
+  if (!s || !scal_dev) return fail(PSP_EINVAL, "psp_kd_pcg_scalar_r: NULL argument");
+  hipLaunchKernelGGL(pcg_dist_scalar_r_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev, s->hist_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+// ---- MINRES on row blocks (minres.c:96-193, two reductions per iteration)
+
+int psp_minresstate_create(psp_minresstate_t **out) {
+  if (!out) return fail(PSP_EINVAL, "psp_minresstate_create: NULL argument");
+  PSP_TRY(ensure_device());
+  psp_minresstate *s = new psp_minresstate();
+  hipError_t e1 = hipMalloc((void **)&s->dev, sizeof(MinresDev));
+  hipError_t e2 = hipHostMalloc((void **)&s->host, sizeof(MinresDev), hipHostMallocDefault);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    psp_minresstate_destroy(s);
+    return fail(PSP_ENOMEM, "psp_minresstate_create: allocation failed");
+  }
+  *out = s;
+  return PSP_OK;
+}
+
+int psp_minresstate_destroy(psp_minresstate_t *s) {
+  if (!s) return PSP_OK;
+  if (s->dev) (void)hipFree(s->dev);
+  if (s->host) (void)hipHostFree(s->host);
+  if (s->hist_dev) (void)hipFree(s->hist_dev);
+  delete s;
+  return PSP_OK;
+}
+
+int psp_minresstate_init(psp_minresstate_t *s, double norm_r0, double beta0, double errtol, int it_max,
+                         int want_hist) {
+  if (!s || it_max < 1) return fail(PSP_EINVAL, "psp_minresstate_init: bad argument");
+  if (want_hist && s->hist_cap < it_max + 1) {
+    if (s->hist_dev) (void)hipFree(s->hist_dev);
+    s->hist_dev = nullptr;
+    s->hist_cap = 0;
+    PSP_HIP(hipMalloc((void **)&s->hist_dev, sizeof(double) * ((size_t)it_max + 1)));
+    s->hist_cap = it_max + 1;
+  }
+  if (want_hist) PSP_HIP(hipMemsetAsync(s->hist_dev, 0xff, sizeof(double) * ((size_t)it_max + 1), stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  MinresDev *h = s->host;
+  memset(h, 0, sizeof(MinresDev));
+  h->beta = beta0;
+  h->beta_old = 1.0;
+  h->c = 1.0;
+  h->c_old = 1.0;
+  h->eta = beta0;
+  h->norm_rmr = norm_r0;
+  h->norm_r0 = norm_r0;
+  h->errtol = errtol;
+  h->iter = 1;
+  h->it_max = it_max;
+  h->info = -1;
+  PSP_HIP(hipMemcpyAsync(s->dev, h, sizeof(MinresDev), hipMemcpyHostToDevice, stream()));
+  return PSP_OK;
+}
+
+int psp_minresstate_fetch(psp_minresstate_t *s, psp_minres_status_t *out) {
+  if (!s || !out) return fail(PSP_EINVAL, "psp_minresstate_fetch: NULL argument");
+  PSP_HIP(hipMemcpyAsync(s->host, s->dev, sizeof(MinresDev), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  const MinresDev *h = s->host;
+  out->status = h->status;
+  out->stop = h->stop;
+  out->info = h->info;
+  out->iter = h->iter;
+  out->relres = h->relres;
+  out->norm_rmr = h->norm_rmr;
+  return PSP_OK;
+}
+
+int psp_minresstate_hist(psp_minresstate_t *s, int first, int count, double *hist_host) {
+  if (!s || !hist_host || !s->hist_dev || first < 0 || count < 0 || first + count > s->hist_cap)
+    return fail(PSP_EINVAL, "psp_minresstate_hist: bad argument");
+  if (count) PSP_HIP(hipMemcpy(hist_host, s->hist_dev + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return PSP_OK;
+}
+
+// the row-block form keeps v = y / beta as a vector of its own (its ghost entries are what the halo
+// exchange moves); the single-GPU loop's scaled SpMV has no split-around-a-wait form
+int psp_kd_minres_scale(const psp_minresstate_t *s, int n, const double *y_dev, double *v_dev) {
+  if (!s || !y_dev || !v_dev) return fail(PSP_EINVAL, "psp_kd_minres_scale: NULL argument");
+  return k_scale_div(n, y_dev, 1.0, v_dev, s->dev);
+}
+
+int psp_kd_minres_matvec(const psp_minresstate_t *s, psp_csr_t *A, const double *v_dev, int v_offset,
+                         double *av_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
+  if (!s || !A || !v_dev || !av_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_minres_matvec: NULL");
+  if (v_offset < 0 || v_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
+    return fail(PSP_EINVAL, "psp_kd_minres_matvec: row range / offset out of bounds");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np = 0;
+  PSP_TRY(csr_spmv_overlap(A, v_dev, av_dev, v_dev + v_offset, w->partials, &np, row_a, row_b, wait, ctx,
+                           &s->dev->skip));
+  return finish_partials(w->partials, np, 1, dot_out_dev);
+}
+
+int psp_kd_minres_lanczos(const psp_minresstate_t *s, int n, const double *av_dev, const double *v_hat_dev,
+                          double *v_hat_old_dev, const double *dinv_dev, double *y_dev, double *out_dev) {
+  if (!s || !av_dev || !v_hat_dev || !v_hat_old_dev || !out_dev)
+    return fail(PSP_EINVAL, "psp_kd_minres_lanczos: NULL argument");
+  if (dinv_dev && !y_dev) return fail(PSP_EINVAL, "psp_kd_minres_lanczos: y is needed with a preconditioner");
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  int np;
+  PSP_TRY(k_lanczos(n, av_dev, 0.0, 0.0, v_hat_dev, v_hat_old_dev, dinv_dev, y_dev, w->partials, &np, s->dev));
+  return finish_partials(w->partials, np, 1, out_dev);
+}
+
+int psp_kd_minres_scalar(psp_minresstate_t *s, int which, const double *scal_dev) {
+  if (!s || !scal_dev || (which != 0 && which != 1)) return fail(PSP_EINVAL, "psp_kd_minres_scalar: bad argument");
+  hipLaunchKernelGGL(minres_dist_scalar_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev, which, s->hist_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int psp_kd_minres_wx(const psp_minresstate_t *s, int n, const double *v_dev, const double *w_dev,
+                     double *w_old_dev, double *x_dev) {
+  if (!s || !v_dev || !w_dev || !w_old_dev || !x_dev) return fail(PSP_EINVAL, "psp_kd_minres_wx: NULL argument");
+  return k_minres_wx(n, v_dev, 0.0, 0.0, 0.0, 0.0, w_dev, w_old_dev, x_dev, false, 1.0, s->dev);
+}
+
+}  // extern "C"
 
 // ====================================================================== C ABI
 

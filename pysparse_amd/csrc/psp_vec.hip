@@ -355,7 +355,12 @@ __global__ __launch_bounds__(kBlock) void dinv_kernel(long n, const double *__re
 // ---- MINRES: v = y / beta (minres.c:123-124)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scale_div_kernel(long n, const double *__restrict__ y,
-                                                           double beta, double *__restrict__ v) {
+                                                           double beta, double *__restrict__ v,
+                                                           const MinresDev *__restrict__ ds) {
+  if (ds) {  // asynchronous loop: scalars live on the device
+    if (ds->skip) return;
+    beta = ds->beta;
+  }
   PSP_VEC_LOOP(i, n) {
     Pack<V> a = ld<V>(y, i);
 #pragma unroll
@@ -371,7 +376,12 @@ template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void lanczos_kernel(
     long n, const double *__restrict__ av, double c1, double c2, const double *__restrict__ v_hat,
     double *__restrict__ v_hat_old, const double *__restrict__ dinv, double dc, double *__restrict__ y,
-    double *__restrict__ partials) {
+    double *__restrict__ partials, const MinresDev *__restrict__ ds) {
+  if (ds) {
+    if (ds->skip) return;
+    c1 = ds->c1;
+    c2 = ds->c2;
+  }
   // The new v_hat is written over v_hat_old (its old value is consumed here) and the caller swaps the
   // two names: "v_hat_old = old v_hat" (minres.c:125,135) then costs no store.  PRE as in residual_kernel.
   double acc[1] = {0.0};
@@ -425,7 +435,16 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double 
                                                            double vdiv, double r1, double r2, double r3,
                                                            double c_eta, const double *__restrict__ w,
                                                            double *__restrict__ w_old,
-                                                           double *__restrict__ x) {
+                                                           double *__restrict__ x,
+                                                           const MinresDev *__restrict__ ds) {
+  if (ds) {  // the update of the running iteration is still due when only `stop` is set
+    if (ds->status) return;
+    vdiv = ds->beta_old;  // beta at the start of this iteration (the scalar step has moved on)
+    r1 = ds->r1;
+    r2 = ds->r2;
+    r3 = ds->r3;
+    c_eta = ds->c_eta;
+  }
   // SCALED: v holds the unnormalised Lanczos vector and v / vdiv is formed here (minres.c:123-124)
   PSP_VEC_LOOP(i, n) {
     Pack<V> vv = ld<V>(v, i);
@@ -731,20 +750,20 @@ int k_dinv(long n, const double *diag, double omega, double *dinv, double *parti
   return PSP_OK;
 }
 
-int k_scale_div(long n, const double *y, double beta, double *v) {
+int k_scale_div(long n, const double *y, double beta, double *v, const MinresDev *ds) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   if (can_vec2(n, y, v))
-    hipLaunchKernelGGL(scale_div_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v);
+    hipLaunchKernelGGL(scale_div_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v, ds);
   else
-    hipLaunchKernelGGL(scale_div_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v);
+    hipLaunchKernelGGL(scale_div_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, y, beta, v, ds);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
 
 int k_lanczos(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old,
-              const double *dinv, double *y, double *partials, int *nparts) {
+              const double *dinv, double *y, double *partials, int *nparts, const MinresDev *ds) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -754,7 +773,7 @@ int k_lanczos(long n, const double *av, double c1, double c2, const double *v_ha
                        : can_vec2(n, av, v_hat, v_hat_old);
 #define L(V, PRE)                                                                              \
   hipLaunchKernelGGL((lanczos_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, av, c1, \
-                     c2, v_hat, v_hat_old, dinv, dc, y, partials)
+                     c2, v_hat, v_hat_old, dinv, dc, y, partials, ds)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -804,14 +823,14 @@ int k_scal(long n, double a, double *x) {
 }
 
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w_,
-                double *w_old, double *x, bool scaled, double vdiv) {
+                double *w_old, double *x, bool scaled, double vdiv, const MinresDev *ds) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   const bool v2 = can_vec2(n, v, w_, w_old, x);
 #define L(V, S)                                                                                   \
   hipLaunchKernelGGL((minres_wx_kernel<V, S>), dim3(grid), dim3(kBlock), 0, stream(), n, v, vdiv, r1, \
-                     r2, r3, c_eta, w_, w_old, x)
+                     r2, r3, c_eta, w_, w_old, x, ds)
   if (scaled) { if (v2) L(2, true); else L(1, true); }
   else { if (v2) L(2, false); else L(1, false); }
 #undef L
@@ -926,6 +945,12 @@ int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_de
   int np;
   PSP_TRY(k_xr_update(n, alpha, p_dev, q_dev, dinv_dev, x_dev, r_dev, w->partials, &np, nullptr));
   return finish_partials(w->partials, np, 3, out_dev);
+}
+
+int psp_k_jacobi(int n, const double *x_dev, const double *dinv_dev, double *y_dev) {
+  if (!x_dev || !dinv_dev || !y_dev || n < 0) return fail(PSP_EINVAL, "psp_k_jacobi: bad argument");
+  if (n == 0) return PSP_OK;
+  return k_jacobi_first(n, x_dev, dinv_dev, y_dev);
 }
 
 int psp_k_gather(int count, const int *idx_dev, const double *v_dev, double *send_dev) {

@@ -10,7 +10,11 @@ The reference is single-process; this is the MI355X-native extension of its PCG
   * before every q = A p the ghost entries of p are exchanged with the neighbouring ranks
     (RCCL send/recv through torch.distributed, point-to-point over xGMI);
   * the three sum reductions and the stagnation test of one PCG iteration are packed into
-    TWO all-reduces:  #1 {p.q}  and  #2 {r.r, r.z, number of non-stagnated ranks}.
+    TWO all-reduces:  #1 {p.q, number of non-stagnated workgroups}  and  #2 {r.r, r.z};
+  * alpha / beta / the exit tests live in a small DEVICE-side state (psp_pcgstate_*, psp_kd_*):
+    the all-reduces are issued in stream order between "finish the local partial sums" and "take
+    the reference's branches on the reduced values", the host enqueues 16 iterations at a time and
+    reads the state once per batch (dist_pcg, dist_minres) -- no host round trip per reduction.
 
 All arithmetic on vectors is done by a *backend*: HipBackend calls the HIP kernels of
 libpysparse_hip.so through the C ABI on torch CUDA tensors (the product path); the CPU
@@ -231,6 +235,81 @@ class HipBackend:
         self._capi.check(self.L.psp_k_x_update(x.numel(), float(alpha), self._p(p_owned), self._p(x), self._p(out)))
         return out
 
+    # ---- device-resident scalars (psp_pcgstate_* / psp_minresstate_*, include/pysparse_hip.h): results of
+    # the local reductions land in self.scal, the caller all-reduces slices of it in stream order
+    @property
+    def scal(self):
+        return self._scal
+
+    def pcg_state(self, n2b, tolb, normr0, rho0, maxit, want_hist):
+        return _HipPcgState(self, n2b, tolb, normr0, rho0, maxit, want_hist)
+
+    def kd_px_update(self, st, r, dinv, p_owned, x):
+        self._capi.check(self.L.psp_kd_px_update(st._h, r.numel(), self._p(r), self._p(dinv) if dinv is not None
+                                                 else None, self._p(p_owned), self._p(x), self._p(self._scal[1:2])))
+
+    def _wait_cb(self, wait, err):
+        def _wait(ctx):
+            try:
+                if wait is not None:
+                    wait()
+                return 0
+            except BaseException as e:  # noqa: BLE001 - re-raised by the caller
+                err.append(e)
+                return 1
+        return self._capi.WAIT_FN(_wait)
+
+    def kd_matvec_overlap(self, st, A, p_ext, p_offset, q, interior, wait):
+        err = []
+        cb = self._wait_cb(wait, err)
+        rc = self.L.psp_kd_csr_matvec_overlap(st._h, A._h, self._p(p_ext), int(p_offset), self._p(q),
+                                              int(interior[0]), int(interior[1]), cb, None, self._p(self._scal[0:1]))
+        if err:
+            raise err[0]
+        self._capi.check(rc)
+
+    def kd_pcg_scalar_xpq(self, st):
+        self._capi.check(self.L.psp_kd_pcg_scalar_xpq(st._h, self._p(self._scal[0:2])))
+
+    def kd_r_update(self, st, q, dinv, r):
+        self._capi.check(self.L.psp_kd_r_update(st._h, r.numel(), self._p(q), self._p(dinv) if dinv is not None
+                                                else None, self._p(r), self._p(self._scal[2:4])))
+
+    def kd_pcg_scalar_r(self, st):
+        self._capi.check(self.L.psp_kd_pcg_scalar_r(st._h, self._p(self._scal[2:4])))
+
+    def minres_state(self, norm_r0, beta0, tol, maxit, want_hist):
+        return _HipMinresState(self, norm_r0, beta0, tol, maxit, want_hist)
+
+    def jacobi(self, x, dinv, y):
+        """y = x .* dinv (preconmodule.c:41-42)"""
+        self._capi.check(self.L.psp_k_jacobi(x.numel(), self._p(x), self._p(dinv), self._p(y)))
+
+    def kd_minres_scale(self, st, y, v_owned):
+        self._capi.check(self.L.psp_kd_minres_scale(st._h, y.numel(), self._p(y), self._p(v_owned)))
+
+    def kd_minres_matvec(self, st, A, v_ext, v_offset, av, interior, wait):
+        err = []
+        cb = self._wait_cb(wait, err)
+        rc = self.L.psp_kd_minres_matvec(st._h, A._h, self._p(v_ext), int(v_offset), self._p(av), int(interior[0]),
+                                         int(interior[1]), cb, None, self._p(self._scal[0:1]))
+        if err:
+            raise err[0]
+        self._capi.check(rc)
+
+    def kd_minres_lanczos(self, st, av, v_hat, v_hat_old, dinv, y):
+        self._capi.check(self.L.psp_kd_minres_lanczos(st._h, av.numel(), self._p(av), self._p(v_hat),
+                                                      self._p(v_hat_old), self._p(dinv) if dinv is not None else None,
+                                                      self._p(y) if y is not None else None, self._p(self._scal[4:5])))
+
+    def kd_minres_scalar(self, st, which):
+        off = 0 if which == 0 else 4
+        self._capi.check(self.L.psp_kd_minres_scalar(st._h, int(which), self._p(self._scal[off:off + 1])))
+
+    def kd_minres_wx(self, st, v_owned, w, w_old, x):
+        self._capi.check(self.L.psp_kd_minres_wx(st._h, x.numel(), self._p(v_owned), self._p(w), self._p(w_old),
+                                                 self._p(x)))
+
     def hint_constant(self, v):
         self._capi.check(self.L.psp_k_hint_constant(self._p(v), v.numel()))
 
@@ -239,6 +318,285 @@ class HipBackend:
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
+
+
+
+class _HipPcgState:
+    """psp_pcgstate_t handle"""
+
+    def __init__(self, be, n2b, tolb, normr0, rho0, maxit, want_hist):
+        self.be = be
+        self._h = C.c_void_p()
+        be._capi.check(be.L.psp_pcgstate_create(C.byref(self._h)))
+        be._capi.check(be.L.psp_pcgstate_init(self._h, float(n2b), float(tolb), float(normr0), float(rho0),
+                                              int(maxit), 1 if want_hist else 0))
+
+    def fetch(self):
+        s = self.be._capi.PcgStatus()
+        self.be._capi.check(self.be.L.psp_pcgstate_fetch(self._h, C.byref(s)))
+        return s
+
+    def hist(self, first, count):
+        out = np.empty(count)
+        self.be._capi.check(self.be.L.psp_pcgstate_hist(self._h, int(first), int(count),
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.be.L.psp_pcgstate_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _HipMinresState:
+    """psp_minresstate_t handle"""
+
+    def __init__(self, be, norm_r0, beta0, tol, maxit, want_hist):
+        self.be = be
+        self._h = C.c_void_p()
+        be._capi.check(be.L.psp_minresstate_create(C.byref(self._h)))
+        be._capi.check(be.L.psp_minresstate_init(self._h, float(norm_r0), float(beta0), float(tol), int(maxit),
+                                                 1 if want_hist else 0))
+
+    def fetch(self):
+        s = self.be._capi.MinresStatus()
+        self.be._capi.check(self.be.L.psp_minresstate_fetch(self._h, C.byref(s)))
+        return s
+
+    def hist(self, first, count):
+        out = np.empty(count)
+        self.be._capi.check(self.be.L.psp_minresstate_hist(self._h, int(first), int(count),
+                                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.be.L.psp_minresstate_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostPcgState:
+    """Python mirror of the device state machine (psp_solvers.hip: pcg_lazy_scalar_x / _pq / _r) for
+    backends that keep scalars on the host (the CPU test backends); same fields, same branch order."""
+
+    def __init__(self, n2b, tolb, normr0, rho0, maxit, want_hist):
+        self.rho, self.rho1, self.alpha, self.beta = rho0, 1.0, 0.0, 0.0
+        self.normr, self.tolb, self.n2b, self.relres = normr0, tolb, n2b, 0.0
+        self.status = self.info = self.iter = self.stag = 0
+        self.it, self.maxit = 1, maxit
+        self.xpend = self.stag0 = self.head_rho0 = self.head_beta0 = self.pend_maxit = 0
+        self.alpha_x = 0.0
+        self._hist = {} if want_hist else None
+
+    def _finish(self, code, it):
+        self.status, self.info, self.iter = 1, code, it
+        self.relres = self.normr / self.n2b  # pcg.c:166
+
+    def scalar_x(self, nonstag):
+        if self.status:
+            return
+        if self.xpend:  # iteration it-1: pcg.c:159-162
+            self.xpend = 0
+            if self.stag0 or nonstag == 0.0:
+                self.stag = 1
+                self._finish(-5, self.it - 1)
+                return
+        if self.head_rho0:  # pcg.c:101-104 of iteration it
+            self._finish(-2, self.it)
+        elif self.head_beta0:  # pcg.c:109-112
+            self._finish(-6, self.it)
+
+    def scalar_pq(self, pq):
+        if self.status:
+            return
+        if pq == 0.0:  # pcg.c:118-120
+            self._finish(-6, self.it)
+            return
+        self.alpha = self.alpha_x = self.rho / pq
+        self.stag0 = 1 if self.alpha == 0.0 else 0
+        self.xpend = 1
+
+    def scalar_r(self, rr, rz):
+        if self.status:
+            return
+        it = self.it
+        self.normr = float(np.sqrt(rr))
+        if self._hist is not None:
+            self._hist[it] = self.normr
+        if self.normr <= self.tolb:
+            self._finish(0, it)  # x update of iteration it still pending: final pass
+        elif it == self.maxit:
+            self.pend_maxit = 1  # -5 or -1: decided by the scan of the final pass
+            self.status = 1
+        else:
+            self.rho1, self.rho = self.rho, rz
+            self.it = it + 1
+            self.head_rho0 = 1 if rz == 0.0 else 0
+            self.head_beta0 = 0
+            if rz != 0.0:
+                self.beta = self.rho / self.rho1
+                self.head_beta0 = 1 if self.beta == 0.0 else 0
+
+    def fetch(self):
+        return self
+
+    def hist(self, first, count):
+        return np.array([self._hist.get(i, np.nan) for i in range(first, first + count)])
+
+    def close(self):
+        pass
+
+
+class HostMinresState:
+    """Python mirror of psp_solvers.hip's minres_scalar_alpha / minres_scalar_beta (minres.c:129-192)."""
+
+    def __init__(self, norm_r0, beta0, tol, maxit, want_hist):
+        self.beta, self.beta_old, self.alpha = beta0, 1.0, 0.0
+        self.c = self.c_old = 1.0
+        self.s = self.s_old = 0.0
+        self.eta, self.norm_rmr, self.norm_r0, self.errtol, self.relres = beta0, norm_r0, norm_r0, tol, 0.0
+        self.c1 = self.c2 = self.r1 = self.r2 = self.r3 = self.c_eta = 0.0
+        self.status = self.stop = self.skip = 0
+        self.info, self.iter, self.it_max = -1, 1, maxit
+        self._hist = {} if want_hist else None
+
+    def scalar_alpha(self, alpha):
+        if self.status:
+            return
+        if self.stop:
+            self.status = 1
+            return
+        self.alpha = alpha
+        self.c1 = alpha / self.beta
+        self.c2 = self.beta / self.beta_old
+
+    def scalar_beta(self, b2):
+        if self.status:
+            return
+        alpha, beta_old = self.alpha, self.beta
+        self.beta_old = beta_old
+        if b2 < 0.0:  # minres.c:144-146
+            self.status = self.skip = 1
+            self.info = -3
+            return
+        beta = float(np.sqrt(b2))
+        self.beta = beta
+        c_oold, c_old, s_oold, s_old = self.c_old, self.c, self.s_old, self.s
+        self.c_old, self.s_old = c_old, s_old
+        r1_hat = c_old * alpha - c_oold * s_old * beta_old
+        r1 = float(np.sqrt(r1_hat * r1_hat + beta * beta))
+        r2 = s_old * alpha + c_oold * c_old * beta_old
+        r3 = s_oold * beta_old
+        if r1 == 0.0:  # minres.c:160-162
+            self.status = self.skip = 1
+            self.info = -6
+            return
+        self.c, self.s = r1_hat / r1, beta / r1
+        self.r1, self.r2, self.r3 = r1, r2, r3
+        self.c_eta = self.c * self.eta
+        self.eta = -self.s * self.eta
+        self.norm_rmr = self.norm_rmr * abs(self.s)
+        if self._hist is not None:
+            self._hist[self.iter] = self.norm_rmr
+        conv = self.norm_rmr < self.errtol * self.norm_r0
+        if self.iter >= self.it_max or conv:
+            self.stop = self.skip = 1
+            self.relres = self.norm_rmr / self.norm_r0
+            self.info = 0 if conv else -1
+        else:
+            self.iter += 1
+
+    def fetch(self):
+        return self
+
+    def hist(self, first, count):
+        return np.array([self._hist.get(i, np.nan) for i in range(first, first + count)])
+
+    def close(self):
+        pass
+
+
+class HostStateOps:
+    """The state-driven phase ops (kd_*) expressed with a backend's host-scalar ops + the Python state
+    mirrors above: what a CPU test backend inherits so that dist_pcg / dist_minres run the same driver
+    code as HipBackend.  `scal` is an 8-double tensor like HipBackend's."""
+
+    @property
+    def scal(self):
+        if getattr(self, "_scal8", None) is None:
+            self._scal8 = torch.zeros(8, dtype=torch.float64)
+        return self._scal8
+
+    def pcg_state(self, n2b, tolb, normr0, rho0, maxit, want_hist):
+        return HostPcgState(n2b, tolb, normr0, rho0, maxit, want_hist)
+
+    def kd_px_update(self, st, r, dinv, p_owned, x):
+        if not st.status:
+            self.scal[1] = self.px_update(r, dinv, st.beta, st.it == 1, st.alpha_x, bool(st.xpend), p_owned, x)[0]
+
+    def kd_matvec_overlap(self, st, A, p_ext, p_offset, q, interior, wait):
+        if st.status:
+            if wait is not None:
+                wait()
+            return
+        if wait is None:
+            self.scal[0] = self.matvec_dot(A, p_ext, p_offset, q)[0]
+        else:
+            self.scal[0] = self.matvec_overlap(A, p_ext, p_offset, q, interior, wait, True)[0]
+
+    def kd_pcg_scalar_xpq(self, st):
+        st.scalar_x(float(self.scal[1]))
+        st.scalar_pq(float(self.scal[0]))
+
+    def kd_r_update(self, st, q, dinv, r):
+        if not st.status:
+            self.scal[2:4] = self.r_update(st.alpha, q, dinv, r)
+
+    def kd_pcg_scalar_r(self, st):
+        st.scalar_r(float(self.scal[2]), float(self.scal[3]))
+
+    def minres_state(self, norm_r0, beta0, tol, maxit, want_hist):
+        return HostMinresState(norm_r0, beta0, tol, maxit, want_hist)
+
+    def kd_minres_scale(self, st, y, v_owned):
+        if not st.skip:
+            self.scale_div(y, st.beta, v_owned)
+
+    def kd_minres_matvec(self, st, A, v_ext, v_offset, av, interior, wait):
+        if st.skip:
+            if wait is not None:
+                wait()
+            return
+        if wait is None:
+            self.scal[0] = self.matvec_dot(A, v_ext, v_offset, av)[0]
+        else:
+            self.scal[0] = self.matvec_overlap(A, v_ext, v_offset, av, interior, wait, True)[0]
+
+    def kd_minres_lanczos(self, st, av, v_hat, v_hat_old, dinv, y):
+        if not st.skip:
+            self.scal[4] = self.lanczos(av, st.c1, st.c2, v_hat, v_hat_old, dinv, y)[0]
+
+    def kd_minres_scalar(self, st, which):
+        if which == 0:
+            st.scalar_alpha(float(self.scal[0]))
+        else:
+            st.scalar_beta(float(self.scal[4]))
+
+    def kd_minres_wx(self, st, v_owned, w, w_old, x):
+        if not st.status:
+            self.minres_wx(v_owned, st.r1, st.r2, st.r3, st.c_eta, w, w_old, x)
 
 
 class Comm:
@@ -372,8 +730,22 @@ class DistCSR:
         return self.be.matvec_overlap(self.A, v_ext, self.plan.p_offset, y, self.plan.interior, wait, want_dot)
 
 
+def _matvec_state(A, kd, st, v_ext, y):
+    """y = A v for the owned rows through a state-driven kernel (kd = be.kd_matvec_overlap or
+    be.kd_minres_matvec): the ghost exchange is started first and overlapped with the interior rows;
+    the local v_owned . y lands in be.scal[0]"""
+    if A.comm.world == 1:
+        kd(st, A.A, v_ext, A.plan.p_offset, y, (0, A.n_local), None)
+        return
+    sends, recvs = A._halo_ops(v_ext)
+    wait = A.comm.exchange_start(sends, recvs)
+    kd(st, A.A, v_ext, A.plan.p_offset, y, A.plan.interior, wait)
+
+
 def dist_pcg_mode():
     """which loop dist_pcg runs (bench.py prints it)"""
+    if os.environ.get("PSP_DIST_DEVSCALARS", "1") != "0":
+        return "device-resident scalars, in-stream all-reduces, lazy x update"
     return "host scalars, lazy x update" if os.environ.get("PSP_DIST_LAZYX", "1") != "0" else "host scalars, eager"
 
 
@@ -385,8 +757,9 @@ def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     if hint is not None:
         hint(dinv)
     lazy = hasattr(A.be, "px_update") and os.environ.get("PSP_DIST_LAZYX", "1") != "0"
+    devs = hasattr(A.be, "kd_px_update") and os.environ.get("PSP_DIST_DEVSCALARS", "1") != "0"
     try:
-        return (_dist_pcg_lazy if lazy else _dist_pcg)(A, b, x, tol, maxit, dinv, hist)
+        return (_dist_pcg_dev if devs else _dist_pcg_lazy if lazy else _dist_pcg)(A, b, x, tol, maxit, dinv, hist)
     finally:
         if hint is not None:
             A.be.unhint(dinv)
@@ -544,3 +917,136 @@ def _dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
             break
         it += 1
     return info, it, normr / n2b
+
+
+PCG_BATCH = 16  # iterations enqueued between two reads of the device state
+
+
+def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None):
+    """_dist_pcg_lazy with the scalars on the device: per iteration the host only enqueues -- px update,
+    SpMV around the halo exchange, all-reduce #1 {p.q, nonstag} (in stream order), the scalar step that
+    takes pcg.c:159-162 / :101-125's branches, r update, all-reduce #2 {r.r, r.z}, the scalar step of
+    pcg.c:152-157 -- and reads the state back once per PCG_BATCH iterations.  Every kernel of an iteration
+    that starts after the loop has ended is a no-op (the all-reduces still run; their operands are ignored).
+    Same results as the host-scalar loops bit for bit (tests/test_distributed_cpu.py, test_gpu_distributed.py)."""
+    be, comm = A.be, A.comm
+    n = A.n_local
+    r, q = be.zeros(n), be.zeros(n)
+    p_ext = A.new_ext()
+    p = A.owned(p_ext)
+
+    s = comm.allreduce_sum(be.dot(b, b).clone()).tolist()
+    n2b = float(np.sqrt(s[0]))
+    if n2b == 0.0:  # pcg.c:58-67
+        x.zero_()
+        return 0, 0, 0.0
+    tolb = tol * n2b
+    p.copy_(x)
+    A.matvec(p_ext, r)
+    s = comm.allreduce_sum(be.residual(b, r, dinv).clone()).tolist()
+    normr = float(np.sqrt(s[0]))
+    if hist is not None:
+        hist.append(normr)
+    if normr <= tolb:  # pcg.c:77-84
+        return 0, 0, normr / n2b
+    if maxit < 1:
+        return -1, 1, normr / n2b
+    if s[1] == 0.0:  # pcg.c:101-104 in iteration 1
+        return -2, 1, normr / n2b
+    st = be.pcg_state(n2b, tolb, normr, s[1], maxit, hist is not None)
+    try:
+        enq = 0
+        while True:
+            batch = max(1, min(PCG_BATCH, maxit - enq))
+            for _ in range(batch):
+                be.kd_px_update(st, r, dinv, p, x)                      # -> scal[1]
+                _matvec_state(A, be.kd_matvec_overlap, st, p_ext, q)    # -> scal[0]
+                comm.allreduce_sum(be.scal[0:2])                        # all-reduce #1
+                be.kd_pcg_scalar_xpq(st)
+                be.kd_r_update(st, q, dinv, r)                          # -> scal[2:4]
+                comm.allreduce_sum(be.scal[2:4])                        # all-reduce #2
+                be.kd_pcg_scalar_r(st)
+            enq += batch
+            f = st.fetch()
+            if f.status:
+                break
+        info, it, relres = f.info, f.iter, f.relres
+        if f.xpend:  # the x update (and scan) of the last iteration
+            flag = comm.allreduce_sum(be.x_update(f.alpha_x, p, x).clone()).tolist()
+            if f.pend_maxit:
+                stag = bool(f.stag0) or flag[0] == 0.0
+                info, it = (-5, maxit) if stag else (-1, maxit + 1)  # pcg.c:159-165
+                relres = f.normr / f.n2b
+        if hist is not None:
+            cnt = min(it, maxit)
+            if cnt >= 1:
+                hist.extend(float(v) for v in st.hist(1, cnt))
+        return info, it, relres
+    finally:
+        st.close()
+
+
+def dist_minres(A, b, x, tol, maxit, dinv=None, hist=None):
+    """info, iter, relres = dist_minres(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices: the
+    reference's preconditioned MINRES (pysparse/itsolvers/src/minres.c:43-200) on row blocks, K = None
+    (dinv is None) or jacobi(steps=1) given by its local dinv slice.  Two all-reduces per iteration --
+    alpha = v.Av (minres.c:129) and beta^2 = v_hat.y (:143) -- issued in stream order; the Lanczos / Givens
+    recurrences run on the device (psp_minresstate_*), the host reads the state once per PCG_BATCH
+    iterations.  x is updated in place; every rank returns the same triple."""
+    be, comm = A.be, A.comm
+    n = A.n_local
+    v_hat, v_hat_old = be.zeros(n), be.zeros(n)
+    wv, w_old, av = be.zeros(n), be.zeros(n), be.zeros(n)
+    v_ext = A.new_ext()
+    v = A.owned(v_ext)
+    y = be.zeros(n) if dinv is not None else None
+    hint = getattr(be, "hint_constant", None) if dinv is not None else None
+    if hint is not None:
+        hint(dinv)
+    st = None
+    try:
+        # v_hat = b - A x, norm_r0 (minres.c:67-71); y = K v_hat, beta = sqrt(v_hat.y) (:73-82)
+        v.copy_(x)
+        A.matvec(v_ext, v_hat)
+        s = comm.allreduce_sum(be.residual(b, v_hat, dinv).clone()).tolist()
+        norm_r0 = float(np.sqrt(s[0]))
+        beta = s[1]
+        if dinv is not None:
+            be.jacobi(v_hat, dinv, y)
+        if beta < 0.0:  # minres.c:79-80
+            return -3, 0, 0.0
+        beta = float(np.sqrt(beta))
+        if hist is not None:
+            hist.append(norm_r0)
+        conv0 = norm_r0 < tol * norm_r0
+        if maxit < 1 or conv0:  # minres.c:114 before the first iteration
+            return (0 if conv0 else -1), 0, float(np.float64(norm_r0) / np.float64(norm_r0))
+        st = be.minres_state(norm_r0, beta, tol, maxit, hist is not None)
+        enq = 0
+        while True:
+            batch = max(1, min(PCG_BATCH, maxit - enq))
+            for _ in range(batch):
+                be.kd_minres_scale(st, y if dinv is not None else v_hat, v)   # v = y / beta
+                _matvec_state(A, be.kd_minres_matvec, st, v_ext, av)          # -> scal[0]
+                comm.allreduce_sum(be.scal[0:1])                              # all-reduce #1: alpha
+                be.kd_minres_scalar(st, 0)
+                be.kd_minres_lanczos(st, av, v_hat, v_hat_old, dinv, y)       # -> scal[4]
+                v_hat, v_hat_old = v_hat_old, v_hat
+                comm.allreduce_sum(be.scal[4:5])                              # all-reduce #2: beta^2
+                be.kd_minres_scalar(st, 1)
+                be.kd_minres_wx(st, v, wv, w_old, x)
+                wv, w_old = w_old, wv
+            enq += batch
+            f = st.fetch()
+            if f.status or f.stop:
+                break
+        if hist is not None:
+            cnt = min(f.iter, maxit)
+            if cnt >= 1:
+                hist.extend(float(t) for t in st.hist(1, cnt) if not np.isnan(t))
+        return f.info, f.iter, (f.relres if f.info in (0, -1) else 0.0)
+    finally:
+        if st is not None:
+            st.close()
+        if hint is not None:
+            be.unhint(dinv)

@@ -5,9 +5,10 @@ import numpy as np
 import torch
 
 from oracle import oracle as O
+from pysparse_amd.distributed import HostStateOps
 
 
-class OracleBackend:
+class OracleBackend(HostStateOps):
     def zeros(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
@@ -104,6 +105,26 @@ class OracleBackend:
         if alpha != 0.0:
             xn += alpha * pn
         return torch.tensor([flag], dtype=torch.float64)
+
+    # ---- MINRES pieces (minres.c:123-124, :131-143, :172-180), host scalars
+    def jacobi(self, x, dinv, y):
+        y.numpy()[:] = x.numpy() * dinv.numpy()
+
+    def scale_div(self, y, beta, v):
+        v.numpy()[:] = y.numpy() / beta
+
+    def lanczos(self, av, c1, c2, v_hat, v_hat_old, dinv, y):
+        vo = v_hat_old.numpy()
+        vo[:] = av.numpy() - c1 * v_hat.numpy() - c2 * vo  # the caller swaps the names
+        if dinv is not None:
+            y.numpy()[:] = vo * dinv.numpy()
+            return torch.tensor([float(np.dot(vo, y.numpy()))], dtype=torch.float64)
+        return torch.tensor([float(np.dot(vo, vo))], dtype=torch.float64)
+
+    def minres_wx(self, v, r1, r2, r3, c_eta, w, w_old, x):
+        wo = w_old.numpy()
+        wo[:] = (v.numpy() - r3 * wo - r2 * w.numpy()) / r1  # the caller swaps the names
+        x.numpy()[:] += c_eta * wo
 
     def gather(self, idx, v, out):
         out.numpy()[:] = v.numpy()[idx.numpy()]

@@ -88,6 +88,41 @@ def _worker(rank, world, port, case, q):
             same = same and tuple(re_) == tuple(rl) and bool(np.array_equal(xe.numpy(), xl.numpy()))
         out["lazy_equals_eager"] = same
         out["lazy_infos"] = sorted(infos)
+        # device-resident-scalar driver (here: its Python state mirror, batches of 16 iterations between two
+        # reads of the state) against the host-scalar lazy loop at every truncation point, bit for bit --
+        # results, iterates and residual histories
+        same_dev, dev_infos = True, set()
+        for maxit in list(range(1, 60, 3)) + [400]:
+            xl, xd = be.zeros(hi - lo), be.zeros(hi - lo)
+            hl, hd = [], []
+            rl = D._dist_pcg_lazy(A, bl, xl, 0.0, maxit, dl, hl)
+            rd = D._dist_pcg_dev(A, bl, xd, 0.0, maxit, dl, hd)
+            dev_infos.add(rd[0])
+            same_dev = (same_dev and tuple(rl) == tuple(rd) and bool(np.array_equal(xl.numpy(), xd.numpy()))
+                        and hl == hd)
+        for tol_ in (1e-3, 1e-9):
+            xl, xd = be.zeros(hi - lo), be.zeros(hi - lo)
+            same_dev = same_dev and tuple(D._dist_pcg_lazy(A, bl, xl, tol_, 500, None)) == \
+                tuple(D._dist_pcg_dev(A, bl, xd, tol_, 500, None)) and bool(np.array_equal(xl.numpy(), xd.numpy()))
+        out["dev_equals_lazy"] = same_dev
+        out["dev_infos"] = sorted(dev_infos)
+        # MINRES on row blocks against the oracle's MINRES on the global system
+        mres = {}
+        for name, dg in (("none", None), ("jacobi", dinv_g)):
+            for tol_, mx in ((1e-9, 500), (1e-30, 7)):
+                xo = np.zeros(n)
+                ref = O.minres(G, bg, xo, tol_, mx, dg, hist=True)
+                x = be.zeros(hi - lo)
+                hist = []
+                got = D.dist_minres(A, be.from_numpy(bg[lo:hi]), x, tol_, mx,
+                                    be.from_numpy(dg[lo:hi]) if dg is not None else None, hist)
+                err = float(np.abs(x.numpy() - xo[lo:hi]).max() / np.abs(xo).max())
+                hr = ref[3][:ref[1] + 1]
+                herr = float(np.max(np.abs(np.array(hist) - hr) / hr)) if len(hist) == len(hr) else np.inf
+                mres[(name, mx)] = (ref[:3], got, err, herr)
+        out["minres"] = mres
+        x = be.from_numpy(np.ones(hi - lo))
+        out["minres_maxit0"] = D.dist_minres(A, be.from_numpy(bg[lo:hi]), x, 1e-9, 0)
         # maxit exhausted -> iter = maxit + 1; zero rhs -> (0, 0, 0.0)
         x = be.zeros(hi - lo)
         out["maxit"] = D.dist_pcg(A, be.from_numpy(bg[lo:hi]), x, 1e-30, 3)
@@ -130,6 +165,13 @@ def test_row_partitioned_spmv_and_pcg(world, case):
             assert nhist == got[1] + 1
         assert out["lazy_equals_eager"], out["lazy_infos"]
         assert -1 in out["lazy_infos"] and (-5 in out["lazy_infos"] or case[0] != "poisson")
+        assert out["dev_equals_lazy"], out["dev_infos"]
+        assert -1 in out["dev_infos"] and (-5 in out["dev_infos"] or case[0] != "poisson")
+        for key, (ref, got, err, herr) in out["minres"].items():
+            assert tuple(got[:2]) == tuple(ref[:2]), (key, ref, got)
+            assert abs(got[2] - ref[2]) <= 1e-8 * abs(ref[2]), (key, ref, got)
+            assert err < 1e-12 and herr < 1e-8, (key, err, herr)
+        assert tuple(out["minres_maxit0"][:2]) == (-1, 0)
         assert tuple(out["maxit"][:2]) == (-1, 4)
         assert out["zero"] == (0, 0, 0.0, 0.0)
     # every rank reports the same triple

@@ -37,6 +37,30 @@ def test_world1_matches_single_gpu_solver(oracle):
             got = D.dist_pcg(A, be.from_numpy(b_np), x, 1e-9, 1000, be.from_numpy(dinv) if dinv is not None else None)
             assert tuple(got[:2]) == tuple(ref[:2])
             assert np.abs(x.cpu().numpy() - xo).max() <= 1e-12 * np.abs(xo).max()
+            # the three drivers -- device-resident scalars (default), host-scalar lazy, host-scalar eager --
+            # are the same algorithm: bitwise identical results, iterates and histories at every truncation
+            bt = be.from_numpy(b_np)
+            dt = be.from_numpy(dinv) if dinv is not None else None
+            for tol, mx in [(1e-9, 1000)] + [(0.0, k) for k in (1, 2, 3, 15, 16, 17, 33, 50)]:
+                res = []
+                for fn in (D._dist_pcg_dev, D._dist_pcg_lazy, D._dist_pcg):
+                    xx, hh = be.zeros(n), []
+                    r = fn(A, bt, xx, tol, mx, dt, hh)
+                    res.append((tuple(r), xx.cpu().numpy().copy(), hh))
+                for other in res[1:]:
+                    assert other[0] == res[0][0] and np.array_equal(other[1], res[0][1]) and other[2] == res[0][2]
+            # MINRES on row blocks == the oracle's MINRES
+            for tol, mx in ((1e-9, 1000), (1e-30, 9)):
+                xo = np.zeros(n)
+                refm = oracle.minres(G, b_np, xo, tol, mx, dinv, hist=True)
+                x = be.zeros(n)
+                hh = []
+                gotm = D.dist_minres(A, bt, x, tol, mx, dt, hh)
+                assert tuple(gotm[:2]) == tuple(refm[:2])
+                assert abs(gotm[2] - refm[2]) <= 1e-8 * refm[2]
+                assert np.abs(x.cpu().numpy() - xo).max() <= 1e-12 * np.abs(xo).max()
+                hr = refm[3][:refm[1] + 1]
+                assert len(hh) == len(hr) and np.max(np.abs(np.array(hh) - hr) / hr) <= 1e-8
     finally:
         from pysparse_amd import _capi
         _capi.lib().psp_set_stream(None)
@@ -117,6 +141,14 @@ def _worker(rank, world, port, q):
         x = be.zeros(hi - lo)
         got = D.dist_pcg(A, be.from_numpy(bg[lo:hi]), x, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
         out["pcg"] = (ref, got, float(np.abs(x.cpu().numpy() - xo[lo:hi]).max() / np.abs(xo).max()))
+        xl = be.zeros(hi - lo)
+        gl = D._dist_pcg_lazy(A, be.from_numpy(bg[lo:hi]), xl, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
+        out["dev_equals_lazy"] = bool(tuple(gl) == tuple(got) and torch.equal(xl, x))
+        xo = np.zeros(n)
+        refm = O.minres(G, bg, xo, 1e-9, 1000, dinv_g)
+        xm = be.zeros(hi - lo)
+        gotm = D.dist_minres(A, be.from_numpy(bg[lo:hi]), xm, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
+        out["minres"] = (refm, gotm, float(np.abs(xm.cpu().numpy() - xo[lo:hi]).max() / np.abs(xo).max()))
         q.put((rank, out))
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001
@@ -141,3 +173,6 @@ def test_two_ranks_sharing_one_gpu():
         ref, got, err = out["pcg"]
         assert tuple(got[:2]) == tuple(ref[:2])
         assert err < 1e-12
+        assert out["dev_equals_lazy"]
+        ref, got, err = out["minres"]
+        assert tuple(got[:2]) == tuple(ref[:2]) and err < 1e-12

@@ -417,6 +417,74 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     assert all(o == outs[0] for o in outs)  # bitwise: same products, same reduction order
 
 
+def test_minres_loop_variants_agree(oracle):
+    """MINRES with device-resident scalars (default: Lanczos / Givens recurrences evaluated by the thread that
+    finishes each reduction, 16 iterations enqueued per read of the state) against the host-scalar loop
+    (PSP_MINRES_ASYNC=0): the same algorithm -- identical info / iteration counts / residual histories /
+    iterates, on the scaled index-free path (stencil csr and sss), without it (PSP_MINRES_SCALED=0) and on a
+    general CSR matrix (csr_spmv_w2, variant 16578); with and without Jacobi; converged, truncated at every
+    small maxit, and maxit = 0."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);"
+        "from pysparse_amd.device import DeviceCSR, DeviceSSS, DeviceJacobi, minres;"
+        "out = [];\n"
+        "for M in (DeviceCSR.poisson(60, 50), DeviceSSS.poisson(20, 18, 16), 'w2'):\n"
+        "    if M == 'w2':\n"
+        "        M = DeviceCSR.poisson(60, 50); M.set_variant(16578)\n"
+        "    n = M.shape[0]; b = np.random.default_rng(3).standard_normal(n)\n"
+        "    for K in (None, DeviceJacobi(M)):\n"
+        "        for tol, mx in [(1e-9, 4000)] + [(0.0, k) for k in range(0, 40, 3)]:\n"
+        "            x = np.zeros(n); r = minres(M, b, x, tol, mx, K, hist=True)\n"
+        "            out.append([r[0], r[1], r[2], float(x[0]), float(x[n // 2]), float(np.abs(x).sum()),"
+        " [float(t) for t in r[3] if t == t]])\n"
+        "print(json.dumps(out))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"PSP_MINRES_ASYNC": "0"}, {}, {"PSP_MINRES_SCALED": "0"},
+                {"PSP_MINRES_SCALED": "0", "PSP_MINRES_ASYNC": "0"}):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    assert outs[0][0][0] == 0 and outs[0][0][1] > 50  # the first case converges
+    assert all(o == outs[0] for o in outs)  # bitwise: same products, same reduction order
+
+
+def test_minres_async_special_exits(oracle):
+    """exits of the device-resident MINRES loop: -3 (indefinite preconditioner: beta^2 < 0 inside the loop),
+    a zero right-hand side (norm_r0 = 0: NaN relres like the reference), maxit = 0"""
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, minres
+    A = oracle.poisson_csr(12, 10)
+    n = A.shape[0]
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+
+    class Indef:  # preconditioner that is not positive definite -> generic path, -3 at setup or in the loop
+        shape = (n, n)
+
+        def precon(self, x, y):
+            y[:] = -x
+    b = np.random.default_rng(0).standard_normal(n)
+    x = np.zeros(n)
+    assert minres(D, b, x, 1e-9, 50, Indef())[0] == -3
+    # variable-sign diagonal through the fused (device-scalar) path: dinv with negative entries
+    val = A.val.copy()
+    rows = np.repeat(np.arange(n), np.diff(A.ind))
+    val[(A.col == rows) & (rows % 2 == 1)] *= -1.0
+    Dn = DeviceCSR.from_arrays(A.shape, A.ind, A.col, val)
+    An = oracle.CSR(A.shape, val, A.col, A.ind)
+    xo, xg = np.zeros(n), np.zeros(n)
+    dinv = oracle.jacobi_dinv(An.diagonal())
+    ref = oracle.minres(An, b, xo, 1e-9, 200, dinv)
+    got = minres(Dn, b, xg, 1e-9, 200, DeviceJacobi(Dn))
+    assert got[:2] == ref[:2] and (ref[0] in (-3, -6) or np.abs(xg - xo).max() <= 1e-10 * np.abs(xo).max())
+    x = np.ones(n)
+    r = minres(D, np.zeros(n), x, 1e-9, 10)
+    assert r[1] == 0
+    assert minres(D, b, np.zeros(n), 1e-9, 0)[:2] == (-1, 0)
+
+
 def test_pcg_jacobi_constant_and_variable_diagonal(oracle):
     """precon.jacobi registers a dinv that holds one value everywhere (constant-diagonal operator) so
     the vector kernels form z = r*c without streaming dinv; a variable diagonal takes the array path.
