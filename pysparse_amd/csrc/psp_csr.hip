@@ -743,7 +743,9 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const unsigned short *__restrict__ col16, const int *__restrict__ blist,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    const int *__restrict__ perm) {
+    const int *__restrict__ perm, const int *__restrict__ rowperm) {
+  // rowperm (renumbered operators, psp_reorder.hip): row r of this matrix is row rowperm[r] of the
+  // caller's: its sum is stored to y[rowperm[r]] and meets dotv[rowperm[r]]
   constexpr int WT = 1024;
   constexpr int STEPS = WT / 256;
   constexpr int E = 64 * NP;
@@ -865,11 +867,12 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
         }
+        const int ro_ = rowperm ? rowperm[r0 + i] : r0 + i;
         if constexpr (NTS)
-          __builtin_nontemporal_store(acc, &y[r0 + i]);
+          __builtin_nontemporal_store(acc, &y[ro_]);
         else
-          y[r0 + i] = acc;
-        if (dotv) dsum += dotv[r0 + i] * acc;
+          y[ro_] = acc;
+        if (dotv) dsum += dotv[ro_] * acc;
       }
     }
   }
@@ -1823,6 +1826,12 @@ struct CsrExtra {
   unsigned short *dia_mask = nullptr;  // dia_no <= 16
   unsigned *dia_mask32 = nullptr;      // dia_no > 16
   psp_csr *transposed = nullptr;       // A^T as its own handle (matvec_transp on irregular matrices)
+  // renumbered copy R = P A P^T for csr_spmv_w3 (psp_reorder.hip): state -1 not examined, 0 none, 1 built
+  int reorder_state = -1;
+  psp_csr *reordered = nullptr;
+  int *perm = nullptr;     // new -> old (device)
+  double *xp = nullptr;    // x in the new numbering (scratch, nrows doubles)
+  int orig_max_blocks = 0;
 };
 
 }  // namespace psp
@@ -2390,6 +2399,67 @@ done:
   return PSP_OK;
 }
 
+// renumbered copy of an irregular square operator for csr_spmv_w3 (psp_reorder.hip); built on first use
+namespace psp {
+int reorder_rcm_host(int n, const int *ind, const int *col, const double *val, std::vector<int> &perm,
+                     std::vector<int> &rind, std::vector<int> &rcol, std::vector<double> &rval);
+int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);
+}  // namespace psp
+
+static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_blocks) {
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    if (ex->reorder_state >= 0) return PSP_OK;
+    ex->reorder_state = 0;
+    ex->orig_max_blocks = orig_max_blocks;
+  }
+  static const bool off = [] {
+    const char *e = getenv("PSP_SPMV_REORDER");
+    return e && atoi(e) == 0;
+  }();
+  // worth it when the gather pass (20 n bytes) is small against the matrix stream (12 nnz)
+  if (off || A->no_reorder || A->w4_only || A->nrows != A->ncols || A->nrows < 1024 ||
+      (long)A->nnz < 12L * A->nrows)
+    return PSP_OK;
+  const int n = A->nrows;
+  const size_t nnz = (size_t)A->nnz;
+  std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
+  std::vector<double> val(nnz), rval;
+  PSP_HIP(hipMemcpy(ind.data(), A->ind, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  PSP_HIP(hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+  PSP_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+  PSP_TRY(psp::reorder_rcm_host(n, ind.data(), col.data(), val.data(), perm, rind, rcol, rval));
+  psp_csr *R = nullptr;
+  int rc = alloc_csr(n, n, (long)nnz, &R);
+  if (rc != PSP_OK) return PSP_OK;  // no room: stay with the gather kernels
+  R->no_reorder = true;
+  int *dperm = nullptr;
+  double *xp = nullptr;
+  bool ok = hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void **)&dperm, sizeof(int) * (size_t)n) == hipSuccess &&
+            hipMalloc((void **)&xp, sizeof(double) * (size_t)n) == hipSuccess &&
+            hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+            finalize_csr(R) == PSP_OK;
+  ChunkTable *t = nullptr;
+  if (ok) ok = get_chunk_table(R, 1024, &t) == PSP_OK && ensure_rowoff(R, t) == PSP_OK && t->np != 0 &&
+               ensure_w3(R, t) == PSP_OK && t->nb > 0;
+  if (!ok) {  // the new numbering does not qualify either
+    (void)hipGetLastError();
+    psp_csr_destroy(R);
+    if (dperm) (void)hipFree(dperm);
+    if (xp) (void)hipFree(xp);
+    return PSP_OK;
+  }
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  ex->reordered = R;
+  ex->perm = dperm;
+  ex->xp = xp;
+  ex->reorder_state = 1;
+  return PSP_OK;
+}
+
 static int ensure_packed(const psp_csr *A, char **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   psp::CsrExtra &ex = g_extra[A];
@@ -2452,11 +2522,11 @@ static int w3_ab(const psp_csr *A) { return (A->variant >= 0 ? (A->variant >> 25
 template <int NP, int NB>
 static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
                             int c1, const double *x, double *y, const double *dotv, double *pbuf,
-                            const int *skip, const int *perm) {
+                            const int *skip, const int *perm, const int *rowperm) {
 #define PSP_W3_AB(NTL, PAIRS)                                                                          \
   hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, NTL, PAIRS>), dim3(grid), dim3(256), 0, stream(), c0, c1, \
                      stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
-                     A->val, x, y, dotv, pbuf, skip, perm)
+                     A->val, x, y, dotv, pbuf, skip, perm, rowperm)
   const int ab = w3_ab(A);
   if (nts && ab == 1) PSP_W3_AB(true, false);
   else if (nts && ab == 2) PSP_W3_AB(false, true);
@@ -2464,28 +2534,55 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
   else if (nts)
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm);
   else
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, false>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm);
 }
 
 template <int NP>
 static void launch_w3_np(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
                          int c1, const double *x, double *y, const double *dotv, double *pbuf,
-                         const int *skip, const int *perm) {
-  if (t->nb == 32) launch_w3_np_nb<NP, 32>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
-  else if (t->nb == 64) launch_w3_np_nb<NP, 64>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
-  else launch_w3_np_nb<NP, 128>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+                         const int *skip, const int *perm, const int *rowperm) {
+  if (t->nb == 32) launch_w3_np_nb<NP, 32>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
+  else if (t->nb == 64) launch_w3_np_nb<NP, 64>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
+  else launch_w3_np_nb<NP, 128>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
 }
 
 static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0, int c1,
                       const double *x, double *y, const double *dotv, double *pbuf, const int *skip,
-                      const int *perm = nullptr) {
-  if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
-  else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
-  else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm);
+                      const int *perm = nullptr, const int *rowperm = nullptr) {
+  if (t->np == 2) launch_w3_np<2>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
+  else if (t->np == 3) launch_w3_np<3>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
+  else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
+}
+
+// y = A x through the renumbered copy: xp = x[perm]; csr_spmv_w3 on R stores row i to y[perm[i]]
+static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, const double *x, double *y,
+                            const double *dotv, double *partials, int *nparts, const int *skip) {
+  psp_csr *R = ex->reordered;
+  ChunkTable *t;
+  PSP_TRY(get_chunk_table(R, 1024, &t));
+  int grid = (t->nchunks + 3) / 4;
+  if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
+  double *pbuf = partials;
+  if (partials && grid > kMaxParts) {
+    PSP_TRY(ensure_big_partials(ex, grid));
+    pbuf = ex->big_partials;
+  }
+  PSP_TRY(psp::reorder_gather(A->nrows, ex->perm, x, ex->xp, skip));
+  R->variant = A->variant;
+  launch_w3(R, t, true, grid, stripe, 0, t->nchunks, ex->xp, y, dotv, pbuf, skip, nullptr, ex->perm);
+  PSP_LAUNCH_CHECK();
+  int np = grid;
+  if (pbuf != partials) {
+    np = kFold;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid, partials, np);
+    PSP_LAUNCH_CHECK();
+  }
+  if (nparts) *nparts = np;
+  return PSP_OK;
 }
 
 // y = A (x ./ xdiv) and the partials of (x ./ xdiv) . y, for the two index-free layouts only
@@ -2722,6 +2819,15 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
         ex->big_cap = grid;
       }
       pbuf = ex->big_partials;
+    }
+    if (!use_w3 && v.w2 && v.w3 && t->max_blocks > 0) {  // irregular numbering: try the renumbered copy
+      psp::CsrExtra *exr;
+      {
+        std::lock_guard<std::mutex> lk(g_extra_mu);
+        exr = &g_extra[A];
+      }
+      PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
+      if (exr->reorder_state == 1) return launch_reordered(A, exr, stripe, x, y, dotv, partials, nparts, skip);
     }
     if (use_w3) {
       launch_w3(A, t, v.full_grid, grid, stripe, 0, t->nchunks, x, y, dotv, pbuf, skip, perm);
@@ -3187,12 +3293,15 @@ int64_t psp_csr_nnz64(const psp_csr_t *A) { return A ? (A->w4_only ? A->nnz64 : 
 
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
-  psp_csr *transposed = nullptr;
+  psp_csr *transposed = nullptr, *reordered = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_extra_mu);
     auto it = g_extra.find(A);
     if (it != g_extra.end()) {
       transposed = it->second.transposed;
+      reordered = it->second.reordered;
+      if (it->second.perm) (void)hipFree(it->second.perm);
+      if (it->second.xp) (void)hipFree(it->second.xp);
       for (auto &t : it->second.t) {
         if (t.second.tab) (void)hipFree(t.second.tab);
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
@@ -3209,6 +3318,7 @@ int psp_csr_destroy(psp_csr_t *A) {
     }
   }
   if (transposed) psp_csr_destroy(transposed);  // outside the lock: it has side tables of its own
+  if (reordered) psp_csr_destroy(reordered);
   (void)hipFree(A->ind);
   (void)hipFree(A->col);
   (void)hipFree(A->val);
@@ -3371,6 +3481,22 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
         if (v.w3) {
           PSP_TRY(ensure_w3(A, t));
           vals[1] = t->max_blocks;
+          if (t->nb == 0 && t->max_blocks > 0) {  // the renumbered copy (psp_reorder.hip), if it qualifies
+            psp::CsrExtra *exr;
+            {
+              std::lock_guard<std::mutex> lk(g_extra_mu);
+              exr = &g_extra[A];
+            }
+            PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
+            if (exr->reorder_state == 1) {
+              ChunkTable *rt;
+              PSP_TRY(get_chunk_table(exr->reordered, 1024, &rt));
+              k = "csr_spmv_w3_rcm";
+              vals[0] = rt->nb;
+              vals[1] = rt->max_blocks;
+              vals[3] = t->max_blocks;  // what the stored numbering needs
+            }
+          }
           if (t->nb > 0) {
             k = "csr_spmv_w3";
             vals[0] = t->nb;

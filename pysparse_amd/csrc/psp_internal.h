@@ -109,6 +109,7 @@ struct psp_csr {
   bool w4_only = false;
   int64_t nnz64 = 0;
   int w4_diag_slot = -1;  // w4_only: which offset slot holds A[r, r]
+  bool no_reorder = false;  // internal copies (renumbered / transposed) are never renumbered again
 };
 
 struct psp_sss {

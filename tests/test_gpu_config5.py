@@ -1,0 +1,75 @@
+"""GPU: BASELINE.json configs[4] -- an irregular symmetric sss_mat of Emilia_923's size + MINRES on one GPU --
+at config scale.  The SuiteSparse file cannot be fetched here, so the same assertions run on two seeded
+stand-ins (pysparse_amd/tools/standins.py: n = 929 424 FEM-like with shuffled node numbers, n = 923 136
+log-spaced) and, when EMILIA_MTX names a MatrixMarket file, on the real matrix through
+tools.mtx.sss_arrays_from_mtx:
+  * sss_mat.matvec bit-identical to the oracle's sss_matvec loop (sss_mat.c:40-56), whichever kernel runs
+    (the renumbered csr_spmv_w3 for numberings that can be made banded, the gather kernels otherwise);
+  * Jacobi-MINRES: same info and iteration count as the oracle (minres.c:43-200), iterate <= 1e-12 relative,
+    residual history to 1e-8;
+  * Jacobi-PCG likewise (the matrices are SPD)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    from pysparse_amd.tools import standins
+    yield "fem_shuffle32", lambda: standins.fem_sss_arrays(68, 68, 67, 32)
+    yield "fem_shuffle512", lambda: standins.fem_sss_arrays(68, 68, 67, 512)
+    yield "logspaced", lambda: standins.logspaced_sss_arrays(923136)
+    path = os.environ.get("EMILIA_MTX")
+    if path:
+        from pysparse_amd.tools import mtx
+        yield "emilia_mtx", lambda: mtx.sss_arrays_from_mtx(path)
+
+
+@pytest.mark.parametrize("name", ["fem_shuffle32", "fem_shuffle512", "logspaced", "emilia_mtx"])
+def test_config5_sss_matvec_and_minres_at_scale(oracle, name):
+    from pysparse_amd import device as dev
+    make = dict(_cases()).get(name)
+    if make is None:
+        pytest.skip("set EMILIA_MTX=/path/to/Emilia_923.mtx to run this on the real matrix")
+    n, ind, col, val, diag = make()
+    assert n > 9e5 or name == "emilia_mtx"
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    So = oracle.SSS(n, val, diag, col, ind)
+    kern, info = S.kernel_info()
+    if name.startswith("fem"):
+        assert kern == "csr_spmv_w3_rcm" and info["max_blocks"] <= 64 < info["half_band"], (kern, info)
+    rng = np.random.default_rng(7)
+    for trial in range(2):
+        x = rng.standard_normal(n)
+        y = np.full(n, np.nan)  # y is assigned, not accumulated (sss_mat.c:54)
+        yo = np.empty(n)
+        S.matvec(x, y)
+        So.matvec(x, yo)
+        assert np.array_equal(y, yo), name
+    # every other kernel gives the same bits
+    for variant in (16578, 16513):
+        S.set_variant(variant)
+        y2 = np.empty(n)
+        S.matvec(x, y2)
+        assert np.array_equal(y2, yo), (name, variant, S.kernel_info())
+    S.set_variant(-1)
+    # Jacobi-MINRES and Jacobi-PCG against the oracle
+    b = np.zeros(n)
+    b[0] = 1.0
+    b += 1e-3 * rng.standard_normal(n)
+    dinv = oracle.jacobi_dinv(diag)
+    K = dev.DeviceJacobi(S)
+    xo, xg = np.zeros(n), np.zeros(n)
+    ref = oracle.minres(So, b, xo, 1e-10, 500, dinv, hist=True)
+    got = dev.minres(S, b, xg, 1e-10, 500, K, hist=True)
+    assert got[:2] == ref[:2] and ref[0] == 0, (ref[:3], got[:3])
+    assert np.abs(xg - xo).max() <= 1e-12 * np.abs(xo).max()
+    k = ref[1] + 1
+    assert np.max(np.abs(got[3][:k] - ref[3][:k]) / ref[3][:k]) <= 1e-8
+    xo, xg = np.zeros(n), np.zeros(n)
+    ref = oracle.pcg(So, b, xo, 1e-10, 500, dinv)
+    got = dev.pcg(S, b, xg, 1e-10, 500, K)
+    assert got[:2] == ref[:2] and ref[0] == 0, (ref, got)
+    assert np.abs(xg - xo).max() <= 1e-12 * np.abs(xo).max()

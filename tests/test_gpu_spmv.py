@@ -479,3 +479,57 @@ def test_csr_matvec_transp_w4_exact(oracle, case):
     y2 = np.full(n, -5.0)
     D.matvec_transp(x, y2)
     assert np.array_equal(y, y2, equal_nan=True)  # reproducible
+
+
+@pytest.mark.parametrize("shuffle", [8, 64])
+def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
+    """Irregular numbering (FEM-like stand-in with shuffled node ids): chunks reference more than 64 x blocks,
+    so csr_spmv_w3 does not apply to the stored numbering; the handle builds a reverse Cuthill-McKee
+    renumbered copy (psp_reorder.hip) and multiplies through it -- gather x, csr_spmv_w3 storing through the
+    row permutation.  Per-row storage order is kept, so y has the oracle's bits; the fused dot and the
+    solvers run through the same path."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    from pysparse_amd.tools.standins import fem_sss_arrays
+    n, ind, col, val, diag = fem_sss_arrays(20, 18, 16, shuffle)
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    So = oracle.SSS(n, val, diag, col, ind)
+    Ao = oracle.sss_to_csr(So)
+    A = dev.DeviceCSR.from_arrays(Ao.shape, Ao.ind, Ao.col, Ao.val)
+    x = np.random.default_rng(3).standard_normal(n)
+    yo = np.empty(n)
+    So.matvec(x, yo)
+    for M in (S, A):
+        kern, info = M.kernel_info()
+        assert kern == "csr_spmv_w3_rcm" and info["max_blocks"] <= 64 < info["half_band"], (kern, info)
+        y = np.full(n, np.nan)
+        M.matvec(x, y)
+        assert np.array_equal(y, yo)
+    ya = np.empty(n)
+    Ao.matvec(x, ya)  # the csr form adds the same terms in column order: may differ from sss order by rounding
+    y = np.empty(n)
+    A.matvec(x, y)
+    assert np.array_equal(y, ya)
+    # fused dot product of the PCG path
+    L = lib()
+    xd = dev.DeviceBuffer.from_host(x)
+    yd = dev.DeviceBuffer(n)
+    out = dev.DeviceBuffer(1)
+    check(L.psp_k_csr_matvec_dot(A._h, xd.ptr, 0, yd.ptr, out.ptr))
+    assert np.array_equal(yd.download(), ya)
+    d = float(out.download()[0])
+    assert abs(d - float(np.dot(x, ya))) <= 1e-12 * abs(d)
+    # solvers through the renumbered product
+    b = np.empty(n)
+    Ao.matvec(np.ones(n), b)
+    dinv = oracle.jacobi_dinv(diag)
+    for solver_g, solver_o in ((dev.pcg, oracle.pcg), (dev.minres, oracle.minres)):
+        xo, xg = np.zeros(n), np.zeros(n)
+        ref = solver_o(Ao, b, xo, 1e-10, 500, dinv)
+        got = solver_g(A, b, xg, 1e-10, 500, dev.DeviceJacobi(A))
+        assert got[:2] == ref[:2] and np.abs(xg - xo).max() <= 1e-12 * np.abs(xo).max()
+    # PSP_SPMV_REORDER is read once per process; the explicit w2 variant bypasses the renumbered copy
+    A.set_variant(16578)
+    assert A.kernel_info()[0] == "csr_spmv_w2"
+    A.matvec(x, y)
+    assert np.array_equal(y, ya)

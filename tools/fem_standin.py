@@ -19,40 +19,8 @@ from tools.spmv_sweep import time_launches  # noqa: E402
 
 
 def fem_sss(gx, gy, gz, shuffle, seed=0):
-    rng = np.random.default_rng(seed)
-    nn = gx * gy * gz
-    ids = np.arange(nn, dtype=np.int64)
-    if shuffle > 1:  # local renumbering
-        for a in range(0, nn, shuffle):
-            b = min(nn, a + shuffle)
-            ids[a:b] = a + rng.permutation(b - a)
-    i = np.arange(nn) % gx
-    j = (np.arange(nn) // gx) % gy
-    k = np.arange(nn) // (gx * gy)
-    nb = [(0, 0, 0)] + [(s, 0, 0) for s in (-1, 1)] + [(0, s, 0) for s in (-1, 1)] + [(0, 0, s) for s in (-1, 1)]
-    nb += [(a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)]
-    rows, cols, vals = [], [], []
-    for (di, dj, dk) in nb:
-        ok = (i + di >= 0) & (i + di < gx) & (j + dj >= 0) & (j + dj < gy) & (k + dk >= 0) & (k + dk < gz)
-        p = np.nonzero(ok)[0]
-        q = p + di + gx * (dj + gy * dk)
-        P, Q = ids[p], ids[q]
-        for d in range(3):
-            for e in range(3):
-                r, c = 3 * P + d, 3 * Q + e
-                lower = c < r
-                rr, cc = r[lower], c[lower]
-                rows.append(rr)
-                cols.append(cc)
-                vals.append(-(0.05 + 0.01 * ((rr * 7 + cc * 13) % 10)))
-    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
-    order = np.lexsort((cols, rows))
-    rows, cols, vals = rows[order], cols[order], vals[order]
-    n = 3 * nn
-    ind = np.zeros(n + 1, dtype=np.int32)
-    np.cumsum(np.bincount(rows, minlength=n), out=ind[1:])
-    diag = 10.0 + rng.random(n)
-    return n, ind, cols.astype(np.int32), vals, diag
+    from pysparse_amd.tools.standins import fem_sss_arrays
+    return fem_sss_arrays(gx, gy, gz, shuffle, seed)
 
 
 def main():
