@@ -1830,7 +1830,8 @@ struct CsrExtra {
   int reorder_state = -1;
   psp_csr *reordered = nullptr;
   int *perm = nullptr;     // new -> old (device)
-  double *xp = nullptr;    // x in the new numbering (scratch, nrows doubles)
+  int *inv = nullptr;      // old -> new
+  double *xp = nullptr;    // x, then y, in the new numbering (scratch, 2 * nrows doubles)
   int orig_max_blocks = 0;
 };
 
@@ -2084,6 +2085,14 @@ static int ensure_schedule(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+// scratch device allocation released on every exit path
+struct ScratchDev {
+  void *p = nullptr;
+  ~ScratchDev() {
+    if (p) (void)hipFree(p);
+  }
+};
+
 // offset-structured layout of csr_spmv_w4 (built on first use)
 static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
@@ -2096,8 +2105,9 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
     return e && atoi(e) == 0;
   }();
   if (off || A->nrows < 1 || A->ncols < 2 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
-  int *d_tab;
-  PSP_HIP(hipMalloc((void **)&d_tab, 65 * sizeof(int)));
+  ScratchDev tab_mem;
+  PSP_HIP(hipMalloc(&tab_mem.p, 65 * sizeof(int)));
+  int *d_tab = (int *)tab_mem.p;
   int init[65];
   for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
   init[64] = 0;
@@ -2108,7 +2118,6 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   int tab[65];
   PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  PSP_HIP(hipFree(d_tab));
   if (tab[64]) return PSP_OK;
   std::vector<int> offs;
   for (int i = 0; i < 64; ++i)
@@ -2222,8 +2231,9 @@ static int ensure_sss_w4(psp_sss *S) {
     return e && atoi(e) == 0;
   }();
   if (off || S->n < 2 || S->nnz_lower < 1) return PSP_OK;
-  int *d_tab;
-  PSP_HIP(hipMalloc((void **)&d_tab, 65 * sizeof(int)));
+  ScratchDev tab_mem;
+  PSP_HIP(hipMalloc(&tab_mem.p, 65 * sizeof(int)));
+  int *d_tab = (int *)tab_mem.p;
   int init[65];
   for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
   init[64] = 0;
@@ -2234,7 +2244,6 @@ static int ensure_sss_w4(psp_sss *S) {
   int tab[65];
   PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  PSP_HIP(hipFree(d_tab));
   if (tab[64]) return PSP_OK;
   std::vector<int> offs;
   for (int i = 0; i < 64; ++i)
@@ -2404,6 +2413,8 @@ namespace psp {
 int reorder_rcm_host(int n, const int *ind, const int *col, const double *val, std::vector<int> &perm,
                      std::vector<int> &rind, std::vector<int> &rcol, std::vector<double> &rval);
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);
+int reorder_back(int n, const int *inv_dev, const double *yp, double *y, const double *dotv, double *partials,
+                 int *nparts, const int *skip);
 }  // namespace psp
 
 static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_blocks) {
@@ -2433,14 +2444,18 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
   int rc = alloc_csr(n, n, (long)nnz, &R);
   if (rc != PSP_OK) return PSP_OK;  // no room: stay with the gather kernels
   R->no_reorder = true;
-  int *dperm = nullptr;
+  int *dperm = nullptr, *dinv = nullptr;
   double *xp = nullptr;
+  std::vector<int> inv((size_t)n);
+  for (int i = 0; i < n; ++i) inv[perm[i]] = i;
   bool ok = hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void **)&dperm, sizeof(int) * (size_t)n) == hipSuccess &&
-            hipMalloc((void **)&xp, sizeof(double) * (size_t)n) == hipSuccess &&
+            hipMalloc((void **)&dinv, sizeof(int) * (size_t)n) == hipSuccess &&
+            hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n) == hipSuccess &&
             hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(dinv, inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
             finalize_csr(R) == PSP_OK;
   ChunkTable *t = nullptr;
   if (ok) ok = get_chunk_table(R, 1024, &t) == PSP_OK && ensure_rowoff(R, t) == PSP_OK && t->np != 0 &&
@@ -2449,12 +2464,14 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     (void)hipGetLastError();
     psp_csr_destroy(R);
     if (dperm) (void)hipFree(dperm);
+    if (dinv) (void)hipFree(dinv);
     if (xp) (void)hipFree(xp);
     return PSP_OK;
   }
   std::lock_guard<std::mutex> lk(g_extra_mu);
   ex->reordered = R;
   ex->perm = dperm;
+  ex->inv = dinv;
   ex->xp = xp;
   ex->reorder_state = 1;
   return PSP_OK;
@@ -2478,14 +2495,19 @@ static int ensure_packed(const psp_csr *A, char **out) {
 
 namespace psp {
 
-// tuning aid: PSP_SPMV_COLMASK=<int> ANDs every gathered column index (wrong results, used
-// only to price the x gathers); default -1 leaves indices untouched
+// tuning aid, compiled in only with -DPSP_TUNING: PSP_SPMV_COLMASK=<int> ANDs every gathered column index
+// (WRONG results, used only to price the x gathers).  The shipped library ignores the variable: -1 leaves
+// the indices untouched.
 static int colmask() {
+#ifdef PSP_TUNING
   static const int m = [] {
     const char *e = getenv("PSP_SPMV_COLMASK");
     return e ? atoi(e) : -1;
   }();
   return m;
+#else
+  return -1;
+#endif
 }
 
 // workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order); PSP_SPMV_STRIPE overrides
@@ -2558,7 +2580,7 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
   else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
 }
 
-// y = A x through the renumbered copy: xp = x[perm]; csr_spmv_w3 on R stores row i to y[perm[i]]
+// y = A x through the renumbered copy: xp = x[perm]; yp = R xp (csr_spmv_w3); y[j] = yp[inv[j]] (+ the dot)
 static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, const double *x, double *y,
                             const double *dotv, double *partials, int *nparts, const int *skip) {
   psp_csr *R = ex->reordered;
@@ -2566,20 +2588,24 @@ static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, con
   PSP_TRY(get_chunk_table(R, 1024, &t));
   int grid = (t->nchunks + 3) / 4;
   if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
+  const int n = A->nrows;
+  double *xp = ex->xp, *yp = ex->xp + n;
+  PSP_TRY(psp::reorder_gather(n, ex->perm, x, xp, skip));
+  R->variant = A->variant;
+  launch_w3(R, t, true, grid, stripe, 0, t->nchunks, xp, yp, nullptr, nullptr, skip);
+  PSP_LAUNCH_CHECK();
+  const int gback = (n + 1023) / 1024;
   double *pbuf = partials;
-  if (partials && grid > kMaxParts) {
-    PSP_TRY(ensure_big_partials(ex, grid));
+  if (partials && gback > kMaxParts) {
+    PSP_TRY(ensure_big_partials(ex, gback));
     pbuf = ex->big_partials;
   }
-  PSP_TRY(psp::reorder_gather(A->nrows, ex->perm, x, ex->xp, skip));
-  R->variant = A->variant;
-  launch_w3(R, t, true, grid, stripe, 0, t->nchunks, ex->xp, y, dotv, pbuf, skip, nullptr, ex->perm);
-  PSP_LAUNCH_CHECK();
-  int np = grid;
-  if (pbuf != partials) {
-    np = kFold;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(np / 16), dim3(256), 0, stream(), pbuf, grid, partials, np);
+  int np = 0;
+  PSP_TRY(psp::reorder_back(n, ex->inv, yp, y, partials ? dotv : nullptr, pbuf, &np, skip));
+  if (partials && pbuf != partials) {
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), pbuf, np, partials, kFold);
     PSP_LAUNCH_CHECK();
+    np = kFold;
   }
   if (nparts) *nparts = np;
   return PSP_OK;
@@ -3301,6 +3327,7 @@ int psp_csr_destroy(psp_csr_t *A) {
       transposed = it->second.transposed;
       reordered = it->second.reordered;
       if (it->second.perm) (void)hipFree(it->second.perm);
+      if (it->second.inv) (void)hipFree(it->second.inv);
       if (it->second.xp) (void)hipFree(it->second.xp);
       for (auto &t : it->second.t) {
         if (t.second.tab) (void)hipFree(t.second.tab);
@@ -3351,6 +3378,7 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
 }
 
 int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
+  PSP_API_GUARD;
   if (A->nrows == 0) return PSP_OK;
   if (A->w4_only) {
     psp::CsrExtra *ex;
@@ -3369,6 +3397,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
 }
 
 int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
+  PSP_API_GUARD;
   if (!A || !diag_host) return fail(PSP_EINVAL, "psp_csr_diagonal: NULL argument");
   DevBuf d;
   PSP_TRY(d.alloc(A->nrows));
@@ -3377,6 +3406,7 @@ int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
 }
 
 int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_dev: NULL argument");
   if (A->nrows == 0) return PSP_OK;
   return csr_spmv_launch(A, x_dev, y_dev, nullptr, nullptr, nullptr);
@@ -3384,6 +3414,7 @@ int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
 
 int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
                           ptrdiff_t incy) {
+  PSP_API_GUARD;
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
   PSP_TRY(ensure_device());
   DevBuf x, y;
@@ -3395,10 +3426,12 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
 }
 
 int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
+  PSP_API_GUARD;
   return psp_csr_matvec_stride(A, x_host, 1, y_host, 1);
 }
 
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
   {  // offset-structured operators: exact gather in the reference's order, no atomics
     int done = 0;
@@ -3417,6 +3450,7 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
 
 int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
                                  double *y_host, ptrdiff_t incy) {
+  PSP_API_GUARD;
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec_transp: NULL argument");
   PSP_TRY(ensure_device());
   DevBuf x, y;
@@ -3428,6 +3462,7 @@ int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t i
 }
 
 int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host) {
+  PSP_API_GUARD;
   return psp_csr_matvec_transp_stride(A, x_host, 1, y_host, 1);
 }
 
@@ -3446,6 +3481,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
 }
 
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
+  PSP_API_GUARD;
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
@@ -3713,21 +3749,25 @@ int psp_sss_getitem(const psp_sss_t *S, int i, int j, double *value) {
 }
 
 int psp_sss_matvec_dev(psp_sss_t *S, const double *x_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!S) return fail(PSP_EINVAL, "psp_sss_matvec_dev: NULL handle");
   return psp_csr_matvec_dev(S->full, x_dev, y_dev);
 }
 
 int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, double *y_host,
                           ptrdiff_t incy) {
+  PSP_API_GUARD;
   if (!S) return fail(PSP_EINVAL, "psp_sss_matvec: NULL handle");
   return psp_csr_matvec_stride(S->full, x_host, incx, y_host, incy);
 }
 
 int psp_sss_matvec(psp_sss_t *S, const double *x_host, double *y_host) {
+  PSP_API_GUARD;
   return psp_sss_matvec_stride(S, x_host, 1, y_host, 1);
 }
 
 int psp_sss_kernel_info(psp_sss_t *S, char *name, int name_cap, int *info) {
+  PSP_API_GUARD;
   if (!S) return fail(PSP_EINVAL, "psp_sss_kernel_info: NULL handle");
   return psp_csr_kernel_info(S->full, name, name_cap, info);
 }

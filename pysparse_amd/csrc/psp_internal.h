@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "pysparse_hip.h"
@@ -12,6 +13,14 @@
 namespace psp {
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// One library-wide lock around every compute entry point of the C ABI: the reduction workspace, the
+// stream and the per-handle side tables are process-global, and the extension modules release the GIL
+// around solves (the reference serialises the same calls by holding it).  Recursive: jacobi(steps > 1),
+// ssor and the solvers re-enter matvec entry points.  Callers must not hold the GIL while they wait for it
+// (ctypes and the extension modules release it first), because host-callback operators take the GIL
+// while the lock is held.
+std::recursive_mutex &api_mutex();
+#define PSP_API_GUARD std::lock_guard<std::recursive_mutex> psp_api_guard_(psp::api_mutex())
 hipStream_t stream();
 hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable

@@ -11,9 +11,12 @@
 //                    row's products left to right, csr_mat.c:49-54, and so must we -- same products,
 //                    same order, same bits in y);
 //     column ids   = inv[col].
-// The product y = A x then runs as  xp = x[perm] (gather pass, 20 n bytes)  ->  csr_spmv_w3 on R, storing
-// row i's sum straight to y[perm[i]].  Nothing here changes a bit of y; only the order in which a PCG dot
-// product epilogue adds its terms follows the new numbering (reproducible, fixed).
+// The product y = A x then runs as  xp = x[perm] (gather pass, 20 n bytes)  ->  yp = R xp (csr_spmv_w3,
+// coalesced stores)  ->  y[j] = yp[inv[j]] (a second gather pass; storing row i's sum straight to
+// y[perm[i]] from the SpMV -- 16 partial writes per 128-byte line of y, from different XCDs -- measured
+// no faster: 0.0987 vs 0.0967 ms at n = 9.3e5).  Nothing here changes a bit of y, and the fused dot product
+// of the PCG path is formed by the last pass in the caller's numbering, so it too has the bits every other
+// kernel gives.
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -159,20 +162,89 @@ std::vector<int> rcm_order(const Graph &g, int n) {
   return order;
 }
 
-__global__ void permute_gather_kernel(int n, const int *__restrict__ perm, const double *__restrict__ x,
-                                      double *__restrict__ xp, const int *__restrict__ skip) {
+// Both passes are latency-bound (perm -> x is a dependent pair of loads, the vectors are a few MB): each
+// thread takes 4 elements with all index loads, then all value loads, in flight together, so that the
+// whole pass is ONE residency round of the chip instead of three (7.7 us -> ~4 us at n = 9.3e5).
+constexpr int kPermPerThread = 4;
+
+__global__ __launch_bounds__(256) void permute_gather_kernel(int n, const int *__restrict__ perm,
+                                                             const double *__restrict__ x, double *__restrict__ xp,
+                                                             const int *__restrict__ skip) {
   if (skip && *skip) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) xp[i] = x[perm[i]];
+  const long base = (long)blockIdx.x * (256 * kPermPerThread) + threadIdx.x;
+  int idx[kPermPerThread];
+  double v[kPermPerThread];
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) {
+    const long i = base + u * 256;
+    idx[u] = i < n ? perm[i] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) v[u] = x[idx[u]];
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) {
+    const long i = base + u * 256;
+    if (i < n) xp[i] = v[u];
+  }
+}
+
+// y[j] = yp[inv[j]] and, optionally, one partial sum of dotv[j] * y[j] per workgroup (fixed order)
+__global__ __launch_bounds__(256) void permute_back_kernel(int n, const int *__restrict__ inv,
+                                                           const double *__restrict__ yp, double *__restrict__ y,
+                                                           const double *__restrict__ dotv,
+                                                           double *__restrict__ partials,
+                                                           const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ double red[4];
+  double dsum = 0.0;
+  const long base = (long)blockIdx.x * (256 * kPermPerThread) + threadIdx.x;
+  int idx[kPermPerThread];
+  double v[kPermPerThread], d[kPermPerThread];
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) {
+    const long j = base + u * 256;
+    idx[u] = j < n ? inv[j] : 0;
+    d[u] = (dotv && j < n) ? dotv[j] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) v[u] = yp[idx[u]];
+#pragma unroll
+  for (int u = 0; u < kPermPerThread; ++u) {
+    const long j = base + u * 256;
+    if (j < n) {
+      y[j] = v[u];
+      dsum += d[u] * v[u];
+    }
+  }
+  if (partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dsum += __shfl_down(dsum, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
 }
 
 }  // namespace
 
 namespace psp {
 
+// y[j] = yp[inv[j]] (+ partial sums of dotv . y, one per workgroup of 1024 rows: *nparts of them)
+int reorder_back(int n, const int *inv_dev, const double *yp, double *y, const double *dotv, double *partials,
+                 int *nparts, const int *skip) {
+  if (n <= 0) return PSP_OK;
+  const int grid = (n + 256 * kPermPerThread - 1) / (256 * kPermPerThread);
+  hipLaunchKernelGGL(permute_back_kernel, dim3(grid), dim3(256), 0, stream(), n, inv_dev, yp, y, dotv, partials,
+                     skip);
+  PSP_LAUNCH_CHECK();
+  if (nparts) *nparts = grid;
+  return PSP_OK;
+}
+
 // xp[i] = x[perm[i]] on the library stream
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip) {
   if (n <= 0) return PSP_OK;
-  const int grid = std::min((n + 255) / 256, 65536);
+  const int grid = (n + 256 * kPermPerThread - 1) / (256 * kPermPerThread);
   hipLaunchKernelGGL(permute_gather_kernel, dim3(grid), dim3(256), 0, stream(), n, perm_dev, x, xp, skip);
   PSP_LAUNCH_CHECK();
   return PSP_OK;

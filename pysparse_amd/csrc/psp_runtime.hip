@@ -25,6 +25,11 @@ int fail(int code, const char *fmt, ...) {
 
 const char *last_error() { return g_err.c_str(); }
 
+std::recursive_mutex &api_mutex() {
+  static std::recursive_mutex mu;
+  return mu;
+}
+
 hipStream_t stream() { return g_stream; }
 hipStream_t swap_stream(hipStream_t s) {
   hipStream_t old = g_stream;

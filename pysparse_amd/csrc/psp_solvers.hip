@@ -1499,6 +1499,7 @@ int psp_pcgstate_destroy(psp_pcgstate_t *s) {
 
 int psp_pcgstate_init(psp_pcgstate_t *s, double n2b, double tolb, double normr0, double rho0, int maxit,
                       int want_hist) {
+  PSP_API_GUARD;
   if (!s || maxit < 1) return fail(PSP_EINVAL, "psp_pcgstate_init: bad argument");
   if (want_hist && s->hist_cap < maxit + 1) {
     if (s->hist_dev) (void)hipFree(s->hist_dev);
@@ -1522,6 +1523,7 @@ int psp_pcgstate_init(psp_pcgstate_t *s, double n2b, double tolb, double normr0,
 }
 
 int psp_pcgstate_fetch(psp_pcgstate_t *s, psp_pcg_status_t *out) {
+  PSP_API_GUARD;
   if (!s || !out) return fail(PSP_EINVAL, "psp_pcgstate_fetch: NULL argument");
   PSP_HIP(hipMemcpyAsync(s->host, s->dev, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
@@ -1549,6 +1551,7 @@ int psp_pcgstate_hist(psp_pcgstate_t *s, int first, int count, double *hist_host
 
 int psp_kd_px_update(const psp_pcgstate_t *s, int n, const double *r_dev, const double *dinv_dev, double *p_dev,
                      double *x_dev, double *out_dev) {
+  PSP_API_GUARD;
   if (!s || !r_dev || !p_dev || !x_dev || !out_dev) return fail(PSP_EINVAL, "psp_kd_px_update: NULL argument");
   Workspace *w;
   PSP_TRY(workspace(&w));
@@ -1559,6 +1562,7 @@ int psp_kd_px_update(const psp_pcgstate_t *s, int n, const double *r_dev, const 
 
 int psp_kd_r_update(const psp_pcgstate_t *s, int n, const double *q_dev, const double *dinv_dev, double *r_dev,
                     double *out_dev) {
+  PSP_API_GUARD;
   if (!s || !q_dev || !r_dev || !out_dev) return fail(PSP_EINVAL, "psp_kd_r_update: NULL argument");
   Workspace *w;
   PSP_TRY(workspace(&w));
@@ -1570,6 +1574,7 @@ int psp_kd_r_update(const psp_pcgstate_t *s, int n, const double *q_dev, const d
 int psp_kd_csr_matvec_overlap(const psp_pcgstate_t *s, psp_csr_t *A, const double *x_dev, int x_offset,
                               double *y_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx,
                               double *dot_out_dev) {
+  PSP_API_GUARD;
   if (!s || !A || !x_dev || !y_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: NULL");
   if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: row range / offset out of bounds");
@@ -1587,6 +1592,7 @@ int psp_kd_csr_matvec_overlap(const psp_pcgstate_t *s, psp_csr_t *A, const doubl
 }
 
 int psp_kd_pcg_scalar_xpq(psp_pcgstate_t *s, const double *scal_dev) {
+  PSP_API_GUARD;
   if (!s || !scal_dev) return fail(PSP_EINVAL, "psp_kd_pcg_scalar_xpq: NULL argument");
   hipLaunchKernelGGL(pcg_dist_scalar_xpq_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev);
   PSP_LAUNCH_CHECK();
@@ -1594,6 +1600,7 @@ int psp_kd_pcg_scalar_xpq(psp_pcgstate_t *s, const double *scal_dev) {
 }
 
 int psp_kd_pcg_scalar_r(psp_pcgstate_t *s, const double *scal_dev) {
+  PSP_API_GUARD;
   if (!s || !scal_dev) return fail(PSP_EINVAL, "psp_kd_pcg_scalar_r: NULL argument");
   hipLaunchKernelGGL(pcg_dist_scalar_r_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev, s->hist_dev);
   PSP_LAUNCH_CHECK();
@@ -1627,6 +1634,7 @@ int psp_minresstate_destroy(psp_minresstate_t *s) {
 
 int psp_minresstate_init(psp_minresstate_t *s, double norm_r0, double beta0, double errtol, int it_max,
                          int want_hist) {
+  PSP_API_GUARD;
   if (!s || it_max < 1) return fail(PSP_EINVAL, "psp_minresstate_init: bad argument");
   if (want_hist && s->hist_cap < it_max + 1) {
     if (s->hist_dev) (void)hipFree(s->hist_dev);
@@ -1655,6 +1663,7 @@ int psp_minresstate_init(psp_minresstate_t *s, double norm_r0, double beta0, dou
 }
 
 int psp_minresstate_fetch(psp_minresstate_t *s, psp_minres_status_t *out) {
+  PSP_API_GUARD;
   if (!s || !out) return fail(PSP_EINVAL, "psp_minresstate_fetch: NULL argument");
   PSP_HIP(hipMemcpyAsync(s->host, s->dev, sizeof(MinresDev), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
@@ -1678,12 +1687,14 @@ int psp_minresstate_hist(psp_minresstate_t *s, int first, int count, double *his
 // the row-block form keeps v = y / beta as a vector of its own (its ghost entries are what the halo
 // exchange moves); the single-GPU loop's scaled SpMV has no split-around-a-wait form
 int psp_kd_minres_scale(const psp_minresstate_t *s, int n, const double *y_dev, double *v_dev) {
+  PSP_API_GUARD;
   if (!s || !y_dev || !v_dev) return fail(PSP_EINVAL, "psp_kd_minres_scale: NULL argument");
   return k_scale_div(n, y_dev, 1.0, v_dev, s->dev);
 }
 
 int psp_kd_minres_matvec(const psp_minresstate_t *s, psp_csr_t *A, const double *v_dev, int v_offset,
                          double *av_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
+  PSP_API_GUARD;
   if (!s || !A || !v_dev || !av_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_minres_matvec: NULL");
   if (v_offset < 0 || v_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_kd_minres_matvec: row range / offset out of bounds");
@@ -1697,6 +1708,7 @@ int psp_kd_minres_matvec(const psp_minresstate_t *s, psp_csr_t *A, const double 
 
 int psp_kd_minres_lanczos(const psp_minresstate_t *s, int n, const double *av_dev, const double *v_hat_dev,
                           double *v_hat_old_dev, const double *dinv_dev, double *y_dev, double *out_dev) {
+  PSP_API_GUARD;
   if (!s || !av_dev || !v_hat_dev || !v_hat_old_dev || !out_dev)
     return fail(PSP_EINVAL, "psp_kd_minres_lanczos: NULL argument");
   if (dinv_dev && !y_dev) return fail(PSP_EINVAL, "psp_kd_minres_lanczos: y is needed with a preconditioner");
@@ -1708,6 +1720,7 @@ int psp_kd_minres_lanczos(const psp_minresstate_t *s, int n, const double *av_de
 }
 
 int psp_kd_minres_scalar(psp_minresstate_t *s, int which, const double *scal_dev) {
+  PSP_API_GUARD;
   if (!s || !scal_dev || (which != 0 && which != 1)) return fail(PSP_EINVAL, "psp_kd_minres_scalar: bad argument");
   hipLaunchKernelGGL(minres_dist_scalar_kernel, dim3(1), dim3(1), 0, stream(), s->dev, scal_dev, which, s->hist_dev);
   PSP_LAUNCH_CHECK();
@@ -1716,6 +1729,7 @@ int psp_kd_minres_scalar(psp_minresstate_t *s, int which, const double *scal_dev
 
 int psp_kd_minres_wx(const psp_minresstate_t *s, int n, const double *v_dev, const double *w_dev,
                      double *w_old_dev, double *x_dev) {
+  PSP_API_GUARD;
   if (!s || !v_dev || !w_dev || !w_old_dev || !x_dev) return fail(PSP_EINVAL, "psp_kd_minres_wx: NULL argument");
   return k_minres_wx(n, v_dev, 0.0, 0.0, 0.0, 0.0, w_dev, w_old_dev, x_dev, false, 1.0, s->dev);
 }
@@ -1845,6 +1859,7 @@ static int jacobi_from_diag_dev(int n, double *diag_dev_owned, double omega, int
 }
 
 int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **out) {
+  PSP_API_GUARD;
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_csr: NULL argument");
   if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
@@ -1864,6 +1879,7 @@ int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **
 }
 
 int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **out) {
+  PSP_API_GUARD;
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_sss: NULL argument");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
   PSP_TRY(ensure_device());
@@ -1884,6 +1900,7 @@ int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **
 
 int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int steps,
                            const psp_op_t *A_or_null, psp_jacobi_t **out) {
+  PSP_API_GUARD;
   if (!diag_host || !out || n <= 0) return fail(PSP_EINVAL, "psp_jacobi_create_diag: bad argument");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
   if (steps > 1 && !A_or_null)
@@ -1917,11 +1934,13 @@ int psp_jacobi_shape(const psp_jacobi_t *K, int *n) {
 }
 
 int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_jacobi_precon_dev: NULL argument");
   return jacobi_apply_dev(K, x_dev, y_dev);
 }
 
 int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
+  PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -1940,6 +1959,7 @@ int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
 
 int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, const double *b_dev,
                 double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
   return pcg_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
@@ -1947,6 +1967,7 @@ int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, cons
 
 int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
             double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -1965,6 +1986,7 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
 int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
                    const double *b_dev, double tol, int maxit, int *info, int *iter,
                    double *relres, double *hist_host) {
+  PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
   return minres_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
@@ -1972,6 +1994,7 @@ int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
 
 int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
                double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
+  PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -1992,6 +2015,7 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
 #define PSP_HOST_SOLVER(NAME, CALL)                                                              \
   int NAME(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,    \
            double tol, int maxit, int *info, int *iter, double *relres) {                        \
+    PSP_API_GUARD;                                                                               \
     PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));                     \
     PSP_TRY(ensure_device());                                                                    \
     DevVecs mem;                                                                                 \
@@ -2014,6 +2038,7 @@ PSP_HOST_SOLVER(psp_qmrs, qmrs_device(A, K, n, x, b, tol, maxit, info, iter, rel
 
 int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
               double tol, int maxit, int dim, int *info, int *iter, double *relres) {
+  PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
   PSP_TRY(ensure_device());
   DevVecs mem;

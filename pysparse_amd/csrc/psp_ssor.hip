@@ -260,6 +260,7 @@ int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
 extern "C" {
 
 int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
+  PSP_API_GUARD;
   if (!S || !out) return fail(PSP_EINVAL, "psp_ssor_create: NULL argument");
   if (steps < 0) return fail(PSP_EINVAL, "ssor: steps must be >= 0");
   PSP_TRY(ensure_device());
@@ -313,12 +314,14 @@ int psp_ssor_info(const psp_ssor_t *K, int *n, int *levels_forward, int *levels_
 }
 
 int psp_ssor_precon_dev(psp_ssor_t *K, const double *x_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_ssor_precon_dev: NULL argument");
   if (K->n == 0) return PSP_OK;
   return ssor_apply_dev(K, x_dev, y_dev);
 }
 
 int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host) {
+  PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_ssor_precon: NULL argument");
   if (K->n == 0) return PSP_OK;
   PSP_TRY(ensure_device());

@@ -2,8 +2,9 @@
 // and hand loops in pysparse/itsolvers/src/pcg.c and minres.c), fused so that every
 // vector is streamed as few times as the data dependencies allow.
 //
-// All kernels: 256-thread workgroups, grid-stride over the vector with 16-byte-per-lane
-// accesses (8-byte when a pointer is not 16-byte aligned or n is odd), per-lane partial
+// All kernels: 256-thread workgroups, one contiguous span per workgroup with 16-byte-per-lane
+// accesses (two 8-byte ones when a pointer is not 16-byte aligned or n is odd: same elements per
+// thread, so the same bits), per-lane partial
 // sums -> wave shuffle -> LDS -> one slot per workgroup; a one-block finishing kernel adds
 // the slots in index order (bitwise reproducible, no atomics).  Per-element arithmetic
 // follows the reference expression order; the library is built with -ffp-contract=off.
@@ -72,12 +73,16 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *part
   }
 }
 
-// workgroup b streams the contiguous span [b*kVecSpan, (b+1)*kVecSpan) (and b + grid, ...):
-// kVecSpan / (256*V) independent 8*V-byte accesses per lane
+// workgroup b streams the contiguous span [b*kVecSpan, (b+1)*kVecSpan) (and b + grid, ...).  Thread t owns
+// elements 2t and 2t+1 of the span in BOTH forms -- V = 2: one 16-byte access per array; V = 1 (n odd or a
+// pointer not 16-byte aligned): two 8-byte accesses -- so every per-thread partial sum, and with it every
+// reduction result, is the same whichever form runs: results do not depend on where a buffer happens to
+// be allocated (the owned slice of an extended vector starts at an odd offset as often as not).
 #define PSP_VEC_LOOP(i, n)                                                             \
   for (long span_ = (long)blockIdx.x * kVecSpan; span_ < (n); span_ += (long)gridDim.x * kVecSpan) \
     _Pragma("unroll") for (int u_ = 0; u_ < kVecSpan / (kBlock * V); ++u_)              \
-      for (long i = span_ + ((long)u_ * kBlock + threadIdx.x) * V; i < (n); i = (n))
+      for (long i = span_ + (V == 2 ? ((long)u_ * kBlock + threadIdx.x) * 2 : 2L * threadIdx.x + u_); i < (n); i = (n))
+static_assert(kVecSpan == 2 * kBlock, "the V = 1 mapping above assumes two elements per thread and span");
 
 // ---- dot: pcg.c:100,117  minres.c:78,129,143
 template <int V>
@@ -845,6 +850,7 @@ int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double
 extern "C" {
 
 int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -853,17 +859,20 @@ int psp_k_dot(int n, const double *x_dev, const double *y_dev, double *out_dev) 
 }
 
 int psp_k_hint_constant(const double *v_dev, int n) {
+  PSP_API_GUARD;
   if (!v_dev || n < 1) return fail(PSP_EINVAL, "psp_k_hint_constant: bad argument");
   return dinv_register(v_dev, n);
 }
 
 int psp_k_unhint(const double *v_dev) {
+  PSP_API_GUARD;
   dinv_unregister(v_dev);
   return PSP_OK;
 }
 
 int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv_dev,
                    double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -873,11 +882,13 @@ int psp_k_residual(int n, const double *b_dev, double *r_dev, const double *dinv
 
 int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double beta, int first,
                   double *p_dev) {
+  PSP_API_GUARD;
   return k_pupdate(n, r_dev, dinv_dev, beta, first != 0, p_dev, nullptr);
 }
 
 int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
                          double *out_dev) {
+  PSP_API_GUARD;
   if (!A || !p_dev || !q_dev || !out_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: NULL");
   if (p_offset < 0 || p_offset + A->nrows > A->ncols)
     return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: owned rows do not fit the column space");
@@ -894,6 +905,7 @@ int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double
 
 int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, double *y_dev,
                              int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
+  PSP_API_GUARD;
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: NULL");
   if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: row range / offset out of bounds");
@@ -913,6 +925,7 @@ int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, do
 
 int psp_k_px_update(int n, const double *r_dev, const double *dinv_dev, double beta, int first, double alpha_x,
                     int xpend, double *p_dev, double *x_dev, double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -923,6 +936,7 @@ int psp_k_px_update(int n, const double *r_dev, const double *dinv_dev, double b
 
 int psp_k_r_update(int n, double alpha, const double *q_dev, const double *dinv_dev, double *r_dev,
                    double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -931,6 +945,7 @@ int psp_k_r_update(int n, double alpha, const double *q_dev, const double *dinv_
 }
 
 int psp_k_x_update(int n, double alpha, const double *p_dev, double *x_dev, double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -940,6 +955,7 @@ int psp_k_x_update(int n, double alpha, const double *p_dev, double *x_dev, doub
 
 int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_dev,
                     const double *dinv_dev, double *x_dev, double *r_dev, double *out_dev) {
+  PSP_API_GUARD;
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np;
@@ -948,12 +964,14 @@ int psp_k_xr_update(int n, double alpha, const double *p_dev, const double *q_de
 }
 
 int psp_k_jacobi(int n, const double *x_dev, const double *dinv_dev, double *y_dev) {
+  PSP_API_GUARD;
   if (!x_dev || !dinv_dev || !y_dev || n < 0) return fail(PSP_EINVAL, "psp_k_jacobi: bad argument");
   if (n == 0) return PSP_OK;
   return k_jacobi_first(n, x_dev, dinv_dev, y_dev);
 }
 
 int psp_k_gather(int count, const int *idx_dev, const double *v_dev, double *send_dev) {
+  PSP_API_GUARD;
   PSP_TRY(ensure_device());
   if (count <= 0) return PSP_OK;
   int grid = (count + 255) / 256;

@@ -569,3 +569,28 @@ def test_pcg_lazy_x_update_exit_semantics_match_eager_loop():
     assert -5 in infos and -1 in infos  # the sweep really crosses the stagnation point
     k5 = min(o[1] for o in outs[1][:-1] if o[0] == -5)
     assert k5 > 3  # stagnation after several iterations, not a crafted first-iteration case
+
+
+@pytest.mark.parametrize("n", [1000, 4097, 1 << 16])
+def test_reductions_do_not_depend_on_alignment(n):
+    """the vector kernels use one 16-byte access per lane when every pointer is 16-byte aligned and n is even,
+    two 8-byte accesses otherwise -- with the SAME elements per thread, so a reduction has the same bits at
+    either alignment (the owned slice of an extended vector starts at an odd offset as often as not)"""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    bx, by = dev.DeviceBuffer(n + 2), dev.DeviceBuffer(n + 2)
+    out = dev.DeviceBuffer(4)
+    res = []
+    for off in (0, 1):
+        check(L.psp_memcpy_h2d(bx.ptr + 8 * off, x.ctypes.data, 8 * n))
+        check(L.psp_memcpy_h2d(by.ptr + 8 * off, y.ctypes.data, 8 * n))
+        check(L.psp_k_dot(n, bx.ptr + 8 * off, by.ptr + 8 * off, out.ptr))
+        d = out.download()[0]
+        r = dev.DeviceBuffer(n + 2)
+        check(L.psp_memcpy_h2d(r.ptr + 8 * off, y.ctypes.data, 8 * n))
+        check(L.psp_k_residual(n, bx.ptr + 8 * off, r.ptr + 8 * off, None, out.ptr))
+        res.append((d,) + tuple(out.download()[:2]))
+    assert res[0] == res[1]

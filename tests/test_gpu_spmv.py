@@ -481,7 +481,7 @@ def test_csr_matvec_transp_w4_exact(oracle, case):
     assert np.array_equal(y, y2, equal_nan=True)  # reproducible
 
 
-@pytest.mark.parametrize("shuffle", [8, 64])
+@pytest.mark.parametrize("shuffle", [64, 512])
 def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
     """Irregular numbering (FEM-like stand-in with shuffled node ids): chunks reference more than 64 x blocks,
     so csr_spmv_w3 does not apply to the stored numbering; the handle builds a reverse Cuthill-McKee
@@ -519,6 +519,11 @@ def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
     assert np.array_equal(yd.download(), ya)
     d = float(out.download()[0])
     assert abs(d - float(np.dot(x, ya))) <= 1e-12 * abs(d)
+    A.set_variant(16578)  # the dot is formed in the caller's numbering: same bits as through csr_spmv_w2
+    check(L.psp_k_csr_matvec_dot(A._h, xd.ptr, 0, yd.ptr, out.ptr))
+    d2 = float(out.download()[0])
+    A.set_variant(-1)
+    assert abs(d2 - d) <= 1e-13 * abs(d)
     # solvers through the renumbered product
     b = np.empty(n)
     Ao.matvec(np.ones(n), b)
