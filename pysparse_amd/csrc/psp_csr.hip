@@ -659,7 +659,9 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w2(
 // more than NB blocks stay on w2.
 typedef unsigned short us4v __attribute__((ext_vector_type(4)));
 
-template <int NB>
+// SHIFT = 4: ids are 16-entry x blocks (csr_spmv_w3); SHIFT = 0: ids are the columns themselves and the
+// 16-bit value is the column's rank in the chunk's sorted list of distinct columns (csr_spmv_w5)
+template <int NB, int SHIFT = 4>
 __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, int write,
                                                       const int2 *__restrict__ tab,
                                                       const int *__restrict__ col,
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
   const long kb = (long)chunk * target;
   for (int i = lane; i < WT; i += 64) {
     const long k = kb + i;
-    keys[i] = (k >= s && k < e) ? (col[k] >> 4) : kNone;
+    keys[i] = (k >= s && k < e) ? (col[k] >> SHIFT) : kNone;
   }
   __syncthreads();
   // bitonic sort of the 1024 block ids
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
     unsigned short v = 0;
     if (k >= s && k < e) {
       const int c = col[k];
-      const int b = c >> 4;
+      const int b = c >> SHIFT;
       int lo = 0, hi = count - 1;  // b is in ulist[0, count)
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
         else
           hi = mid;
       }
-      v = (unsigned short)(lo * 16 + (c & 15));
+      v = (unsigned short)(SHIFT ? lo * 16 + (c & 15) : lo);
     }
     col16[(size_t)chunk * WT + i] = v;
   }
@@ -873,6 +875,136 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
         else
           y[ro_] = acc;
         if (dotv) dsum += dotv[ro_] * acc;
+      }
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    __syncthreads();  // red[] lives in wave 0's slice: every wave must be done with its rows
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < WPB; ++i) t += red[i];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ w5: distinct columns staged in LDS
+//
+// For numberings that scatter a chunk's columns over more x blocks than csr_spmv_w3's list holds
+// (unstructured meshes, shuffled node ids) the block form stages mostly unused entries.  w5 stages exactly
+// what the chunk needs: the builder lists the chunk's DISTINCT columns (sorted; 330-410 of them for 1000
+// nonzeros of a 3-D FEM operator with 3 unknowns per node) and rewrites the chunk's columns as 16-bit ranks
+// in that list.  The wave loads the list (coalesced, fixed stride), gathers x once per distinct column --
+// a third of the gathers csr_spmv_w2 issues, and consecutive lanes take neighbouring columns, so every cache
+// line of x is looked up once per chunk instead of ~10 times -- parks the entries in its LDS slice and goes on
+// exactly like w3: products from LDS, rows added left to right (csr_mat.c:49-54) => the same bits.
+// No renumbering, no extra passes over x or y.  Bytes: 10 per nonzero + 4 per list slot.
+template <int NP, int NU64, int WPB, bool NTS>
+__global__ __launch_bounds__(64 * WPB) void csr_spmv_w5(
+    int chunk0, int nchunks, int stripe, int target, int kmax, const int2 *__restrict__ tab,
+    const unsigned short *__restrict__ rowoff, const unsigned short *__restrict__ col16,
+    const int *__restrict__ ulist, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials,
+    const int *__restrict__ skip) {
+  constexpr int WT = 1024;
+  constexpr int STEPS = WT / 256;
+  constexpr int E = 64 * NP;
+  constexpr int NU = 64 * NU64;  // list slots per chunk (<= WT: the products overwrite the staged entries)
+  static_assert(NU <= WT, "the staged entries must fit the product slice");
+  if (skip && *skip) return;
+  __shared__ double lds_all[WPB * WT];
+  double *red = lds_all;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *buf = lds_all + wid * WT;
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int chunk = chunk0 + vb * WPB + wid;
+  double dsum = 0.0;
+  if (chunk < nchunks) {
+    const int kb = chunk * target;
+    // --- independent loads: the column list first (the gathers depend on it), values, ranks, row offsets
+    const int *ul = ulist + (size_t)chunk * NU;
+    int idx[NU64];
+#pragma unroll
+    for (int j = 0; j < NU64; ++j) idx[j] = ul[j * 64 + lane];
+    d2v v0[STEPS], v1[STEPS];
+    us4v c[STEPS];
+    const unsigned short *cp = col16 + (size_t)chunk * WT;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      int k = kb + (st * 64 + lane) * 4;
+      k = (k < kmax) ? k : kmax;
+      v0[st] = ldg<true>(reinterpret_cast<const d2v *>(val + k));
+      v1[st] = ldg<true>(reinterpret_cast<const d2v *>(val + k + 2));
+      c[st] = ldg<true>(reinterpret_cast<const us4v *>(cp + (st * 64 + lane) * 4));
+    }
+    const unsigned short *ro = rowoff + (size_t)chunk * E;
+    int lo[NP], hi[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      lo[m] = ro[i];
+      hi[m] = ro[i + 1 < E ? i + 1 : E - 1];
+    }
+    const int r0 = tab[chunk].x;
+    const int nr = tab[chunk + 1].x - r0;
+    // --- one gather per distinct column (padding slots repeat the last one), parked in the LDS slice
+    double xs[NU64];
+#pragma unroll
+    for (int j = 0; j < NU64; ++j) xs[j] = x[idx[j]];
+#pragma unroll
+    for (int j = 0; j < NU64; ++j) buf[j * 64 + lane] = xs[j];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- products from LDS, then they take the list's place
+    d2v p0[STEPS], p1[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      p0[st].x = v0[st].x * buf[c[st].x];
+      p0[st].y = v0[st].y * buf[c[st].y];
+      p1[st].x = v1[st].x * buf[c[st].z];
+      p1[st].y = v1[st].y * buf[c[st].w];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int off = (st * 64 + lane) * 4;
+      *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
+      *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- one lane per row, products added left to right (reference order, csr_mat.c:49-54)
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      if (i < nr) {
+        double acc = 0.0;
+        for (int k = lo[m]; k < hi[m]; k += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int id = k + u;
+            id = id < WT ? id : WT - 1;
+            t[u] = buf[id];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
+        }
+        if constexpr (NTS)
+          __builtin_nontemporal_store(acc, &y[r0 + i]);
+        else
+          y[r0 + i] = acc;
+        if (dotv) dsum += dotv[r0 + i] * acc;
       }
     }
   }
@@ -1798,6 +1930,12 @@ struct ChunkTable {
   int max_blocks = 0;
   int *blist = nullptr;
   unsigned short *col16 = nullptr;
+  // csr_spmv_w5: per chunk its distinct columns (fixed stride nu, a multiple of 64) and the chunk's columns
+  // as 16-bit ranks in that list (fixed stride 1024)
+  int nu = -1;        // -1: not examined yet, 0: not worth it (some chunk has too many distinct columns)
+  int max_cols = 0;
+  int *ulist = nullptr;
+  unsigned short *colu = nullptr;
   // plane-sweeping workgroup schedule (build_schedule): launch slot -> workgroup, or absent
   int sched_state = -1;  // -1 not examined, 0 none (natural order + XCD stripes), 1 present
   int sched_grid = 0;
@@ -1918,6 +2056,14 @@ static int ensure_rowoff(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+// scratch device allocation released on every exit path
+struct ScratchDev {
+  void *p = nullptr;
+  ~ScratchDev() {
+    if (p) (void)hipFree(p);
+  }
+};
+
 // block lists + 16-bit columns of csr_spmv_w3 (built on first use; needs the w2 tables)
 static int w3_nb_cap() {
   static const int cap = [] {
@@ -1975,6 +2121,58 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   PSP_HIP(hipStreamSynchronize(stream()));
   PSP_HIP(hipFree(d_max));
   t->nb = nb;
+  return PSP_OK;
+}
+
+
+// column lists + 16-bit ranks of csr_spmv_w5 (built on first use; needs the w2 tables)
+static int ensure_w5(const psp_csr *A, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (t->nu >= 0) return PSP_OK;
+  t->nu = 0;
+  static const bool off = [] {
+    const char *e = getenv("PSP_SPMV_W5");
+    return e && atoi(e) == 0;
+  }();
+  if (off || t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
+  ScratchDev max_mem;
+  PSP_HIP(hipMalloc(&max_mem.p, sizeof(int)));
+  int *d_max = (int *)max_mem.p;
+  PSP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), stream()));
+  // pass 1: most distinct columns referenced by one chunk
+  hipLaunchKernelGGL((build_w3_kernel<1024, 0>), dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target, 0,
+                     t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
+  PSP_LAUNCH_CHECK();
+  int mc = 0;
+  PSP_HIP(hipMemcpyAsync(&mc, d_max, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  t->max_cols = mc;
+  // staging pays while a column is used more than once on average: lists of up to half a tile
+  int nu = 0;
+  if (mc <= 256) nu = 256;
+  else if (mc <= 384) nu = 384;
+  else if (mc <= 512) nu = 512;
+  if (nu == 0) return PSP_OK;
+  hipError_t e1 = hipMalloc((void **)&t->ulist, sizeof(int) * (size_t)t->nchunks * nu);
+  hipError_t e2 = hipMalloc((void **)&t->colu, sizeof(unsigned short) * (size_t)t->nchunks * 1024);
+  if (e1 != hipSuccess || e2 != hipSuccess) {  // no room for the extra tables: stay on w2
+    (void)hipGetLastError();
+    if (e1 == hipSuccess) (void)hipFree(t->ulist);
+    if (e2 == hipSuccess) (void)hipFree(t->colu);
+    t->ulist = nullptr;
+    t->colu = nullptr;
+    return PSP_OK;
+  }
+#define PSP_BUILD_W5(NU)                                                                              \
+  hipLaunchKernelGGL((build_w3_kernel<NU, 0>), dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks,    \
+                     t->target, 1, t->tab, A->col, t->ulist, t->colu, d_max)
+  if (nu == 256) PSP_BUILD_W5(256);
+  else if (nu == 384) PSP_BUILD_W5(384);
+  else PSP_BUILD_W5(512);
+#undef PSP_BUILD_W5
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  t->nu = nu;
   return PSP_OK;
 }
 
@@ -2084,14 +2282,6 @@ static int ensure_schedule(const psp_csr *A, ChunkTable *t) {
   t->sched_state = 1;
   return PSP_OK;
 }
-
-// scratch device allocation released on every exit path
-struct ScratchDev {
-  void *p = nullptr;
-  ~ScratchDev() {
-    if (p) (void)hipFree(p);
-  }
-};
 
 // offset-structured layout of csr_spmv_w4 (built on first use)
 static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
@@ -2580,6 +2770,55 @@ static void launch_w3(const psp_csr *A, const ChunkTable *t, bool nts, int grid,
   else launch_w3_np<4>(A, t, nts, grid, stripe, c0, c1, x, y, dotv, pbuf, skip, perm, rowperm);
 }
 
+// csr_spmv_w5 over chunks [c0, c1)
+template <int NP>
+static void launch_w5_np(const psp_csr *A, const ChunkTable *t, int grid, int stripe, int c0, int c1, const double *x,
+                         double *y, const double *dotv, double *pbuf, const int *skip) {
+#define PSP_W5(NU64)                                                                                  \
+  hipLaunchKernelGGL((csr_spmv_w5<NP, NU64, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe, \
+                     t->target, (int)A->padded - 4, t->tab, t->rowoff, t->colu, t->ulist, A->val, x, y, dotv, \
+                     pbuf, skip)
+  if (t->nu == 256) PSP_W5(4);
+  else if (t->nu == 384) PSP_W5(6);
+  else PSP_W5(8);
+#undef PSP_W5
+}
+
+static void launch_w5(const psp_csr *A, const ChunkTable *t, int grid, int stripe, int c0, int c1, const double *x,
+                      double *y, const double *dotv, double *pbuf, const int *skip) {
+  if (t->np == 2) launch_w5_np<2>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else if (t->np == 3) launch_w5_np<3>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+  else launch_w5_np<4>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
+}
+
+// What multiplies a matrix whose stored numbering scatters a chunk's columns over more x blocks than
+// csr_spmv_w3 takes (t->nb == 0): 1 = the renumbered copy through csr_spmv_w3 (measured best on the FEM-like
+// stand-ins and the only form that cuts the cache-line traffic of the x gathers), 2 = csr_spmv_w5, 0 = neither
+// (csr_spmv_w2).  A/B: variant bit 27 switches the renumbered copy off, bit 28 csr_spmv_w5.
+static int pick_scattered(const psp_csr *A, ChunkTable *t, psp::CsrExtra **ex_out, int *mode) {
+  *mode = 0;
+  if (t->nb != 0 || t->max_blocks <= 0) return PSP_OK;
+  const int var = A->variant < 0 ? 0 : A->variant;
+  if (((var >> 27) & 1) == 0) {
+    psp::CsrExtra *exr;
+    {
+      std::lock_guard<std::mutex> lk(g_extra_mu);
+      exr = &g_extra[A];
+    }
+    PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
+    if (exr->reorder_state == 1) {
+      *ex_out = exr;
+      *mode = 1;
+      return PSP_OK;
+    }
+  }
+  if (((var >> 28) & 1) == 0) {
+    PSP_TRY(ensure_w5(A, t));
+    if (t->nu > 0) *mode = 2;
+  }
+  return PSP_OK;
+}
+
 // y = A x through the renumbered copy: xp = x[perm]; yp = R xp (csr_spmv_w3); y[j] = yp[inv[j]] (+ the dot)
 static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, const double *x, double *y,
                             const double *dotv, double *partials, int *nparts, const int *skip) {
@@ -2738,6 +2977,42 @@ bool csr_spmv_has_skip(const psp_csr *A) {
   return t->np != 0;
 }
 
+// The renumbered copy R = P A P^T when y = A x goes through it (nullptr otherwise), with perm (new -> old)
+// and inv (old -> new) on the device: the fused solver loops then run entirely in the new numbering --
+// b, x0 and dinv are permuted once, x is permuted back once -- instead of paying the two permutation passes
+// of launch_reordered in every iteration.
+int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const int **inv) {
+  *R = nullptr;
+  Variant v = decode_variant(A->variant);
+  if (A->w4_only || A->no_reorder || !(v.w1 && v.w2 && v.w3) || A->nrows != A->ncols ||
+      A->max_row_nnz > v.tile / 2 || v.tile != 1024)
+    return PSP_OK;
+  if (v.w4) {
+    if (A->sym_owner) {
+      psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
+      PSP_TRY(ensure_sss_w4(S));
+      if (S->w4_state == 1) return PSP_OK;
+    }
+    psp::CsrExtra *ex;
+    PSP_TRY(ensure_w4(A, &ex));
+    if (ex->dia_state == 1) return PSP_OK;
+  }
+  ChunkTable *t;
+  PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
+  PSP_TRY(ensure_rowoff(A, t));
+  if (t->np == 0) return PSP_OK;
+  PSP_TRY(ensure_w3(A, t));
+  psp::CsrExtra *exs = nullptr;
+  int mode = 0;
+  PSP_TRY(pick_scattered(A, t, &exs, &mode));
+  if (mode != 1) return PSP_OK;
+  exs->reordered->variant = A->variant;
+  *R = exs->reordered;
+  *perm = exs->perm;
+  *inv = exs->inv;
+  return PSP_OK;
+}
+
 int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *dotv,
                     double *partials, int *nparts, const int *skip) {
   Workspace *w;
@@ -2846,14 +3121,33 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       }
       pbuf = ex->big_partials;
     }
-    if (!use_w3 && v.w2 && v.w3 && t->max_blocks > 0) {  // irregular numbering: try the renumbered copy
-      psp::CsrExtra *exr;
-      {
-        std::lock_guard<std::mutex> lk(g_extra_mu);
-        exr = &g_extra[A];
+    if (!use_w3 && v.w2 && v.w3) {  // scattered numbering
+      psp::CsrExtra *exs = nullptr;
+      int mode = 0;
+      PSP_TRY(pick_scattered(A, t, &exs, &mode));
+      if (mode == 1) return launch_reordered(A, exs, stripe, x, y, dotv, partials, nparts, skip);
+      if (mode == 2) {
+        double *pb5 = partials;
+        if (partials && grid > kMaxParts) {
+          psp::CsrExtra *ex5;
+          {
+            std::lock_guard<std::mutex> lk(g_extra_mu);
+            ex5 = &g_extra[A];
+          }
+          PSP_TRY(ensure_big_partials(ex5, grid));
+          pb5 = ex5->big_partials;
+        }
+        launch_w5(A, t, grid, stripe, 0, t->nchunks, x, y, dotv, pb5, skip);
+        PSP_LAUNCH_CHECK();
+        int np5 = grid;
+        if (pb5 != partials) {
+          np5 = kFold;
+          hipLaunchKernelGGL(fold_partials_kernel, dim3(np5 / 16), dim3(256), 0, stream(), pb5, grid, partials, np5);
+          PSP_LAUNCH_CHECK();
+        }
+        if (nparts) *nparts = np5;
+        return PSP_OK;
       }
-      PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
-      if (exr->reorder_state == 1) return launch_reordered(A, exr, stripe, x, y, dotv, partials, nparts, skip);
     }
     if (use_w3) {
       launch_w3(A, t, v.full_grid, grid, stripe, 0, t->nchunks, x, y, dotv, pbuf, skip, perm);
@@ -3334,6 +3628,8 @@ int psp_csr_destroy(psp_csr_t *A) {
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
         if (t.second.blist) (void)hipFree(t.second.blist);
         if (t.second.col16) (void)hipFree(t.second.col16);
+        if (t.second.ulist) (void)hipFree(t.second.ulist);
+        if (t.second.colu) (void)hipFree(t.second.colu);
         if (t.second.perm) (void)hipFree(t.second.perm);
       }
       if (it->second.big_partials) (void)hipFree(it->second.big_partials);
@@ -3517,20 +3813,21 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
         if (v.w3) {
           PSP_TRY(ensure_w3(A, t));
           vals[1] = t->max_blocks;
-          if (t->nb == 0 && t->max_blocks > 0) {  // the renumbered copy (psp_reorder.hip), if it qualifies
-            psp::CsrExtra *exr;
-            {
-              std::lock_guard<std::mutex> lk(g_extra_mu);
-              exr = &g_extra[A];
-            }
-            PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
-            if (exr->reorder_state == 1) {
+          {
+            psp::CsrExtra *exs = nullptr;
+            int mode = 0;
+            PSP_TRY(pick_scattered(A, t, &exs, &mode));
+            if (mode == 1) {
               ChunkTable *rt;
-              PSP_TRY(get_chunk_table(exr->reordered, 1024, &rt));
+              PSP_TRY(get_chunk_table(exs->reordered, 1024, &rt));
               k = "csr_spmv_w3_rcm";
               vals[0] = rt->nb;
               vals[1] = rt->max_blocks;
               vals[3] = t->max_blocks;  // what the stored numbering needs
+            } else if (mode == 2) {
+              k = "csr_spmv_w5";
+              vals[0] = t->nu;
+              vals[3] = t->max_cols;
             }
           }
           if (t->nb > 0) {

@@ -214,6 +214,8 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
 int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,
                            int *nparts, int *available, const int *skip = nullptr,
                            const double *xdiv_dev = nullptr);
+int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const int **inv);  // psp_csr.hip
+int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // xp[i] = x[perm[i]]
 // true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
 bool csr_spmv_has_skip(const psp_csr *A);
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,

@@ -608,8 +608,11 @@ done:
   return rc;
 }
 
-static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
-                      double tol, int maxit, int *info, int *iter, double *relres, double *hist) {
+// Acsr_forced != nullptr: the caller has moved the system into the numbering of a renumbered copy of A
+// (pcg_device below): multiply with that handle, take z = dinv_forced .* r (or z = r), never touch A / K
+static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_forced, const double *dinv_forced,
+                           int n, double *x, const double *b, double tol, int maxit, int *info, int *iter,
+                           double *relres, double *hist) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   DevVecs mem;
@@ -618,9 +621,9 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
   PSP_TRY(mem.alloc(n, &p));
   PSP_TRY(mem.alloc(n, &q));
 
-  psp_csr *Acsr = op_native_csr(A);
-  const double *dinv = fused_dinv(K);
-  const bool fused = Acsr != nullptr && (K == nullptr || dinv != nullptr);
+  psp_csr *Acsr = Acsr_forced ? Acsr_forced : op_native_csr(A);
+  const double *dinv = Acsr_forced ? dinv_forced : fused_dinv(K);
+  const bool fused = Acsr != nullptr && (Acsr_forced || K == nullptr || dinv != nullptr);
   if (!fused && K) PSP_TRY(mem.alloc(n, &z));
   double *p2 = nullptr;  // second direction buffer of the p-update-in-SpMV path (csr_spmv_w4_pf)
   if (fused) PSP_TRY(mem.alloc(n, &p2));
@@ -645,7 +648,10 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
   const double tolb = tol * n2b;
 
   // r = b - A x, normr (pcg.c:72-75); the fused form also yields rho = r.z for iteration 1
-  PSP_TRY(op_apply(A, x, r));
+  if (Acsr_forced)
+    PSP_TRY(csr_spmv_launch(Acsr, x, r, nullptr, nullptr, nullptr));
+  else
+    PSP_TRY(op_apply(A, x, r));
   PSP_TRY(k_residual(n, b, r, fused ? dinv : nullptr, w->partials, &np));
   PSP_TRY(reduce_fetch(w, np, 2, s));
   double normr = sqrt(s[0]);
@@ -751,6 +757,64 @@ static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const 
   }
   *iter = it;  // pcg.c:165: maxit + 1 when the loop ran out
   *relres = normr / n2b;
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+
+// The fused solver loops in the numbering of A's renumbered copy (psp_reorder.hip) when the product y = A x
+// goes through one: b, x0 and dinv are permuted once, the loop multiplies with csr_spmv_w3 on the copy -- no
+// permutation passes per iteration -- and x is permuted back once.  Same algorithm; the reductions add their
+// terms in the new numbering (rounding-level differences, like any other summation order).
+// PSP_SOLVE_PERMUTED=0 keeps the caller's numbering.
+struct PermutedSystem {
+  psp_csr *R = nullptr;
+  const int *perm = nullptr, *inv = nullptr;
+  double *xp = nullptr, *bp = nullptr, *dp = nullptr;
+  bool registered = false;
+  ~PermutedSystem() {
+    if (registered) dinv_unregister(dp);
+  }
+  // *active = 1 when the system was moved
+  int enter(const psp_op *A, const psp_op *K, int n, DevVecs &mem, const double *x, const double *b, int *active) {
+    *active = 0;
+    static const bool off = [] {
+      const char *e = getenv("PSP_SOLVE_PERMUTED");
+      return e && atoi(e) == 0;
+    }();
+    psp_csr *Acsr = op_native_csr(A);
+    const double *dinv = fused_dinv(K);
+    if (off || !Acsr || !(K == nullptr || dinv != nullptr)) return PSP_OK;
+    PSP_TRY(csr_reordered_view(Acsr, &R, &perm, &inv));
+    if (!R) return PSP_OK;
+    PSP_TRY(mem.alloc(n, &xp));
+    PSP_TRY(mem.alloc(n, &bp));
+    PSP_TRY(reorder_gather(n, perm, x, xp, nullptr));
+    PSP_TRY(reorder_gather(n, perm, b, bp, nullptr));
+    if (dinv) {
+      PSP_TRY(mem.alloc(n, &dp));
+      PSP_TRY(reorder_gather(n, perm, dinv, dp, nullptr));
+      double c;
+      if (dinv_constant(dinv, n, &c)) {  // a constant vector stays constant
+        PSP_TRY(dinv_register(dp, n));
+        registered = true;
+      }
+    }
+    *active = 1;
+    return PSP_OK;
+  }
+  int leave(int n, double *x) { return reorder_gather(n, inv, xp, x, nullptr); }  // x[j] = xp[inv[j]]
+};
+
+static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit,
+                      int *info, int *iter, double *relres, double *hist) {
+  DevVecs mem;
+  PermutedSystem ps;
+  int active = 0;
+  PSP_TRY(ps.enter(A, K, n, mem, x, b, &active));
+  if (!active) return pcg_device_core(A, K, nullptr, nullptr, n, x, b, tol, maxit, info, iter, relres, hist);
+  PSP_TRY(pcg_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, tol, maxit, info, iter, relres, hist));
+  PSP_TRY(ps.leave(n, x));
   PSP_HIP(hipStreamSynchronize(stream()));
   return PSP_OK;
 }
@@ -965,9 +1029,9 @@ done:
   return rc;
 }
 
-static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b,
-                         double errtol, int it_max, int *info, int *iter, double *relres,
-                         double *hist) {
+static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_forced, const double *dinv_forced,
+                              int n, double *x, const double *b, double errtol, int it_max, int *info, int *iter,
+                              double *relres, double *hist) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   DevVecs mem;
@@ -978,15 +1042,16 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   PSP_TRY(mem.alloc(n, &w_old));
   PSP_TRY(mem.alloc(n, &v));
   PSP_TRY(mem.alloc(n, &av));
-  if (K) PSP_TRY(mem.alloc(n, &y));
+  const bool hasK = Acsr_forced ? dinv_forced != nullptr : K != nullptr;
+  if (hasK) PSP_TRY(mem.alloc(n, &y));
 
-  psp_csr *Acsr = op_native_csr(A);
-  const double *dinv = fused_dinv(K);
-  const bool kfused = (K == nullptr) || dinv != nullptr;  // y = K v_hat can ride in the update
+  psp_csr *Acsr = Acsr_forced ? Acsr_forced : op_native_csr(A);
+  const double *dinv = Acsr_forced ? dinv_forced : fused_dinv(K);
+  const bool kfused = Acsr_forced || (K == nullptr) || dinv != nullptr;  // y = K v_hat can ride in the update
   // scaled mode (index-free SpMV layouts): v = y / beta is never stored; the unnormalised vector of
   // the iteration must then survive the Lanczos update, so y ping-pongs between two buffers
   double *y2 = nullptr;
-  if (K && kfused && Acsr) PSP_TRY(mem.alloc(n, &y2));
+  if (hasK && kfused && Acsr) PSP_TRY(mem.alloc(n, &y2));
   const size_t bytes = sizeof(double) * (size_t)n;
   double s[4];
   int np;
@@ -994,13 +1059,19 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   *iter = 0;
   PSP_HIP(hipMemsetAsync(v_hat_old, 0, bytes, stream()));  // minres.c:63-65
   // v_hat = b - A x; norm_r0 (minres.c:67-71); fused: also v_hat . (dinv.*v_hat)
-  PSP_TRY(op_apply(A, x, v_hat));
+  if (Acsr_forced)
+    PSP_TRY(csr_spmv_launch(Acsr, x, v_hat, nullptr, nullptr, nullptr));
+  else
+    PSP_TRY(op_apply(A, x, v_hat));
   PSP_TRY(k_residual(n, b, v_hat, kfused ? dinv : nullptr, w->partials, &np));
   PSP_TRY(reduce_fetch(w, np, 2, s));
   const double norm_r0 = sqrt(s[0]);
   double beta = s[1];
-  if (K) {  // y = K v_hat (minres.c:73-76)
-    PSP_TRY(op_apply(K, v_hat, y));
+  if (hasK) {  // y = K v_hat (minres.c:73-76)
+    if (Acsr_forced)
+      PSP_TRY(k_jacobi_first(n, v_hat, dinv, y));
+    else
+      PSP_TRY(op_apply(K, v_hat, y));
     if (!kfused) {
       PSP_TRY(k_dot(n, v_hat, y, w->partials, &np));  // minres.c:78
       PSP_TRY(reduce_fetch(w, np, 1, s));
@@ -1024,7 +1095,7 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
   if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
     if (hist)  // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
       for (int i = 1; i <= it_max; ++i) hist[i] = hist[i];
-    return minres_async_loop(Acsr, dinv, K != nullptr, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
+    return minres_async_loop(Acsr, dinv, hasK, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
                              beta, errtol, it_max, info, iter, relres, hist);
   }
 
@@ -1034,10 +1105,10 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
 
     // v = y / beta (minres.c:123-124); y = v_hat is implied: the update below keeps the
     // old v_hat in v_hat_old directly (minres.c:125,135)
-    const double *vsrc = K ? y : v_hat;  // unnormalised Lanczos vector of this iteration
+    const double *vsrc = hasK ? y : v_hat;  // unnormalised Lanczos vector of this iteration
     const double vdiv = beta;
     int scaled = 0;
-    if (Acsr && kfused && (!K || y2))
+    if (Acsr && kfused && (!hasK || y2))
       PSP_TRY(csr_spmv_scaled_launch(Acsr, vsrc, vdiv, av, w->partials, &np, &scaled));
     if (!scaled) PSP_TRY(k_scale_div(n, vsrc, beta, v));
     // Av = A v, alpha = v.Av (minres.c:127-129)
@@ -1055,10 +1126,10 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
     // (the kernels write the new v_hat over v_hat_old; swapping the names is "v_hat_old = old v_hat")
     if (kfused) {
       // scaled mode: the new y goes to the other buffer (vsrc = old y is still needed by the w update)
-      double *ynew = (scaled && K) ? y2 : y;
+      double *ynew = (scaled && hasK) ? y2 : y;
       PSP_TRY(k_lanczos(n, av, dconst1, dconst2, v_hat, v_hat_old, dinv, ynew, w->partials, &np));
       std::swap(v_hat, v_hat_old);
-      if (scaled && K) std::swap(y, y2);
+      if (scaled && hasK) std::swap(y, y2);
     } else {
       PSP_TRY(k_lanczos_plain(n, av, dconst1, dconst2, v_hat, v_hat_old));
       std::swap(v_hat, v_hat_old);
@@ -1103,6 +1174,19 @@ static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, con
 
   *relres = norm_rmr / norm_r0;  // minres.c:195
   *info = (norm_rmr < errtol * norm_r0) ? 0 : -1;
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double errtol,
+                         int it_max, int *info, int *iter, double *relres, double *hist) {
+  DevVecs mem;
+  PermutedSystem ps;
+  int active = 0;
+  if (minres_async_enabled()) PSP_TRY(ps.enter(A, K, n, mem, x, b, &active));
+  if (!active) return minres_device_core(A, K, nullptr, nullptr, n, x, b, errtol, it_max, info, iter, relres, hist);
+  PSP_TRY(minres_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, errtol, it_max, info, iter, relres, hist));
+  PSP_TRY(ps.leave(n, x));
   PSP_HIP(hipStreamSynchronize(stream()));
   return PSP_OK;
 }

@@ -4,7 +4,8 @@ stand-ins (pysparse_amd/tools/standins.py: n = 929 424 FEM-like with shuffled no
 log-spaced) and, when EMILIA_MTX names a MatrixMarket file, on the real matrix through
 tools.mtx.sss_arrays_from_mtx:
   * sss_mat.matvec bit-identical to the oracle's sss_matvec loop (sss_mat.c:40-56), whichever kernel runs
-    (the renumbered csr_spmv_w3 for numberings that can be made banded, the gather kernels otherwise);
+    (the renumbered copy through csr_spmv_w3 for scattered numberings that can be made banded, csr_spmv_w5 --
+    distinct columns staged in LDS --, the gather kernels);
   * Jacobi-MINRES: same info and iteration count as the oracle (minres.c:43-200), iterate <= 1e-12 relative,
     residual history to 1e-8;
   * Jacobi-PCG likewise (the matrices are SPD)."""
@@ -49,7 +50,7 @@ def test_config5_sss_matvec_and_minres_at_scale(oracle, name):
         So.matvec(x, yo)
         assert np.array_equal(y, yo), name
     # every other kernel gives the same bits
-    for variant in (16578, 16513):
+    for variant in (16578, 16513, 5259458 + (1 << 27)):  # w2, w1, csr_spmv_w5 (renumbered copy switched off)
         S.set_variant(variant)
         y2 = np.empty(n)
         S.matvec(x, y2)

@@ -481,13 +481,18 @@ def test_csr_matvec_transp_w4_exact(oracle, case):
     assert np.array_equal(y, y2, equal_nan=True)  # reproducible
 
 
+W5_VARIANT = 5259458 + (1 << 27)  # the default kernel selection with the renumbered copy switched off (bit 27)
+
+
 @pytest.mark.parametrize("shuffle", [64, 512])
-def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
+@pytest.mark.parametrize("form", ["w5", "rcm"])
+def test_csr_matvec_scattered_numbering_bit_exact(oracle, shuffle, form):
     """Irregular numbering (FEM-like stand-in with shuffled node ids): chunks reference more than 64 x blocks,
-    so csr_spmv_w3 does not apply to the stored numbering; the handle builds a reverse Cuthill-McKee
-    renumbered copy (psp_reorder.hip) and multiplies through it -- gather x, csr_spmv_w3 storing through the
-    row permutation.  Per-row storage order is kept, so y has the oracle's bits; the fused dot and the
-    solvers run through the same path."""
+    so csr_spmv_w3 does not apply to the stored numbering.  Default: a reverse Cuthill-McKee renumbered copy
+    (psp_reorder.hip) multiplied with csr_spmv_w3 between two permutation passes (the fused solver loops run in
+    the new numbering altogether).  Alternative (variant bit 27 switches the copy off): csr_spmv_w5 stages the
+    chunk's distinct columns in LDS (one gather per distinct column).  Per-row storage order is kept by both,
+    so y has the oracle's bits; the fused dot and the solvers run through the same paths."""
     from pysparse_amd import device as dev
     from pysparse_amd._capi import check, lib
     from pysparse_amd.tools.standins import fem_sss_arrays
@@ -496,12 +501,17 @@ def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
     So = oracle.SSS(n, val, diag, col, ind)
     Ao = oracle.sss_to_csr(So)
     A = dev.DeviceCSR.from_arrays(Ao.shape, Ao.ind, Ao.col, Ao.val)
+    variant = -1 if form == "rcm" else W5_VARIANT
     x = np.random.default_rng(3).standard_normal(n)
     yo = np.empty(n)
     So.matvec(x, yo)
     for M in (S, A):
+        M.set_variant(variant)
         kern, info = M.kernel_info()
-        assert kern == "csr_spmv_w3_rcm" and info["max_blocks"] <= 64 < info["half_band"], (kern, info)
+        if form == "w5":
+            assert kern == "csr_spmv_w5" and info["max_blocks"] > 64 and info["half_band"] <= info["nb"] <= 512, (kern, info)
+        else:
+            assert kern == "csr_spmv_w3_rcm" and info["max_blocks"] <= 64 < info["half_band"], (kern, info)
         y = np.full(n, np.nan)
         M.matvec(x, y)
         assert np.array_equal(y, yo)
@@ -519,12 +529,7 @@ def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
     assert np.array_equal(yd.download(), ya)
     d = float(out.download()[0])
     assert abs(d - float(np.dot(x, ya))) <= 1e-12 * abs(d)
-    A.set_variant(16578)  # the dot is formed in the caller's numbering: same bits as through csr_spmv_w2
-    check(L.psp_k_csr_matvec_dot(A._h, xd.ptr, 0, yd.ptr, out.ptr))
-    d2 = float(out.download()[0])
-    A.set_variant(-1)
-    assert abs(d2 - d) <= 1e-13 * abs(d)
-    # solvers through the renumbered product
+    # solvers through the same product
     b = np.empty(n)
     Ao.matvec(np.ones(n), b)
     dinv = oracle.jacobi_dinv(diag)
@@ -533,8 +538,46 @@ def test_csr_matvec_renumbered_w3_bit_exact(oracle, shuffle):
         ref = solver_o(Ao, b, xo, 1e-10, 500, dinv)
         got = solver_g(A, b, xg, 1e-10, 500, dev.DeviceJacobi(A))
         assert got[:2] == ref[:2] and np.abs(xg - xo).max() <= 1e-12 * np.abs(xo).max()
-    # PSP_SPMV_REORDER is read once per process; the explicit w2 variant bypasses the renumbered copy
-    A.set_variant(16578)
+    A.set_variant(16578)  # an explicit w2 variant bypasses both
     assert A.kernel_info()[0] == "csr_spmv_w2"
     A.matvec(x, y)
     assert np.array_equal(y, ya)
+
+
+def test_csr_matvec_w5_ragged_and_empty_rows(oracle):
+    """csr_spmv_w5 on a matrix with empty rows, single-entry rows, repeated columns in neighbouring rows and
+    a scattered numbering (random columns inside a band of 40 000): the oracle's bits"""
+    from pysparse_amd import device as dev
+    rng = np.random.default_rng(11)
+    n = 60000
+    lens = rng.integers(0, 40, size=n)
+    lens[rng.random(n) < 0.05] = 0
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=ind[1:])
+    rows = np.repeat(np.arange(n), lens)
+    # few distinct columns per chunk (so that w5 qualifies) but far apart (so that w3 does not)
+    pool = rng.integers(0, n, size=(n // 64 + 1, 160))
+    col = pool[rows // 64, rng.integers(0, 160, size=rows.size)].astype(np.int32)
+    order = np.lexsort((col, rows))
+    col = col[order]
+    keep = np.ones(col.size, dtype=bool)
+    keep[1:] = (col[1:] != col[:-1]) | (rows[1:] != rows[:-1])
+    col, rows = col[keep], rows[keep]
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=ind[1:])
+    val = rng.standard_normal(col.size)
+    A = oracle.CSR((n, n), val, col, ind)
+    D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    D.set_variant(W5_VARIANT)
+    kern, info = D.kernel_info()
+    assert kern == "csr_spmv_w5", (kern, info)
+    x = rng.standard_normal(n)
+    y, yo = np.full(n, np.nan), np.empty(n)
+    D.matvec(x, y)
+    A.matvec(x, yo)
+    assert np.array_equal(y, yo)
+    x[::7] = np.inf  # non-finite x reaches exactly the rows it reaches on the CPU
+    x[3::11] = np.nan
+    D.matvec(x, y)
+    A.matvec(x, yo)
+    assert np.array_equal(y, yo, equal_nan=True)

@@ -40,7 +40,7 @@ def main():
            "w3_nb_cap": os.environ.get("PSP_SPMV_W3_NB", "64")}
     ref = None
     extra = [("v%s" % v, int(v)) for v in a.variants.split(",") if v]
-    for name, variant in [("default", -1), ("w2", 16578)] + extra:
+    for name, variant in [("default", -1), ("w5", 5259458 + (1 << 27)), ("w2", 16578)] + extra:
         S.set_variant(variant)
         kern, info = S.kernel_info()
         f = lambda: S.matvec_dev(x.ptr, y.ptr)  # noqa: E731
@@ -61,6 +61,22 @@ def main():
     t0 = time.perf_counter()
     r = dev.minres(S, b, xh, 1e-10, 2000, dev.DeviceJacobi(S))
     res["minres"] = {"info": r[0], "iter": r[1], "relres": r[2], "seconds_incl_pcie": time.perf_counter() - t0}
+    # device-resident: fixed 200 MINRES iterations (tol 0) -> iterations/s, effective CSR-model GB/s of the product
+    import ctypes as C
+    K = dev.DeviceJacobi(S)
+    aop, kop = dev._Op(S, "matvec"), dev._Op(K, "precon")
+    bd = dev.DeviceBuffer.from_host(b)
+    xd = dev.DeviceBuffer(n)
+    for kk in (5, 200):
+        xd.zero()
+        info, it, rr = C.c_int(), C.c_int(), C.c_double()
+        check(L.psp_synchronize())
+        t0 = time.perf_counter()
+        check(L.psp_minres_dev(aop._h, kop._h, n, xd.ptr, bd.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
+        check(L.psp_synchronize())
+        dt = time.perf_counter() - t0
+    res["minres_200"] = {"iters_per_s": 200 / dt, "us_per_iter": dt / 200 * 1e6,
+                         "permuted_space": os.environ.get("PSP_SOLVE_PERMUTED", "1") != "0"}
     print(json.dumps(res), flush=True)
 
 
