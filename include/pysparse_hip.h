@@ -111,6 +111,22 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out);
 int psp_csr_poisson_big_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
                              int ncols_local, psp_csr_t **out);
 int64_t psp_csr_nnz64(const psp_csr_t *A);
+/* General CSR beyond the reference's C int (csr_mat.h:6-13: `int nnz`, `int *ind`): row offsets are 64-bit at
+ * this boundary, column indices stay 32-bit.  Above 2^30 nonzeros the rows are cut into parts of < 2^30
+ * nonzeros that share x and write disjoint row ranges of y ("64-bit row offsets ... or
+ * partitions resident on one device"): the SpMV kernels never see a 64-bit offset.  matvec, the diagonal,
+ * jacobi and the solvers work on such a handle; download goes by row ranges; there is no transposed product. */
+int psp_csr_create64(int nrows, int ncols, int64_t nnz, const int64_t *ind_host, const int *col_host,
+                     const double *val_host, psp_csr_t **out);
+/* Synthetic general (non-stencil) CSR generated on the device, for tests and measurements at sizes no host
+ * array reaches: row r stores m entries, entry j in column (r + (j - m/2)*stride + h(r, j) mod stride) mod ncols
+ * with a value in [-1, 1), h = splitmix64 of (seed, r, j) (psp_csr.hip: random_banded_kernel; the tests restate
+ * the formula).  nrows*m may exceed 2^31. */
+int psp_csr_random_banded(int nrows, int ncols, int m, int stride, uint64_t seed, psp_csr_t **out);
+/* rows [row_lo, row_hi) of any handle with CSR arrays: ind_host gets row_hi - row_lo + 1 offsets relative to
+ * row_lo; col_host / val_host (may be NULL) the entries */
+int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *ind_host, int *col_host,
+                          double *val_host);
 int psp_csr_destroy(psp_csr_t *A);
 /* shape / nnz attributes: CSRMatType_getattr, csr_mat.c:208-231 */
 int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz);

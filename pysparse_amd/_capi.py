@@ -20,7 +20,7 @@ SYMBOLS = """
 psp_last_error psp_version psp_device_count psp_set_device psp_set_stream psp_synchronize
 psp_device_info psp_mem_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset psp_trim
 psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms
-psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_destroy psp_csr_shape
+psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
 psp_csr_set_schedule psp_csr_kernel_info psp_csr_device_bytes
@@ -107,6 +107,9 @@ def _declare(L):
         "psp_csr_poisson": [i, i, i, pvp], "psp_csr_poisson_big": [i, i, i, pvp],
         "psp_csr_poisson_slab": [i, i, i, i64, i64, i64, i, pvp],
         "psp_csr_poisson_big_slab": [i, i, i, i64, i64, i64, i, pvp],
+        "psp_csr_create64": [i, i, i64, vp, vp, vp, pvp],
+        "psp_csr_random_banded": [i, i, i, i, C.c_uint64, pvp],
+        "psp_csr_download_rows": [vp, i, i, vp, vp, vp],
         "psp_csr_destroy": [vp], "psp_csr_shape": [vp, pi, pi, pi],
         "psp_csr_download": [vp, vp, vp, vp], "psp_csr_diagonal": [vp, vp],
         "psp_csr_matvec": [vp, vp, vp], "psp_csr_matvec_stride": [vp, vp, pt, vp, pt],

@@ -1722,14 +1722,45 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__rest
   if (g == 0 && o < nout) out[o] = s;
 }
 
-__global__ void csr_diag_kernel(int nrows, const int *__restrict__ ind,
+__global__ void csr_diag_kernel(int nrows, int row0, const int *__restrict__ ind,
                                 const int *__restrict__ col, const double *__restrict__ val,
                                 double *__restrict__ diag) {
+  // row0: global number of this handle's first row (parts of a partitioned matrix)
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     double d = 0.0;
     for (int k = ind[r]; k < ind[r + 1]; ++k)
-      if (col[k] == r) d = val[k];
+      if (col[k] == r + row0) d = val[k];
     diag[r] = d;
+  }
+}
+
+// pseudo-random banded rows for psp_csr_random_banded: row r stores m entries, entry j in column
+// (r + (j - m/2)*stride + h(r, j) mod stride) mod ncols with value in [-1, 1); the same integer formula is
+// restated by the tests (tests/test_gpu_big_csr.py)
+__device__ __host__ inline unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void random_banded_kernel(int nrows_part, long row0, int ncols, int m, int stride,
+                                     unsigned long long seed, int *__restrict__ ind, int *__restrict__ col,
+                                     double *__restrict__ val) {
+  const long total = (long)nrows_part * m;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t <= total; t += (long)gridDim.x * blockDim.x) {
+    if (t % m == 0) ind[t / m] = (int)t;
+    if (t == total) break;
+    const long r = row0 + t / m;
+    const int j = (int)(t % m);
+    const unsigned long long h = splitmix64(seed + (unsigned long long)r * 0x100000001B3ull +
+                                            (unsigned long long)j * 0xD6E8FEB86659FD93ull);
+    long c = r + (long)(j - m / 2) * stride + (long)(h % (unsigned long long)stride);
+    c %= ncols;
+    if (c < 0) c += ncols;
+    col[t] = (int)c;
+    const unsigned long long h2 = splitmix64(h);
+    val[t] = (double)(h2 >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
   }
 }
 
@@ -2505,6 +2536,7 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
 // y = A^T x through csr_spmv_w4_transp; *available = 0 when A has no 16-bit-mask w4 layout
 static int launch_w4_transp(const psp_csr *A, const double *x, double *y, int *available) {
   *available = 0;
+  if (A->nparts) return PSP_OK;
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   if (!v.w4 || A->nrows < 1 || A->ncols < 1) return PSP_OK;
@@ -2861,7 +2893,7 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
   }();
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
-  if (!on || !v.w4 || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  if (!on || !v.w4 || A->nparts || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
   const int stripe = w4_stripe(A, v);
   const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
   const int grid = w4_grid(nblk, stripe);
@@ -2914,7 +2946,7 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
     return e ? atoi(e) != 0 : false;
   }();
   Variant v = decode_variant(A->variant);
-  if (!on || !v.w4 || A->sym_owner || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  if (!on || !v.w4 || A->nparts || A->sym_owner || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
   psp::CsrExtra *ex;
   PSP_TRY(ensure_w4(A, &ex));
   if (ex->dia_state != 1 || ex->dia_no > 8) return PSP_OK;  // register budget: up to 8 offsets
@@ -2958,6 +2990,11 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
 }
 
 bool csr_spmv_has_skip(const psp_csr *A) {
+  if (A->nparts) {
+    for (int p = 0; p < A->nparts; ++p)
+      if (A->parts[p]->nrows && !csr_spmv_has_skip(A->parts[p])) return false;
+    return true;
+  }
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   if (v.w4 && A->sym_owner) {
@@ -2984,7 +3021,7 @@ bool csr_spmv_has_skip(const psp_csr *A) {
 int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const int **inv) {
   *R = nullptr;
   Variant v = decode_variant(A->variant);
-  if (A->w4_only || A->no_reorder || !(v.w1 && v.w2 && v.w3) || A->nrows != A->ncols ||
+  if (A->nparts || A->w4_only || A->no_reorder || !(v.w1 && v.w2 && v.w3) || A->nrows != A->ncols ||
       A->max_row_nnz > v.tile / 2 || v.tile != 1024)
     return PSP_OK;
   if (v.w4) {
@@ -3017,6 +3054,28 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
                     double *partials, int *nparts, const int *skip) {
   Workspace *w;
   PSP_TRY(workspace(&w));
+  if (A->nparts) {
+    // partitioned matrix: one product per part, rows offset; each part's dot partials are folded to kFold
+    // values at partials + p*kFold (fixed order), through the workspace's last slot
+    double *tmp = w->partials + (size_t)(kSlots - 1) * kMaxParts;
+    if (partials && (partials == tmp || (long)A->nparts * kFold > kMaxParts))
+      return fail(PSP_EINVAL, "csr_spmv_launch: partitioned matrix needs a partial-sum slot other than the last");
+    for (int p = 0; p < A->nparts; ++p) {
+      const psp_csr *P = A->parts[p];
+      if (P->nrows == 0) continue;
+      const int r0 = A->part_row0[p];
+      int np = 0;
+      PSP_TRY(csr_spmv_launch(P, x, y + r0, (partials && dotv) ? dotv + r0 : nullptr, partials ? tmp : nullptr, &np,
+                              skip));
+      if (partials) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), tmp, np,
+                           partials + (size_t)p * kFold, kFold);
+        PSP_LAUNCH_CHECK();
+      }
+    }
+    if (nparts) *nparts = A->nparts * kFold;
+    return PSP_OK;
+  }
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   if (v.w4 && A->sym_owner) {  // the full mirror of an sss_mat: multiply with the lower triangle only
@@ -3305,6 +3364,10 @@ static void launch_w2_range(const psp_csr *A, const ChunkTable *t, bool w3, int 
 int csr_spmv_overlap(const psp_csr *A, const double *x, double *y, const double *dotv,
                      double *partials, int *nparts, int row_a, int row_b, int (*wait)(void *),
                      void *ctx, const int *skip) {
+  if (A->nparts) {  // no split form: exchange first, then everything
+    if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+    return csr_spmv_launch(A, x, y, dotv, partials, nparts, skip);
+  }
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   if (v.w4 && row_a < row_b) {
@@ -3609,7 +3672,147 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
   return psp_csr_poisson_big_slab(nx, ny, nz, 0, n, 0, (int)n, out);
 }
 
-int64_t psp_csr_nnz64(const psp_csr_t *A) { return A ? (A->w4_only ? A->nnz64 : (int64_t)A->nnz) : 0; }
+int64_t psp_csr_nnz64(const psp_csr_t *A) {
+  return A ? ((A->w4_only || A->nparts) ? A->nnz64 : (int64_t)A->nnz) : 0;
+}
+
+// rows [r0, r1) of a host triple with 64-bit offsets as one ordinary handle
+static int create_part(int ncols, int64_t r0, int64_t r1, const int64_t *ind, const int *col, const double *val,
+                       psp_csr **out) {
+  const int64_t base = ind[r0];
+  const int64_t pn = ind[r1] - base;
+  std::vector<int> pind((size_t)(r1 - r0) + 1);
+  for (int64_t r = r0; r <= r1; ++r) pind[(size_t)(r - r0)] = (int)(ind[r] - base);
+  return psp_csr_create((int)(r1 - r0), ncols, (int)pn, pind.data(), col + base, val + base, out);
+}
+
+// nonzeros per part of a partitioned matrix; PSP_PART_NNZ lowers it so that the tests can cut small matrices
+static int64_t part_nnz() {
+  static const int64_t v = [] {
+    const char *e = getenv("PSP_PART_NNZ");
+    const long long t = e ? atoll(e) : 0;
+    return (int64_t)((t >= 64 && t < (1LL << 30)) ? t : (1LL << 30));
+  }();
+  return v;
+}
+#define kPartNnz part_nnz()
+
+static psp_csr *new_partitioned(int nrows, int ncols, int64_t nnz, int nparts) {
+  psp_csr *A = new psp_csr();
+  A->nrows = nrows;
+  A->ncols = ncols;
+  A->nnz = -1;
+  A->nnz64 = nnz;
+  A->nparts = nparts;
+  A->parts = new psp_csr *[nparts]();
+  A->part_row0 = new int[nparts + 1]();
+  return A;
+}
+
+int psp_csr_create64(int nrows, int ncols, int64_t nnz, const int64_t *ind_host, const int *col_host,
+                     const double *val_host, psp_csr_t **out) {
+  if (!out || !ind_host || (nnz > 0 && (!col_host || !val_host)))
+    return fail(PSP_EINVAL, "psp_csr_create64: NULL argument");
+  if (nrows < 0 || ncols < 0 || nnz < 0) return fail(PSP_EINVAL, "psp_csr_create64: negative size");
+  if (ind_host[0] != 0 || ind_host[nrows] != nnz)
+    return fail(PSP_EINVAL, "psp_csr_create64: ind[0] must be 0 and ind[nrows] == nnz");
+  for (int i = 0; i < nrows; ++i)
+    if (ind_host[i + 1] < ind_host[i]) return fail(PSP_EINVAL, "psp_csr_create64: ind not monotone at row %d", i);
+  if (nnz <= kPartNnz) {  // fits 32-bit offsets: an ordinary handle
+    psp_csr *P = nullptr;
+    PSP_TRY(create_part(ncols, 0, nrows, ind_host, col_host, val_host, &P));
+    *out = P;
+    return PSP_OK;
+  }
+  // cut at row boundaries so that every part holds at most kPartNnz nonzeros
+  std::vector<int64_t> cuts{0};
+  while (cuts.back() < nrows) {
+    const int64_t r0 = cuts.back();
+    const int64_t want = ind_host[r0] + kPartNnz;
+    int64_t r1 = std::upper_bound(ind_host + r0, ind_host + nrows + 1, want) - ind_host - 1;  // last r with ind[r] <= want
+    if (r1 <= r0) return fail(PSP_EINVAL, "psp_csr_create64: row %ld alone exceeds 2^30 nonzeros", (long)r0);
+    cuts.push_back(std::min<int64_t>(r1, nrows));
+  }
+  const int np = (int)cuts.size() - 1;
+  psp_csr *A = new_partitioned(nrows, ncols, nnz, np);
+  for (int p = 0; p < np; ++p) {
+    A->part_row0[p] = (int)cuts[p];
+    int rc = create_part(ncols, cuts[p], cuts[p + 1], ind_host, col_host, val_host, &A->parts[p]);
+    if (rc != PSP_OK) {
+      psp_csr_destroy(A);
+      return rc;
+    }
+    A->parts[p]->no_reorder = true;
+    A->max_row_nnz = std::max(A->max_row_nnz, A->parts[p]->max_row_nnz);
+  }
+  A->part_row0[np] = nrows;
+  *out = A;
+  return PSP_OK;
+}
+
+int psp_csr_random_banded(int nrows, int ncols, int m, int stride, uint64_t seed, psp_csr_t **out) {
+  if (!out || nrows < 1 || ncols < 1 || m < 1 || m > 512 || stride < 1 || (long)m * stride > ncols)
+    return fail(PSP_EINVAL, "psp_csr_random_banded: bad argument (need m*stride <= ncols)");
+  PSP_TRY(ensure_device());
+  const int64_t nnz = (int64_t)nrows * m;
+  const int64_t rows_per_part = std::max<int64_t>(1, kPartNnz / m);
+  const int np = (int)((nrows + rows_per_part - 1) / rows_per_part);
+  psp_csr *A = nullptr;
+  if (np > 1) A = new_partitioned(nrows, ncols, nnz, np);
+  for (int p = 0; p < np; ++p) {
+    const int64_t r0 = (int64_t)p * rows_per_part, r1 = std::min<int64_t>(nrows, r0 + rows_per_part);
+    psp_csr *P = nullptr;
+    int rc = alloc_csr((int)(r1 - r0), ncols, (r1 - r0) * m, &P);
+    if (rc == PSP_OK) {
+      hipLaunchKernelGGL(random_banded_kernel, dim3(65536), dim3(256), 0, stream(), (int)(r1 - r0), (long)r0, ncols, m,
+                         stride, (unsigned long long)seed, P->ind, P->col, P->val);
+      if (hipGetLastError() != hipSuccess) rc = fail(PSP_ENODEV, "psp_csr_random_banded: launch failed");
+    }
+    if (rc == PSP_OK) rc = finalize_csr(P);
+    if (rc != PSP_OK) {
+      if (P) psp_csr_destroy(P);
+      if (A) psp_csr_destroy(A);
+      return rc;
+    }
+    if (!A) {
+      *out = P;
+      return PSP_OK;
+    }
+    P->no_reorder = true;
+    A->parts[p] = P;
+    A->part_row0[p] = (int)r0;
+    A->max_row_nnz = std::max(A->max_row_nnz, P->max_row_nnz);
+  }
+  A->part_row0[np] = nrows;
+  *out = A;
+  return PSP_OK;
+}
+
+int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *ind_host, int *col_host,
+                          double *val_host) {
+  if (!A || !ind_host) return fail(PSP_EINVAL, "psp_csr_download_rows: NULL argument");
+  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download_rows: the operator has no CSR arrays");
+  if (row_lo < 0 || row_hi > A->nrows || row_lo > row_hi) return fail(PSP_EINVAL, "psp_csr_download_rows: bad row range");
+  int64_t written = 0;
+  ind_host[0] = 0;
+  const int np = A->nparts ? A->nparts : 1;
+  for (int p = 0; p < np; ++p) {
+    const psp_csr *P = A->nparts ? A->parts[p] : A;
+    const int p0 = A->nparts ? A->part_row0[p] : 0;
+    const int a = std::max(row_lo, p0) - p0, b = std::min(row_hi, p0 + P->nrows) - p0;
+    if (a >= b) continue;
+    std::vector<int> pi((size_t)(b - a) + 1);
+    PSP_HIP(hipMemcpy(pi.data(), P->ind + a, sizeof(int) * pi.size(), hipMemcpyDeviceToHost));
+    const int k0 = pi[0], cnt = pi.back() - k0;
+    for (int r = a; r < b; ++r) ind_host[(size_t)(p0 + r - row_lo) + 1] = written + (pi[(size_t)(r - a) + 1] - k0);
+    if (cnt > 0) {
+      if (col_host) PSP_HIP(hipMemcpy(col_host + written, P->col + k0, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost));
+      if (val_host) PSP_HIP(hipMemcpy(val_host + written, P->val + k0, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    }
+    written += cnt;
+  }
+  return PSP_OK;
+}
 
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
@@ -3640,6 +3843,9 @@ int psp_csr_destroy(psp_csr_t *A) {
       g_extra.erase(it);
     }
   }
+  for (int p = 0; p < A->nparts; ++p) psp_csr_destroy(A->parts[p]);
+  delete[] A->parts;
+  delete[] A->part_row0;
   if (transposed) psp_csr_destroy(transposed);  // outside the lock: it has side tables of its own
   if (reordered) psp_csr_destroy(reordered);
   (void)hipFree(A->ind);
@@ -3660,6 +3866,7 @@ int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz) {
 int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host) {
   if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
   if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big)");
+  if (A->nparts) return fail(PSP_EINVAL, "psp_csr_download: more than 2^31 nonzeros: use psp_csr_download_rows");
   if (ind_host)
     PSP_HIP(hipMemcpyAsync(ind_host, A->ind, sizeof(int) * ((size_t)A->nrows + 1),
                            hipMemcpyDeviceToHost, stream()));
@@ -3676,6 +3883,16 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
 int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
   PSP_API_GUARD;
   if (A->nrows == 0) return PSP_OK;
+  if (A->nparts) {
+    for (int p = 0; p < A->nparts; ++p) {
+      const psp_csr *P = A->parts[p];
+      if (P->nrows == 0) continue;
+      hipLaunchKernelGGL(csr_diag_kernel, dim3(std::min((P->nrows + 255) / 256, 4096)), dim3(256), 0, stream(),
+                         P->nrows, A->part_row0[p], P->ind, P->col, P->val, diag_dev + A->part_row0[p]);
+    }
+    PSP_LAUNCH_CHECK();
+    return PSP_OK;
+  }
   if (A->w4_only) {
     psp::CsrExtra *ex;
     PSP_TRY(ensure_w4(A, &ex));
@@ -3686,7 +3903,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
     return PSP_OK;
   }
   int grid = std::min((A->nrows + 255) / 256, 4096);
-  hipLaunchKernelGGL(csr_diag_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, A->ind, A->col,
+  hipLaunchKernelGGL(csr_diag_kernel, dim3(grid), dim3(256), 0, stream(), A->nrows, 0, A->ind, A->col,
                      A->val, diag_dev);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
@@ -3735,6 +3952,7 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
     if (done) return PSP_OK;
   }
   if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big)");
+  if (A->nparts) return fail(PSP_EINVAL, "matvec_transp: not available for a partitioned (> 2^31 nonzeros) matrix");
   if (A->ncols == 0) return PSP_OK;
   // irregular matrices: multiply with A^T stored as CSR (built once): every y[c] adds its terms by
   // ascending row, the order of csr_matvec_transp_kernel (csr_mat.c:80-87) -- exact, no atomics
@@ -3779,6 +3997,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   PSP_API_GUARD;
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
+  if (A->nparts) return psp_csr_kernel_info(A->parts[0], name, name_cap, info);  // every part by its own rules
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
   const char *k = "csr_spmv_stream";
@@ -3855,11 +4074,17 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
 int psp_csr_set_variant(psp_csr_t *A, int variant) {
   if (!A) return fail(PSP_EINVAL, "psp_csr_set_variant: NULL handle");
   A->variant = variant;
+  for (int p = 0; p < A->nparts; ++p) A->parts[p]->variant = variant;
   return PSP_OK;
 }
 
 int64_t psp_csr_device_bytes(const psp_csr_t *A) {
   if (!A) return 0;
+  if (A->nparts) {
+    int64_t b = 0;
+    for (int p = 0; p < A->nparts; ++p) b += psp_csr_device_bytes(A->parts[p]);
+    return b;
+  }
   if (A->w4_only) {
     const int64_t rows = ((int64_t)A->nrows + kDiaRows - 1) / kDiaRows * kDiaRows;
     return rows * (8 * (int64_t)A->max_row_nnz + 2);

@@ -119,6 +119,12 @@ struct psp_csr {
   int64_t nnz64 = 0;
   int w4_diag_slot = -1;  // w4_only: which offset slot holds A[r, r]
   bool no_reorder = false;  // internal copies (renumbered / transposed) are never renumbered again
+  // More than 2^31 - 8192 nonzeros (psp_csr_create64, psp_csr_random_banded): the rows are cut into parts of
+  // < 2^30 nonzeros, each an ordinary handle with 32-bit offsets over the same column space; part p holds rows
+  // [part_row0[p], part_row0[p+1]).  The kernels never see a 64-bit offset; nnz is -1, nnz64 the count.
+  int nparts = 0;
+  psp_csr **parts = nullptr;
+  int *part_row0 = nullptr;
 };
 
 struct psp_sss {

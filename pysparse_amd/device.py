@@ -75,7 +75,35 @@ class DeviceCSR:
         nr, nc, nz = C.c_int(), C.c_int(), C.c_int()
         check(lib().psp_csr_shape(handle, C.byref(nr), C.byref(nc), C.byref(nz)))
         self.shape = (nr.value, nc.value)
-        self.nnz = nz.value
+        self.nnz = nz.value if nz.value >= 0 else int(lib().psp_csr_nnz64(handle))  # > 2^31: the 64-bit count
+
+    @classmethod
+    def from_arrays64(cls, shape, ind, col, val):
+        """CSR triple with 64-bit row offsets (nnz may exceed the reference's C int, csr_mat.h:6-13)"""
+        ind = np.ascontiguousarray(ind, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        if ind.shape[0] != shape[0] + 1 or col.shape[0] != val.shape[0]:
+            raise ValueError("inconsistent CSR arrays")
+        h = C.c_void_p()
+        check(lib().psp_csr_create64(shape[0], shape[1], val.shape[0], _ptr(ind), _ptr(col), _ptr(val), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def random_banded(cls, nrows, ncols, m, stride, seed=0):
+        """synthetic general CSR generated on the device (nrows*m may exceed 2^31), psp_csr_random_banded"""
+        h = C.c_void_p()
+        check(lib().psp_csr_random_banded(nrows, ncols, m, stride, seed, C.byref(h)))
+        return cls(h)
+
+    def download_rows(self, row_lo, row_hi):
+        """(ind64 relative to row_lo, col, val) of rows [row_lo, row_hi)"""
+        ind = np.empty(row_hi - row_lo + 1, dtype=np.int64)
+        check(lib().psp_csr_download_rows(self._h, row_lo, row_hi, _ptr(ind), None, None))
+        col = np.empty(int(ind[-1]), dtype=np.int32)
+        val = np.empty(int(ind[-1]), dtype=np.float64)
+        check(lib().psp_csr_download_rows(self._h, row_lo, row_hi, _ptr(ind), _ptr(col), _ptr(val)))
+        return ind, col, val
 
     @classmethod
     def from_arrays(cls, shape, ind, col, val):

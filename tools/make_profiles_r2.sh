@@ -1,0 +1,51 @@
+#!/bin/bash
+# Round-2 profile artefacts on the GPU box (run via gpurun); everything lands in gpurun_out/profiles_r2/
+# and is then copied into profiles/ (tracked).
+#   (1) the bench line itself, (2) rocprofv3 --kernel-trace --stats of the SAME command,
+#   (3) PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one) for csr_spmv_w4 / w3 / w2 on the
+#       512^3 operator -> r2_spmv[_w3|_w2]_pmc.json, which bench.py reads for roofline.traffic
+set -u
+OUT=gpurun_out/profiles_r2; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 600 python3 bench.py > $OUT/r2_bench.json 2> $OUT/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-clocks > $OUT/trace.log 2>&1
+cp $OUT/trace/*/*kernel_stats.csv $OUT/r2_bench_kernel_stats.csv 2>/dev/null
+for kv in "w4:-1" "w3:1065154" "w2:16578"; do
+  k=${kv%%:*}; v=${kv##*:}; i=1
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
+             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS"; do
+    timeout 180 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_${k}_$i -- python3 tools/prof_spmv.py --reps 3 --variant $v > $OUT/pmc_${k}_$i.log 2>&1
+    i=$((i+1))
+  done
+done
+python3 - $OUT <<'PY'
+import csv, glob, json, os, sys, collections
+out = sys.argv[1]
+n, nnz = 134217728, 937951232
+for k, fname in (("w4", "r2_spmv"), ("w3", "r2_spmv_w3"), ("w2", "r2_spmv_w2")):
+    vals, kname = {}, None
+    for f in sorted(glob.glob(os.path.join(out, "pmc_%s_*" % k, "**", "*counter_collection.csv"), recursive=True)):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "csr_spmv" in r.get("Kernel_Name", ""):
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                kname = [w for w in r["Kernel_Name"].replace("<", " ").replace("(", " ").replace(":", " ").split() if w.startswith("csr_spmv")][0]
+        for c, v in acc.items():
+            vals[c] = sum(v) / len(v)
+    with open(os.path.join(out, fname + "_pmc_summary.txt"), "w") as g:
+        g.write("# rocprofv3 --pmc averages per launch, %s, 7-pt Poisson 512^3 (tools/prof_spmv.py)\n" % kname)
+        for c in sorted(vals):
+            g.write("%-36s %18.1f\n" % (c, vals[c]))
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        # MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports exactly half of the bytes of a wide coalesced
+        # streaming read on gfx950 -> doubled; WRITE_SIZE (KB) is exact for 16-byte-per-lane streaming stores
+        hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        json.dump({"kernel": kname, "workload": "7-pt Poisson 512^3", "FETCH_SIZE_KB": vals["FETCH_SIZE"],
+                   "WRITE_SIZE_KB": vals["WRITE_SIZE"], "fetch_correction": 2.0, "hbm_bytes_per_launch": hbm,
+                   "csr_model_bytes_per_launch": 12 * nnz + 20 * n + 4,
+                   "note": "L2<->fabric request bytes (Infinity-Cache hits are counted, MI355X_MICROARCH.md), "
+                           "not DRAM-only"},
+                  open(os.path.join(out, fname + "_pmc.json"), "w"), indent=1)
+PY
+ls $OUT | head -40; cat $OUT/r2_bench.json | head -c 1500; echo; head -8 $OUT/r2_bench_kernel_stats.csv | cut -c1-160
