@@ -16,12 +16,14 @@
 //     CPU (the sweep runs i = n-1 .. 0); the gather walks row j's upper entries from the last
 //     to the first, i.e. the same addends in the same order, and rlevel(j) = 1 + max rlevel(i)
 //     over the upper entries guarantees the x[i] it reads are final.
-// One small kernel per level (a 512^3 grid has 1534 levels in each direction); the rows of a
-// level are kept sorted so neighbouring lanes touch neighbouring lines.
-// Bandwidth is not the bound here (dependent launches are); see DESIGN.md.
+// One small kernel per level (a 512^3 grid has 1534 levels in each direction).  Round 2: the triangle,
+// the diagonal and the vectors are kept in LEVEL ORDER (struct psp_ssor), so a level sweep streams, and
+// the launches of one application are replayed from a hipGraph; see DESIGN.md.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
+#include <initializer_list>
 #include <vector>
 
 #include "psp_internal.h"
@@ -33,10 +35,31 @@ struct psp_ssor {
   double omega = 1.0;
   int steps = 1;
   psp_sss *S = nullptr;  // borrowed; the Python object keeps the matrix alive
-  int *rows_f = nullptr, *rows_b = nullptr;  // rows sorted by (level, row)
-  std::vector<int> ptr_f, ptr_b;             // level l = rows[ptr[l] .. ptr[l+1])
-  int *dptr_f = nullptr, *dptr_b = nullptr;  // the same on the device (runs of small levels)
-  double *temp = nullptr;                    // y (symgs) / h (ssor)
+  // Everything the sweeps touch lives in FORWARD-LEVEL ORDER ("positions"): position t holds row pos2row[t],
+  // the rows of forward level l are positions [ptr_f[l], ptr_f[l+1]).  A level's rows, their matrix entries
+  // and their vector entries are then contiguous, so a level sweep streams instead of gathering 36-byte
+  // row fragments from all over the triangle (round 1: 85 ms per application at 512^3, dependency- AND
+  // gather-bound).  The triangle is copied twice in that order:
+  //   forward : f_ptr / f_val / f_pos = the strict lower entries of each position's row, in storage order
+  //             (ascending original column), columns as positions;
+  //   backward: rows in (backward level, row) order; b_row[u] = position of the u-th row, b_ptr / b_val /
+  //             b_pos = its mirrored upper entries from the LAST to the first (the order in which the CPU's
+  //             descending sweep scatters into it, preconmodule.c:186-193).
+  int *pos2row = nullptr, *row2pos = nullptr;
+  std::vector<int> ptr_f, ptr_b;  // level l = positions / backward slots [ptr[l], ptr[l+1])
+  int *dptr_f = nullptr, *dptr_b = nullptr;
+  int *f_ptr = nullptr, *f_pos = nullptr;
+  double *f_val = nullptr;
+  int *b_row = nullptr, *b_ptr = nullptr, *b_pos = nullptr;
+  double *b_val = nullptr;
+  double *da = nullptr;                 // diagonal by position
+  double *bp = nullptr, *xp = nullptr;  // right-hand side and iterate by position
+  double *temp = nullptr;               // y (symgs) / h (ssor) by position
+  // the level launches of one application, captured once (they only touch the buffers above)
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t cap_stream = nullptr;
+  int graph_state = -1;  // -1 not tried, 0 unavailable (direct launches), 1 captured
 };
 
 namespace {
@@ -69,53 +92,55 @@ __global__ void level_ptr_kernel(int n, const int *__restrict__ keys, int *__res
     if (i == 0 || keys[i] != keys[i - 1]) ptr[keys[i]] = i;
 }
 
-// ---- one row of each sweep (KIND 0: symgs forward, 1: symgs backward, 2: ssor forward, 3: ssor backward)
-// symgs_kernel, preconmodule.c:149-193 (omega == 1):
+// ---- one row of each sweep (KIND 0: symgs forward, 1: symgs backward, 2: ssor forward, 3: ssor backward),
+// everything by position.  symgs_kernel, preconmodule.c:149-193 (omega == 1):
 //   forward : s = sum_{lower} va*x[j]; x[i] = (b[i] - y[i] - s)/da[i]; y[i] = s          (:171-179)
 //   backward: x[i] holds y of the forward step ("x[k] = y[k]", :182-185), y[i] is rebuilt from the
 //             rows above in descending order, x[i] = (b[i] - x[i] - y[i]) / da[i]         (:186-193)
 // ssor_kernel, preconmodule.c:95-143 (omega != 1): temp / h as at :110-140
+// `t` = the row's position (vectors), [k0, k1) = its entries in the sweep's own copy of the triangle
 template <int KIND>
-__device__ __forceinline__ void ssor_row(int i, const int *__restrict__ ind, const int *__restrict__ col,
+__device__ __forceinline__ void ssor_row(int t, int k0, int k1, const int *__restrict__ pos,
                                          const double *__restrict__ val, const double *__restrict__ da,
                                          const double *__restrict__ b, double *x, double *y, double omega,
                                          int first) {
   if constexpr (KIND == 0) {
     double s = 0.0;
-    for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s += val[k] * x[col[k]];
-    x[i] = (b[i] - y[i] - s) / da[i];
-    y[i] = s;
+    for (int k = k0; k < k1; ++k) s += val[k] * x[pos[k]];
+    x[t] = (b[t] - y[t] - s) / da[t];
+    y[t] = s;
   } else if constexpr (KIND == 1) {
-    const double yf = y[i];
+    const double yf = y[t];
     double acc = 0.0;
-    for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc += val[k] * x[col[k]];
-    x[i] = (b[i] - yf - acc) / da[i];
-    y[i] = acc;
+    for (int k = k0; k < k1; ++k) acc += val[k] * x[pos[k]];
+    x[t] = (b[t] - yf - acc) / da[t];
+    y[t] = acc;
   } else if constexpr (KIND == 2) {
-    const double temp = first ? omega * b[i] : (1.0 - omega) * x[i] * da[i] + y[i] + omega * b[i];
+    const double temp = first ? omega * b[t] : (1.0 - omega) * x[t] * da[t] + y[t] + omega * b[t];
     double s = 0.0;
-    for (int k = ind[i]; k < ind[i + 1] && col[k] < i; ++k) s -= val[k] * x[col[k]];
+    for (int k = k0; k < k1; ++k) s -= val[k] * x[pos[k]];
     const double hi = omega * s;
-    y[i] = hi;
-    x[i] = (temp + hi) / da[i];
+    y[t] = hi;
+    x[t] = (temp + hi) / da[t];
   } else {
-    const double temp = (1.0 - omega) * x[i] * da[i] + y[i] + omega * b[i];
+    const double temp = (1.0 - omega) * x[t] * da[t] + y[t] + omega * b[t];
     double acc = 0.0;
-    for (int k = ind[i + 1] - 1; k >= ind[i] && col[k] > i; --k) acc -= val[k] * x[col[k]];
+    for (int k = k0; k < k1; ++k) acc -= val[k] * x[pos[k]];
     const double hi = omega * acc;
-    y[i] = hi;
-    x[i] = (temp + hi) / da[i];
+    y[t] = hi;
+    x[t] = (temp + hi) / da[t];
   }
 }
 
-// the rows of ONE level (independent of each other)
+// slots [a, e) of ONE level (independent rows).  Forward sweeps: slot == position (rowmap == nullptr);
+// backward sweeps: rowmap[slot] = position
 template <int KIND>
-__global__ void ssor_level_kernel(int cnt, const int *__restrict__ rows, const int *__restrict__ ind,
-                                  const int *__restrict__ col, const double *__restrict__ val,
+__global__ void ssor_level_kernel(int a, int e, const int *__restrict__ rowmap, const int *__restrict__ ptr,
+                                  const int *__restrict__ pos, const double *__restrict__ val,
                                   const double *__restrict__ da, const double *__restrict__ b, double *x,
                                   double *y, double omega, int first) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < cnt) ssor_row<KIND>(rows[t], ind, col, val, da, b, x, y, omega, first);
+  const int u = a + blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < e) ssor_row<KIND>(rowmap ? rowmap[u] : u, ptr[u], ptr[u + 1], pos, val, da, b, x, y, omega, first);
 }
 
 // a RUN of small levels [l0, l1) in one launch: a single workgroup walks them with a barrier in
@@ -124,16 +149,67 @@ __global__ void ssor_level_kernel(int cnt, const int *__restrict__ rows, const i
 // of at most 100 rows in each direction.
 constexpr int kSmallLevel = 256;  // measured: 2048 made poisson2d(2048) 3x slower (one CU walks 18 us levels)
 template <int KIND>
-__global__ __launch_bounds__(256) void ssor_levels_kernel(int l0, int l1, const int *__restrict__ ptr,
-                                                          const int *__restrict__ rows, const int *__restrict__ ind,
-                                                          const int *__restrict__ col, const double *__restrict__ val,
+__global__ __launch_bounds__(256) void ssor_levels_kernel(int l0, int l1, const int *__restrict__ lptr,
+                                                          const int *__restrict__ rowmap, const int *__restrict__ ptr,
+                                                          const int *__restrict__ pos, const double *__restrict__ val,
                                                           const double *__restrict__ da, const double *__restrict__ b,
                                                           double *x, double *y, double omega, int first) {
   for (int l = l0; l < l1; ++l) {
-    const int a = ptr[l], e = ptr[l + 1];
-    for (int t = a + (int)threadIdx.x; t < e; t += (int)blockDim.x)
-      ssor_row<KIND>(rows[t], ind, col, val, da, b, x, y, omega, first);
+    const int a = lptr[l], e = lptr[l + 1];
+    for (int u = a + (int)threadIdx.x; u < e; u += (int)blockDim.x)
+      ssor_row<KIND>(rowmap ? rowmap[u] : u, ptr[u], ptr[u + 1], pos, val, da, b, x, y, omega, first);
     __syncthreads();
+  }
+}
+
+// ---- builders of the level-ordered copies
+__global__ void invert_perm_kernel(int n, const int *__restrict__ perm, int *__restrict__ inv) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) inv[perm[i]] = i;
+}
+
+// forward: entries of slot u = the strict lower entries of row rows[u] (the sss arrays hold exactly those,
+// ascending column).  count pass (cnt[u]) or, with ptr, fill pass.
+__global__ void ssor_fill_forward_kernel(int n, const int *__restrict__ rows, const int *__restrict__ sind,
+                                         const int *__restrict__ scol, const double *__restrict__ sval,
+                                         const int *__restrict__ row2pos, int *__restrict__ cnt,
+                                         const int *__restrict__ ptr, int *__restrict__ pos,
+                                         double *__restrict__ val) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    const int r = rows[u];
+    const int a = sind[r], e = sind[r + 1];
+    if (cnt) {
+      cnt[u] = e - a;
+    } else {
+      int o = ptr[u];
+      for (int k = a; k < e; ++k, ++o) {
+        pos[o] = row2pos[scol[k]];
+        val[o] = sval[k];
+      }
+    }
+  }
+}
+
+// backward: entries of slot u = the entries (r, j > r) of the full mirror's row r = rows[u], LAST to first
+__global__ void ssor_fill_backward_kernel(int n, const int *__restrict__ rows, const int *__restrict__ find,
+                                          const int *__restrict__ fcol, const double *__restrict__ fval,
+                                          const int *__restrict__ row2pos, int *__restrict__ cnt,
+                                          const int *__restrict__ ptr, int *__restrict__ pos,
+                                          double *__restrict__ val, int *__restrict__ b_row) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    const int r = rows[u];
+    const int a = find[r], e = find[r + 1];
+    if (cnt) {
+      int c = 0;
+      for (int k = e - 1; k >= a && fcol[k] > r; --k) ++c;
+      cnt[u] = c;
+      b_row[u] = row2pos[r];
+    } else {
+      int o = ptr[u];
+      for (int k = e - 1; k >= a && fcol[k] > r; --k, ++o) {
+        pos[o] = row2pos[fcol[k]];
+        val[o] = fval[k];
+      }
+    }
   }
 }
 
@@ -214,48 +290,177 @@ done:
 
 namespace psp {
 
+int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // psp_reorder.hip
+
+// the launches of one sweep on stream st, everything by position
 template <int KIND>
-static void sweep(const psp_ssor *K, const std::vector<int> &ptr, const int *dptr, const int *rows,
-                  const double *b, double *x, double *y, int first) {
-  const psp_csr *F = K->S->full;
-  const double *da = K->S->diag;
-  const int nl = (int)ptr.size() - 1;
+static void sweep(const psp_ssor *K, hipStream_t st, bool forward, int first) {
+  const std::vector<int> &lp = forward ? K->ptr_f : K->ptr_b;
+  const int *dlp = forward ? K->dptr_f : K->dptr_b;
+  const int *rowmap = forward ? nullptr : K->b_row;
+  const int *ptr = forward ? K->f_ptr : K->b_ptr;
+  const int *pos = forward ? K->f_pos : K->b_pos;
+  const double *val = forward ? K->f_val : K->b_val;
+  const int nl = (int)lp.size() - 1;
   int l = 0;
   while (l < nl) {
     int e = l;  // maximal run of small levels starting at l
-    while (e < nl && ptr[e + 1] - ptr[e] <= kSmallLevel) ++e;
+    while (e < nl && lp[e + 1] - lp[e] <= kSmallLevel) ++e;
     if (e - l >= 2) {
-      hipLaunchKernelGGL(ssor_levels_kernel<KIND>, dim3(1), dim3(256), 0, stream(), l, e, dptr, rows, F->ind,
-                         F->col, F->val, da, b, x, y, K->omega, first);
+      hipLaunchKernelGGL(ssor_levels_kernel<KIND>, dim3(1), dim3(256), 0, st, l, e, dlp, rowmap, ptr, pos, val, K->da,
+                         K->bp, K->xp, K->temp, K->omega, first);
       l = e;
       continue;
     }
-    const int a = ptr[l], cnt = ptr[l + 1] - a;
+    const int a = lp[l], cnt = lp[l + 1] - a;
     if (cnt > 0)
-      hipLaunchKernelGGL(ssor_level_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, stream(), cnt, rows + a,
-                         F->ind, F->col, F->val, da, b, x, y, K->omega, first);
+      hipLaunchKernelGGL(ssor_level_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, st, a, a + cnt, rowmap, ptr,
+                         pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
     ++l;
   }
 }
 
-int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
-  double *y = K->temp;
+// all sweeps of one application (they only touch K's own buffers)
+static void enqueue_sweeps(const psp_ssor *K, hipStream_t st) {
   const bool gs = K->omega == 1.0;
-  if (gs) PSP_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
   for (int step = 0; step < K->steps; ++step) {
     if (gs) {
-      sweep<0>(K, K->ptr_f, K->dptr_f, K->rows_f, b, x, y, 0);
-      sweep<1>(K, K->ptr_b, K->dptr_b, K->rows_b, b, x, y, 0);
+      sweep<0>(K, st, true, 0);
+      sweep<1>(K, st, false, 0);
     } else {
-      sweep<2>(K, K->ptr_f, K->dptr_f, K->rows_f, b, x, y, step == 0 ? 1 : 0);
-      sweep<3>(K, K->ptr_b, K->dptr_b, K->rows_b, b, x, y, 0);
+      sweep<2>(K, st, true, step == 0 ? 1 : 0);
+      sweep<3>(K, st, false, 0);
     }
+  }
+}
+
+// One application = thousands of tiny dependent launches (512^3: 2 x 1534 levels of ~1 us of streaming
+// each): issued one by one the host is the bound (~3.5 us per launch), replayed from a hipGraph the device's
+// own dependent-launch latency is (~1.5-2 us).  Captured once per handle; PSP_SSOR_GRAPH=0 keeps direct launches.
+static void ensure_graph(psp_ssor *K) {
+  if (K->graph_state >= 0) return;
+  K->graph_state = 0;
+  static const bool off = [] {
+    const char *e = getenv("PSP_SSOR_GRAPH");
+    return e && atoi(e) == 0;
+  }();
+  const long launches = (long)K->steps * ((long)K->ptr_f.size() + (long)K->ptr_b.size());
+  if (off || launches < 8) return;
+  if (hipStreamCreateWithFlags(&K->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    K->cap_stream = nullptr;
+    return;
+  }
+  bool ok = hipStreamBeginCapture(K->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    enqueue_sweeps(K, K->cap_stream);
+    ok = hipStreamEndCapture(K->cap_stream, &K->graph) == hipSuccess && K->graph != nullptr &&
+         hipGraphInstantiate(&K->exec, K->graph, nullptr, nullptr, 0) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    if (K->graph) (void)hipGraphDestroy(K->graph);
+    K->graph = nullptr;
+    K->exec = nullptr;
+    return;
+  }
+  K->graph_state = 1;
+}
+
+int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
+  if (K->steps <= 0) return PSP_OK;  // the reference leaves y untouched
+  PSP_TRY(reorder_gather(K->n, K->pos2row, b, K->bp, nullptr));  // bp[t] = b[pos2row[t]]
+  if (K->omega == 1.0) PSP_HIP(hipMemsetAsync(K->temp, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
+  ensure_graph(K);
+  if (K->graph_state == 1 && hipGraphLaunch(K->exec, stream()) != hipSuccess) {
+    (void)hipGetLastError();
+    K->graph_state = 0;  // this runtime does not replay into the library's stream: direct launches from now on
+  }
+  if (K->graph_state != 1) {
+    enqueue_sweeps(K, stream());
     PSP_LAUNCH_CHECK();
   }
-  return PSP_OK;
+  return reorder_gather(K->n, K->row2pos, K->xp, x, nullptr);  // x[i] = xp[row2pos[i]]
 }
 
 }  // namespace psp
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  PSP_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+  return PSP_OK;
+}
+
+// exclusive prefix sum of cnt[0..n) into ptr[0..n]
+int exclusive_scan(int n, const int *cnt, int *ptr, long *total) {
+  size_t bytes = 0;
+  void *tmp = nullptr;
+  PSP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, ptr, n, stream()));
+  PSP_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cnt, ptr, n, stream());
+  int last_ptr = 0, last_cnt = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&last_ptr, ptr + (n - 1), sizeof(int), hipMemcpyDeviceToHost, stream());
+  if (e == hipSuccess) e = hipMemcpyAsync(&last_cnt, cnt + (n - 1), sizeof(int), hipMemcpyDeviceToHost, stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(stream());
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(PSP_ENODEV, "ssor: scan failed: %s", hipGetErrorString(e));
+  *total = (long)last_ptr + last_cnt;
+  const int tot = (int)*total;
+  PSP_HIP(hipMemcpy(ptr + n, &tot, sizeof(int), hipMemcpyHostToDevice));
+  return PSP_OK;
+}
+
+// the level-ordered copies of the triangle (see struct psp_ssor)
+int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
+  const psp_sss *S = K->S;
+  const psp_csr *F = S->full;
+  const int n = K->n;
+  const int grid = std::min((n + 255) / 256, 65536);
+  K->pos2row = rows_f;  // takes ownership
+  PSP_TRY(dev_alloc(&K->row2pos, n));
+  hipLaunchKernelGGL(invert_perm_kernel, dim3(grid), dim3(256), 0, stream(), n, K->pos2row, K->row2pos);
+  PSP_LAUNCH_CHECK();
+  int *cnt = nullptr;
+  PSP_TRY(dev_alloc(&cnt, n));
+  int rc = PSP_OK;
+  long tot = 0;
+  // forward
+  hipLaunchKernelGGL(ssor_fill_forward_kernel, dim3(grid), dim3(256), 0, stream(), n, K->pos2row, S->ind, S->col, S->val,
+                     K->row2pos, cnt, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+  if (rc == PSP_OK) rc = dev_alloc(&K->f_ptr, (size_t)n + 1);
+  if (rc == PSP_OK) rc = exclusive_scan(n, cnt, K->f_ptr, &tot);
+  if (rc == PSP_OK) rc = dev_alloc(&K->f_pos, (size_t)tot);
+  if (rc == PSP_OK) rc = dev_alloc(&K->f_val, (size_t)tot);
+  if (rc == PSP_OK)
+    hipLaunchKernelGGL(ssor_fill_forward_kernel, dim3(grid), dim3(256), 0, stream(), n, K->pos2row, S->ind, S->col,
+                       S->val, K->row2pos, (int *)nullptr, K->f_ptr, K->f_pos, K->f_val);
+  // backward
+  if (rc == PSP_OK) rc = dev_alloc(&K->b_row, n);
+  if (rc == PSP_OK)
+    hipLaunchKernelGGL(ssor_fill_backward_kernel, dim3(grid), dim3(256), 0, stream(), n, rows_b, F->ind, F->col, F->val,
+                       K->row2pos, cnt, (const int *)nullptr, (int *)nullptr, (double *)nullptr, K->b_row);
+  if (rc == PSP_OK) rc = dev_alloc(&K->b_ptr, (size_t)n + 1);
+  if (rc == PSP_OK) rc = exclusive_scan(n, cnt, K->b_ptr, &tot);
+  if (rc == PSP_OK) rc = dev_alloc(&K->b_pos, (size_t)tot);
+  if (rc == PSP_OK) rc = dev_alloc(&K->b_val, (size_t)tot);
+  if (rc == PSP_OK)
+    hipLaunchKernelGGL(ssor_fill_backward_kernel, dim3(grid), dim3(256), 0, stream(), n, rows_b, F->ind, F->col, F->val,
+                       K->row2pos, (int *)nullptr, K->b_ptr, K->b_pos, K->b_val, (int *)nullptr);
+  // vectors by position
+  if (rc == PSP_OK) rc = dev_alloc(&K->da, n);
+  if (rc == PSP_OK) rc = dev_alloc(&K->bp, n);
+  if (rc == PSP_OK) rc = dev_alloc(&K->xp, n);
+  if (rc == PSP_OK) rc = dev_alloc(&K->temp, n);
+  if (rc == PSP_OK) rc = reorder_gather(n, K->pos2row, S->diag, K->da, nullptr);
+  if (rc == PSP_OK && hipStreamSynchronize(stream()) != hipSuccess) rc = fail(PSP_ENODEV, "ssor: build failed");
+  if (rc == PSP_OK && hipGetLastError() != hipSuccess) rc = fail(PSP_ENODEV, "ssor: build kernels failed");
+  (void)hipFree(cnt);
+  return rc;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -271,10 +476,16 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
   K->S = S;
   int rc = PSP_OK;
   if (S->n > 0) {
-    rc = build_schedule(S->full, 0, &K->rows_f, &K->ptr_f);
-    if (rc == PSP_OK) rc = build_schedule(S->full, 1, &K->rows_b, &K->ptr_b);
-    if (rc == PSP_OK && hipMalloc((void **)&K->temp, sizeof(double) * (size_t)S->n) != hipSuccess)
-      rc = fail(PSP_ENOMEM, "ssor: work vector allocation failed");
+    int *rows_f = nullptr, *rows_b = nullptr;
+    rc = build_schedule(S->full, 0, &rows_f, &K->ptr_f);
+    if (rc == PSP_OK) rc = build_schedule(S->full, 1, &rows_b, &K->ptr_b);
+    if (rc == PSP_OK) {
+      // backward slots are (level, row)-sorted rows; ptr_b indexes slots
+      rc = build_level_ordered(K, rows_f, rows_b);
+      rows_f = nullptr;  // owned by K now (pos2row), even on failure
+    }
+    (void)hipFree(rows_f);
+    (void)hipFree(rows_b);
     if (rc == PSP_OK) {
       const size_t bf = sizeof(int) * K->ptr_f.size(), bb = sizeof(int) * K->ptr_b.size();
       if (hipMalloc((void **)&K->dptr_f, bf) != hipSuccess || hipMalloc((void **)&K->dptr_b, bb) != hipSuccess ||
@@ -296,11 +507,13 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
 
 int psp_ssor_destroy(psp_ssor_t *K) {
   if (!K) return PSP_OK;
-  (void)hipFree(K->rows_f);
-  (void)hipFree(K->rows_b);
-  (void)hipFree(K->dptr_f);
-  (void)hipFree(K->dptr_b);
-  (void)hipFree(K->temp);
+  if (K->exec) (void)hipGraphExecDestroy(K->exec);
+  if (K->graph) (void)hipGraphDestroy(K->graph);
+  if (K->cap_stream) (void)hipStreamDestroy(K->cap_stream);
+  for (void *p : {(void *)K->pos2row, (void *)K->row2pos, (void *)K->dptr_f, (void *)K->dptr_b, (void *)K->f_ptr,
+                  (void *)K->f_pos, (void *)K->f_val, (void *)K->b_row, (void *)K->b_ptr, (void *)K->b_pos,
+                  (void *)K->b_val, (void *)K->da, (void *)K->bp, (void *)K->xp, (void *)K->temp})
+    (void)hipFree(p);
   delete K;
   return PSP_OK;
 }
@@ -334,7 +547,6 @@ int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host) {
   }
   int rc = PSP_OK;
   hipError_t e = hipMemcpyAsync(x, x_host, bytes, hipMemcpyHostToDevice, stream());
-  // the reference sweeps start from whatever y holds only for entries it has already written;
   // steps == 0 leaves y untouched, so hand the caller's y through
   if (e == hipSuccess) e = hipMemcpyAsync(y, y_host, bytes, hipMemcpyHostToDevice, stream());
   if (e == hipSuccess) rc = ssor_apply_dev(K, x, y);
