@@ -52,6 +52,13 @@ struct psp_ssor {
   double *f_val = nullptr;
   int *b_row = nullptr, *b_ptr = nullptr, *b_pos = nullptr;
   double *b_val = nullptr;
+  // Rows with at most 8 entries per sweep (every stencil) use a padded slot-major (ELL) form instead of the
+  // ptr / val / pos triple: entry s of slot u at [s*n + u], counts in one byte per slot.  A level kernel is
+  // bound by its chain of dependent loads, not by bytes (a level of the 512^3 operator is ~1 us of streaming):
+  // with the entries at computable addresses the chain is two loads deep (entries -> x) instead of three
+  // (ptr -> entries -> x; four in the backward sweep, whose slots are rows by indirection).
+  int ell_f = 0, ell_b = 0;  // width (0: CSR form)
+  unsigned char *fc8 = nullptr, *bc8 = nullptr;
   double *da = nullptr;                 // diagonal by position
   double *bp = nullptr, *xp = nullptr;  // right-hand side and iterate by position
   double *temp = nullptr;               // y (symgs) / h (ssor) by position
@@ -159,6 +166,110 @@ __global__ __launch_bounds__(256) void ssor_levels_kernel(int l0, int l1, const 
     for (int u = a + (int)threadIdx.x; u < e; u += (int)blockDim.x)
       ssor_row<KIND>(rowmap ? rowmap[u] : u, ptr[u], ptr[u + 1], pos, val, da, b, x, y, omega, first);
     __syncthreads();
+  }
+}
+
+// ---- the same rows with the entries in padded slot-major form (W <= 8 entries per slot): all entry loads are
+// issued before anything depends on them; padding slots are loaded (valid addresses) but never added
+template <int KIND, int W>
+__device__ __forceinline__ void ssor_row_ell(int u, int t, int n, const unsigned char *__restrict__ cnt8,
+                                             const int *__restrict__ pos, const double *__restrict__ val,
+                                             const double *__restrict__ da, const double *__restrict__ b, double *x,
+                                             double *y, double omega, int first) {
+  const int cnt = cnt8[u];
+  double v[W];
+  int p[W];
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    v[s] = val[(size_t)s * n + u];
+    p[s] = pos[(size_t)s * n + u];
+  }
+  double xs[W];
+#pragma unroll
+  for (int s = 0; s < W; ++s) xs[s] = x[p[s]];
+  const double bt = b[t], dt = da[t], yt = y[t];
+  if constexpr (KIND == 0) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const double tt = s_ + v[s] * xs[s];
+      s_ = s < cnt ? tt : s_;
+    }
+    x[t] = (bt - yt - s_) / dt;
+    y[t] = s_;
+  } else if constexpr (KIND == 1) {
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const double tt = acc + v[s] * xs[s];
+      acc = s < cnt ? tt : acc;
+    }
+    x[t] = (bt - yt - acc) / dt;
+    y[t] = acc;
+  } else {
+    const double xt = (KIND == 2 && first) ? 0.0 : x[t];
+    const double temp = (KIND == 2 && first) ? omega * bt : (1.0 - omega) * xt * dt + yt + omega * bt;
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const double tt = acc - v[s] * xs[s];
+      acc = s < cnt ? tt : acc;
+    }
+    const double hi = omega * acc;
+    y[t] = hi;
+    x[t] = (temp + hi) / dt;
+  }
+}
+
+template <int KIND, int W>
+__global__ void ssor_level_ell_kernel(int a, int e, int n, const int *__restrict__ rowmap,
+                                      const unsigned char *__restrict__ cnt8, const int *__restrict__ pos,
+                                      const double *__restrict__ val, const double *__restrict__ da,
+                                      const double *__restrict__ b, double *x, double *y, double omega, int first) {
+  const int u = a + blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < e) ssor_row_ell<KIND, W>(u, rowmap ? rowmap[u] : u, n, cnt8, pos, val, da, b, x, y, omega, first);
+}
+
+template <int KIND, int W>
+__global__ __launch_bounds__(256) void ssor_levels_ell_kernel(int l0, int l1, int n, const int *__restrict__ lptr,
+                                                              const int *__restrict__ rowmap,
+                                                              const unsigned char *__restrict__ cnt8,
+                                                              const int *__restrict__ pos,
+                                                              const double *__restrict__ val,
+                                                              const double *__restrict__ da,
+                                                              const double *__restrict__ b, double *x, double *y,
+                                                              double omega, int first) {
+  for (int l = l0; l < l1; ++l) {
+    const int a = lptr[l], e = lptr[l + 1];
+    for (int u = a + (int)threadIdx.x; u < e; u += (int)blockDim.x)
+      ssor_row_ell<KIND, W>(u, rowmap ? rowmap[u] : u, n, cnt8, pos, val, da, b, x, y, omega, first);
+    __syncthreads();
+  }
+}
+
+__global__ void row_len_kernel(int n, const int *__restrict__ ptr, int *__restrict__ len) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) len[u] = ptr[u + 1] - ptr[u];
+}
+
+__global__ void max_int_kernel(int n, const int *__restrict__ v, int *__restrict__ out) {
+  int m = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// CSR-form copy (ptr / pos / val by slot) -> padded slot-major form of width W
+__global__ void ssor_to_ell_kernel(int n, int W, const int *__restrict__ ptr, const int *__restrict__ pos,
+                                   const double *__restrict__ val, unsigned char *__restrict__ cnt8,
+                                   int *__restrict__ epos, double *__restrict__ eval) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    const int a = ptr[u], c = ptr[u + 1] - a;
+    cnt8[u] = (unsigned char)c;
+    for (int s = 0; s < W; ++s) {
+      epos[(size_t)s * n + u] = s < c ? pos[a + s] : 0;
+      eval[(size_t)s * n + u] = s < c ? val[a + s] : 0.0;
+    }
   }
 }
 
@@ -293,30 +404,53 @@ namespace psp {
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // psp_reorder.hip
 
 // the launches of one sweep on stream st, everything by position
-template <int KIND>
-static void sweep(const psp_ssor *K, hipStream_t st, bool forward, int first) {
+template <int KIND, int W>
+static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) {
   const std::vector<int> &lp = forward ? K->ptr_f : K->ptr_b;
   const int *dlp = forward ? K->dptr_f : K->dptr_b;
   const int *rowmap = forward ? nullptr : K->b_row;
   const int *ptr = forward ? K->f_ptr : K->b_ptr;
   const int *pos = forward ? K->f_pos : K->b_pos;
   const double *val = forward ? K->f_val : K->b_val;
+  const unsigned char *c8 = forward ? K->fc8 : K->bc8;
   const int nl = (int)lp.size() - 1;
   int l = 0;
   while (l < nl) {
     int e = l;  // maximal run of small levels starting at l
     while (e < nl && lp[e + 1] - lp[e] <= kSmallLevel) ++e;
     if (e - l >= 2) {
-      hipLaunchKernelGGL(ssor_levels_kernel<KIND>, dim3(1), dim3(256), 0, st, l, e, dlp, rowmap, ptr, pos, val, K->da,
-                         K->bp, K->xp, K->temp, K->omega, first);
+      if constexpr (W > 0)
+        hipLaunchKernelGGL((ssor_levels_ell_kernel<KIND, W>), dim3(1), dim3(256), 0, st, l, e, K->n, dlp, rowmap, c8,
+                           pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
+      else
+        hipLaunchKernelGGL(ssor_levels_kernel<KIND>, dim3(1), dim3(256), 0, st, l, e, dlp, rowmap, ptr, pos, val,
+                           K->da, K->bp, K->xp, K->temp, K->omega, first);
       l = e;
       continue;
     }
     const int a = lp[l], cnt = lp[l + 1] - a;
-    if (cnt > 0)
-      hipLaunchKernelGGL(ssor_level_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, st, a, a + cnt, rowmap, ptr,
-                         pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
+    if (cnt > 0) {
+      if constexpr (W > 0)
+        hipLaunchKernelGGL((ssor_level_ell_kernel<KIND, W>), dim3((cnt + 255) / 256), dim3(256), 0, st, a, a + cnt,
+                           K->n, rowmap, c8, pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
+      else
+        hipLaunchKernelGGL(ssor_level_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, st, a, a + cnt, rowmap,
+                           ptr, pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
+    }
     ++l;
+  }
+}
+
+template <int KIND>
+static void sweep(const psp_ssor *K, hipStream_t st, bool forward, int first) {
+  switch (forward ? K->ell_f : K->ell_b) {
+    case 1: sweep_w<KIND, 1>(K, st, forward, first); break;
+    case 2: sweep_w<KIND, 2>(K, st, forward, first); break;
+    case 3: sweep_w<KIND, 3>(K, st, forward, first); break;
+    case 4: sweep_w<KIND, 4>(K, st, forward, first); break;
+    case 6: sweep_w<KIND, 6>(K, st, forward, first); break;
+    case 8: sweep_w<KIND, 8>(K, st, forward, first); break;
+    default: sweep_w<KIND, 0>(K, st, forward, first); break;
   }
 }
 
@@ -448,6 +582,57 @@ int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
   if (rc == PSP_OK)
     hipLaunchKernelGGL(ssor_fill_backward_kernel, dim3(grid), dim3(256), 0, stream(), n, rows_b, F->ind, F->col, F->val,
                        K->row2pos, (int *)nullptr, K->b_ptr, K->b_pos, K->b_val, (int *)nullptr);
+  // narrow rows: padded slot-major form, the ptr / pos / val triple is dropped
+  if (rc == PSP_OK) {
+    for (int dir = 0; dir < 2 && rc == PSP_OK; ++dir) {
+      int **ptr = dir ? &K->b_ptr : &K->f_ptr, **pos = dir ? &K->b_pos : &K->f_pos;
+      double **val = dir ? &K->b_val : &K->f_val;
+      int *dmax = nullptr, maxc = 0;
+      rc = dev_alloc(&dmax, 1);
+      if (rc != PSP_OK) break;
+      (void)hipMemsetAsync(dmax, 0, sizeof(int), stream());
+      // widest row = largest difference of consecutive offsets
+      hipLaunchKernelGGL(row_len_kernel, dim3(grid), dim3(256), 0, stream(), n, *ptr, cnt);
+      hipLaunchKernelGGL(max_int_kernel, dim3(std::min(grid, 2048)), dim3(256), 0, stream(), n, cnt, dmax);
+      if (hipMemcpy(&maxc, dmax, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PSP_ENODEV, "ssor: max");
+      (void)hipFree(dmax);
+      if (rc != PSP_OK) break;
+      static const bool ell_off = [] {
+        const char *e = getenv("PSP_SSOR_ELL");
+        return e && atoi(e) == 0;
+      }();
+      int W = 0;
+      for (int w : {1, 2, 3, 4, 6, 8})
+        if (maxc <= w) {
+          W = w;
+          break;
+        }
+      if (maxc == 0 || ell_off) W = 0;
+      if (W == 0) continue;
+      int *epos = nullptr;
+      double *eval = nullptr;
+      unsigned char *c8 = nullptr;
+      if (hipMalloc((void **)&epos, sizeof(int) * (size_t)W * n) != hipSuccess ||
+          hipMalloc((void **)&eval, sizeof(double) * (size_t)W * n) != hipSuccess ||
+          hipMalloc((void **)&c8, (size_t)n) != hipSuccess) {  // no room: keep the CSR form
+        (void)hipGetLastError();
+        (void)hipFree(epos);
+        (void)hipFree(eval);
+        (void)hipFree(c8);
+        continue;
+      }
+      hipLaunchKernelGGL(ssor_to_ell_kernel, dim3(grid), dim3(256), 0, stream(), n, W, *ptr, *pos, *val, c8, epos, eval);
+      if (hipStreamSynchronize(stream()) != hipSuccess) rc = fail(PSP_ENODEV, "ssor: ell build failed");
+      (void)hipFree(*ptr);
+      (void)hipFree(*pos);
+      (void)hipFree(*val);
+      *ptr = nullptr;
+      *pos = epos;
+      *val = eval;
+      (dir ? K->bc8 : K->fc8) = c8;
+      (dir ? K->ell_b : K->ell_f) = W;
+    }
+  }
   // vectors by position
   if (rc == PSP_OK) rc = dev_alloc(&K->da, n);
   if (rc == PSP_OK) rc = dev_alloc(&K->bp, n);
@@ -512,7 +697,8 @@ int psp_ssor_destroy(psp_ssor_t *K) {
   if (K->cap_stream) (void)hipStreamDestroy(K->cap_stream);
   for (void *p : {(void *)K->pos2row, (void *)K->row2pos, (void *)K->dptr_f, (void *)K->dptr_b, (void *)K->f_ptr,
                   (void *)K->f_pos, (void *)K->f_val, (void *)K->b_row, (void *)K->b_ptr, (void *)K->b_pos,
-                  (void *)K->b_val, (void *)K->da, (void *)K->bp, (void *)K->xp, (void *)K->temp})
+                  (void *)K->b_val, (void *)K->da, (void *)K->bp, (void *)K->xp, (void *)K->temp, (void *)K->fc8,
+                  (void *)K->bc8})
     (void)hipFree(p);
   delete K;
   return PSP_OK;
