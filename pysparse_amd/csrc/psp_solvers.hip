@@ -610,6 +610,40 @@ done:
 
 // Acsr_forced != nullptr: the caller has moved the system into the numbering of a renumbered copy of A
 // (pcg_device below): multiply with that handle, take z = dinv_forced .* r (or z = r), never touch A / K
+// ||v||_2 where the sum of squares `sq` has left [1e-280, 1e280] (or is not a number): sqrt(sum v_i^2) cannot be
+// trusted there, the reference's dnrm2 (scaled form: pcg.c:57,75; minres.c:71) still can.  The norm is then
+// formed at a power-of-two scale (exact): 2^e * sqrt(sum (v_i * 2^-e)^2), e = exponent of max |v_i|.  Only the
+// setup norms take this path; the reference's ddot (rho = r.z, p.q, alpha = v.Av) underflows / overflows at
+// such scales exactly as the reductions here do, and the solvers then leave through the same exits as the CPU
+// (rho == 0 -> -2; NaN iterates -> -5 / -1): tests/test_gpu_solvers.py::test_badly_scaled_right_hand_side.
+static bool norm2_unsafe(double sq) { return !(sq >= 1e-280 && sq <= 1e280); }
+static int abs_max(int n, const double *v, double *out);
+static int robust_nrm2(Workspace *w, int n, const double *v, double sq, double *out) {
+  if (!norm2_unsafe(sq)) {
+    *out = sqrt(sq);
+    return PSP_OK;
+  }
+  double vmax = 0.0;
+  PSP_TRY(abs_max(n, v, &vmax));
+  if (vmax == 0.0 || vmax != vmax || std::isinf(vmax)) {  // all zero / NaN / Inf: what sqrt(sq) says
+    *out = vmax == 0.0 ? 0.0 : sqrt(sq);
+    return PSP_OK;
+  }
+  int e = 0;
+  (void)frexp(vmax, &e);
+  DevVecs mem;
+  double *t;
+  PSP_TRY(mem.alloc(n, &t));
+  PSP_HIP(hipMemcpyAsync(t, v, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_TRY(k_scal(n, ldexp(1.0, -e), t));
+  int np;
+  double s1;
+  PSP_TRY(k_dot(n, t, t, w->partials, &np));
+  PSP_TRY(reduce_fetch(w, np, 1, &s1));
+  *out = ldexp(sqrt(s1), e);
+  return PSP_OK;
+}
+
 static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_forced, const double *dinv_forced,
                            int n, double *x, const double *b, double tol, int maxit, int *info, int *iter,
                            double *relres, double *hist) {
@@ -634,7 +668,8 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
   // n2b = ||b||  (pcg.c:57)
   PSP_TRY(k_dot(n, b, b, w->partials, &np));
   PSP_TRY(reduce_fetch(w, np, 1, s));
-  const double n2b = sqrt(s[0]);
+  double n2b;
+  PSP_TRY(robust_nrm2(w, n, b, s[0], &n2b));
   if (n2b == 0.0) {  // pcg.c:58-67
     PSP_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, stream()));
     PSP_HIP(hipStreamSynchronize(stream()));
@@ -654,7 +689,8 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     PSP_TRY(op_apply(A, x, r));
   PSP_TRY(k_residual(n, b, r, fused ? dinv : nullptr, w->partials, &np));
   PSP_TRY(reduce_fetch(w, np, 2, s));
-  double normr = sqrt(s[0]);
+  double normr;
+  PSP_TRY(robust_nrm2(w, n, r, s[0], &normr));
   double rho_next = s[1];
   if (hist) hist[0] = normr;
 
@@ -806,17 +842,24 @@ struct PermutedSystem {
   int leave(int n, double *x) { return reorder_gather(n, inv, xp, x, nullptr); }  // x[j] = xp[inv[j]]
 };
 
-static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit,
-                      int *info, int *iter, double *relres, double *hist) {
+static int pcg_permuted(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit,
+                        int *info, int *iter, double *relres, double *hist) {
   DevVecs mem;
   PermutedSystem ps;
   int active = 0;
   PSP_TRY(ps.enter(A, K, n, mem, x, b, &active));
-  if (!active) return pcg_device_core(A, K, nullptr, nullptr, n, x, b, tol, maxit, info, iter, relres, hist);
-  PSP_TRY(pcg_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, tol, maxit, info, iter, relres, hist));
+  if (!active)
+    return pcg_device_core(A, K, nullptr, nullptr, n, x, b, tol, maxit, info, iter, relres, hist);
+  const int rc = pcg_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, tol, maxit, info, iter, relres, hist);
+  if (rc != PSP_OK) return rc;
   PSP_TRY(ps.leave(n, x));
   PSP_HIP(hipStreamSynchronize(stream()));
   return PSP_OK;
+}
+
+static int pcg_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit,
+                      int *info, int *iter, double *relres, double *hist) {
+  return pcg_permuted(A, K, n, x, b, tol, maxit, info, iter, relres, hist);
 }
 
 // ====================================================================== MINRES
@@ -1065,7 +1108,9 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
     PSP_TRY(op_apply(A, x, v_hat));
   PSP_TRY(k_residual(n, b, v_hat, kfused ? dinv : nullptr, w->partials, &np));
   PSP_TRY(reduce_fetch(w, np, 2, s));
-  const double norm_r0 = sqrt(s[0]);
+  double norm_r0_;
+  PSP_TRY(robust_nrm2(w, n, v_hat, s[0], &norm_r0_));
+  const double norm_r0 = norm_r0_;
   double beta = s[1];
   if (hasK) {  // y = K v_hat (minres.c:73-76)
     if (Acsr_forced)
@@ -1178,16 +1223,70 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   return PSP_OK;
 }
 
-static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double errtol,
-                         int it_max, int *info, int *iter, double *relres, double *hist) {
+static int minres_permuted(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double errtol,
+                           int it_max, int *info, int *iter, double *relres, double *hist) {
   DevVecs mem;
   PermutedSystem ps;
   int active = 0;
   if (minres_async_enabled()) PSP_TRY(ps.enter(A, K, n, mem, x, b, &active));
-  if (!active) return minres_device_core(A, K, nullptr, nullptr, n, x, b, errtol, it_max, info, iter, relres, hist);
-  PSP_TRY(minres_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, errtol, it_max, info, iter, relres, hist));
+  if (!active)
+    return minres_device_core(A, K, nullptr, nullptr, n, x, b, errtol, it_max, info, iter, relres, hist);
+  const int rc =
+      minres_device_core(A, K, ps.R, ps.dp, n, ps.xp, ps.bp, errtol, it_max, info, iter, relres, hist);
+  if (rc != PSP_OK) return rc;
   PSP_TRY(ps.leave(n, x));
   PSP_HIP(hipStreamSynchronize(stream()));
+  return PSP_OK;
+}
+
+static int minres_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double errtol,
+                         int it_max, int *info, int *iter, double *relres, double *hist) {
+  return minres_permuted(A, K, n, x, b, errtol, it_max, info, iter, relres, hist);
+}
+
+// largest |v_i|: per-workgroup maxima on the device, the few thousand of them on the host (a path taken once
+// per badly scaled solve)
+__global__ __launch_bounds__(256) void abs_max_kernel(long n, const double *__restrict__ v, double *__restrict__ out) {
+  double m = 0.0;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double a = fabs(v[i]);
+    bad |= a != a;
+    m = a > m ? a : m;
+  }
+  if (bad) m = NAN;
+  __shared__ double sh[256];
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    bool nan = false;
+    for (int i = 0; i < 256; ++i) {
+      nan |= sh[i] != sh[i];
+      r = sh[i] > r ? sh[i] : r;
+    }
+    out[blockIdx.x] = nan ? NAN : r;
+  }
+}
+
+static int abs_max(int n, const double *v, double *out) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = std::min((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(abs_max_kernel, dim3(grid), dim3(256), 0, stream(), (long)n, v, w->partials);
+  PSP_LAUNCH_CHECK();
+  std::vector<double> h((size_t)grid);
+  PSP_HIP(hipMemcpyAsync(h.data(), w->partials, sizeof(double) * (size_t)grid, hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  double r = 0.0;
+  for (double t : h) {
+    if (t != t) {
+      *out = NAN;
+      return PSP_OK;
+    }
+    r = t > r ? t : r;
+  }
+  *out = r;
   return PSP_OK;
 }
 

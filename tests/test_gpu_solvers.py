@@ -594,3 +594,36 @@ def test_reductions_do_not_depend_on_alignment(n):
         check(L.psp_k_residual(n, bx.ptr + 8 * off, r.ptr + 8 * off, None, out.ptr))
         res.append((d,) + tuple(out.download()[:2]))
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("scale", [1e-170, 1e160, 2.0 ** -600, 1e-120, 1e140])
+def test_badly_scaled_right_hand_side(oracle, scale):
+    """|b| ~ 1e-170 or 1e+160: sum b_i^2 underflows to 0 / overflows to inf, where the reference's dnrm2 (scaled
+    form, pcg.c:57,75; minres.c:71) still gives ||b||.  The setup norms are formed at a power-of-two scale then,
+    so the solvers do NOT mistake b for a zero right-hand side (x := 0, info 0); from there on the reference's own
+    ddot reductions underflow / overflow exactly like the ones here and both leave through the same exit
+    (rho == 0 -> -2 at iteration 1, NaN iterates -> -5 / -1).  At 1e-120 / 1e140 the iteration itself stays in range and the
+    solves converge.  Bar: the oracle's (info, iter), relres equal or both NaN, iterates equal to 1e-12 or NaN
+    in the same places."""
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, minres, pcg
+    A = oracle.poisson_csr(30, 20)
+    n = A.shape[0]
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    b1 = np.empty(n)
+    A.matvec(np.ones(n), b1)
+    b = b1 * scale
+    dinv = oracle.jacobi_dinv(A.diagonal())
+    for sg, so in ((pcg, oracle.pcg), (minres, oracle.minres)):
+        for K, dv in ((None, None), (DeviceJacobi(D), dinv)):
+            xo, xg = np.zeros(n), np.zeros(n)
+            ref = so(A, b, xo, 1e-9, 60, dv)
+            got = sg(D, b, xg, 1e-9, 60, K)
+            assert got[:2] == ref[:2], (sg.__name__, scale, ref, got)
+            assert (np.isnan(ref[2]) and np.isnan(got[2])) or abs(got[2] - ref[2]) <= 1e-6 * abs(ref[2])
+            assert np.array_equal(np.isnan(xg), np.isnan(xo))
+            ok = ~np.isnan(xo)
+            if ok.any() and np.abs(xo[ok]).max() > 0:
+                assert np.abs(xg[ok] - xo[ok]).max() <= 1e-12 * np.abs(xo[ok]).max()
+    # a right-hand side that IS zero still takes pcg.c:58-67
+    x = np.ones(n)
+    assert pcg(D, np.zeros(n), x, 1e-9, 10) == (0, 0, 0.0) and not x.any()
