@@ -8,7 +8,8 @@ set -u
 OUT=gpurun_out/profiles_r2; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 python3 bench.py > $OUT/r2_bench.json 2> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-clocks > $OUT/trace.log 2>&1
+# the 512^3 legs only: the 1024^3 leg would mix 13 ms launches of the same kernel into its average
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-clocks --no-strong-n1 > $OUT/r2_bench_traced.json 2> $OUT/trace.log
 cp $OUT/trace/*/*kernel_stats.csv $OUT/r2_bench_kernel_stats.csv 2>/dev/null
 for kv in "w4:-1" "w3:1065154" "w2:16578"; do
   k=${kv%%:*}; v=${kv##*:}; i=1
@@ -48,4 +49,11 @@ for k, fname in (("w4", "r2_spmv"), ("w3", "r2_spmv_w3"), ("w2", "r2_spmv_w2")):
                            "not DRAM-only"},
                   open(os.path.join(out, fname + "_pmc.json"), "w"), indent=1)
 PY
-ls $OUT | head -40; cat $OUT/r2_bench.json | head -c 1500; echo; head -8 $OUT/r2_bench_kernel_stats.csv | cut -c1-160
+# (4) the other measurements quoted in DESIGN.md
+rm -f $OUT/r2_fem_standin.txt
+for s in 1 32 512; do timeout 300 python3 tools/fem_standin.py --shuffle $s --variants 16513 >> $OUT/r2_fem_standin.txt 2>> $OUT/tools.err; done
+timeout 300 python3 tools/small_solver_timing.py > $OUT/r2_small_solvers.txt 2>> $OUT/tools.err
+timeout 300 python3 tools/minres_timing.py > $OUT/r2_minres_timing.txt 2>> $OUT/tools.err
+timeout 300 python3 tools/bench_configs.py > $OUT/r2_configs.json 2>> $OUT/tools.err
+timeout 600 python3 bench.py --gpus 1 --scaling strong --no-cpu-baseline > $OUT/r2_bench_strong_world1.json 2>> $OUT/tools.err
+ls $OUT | head -60; cat $OUT/r2_bench.json | head -c 1500; echo; head -8 $OUT/r2_bench_kernel_stats.csv | cut -c1-160
