@@ -1326,15 +1326,31 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     // lower entries of rows r, r+1 and the x they multiply
     d2v vl[NOL], xl[NOL];
     const double *vp = valL + (size_t)blk * NOL * kDiaRows + 2 * lane;
+    // FLAGS & 4: the offset -1 (always the last one when present) takes no loads of its own -- x[r-1], x[r+2] and
+    // the mirrored values L[r+1, r], L[r+2, r+1] are the neighbouring lanes' x0 / vl registers (lanes 0 and 63
+    // fetch their one halo element) -- and the mirrored pair of an EVEN offset is one aligned 16-byte load:
+    // 14-16 load instructions per lane instead of 20 for the 7-point operator.
+    constexpr bool SHFL = (FLAGS & 4) != 0;
+    const bool off1 = SHFL && offs.o[NOL - 1] == -1;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {
       vl[j] = ldg<(FLAGS & 1) != 0>(reinterpret_cast<const d2v *>(vp + j * kDiaRows));  // plain: the line is usually in L2 already (shifted read), NT costs 6 %
+      if (off1 && j == NOL - 1) continue;
       const long c = r + offs.o[j];  // < r
       const long cc = c < 0 ? 0 : c;
       const d2u t = *reinterpret_cast<const d2u *>(x + cc);
       xl[j].x = t.x;
       xl[j].y = t.y;
       edge |= c < 0;
+    }
+    double halo_xm1 = 0.0, halo_x2 = 0.0, halo_v2 = 0.0;
+    if (off1) {
+      if (lane == 0 && r > 0) halo_xm1 = x[r - 1];
+      if (lane == 63) {
+        if (r + 2 < n) halo_x2 = x[r + 2];
+        if (r + 2 < npad)
+          halo_v2 = valL[((size_t)((r + 2) / kDiaRows) * NOL + (NOL - 1)) * kDiaRows + (size_t)((r + 2) % kDiaRows)];
+      }
     }
     // diagonal
     d2v dg, x0;
@@ -1348,10 +1364,17 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     d2v vu[NOL], xu[NOL];
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {
+      if (off1 && j == NOL - 1) continue;
       const long ru = r - offs.o[j];
-      const long v0 = ru < npad ? ru : npad - 1, v1 = ru + 1 < npad ? ru + 1 : npad - 1;
-      vu[j].x = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows));
-      vu[j].y = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows));
+      if (SHFL && (offs.o[j] & 1) == 0) {  // ru even: rows ru, ru + 1 sit side by side in one block
+        const long v0 = ru < npad ? ru : npad - 2;
+        vu[j] = ldg<(FLAGS & 2) != 0>(reinterpret_cast<const d2v *>(
+            valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows)));
+      } else {
+        const long v0 = ru < npad ? ru : npad - 1, v1 = ru + 1 < npad ? ru + 1 : npad - 1;
+        vu[j].x = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows));
+        vu[j].y = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows));
+      }
       const long xr = ru > xmax ? xmax : ru;
       const d2u t = *reinterpret_cast<const d2u *>(x + xr);
       xu[j].x = t.x;
@@ -1378,6 +1401,18 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
         x0.x = x[r];
         x0.y = 0.0;
       }
+    }
+    if (off1) {  // the -1 offset from the neighbouring lanes (after the repairs: x0 is final)
+      constexpr int j = NOL - 1;
+      const double up = __shfl_up(x0.y, 1, 64);        // x[r - 1]
+      const double dnx = __shfl_down(x0.x, 1, 64);     // x[r + 2]
+      const double dnv = __shfl_down(vl[j].x, 1, 64);  // L[r + 2, r + 1]
+      xl[j].x = lane == 0 ? halo_xm1 : up;
+      xl[j].y = x0.x;
+      vu[j].x = vl[j].y;  // L[r + 1, r]
+      vu[j].y = lane == 63 ? halo_v2 : dnv;
+      xu[j].x = x0.y;
+      xu[j].y = lane == 63 ? halo_x2 : dnx;
     }
     if (use_div) {  // x ./ xdiv (see csr_spmv_w4)
 #pragma unroll
@@ -2515,9 +2550,14 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
 #define PSP_SW4_F(NOL, F)                                                                            \
   hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
                      S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv, xdiv_dev)
+  static const bool shfl = [] {
+    const char *e = getenv("PSP_SSS_SHFL");  // A/B: 0 = every offset by its own loads (round 1)
+    return e ? atoi(e) != 0 : true;
+  }();
 #define PSP_SW4(NOL)                                                                                 \
   case NOL:                                                                                          \
-    if (flags == 0) PSP_SW4_F(NOL, 0);                                                               \
+    if (flags == 0 && shfl) PSP_SW4_F(NOL, 4);                                                       \
+    else if (flags == 0) PSP_SW4_F(NOL, 0);                                                          \
     else if (flags == 1) PSP_SW4_F(NOL, 1);                                                          \
     else if (flags == 2) PSP_SW4_F(NOL, 2);                                                          \
     else PSP_SW4_F(NOL, 3);                                                                          \

@@ -149,6 +149,16 @@ def _worker(rank, world, port, q):
         xm = be.zeros(hi - lo)
         gotm = D.dist_minres(A, be.from_numpy(bg[lo:hi]), xm, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
         out["minres"] = (refm, gotm, float(np.abs(xm.cpu().numpy() - xo[lo:hi]).max() / np.abs(xo).max()))
+        # the operator of the strong-scaling runs (index-free slab, psp_csr_poisson_big_slab) on the same ranks:
+        # same bits for the product, same PCG result
+        B = D.DistCSR.poisson(nx, ny, nz, comm, be, dev.DeviceCSR.poisson_big_slab)
+        yb = be.zeros(hi - lo)
+        vb = B.new_ext()
+        B.owned(vb).copy_(be.from_numpy(xg[lo:hi]))
+        B.matvec(vb, yb)
+        xb = be.zeros(hi - lo)
+        gb = D.dist_pcg(B, be.from_numpy(bg[lo:hi]), xb, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
+        out["big_slab"] = bool(torch.equal(yb, y) and tuple(gb) == tuple(got) and torch.equal(xb, x))
         q.put((rank, out))
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001
@@ -173,6 +183,6 @@ def test_two_ranks_sharing_one_gpu():
         ref, got, err = out["pcg"]
         assert tuple(got[:2]) == tuple(ref[:2])
         assert err < 1e-12
-        assert out["dev_equals_lazy"]
+        assert out["dev_equals_lazy"] and out["big_slab"]
         ref, got, err = out["minres"]
         assert tuple(got[:2]) == tuple(ref[:2]) and err < 1e-12
