@@ -132,6 +132,36 @@ def general_halo_plan(n_global, row_lo, row_hi, col_global, world, rank, all_gat
     return plan, col_local
 
 
+def sss_rows_expanded(n, ind, col, val, diag):
+    """Full CSR of an SSS matrix with every row in sss_matvec's summation order (sss_mat.c:45-55): stored lower
+    entries (ascending column), the diagonal, mirrored entries (j, i), j > i, by ascending j.  Host arrays."""
+    ind = np.asarray(ind, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    val = np.asarray(val, dtype=np.float64)
+    nl = np.diff(ind)
+    rows = np.repeat(np.arange(n, dtype=np.int64), nl)
+    up_cnt = np.bincount(col, minlength=n)                  # mirrored entries land in row col[k]
+    f_ind = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nl + 1 + up_cnt, out=f_ind[1:])
+    f_col = np.empty(f_ind[-1], dtype=np.int64)
+    f_val = np.empty(f_ind[-1], dtype=np.float64)
+    within = np.arange(len(col), dtype=np.int64) - ind[rows]
+    f_col[f_ind[rows] + within] = col                       # lower part, stored order
+    f_val[f_ind[rows] + within] = val
+    dpos = f_ind[:-1] + nl
+    f_col[dpos] = np.arange(n)
+    f_val[dpos] = diag
+    order = np.argsort(col, kind="stable")                  # by target row, then by source row (ascending)
+    tgt = col[order]
+    start = np.concatenate([[0], np.cumsum(up_cnt)])[tgt]
+    k = np.arange(len(col), dtype=np.int64) - start
+    f_col[dpos[tgt] + 1 + k] = rows[order]
+    f_val[dpos[tgt] + 1 + k] = val[order]
+    if f_ind[-1] > 2 ** 31 - 1:
+        raise ValueError("expanded matrix exceeds 32-bit offsets: partition before expanding")
+    return f_ind.astype(np.int32), f_col.astype(np.int32), f_val
+
+
 # ----------------------------------------------------------------------------- backends
 
 class HipBackend:
@@ -688,6 +718,28 @@ class DistCSR:
         plan = poisson_halo_plan(nx, ny, nz, comm.world, comm.rank)
         A = make_local(nx, ny, nz, plan.row_lo, plan.row_hi, plan.row_lo - plan.ghost_lo, plan.n_ext)
         return cls(A, plan, comm, backend)
+
+    @classmethod
+    def from_global_csr(cls, n, ind, col, val, comm, backend, make_local):
+        """Row block [lo, hi) of a global CSR triple held on the host by every rank (small / medium problems:
+        MatrixMarket files, the irregular configs).  make_local(shape, ind, col, val) -> csr handle
+        (HipBackend: DeviceCSR.from_arrays)."""
+        lo, hi = row_range(n, comm.world, comm.rank)
+        a, b = int(ind[lo]), int(ind[hi])
+        ind_loc = (np.asarray(ind[lo:hi + 1], dtype=np.int64) - a).astype(np.int32)
+        plan, col_local = general_halo_plan(n, lo, hi, col[a:b], comm.world, comm.rank, comm.all_gather_object,
+                                            ind=ind_loc)
+        A = make_local((hi - lo, plan.n_ext), ind_loc, col_local, np.ascontiguousarray(val[a:b], dtype=np.float64))
+        return cls(A, plan, comm, backend)
+
+    @classmethod
+    def from_global_sss(cls, n, ind, col, val, diag, comm, backend, make_local):
+        """An sss_mat (strict lower triangle + diagonal, sss_mat.h:6-14) on row blocks: every rank expands ITS rows
+        of the full matrix in the order sss_matvec adds them (sss_mat.c:45-55: lower entries by ascending column,
+        the diagonal, then the mirrored entries by ascending row), so the distributed product has the bits of the
+        single-GPU sss_mat.matvec."""
+        f_ind, f_col, f_val = sss_rows_expanded(n, ind, col, val, diag)
+        return cls.from_global_csr(n, f_ind, f_col, f_val, comm, backend, make_local)
 
     def new_ext(self):
         return self.be.zeros(self.plan.n_ext)

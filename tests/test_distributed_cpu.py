@@ -37,6 +37,15 @@ def _worker(rank, world, port, case, q):
             nx, ny, nz = case[1]
             G = O.poisson_csr(nx, ny, nz)
             A = D.DistCSR.poisson(nx, ny, nz, comm, be, local_poisson_from_oracle)
+        elif case[0] == "sss":  # an sss_mat on row blocks: rows expanded in sss_matvec's summation order
+            rng = np.random.default_rng(5)
+            n = 300
+            S = O.tendigit_sss(n)
+            S.diag[:] = 40.0 + rng.random(n)
+            S.val[:] = rng.standard_normal(S.val.size)
+            G = S  # the oracle's sss_matvec / sss solvers are the reference here
+            A = D.DistCSR.from_global_sss(n, S.ind, S.col, S.val, S.diag, comm, be,
+                                          lambda shape, i, c, v: O.CSR(shape, v, c, i))
         else:  # general CSR with irregular coupling across the partition
             rng = np.random.default_rng(5)
             n = 300
@@ -63,7 +72,7 @@ def _worker(rank, world, port, case, q):
         # ---- distributed PCG == oracle PCG on the global system
         bg = np.empty(n)
         G.matvec(np.ones(n), bg)
-        dinv_g = O.jacobi_dinv(G.diagonal())
+        dinv_g = O.jacobi_dinv(G.diag if case[0] == "sss" else G.diagonal())
         res = {}
         for name, dg in (("none", None), ("jacobi", dinv_g)):
             xo = np.zeros(n)
@@ -150,7 +159,8 @@ def _run(world, case):
 
 
 @pytest.mark.parametrize("world,case", [(2, ("poisson", (6, 5, 8))), (3, ("poisson", (5, 4, 7))),
-                                        (2, ("poisson", (16, 9, 0))), (2, ("general",)), (3, ("general",))])
+                                        (2, ("poisson", (16, 9, 0))), (2, ("general",)), (3, ("general",)),
+                                        (2, ("sss",)), (3, ("sss",))])
 def test_row_partitioned_spmv_and_pcg(world, case):
     results = _run(world, case)
     assert len(results) == world
