@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--no-clocks", action="store_true")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo, which moves device "
+                         "tensors on this image; RCCL refuses two ranks on one GPU).  Not a measurement.")
     ap.add_argument("--test-backend", default="",
                     help="module:factory returning (backend, make_local) -- CPU dry run of the launcher and the "
                          "row-range driver over gloo (tests/); the line it prints is marked dry_run, not a measurement")
@@ -371,6 +374,8 @@ def main():
             be, make_local = getattr(importlib.import_module(mod), fn)()
             dev_sync = lambda: None  # noqa: E731
         else:
+            if a.share_gpu:
+                local_rank = 0
             torch.cuda.set_device(local_rank)
             if a.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -598,6 +603,9 @@ def main():
             out["backend"] = dist.get_backend()
         if dry:
             out["dry_run"] = "launcher / driver plumbing over gloo with " + a.test_backend + ": NOT a measurement"
+        if a.share_gpu:
+            out["dry_run"] = "%d ranks sharing cuda:0 over %s: a rehearsal of the N > 1 path, NOT a measurement" % (
+                world, a.backend)
         if kernels is not None:
             out["kernels_same_operator"] = kernels
         if sss is not None:

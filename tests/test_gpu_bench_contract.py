@@ -67,6 +67,41 @@ def test_bench_strong_path_world_size_1():
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_n_ranks_rehearsal_on_one_gpu(world):
+    """`python bench.py --gpus N` end to end with the HIP kernels: self-launched ranks, index-free slab operators,
+    halo exchange of device tensors, device-resident scalars with in-stream all-reduces -- everything of the N > 1
+    path except the transport, which is gloo here (it moves device tensors on this image; RCCL needs one GPU per
+    rank and the box has one).  World 3: the middle rank has halos on both sides."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo",
+                          "--share-gpu", "--grid", "64,48,36", "--steps", "4", "--warmup", "2", "--pcg-iters", "40",
+                          "--no-cpu-baseline", "--no-clocks", "--no-strong-n1"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and "dry_run" in d
+    assert d["scaling"] == "strong" and d["config"]["n"] == 64 * 48 * 36
+    assert d["roofline"]["kernel"] == "csr_spmv_w4"
+    # tol = 0: exactly 40 iterations; the same count and residual as the one-GPU solver on the whole problem
+    assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 41
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from pysparse_amd import device as dev
+    A = dev.DeviceCSR.poisson(64, 48, 36)
+    n = A.shape[0]
+    b = np.empty(n)
+    A.matvec(np.ones(n), b)
+    x = np.zeros(n)
+    ref = dev.pcg(A, b, x, 0.0, 40, dev.DeviceJacobi(A))
+    assert ref[:2] == (-1, 41) and abs(ref[2] - d["pcg_check"]["relres"]) <= 1e-9 * ref[2]
+
+
 def test_bench_cpu_baseline_objects_small_sample():
     sys.path.insert(0, ROOT)
     import bench

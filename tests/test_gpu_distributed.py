@@ -74,7 +74,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="host_staged"):
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -118,7 +118,9 @@ def _worker(rank, world, port, q):
                 return wait
 
         be = D.HipBackend(0)
-        comm = HostStagedComm()
+        # "gloo_device": the product's Comm class unchanged -- gloo moves device tensors on this image, so the
+        # batch_isend_irecv / all_reduce calls are the ones the RCCL runs make
+        comm = HostStagedComm() if transport == "host_staged" else D.Comm()
         nx, ny, nz = 48, 40, 24
         A = D.DistCSR.poisson(nx, ny, nz, comm, be, dev.DeviceCSR.poisson_slab)
         G = O.poisson_csr(nx, ny, nz)
@@ -166,15 +168,18 @@ def _worker(rank, world, port, q):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def test_two_ranks_sharing_one_gpu():
+@pytest.mark.parametrize("transport", ["host_staged", "gloo_device"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu(world, transport):
+    """world 3: the middle rank has ghost planes on both sides (the interior ranks of the 8-GPU partition)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=300) for _ in range(2))
+    results = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     for rank, out in results.items():
