@@ -630,16 +630,28 @@ class HostStateOps:
 
 
 class Comm:
-    """torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests)."""
+    """torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).
+
+    RCCL work is stream-ordered: a collective / P2P batch waits for the kernels enqueued before it on the current
+    stream and `wait()` makes the current stream wait for it -- nothing blocks the host.  gloo moves device tensors
+    too on this image (the one-GPU rehearsals, tests/test_gpu_distributed.py), but through host staging on its own
+    streams: there the device is synchronised around every transfer (`_dev_sync`), which only costs time."""
 
     def __init__(self, group=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stream_ordered = dist.get_backend(group) == "nccl"
+
+    def _dev_sync(self, tensors):
+        if not self.stream_ordered and any(t.is_cuda for t in tensors):
+            torch.cuda.synchronize()
 
     def allreduce_sum(self, t):
         if self.world > 1:
+            self._dev_sync([t])
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._dev_sync([t])
         return t
 
     def all_gather_object(self, obj):
@@ -649,17 +661,14 @@ class Comm:
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer, tensor).  One grouped RCCL send/recv batch."""
-        if not sends and not recvs:
-            return
-        ops = [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
-        ops += [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        self.exchange_start(sends, recvs)()
 
     def exchange_start(self, sends, recvs):
         """Post the grouped send/recv batch; returns wait() that completes it (stream order)."""
         if not sends and not recvs:
             return lambda: None
+        tensors = [t for _, t in sends] + [t for _, t in recvs]
+        self._dev_sync(tensors)
         ops = [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
         ops += [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
         works = dist.batch_isend_irecv(ops)
@@ -667,6 +676,7 @@ class Comm:
         def wait():
             for w in works:
                 w.wait()
+            self._dev_sync(tensors)
         return wait
 
     def barrier(self):
