@@ -61,6 +61,58 @@ def test_ssor_precon_bit_exact(oracle, which, omega, steps):
         K.precon(x, y[::2])
 
 
+def grid_sss(O, nx, ny, nz, seed, keep=0.85):
+    """variable-coefficient 7-point-like operator in natural ordering with some couplings removed: lower offsets
+    -nx*ny, -nx, -1 (never across a grid line or plane), random values, dominant diagonal"""
+    rng = np.random.default_rng(seed)
+    P = O.poisson_sss(nx, ny, nz)
+    sel = rng.random(P.val.size) < keep
+    lens = np.add.reduceat(sel.astype(np.int64), P.ind[:-1].astype(np.int64)) * (np.diff(P.ind) > 0)
+    ind = np.zeros(P.n + 1, dtype=np.int32)
+    np.cumsum(lens, out=ind[1:])
+    col = P.col[sel]
+    val = -(0.2 + rng.random(col.size))
+    diag = 6.5 + rng.random(P.n)
+    return O.SSS(P.n, val, diag, col, ind)
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.0, 3), (1.35, 1), (0.7, 2)])
+@pytest.mark.parametrize("grid", [(16, 4, 8), (40, 30, 20), (33, 17, 9), (7, 5, 64), (100, 3, 3), (17, 64, 2)])
+def test_ssor_tiled_wavefront_bit_exact(oracle, grid, omega, steps):
+    """3-D grid operators take the tiled wavefront schedule (tiles of 16 x 4 x 8 points swept in registers, one
+    launch per tile level): whole and partial tiles, one tile and many in every direction, missing couplings --
+    bit-identical to the sequential sweeps of the oracle; an operator with a coupling across a grid line is not a
+    grid operator and stays on the level schedule (also bit-identical)."""
+    from pysparse_amd.device import DeviceSSOR, DeviceSSS
+    S = grid_sss(oracle, *grid, seed=sum(grid))
+    D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    K = DeviceSSOR(D, omega, steps)
+    x = rng_vec(S.n, 3)
+    y_ref = np.full(S.n, -1.5)
+    oracle.ssor_apply(S, x, y_ref, omega, steps)
+    y = np.full(S.n, -1.5)
+    K.precon(x, y)
+    assert np.array_equal(y, y_ref)
+    # the same matrix with ONE extra coupling that wraps around a grid line (row i = 0 of line 1 to the last point
+    # of line 0): offsets unchanged, but not a grid operator any more
+    nx = grid[0]
+    if S.n >= 512:
+        r = nx  # first point of the second grid line: its offset -1 neighbour is the end of the first line
+        lo, hi = S.ind[r], S.ind[r + 1]
+        if (r - 1) not in S.col[lo:hi]:
+            col = np.insert(S.col, hi, r - 1)
+            val = np.insert(S.val, hi, -0.25)
+            ind = S.ind.copy()
+            ind[r + 1:] += 1
+            S2 = oracle.SSS(S.n, val, S.diag, col, ind)
+            D2 = DeviceSSS.from_arrays(S2.n, S2.ind, S2.col, S2.val, S2.diag)
+            y_ref = np.zeros(S.n)
+            oracle.ssor_apply(S2, x, y_ref, omega, steps)
+            y = np.zeros(S.n)
+            DeviceSSOR(D2, omega, steps).precon(x, y)
+            assert np.array_equal(y, y_ref)
+
+
 def test_ssor_requires_sss(oracle):
     from pysparse_amd.device import DeviceCSR, DeviceSSOR
     with pytest.raises(TypeError):
