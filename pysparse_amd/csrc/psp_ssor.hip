@@ -59,14 +59,6 @@ struct psp_ssor {
   // (ptr -> entries -> x; four in the backward sweep, whose slots are rows by indirection).
   int ell_f = 0, ell_b = 0;  // width (0: CSR form)
   unsigned char *fc8 = nullptr, *bc8 = nullptr;
-  // Tiled wavefront schedule for 3-D grid operators (lower offsets -nx*ny, -nx, -1 in natural ordering: every
-  // 7-point-like stencil): see ssor_tile_kernel.  tiles[] = packed tile ids sorted by tile level tx + ty + tz,
-  // tile_ptr[l] .. tile_ptr[l+1] = the tiles of level l; the sweeps then work on the caller's vectors in place
-  // (natural order) and none of the level-ordered copies above is built.
-  int grid_nx = 0, grid_ny = 0, grid_nz = 0, ntx = 0, nty = 0, ntz = 0;
-  int *tiles = nullptr;
-  std::vector<int> tile_ptr;
-  double *ytemp = nullptr;  // y (symgs) / h (ssor) in natural order
   double *da = nullptr;                 // diagonal by position
   double *bp = nullptr, *xp = nullptr;  // right-hand side and iterate by position
   double *temp = nullptr;               // y (symgs) / h (ssor) by position
@@ -281,154 +273,6 @@ __global__ void ssor_to_ell_kernel(int n, int W, const int *__restrict__ ptr, co
   }
 }
 
-// ------------------------------------------------------------------ tiled wavefront sweeps (3-D grids)
-//
-// Level scheduling costs one dependent kernel launch per hyperplane i + j + k = const: 2 x 1534 launches of ~5 us
-// at 512^3, whatever the kernels do.  For an operator whose strict lower triangle has the offsets
-// {-nx*ny, -nx, -1} (natural ordering of an nx x ny x nz grid; verified on the device: no entry wraps around a
-// grid line or plane) the same dependency order can be walked in TILES: a wavefront owns a tile of
-// 16 x 4 x 8 points, lane (li, lj) the column of 8 points along z, and sweeps the tile's own hyperplanes
-// li + lj + lk = w, w = 0 .. 25, in registers: at step w the lane relaxes its point lk = w - li - lj; its -z
-// neighbour is the value it computed one step earlier, its -x / -y neighbours are what lanes - 1 / - 16 computed one
-// step earlier (__shfl_up of their latest value), and the three tile faces come from global memory, written by
-// earlier launches.  Tiles depend on their -x / -y / -z neighbours only, so tiles with equal tx + ty + tz are
-// independent: 32 + 128 + 64 - 2 = 222 launches per sweep at 512^3 instead of 1534, each ~1200 tiles.
-// A lane keeps its 8 points in registers ROTATED by li + lj (point lk in slot (lk + li + lj) & 7), so that the slot
-// used at step w is w & 7 for every lane -- a compile-time index once the 26 steps are unrolled.
-// Every row performs the reference's operations in the reference's order (lower entries by ascending column:
-// -nx*ny, -nx, -1; the backward sweep's gather from the last upper entry to the first: +nx*ny, +nx, +1;
-// preconmodule.c:95-193), so the result is bit-identical to the sequential sweeps and to the level-scheduled ones.
-constexpr int kTX = 16, kTY = 4, kTZ = 8;
-constexpr int kTileSteps = kTX + kTY + kTZ - 2;
-
-struct TileGrid {
-  int nx, ny, nz, ntx, nty, ntz;
-};
-
-// lower entries must not wrap: offset -1 only where i > 0, offset -nx only where j > 0
-__global__ void ssor_grid_check_kernel(int n, int nx, int ny, const unsigned short *__restrict__ mask,
-                                       int *__restrict__ bad) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const unsigned m = mask[r];
-    const int i = r % nx, j = (r / nx) % ny;
-    if (((m >> 2) & 1u) && i == 0) *bad = 1;
-    if (((m >> 1) & 1u) && j == 0) *bad = 1;
-  }
-}
-
-// KIND 0 / 2: forward sweep (symgs / ssor), 1 / 3: backward
-template <int KIND>
-__global__ __launch_bounds__(256) void ssor_tile_kernel(TileGrid g, int ntiles, const int *__restrict__ tiles,
-                                                        const double *__restrict__ valL,
-                                                        const unsigned short *__restrict__ mask,
-                                                        const double *__restrict__ da, const double *__restrict__ b,
-                                                        double *x, double *y, double omega, int first) {
-  constexpr bool FWD = KIND == 0 || KIND == 2;
-  constexpr bool GS = KIND <= 1;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= ntiles) return;  // whole waves only: the shuffles below stay convergent
-  const int tile = tiles[wave];
-  const int tx = tile % g.ntx, ty = (tile / g.ntx) % g.nty, tz = tile / (g.ntx * g.nty);
-  // forward: lane (li, lj) as is; backward: everything mirrored, so that "previous" means +x / +y / +z
-  const int li = lane & 15, lj = lane >> 4;
-  const int gi = tx * kTX + (FWD ? li : kTX - 1 - li);
-  const int gj = ty * kTY + (FWD ? lj : kTY - 1 - lj);
-  const int gk0 = tz * kTZ;
-  const long nxy = (long)g.nx * g.ny;
-  const bool col_ok = gi < g.nx && gj < g.ny;
-  const int dir = FWD ? -1 : 1;  // where the already relaxed neighbours are
-  const bool face_x = li == 0, face_y = lj == 0;
-  // ---- the lane's 8 points, rotated: slot q holds local step-coordinate lk = (q - li - lj) & 7
-  double c[kTZ], d[kTZ], v0[kTZ], v1[kTZ], v2[kTZ], hx[kTZ], hy[kTZ];
-  unsigned mk[kTZ];
-  long rr[kTZ];
-  double hz = 0.0;
-#pragma unroll
-  for (int q = 0; q < kTZ; ++q) {
-    const int lk = (q - li - lj) & (kTZ - 1);
-    const int gk = gk0 + (FWD ? lk : kTZ - 1 - lk);
-    const bool ok = col_ok && gk < g.nz;
-    const long r = ok ? gi + (long)g.nx * (gj + (long)g.ny * gk) : 0;
-    rr[q] = ok ? r : -1;
-    unsigned m = ok ? mask[r] : 0u;
-    double bb = 0.0, yy = 0.0, dd = 1.0, xo = 0.0;
-    if (ok) {
-      bb = b[r];
-      yy = y[r];
-      dd = da[r];
-      if (KIND == 3 || (KIND == 2 && !first)) xo = x[r];
-    }
-    if constexpr (GS) {
-      c[q] = bb - yy;  // (b - y - s) / d = ((b - y) - s) / d
-    } else {
-      c[q] = (KIND == 2 && first) ? omega * bb : (1.0 - omega) * xo * dd + yy + omega * bb;
-    }
-    d[q] = dd;
-    // entries towards the relaxed side, slot s <-> offset {-nxy, -nx, -1} (forward: the row's own lower entries;
-    // backward: the mirrored ones, stored in rows r + nxy, r + nx, r + 1; existence in mask bits 8..10)
-    double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-    if (ok) {
-      if constexpr (FWD) {
-        const size_t base = ((size_t)(r / 128) * 3) * 128 + (size_t)(r % 128);
-        e0 = valL[base];
-        e1 = valL[base + 128];
-        e2 = valL[base + 256];
-      } else {
-        m >>= 8;
-        const long r0 = r + nxy, r1 = r + g.nx, r2 = r + 1;
-        if (m & 1u) e0 = valL[((size_t)(r0 / 128) * 3 + 0) * 128 + (size_t)(r0 % 128)];
-        if (m & 2u) e1 = valL[((size_t)(r1 / 128) * 3 + 1) * 128 + (size_t)(r1 % 128)];
-        if (m & 4u) e2 = valL[((size_t)(r2 / 128) * 3 + 2) * 128 + (size_t)(r2 % 128)];
-      }
-    }
-    mk[q] = m & 7u;
-    v0[q] = e0;
-    v1[q] = e1;
-    v2[q] = e2;
-    // tile faces: neighbours relaxed by earlier launches (only where an entry exists)
-    hx[q] = (ok && face_x && (m & 4u)) ? x[r + dir] : 0.0;
-    hy[q] = (ok && face_y && (m & 2u)) ? x[r + (long)dir * g.nx] : 0.0;
-    if (ok && lk == 0 && (m & 1u)) hz = x[r + dir * nxy];
-  }
-  // ---- the tile's own hyperplanes
-  double xlast = 0.0;
-#pragma unroll
-  for (int w = 0; w < kTileSteps; ++w) {
-    const int q = w & (kTZ - 1);
-    const int lk = w - li - lj;
-    const bool active = lk >= 0 && lk < kTZ && rr[q] >= 0;
-    const double from_x = __shfl_up(xlast, 1, 64);   // lane (li - 1, lj): the same lk, one step ago
-    const double from_y = __shfl_up(xlast, 16, 64);  // lane (li, lj - 1)
-    const double xn = face_x ? hx[q] : from_x;
-    const double yn = face_y ? hy[q] : from_y;
-    const double zn = lk == 0 ? hz : xlast;
-    double s_ = 0.0;
-    {
-      const double t0 = GS ? s_ + v0[q] * zn : s_ - v0[q] * zn;
-      s_ = (mk[q] & 1u) ? t0 : s_;
-      const double t1 = GS ? s_ + v1[q] * yn : s_ - v1[q] * yn;
-      s_ = (mk[q] & 2u) ? t1 : s_;
-      const double t2 = GS ? s_ + v2[q] * xn : s_ - v2[q] * xn;
-      s_ = (mk[q] & 4u) ? t2 : s_;
-    }
-    double xnew, ynew;
-    if constexpr (GS) {
-      xnew = (c[q] - s_) / d[q];
-      ynew = s_;
-    } else {
-      const double hi = omega * s_;
-      ynew = hi;
-      xnew = (c[q] + hi) / d[q];
-    }
-    if (active) {
-      x[rr[q]] = xnew;
-      y[rr[q]] = ynew;
-      xlast = xnew;
-    }
-  }
-}
-
 // ---- builders of the level-ordered copies
 __global__ void invert_perm_kernel(int n, const int *__restrict__ perm, int *__restrict__ inv) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) inv[perm[i]] = i;
@@ -557,6 +401,7 @@ done:
 
 namespace psp {
 
+int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // psp_reorder.hip
 
 // the launches of one sweep on stream st, everything by position
 template <int KIND, int W>
@@ -656,39 +501,8 @@ static void ensure_graph(psp_ssor *K) {
   K->graph_state = 1;
 }
 
-// tiled wavefront sweeps on the caller's vectors (natural order); forward: tile levels ascending, backward: descending
-template <int KIND>
-static void tile_sweep(const psp_ssor *K, const double *b, double *x, int first) {
-  const psp_sss *S = K->S;
-  TileGrid g{K->grid_nx, K->grid_ny, K->grid_nz, K->ntx, K->nty, K->ntz};
-  const int nl = (int)K->tile_ptr.size() - 1;
-  constexpr bool fwd = KIND == 0 || KIND == 2;
-  for (int i = 0; i < nl; ++i) {
-    const int l = fwd ? i : nl - 1 - i;
-    const int a = K->tile_ptr[l], cnt = K->tile_ptr[l + 1] - a;
-    if (cnt <= 0) continue;
-    hipLaunchKernelGGL(ssor_tile_kernel<KIND>, dim3((cnt + 3) / 4), dim3(256), 0, stream(), g, cnt, K->tiles + a,
-                       S->w4_val, S->w4_mask, S->diag, b, x, K->ytemp, K->omega, first);
-  }
-}
-
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
   if (K->steps <= 0) return PSP_OK;  // the reference leaves y untouched
-  if (K->tiles) {
-    const bool gs = K->omega == 1.0;
-    if (gs) PSP_HIP(hipMemsetAsync(K->ytemp, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
-    for (int step = 0; step < K->steps; ++step) {
-      if (gs) {
-        tile_sweep<0>(K, b, x, 0);
-        tile_sweep<1>(K, b, x, 0);
-      } else {
-        tile_sweep<2>(K, b, x, step == 0 ? 1 : 0);
-        tile_sweep<3>(K, b, x, 0);
-      }
-    }
-    PSP_LAUNCH_CHECK();
-    return PSP_OK;
-  }
   PSP_TRY(reorder_gather(K->n, K->pos2row, b, K->bp, nullptr));  // bp[t] = b[pos2row[t]]
   if (K->omega == 1.0) PSP_HIP(hipMemsetAsync(K->temp, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
   ensure_graph(K);
@@ -831,65 +645,6 @@ int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
   return rc;
 }
 
-// 3-D grid operator in natural ordering?  Then the tile schedule (ssor_tile_kernel) replaces the level one.
-int try_grid_schedule(psp_ssor *K) {
-  static const bool off = [] {
-    const char *e = getenv("PSP_SSOR_TILES");
-    return e && atoi(e) == 0;
-  }();
-  psp_sss *S = K->S;
-  if (off || S->n < kTX * kTY * kTZ) return PSP_OK;
-  PSP_TRY(sss_ensure_w4(S));
-  if (S->w4_state != 1 || S->w4_nol != 3 || S->w4_offs[2] != -1) return PSP_OK;
-  const long nx = -(long)S->w4_offs[1], nxy = -(long)S->w4_offs[0];
-  if (nx < 2 || nxy <= nx || nxy % nx != 0 || (long)S->n % nxy != 0) return PSP_OK;
-  const long ny = nxy / nx, nz = S->n / nxy;
-  if (ny < 2 || nz < 2) return PSP_OK;
-  int *bad = nullptr;
-  PSP_HIP(hipMalloc((void **)&bad, sizeof(int)));
-  int hbad = 1;
-  hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), stream());
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(ssor_grid_check_kernel, dim3(std::min((S->n + 255) / 256, 65536)), dim3(256), 0, stream(), S->n,
-                       (int)nx, (int)ny, S->w4_mask, bad);
-    e = hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost);
-  }
-  (void)hipFree(bad);
-  if (e != hipSuccess) return fail(PSP_ENODEV, "ssor: grid check failed: %s", hipGetErrorString(e));
-  if (hbad) return PSP_OK;  // an entry wraps around a grid line / plane: not a grid operator
-  const int ntx = (int)((nx + kTX - 1) / kTX), nty = (int)((ny + kTY - 1) / kTY), ntz = (int)((nz + kTZ - 1) / kTZ);
-  const long nt = (long)ntx * nty * ntz;
-  if (nt > 0x7fffffffL) return PSP_OK;
-  const int nl = ntx + nty + ntz - 2;
-  std::vector<int> cnt((size_t)nl + 1, 0), tiles((size_t)nt);
-  for (int tz = 0; tz < ntz; ++tz)
-    for (int ty = 0; ty < nty; ++ty)
-      for (int tx = 0; tx < ntx; ++tx) ++cnt[(size_t)(tx + ty + tz) + 1];
-  for (int l = 0; l < nl; ++l) cnt[(size_t)l + 1] += cnt[l];
-  std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-  for (int tz = 0; tz < ntz; ++tz)
-    for (int ty = 0; ty < nty; ++ty)
-      for (int tx = 0; tx < ntx; ++tx) tiles[(size_t)fill[tx + ty + tz]++] = tx + ntx * (ty + nty * tz);
-  if (hipMalloc((void **)&K->tiles, sizeof(int) * (size_t)nt) != hipSuccess ||
-      hipMalloc((void **)&K->ytemp, sizeof(double) * (size_t)S->n) != hipSuccess ||
-      hipMemcpy(K->tiles, tiles.data(), sizeof(int) * (size_t)nt, hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(K->tiles);
-    (void)hipFree(K->ytemp);
-    K->tiles = nullptr;
-    K->ytemp = nullptr;
-    return PSP_OK;  // no room: level schedule
-  }
-  K->tile_ptr = cnt;
-  K->grid_nx = (int)nx;
-  K->grid_ny = (int)ny;
-  K->grid_nz = (int)nz;
-  K->ntx = ntx;
-  K->nty = nty;
-  K->ntz = ntz;
-  return PSP_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -909,8 +664,7 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     int *rows_f = nullptr, *rows_b = nullptr;
     rc = build_schedule(S->full, 0, &rows_f, &K->ptr_f);
     if (rc == PSP_OK) rc = build_schedule(S->full, 1, &rows_b, &K->ptr_b);
-    if (rc == PSP_OK) rc = try_grid_schedule(K);
-    if (rc == PSP_OK && !K->tiles) {
+    if (rc == PSP_OK) {
       // backward slots are (level, row)-sorted rows; ptr_b indexes slots
       rc = build_level_ordered(K, rows_f, rows_b);
       rows_f = nullptr;  // owned by K now (pos2row), even on failure
@@ -944,7 +698,7 @@ int psp_ssor_destroy(psp_ssor_t *K) {
   for (void *p : {(void *)K->pos2row, (void *)K->row2pos, (void *)K->dptr_f, (void *)K->dptr_b, (void *)K->f_ptr,
                   (void *)K->f_pos, (void *)K->f_val, (void *)K->b_row, (void *)K->b_ptr, (void *)K->b_pos,
                   (void *)K->b_val, (void *)K->da, (void *)K->bp, (void *)K->xp, (void *)K->temp, (void *)K->fc8,
-                  (void *)K->bc8, (void *)K->tiles, (void *)K->ytemp})
+                  (void *)K->bc8})
     (void)hipFree(p);
   delete K;
   return PSP_OK;

@@ -78,11 +78,10 @@ def grid_sss(O, nx, ny, nz, seed, keep=0.85):
 
 @pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.0, 3), (1.35, 1), (0.7, 2)])
 @pytest.mark.parametrize("grid", [(16, 4, 8), (40, 30, 20), (33, 17, 9), (7, 5, 64), (100, 3, 3), (17, 64, 2)])
-def test_ssor_tiled_wavefront_bit_exact(oracle, grid, omega, steps):
-    """3-D grid operators take the tiled wavefront schedule (tiles of 16 x 4 x 8 points swept in registers, one
-    launch per tile level): whole and partial tiles, one tile and many in every direction, missing couplings --
-    bit-identical to the sequential sweeps of the oracle; an operator with a coupling across a grid line is not a
-    grid operator and stays on the level schedule (also bit-identical)."""
+def test_ssor_grid_operators_bit_exact(oracle, grid, omega, steps):
+    """variable-coefficient 3-D grid operators with missing couplings (rows of 0-3 lower entries: the padded
+    slot-major form of the level-ordered triangle), thin and thick grids -- bit-identical to the sequential sweeps
+    of the oracle; likewise with one extra coupling that wraps around a grid line."""
     from pysparse_amd.device import DeviceSSOR, DeviceSSS
     S = grid_sss(oracle, *grid, seed=sum(grid))
     D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
