@@ -627,3 +627,40 @@ def test_badly_scaled_right_hand_side(oracle, scale):
     # a right-hand side that IS zero still takes pcg.c:58-67
     x = np.ones(n)
     assert pcg(D, np.zeros(n), x, 1e-9, 10) == (0, 0, 0.0) and not x.any()
+
+
+def test_concurrent_solves_from_python_threads(oracle):
+    """The extension modules and ctypes release the GIL around device work, and the library's reduction workspace
+    and stream are process-global: every compute entry point takes one library-wide lock, so solves issued from
+    several Python threads at once serialise (as they do in the reference, which holds the GIL) instead of reading
+    each other's partial sums.  Eight threads x mixed pcg / minres / matvec on different handles: every result
+    equals the one obtained alone."""
+    import threading
+    from pysparse_amd.device import DeviceCSR, DeviceJacobi, DeviceSSS, minres, pcg
+    work = []
+    for k, grid in enumerate([(40, 30, 0), (24, 20, 12), (64, 64, 0), (18, 17, 16)]):
+        A = DeviceCSR.poisson(*grid)
+        S = DeviceSSS.poisson(*grid)
+        n = A.shape[0]
+        b = np.random.default_rng(k).standard_normal(n)
+        work.append((pcg, A, b, DeviceJacobi(A)))
+        work.append((minres, S, b, DeviceJacobi(S)))
+    def solve(item):
+        fn, M, b, K = item
+        x = np.zeros(len(b))
+        r = fn(M, b, x, 1e-9, 3000, K)
+        y = np.empty(len(b))
+        M.matvec(x, y)
+        return r, x, y
+    alone = [solve(w) for w in work]
+    for trial in range(3):
+        got = [None] * len(work)
+        def run(i):
+            got[i] = solve(work[i])
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for (r0, x0, y0), (r1, x1, y1) in zip(alone, got):
+            assert r0 == r1 and np.array_equal(x0, x1) and np.array_equal(y0, y1)
