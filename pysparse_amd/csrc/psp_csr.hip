@@ -2690,9 +2690,15 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     const char *e = getenv("PSP_SPMV_REORDER");
     return e && atoi(e) == 0;
   }();
-  // worth it when the gather pass (20 n bytes) is small against the matrix stream (12 nnz)
+  // worth it when the gather pass (20 n bytes) is small against the matrix stream (12 nnz); the numbering is
+  // computed on the host from a copy of the arrays (seconds and 30 bytes of host memory per nonzero): not attempted
+  // beyond PSP_SPMV_REORDER_MAX_NNZ nonzeros (default 3e8)
+  static const long max_nnz = [] {
+    const char *e = getenv("PSP_SPMV_REORDER_MAX_NNZ");
+    return e ? atol(e) : 300000000L;
+  }();
   if (off || A->no_reorder || A->w4_only || A->nrows != A->ncols || A->nrows < 1024 ||
-      (long)A->nnz < 12L * A->nrows)
+      (long)A->nnz < 12L * A->nrows || (long)A->nnz > max_nnz)
     return PSP_OK;
   const int n = A->nrows;
   const size_t nnz = (size_t)A->nnz;
