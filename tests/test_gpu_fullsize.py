@@ -372,3 +372,27 @@ def test_poisson_big_slab_rejects_bad_arguments():
         dev.DeviceCSR.poisson_big_slab(8, 8, 8, 64, 128, 64, 64 + 8)  # halo below the slab not covered
     with pytest.raises(PspError):
         dev.DeviceCSR.poisson_big_slab(8, 8, 8, 128, 64, 0, 512)       # empty / inverted range
+
+
+def test_config4_1024_cubed_four_ranks_rehearsal():
+    """BASELINE.json configs[3] at its true size on the ranks' true shares: the 1024^3 operator cut into 4 z-slabs of
+    2^28 rows (1.9e9 nonzeros each: beyond 32-bit CSR offsets, index-free slab operator), bench.py's own launcher
+    and driver, all four ranks on this one GPU over gloo (RCCL needs a GPU per rank).  20 Jacobi-PCG iterations of
+    the row-partitioned driver must reproduce the residual of the whole problem solved by the single-GPU loop
+    (`strong_n1`, timed by rank 0 in the same job) to rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo",
+                          "--share-gpu", "--steps", "3", "--warmup", "1", "--pcg-iters", "20", "--no-cpu-baseline",
+                          "--no-clocks"], capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["config"]["n"] == 1 << 30 and d["config"]["nnz"] == 7509901312 and d["config"]["rows_per_gpu"] == 1 << 28
+    assert d["rccl_ranks"] == 4 and d["scaling"] == "strong"
+    one, four = d["strong_n1"]["pcg_check"], d["pcg_check"]
+    assert (one["info"], one["iter"]) == (four["info"], four["iter"]) == (-1, 21)
+    assert abs(one["relres"] - four["relres"]) <= 1e-12 * one["relres"]
