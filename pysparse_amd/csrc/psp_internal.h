@@ -46,7 +46,8 @@ int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usa
 // workgroup b leaves its partial sums in partials[slot*kMaxParts + b]; the finishing step
 // (a fixed-order fold to 1024 values when there are more, then one workgroup) adds them
 // in index order.  Fixed grid + fixed order => bitwise reproducible results, no atomics.
-constexpr int kMaxParts = 1 << 18;
+constexpr int kMaxParts = 1 << 21;  // one span per workgroup up to n = 2^30 (64 MB of partial-sum slots); round 1: 2^18,
+                                    // i.e. looping grids -- 10-20 % slower vector kernels -- from 2^27 + 1 elements on
 constexpr int kSlots = 4;
 constexpr int kFold = 1024;
 // streaming vector kernels: one workgroup per contiguous span of kVecSpan elements
