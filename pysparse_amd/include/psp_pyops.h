@@ -22,10 +22,16 @@ typedef struct {
   int is_precon;
 } PyOpRef;
 
+/* Called by libpysparse_hip.so from inside a solve.  The extension modules ALWAYS release the GIL before they
+ * enter the library (its compute entry points take a library-wide lock, and nobody may wait for that lock while
+ * holding the GIL: a callback of the lock's holder would never get it), so the callback takes the GIL itself. */
 static int pyop_trampoline(void *ctx, int n, const double *x, double *y) {
   PyOpRef *r = (PyOpRef *)ctx;
-  if (r->is_precon) return SpMatrix_Precon(r->obj, n, (double *)x, y);
-  return SpMatrix_Matvec(r->obj, n, (double *)x, n, y);
+  PyGILState_STATE g = PyGILState_Ensure();
+  int rc = r->is_precon ? SpMatrix_Precon(r->obj, n, (double *)x, y)
+                        : SpMatrix_Matvec(r->obj, n, (double *)x, n, y);
+  PyGILState_Release(g);
+  return rc;
 }
 
 /* returns 0 and fills *r, or -1 with a Python exception set.  *n_out = operator order. */

@@ -77,15 +77,11 @@ static PyObject *run_solver(PyObject *args, int which, int gmres_dim, int check_
     }
   }
 
-  if (aref.is_callback || (have_k && kref.is_callback)) {
-    rc = dispatch(which, gmres_dim, aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
-                  (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres);
-  } else {
-    Py_BEGIN_ALLOW_THREADS
-    rc = dispatch(which, gmres_dim, aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
-                  (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres);
-    Py_END_ALLOW_THREADS
-  }
+  /* the GIL is released for every solve; callback operators take it back in pyop_trampoline */
+  Py_BEGIN_ALLOW_THREADS
+  rc = dispatch(which, gmres_dim, aref.op, have_k ? kref.op : NULL, n, (double *)PyArray_DATA(x),
+                (const double *)PyArray_DATA(b), tol, maxit, &info, &iter, &relres);
+  Py_END_ALLOW_THREADS
   if (PyErr_Occurred()) goto done; /* a callback raised (itsolversmodule.c:114-115) */
   if (rc != PSP_OK) {
     PyErr_SetString(rc == PSP_ENOMEM ? PyExc_MemoryError

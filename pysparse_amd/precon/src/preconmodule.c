@@ -62,9 +62,13 @@ static PyObject *newJacobiObject(PyObject *matrix, double omega, int steps) {
   op->have_aref = 0;
 
   if (PyObject_TypeCheck(matrix, &CSRMatType)) {
+    Py_BEGIN_ALLOW_THREADS
     rc = psp_jacobi_create_csr(((CSRMatObject *)matrix)->dev, omega, steps, &op->dev);
+    Py_END_ALLOW_THREADS
   } else if (PyObject_TypeCheck(matrix, &SSSMatType)) {
+    Py_BEGIN_ALLOW_THREADS
     rc = psp_jacobi_create_sss(((SSSMatObject *)matrix)->dev, omega, steps, &op->dev);
+    Py_END_ALLOW_THREADS
   } else {
     double *diag = PyMem_New(double, n > 0 ? n : 1);
     int nn;
@@ -91,7 +95,9 @@ static PyObject *newJacobiObject(PyObject *matrix, double omega, int steps) {
       }
       op->have_aref = 1;
     }
+    Py_BEGIN_ALLOW_THREADS
     rc = psp_jacobi_create_diag(n, diag, omega, steps, op->have_aref ? op->aref.op : NULL, &op->dev);
+    Py_END_ALLOW_THREADS
     PyMem_Del(diag);
   }
   if (rc != PSP_OK) {
@@ -118,13 +124,9 @@ static PyObject *Jacobi_precon(JacobiObject *self, PyObject *args) {
   double *x, *y;
   int rc;
   if (SpMatrix_ParseVecOpArgs(args, &x, &y, self->n)) return NULL;
-  if (self->have_aref && self->aref.is_callback) {
-    rc = psp_jacobi_precon(self->dev, x, y); /* sweeps call back into Python: keep the GIL */
-  } else {
-    Py_BEGIN_ALLOW_THREADS
-    rc = psp_jacobi_precon(self->dev, x, y);
-    Py_END_ALLOW_THREADS
-  }
+  Py_BEGIN_ALLOW_THREADS /* sweeps of a callback operator take the GIL back in pyop_trampoline */
+  rc = psp_jacobi_precon(self->dev, x, y);
+  Py_END_ALLOW_THREADS
   if (PyErr_Occurred()) return NULL;
   if (rc != PSP_OK) {
     PyErr_SetString(PyExc_RuntimeError, "unknown error in Jacobi iteration"); /* :74 */

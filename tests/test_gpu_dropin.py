@@ -269,3 +269,49 @@ def test_pysparse_matrix_products_on_gpu(oracle, L100):
     res = pcg(A.getMatrix(), b, xsol, 1e-8, 2 * n, precon.jacobi(A.getMatrix()))
     ref = oracle.pcg(R, b, xo, 1e-8, 2 * n, oracle.jacobi_dinv(R.diagonal()))
     assert res[:2] == ref[:2] and np.abs(xsol - xo).max() <= 1e-12 * np.abs(xo).max()
+
+
+def test_callback_solves_from_two_threads_do_not_deadlock(oracle):
+    """One thread solves through the extension modules with a duck-typed Python operator, another through the
+    ctypes layer with one: both callbacks need the GIL while their solve holds the library's lock.  Every path
+    releases the GIL before it enters the library and the callbacks take it back, so the two interleave (and
+    serialise on the lock) instead of deadlocking; results equal the ones obtained alone."""
+    import threading
+    from pysparse.itsolvers.krylov import pcg as ext_pcg
+    from pysparse.sparse import spmatrix
+    from pysparse_amd import device as dev
+
+    class Duck:
+        def __init__(self, A, n):
+            self.A, self.shape, self.calls = A, (n, n), 0
+
+        def matvec(self, x, y):
+            self.calls += 1
+            self.A.matvec(x, y)
+
+    n1 = 24
+    n = n1 * n1
+    Ae = spmatrix.poisson_csr(n1, n1)
+    Ad = dev.DeviceCSR.poisson(n1, n1)
+    b = np.random.default_rng(4).standard_normal(n)
+
+    def run_ext(out):
+        x = np.zeros(n)
+        out["ext"] = (ext_pcg(Duck(Ae, n), b, x, 1e-10, 500), x)
+
+    def run_ctypes(out):
+        x = np.zeros(n)
+        out["ctypes"] = (dev.pcg(Duck(Ad, n), b, x, 1e-10, 500), x)
+    alone = {}
+    run_ext(alone)
+    run_ctypes(alone)
+    for trial in range(3):
+        got = {}
+        ts = [threading.Thread(target=run_ext, args=(got,)), threading.Thread(target=run_ctypes, args=(got,))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts), "deadlock between callback solves"
+        for k in ("ext", "ctypes"):
+            assert got[k][0] == alone[k][0] and np.array_equal(got[k][1], alone[k][1])
