@@ -3035,10 +3035,6 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
   return PSP_OK;
 }
 
-// the offset-major lower-triangle tables of an sss_mat (w4_val / w4_mask / w4_offs), built on first use;
-// S->w4_state == 1 afterwards when the matrix is offset-structured
-int sss_ensure_w4(psp_sss *S) { return ensure_sss_w4(S); }
-
 bool csr_spmv_has_skip(const psp_csr *A) {
   if (A->nparts) {
     for (int p = 0; p < A->nparts; ++p)

@@ -222,7 +222,6 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
                            int *nparts, int *available, const int *skip = nullptr,
                            const double *xdiv_dev = nullptr);
 int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const int **inv);  // psp_csr.hip
-int sss_ensure_w4(psp_sss *S);  // psp_csr.hip: builds S->w4_val / w4_mask / w4_offs when S is offset-structured
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // xp[i] = x[perm[i]]
 // true when the SpMV kernel selected for A honours the `skip` flag (csr_spmv_w2)
 bool csr_spmv_has_skip(const psp_csr *A);
