@@ -166,6 +166,11 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
  *   chunk-local columns; csr_spmv_w2 / w1 / stream: any CSR.  All add each row's products left
  *   to right (csr_mat.c:49-54), so the choice never changes a bit of y. */
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
+/* The renumbering behind "csr_spmv_w3_rcm" (irregular square operators): perm_host[new] = old row
+ * (nrows ints) and *available = 2 (numbering computed on the device) or 1 (on the host: unsymmetric pattern) when
+ * psp_csr_kernel_info / a product has built one for this handle; *available = 0 otherwise (perm_host untouched).
+ * Diagnostic: no product needs it. */
+int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available);
 /* bytes of device memory held by the handle */
 int64_t psp_csr_device_bytes(const psp_csr_t *A);
 

@@ -23,7 +23,7 @@ psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
-psp_csr_set_schedule psp_csr_kernel_info psp_csr_device_bytes
+psp_csr_set_schedule psp_csr_kernel_info psp_csr_renumbering psp_csr_device_bytes
 psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
 psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
 psp_sss_kernel_info psp_sss_set_variant
@@ -117,6 +117,7 @@ def _declare(L):
         "psp_csr_matvec_dev": [vp, vp, vp], "psp_csr_matvec_transp_dev": [vp, vp, vp],
         "psp_csr_set_variant": [vp, i], "psp_csr_set_schedule": [vp, i],
         "psp_csr_kernel_info": [vp, C.c_char_p, i, pi],
+        "psp_csr_renumbering": [vp, vp, pi],
         "psp_sss_create": [i, i, vp, vp, vp, vp, pvp], "psp_sss_poisson": [i, i, i, pvp],
         "psp_sss_destroy": [vp], "psp_sss_shape": [vp, pi, pi],
         "psp_sss_download": [vp, vp, vp, vp, vp], "psp_sss_getitem": [vp, i, i, pd],

@@ -2037,6 +2037,7 @@ struct CsrExtra {
   int *inv = nullptr;      // old -> new
   double *xp = nullptr;    // x, then y, in the new numbering (scratch, 2 * nrows doubles)
   int orig_max_blocks = 0;
+  bool reorder_on_device = false;  // the numbering was computed by reorder_rcm_device
 };
 
 }  // namespace psp
@@ -2601,20 +2602,10 @@ static int launch_w4_transp(const psp_csr *A, const double *x, double *y, int *a
   return PSP_OK;
 }
 
-// A^T as a CSR handle of its own, cached on A (irregular matrices; w4 matrices use csr_spmv_w4_transp)
-static int ensure_transposed(const psp_csr *A, psp_csr **out) {
-  psp::CsrExtra *ex;
-  {
-    std::lock_guard<std::mutex> lk(g_extra_mu);
-    ex = &g_extra[A];
-    if (ex->transposed) {
-      *out = ex->transposed;
-      return PSP_OK;
-    }
-  }
-  psp_csr *T = nullptr;
-  PSP_TRY(alloc_csr(A->ncols, A->nrows, A->nnz, &T));
-  const int nnz = A->nnz;
+// T (allocated: ncols x nrows, nnz entries) = transpose of the CSR triple (device arrays): stable sort by column, so
+// each row of T keeps its entries in ascending original-row order
+static int transpose_into(int nrows, int ncols, int nnz, const int *ind, const int *col, const double *val,
+                          psp_csr *T) {
   int rc = PSP_OK;
   int *rows = nullptr, *pos = nullptr, *keys = nullptr, *perm = nullptr;
   void *tmp = nullptr;
@@ -2634,20 +2625,20 @@ static int ensure_transposed(const psp_csr *A, psp_csr **out) {
     TR_HIP(hipMalloc((void **)&keys, ib));
     TR_HIP(hipMalloc((void **)&perm, ib));
     const int g = std::min((nnz + 255) / 256, 65536);
-    hipLaunchKernelGGL(rows_of_nonzeros_kernel, dim3(std::min((A->nrows + 3) / 4, 65536)), dim3(256), 0, stream(),
-                       A->nrows, A->ind, rows);
+    hipLaunchKernelGGL(rows_of_nonzeros_kernel, dim3(std::min((nrows + 3) / 4, 65536)), dim3(256), 0, stream(),
+                       nrows, ind, rows);
     hipLaunchKernelGGL(iota_int_kernel, dim3(g), dim3(256), 0, stream(), nnz, pos);
     int bits = 1;
-    while (bits < 31 && (1L << bits) < A->ncols) ++bits;
+    while (bits < 31 && (1L << bits) < ncols) ++bits;
     size_t bytes = 0;
-    TR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, A->col, keys, pos, perm, nnz, 0, bits, stream()));
+    TR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, col, keys, pos, perm, nnz, 0, bits, stream()));
     TR_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
-    TR_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, A->col, keys, pos, perm, nnz, 0, bits, stream()));  // stable
-    hipLaunchKernelGGL(transp_gather_kernel, dim3(g), dim3(256), 0, stream(), nnz, perm, rows, A->val, T->col, T->val);
-    hipLaunchKernelGGL(transp_ptr_kernel, dim3(g), dim3(256), 0, stream(), nnz, A->ncols, keys, T->ind);
+    TR_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, col, keys, pos, perm, nnz, 0, bits, stream()));  // stable
+    hipLaunchKernelGGL(transp_gather_kernel, dim3(g), dim3(256), 0, stream(), nnz, perm, rows, val, T->col, T->val);
+    hipLaunchKernelGGL(transp_ptr_kernel, dim3(g), dim3(256), 0, stream(), nnz, ncols, keys, T->ind);
     TR_HIP(hipGetLastError());
   } else {
-    TR_HIP(hipMemsetAsync(T->ind, 0, sizeof(int) * ((size_t)A->ncols + 1), stream()));
+    TR_HIP(hipMemsetAsync(T->ind, 0, sizeof(int) * ((size_t)ncols + 1), stream()));
   }
   TR_HIP(hipStreamSynchronize(stream()));
   rc = finalize_csr(T);
@@ -2658,6 +2649,22 @@ done:
   (void)hipFree(keys);
   (void)hipFree(perm);
   (void)hipFree(tmp);
+  return rc;
+}
+
+// A^T as a CSR handle of its own, cached on A (irregular matrices; w4 matrices use csr_spmv_w4_transp)
+static int ensure_transposed(const psp_csr *A, psp_csr **out) {
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    psp::CsrExtra *ex = &g_extra[A];
+    if (ex->transposed) {
+      *out = ex->transposed;
+      return PSP_OK;
+    }
+  }
+  psp_csr *T = nullptr;
+  PSP_TRY(alloc_csr(A->ncols, A->nrows, A->nnz, &T));
+  const int rc = transpose_into(A->nrows, A->ncols, A->nnz, A->ind, A->col, A->val, T);
   if (rc != PSP_OK) {
     psp_csr_destroy(T);
     return rc;
@@ -2674,6 +2681,9 @@ done:
 namespace psp {
 int reorder_rcm_host(int n, const int *ind, const int *col, const double *val, std::vector<int> &perm,
                      std::vector<int> &rind, std::vector<int> &rcol, std::vector<double> &rval);
+int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, int **inv_dev, int *status);
+int reorder_build_device(int n, const int *ind, const int *col, const double *val, const int *perm_dev,
+                         const int *inv_dev, int *rind, int *rcol, double *rval);
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);
 int reorder_back(int n, const int *inv_dev, const double *yp, double *y, const double *dotv, double *partials,
                  int *nparts, const int *skip);
@@ -2702,29 +2712,46 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     return PSP_OK;
   const int n = A->nrows;
   const size_t nnz = (size_t)A->nnz;
-  std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
-  std::vector<double> val(nnz), rval;
-  PSP_HIP(hipMemcpy(ind.data(), A->ind, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
-  PSP_HIP(hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
-  PSP_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-  PSP_TRY(psp::reorder_rcm_host(n, ind.data(), col.data(), val.data(), perm, rind, rcol, rval));
+  // the numbering: on the device when the pattern is structurally symmetric with ascending rows (tens of
+  // milliseconds at n = 1e6), else on the host from a copy of the arrays (a second or more; also what
+  // PSP_SPMV_REORDER_HOST=1 forces -- the two give the same permutation, tests/test_gpu_spmv.py)
+  static const bool host_forced = [] {
+    const char *e = getenv("PSP_SPMV_REORDER_HOST");
+    return e && atoi(e) != 0;
+  }();
+  int *dperm = nullptr, *dinv = nullptr;
+  int on_device = 0;
+  if (!host_forced) PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
   psp_csr *R = nullptr;
   int rc = alloc_csr(n, n, (long)nnz, &R);
-  if (rc != PSP_OK) return PSP_OK;  // no room: stay with the gather kernels
+  if (rc != PSP_OK) {  // no room: stay with the gather kernels
+    if (dperm) (void)hipFree(dperm);
+    if (dinv) (void)hipFree(dinv);
+    return PSP_OK;
+  }
   R->no_reorder = true;
-  int *dperm = nullptr, *dinv = nullptr;
   double *xp = nullptr;
-  std::vector<int> inv((size_t)n);
-  for (int i = 0; i < n; ++i) inv[perm[i]] = i;
-  bool ok = hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
-            hipMalloc((void **)&dperm, sizeof(int) * (size_t)n) == hipSuccess &&
-            hipMalloc((void **)&dinv, sizeof(int) * (size_t)n) == hipSuccess &&
-            hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n) == hipSuccess &&
-            hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(dinv, inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-            finalize_csr(R) == PSP_OK;
+  bool ok;
+  if (on_device) {
+    ok = psp::reorder_build_device(n, A->ind, A->col, A->val, dperm, dinv, R->ind, R->col, R->val) == PSP_OK;
+  } else {
+    std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
+    std::vector<double> val(nnz), rval;
+    PSP_HIP(hipMemcpy(ind.data(), A->ind, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+    PSP_HIP(hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+    PSP_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+    PSP_TRY(psp::reorder_rcm_host(n, ind.data(), col.data(), val.data(), perm, rind, rcol, rval));
+    std::vector<int> inv((size_t)n);
+    for (int i = 0; i < n; ++i) inv[perm[i]] = i;
+    ok = hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMalloc((void **)&dperm, sizeof(int) * (size_t)n) == hipSuccess &&
+         hipMalloc((void **)&dinv, sizeof(int) * (size_t)n) == hipSuccess &&
+         hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dinv, inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  ok = ok && hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n) == hipSuccess && finalize_csr(R) == PSP_OK;
   ChunkTable *t = nullptr;
   if (ok) ok = get_chunk_table(R, 1024, &t) == PSP_OK && ensure_rowoff(R, t) == PSP_OK && t->np != 0 &&
                ensure_w3(R, t) == PSP_OK && t->nb > 0;
@@ -2741,6 +2768,7 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
   ex->perm = dperm;
   ex->inv = dinv;
   ex->xp = xp;
+  ex->reorder_on_device = on_device != 0;
   ex->reorder_state = 1;
   return PSP_OK;
 }
@@ -4040,6 +4068,26 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
   return PSP_OK;
 }
 
+int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
+  PSP_API_GUARD;
+  if (!A || !perm_host || !available) return fail(PSP_EINVAL, "psp_csr_renumbering: NULL argument");
+  *available = 0;
+  const int *dperm = nullptr;
+  bool on_device = false;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    auto it = g_extra.find(A);
+    if (it != g_extra.end() && it->second.reorder_state == 1) {
+      dperm = it->second.perm;
+      on_device = it->second.reorder_on_device;
+    }
+  }
+  if (!dperm) return PSP_OK;
+  PSP_HIP(hipMemcpy(perm_host, dperm, sizeof(int) * (size_t)A->nrows, hipMemcpyDeviceToHost));
+  *available = on_device ? 2 : 1;
+  return PSP_OK;
+}
+
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   PSP_API_GUARD;
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
@@ -4140,6 +4188,37 @@ int64_t psp_csr_device_bytes(const psp_csr_t *A) {
 
 // ------------------------------------------------------------------ C ABI: sss
 
+// rows of the full mirror of an sss_mat: lower entries, the diagonal, the transposed lower triangle's row
+__global__ __launch_bounds__(256) void sss_full_len_kernel(int n, const int *__restrict__ lind,
+                                                           const int *__restrict__ tind, int *__restrict__ flen) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flen[i] = (lind[i + 1] - lind[i]) + 1 + (tind[i + 1] - tind[i]);
+  else if (i == n) flen[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void sss_full_fill_kernel(
+    int n, const int *__restrict__ lind, const int *__restrict__ lcol, const double *__restrict__ lval,
+    const double *__restrict__ diag, const int *__restrict__ tind, const int *__restrict__ tcol,
+    const double *__restrict__ tval, const int *__restrict__ find, int *__restrict__ fcol,
+    double *__restrict__ fval) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+  if (i >= n) return;
+  const int l0 = lind[i], ll = lind[i + 1] - l0, t0 = tind[i], tl = tind[i + 1] - t0, f0 = find[i];
+  for (int k = lane; k < ll; k += 64) {
+    fcol[f0 + k] = lcol[l0 + k];
+    fval[f0 + k] = lval[l0 + k];
+  }
+  if (lane == 0) {
+    fcol[f0 + ll] = (int)i;
+    fval[f0 + ll] = diag[i];
+  }
+  for (int k = lane; k < tl; k += 64) {
+    fcol[f0 + ll + 1 + k] = tcol[t0 + k];
+    fval[f0 + ll + 1 + k] = tval[t0 + k];
+  }
+}
+
 int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_host,
                    const double *val_host, const double *diag_host, psp_sss_t **out) {
   if (!out || !ind_host || !diag_host || (nnz_lower > 0 && (!col_host || !val_host)))
@@ -4159,42 +4238,13 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
     return fail(PSP_EINVAL, "psp_sss_create: expanded matrix exceeds 32-bit indices");
   PSP_TRY(ensure_device());
 
-  // Expand to the full, column-sorted CSR the device multiplies with.  Row i receives its
-  // lower entries (stored order), the diagonal, then the mirrored entries (i, r) for the
-  // rows r > i that reference column i, appended in ascending r -- the summation order of
-  // sss_matvec (sss_mat.c:45-55).
-  std::vector<int> find((size_t)n + 1, 0);
-  for (int i = 0; i < n; ++i) {
-    find[i + 1] += ind_host[i + 1] - ind_host[i] + 1;
-    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) find[col_host[k] + 1] += 1;
-  }
-  for (int i = 0; i < n; ++i) find[i + 1] += find[i];
-  const int fnnz = find[n];
-  std::vector<int> fcol((size_t)fnnz), fill(find.begin(), find.end() - 1);
-  std::vector<double> fval((size_t)fnnz);
-  for (int i = 0; i < n; ++i) {
-    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) {
-      fcol[fill[i]] = col_host[k];
-      fval[fill[i]++] = val_host[k];
-    }
-    fcol[fill[i]] = i;
-    fval[fill[i]++] = diag_host[i];
-  }
-  for (int i = 0; i < n; ++i)
-    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k) {
-      const int j = col_host[k];
-      fcol[fill[j]] = i;
-      fval[fill[j]++] = val_host[k];
-    }
-
+  // Expand to the full, column-sorted CSR the device multiplies with -- on the device.  Row i receives its
+  // lower entries (stored order), the diagonal, then the mirrored entries (i, r) for the rows r > i that
+  // reference column i, in ascending r (= row i of the stably transposed lower triangle) -- the summation
+  // order of sss_matvec (sss_mat.c:45-55).
   psp_sss *S = new psp_sss();
   S->n = n;
   S->nnz_lower = nnz_lower;
-  int rc = psp_csr_create(n, n, fnnz, find.data(), fcol.data(), fval.data(), &S->full);
-  if (rc != PSP_OK) {
-    delete S;
-    return rc;
-  }
   hipError_t e1 = hipMalloc((void **)&S->ind, sizeof(int) * ((size_t)n + 1));
   hipError_t e2 = hipMalloc((void **)&S->col, sizeof(int) * (size_t)(nnz_lower ? nnz_lower : 1));
   hipError_t e3 = hipMalloc((void **)&S->val, sizeof(double) * (size_t)(nnz_lower ? nnz_lower : 1));
@@ -4203,18 +4253,57 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
     psp_sss_destroy(S);
     return fail(PSP_ENOMEM, "psp_sss_create: device allocation failed");
   }
-  PSP_HIP(hipMemcpyAsync(S->ind, ind_host, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice,
-                         stream()));
+  psp_csr *T = nullptr, *F = nullptr;
+  int *flen = nullptr;
+  void *tmp = nullptr;
+  int rc = PSP_OK;
+  auto cleanup = [&](int code) {
+    if (T) psp_csr_destroy(T);
+    if (flen) (void)hipFree(flen);
+    if (tmp) (void)hipFree(tmp);
+    if (code != PSP_OK) {
+      if (F) psp_csr_destroy(F);
+      psp_sss_destroy(S);
+    }
+    return code;
+  };
+#define SSS_HIP(call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return cleanup(fail(e_ == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "%s: %s", #call,        \
+                          hipGetErrorString(e_)));                                                     \
+  } while (0)
+  SSS_HIP(hipMemcpyAsync(S->ind, ind_host, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, stream()));
   if (nnz_lower) {
-    PSP_HIP(hipMemcpyAsync(S->col, col_host, sizeof(int) * (size_t)nnz_lower,
-                           hipMemcpyHostToDevice, stream()));
-    PSP_HIP(hipMemcpyAsync(S->val, val_host, sizeof(double) * (size_t)nnz_lower,
-                           hipMemcpyHostToDevice, stream()));
+    SSS_HIP(hipMemcpyAsync(S->col, col_host, sizeof(int) * (size_t)nnz_lower, hipMemcpyHostToDevice, stream()));
+    SSS_HIP(hipMemcpyAsync(S->val, val_host, sizeof(double) * (size_t)nnz_lower, hipMemcpyHostToDevice, stream()));
   }
-  if (n)
-    PSP_HIP(hipMemcpyAsync(S->diag, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
-                           stream()));
-  PSP_HIP(hipStreamSynchronize(stream()));
+  if (n) SSS_HIP(hipMemcpyAsync(S->diag, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream()));
+  rc = alloc_csr(n, n, nnz_lower, &T);
+  if (rc != PSP_OK) return cleanup(rc);
+  rc = transpose_into(n, n, nnz_lower, S->ind, S->col, S->val, T);
+  if (rc != PSP_OK) return cleanup(rc);
+  rc = alloc_csr(n, n, 2L * nnz_lower + n, &F);
+  if (rc != PSP_OK) return cleanup(rc);
+  {
+    SSS_HIP(hipMalloc((void **)&flen, sizeof(int) * ((size_t)n + 1)));
+    hipLaunchKernelGGL(sss_full_len_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, stream(), n, S->ind, T->ind, flen);
+    size_t bytes = 0;
+    SSS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flen, F->ind, n + 1, stream()));
+    SSS_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
+    SSS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, flen, F->ind, n + 1, stream()));
+    if (n > 0)
+      hipLaunchKernelGGL(sss_full_fill_kernel, dim3((n + 3) / 4), dim3(256), 0, stream(), n, S->ind, S->col, S->val,
+                         S->diag, T->ind, T->col, T->val, F->ind, F->col, F->val);
+    SSS_HIP(hipGetLastError());
+    SSS_HIP(hipStreamSynchronize(stream()));
+  }
+#undef SSS_HIP
+  rc = finalize_csr(F);
+  if (rc != PSP_OK) return cleanup(rc);
+  S->full = F;
+  (void)cleanup(PSP_OK);
   S->full->sym_owner = S;
   *out = S;
   return PSP_OK;

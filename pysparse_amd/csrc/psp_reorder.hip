@@ -5,8 +5,10 @@
 // (FEM meshes as they come out of a mesh generator, shuffled node ids) breaks that: the same matrix
 // references 100-140 blocks per chunk and falls back to csr_spmv_w2, whose x gathers are bound by the
 // per-CU L1 (0.61-0.67 of the HBM roofline, profiles/r1_fem_standin.txt).  This file computes a reverse
-// Cuthill-McKee numbering on the host (once per handle) and builds the symmetrically permuted matrix
-// R = P A P^T as a second device handle:
+// Cuthill-McKee numbering once per handle -- on the device for structurally symmetric patterns (reorder_rcm_device:
+// 48 ms to the first product at n = 9.3e5, 41 M nonzeros), on the host otherwise (reorder_rcm_host: 1.25 s for the
+// same matrix; same rules, same permutation) -- and builds the symmetrically permuted matrix R = P A P^T as a
+// second device handle:
 //     row i of R   = row perm[i] of A, entries in A's stored order (NOT re-sorted: the reference adds a
 //                    row's products left to right, csr_mat.c:49-54, and so must we -- same products,
 //                    same order, same bits in y);
@@ -20,6 +22,8 @@
 #include <algorithm>
 #include <numeric>
 #include <vector>
+
+#include <hipcub/hipcub.hpp>
 
 #include "psp_internal.h"
 
@@ -117,10 +121,10 @@ std::vector<int> rcm_order(const Graph &g, int n) {
     // eccentricity grows
     int root = s;
     int nlev = bfs_levels(g, root, level, queue, last, ++stamp, seen);
-    {  // lowest degree node of this component as the first guess
+    {  // lowest (degree, id) node of this component as the first guess
       int best = root;
       for (int u : queue)
-        if (g.deg[u] < g.deg[best]) best = u;
+        if (g.deg[u] < g.deg[best] || (g.deg[u] == g.deg[best] && u < best)) best = u;
       if (best != root) {
         root = best;
         nlev = bfs_levels(g, root, level, queue, last, ++stamp, seen);
@@ -129,7 +133,7 @@ std::vector<int> rcm_order(const Graph &g, int n) {
     for (int iter = 0; iter < 8; ++iter) {
       int cand = last[0];
       for (int u : last)
-        if (g.deg[u] < g.deg[cand]) cand = u;
+        if (g.deg[u] < g.deg[cand] || (g.deg[u] == g.deg[cand] && u < cand)) cand = u;
       std::vector<int> q2, last2;
       const int nlev2 = bfs_levels(g, cand, level, q2, last2, ++stamp, seen);
       if (nlev2 <= nlev) break;
@@ -225,9 +229,378 @@ __global__ __launch_bounds__(256) void permute_back_kernel(int n, const int *__r
   }
 }
 
+
+// ---- the same numbering computed on the device (structurally symmetric patterns with ascending rows: the full
+// mirror of an sss_mat, a symmetric ll_mat's to_csr()).  Level-synchronous Cuthill-McKee: the nodes discovered from
+// level l are sorted by (position of their first parent in the order, degree, id) -- exactly the order in which
+// the host loop above appends them -- so both produce the SAME permutation (tests/test_gpu_spmv.py compares them).
+// Every choice is an order-independent minimum or a stable sort of an id-ordered list: no atomics decide an order.
+
+constexpr int kRcmInf = 0x7f7f7f7f;         // "no parent yet": what hipMemset(0x7f) writes
+constexpr int kRcmMaxLevels = 16384;     // levels walked per handle before the device path gives up
+constexpr int kRcmMaxComponents = 256;   // connected components likewise
+constexpr int kRcmBatch = 32;            // BFS levels enqueued between two looks at the result
+
+// deg[i] = entries of row i off the diagonal; *ok = 0 when a row is not strictly ascending or an entry has no
+// mirror; *maxdeg = largest degree
+__global__ __launch_bounds__(256) void rcm_deg_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
+                                                      int *__restrict__ deg, int *__restrict__ ok,
+                                                      int *__restrict__ maxdeg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int d = 0;
+  bool good = true;
+  int prev = -1;
+  for (int k = ind[i]; k < ind[i + 1]; ++k) {
+    const int j = col[k];
+    if (j <= prev || j >= n) {
+      good = false;
+      break;
+    }
+    prev = j;
+    if (j == i) continue;
+    ++d;
+    int lo = ind[j], hi = ind[j + 1];  // is (j, i) stored?
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (col[mid] < i) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo >= ind[j + 1] || col[lo] != i) good = false;
+  }
+  deg[i] = d;
+  if (!good) *ok = 0;
+  atomicMax(maxdeg, d);
+}
+
+// level[v] = -2 (placed in an earlier component) or -1 (not reached yet)
+__global__ __launch_bounds__(256) void rcm_reset_kernel(int n, const int *__restrict__ pos, int *__restrict__ level) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < n) level[v] = pos[v] >= 0 ? -2 : -1;
+}
+
+// one breadth-first level: the nodes of level `cur` give their unreached neighbours level cur + 1
+__global__ __launch_bounds__(256) void rcm_bfs_level_kernel(int n, const int *__restrict__ ind,
+                                                            const int *__restrict__ col, int *level, int cur,
+                                                            int *__restrict__ found) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n || level[u] != cur) return;
+  bool any = false;
+  for (int k = ind[u]; k < ind[u + 1]; ++k) {
+    const int v = col[k];
+    if (level[v] == -1) {
+      level[v] = cur + 1;  // every writer stores the same value
+      any = true;
+    }
+  }
+  if (any) found[cur + 1] = 1;
+}
+
+// smallest (key[v], v) over the nodes with level[v] == want, or level[v] >= 0 when want == -3; key may be null
+// (then the smallest v)
+__global__ __launch_bounds__(256) void rcm_argmin_kernel(int n, const int *__restrict__ level, int want,
+                                                         const int *__restrict__ key,
+                                                         unsigned long long *__restrict__ out) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long best = ~0ull;
+  if (v < n) {
+    const int l = level[v];
+    const bool in = want == -3 ? l >= 0 : l == want;
+    if (in) best = ((unsigned long long)(unsigned)(key ? key[v] : 0) << 32) | (unsigned)v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(best, off, 64);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);
+}
+
+// Cuthill-McKee, one level: positions [lo, hi) of `order` offer themselves as parent to their unplaced neighbours
+__global__ __launch_bounds__(256) void rcm_expand_kernel(int lo, int hi, const int *__restrict__ order,
+                                                         const int *__restrict__ ind, const int *__restrict__ col,
+                                                         const int *__restrict__ pos, int *parent) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int p = lo + (t >> 3), sub = t & 7;
+  if (p >= hi) return;
+  const int u = order[p];
+  for (int k = ind[u] + sub; k < ind[u + 1]; k += 8) {
+    const int v = col[k];
+    if (pos[v] < 0) atomicMin(parent + v, p);
+  }
+}
+
+struct RcmDiscovered {
+  const int *pos, *parent;
+  __device__ bool operator()(int v) const { return pos[v] < 0 && parent[v] != kRcmInf; }
+};
+
+__global__ __launch_bounds__(256) void rcm_keys_kernel(int m, const int *__restrict__ cand,
+                                                       const int *__restrict__ parent, const int *__restrict__ deg,
+                                                       int degbits, unsigned long long *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) {
+    const int v = cand[i];
+    keys[i] = ((unsigned long long)(unsigned)parent[v] << degbits) | (unsigned)deg[v];
+  }
+}
+
+__global__ __launch_bounds__(256) void rcm_assign_kernel(int m, int hi, const int *__restrict__ sorted,
+                                                         int *__restrict__ pos, int *__restrict__ order) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) {
+    const int v = sorted[i];
+    pos[v] = hi + i;
+    order[hi + i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rcm_place_root_kernel(int root, int at, int *pos, int *order) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    pos[root] = at;
+    order[at] = root;
+  }
+}
+
+// perm[i] = order[n - 1 - i] (the "reverse" of reverse Cuthill-McKee), inv = its inverse
+__global__ __launch_bounds__(256) void rcm_finish_kernel(int n, const int *__restrict__ order, int *__restrict__ perm,
+                                                         int *__restrict__ inv) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int o = order[n - 1 - i];
+    perm[i] = o;
+    inv[o] = i;
+  }
+}
+
+// ---- R = P A P^T on the device: row i of R = row perm[i] of A in its stored order, columns through inv
+__global__ __launch_bounds__(256) void rcm_rowlen_kernel(int n, const int *__restrict__ ind,
+                                                         const int *__restrict__ perm, int *__restrict__ rlen) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int o = perm[i];
+    rlen[i] = ind[o + 1] - ind[o];
+  } else if (i == n) {
+    rlen[i] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void rcm_copy_rows_kernel(int n, const int *__restrict__ ind,
+                                                            const int *__restrict__ col,
+                                                            const double *__restrict__ val,
+                                                            const int *__restrict__ perm, const int *__restrict__ inv,
+                                                            const int *__restrict__ rind, int *__restrict__ rcol,
+                                                            double *__restrict__ rval) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+  if (i >= n) return;
+  const int o = perm[i];
+  const int src = ind[o], len = ind[o + 1] - src, dst = rind[i];
+  for (int k = lane; k < len; k += 64) {
+    rcol[dst + k] = inv[col[src + k]];
+    rval[dst + k] = val[src + k];
+  }
+}
+
+struct DevBuf {  // frees on scope exit
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T>
+  T *as() const {
+    return static_cast<T *>(p);
+  }
+};
+
 }  // namespace
 
 namespace psp {
+
+// The numbering on the device.  *status: 1 = perm_dev / inv_dev hold it (n ints each, hipMalloc'ed, the caller
+// frees); 0 = not done -- the pattern is not structurally symmetric with ascending rows, or the graph has more
+// levels / components than the device loop is willing to walk (one host look per level): the caller takes the
+// host path above.
+int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, int **inv_dev, int *status) {
+  *status = 0;
+  *perm_dev = *inv_dev = nullptr;
+  if (n <= 0) return PSP_OK;
+  hipStream_t st = stream();
+  const int g = (n + 255) / 256;
+  DevBuf b_deg, b_level, b_pos, b_order, b_parent, b_cand, b_sorted, b_keys, b_keys2, b_found, b_small, b_tmp;
+  PSP_HIP(b_deg.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_level.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_pos.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_order.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_parent.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_cand.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_sorted.alloc(sizeof(int) * (size_t)n));
+  PSP_HIP(b_keys.alloc(sizeof(unsigned long long) * (size_t)n));
+  PSP_HIP(b_keys2.alloc(sizeof(unsigned long long) * (size_t)n));
+  PSP_HIP(b_found.alloc(sizeof(int) * (size_t)(kRcmMaxLevels + 2 * kRcmBatch + 2)));
+  PSP_HIP(b_small.alloc(64));
+  int *deg = b_deg.as<int>(), *level = b_level.as<int>(), *pos = b_pos.as<int>(), *order = b_order.as<int>();
+  int *parent = b_parent.as<int>(), *cand = b_cand.as<int>(), *sorted = b_sorted.as<int>();
+  unsigned long long *keys = b_keys.as<unsigned long long>(), *keys2 = b_keys2.as<unsigned long long>();
+  int *found = b_found.as<int>();
+  int *d_ok = b_small.as<int>(), *d_maxdeg = d_ok + 1, *d_count = d_ok + 2;
+  unsigned long long *d_min = reinterpret_cast<unsigned long long *>(d_ok + 4);
+
+  // degrees + the symmetry / ordering check
+  {
+    const int init[2] = {1, 0};
+    PSP_HIP(hipMemcpyAsync(d_ok, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rcm_deg_kernel, dim3(g), dim3(256), 0, st, n, ind, col, deg, d_ok, d_maxdeg);
+    PSP_LAUNCH_CHECK();
+    int res[2];
+    PSP_HIP(hipMemcpyAsync(res, d_ok, sizeof(res), hipMemcpyDeviceToHost, st));
+    PSP_HIP(hipStreamSynchronize(st));
+    if (!res[0]) return PSP_OK;
+    int degbits = 1, posbits = 1;
+    while ((1L << degbits) <= res[1]) ++degbits;
+    while ((1L << posbits) < n) ++posbits;
+    if (degbits + posbits > 62) return PSP_OK;
+    // scratch of the two hipcub primitives, sized for n items once
+    size_t bytes_sel = 0, bytes_sort = 0;
+    RcmDiscovered pred{pos, parent};
+    hipcub::CountingInputIterator<int> ids(0);
+    PSP_HIP(hipcub::DeviceSelect::If(nullptr, bytes_sel, ids, cand, d_count, n, pred, st));
+    PSP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes_sort, keys, keys2, cand, sorted, n, 0,
+                                               degbits + posbits, st));
+    const size_t bytes_tmp = std::max(bytes_sel, bytes_sort);
+    PSP_HIP(b_tmp.alloc(bytes_tmp));
+
+    PSP_HIP(hipMemsetAsync(pos, 0xff, sizeof(int) * (size_t)n, st));      // -1: not placed
+    PSP_HIP(hipMemsetAsync(parent, 0x7f, sizeof(int) * (size_t)n, st));   // kRcmInf: no parent yet
+    pred = RcmDiscovered{pos, parent};
+
+    int levels_walked = 0;
+    // breadth-first level structure from `root` inside the unplaced part; returns the number of levels (0 = gave up)
+    auto bfs = [&](int root, int *nlev) -> int {
+      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, level);
+      PSP_HIP(hipMemsetAsync(level + root, 0, sizeof(int), st));
+      PSP_HIP(hipMemsetAsync(found, 0, sizeof(int) * (size_t)(kRcmMaxLevels + 2 * kRcmBatch + 2), st));
+      int cur = 0;
+      int flags[kRcmBatch];
+      for (;;) {
+        if (cur + kRcmBatch > kRcmMaxLevels || levels_walked > 4 * kRcmMaxLevels) {
+          *nlev = 0;
+          return PSP_OK;
+        }
+        for (int b = 0; b < kRcmBatch; ++b)
+          hipLaunchKernelGGL(rcm_bfs_level_kernel, dim3(g), dim3(256), 0, st, n, ind, col, level, cur + b, found);
+        PSP_LAUNCH_CHECK();
+        PSP_HIP(hipMemcpyAsync(flags, found + cur + 1, sizeof(flags), hipMemcpyDeviceToHost, st));
+        PSP_HIP(hipStreamSynchronize(st));
+        int b = 0;
+        while (b < kRcmBatch && flags[b]) ++b;
+        levels_walked += b + 1;
+        if (b < kRcmBatch) {  // level cur + b + 1 is empty: levels 0 .. cur + b exist
+          *nlev = cur + b + 1;
+          return PSP_OK;
+        }
+        cur += kRcmBatch;
+      }
+    };
+    auto argmin = [&](int want, const int *key, int *node) -> int {
+      PSP_HIP(hipMemsetAsync(d_min, 0xff, sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(rcm_argmin_kernel, dim3(g), dim3(256), 0, st, n, level, want, key, d_min);
+      PSP_LAUNCH_CHECK();
+      unsigned long long r;
+      PSP_HIP(hipMemcpyAsync(&r, d_min, sizeof(r), hipMemcpyDeviceToHost, st));
+      PSP_HIP(hipStreamSynchronize(st));
+      *node = r == ~0ull ? -1 : (int)(unsigned)(r & 0xffffffffull);
+      return PSP_OK;
+    };
+
+    int placed = 0, comps = 0;
+    while (placed < n) {
+      if (++comps > kRcmMaxComponents) return PSP_OK;
+      // lowest-numbered node not placed yet
+      int s = -1;
+      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, level);
+      PSP_TRY(argmin(-1, nullptr, &s));
+      if (s < 0) return fail(PSP_EINVAL, "reorder: no unplaced node left at %d of %d", placed, n);
+      // pseudo-peripheral root (George & Liu), as rcm_order above
+      int root = s, nlev = 0;
+      PSP_TRY(bfs(root, &nlev));
+      if (!nlev) return PSP_OK;
+      int best = -1;
+      PSP_TRY(argmin(-3, deg, &best));
+      if (best != root) {
+        root = best;
+        PSP_TRY(bfs(root, &nlev));
+        if (!nlev) return PSP_OK;
+      }
+      for (int iter = 0; iter < 8; ++iter) {
+        int c = -1, nlev2 = 0;
+        PSP_TRY(argmin(nlev - 1, deg, &c));
+        PSP_TRY(bfs(c, &nlev2));
+        if (!nlev2) return PSP_OK;
+        if (nlev2 <= nlev) break;
+        root = c;
+        nlev = nlev2;
+      }
+      // Cuthill-McKee from root, level by level
+      hipLaunchKernelGGL(rcm_place_root_kernel, dim3(1), dim3(64), 0, st, root, placed, pos, order);
+      int lo = placed, hi = placed + 1;
+      for (;;) {
+        if (++levels_walked > 5 * kRcmMaxLevels) return PSP_OK;
+        const int nf = hi - lo;
+        hipLaunchKernelGGL(rcm_expand_kernel, dim3((int)(((long)nf * 8 + 255) / 256)), dim3(256), 0, st, lo, hi, order,
+                           ind, col, pos, parent);
+        size_t tb = bytes_tmp;
+        PSP_HIP(hipcub::DeviceSelect::If(b_tmp.p, tb, ids, cand, d_count, n, pred, st));
+        int m = 0;
+        PSP_HIP(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        PSP_HIP(hipStreamSynchronize(st));
+        if (m == 0) break;
+        const int gm = (m + 255) / 256;
+        hipLaunchKernelGGL(rcm_keys_kernel, dim3(gm), dim3(256), 0, st, m, cand, parent, deg, degbits, keys);
+        tb = bytes_tmp;
+        PSP_HIP(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tb, keys, keys2, cand, sorted, m, 0, degbits + posbits, st));
+        hipLaunchKernelGGL(rcm_assign_kernel, dim3(gm), dim3(256), 0, st, m, hi, sorted, pos, order);
+        PSP_LAUNCH_CHECK();
+        lo = hi;
+        hi += m;
+      }
+      placed = hi;
+    }
+  }
+  int *perm = nullptr, *inv = nullptr;
+  if (hipMalloc((void **)&perm, sizeof(int) * (size_t)n) != hipSuccess ||
+      hipMalloc((void **)&inv, sizeof(int) * (size_t)n) != hipSuccess) {
+    if (perm) (void)hipFree(perm);
+    (void)hipGetLastError();
+    return PSP_OK;
+  }
+  hipLaunchKernelGGL(rcm_finish_kernel, dim3(g), dim3(256), 0, st, n, order, perm, inv);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(st));
+  *perm_dev = perm;
+  *inv_dev = inv;
+  *status = 1;
+  return PSP_OK;
+}
+
+// R = P A P^T from device arrays into device arrays (rind: n + 1, rcol / rval: nnz entries)
+int reorder_build_device(int n, const int *ind, const int *col, const double *val, const int *perm_dev,
+                         const int *inv_dev, int *rind, int *rcol, double *rval) {
+  hipStream_t st = stream();
+  DevBuf b_len, b_tmp;
+  PSP_HIP(b_len.alloc(sizeof(int) * ((size_t)n + 1)));
+  hipLaunchKernelGGL(rcm_rowlen_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, st, n, ind, perm_dev, b_len.as<int>());
+  size_t bytes = 0;
+  PSP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, b_len.as<int>(), rind, n + 1, st));
+  PSP_HIP(b_tmp.alloc(bytes));
+  PSP_HIP(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, bytes, b_len.as<int>(), rind, n + 1, st));
+  hipLaunchKernelGGL(rcm_copy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, ind, col, val, perm_dev, inv_dev,
+                     rind, rcol, rval);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(st));
+  return PSP_OK;
+}
 
 // y[j] = yp[inv[j]] (+ partial sums of dotv . y, one per workgroup of 1024 rows: *nparts of them)
 int reorder_back(int n, const int *inv_dev, const double *yp, double *y, const double *dotv, double *partials,

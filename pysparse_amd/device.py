@@ -189,6 +189,14 @@ class DeviceCSR:
         return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
                                      "half_band": info[3]}
 
+    def renumbering(self):
+        """perm[new] = old row of the renumbered copy behind csr_spmv_w3_rcm, or None when the handle has none."""
+        perm = np.empty(self.shape[0], dtype=np.int32)
+        have = C.c_int()
+        check(lib().psp_csr_renumbering(self._h, perm.ctypes.data, C.byref(have)))
+        self.renumbered_on = {0: None, 1: "host", 2: "device"}[have.value]
+        return perm if have.value else None
+
     @property
     def device_bytes(self):
         return lib().psp_csr_device_bytes(self._h)

@@ -2,6 +2,8 @@
 
 Bar: indptr/indices/values bit-exact; y bit-exact (the kernel adds each row's rounded
 products left to right exactly like csr_mat.c:49-54 / sss_mat.c:45-55)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -542,6 +544,34 @@ def test_csr_matvec_scattered_numbering_bit_exact(oracle, shuffle, form):
     assert A.kernel_info()[0] == "csr_spmv_w2"
     A.matvec(x, y)
     assert np.array_equal(y, ya)
+
+
+@pytest.mark.parametrize("name", ["fem512", "components", "unsymmetric"])
+def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
+    """The reverse Cuthill-McKee numbering is computed on the device for structurally symmetric patterns
+    (psp_reorder.hip: level-synchronous, every tie decided by (degree, id)) and on the host otherwise; the two
+    implement the same rules, so a fresh process with PSP_SPMV_REORDER_HOST=1 must produce the identical
+    permutation -- one component, several components with isolated rows, and an unsymmetric pattern (which the
+    device path declines: both processes then run the host code).  y has the oracle's bits either way."""
+    import subprocess
+    import sys
+    from tests.renumber_helper import case_arrays, renumbering_of
+    kern, perm, y, where = renumbering_of(name)
+    n, ind, col, val = case_arrays(name)
+    assert kern == "csr_spmv_w3_rcm" and perm is not None
+    assert where == ("host" if name == "unsymmetric" else "device")
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    yo = np.empty(n)
+    oracle.CSR((n, n), val, col, ind).matvec(np.random.default_rng(5).standard_normal(n), yo)
+    assert np.array_equal(y, yo)
+    out = str(tmp_path / "host.npz")
+    env = dict(os.environ, PSP_SPMV_REORDER_HOST="1")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "renumber_helper.py"), name, out],
+                   check=True, env=env, timeout=300)
+    h = np.load(out)
+    assert str(h["kern"]) == "csr_spmv_w3_rcm" and str(h["where"]) == "host"
+    assert np.array_equal(h["perm"], perm)
+    assert np.array_equal(h["y"], yo)
 
 
 def test_csr_matvec_w5_ragged_and_empty_rows(oracle):
