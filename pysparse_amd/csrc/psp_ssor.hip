@@ -90,6 +90,79 @@ __global__ void level_pass_kernel(int n, const int *__restrict__ ind, const int 
   }
 }
 
+// ---- the same levels by Kahn's algorithm, one launch per level (O(nnz) work in total instead of one sweep over
+// the whole matrix per relaxation pass).  The pattern is structurally symmetric (F is the mirror of an sss_mat), so
+// the rows that depend on row u are the entries on the OTHER side of the diagonal in row u itself.
+// deps[i] = number of entries row i waits for; the rows with none form level 0
+__global__ __launch_bounds__(256) void kahn_init_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
+                                                        int dir, int *__restrict__ deps, int *__restrict__ level,
+                                                        int *__restrict__ front, int *__restrict__ cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool ready = false;
+  if (i < n) {
+    int d = 0;
+    for (int k = ind[i]; k < ind[i + 1]; ++k) {
+      const int j = col[k];
+      d += (dir == 0 ? j < i : j > i) ? 1 : 0;
+    }
+    deps[i] = d;
+    ready = d == 0;
+    if (ready) level[i] = 0;
+  }
+  // one atomic per wave: the order inside a level does not matter (the rows are sorted by (level, row) afterwards)
+  const unsigned long long m = __ballot(ready);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (ready) front[base + __popcll(m & ((1ull << lane) - 1))] = i;
+}
+
+// level l -> l + 1: every row u of the frontier releases the rows waiting for it; a row whose last dependency
+// this was joins the next frontier with level l + 1.  cnt[0] = size of this frontier, cnt[1] of the next.
+__global__ __launch_bounds__(256) void kahn_level_kernel(const int *__restrict__ ind, const int *__restrict__ col,
+                                                         int dir, int l, const int *__restrict__ front,
+                                                         int *__restrict__ next, int *cnt, int *deps,
+                                                         int *__restrict__ level) {
+  const int nf = cnt[0];
+  const int lane = threadIdx.x & 63;
+  // 8 lanes per frontier row
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; (t >> 3) < (((long)nf + 7) & ~7L); t += (long)gridDim.x * 256) {
+    const long f = t >> 3;
+    const int sub = (int)(t & 7);
+    int k0 = 0, k1 = 0, u = 0;
+    if (f < nf) {
+      u = front[f];
+      k0 = ind[u];
+      k1 = ind[u + 1];
+    }
+    const int span = k1 - k0;
+    int most = span;  // longest row among the 8 rows of this wave: all lanes walk the same number of steps
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(most, off, 64);
+      most = o > most ? o : most;
+    }
+    for (int s = sub; s < most + sub; s += 8) {
+      bool ready = false;
+      int v = 0;
+      if (s < span) {
+        v = col[k0 + s];
+        if (dir == 0 ? v > u : v < u) ready = atomicSub(deps + v, 1) == 1;
+      }
+      if (ready) level[v] = l + 1;
+      const unsigned long long m = __ballot(ready);
+      int base = 0;
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(cnt + 1, __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (ready) next[base + __popcll(m & ((1ull << lane) - 1))] = v;
+      }
+    }
+  }
+}
+
 __global__ void iota_kernel(int n, int *v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
 }
@@ -344,10 +417,57 @@ int build_schedule(const psp_csr *F, int dir, int **rows_out, std::vector<int> *
     SS_HIP(hipMalloc((void **)&level, sizeof(int) * (size_t)n));
     SS_HIP(hipMalloc((void **)&changed, sizeof(int)));
     SS_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, stream()));
-    // in-place relaxation: monotone, converges to the longest-path level; several passes between
-    // host checks (a pass usually propagates many levels because waves start in row order)
+    // Kahn's algorithm, one launch per level, kLevBatch levels between two looks at the counters
+    // (PSP_SSOR_KAHN=0: the relaxation sweeps below, the round-1 method -- same levels)
+    static const bool kahn = [] {
+      const char *e = getenv("PSP_SSOR_KAHN");
+      return e ? atoi(e) != 0 : true;
+    }();
+    bool have_levels = false;
+    if (kahn && n > 0) {
+      constexpr int kLevBatch = 64;
+      const long maxlev = std::min<long>(n, 1L << 22);
+      int *deps = nullptr, *fr[2] = {nullptr, nullptr}, *cnt = nullptr;
+      bool ok = hipMalloc((void **)&deps, sizeof(int) * (size_t)n) == hipSuccess &&
+                hipMalloc((void **)&fr[0], sizeof(int) * (size_t)n) == hipSuccess &&
+                hipMalloc((void **)&fr[1], sizeof(int) * (size_t)n) == hipSuccess &&
+                hipMalloc((void **)&cnt, sizeof(int) * (size_t)(maxlev + kLevBatch + 2)) == hipSuccess &&
+                hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(maxlev + kLevBatch + 2), stream()) == hipSuccess;
+      if (ok) {
+        hipLaunchKernelGGL(kahn_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), n, F->ind, F->col, dir, deps,
+                           level, fr[0], cnt);
+        long l = 0, done_rows = 0;
+        int sizes[kLevBatch];
+        for (;;) {
+          if (l + kLevBatch > maxlev) {
+            ok = false;  // deeper than the counter table: the relaxation below takes over
+            break;
+          }
+          for (int b = 0; b < kLevBatch; ++b)
+            hipLaunchKernelGGL(kahn_level_kernel, dim3(1024), dim3(256), 0, stream(), F->ind, F->col, dir, (int)(l + b),
+                               fr[(l + b) & 1], fr[(l + b + 1) & 1], cnt + l + b, deps, level);
+          if (hipGetLastError() != hipSuccess ||
+              hipMemcpyAsync(sizes, cnt + l, sizeof(sizes), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
+              hipStreamSynchronize(stream()) != hipSuccess) {
+            ok = false;
+            break;
+          }
+          int b = 0;
+          while (b < kLevBatch && sizes[b] > 0) done_rows += sizes[b++];
+          if (b < kLevBatch) break;  // frontier l + b is empty
+          l += kLevBatch;
+        }
+        have_levels = ok && done_rows == n;  // a cycle (not a triangle) or a failure: fall through
+      }
+      (void)hipGetLastError();
+      if (deps) (void)hipFree(deps);
+      if (fr[0]) (void)hipFree(fr[0]);
+      if (fr[1]) (void)hipFree(fr[1]);
+      if (cnt) (void)hipFree(cnt);
+      if (!have_levels) SS_HIP(hipMemsetAsync(level, 0, sizeof(int) * (size_t)n, stream()));
+    }
     int passes = 0;
-    for (;;) {
+    for (; !have_levels;) {
       SS_HIP(hipMemsetAsync(changed, 0, sizeof(int), stream()));
       for (int p = 0; p < 8; ++p)
         hipLaunchKernelGGL(level_pass_kernel, dim3(grid), dim3(256), 0, stream(), n, F->ind, F->col, dir, level,

@@ -16,10 +16,57 @@ from pysparse_amd.tools.standins import fem_sss_arrays  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shuffle", type=int, default=512)
+ap.add_argument("--others", action="store_true", help="also: generated 512^3 csr / sss, 256^3 csr from host arrays, "
+                                                      "the log-spaced stand-in")
 a = ap.parse_args()
 L = lib()
 check(L.psp_set_device(0))
 xw = dev.DeviceBuffer(16)  # context creation outside the timings
+
+
+def first_two(A, n, label, t_create):
+    xb, yb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+    xb.zero()
+    out = {"case": label, "create_s": t_create}
+    for k in ("first_matvec_dev_s", "second_matvec_dev_s"):
+        check(L.psp_synchronize())
+        t = time.perf_counter()
+        A.matvec_dev(xb.ptr, yb.ptr)
+        check(L.psp_synchronize())
+        out[k] = time.perf_counter() - t
+    out["kernel"] = A.kernel_info()[0]
+    xb.free()
+    yb.free()
+    print(json.dumps(out), flush=True)
+
+
+if a.others:
+    from pysparse_amd.tools.standins import logspaced_sss_arrays
+    t = time.perf_counter()
+    A = dev.DeviceCSR.poisson(512, 512, 512)
+    check(L.psp_synchronize())
+    first_two(A, A.shape[0], "csr poisson 512^3 (generated on the device)", time.perf_counter() - t)
+    A.close()
+    t = time.perf_counter()
+    S = dev.DeviceSSS.poisson(512, 512, 512)
+    check(L.psp_synchronize())
+    first_two(S, S.shape[0], "sss poisson 512^3 (generated on the device)", time.perf_counter() - t)
+    S.close()
+    check(L.psp_trim())
+    from oracle import oracle as O  # host arrays of a 256^3 operator (tool only)
+    H = O.poisson_csr(256, 256, 256)
+    t = time.perf_counter()
+    A = dev.DeviceCSR.from_arrays(H.shape, H.ind, H.col, H.val)
+    check(L.psp_synchronize())
+    first_two(A, A.shape[0], "csr 256^3 from host arrays (1.17e8 entries)", time.perf_counter() - t)
+    A.close()
+    del H
+    n, ind, col, val, diag = logspaced_sss_arrays()
+    t = time.perf_counter()
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    check(L.psp_synchronize())
+    first_two(S, n, "sss log-spaced stand-in (n = %d, %d lower entries)" % (n, len(col)), time.perf_counter() - t)
+    S.close()
 n, ind, col, val, diag = fem_sss_arrays(68, 68, 67, a.shuffle, 0)
 res = {"n": n, "nnz_lower": len(col), "shuffle": a.shuffle}
 t = time.perf_counter()
