@@ -605,7 +605,7 @@ def main():
             "config": {
                 "workload": "3D Poisson 7-pt %dx%dx%d fp64 csr_mat (int32 indices), y = A x%s" % (
                     nx, ny, nz, "" if world == 1 else "; z-slab row partition, ghost exchange over %s" % (
-                        "RCCL" if a.backend == "nccl" else a.backend)),
+                        "RCCL" if dist.get_backend() == "nccl" else dist.get_backend())),
                 "n": n_tot, "nnz": nnz_tot, "rows_per_gpu": n_loc,
                 "parallelism": "1 GPU" if world == 1 else "row-range x%d" % world,
                 "scaling_mode": scaling,
