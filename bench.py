@@ -212,6 +212,59 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
     return base, ref
 
 
+def live_traffic(grid, variant):
+    """HBM-side bytes per launch of the SpMV kernel(s) of this operator, measured in THIS job: two child processes
+    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, HBM section: on
+    gfx950 FETCH_SIZE reports half the bytes of a wide streaming read -> doubled; both in KB) run the same operator
+    through tools/prof_spmv.py.  Called BEFORE this process touches the GPU: with a second process holding a context
+    on the device a counter pass takes minutes instead of seconds.  Returns ({kernel name: {...}}, None) or
+    (None, reason): no profiler, a profiler already attached to this process, a time-out -- the caller then falls
+    back to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or \
+            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    tmp = tempfile.mkdtemp(prefix="psp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "prof_spmv.py"), "--reps", "3", "--grid", "%d,%d,%d" % grid,
+                   "--variant", str(variant)]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=90)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (ctr, r.returncode)
+            acc = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "")
+                    if "_spmv_" in name and row.get("Counter_Name") == ctr:
+                        acc.setdefault(name, []).append(float(row["Counter_Value"]))
+            if not acc:
+                return None, "no %s samples of an SpMV kernel" % ctr
+            for name, v in acc.items():
+                vals.setdefault(name, {})[ctr] = sum(v) / len(v)
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for name, v in vals.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[name] = {"bytes": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KB": v["FETCH_SIZE"],
+                         "WRITE_SIZE_KB": v["WRITE_SIZE"], "fetch_correction": 2.0}
+    return (out, None) if out else (None, "counters incomplete")
+
+
 def gpu_clocks():
     """rocm-smi, called while ~1 s of SpMV launches is in flight: which clock / power state the numbers
     of this run come from (runs land in a faster and a slower mode per box)."""
@@ -319,6 +372,9 @@ def main():
     ap.add_argument("--no-kernels", action="store_true", help="skip the w3 / w2 legs on the same operator (N = 1)")
     ap.add_argument("--no-strong-n1", action="store_true", help="skip the one-GPU 1024^3 leg")
     ap.add_argument("--no-clocks", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child runs (N = 1); the committed "
+                         "passes under profiles/ are quoted instead")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -351,14 +407,6 @@ def main():
     use_dist = world > 1 or a.force_dist or scaling != "single"
     if a.test_backend:
         use_dist = True
-    if use_dist or os.environ.get("PSP_IMPORT_TORCH"):
-        # torch first: its bundled HIP runtime must be the one libpysparse_hip.so binds to --
-        # two HIP runtimes in one process do not both see the GPU (INTEGRATION.md)
-        import torch
-        import torch.distributed as dist
-    from pysparse_amd import _capi, device as dev
-    L, check = _capi.lib(), _capi.check
-
     if a.grid:
         nx, ny, nz = (int(t) for t in a.grid.split(","))
     elif scaling == "single":
@@ -368,6 +416,20 @@ def main():
     else:
         nx = ny = 1024
         nz = 128 * world
+
+    # roofline.traffic from the hardware counters of this job's own runs -- child processes, and before this
+    # process creates its GPU context (see live_traffic)
+    pmc_live, pmc_reason = None, None
+    if world == 1 and not use_dist and not a.no_pmc:
+        pmc_live, pmc_reason = live_traffic((nx, ny, nz), a.variant)
+
+    if use_dist or os.environ.get("PSP_IMPORT_TORCH"):
+        # torch first: its bundled HIP runtime must be the one libpysparse_hip.so binds to --
+        # two HIP runtimes in one process do not both see the GPU (INTEGRATION.md)
+        import torch
+        import torch.distributed as dist
+    from pysparse_amd import _capi, device as dev
+    L, check = _capi.lib(), _capi.check
 
     strong_n1 = None
     dry = bool(a.test_backend)
@@ -583,9 +645,21 @@ def main():
         achieved = kbytes_loc / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
         lazy = n_loc >= (1 << 25) or use_dist
         pcg_moved = kbytes_tot + pcg_vector_bytes(n_tot, lazy)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_detail = None, None, None
+        if pmc_live is not None:
+            hits = [v for name, v in pmc_live.items() if kernel in name]
+            if hits:
+                traffic = hits[0]["bytes"]
+                traffic_detail = {k: v for k, v in hits[0].items() if k != "bytes"}
+                traffic_source = ("measured in this job: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of "
+                                  "tools/prof_spmv.py on the same operator (L2<->fabric bytes, Infinity-Cache hits "
+                                  "included; FETCH_SIZE doubled per MI355X_MICROARCH.md)")
+            else:
+                traffic_detail = "no counter samples of " + kernel
+        elif pmc_reason:
+            traffic_detail = pmc_reason
         pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(kernel, ""))
-        if os.path.isfile(pmc) and world == 1 and scaling == "single" and not a.grid:
+        if traffic is None and os.path.isfile(pmc) and world == 1 and scaling == "single" and not a.grid:
             # HBM-side bytes of one launch from the committed rocprofv3 --pmc passes of this kernel on this
             # workload (tools/make_profiles.sh): counters cannot be read in-process, so this is NOT measured
             # in this run -- `traffic_source` says where it comes from
@@ -593,7 +667,9 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get("kernel") == kernel:
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/" + PMC_FILES[kernel] + " (rocprofv3 --pmc, separate run)"
+                    traffic_source = "profiles/" + PMC_FILES[kernel] + " (rocprofv3 --pmc, separate run%s)" % (
+                        "; live measurement not available: %s" % traffic_detail if traffic_detail else "")
+                    traffic_detail = None
             except (OSError, ValueError):
                 traffic = None
         out = {
@@ -623,6 +699,7 @@ def main():
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": traffic_source,
+                "traffic_counters": traffic_detail if isinstance(traffic_detail, dict) else None,
                 "algorithmic_bytes_per_launch": kbytes_loc, "avg_launch_ms": kern_ms,
                 "median_launch_ms": med_ms,
                 "csr_model_bytes_per_launch": csr_model_bytes(n_loc, nnz_loc),

@@ -9,7 +9,7 @@ OUT=gpurun_out/profiles_r2; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 python3 bench.py > $OUT/r2_bench.json 2> $OUT/bench.err
 # the 512^3 legs only: the 1024^3 leg would mix 13 ms launches of the same kernel into its average
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-clocks --no-strong-n1 > $OUT/r2_bench_traced.json 2> $OUT/trace.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-clocks --no-strong-n1 --no-pmc > $OUT/r2_bench_traced.json 2> $OUT/trace.log
 cp $OUT/trace/*/*kernel_stats.csv $OUT/r2_bench_kernel_stats.csv 2>/dev/null
 for kv in "w4:-1" "w3:1065154" "w2:16578"; do
   k=${kv%%:*}; v=${kv##*:}; i=1
