@@ -269,7 +269,8 @@ def gpu_clocks():
     """rocm-smi, called while ~1 s of SpMV launches is in flight: which clock / power state the numbers
     of this run come from (runs land in a faster and a slower mode per box)."""
     try:
-        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--json"],
+        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp",
+                            "--json"],
                            capture_output=True, text=True, timeout=20)
         txt = p.stdout.strip()
         try:
@@ -278,7 +279,7 @@ def gpu_clocks():
             keep = {}
             for k, v in card.items():
                 kl = k.lower()
-                if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+                if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "temperature")):
                     keep[k] = v
             return keep or {"raw": txt[:400]}
         except ValueError:
