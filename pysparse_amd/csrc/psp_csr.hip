@@ -709,8 +709,18 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
     count += __popcll(bal);
   }
   __syncthreads();
-  if (lane == 0) atomicMax(maxblocks, count);
-  if (!write || count > NB) return;
+  if (lane == 0) {
+    atomicMax(maxblocks, count);
+    if (count > 64) atomicAdd(maxblocks + 1, 1);  // chunks that do not fit csr_spmv_w3's 64-block list
+  }
+  if (!write) return;
+  if (count > NB) {
+    // an OUTLIER chunk of a matrix that otherwise qualifies (ensure_w3): no list -- the kernel sees the -1 and
+    // gathers this chunk's x entries from memory through the int32 columns
+    for (int i = lane; i < NB; i += 64) blist[(size_t)chunk * NB + i] = -1;
+    for (int i = lane; i < WT; i += 64) col16[(size_t)chunk * WT + i] = 0;
+    return;
+  }
   for (int i = lane; i < NB; i += 64)
     blist[(size_t)chunk * NB + i] = count ? ulist[i < count ? i : count - 1] : 0;
   for (int i = lane; i < WT; i += 64) {
@@ -738,14 +748,18 @@ typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 // PAIRS: each lane takes 2 consecutive nonzeros per step (8 steps) instead of 4 (4 steps): every
 // value load instruction then covers 1 KB contiguous -- 8 cache lines instead of the 16 that the two
 // half-loads of the 4-wide form touch twice
-template <int NP, int NB, int WPB, bool NTS, bool NTL = false, bool PAIRS = false>
+// OUTL: a few chunks of the matrix reference more than NB blocks (their block list holds -1): those gather x
+// from memory through the int32 columns `colfull`, like csr_spmv_w2 -- same products, same order
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+template <int NP, int NB, int WPB, bool NTS, bool NTL = false, bool PAIRS = false, bool OUTL = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     int chunk0, int nchunks, int stripe, int target, int kmax, int ncols,
     const int2 *__restrict__ tab, const unsigned short *__restrict__ rowoff,
     const unsigned short *__restrict__ col16, const int *__restrict__ blist,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    const int *__restrict__ perm, const int *__restrict__ rowperm) {
+    const int *__restrict__ perm, const int *__restrict__ rowperm, const int *__restrict__ colfull = nullptr) {
   // rowperm (renumbered operators, psp_reorder.hip): row r of this matrix is row rowperm[r] of the
   // caller's: its sum is stored to y[rowperm[r]] and meets dotv[rowperm[r]]
   constexpr int WT = 1024;
@@ -809,33 +823,61 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     }
     const int r0 = tab[chunk].x;
     const int nr = tab[chunk + 1].x - r0;
-    // --- the chunk's x blocks: 8 lanes per 128-byte block, 8 blocks per load instruction
-    d2v xw[XL];
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-      const int src = (j & 7) * 8 + (lane >> 3);
-      const int b = __shfl((NB == 128 && j >= 8) ? blk1 : blk0, src, 64);
-      const long e0 = (long)b * 16 + (lane & 7) * 2;
-      if (e0 + 1 < ncols) {
-        xw[j] = *reinterpret_cast<const d2v *>(x + e0);
-      } else {  // the block that holds the end of x
-        xw[j].x = e0 < ncols ? x[e0] : 0.0;
-        xw[j].y = 0.0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < XL; ++j) *reinterpret_cast<d2v *>(&buf[(j * 64 + lane) * 2]) = xw[j];
-    // LDS operations of one wave execute in order; the fences only pin the compiler
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // --- gathers from LDS, then the products take the window's place
     d2v p0[STEPS], p1[STEPS];
+    bool outlier = false;
+    if constexpr (OUTL) outlier = __builtin_amdgcn_readfirstlane(blk0) < 0;  // wave-uniform: the whole list is -1
+    if (OUTL && outlier) {
+      // --- outlier chunk: x straight from memory through the int32 columns (padding holds valid columns)
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      p0[st].x = v0[st].x * buf[c[st].x];
-      p0[st].y = v0[st].y * buf[c[st].y];
-      p1[st].x = v1[st].x * buf[c[st].z];
-      p1[st].y = v1[st].y * buf[c[st].w];
+      for (int st = 0; st < STEPS; ++st) {
+        if constexpr (PAIRS) {
+          int k0 = kb + (2 * st) * 128 + 2 * lane, k1 = k0 + 128;
+          k0 = (k0 < kmax + 2) ? k0 : kmax + 2;
+          k1 = (k1 < kmax + 2) ? k1 : kmax + 2;
+          const i2v c0 = *reinterpret_cast<const i2v *>(colfull + k0);
+          const i2v c1 = *reinterpret_cast<const i2v *>(colfull + k1);
+          p0[st].x = v0[st].x * x[c0.x];
+          p0[st].y = v0[st].y * x[c0.y];
+          p1[st].x = v1[st].x * x[c1.x];
+          p1[st].y = v1[st].y * x[c1.y];
+        } else {
+          int k = kb + (st * 64 + lane) * 4;
+          k = (k < kmax) ? k : kmax;
+          const i4v cc = *reinterpret_cast<const i4v *>(colfull + k);
+          p0[st].x = v0[st].x * x[cc.x];
+          p0[st].y = v0[st].y * x[cc.y];
+          p1[st].x = v1[st].x * x[cc.z];
+          p1[st].y = v1[st].y * x[cc.w];
+        }
+      }
+    } else {
+      // --- the chunk's x blocks: 8 lanes per 128-byte block, 8 blocks per load instruction
+      d2v xw[XL];
+#pragma unroll
+      for (int j = 0; j < XL; ++j) {
+        const int src = (j & 7) * 8 + (lane >> 3);
+        const int b = __shfl((NB == 128 && j >= 8) ? blk1 : blk0, src, 64);
+        const long e0 = (long)b * 16 + (lane & 7) * 2;
+        if (e0 + 1 < ncols) {
+          xw[j] = *reinterpret_cast<const d2v *>(x + e0);
+        } else {  // the block that holds the end of x
+          xw[j].x = e0 < ncols ? x[e0] : 0.0;
+          xw[j].y = 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < XL; ++j) *reinterpret_cast<d2v *>(&buf[(j * 64 + lane) * 2]) = xw[j];
+      // LDS operations of one wave execute in order; the fences only pin the compiler
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // --- gathers from LDS, then the products take the window's place
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        p0[st].x = v0[st].x * buf[c[st].x];
+        p0[st].y = v0[st].y * buf[c[st].y];
+        p1[st].x = v1[st].x * buf[c[st].z];
+        p1[st].y = v1[st].y * buf[c[st].w];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1994,6 +2036,7 @@ struct ChunkTable {
   // chunk's columns as 16-bit offsets into that list (fixed stride 1024)
   int nb = -1;        // -1: not examined yet, 0: some chunk needs too many blocks
   int max_blocks = 0;
+  int outliers = 0;   // chunks with more than 64 blocks that csr_spmv_w3<OUTL> serves through the int32 columns
   int *blist = nullptr;
   unsigned short *col16 = nullptr;
   // csr_spmv_w5: per chunk its distinct columns (fixed stride nu, a multiple of 64) and the chunk's columns
@@ -2146,21 +2189,32 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   t->nb = 0;
   if (t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
   int *d_max;
-  PSP_HIP(hipMalloc((void **)&d_max, sizeof(int)));
-  PSP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), stream()));
-  // pass 1: most distinct x blocks referenced by one chunk
+  PSP_HIP(hipMalloc((void **)&d_max, 2 * sizeof(int)));
+  PSP_HIP(hipMemsetAsync(d_max, 0, 2 * sizeof(int), stream()));
+  // pass 1: most distinct x blocks referenced by one chunk, and how many chunks need more than 64
   hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
                      0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
   PSP_LAUNCH_CHECK();
-  int mb = 0;
-  PSP_HIP(hipMemcpyAsync(&mb, d_max, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  int st[2] = {0, 0};
+  PSP_HIP(hipMemcpyAsync(st, d_max, sizeof(st), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
+  const int mb = st[0];
   t->max_blocks = mb;
   const int cap = w3_nb_cap();
+  // a matrix that is banded except for a few rows (constraint / boundary rows, a handful of long-range
+  // couplings) keeps the LDS-staged kernel: up to 2 % of the chunks may be outliers (PSP_SPMV_W3_OUTLIERS=0: none)
+  static const bool outl_on = [] {
+    const char *e = getenv("PSP_SPMV_W3_OUTLIERS");
+    return e ? atoi(e) != 0 : true;
+  }();
   int nb = 0;
   if (mb <= 32 && cap >= 32) nb = 32;
   else if (mb <= 64 && cap >= 64) nb = 64;
   else if (mb <= 128 && cap >= 128) nb = 128;
+  else if (outl_on && cap >= 64 && st[1] > 0 && (long)st[1] * 50 <= (long)t->nchunks) {
+    nb = 64;
+    t->outliers = st[1];
+  }
   if (nb == 0) {
     PSP_HIP(hipFree(d_max));
     return PSP_OK;
@@ -2846,6 +2900,14 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
                      stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
                      A->val, x, y, dotv, pbuf, skip, perm, rowperm)
   const int ab = w3_ab(A);
+  if constexpr (NB == 64) {
+    if (t->outliers > 0) {  // one form only: the default stream layout, with the per-chunk fallback compiled in
+      hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, true>), dim3(grid), dim3(256), 0, stream(), c0, c1,
+                         stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
+                         A->val, x, y, dotv, pbuf, skip, perm, rowperm, A->col);
+      return;
+    }
+  }
   if (nts && ab == 1) PSP_W3_AB(true, false);
   else if (nts && ab == 2) PSP_W3_AB(false, true);
   else if (nts && ab == 3) PSP_W3_AB(true, true);

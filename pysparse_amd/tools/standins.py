@@ -8,7 +8,7 @@ import numpy as np
 __all__ = ["fem_sss_arrays", "logspaced_sss_arrays"]
 
 
-def fem_sss_arrays(gx=68, gy=68, gz=67, shuffle=32, seed=0):
+def fem_sss_arrays(gx=68, gy=68, gz=67, shuffle=32, seed=0, wild=0):
     """FEM-like: a gx x gy x gz node grid, 3 unknowns per node, every node coupled to itself, its 6 face and
     8 corner neighbours (45 entries per row of the full matrix, n = 3*gx*gy*gz = 929 424 by default), node
     numbers shuffled inside groups of `shuffle` consecutive nodes to mimic an unstructured numbering.
@@ -41,9 +41,21 @@ def fem_sss_arrays(gx=68, gy=68, gz=67, shuffle=32, seed=0):
                 cols.append(cc)
                 vals.append(-(0.05 + 0.01 * ((rr * 7 + cc * 13) % 10)))
     rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    n = 3 * nn
+    if wild:  # `wild` rows couple to 60 unknowns anywhere below them (constraint rows, long-range couplings)
+        wr = np.random.default_rng(seed + 77).choice(np.arange(n // 2, n), size=wild, replace=False)
+        er = np.repeat(wr, 60)
+        ec = (np.random.default_rng(seed + 78).random(er.size) * er).astype(np.int64)
+        have = set(zip(rows[np.isin(rows, wr)].tolist(), cols[np.isin(rows, wr)].tolist()))
+        keep = np.array([(a, b) not in have for a, b in zip(er.tolist(), ec.tolist())])
+        er, ec = er[keep], ec[keep]
+        key = np.unique(er * n + ec)
+        er, ec = key // n, key % n
+        rows = np.concatenate([rows, er])
+        cols = np.concatenate([cols, ec])
+        vals = np.concatenate([vals, np.full(er.size, -0.001)])
     order = np.lexsort((cols, rows))
     rows, cols, vals = rows[order], cols[order], vals[order]
-    n = 3 * nn
     ind = np.zeros(n + 1, dtype=np.int32)
     np.cumsum(np.bincount(rows, minlength=n), out=ind[1:])
     diag = 10.0 + rng.random(n)

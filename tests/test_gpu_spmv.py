@@ -483,6 +483,7 @@ def test_csr_matvec_transp_w4_exact(oracle, case):
     assert np.array_equal(y, y2, equal_nan=True)  # reproducible
 
 
+W3_VARIANT = (1 << 20) + 16578
 W5_VARIANT = 5259458 + (1 << 27)  # the default kernel selection with the renumbered copy switched off (bit 27)
 
 
@@ -572,6 +573,62 @@ def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
     assert str(h["kern"]) == "csr_spmv_w3_rcm" and str(h["where"]) == "host"
     assert np.array_equal(h["perm"], perm)
     assert np.array_equal(h["y"], yo)
+
+
+def test_csr_matvec_w3_with_outlier_chunks(oracle):
+    """A banded matrix with a handful of rows that couple to columns all over the place (constraint rows, long-range
+    couplings): the chunks holding those rows reference more than 64 x blocks.  Up to 2 % of such chunks keep the
+    LDS-staged csr_spmv_w3 for the rest of the matrix; the outlier chunks gather x through the int32 columns inside
+    the same kernel.  Oracle's bits, also for the fused dot and with non-finite x."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    rng = np.random.default_rng(21)
+    n = 60000
+    rows_c = []
+    wild = set(rng.choice(n, size=12, replace=False).tolist())
+    for r in range(n):
+        if r in wild:
+            c = np.sort(rng.choice(n, size=100, replace=False))
+        else:
+            lo, hi = max(0, r - 150), min(n, r + 151)
+            c = np.sort(rng.choice(np.arange(lo, hi), size=min(30, hi - lo), replace=False))
+        rows_c.append(c)
+    ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum([len(c) for c in rows_c], out=ind[1:])
+    col = np.concatenate(rows_c).astype(np.int32)
+    val = rng.standard_normal(col.size)
+    A = oracle.CSR((n, n), val, col, ind)
+    D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    kern, info = D.kernel_info()
+    assert kern == "csr_spmv_w3" and info["max_blocks"] > 64 and info["nb"] == 64, (kern, info)
+    x = rng.standard_normal(n)
+    y, yo = np.full(n, np.nan), np.empty(n)
+    D.matvec(x, y)
+    A.matvec(x, yo)
+    assert np.array_equal(y, yo)
+    # the other stream layouts of the kernel (variant bits 25-26) take the same per-chunk fallback
+    for ab in (1, 2, 3):
+        D.set_variant(W3_VARIANT + (ab << 25))
+        y[:] = np.nan
+        D.matvec(x, y)
+        assert np.array_equal(y, yo), ab
+    D.set_variant(-1)
+    L = lib()
+    xd, yd, out = dev.DeviceBuffer.from_host(x), dev.DeviceBuffer(n), dev.DeviceBuffer(1)
+    check(L.psp_k_csr_matvec_dot(D._h, xd.ptr, 0, yd.ptr, out.ptr))
+    assert np.array_equal(yd.download(), yo)
+    d = float(out.download()[0])
+    assert abs(d - float(np.dot(x, yo))) <= 1e-12 * max(abs(d), 1.0)
+    x[::97] = np.inf
+    x[5::131] = np.nan
+    D.matvec(x, y)
+    A.matvec(x, yo)
+    assert np.array_equal(y, yo, equal_nan=True)
+    # with the fallback switched off by the A/B hook the same matrix is served by the gather kernels: same bits
+    D.set_variant(16578)
+    assert D.kernel_info()[0] == "csr_spmv_w2"
+    D.matvec(x, y)
+    assert np.array_equal(y, yo, equal_nan=True)
 
 
 def test_csr_matvec_w5_ragged_and_empty_rows(oracle):

@@ -18,9 +18,9 @@ from pysparse_amd._capi import check, lib  # noqa: E402
 from tools.spmv_sweep import time_launches  # noqa: E402
 
 
-def fem_sss(gx, gy, gz, shuffle, seed=0):
+def fem_sss(gx, gy, gz, shuffle, seed=0, wild=0):
     from pysparse_amd.tools.standins import fem_sss_arrays
-    return fem_sss_arrays(gx, gy, gz, shuffle, seed)
+    return fem_sss_arrays(gx, gy, gz, shuffle, seed, wild)
 
 
 def main():
@@ -28,15 +28,17 @@ def main():
     ap.add_argument("--shuffle", type=int, default=32)
     ap.add_argument("--grid", default="68,68,67")
     ap.add_argument("--variants", default="", help="extra kernel variants to time, comma separated")
+    ap.add_argument("--wild", type=int, default=0, help="rows with 60 extra couplings to unknowns anywhere below them")
     a = ap.parse_args()
     gx, gy, gz = (int(t) for t in a.grid.split(","))
     L = lib()
-    n, ind, col, val, diag = fem_sss(gx, gy, gz, a.shuffle)
+    n, ind, col, val, diag = fem_sss(gx, gy, gz, a.shuffle, 0, a.wild)
     nl = len(col)
     S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
     x = dev.DeviceBuffer.from_host(np.random.default_rng(1).standard_normal(n))
     y = dev.DeviceBuffer(n)
-    res = {"n": n, "nnz_lower": nl, "nnz_per_row_full": (2 * nl + n) / n, "shuffle": a.shuffle,
+    res = {"n": n, "nnz_lower": nl, "nnz_per_row_full": (2 * nl + n) / n, "shuffle": a.shuffle, "wild": a.wild,
+           "w3_outliers": os.environ.get("PSP_SPMV_W3_OUTLIERS", "1"),
            "w3_nb_cap": os.environ.get("PSP_SPMV_W3_NB", "64")}
     ref = None
     extra = [("v%s" % v, int(v)) for v in a.variants.split(",") if v]
