@@ -57,3 +57,4 @@ timeout 300 python3 tools/minres_timing.py > $OUT/r2_minres_timing.txt 2>> $OUT/
 timeout 300 python3 tools/bench_configs.py > $OUT/r2_configs.json 2>> $OUT/tools.err
 timeout 600 python3 bench.py --gpus 1 --scaling strong --no-cpu-baseline > $OUT/r2_bench_strong_world1.json 2>> $OUT/tools.err
 ls $OUT | head -60; cat $OUT/r2_bench.json | head -c 1500; echo; head -8 $OUT/r2_bench_kernel_stats.csv | cut -c1-160
+timeout 600 python3 tools/extra_solver_timing.py > $OUT/r2_extra_solvers.txt 2>> $OUT/tools.err
