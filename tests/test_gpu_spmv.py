@@ -575,6 +575,36 @@ def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
     assert np.array_equal(h["y"], yo)
 
 
+@pytest.mark.parametrize("shuffle", [1, 512])
+def test_fem_with_wild_rows_product_and_solvers(oracle, shuffle):
+    """FEM-like stand-in with a few rows that couple to unknowns anywhere: natural ordering -> csr_spmv_w3 with outlier
+    chunks; shuffled -> the renumbered copy qualifies thanks to them (its wild rows stay wild under any numbering).
+    Product: oracle's bits; PCG / MINRES (run in the copy's numbering): the oracle's counts and iterates."""
+    from pysparse_amd import device as dev
+    from pysparse_amd.tools.standins import fem_sss_arrays
+    n, ind, col, val, diag = fem_sss_arrays(20, 18, 16, shuffle, 0, wild=6)
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    So = oracle.SSS(n, val, diag, col, ind)
+    kern, info = S.kernel_info()
+    # (shuffled: at this small size the 360 long-range couplings are shortcuts through the mesh that spoil the
+    # Cuthill-McKee level structure, so the copy may not qualify and csr_spmv_w5 runs; at n = 9.3e5 it does qualify)
+    assert kern == "csr_spmv_w3" if shuffle == 1 else kern in ("csr_spmv_w3_rcm", "csr_spmv_w5"), (kern, info)
+    assert info["max_blocks"] > 64
+    x = np.random.default_rng(8).standard_normal(n)
+    y, yo = np.full(n, np.nan), np.empty(n)
+    S.matvec(x, y)
+    So.matvec(x, yo)
+    assert np.array_equal(y, yo)
+    b = np.empty(n)
+    So.matvec(np.ones(n), b)
+    dinv = oracle.jacobi_dinv(diag)
+    for solver_g, solver_o in ((dev.pcg, oracle.pcg), (dev.minres, oracle.minres)):
+        xo, xg = np.zeros(n), np.zeros(n)
+        ref = solver_o(So, b, xo, 1e-10, 500, dinv)
+        got = solver_g(S, b, xg, 1e-10, 500, dev.DeviceJacobi(S))
+        assert got[:2] == ref[:2] and np.abs(xg - xo).max() <= 1e-12 * np.abs(xo).max()
+
+
 def test_csr_matvec_w3_with_outlier_chunks(oracle):
     """A banded matrix with a handful of rows that couple to columns all over the place (constraint rows, long-range
     couplings): the chunks holding those rows reference more than 64 x blocks.  Up to 2 % of such chunks keep the
