@@ -711,16 +711,20 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
   __syncthreads();
   if (lane == 0) {
     atomicMax(maxblocks, count);
-    if (count > 64) atomicAdd(maxblocks + 1, 1);  // chunks that do not fit csr_spmv_w3's 64-block list
+    if constexpr (SHIFT == 4) {  // (the w5 builder passes a single counter)
+      if (count > 64) atomicAdd(maxblocks + 1, 1);  // chunks that do not fit csr_spmv_w3's 64-block list
+      if (count > 32) atomicAdd(maxblocks + 2, 1);  // ... its 32-block list
+    }
   }
   if (!write) return;
-  if (count > NB) {
+  if (SHIFT == 4 && count > NB) {
     // an OUTLIER chunk of a matrix that otherwise qualifies (ensure_w3): no list -- the kernel sees the -1 and
     // gathers this chunk's x entries from memory through the int32 columns
     for (int i = lane; i < NB; i += 64) blist[(size_t)chunk * NB + i] = -1;
     for (int i = lane; i < WT; i += 64) col16[(size_t)chunk * WT + i] = 0;
     return;
   }
+  if (count > NB) return;
   for (int i = lane; i < NB; i += 64)
     blist[(size_t)chunk * NB + i] = count ? ulist[i < count ? i : count - 1] : 0;
   for (int i = lane; i < WT; i += 64) {
@@ -2189,13 +2193,13 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   t->nb = 0;
   if (t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
   int *d_max;
-  PSP_HIP(hipMalloc((void **)&d_max, 2 * sizeof(int)));
-  PSP_HIP(hipMemsetAsync(d_max, 0, 2 * sizeof(int), stream()));
+  PSP_HIP(hipMalloc((void **)&d_max, 4 * sizeof(int)));
+  PSP_HIP(hipMemsetAsync(d_max, 0, 4 * sizeof(int), stream()));
   // pass 1: most distinct x blocks referenced by one chunk, and how many chunks need more than 64
   hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
                      0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
   PSP_LAUNCH_CHECK();
-  int st[2] = {0, 0};
+  int st[3] = {0, 0, 0};
   PSP_HIP(hipMemcpyAsync(st, d_max, sizeof(st), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
   const int mb = st[0];
@@ -2207,9 +2211,13 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
     const char *e = getenv("PSP_SPMV_W3_OUTLIERS");
     return e ? atoi(e) != 0 : true;
   }();
+  // (the shorter list is worth having: every chunk loads all NB list slots)
   int nb = 0;
   if (mb <= 32 && cap >= 32) nb = 32;
-  else if (mb <= 64 && cap >= 64) nb = 64;
+  else if (outl_on && cap >= 32 && st[2] > 0 && (long)st[2] * 50 <= (long)t->nchunks) {
+    nb = 32;
+    t->outliers = st[2];
+  } else if (mb <= 64 && cap >= 64) nb = 64;
   else if (mb <= 128 && cap >= 128) nb = 128;
   else if (outl_on && cap >= 64 && st[1] > 0 && (long)st[1] * 50 <= (long)t->nchunks) {
     nb = 64;
@@ -2900,7 +2908,7 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
                      stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
                      A->val, x, y, dotv, pbuf, skip, perm, rowperm)
   const int ab = w3_ab(A);
-  if constexpr (NB == 64) {
+  if constexpr (NB == 32 || NB == 64) {
     if (t->outliers > 0) {  // one form only: the default stream layout, with the per-chunk fallback compiled in
       hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, true>), dim3(grid), dim3(256), 0, stream(), c0, c1,
                          stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,

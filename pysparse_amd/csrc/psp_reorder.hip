@@ -20,6 +20,7 @@
 // of the PCG path is formed by the last pass in the caller's numbering, so it too has the bits every other
 // kernel gives.
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -37,7 +38,19 @@ struct Graph {
   std::vector<long> ptr;
   std::vector<int> adj;
   std::vector<int> deg;
+  // HUBS: rows with more than hub_thr neighbours (constraint rows, a few long-range couplings) are left out of the
+  // level structure -- their edges are short cuts through the mesh that blow up the level sets and with them the
+  // band -- and are numbered last (first after the reversal).  No more than 1 % of the rows, else nobody is a hub.
+  int hub_thr = 0x7fffffff;
+  bool hub(int v) const { return deg[v] > hub_thr; }
 };
+
+// the threshold both implementations use: twice the average degree, at least 32
+inline int hub_threshold(long long deg_sum, int n) {
+  const long long avg = n > 0 ? (deg_sum + n - 1) / n : 0;
+  const long long t = 2 * avg;
+  return (int)(t < 32 ? 32 : (t > 0x7ffffffe ? 0x7ffffffe : t));
+}
 
 Graph symmetric_pattern(int n, const int *ind, const int *col) {
   Graph g;
@@ -73,7 +86,15 @@ Graph symmetric_pattern(int n, const int *ind, const int *col) {
   g.ptr[n] = out;
   g.adj.resize((size_t)out);
   g.deg.resize(n);
-  for (int i = 0; i < n; ++i) g.deg[i] = (int)(g.ptr[(size_t)i + 1] - g.ptr[i]);
+  long long sum = 0;
+  for (int i = 0; i < n; ++i) {
+    g.deg[i] = (int)(g.ptr[(size_t)i + 1] - g.ptr[i]);
+    sum += g.deg[i];
+  }
+  const int thr = hub_threshold(sum, n);
+  long hubs = 0;
+  for (int i = 0; i < n; ++i) hubs += g.deg[i] > thr;
+  if (hubs * 100 <= (long)n) g.hub_thr = thr;
   return g;
 }
 
@@ -91,7 +112,7 @@ int bfs_levels(const Graph &g, int root, std::vector<int> &level, std::vector<in
     const int u = queue[head++];
     for (long k = g.ptr[u]; k < g.ptr[(size_t)u + 1]; ++k) {
       const int v = g.adj[(size_t)k];
-      if (seen[v] != stamp) {
+      if (seen[v] != stamp && !g.hub(v)) {
         seen[v] = stamp;
         level[v] = level[u] + 1;
         nlev = level[v] + 1;
@@ -116,7 +137,7 @@ std::vector<int> rcm_order(const Graph &g, int n) {
   int stamp = 0;
   // components in order of their lowest-numbered node; start nodes of minimal degree
   for (int s = 0; s < n; ++s) {
-    if (placed[s]) continue;
+    if (placed[s] || g.hub(s)) continue;
     // pseudo-peripheral node (George & Liu): walk to a minimum-degree node of the last level while the
     // eccentricity grows
     int root = s;
@@ -151,7 +172,7 @@ std::vector<int> rcm_order(const Graph &g, int n) {
       nbrs.clear();
       for (long k = g.ptr[u]; k < g.ptr[(size_t)u + 1]; ++k) {
         const int v = g.adj[(size_t)k];
-        if (!placed[v]) {
+        if (!placed[v] && !g.hub(v)) {
           placed[v] = 1;
           nbrs.push_back(v);
         }
@@ -162,6 +183,8 @@ std::vector<int> rcm_order(const Graph &g, int n) {
       order.insert(order.end(), nbrs.begin(), nbrs.end());
     }
   }
+  for (int v = 0; v < n; ++v)  // the hubs, by id
+    if (g.hub(v)) order.push_back(v);
   std::reverse(order.begin(), order.end());
   return order;
 }
@@ -245,13 +268,13 @@ constexpr int kRcmBatch = 32;            // BFS levels enqueued between two look
 // mirror; *maxdeg = largest degree
 __global__ __launch_bounds__(256) void rcm_deg_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
                                                       int *__restrict__ deg, int *__restrict__ ok,
-                                                      int *__restrict__ maxdeg) {
+                                                      int *__restrict__ maxdeg,
+                                                      unsigned long long *__restrict__ degsum) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   int d = 0;
   bool good = true;
   int prev = -1;
-  for (int k = ind[i]; k < ind[i + 1]; ++k) {
+  for (int k = i < n ? ind[i] : 0; k < (i < n ? ind[i + 1] : 0); ++k) {
     const int j = col[k];
     if (j <= prev || j >= n) {
       good = false;
@@ -268,15 +291,31 @@ __global__ __launch_bounds__(256) void rcm_deg_kernel(int n, const int *__restri
     }
     if (lo >= ind[j + 1] || col[lo] != i) good = false;
   }
-  deg[i] = d;
-  if (!good) *ok = 0;
-  atomicMax(maxdeg, d);
+  if (i < n) {
+    deg[i] = d;
+    if (!good) *ok = 0;
+    atomicMax(maxdeg, d);
+  }
+  // sum of the degrees, one atomic per wave
+  unsigned long long sum = (unsigned long long)d;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(degsum, sum);
+}
+
+__global__ __launch_bounds__(256) void rcm_count_hubs_kernel(int n, const int *__restrict__ deg, int thr,
+                                                             int *__restrict__ count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && deg[i] > thr);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
 }
 
 // level[v] = -2 (placed in an earlier component) or -1 (not reached yet)
-__global__ __launch_bounds__(256) void rcm_reset_kernel(int n, const int *__restrict__ pos, int *__restrict__ level) {
+// (hubs -- more than thr neighbours, see struct Graph -- are never reached: they look placed)
+__global__ __launch_bounds__(256) void rcm_reset_kernel(int n, const int *__restrict__ pos, const int *__restrict__ deg,
+                                                        int thr, int *__restrict__ level) {
   const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v < n) level[v] = pos[v] >= 0 ? -2 : -1;
+  if (v < n) level[v] = (pos[v] >= 0 || deg[v] > thr) ? -2 : -1;
 }
 
 // one breadth-first level: the nodes of level `cur` give their unreached neighbours level cur + 1
@@ -319,16 +358,23 @@ __global__ __launch_bounds__(256) void rcm_argmin_kernel(int n, const int *__res
 // Cuthill-McKee, one level: positions [lo, hi) of `order` offer themselves as parent to their unplaced neighbours
 __global__ __launch_bounds__(256) void rcm_expand_kernel(int lo, int hi, const int *__restrict__ order,
                                                          const int *__restrict__ ind, const int *__restrict__ col,
-                                                         const int *__restrict__ pos, int *parent) {
+                                                         const int *__restrict__ pos, const int *__restrict__ deg,
+                                                         int thr, int *parent) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int p = lo + (t >> 3), sub = t & 7;
   if (p >= hi) return;
   const int u = order[p];
   for (int k = ind[u] + sub; k < ind[u + 1]; k += 8) {
     const int v = col[k];
-    if (pos[v] < 0) atomicMin(parent + v, p);
+    if (pos[v] < 0 && deg[v] <= thr) atomicMin(parent + v, p);
   }
 }
+
+struct RcmHub {
+  const int *deg;
+  int thr;
+  __device__ bool operator()(int v) const { return deg[v] > thr; }
+};
 
 struct RcmDiscovered {
   const int *pos, *parent;
@@ -446,17 +492,30 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
   int *found = b_found.as<int>();
   int *d_ok = b_small.as<int>(), *d_maxdeg = d_ok + 1, *d_count = d_ok + 2;
   unsigned long long *d_min = reinterpret_cast<unsigned long long *>(d_ok + 4);
+  unsigned long long *d_degsum = reinterpret_cast<unsigned long long *>(d_ok + 6);
 
   // degrees + the symmetry / ordering check
   {
-    const int init[2] = {1, 0};
+    const int init[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     PSP_HIP(hipMemcpyAsync(d_ok, init, sizeof(init), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rcm_deg_kernel, dim3(g), dim3(256), 0, st, n, ind, col, deg, d_ok, d_maxdeg);
+    hipLaunchKernelGGL(rcm_deg_kernel, dim3(g), dim3(256), 0, st, n, ind, col, deg, d_ok, d_maxdeg, d_degsum);
     PSP_LAUNCH_CHECK();
-    int res[2];
+    int res[8];
     PSP_HIP(hipMemcpyAsync(res, d_ok, sizeof(res), hipMemcpyDeviceToHost, st));
     PSP_HIP(hipStreamSynchronize(st));
     if (!res[0]) return PSP_OK;
+    // hubs (see struct Graph): the same threshold and the same 1 % rule as the host code
+    long long degsum = 0;
+    memcpy(&degsum, res + 6, sizeof(degsum));
+    int thr = hub_threshold(degsum, n);
+    {
+      PSP_HIP(hipMemsetAsync(d_count, 0, sizeof(int), st));
+      hipLaunchKernelGGL(rcm_count_hubs_kernel, dim3(g), dim3(256), 0, st, n, deg, thr, d_count);
+      int hubs = 0;
+      PSP_HIP(hipMemcpyAsync(&hubs, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+      PSP_HIP(hipStreamSynchronize(st));
+      if ((long)hubs * 100 > (long)n) thr = 0x7fffffff;
+    }
     int degbits = 1, posbits = 1;
     while ((1L << degbits) <= res[1]) ++degbits;
     while ((1L << posbits) < n) ++posbits;
@@ -478,7 +537,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
     int levels_walked = 0;
     // breadth-first level structure from `root` inside the unplaced part; returns the number of levels (0 = gave up)
     auto bfs = [&](int root, int *nlev) -> int {
-      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, level);
+      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, deg, thr, level);
       PSP_HIP(hipMemsetAsync(level + root, 0, sizeof(int), st));
       PSP_HIP(hipMemsetAsync(found, 0, sizeof(int) * (size_t)(kRcmMaxLevels + 2 * kRcmBatch + 2), st));
       int cur = 0;
@@ -515,13 +574,13 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
     };
 
     int placed = 0, comps = 0;
-    while (placed < n) {
-      if (++comps > kRcmMaxComponents) return PSP_OK;
-      // lowest-numbered node not placed yet
+    for (;;) {
+      // lowest-numbered node that is neither placed nor a hub
       int s = -1;
-      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, level);
+      hipLaunchKernelGGL(rcm_reset_kernel, dim3(g), dim3(256), 0, st, n, pos, deg, thr, level);
       PSP_TRY(argmin(-1, nullptr, &s));
-      if (s < 0) return fail(PSP_EINVAL, "reorder: no unplaced node left at %d of %d", placed, n);
+      if (s < 0) break;
+      if (++comps > kRcmMaxComponents) return PSP_OK;
       // pseudo-peripheral root (George & Liu), as rcm_order above
       int root = s, nlev = 0;
       PSP_TRY(bfs(root, &nlev));
@@ -549,7 +608,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
         if (++levels_walked > 5 * kRcmMaxLevels) return PSP_OK;
         const int nf = hi - lo;
         hipLaunchKernelGGL(rcm_expand_kernel, dim3((int)(((long)nf * 8 + 255) / 256)), dim3(256), 0, st, lo, hi, order,
-                           ind, col, pos, parent);
+                           ind, col, pos, deg, thr, parent);
         size_t tb = bytes_tmp;
         PSP_HIP(hipcub::DeviceSelect::If(b_tmp.p, tb, ids, cand, d_count, n, pred, st));
         int m = 0;
@@ -566,6 +625,15 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
         hi += m;
       }
       placed = hi;
+    }
+    if (placed < n) {  // the hubs, by id, behind everybody else
+      size_t tb = bytes_tmp;
+      RcmHub is_hub{deg, thr};
+      PSP_HIP(hipcub::DeviceSelect::If(b_tmp.p, tb, ids, order + placed, d_count, n, is_hub, st));
+      int m = 0;
+      PSP_HIP(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+      PSP_HIP(hipStreamSynchronize(st));
+      if (placed + m != n) return fail(PSP_EINVAL, "reorder: %d placed + %d hubs != %d rows", placed, m, n);
     }
   }
   int *perm = nullptr, *inv = nullptr;

@@ -22,6 +22,9 @@ def case_arrays(name):
     if name == "fem512":
         n, ind, col, val, diag = fem_sss_arrays(20, 18, 16, 512, 0)
         return (n,) + tuple(full_csr_from_sss(n, ind, col, val, diag))
+    if name == "hubs":  # six rows with 60 extra couplings anywhere: left out of the level structure, numbered last
+        n, ind, col, val, diag = fem_sss_arrays(20, 18, 16, 512, 0, wild=6)
+        return (n,) + tuple(full_csr_from_sss(n, ind, col, val, diag))
     if name == "components":
         # two meshes of different size side by side + isolated (diagonal-only) rows in front, between and behind
         parts = [fem_sss_arrays(12, 11, 10, 64, 1), fem_sss_arrays(9, 14, 8, 512, 2)]

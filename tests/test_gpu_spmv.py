@@ -547,7 +547,7 @@ def test_csr_matvec_scattered_numbering_bit_exact(oracle, shuffle, form):
     assert np.array_equal(y, ya)
 
 
-@pytest.mark.parametrize("name", ["fem512", "components", "unsymmetric"])
+@pytest.mark.parametrize("name", ["fem512", "components", "hubs", "unsymmetric"])
 def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
     """The reverse Cuthill-McKee numbering is computed on the device for structurally symmetric patterns
     (psp_reorder.hip: level-synchronous, every tie decided by (degree, id)) and on the host otherwise; the two
@@ -630,7 +630,7 @@ def test_csr_matvec_w3_with_outlier_chunks(oracle):
     A = oracle.CSR((n, n), val, col, ind)
     D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
     kern, info = D.kernel_info()
-    assert kern == "csr_spmv_w3" and info["max_blocks"] > 64 and info["nb"] == 64, (kern, info)
+    assert kern == "csr_spmv_w3" and info["max_blocks"] > 64 and info["nb"] in (32, 64), (kern, info)
     x = rng.standard_normal(n)
     y, yo = np.full(n, np.nan), np.empty(n)
     D.matvec(x, y)
