@@ -725,8 +725,9 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
     return;
   }
   if (count > NB) return;
+  // unused list slots hold -2: the kernel issues no load for them (SHIFT 0, csr_spmv_w5: padded with the last column)
   for (int i = lane; i < NB; i += 64)
-    blist[(size_t)chunk * NB + i] = count ? ulist[i < count ? i : count - 1] : 0;
+    blist[(size_t)chunk * NB + i] = i < count ? ulist[i] : (SHIFT == 4 ? -2 : (count ? ulist[count - 1] : 0));
   for (int i = lane; i < WT; i += 64) {
     const long k = kb + i;
     unsigned short v = 0;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const int nr = tab[chunk + 1].x - r0;
     d2v p0[STEPS], p1[STEPS];
     bool outlier = false;
-    if constexpr (OUTL) outlier = __builtin_amdgcn_readfirstlane(blk0) < 0;  // wave-uniform: the whole list is -1
+    if constexpr (OUTL) outlier = __builtin_amdgcn_readfirstlane(blk0) == -1;  // wave-uniform: the whole list is -1
     if (OUTL && outlier) {
       // --- outlier chunk: x straight from memory through the int32 columns (padding holds valid columns)
 #pragma unroll
@@ -862,7 +863,10 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
         const int src = (j & 7) * 8 + (lane >> 3);
         const int b = __shfl((NB == 128 && j >= 8) ? blk1 : blk0, src, 64);
         const long e0 = (long)b * 16 + (lane & 7) * 2;
-        if (e0 + 1 < ncols) {
+        if (b < 0) {  // unused slot of a chunk with fewer than NB blocks: nothing to fetch
+          xw[j].x = 0.0;
+          xw[j].y = 0.0;
+        } else if (e0 + 1 < ncols) {
           xw[j] = *reinterpret_cast<const d2v *>(x + e0);
         } else {  // the block that holds the end of x
           xw[j].x = e0 < ncols ? x[e0] : 0.0;
