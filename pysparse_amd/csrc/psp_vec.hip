@@ -481,6 +481,96 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(long n, double a, const do
   }
 }
 
+// ---- fused passes of the BiCGSTAB loop (bicgstab.c; native matrix + None / jacobi(1)).  Element by element the
+// same rounded operations, in the same order, as the unfused sequence of lin2 / jacobi kernels they replace.
+//   p = r + beta*(p - omega*v)  (first iteration: p = r);  phat = K p            [PRE 0: phat is p itself]
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void bicg_p_kernel(long n, const double *__restrict__ r,
+                                                        const double *__restrict__ v, double *__restrict__ p,
+                                                        double *__restrict__ phat, const double *__restrict__ dinv,
+                                                        double dc, double beta, double omega, int first) {
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> pp = ld<V>(r, i);
+    if (!first) {
+      const Pack<V> po = ld<V>(p, i), vv = ld<V>(v, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) {
+        const double t = 1.0 * po.v[u] + (-omega) * vv.v[u];  // lin2(1, p, -omega, v)
+        pp.v[u] = 1.0 * pp.v[u] + beta * t;                   // lin2(1, r, beta, t)
+      }
+    }
+    st<V>(p, i, pp);
+    if constexpr (PRE != 0) {
+      Pack<V> ph;
+      if constexpr (PRE == 1) {
+        const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+        for (int u = 0; u < V; ++u) ph.v[u] = pp.v[u] * dd.v[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < V; ++u) ph.v[u] = pp.v[u] * dc;
+      }
+      st<V>(phat, i, ph);
+    }
+  }
+}
+
+//   s = r - alpha*v;  shat = K s                                                 [PRE 0: shat is s itself]
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void bicg_s_kernel(long n, const double *__restrict__ r,
+                                                        const double *__restrict__ v, double *__restrict__ sv,
+                                                        double *__restrict__ shat, const double *__restrict__ dinv,
+                                                        double dc, double alpha) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> rr = ld<V>(r, i), vv = ld<V>(v, i);
+    Pack<V> ss;
+#pragma unroll
+    for (int u = 0; u < V; ++u) ss.v[u] = 1.0 * rr.v[u] + (-alpha) * vv.v[u];
+    st<V>(sv, i, ss);
+    if constexpr (PRE != 0) {
+      Pack<V> sh;
+      if constexpr (PRE == 1) {
+        const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+        for (int u = 0; u < V; ++u) sh.v[u] = ss.v[u] * dd.v[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < V; ++u) sh.v[u] = ss.v[u] * dc;
+      }
+      st<V>(shat, i, sh);
+    }
+  }
+}
+
+//   x = (x + alpha*phat) + omega*shat;  r = s - omega*t;  partials {r.r, rhat.r}
+template <int V>
+__global__ __launch_bounds__(kBlock) void bicg_xr_kernel(long n, double *__restrict__ x,
+                                                         const double *__restrict__ phat,
+                                                         const double *__restrict__ shat,
+                                                         const double *__restrict__ sv, const double *__restrict__ t,
+                                                         double *__restrict__ r, const double *__restrict__ rhat,
+                                                         double alpha, double omega, double *__restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> xx = ld<V>(x, i);
+    const Pack<V> ph = ld<V>(phat, i), sh = ld<V>(shat, i), ss = ld<V>(sv, i), tt = ld<V>(t, i), rh = ld<V>(rhat, i);
+    Pack<V> rn;
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      double xv = 1.0 * xx.v[u] + alpha * ph.v[u];
+      xv = 1.0 * xv + omega * sh.v[u];
+      xx.v[u] = xv;
+      const double rv = 1.0 * ss.v[u] + (-omega) * tt.v[u];
+      rn.v[u] = rv;
+      acc[0] += rv * rv;
+      acc[1] += rh.v[u] * rv;
+    }
+    st<V>(x, i, xx);
+    st<V>(r, i, rn);
+  }
+  block_reduce_store<2>(acc, partials);
+}
+
 // ---- x = a*x (dscal)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
@@ -812,6 +902,59 @@ int k_lin2(long n, double a, const double *x, double b, const double *y, double 
   else
     hipLaunchKernelGGL(lin2_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, a, x, b, y, z);
   PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_bicg_p(long n, const double *r, const double *v, double *p, double *phat, const double *dinv, double beta,
+             double omega, bool first) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, r, v, p, phat) : can_vec2(n, r, v, p, phat, dinv)) : can_vec2(n, r, v, p);
+#define L(V, PRE)                                                                                       \
+  hipLaunchKernelGGL((bicg_p_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, v, p, phat, \
+                     dinv, dc, beta, omega, first ? 1 : 0)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, const double *dinv, double alpha) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, r, v, s, shat) : can_vec2(n, r, v, s, shat, dinv)) : can_vec2(n, r, v, s);
+#define L(V, PRE)                                                                                    \
+  hipLaunchKernelGGL((bicg_s_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, v, s, shat, \
+                     dinv, dc, alpha)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_bicg_xr(long n, double *x, const double *phat, const double *shat, const double *s, const double *t, double *r,
+              const double *rhat, double alpha, double omega, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, x, phat, shat, s, t, r, rhat))
+    hipLaunchKernelGGL(bicg_xr_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, x, phat, shat, s, t, r, rhat,
+                       alpha, omega, partials);
+  else
+    hipLaunchKernelGGL(bicg_xr_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, x, phat, shat, s, t, r, rhat,
+                       alpha, omega, partials);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
   return PSP_OK;
 }
 
