@@ -571,6 +571,87 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_kernel(long n, double *__restr
   block_reduce_store<2>(acc, partials);
 }
 
+// ---- fused passes of the CGS loop (cgs.c; native matrix + None / jacobi(1)).  Each line is the copy + daxpy pair
+// of the reference with daxpy's quick return for a zero coefficient (netlib: the vector is left untouched).
+//   q = u - alpha*v;  tmp = u + q;  tmp2 = K tmp;  x = x + alpha*tmp2
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void cgs_q_kernel(long n, const double *__restrict__ u,
+                                                       const double *__restrict__ v, double *__restrict__ x,
+                                                       double *__restrict__ q, double *__restrict__ tmp2,
+                                                       const double *__restrict__ dinv, double dc, double alpha) {
+  const bool upd = alpha != 0.0;
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> uu = ld<V>(u, i), vv = ld<V>(v, i);
+    Pack<V> xx = ld<V>(x, i), qq, t2;
+    Pack<V> dd;
+    if constexpr (PRE == 1) dd = ld<V>(dinv, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      qq.v[k] = upd ? 1.0 * uu.v[k] + (-alpha) * vv.v[k] : uu.v[k];
+      const double t = 1.0 * uu.v[k] + 1.0 * qq.v[k];
+      t2.v[k] = PRE == 0 ? t : (PRE == 1 ? t * dd.v[k] : t * dc);
+      if (upd) xx.v[k] = 1.0 * xx.v[k] + alpha * t2.v[k];
+    }
+    st<V>(q, i, qq);
+    st<V>(tmp2, i, t2);
+    st<V>(x, i, xx);
+  }
+}
+
+//   r = r - alpha*t;  partials {r.r, r.r0}
+template <int V>
+__global__ __launch_bounds__(kBlock) void cgs_r_kernel(long n, double *__restrict__ r, const double *__restrict__ t,
+                                                       const double *__restrict__ r0, double alpha,
+                                                       double *__restrict__ partials) {
+  const bool upd = alpha != 0.0;
+  double acc[2] = {0.0, 0.0};
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> rr = ld<V>(r, i);
+    const Pack<V> tt = ld<V>(t, i), r0v = ld<V>(r0, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      if (upd) rr.v[k] = 1.0 * rr.v[k] + (-alpha) * tt.v[k];
+      acc[0] += rr.v[k] * rr.v[k];
+      acc[1] += rr.v[k] * r0v.v[k];
+    }
+    st<V>(r, i, rr);
+  }
+  block_reduce_store<2>(acc, partials);
+}
+
+//   u = r + beta*q;  tmp = q + beta*p;  p = u + beta*tmp;  kp = K p                [PRE 0: kp is p itself]
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void cgs_p_kernel(long n, const double *__restrict__ r,
+                                                       const double *__restrict__ q, double *__restrict__ p,
+                                                       double *__restrict__ u, double *__restrict__ kp,
+                                                       const double *__restrict__ dinv, double dc, double beta) {
+  const bool upd = beta != 0.0;
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> rr = ld<V>(r, i), qq = ld<V>(q, i), po = ld<V>(p, i);
+    Pack<V> uu, pn;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      uu.v[k] = upd ? 1.0 * rr.v[k] + beta * qq.v[k] : rr.v[k];
+      const double t = upd ? 1.0 * qq.v[k] + beta * po.v[k] : qq.v[k];
+      pn.v[k] = upd ? 1.0 * uu.v[k] + beta * t : uu.v[k];
+    }
+    st<V>(u, i, uu);
+    st<V>(p, i, pn);
+    if constexpr (PRE != 0) {
+      Pack<V> kk;
+      if constexpr (PRE == 1) {
+        const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) kk.v[k] = pn.v[k] * dd.v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) kk.v[k] = pn.v[k] * dc;
+      }
+      st<V>(kp, i, kk);
+    }
+  }
+}
+
 // ---- x = a*x (dscal)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
@@ -955,6 +1036,57 @@ int k_bicg_xr(long n, double *x, const double *phat, const double *shat, const d
                        alpha, omega, partials);
   PSP_LAUNCH_CHECK();
   *nparts = grid;
+  return PSP_OK;
+}
+
+int k_cgs_q(long n, const double *u, const double *v, double *x, double *q, double *tmp2, const double *dinv,
+            double alpha) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv && !cst ? can_vec2(n, u, v, x, q, tmp2, dinv) : can_vec2(n, u, v, x, q, tmp2);
+#define L(V, PRE)                                                                                       \
+  hipLaunchKernelGGL((cgs_q_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, u, v, x, q, tmp2, \
+                     dinv, dc, alpha)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_cgs_r(long n, double *r, const double *t, const double *r0, double alpha, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, r, t, r0))
+    hipLaunchKernelGGL(cgs_r_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials);
+  else
+    hipLaunchKernelGGL(cgs_r_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_cgs_p(long n, const double *r, const double *q, double *p, double *u, double *kp, const double *dinv,
+            double beta) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, r, q, p, u, kp) : can_vec2(n, r, q, p, u, kp, dinv)) : can_vec2(n, r, q, p, u);
+#define L(V, PRE)                                                                                    \
+  hipLaunchKernelGGL((cgs_p_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, q, p, u, kp, \
+                     dinv, dc, beta)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
 
