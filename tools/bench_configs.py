@@ -41,8 +41,16 @@ for k in (5, 400):
     check(L.psp_pcg_dev(aop._h, kop._h, n, x.ptr, b.ptr, 0.0, k, C.byref(info), C.byref(it), C.byref(rr), None))
     check(L.psp_synchronize())
     tp = time.perf_counter() - t0
-out["C2_poisson2d_4096"] = {"n": n, "nnz": nnz, "spmv_ms": t, "spmv_GBps": (12 * nnz + 20 * n + 4) / t / 1e6,
-                            "pcg_iters_per_s": 400 / tp, "pcg_effective_GBps": (12 * nnz + 108 * n) * 400 / tp / 1e9}
+kern, kinfo = A.kernel_info()
+own = 8 * kinfo["nb"] * ((n + 127) // 128 * 128) + 18 * n if kern == "csr_spmv_w4" else 12 * nnz + 20 * n + 4
+out["C2_poisson2d_4096"] = {
+    "n": n, "nnz": nnz, "kernel": kern, "spmv_ms": t,
+    # what the kernel has to move (csr_spmv_w4: 8 B per offset slot + 2 B mask + x + y; x and y, 134 MB each, can
+    # live in the 256 MB Infinity Cache at this size, so this is not a pure HBM rate) ...
+    "spmv_bytes": own, "spmv_GBps": own / t / 1e6, "spmv_frac_of_hbm_peak": own / t / 1e6 / 8000.0,
+    # ... and the same time priced in CSR-model bytes 12 nnz + 20 n + 4 (an equivalent, not a memory rate)
+    "spmv_csr_model_equiv_GBps": (12 * nnz + 20 * n + 4) / t / 1e6,
+    "pcg_iters_per_s": 400 / tp, "pcg_csr_model_equiv_GBps": (12 * nnz + 108 * n) * 400 / tp / 1e9}
 del A, K, aop, kop
 
 # ---- C5 stand-in
