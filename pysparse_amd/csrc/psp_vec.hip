@@ -652,6 +652,98 @@ __global__ __launch_bounds__(kBlock) void cgs_p_kernel(long n, const double *__r
   }
 }
 
+// ---- fused passes of the QMRS loop (qmrs.c; native matrix + None / jacobi(1)); per element the lin2 / scal / jacobi
+// operations they replace.
+//   wrk1 = K v1;  partial wrk1.v1                                                  (first iteration only; PRE != 0)
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void qmrs_kv_kernel(long n, const double *__restrict__ v1,
+                                                         double *__restrict__ wrk1, const double *__restrict__ dinv,
+                                                         double dc, double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> vv = ld<V>(v1, i);
+    Pack<V> ww = vv;
+    if constexpr (PRE == 1) {
+      const Pack<V> dd = ld<V>(dinv, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) ww.v[k] = vv.v[k] * dd.v[k];
+    }
+    if constexpr (PRE == 2) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) ww.v[k] = vv.v[k] * dc;
+    }
+    if constexpr (PRE != 0) st<V>(wrk1, i, ww);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[0] += ww.v[k] * vv.v[k];
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+//   p = v1 - cc*p;  g = wrk1 - cc*g
+template <int V>
+__global__ __launch_bounds__(kBlock) void qmrs_pg_kernel(long n, const double *__restrict__ v1,
+                                                         const double *__restrict__ wrk1, double *__restrict__ p,
+                                                         double *__restrict__ g, double cc) {
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> vv = ld<V>(v1, i), ww = ld<V>(wrk1, i);
+    Pack<V> pp = ld<V>(p, i), gg = ld<V>(g, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      pp.v[k] = 1.0 * vv.v[k] + (-cc) * pp.v[k];
+      gg.v[k] = 1.0 * ww.v[k] + (-cc) * gg.v[k];
+    }
+    st<V>(p, i, pp);
+    st<V>(g, i, gg);
+  }
+}
+
+//   v1 = t - beta*v1;  partial v1.v1
+template <int V>
+__global__ __launch_bounds__(kBlock) void qmrs_v_kernel(long n, const double *__restrict__ t, double *__restrict__ v1,
+                                                        double beta, double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> tt = ld<V>(t, i);
+    Pack<V> vv = ld<V>(v1, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      vv.v[k] = 1.0 * tt.v[k] + (-beta) * vv.v[k];
+      acc[0] += vv.v[k] * vv.v[k];
+    }
+    st<V>(v1, i, vv);
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+//   d = eta*p + cc*d;  x = x + d;  v1 = rho1inv*v1;  and for the next iteration wrk1 = K v1, partial wrk1.v1
+template <int V, int PRE>
+__global__ __launch_bounds__(kBlock) void qmrs_dx_kernel(long n, const double *__restrict__ p, double *__restrict__ d,
+                                                         double *__restrict__ x, double *__restrict__ v1,
+                                                         double *__restrict__ wrk1, const double *__restrict__ dinv,
+                                                         double dc, double eta, double cc, double rho1inv,
+                                                         double *__restrict__ partials) {
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    const Pack<V> pp = ld<V>(p, i);
+    Pack<V> dd = ld<V>(d, i), xx = ld<V>(x, i), vv = ld<V>(v1, i), ww;
+    Pack<V> di;
+    if constexpr (PRE == 1) di = ld<V>(dinv, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      dd.v[k] = eta * pp.v[k] + cc * dd.v[k];
+      xx.v[k] = 1.0 * xx.v[k] + 1.0 * dd.v[k];
+      vv.v[k] = rho1inv * vv.v[k];
+      ww.v[k] = PRE == 0 ? vv.v[k] : (PRE == 1 ? vv.v[k] * di.v[k] : vv.v[k] * dc);
+      acc[0] += ww.v[k] * vv.v[k];
+    }
+    st<V>(d, i, dd);
+    st<V>(x, i, xx);
+    st<V>(v1, i, vv);
+    if constexpr (PRE != 0) st<V>(wrk1, i, ww);
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
 // ---- x = a*x (dscal)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
@@ -1087,6 +1179,71 @@ int k_cgs_p(long n, const double *r, const double *q, double *p, double *u, doub
   else { if (v2) L(2, 0); else L(1, 0); }
 #undef L
   PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, v1, wrk1) : can_vec2(n, v1, wrk1, dinv)) : can_vec2(n, v1);
+#define L(V, PRE)                                                                                      \
+  hipLaunchKernelGGL((qmrs_kv_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, dinv, \
+                     dc, partials)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, v1, wrk1, p, g))
+    hipLaunchKernelGGL(qmrs_pg_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc);
+  else
+    hipLaunchKernelGGL(qmrs_pg_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, t, v1))
+    hipLaunchKernelGGL(qmrs_v_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials);
+  else
+    hipLaunchKernelGGL(qmrs_v_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials);
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double *wrk1, const double *dinv, double eta,
+              double cc, double rho1inv, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  double dc = 0.0;
+  const bool cst = dinv && dinv_constant(dinv, n, &dc);
+  const bool v2 = dinv ? (cst ? can_vec2(n, p, d, x, v1, wrk1) : can_vec2(n, p, d, x, v1, wrk1, dinv))
+                       : can_vec2(n, p, d, x, v1);
+#define L(V, PRE)                                                                                          \
+  hipLaunchKernelGGL((qmrs_dx_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, p, d, x, v1, wrk1, \
+                     dinv, dc, eta, cc, rho1inv, partials)
+  if (cst) { if (v2) L(2, 2); else L(1, 2); }
+  else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
+  else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
   return PSP_OK;
 }
 
