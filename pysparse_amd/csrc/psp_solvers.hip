@@ -54,6 +54,7 @@ int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double
                 double *w_old, double *x, bool scaled = false, double vdiv = 1.0, const MinresDev *ds = nullptr);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
+int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts);
 int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double *partials, int *nparts);
 int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc);
 int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts);
@@ -1735,12 +1736,28 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
       iter++;
       PSP_TRY(apply_or_copy(K, n, V[i], W[i]));
       PSP_TRY(op_apply(A, W[i], V[i + 1]));
-      for (k = 0; k <= i; k++) {
-        PSP_TRY(B.dot(V[i + 1], V[k], &d));
-        GH(k, i) = d;
-        PSP_TRY(B.axpy(-GH(k, i), V[k], V[i + 1]));
+      // modified Gram-Schmidt (gmres.c:110-116): the axpy of step k and the dot of step k + 1 (at the end: the norm)
+      // share one pass over V[i + 1]
+      static const bool mgs_fused = [] {
+        const char *e = getenv("PSP_GMRES_FUSED");  // 0: one dot and one axpy kernel per step (A/B)
+        return e ? atoi(e) != 0 : true;
+      }();
+      if (mgs_fused) {
+        PSP_TRY(B.dot(V[i + 1], V[0], &d));
+        for (k = 0; k <= i; k++) {
+          GH(k, i) = d;
+          int np;
+          PSP_TRY(k_axpy_dot(n, -GH(k, i), V[k], V[i + 1], k < i ? V[k + 1] : nullptr, w->partials, &np));
+          PSP_TRY(reduce_fetch(w, np, 1, &d));
+        }
+      } else {
+        for (k = 0; k <= i; k++) {
+          PSP_TRY(B.dot(V[i + 1], V[k], &d));
+          GH(k, i) = d;
+          PSP_TRY(B.axpy(-GH(k, i), V[k], V[i + 1]));
+        }
+        PSP_TRY(B.dot(V[i + 1], V[i + 1], &d));
       }
-      PSP_TRY(B.dot(V[i + 1], V[i + 1], &d));
       GH(i + 1, i) = sqrt(d);
       PSP_TRY(k_scal(n, 1.0 / GH(i + 1, i), V[i + 1]));
       for (k = 0; k < i; k++) app_rot(&GH(k, i), &GH(k + 1, i), cs[k], sn[k]);

@@ -744,6 +744,35 @@ __global__ __launch_bounds__(kBlock) void qmrs_dx_kernel(long n, const double *_
   block_reduce_store<1>(acc, partials);
 }
 
+// ---- y = y + a*x (daxpy, quick return for a == 0) and, in the same pass, the partial sums of y.z (z == nullptr: y.y):
+// the modified Gram-Schmidt loop of gmres.c -- every dot needs the vector the previous axpy produced, so the pair
+// "axpy k, dot k + 1" is one pass instead of two
+template <int V, bool SELF>
+__global__ __launch_bounds__(kBlock) void axpy_dot_kernel(long n, double a, const double *__restrict__ x,
+                                                          double *__restrict__ y, const double *__restrict__ z,
+                                                          double *__restrict__ partials) {
+  const bool upd = a != 0.0;
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> yy = ld<V>(y, i);
+    if (upd) {
+      const Pack<V> xx = ld<V>(x, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) yy.v[k] = 1.0 * yy.v[k] + a * xx.v[k];
+      st<V>(y, i, yy);
+    }
+    if constexpr (SELF) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[0] += yy.v[k] * yy.v[k];
+    } else {
+      const Pack<V> zz = ld<V>(z, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[0] += yy.v[k] * zz.v[k];
+    }
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
 // ---- x = a*x (dscal)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
@@ -1241,6 +1270,21 @@ int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double 
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  const bool v2 = z ? can_vec2(n, x, y, z) : can_vec2(n, x, y);
+#define L(V, SELF)                                                                                      \
+  hipLaunchKernelGGL((axpy_dot_kernel<V, SELF>), dim3(grid), dim3(kBlock), 0, stream(), n, a, x, y, z, partials)
+  if (z) { if (v2) L(2, false); else L(1, false); }
+  else { if (v2) L(2, true); else L(1, true); }
 #undef L
   PSP_LAUNCH_CHECK();
   *nparts = grid;

@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", default="512,512,512")
 ap.add_argument("--short", type=int, default=5)
 ap.add_argument("--long", type=int, default=45)
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--only", default="", help="comma separated solver names")
 a = ap.parse_args()
 nx, ny, nz = (int(t) for t in a.grid.split(","))
 A = dev.DeviceCSR.poisson(nx, ny, nz)
@@ -27,8 +29,10 @@ A.matvec(np.ones(n), b)
 out = {"grid": [nx, ny, nz], "n": n, "kernel": A.kernel_info()[0]}
 for name, fn in (("pcg", dev.pcg), ("minres", dev.minres), ("cgs", dev.cgs), ("bicgstab", dev.bicgstab),
                  ("qmrs", dev.qmrs), ("gmres20", dev.gmres)):
+    if a.only and name not in a.only.split(","):
+        continue
     ts, res = {}, None
-    for k in (a.short, a.long, a.short, a.long):
+    for k in (a.short, a.long) * a.reps:
         x = np.zeros(n)
         t = time.perf_counter()
         res = fn(A, b, x, 0.0, k, K)
