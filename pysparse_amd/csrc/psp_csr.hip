@@ -2015,6 +2015,20 @@ int alloc_csr(int nrows, int ncols, long nnz, psp_csr **out) {
   hipError_t e2 = hipMalloc((void **)&A->col, sizeof(int) * A->padded);
   hipError_t e3 = hipMalloc((void **)&A->val, sizeof(double) * A->padded);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    // the solvers' cached work vectors may be what fills the device: drop them and try once more
+    (void)hipGetLastError();
+    if (e1 == hipSuccess) (void)hipFree(A->ind);
+    if (e2 == hipSuccess) (void)hipFree(A->col);
+    if (e3 == hipSuccess) (void)hipFree(A->val);
+    A->ind = nullptr;
+    A->col = nullptr;
+    A->val = nullptr;
+    (void)psp_trim();
+    e1 = hipMalloc((void **)&A->ind, sizeof(int) * ((size_t)nrows + 1));
+    e2 = hipMalloc((void **)&A->col, sizeof(int) * A->padded);
+    e3 = hipMalloc((void **)&A->val, sizeof(double) * A->padded);
+  }
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     (void)hipFree(A->ind);
     (void)hipFree(A->col);
     (void)hipFree(A->val);

@@ -86,7 +86,18 @@ struct ScratchPool {
   };
   std::vector<Item> free_;
   std::mutex mu;
-  static constexpr size_t kMaxCached = 12;
+  // up to 64 vectors and a third of the device memory stay cached (gmres(20) holds 41 work vectors: at n = 2^27 their
+  // hipMalloc / hipFree per call cost more than the solve); psp_trim() and any failed allocation empty the pool
+  static constexpr size_t kMaxCached = 64;
+  size_t cached_bytes = 0;
+  static size_t cap_bytes() {
+    static const size_t cap = [] {
+      size_t f = 0, t = 0;
+      if (hipMemGetInfo(&f, &t) != hipSuccess) return (size_t)0;
+      return t / 3;
+    }();
+    return cap;
+  }
   int get(size_t n, double **out) {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -95,6 +106,7 @@ struct ScratchPool {
         if (free_[i].cap >= n && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
       if (best >= 0 && free_[best].cap <= 2 * n + 1024) {
         *out = free_[best].p;
+        cached_bytes -= free_[best].cap * sizeof(double);
         free_.erase(free_.begin() + best);
         return PSP_OK;
       }
@@ -112,16 +124,18 @@ struct ScratchPool {
   }
   void put(double *p, size_t cap) {
     std::lock_guard<std::mutex> lk(mu);
-    if (free_.size() >= kMaxCached) {
+    if (free_.size() >= kMaxCached || cached_bytes + cap * sizeof(double) > cap_bytes()) {
       (void)hipFree(p);
       return;
     }
     free_.push_back({p, cap});
+    cached_bytes += cap * sizeof(double);
   }
   void trim() {
     std::lock_guard<std::mutex> lk(mu);
     for (auto &it : free_) (void)hipFree(it.p);
     free_.clear();
+    cached_bytes = 0;
   }
 };
 ScratchPool g_pool;
