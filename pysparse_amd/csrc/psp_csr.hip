@@ -2472,6 +2472,11 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   const bool m32 = no > 16;
   const size_t nmask = nblk * kDiaRows + 2;
   hipError_t e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
+  if (e1 != hipSuccess) {  // cached solver work vectors may be in the way: drop them and try once more
+    (void)hipGetLastError();
+    (void)psp_trim();
+    e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
+  }
   hipError_t e2 = m32 ? hipMalloc((void **)&ex.dia_mask32, sizeof(unsigned) * nmask)
                       : hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * nmask);
   if (e1 != hipSuccess || e2 != hipSuccess) {  // no room: stay with the CSR kernels

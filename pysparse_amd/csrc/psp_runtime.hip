@@ -202,7 +202,11 @@ int psp_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
 int psp_malloc(void **dev, size_t bytes) {
   if (!dev) return fail(PSP_EINVAL, "psp_malloc: NULL out pointer");
   PSP_TRY(ensure_device());
-  PSP_HIP(hipMalloc(dev, bytes ? bytes : 8));
+  if (hipMalloc(dev, bytes ? bytes : 8) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)psp_trim();  // the solvers' cached work vectors may be what fills the device
+    PSP_HIP(hipMalloc(dev, bytes ? bytes : 8));
+  }
   return PSP_OK;
 }
 
