@@ -2770,6 +2770,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
 int reorder_build_device(int n, const int *ind, const int *col, const double *val, const int *perm_dev,
                          const int *inv_dev, int *rind, int *rcol, double *rval);
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);
+int reorder_scatter(int n, const int *idx_dev, const double *src, double *dst, const int *skip);
 int reorder_back(int n, const int *inv_dev, const double *yp, double *y, const double *dotv, double *partials,
                  int *nparts, const int *skip);
 }  // namespace psp
@@ -3028,7 +3029,13 @@ static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, con
   if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
   const int n = A->nrows;
   double *xp = ex->xp, *yp = ex->xp + n;
-  PSP_TRY(psp::reorder_gather(n, ex->perm, x, xp, skip));
+  // the permutations as scatters (one load round trip instead of two dependent ones); PSP_SPMV_REORDER_GATHER=1: A/B
+  static const bool gather_form = [] {
+    const char *e = getenv("PSP_SPMV_REORDER_GATHER");
+    return e && atoi(e) != 0;
+  }();
+  if (gather_form) PSP_TRY(psp::reorder_gather(n, ex->perm, x, xp, skip));
+  else PSP_TRY(psp::reorder_scatter(n, ex->inv, x, xp, skip));  // xp[inv[j]] = x[j]
   R->variant = A->variant;
   launch_w3(R, t, true, grid, stripe, 0, t->nchunks, xp, yp, nullptr, nullptr, skip);
   PSP_LAUNCH_CHECK();
@@ -3039,7 +3046,8 @@ static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, con
     pbuf = ex->big_partials;
   }
   int np = 0;
-  PSP_TRY(psp::reorder_back(n, ex->inv, yp, y, partials ? dotv : nullptr, pbuf, &np, skip));
+  if (!partials && !gather_form) PSP_TRY(psp::reorder_scatter(n, ex->perm, yp, y, skip));  // y[perm[i]] = yp[i]
+  else PSP_TRY(psp::reorder_back(n, ex->inv, yp, y, partials ? dotv : nullptr, pbuf, &np, skip));
   if (partials && pbuf != partials) {
     hipLaunchKernelGGL(fold_partials_kernel, dim3(kFold / 16), dim3(256), 0, stream(), pbuf, np, partials, kFold);
     PSP_LAUNCH_CHECK();
