@@ -487,7 +487,7 @@ W3_VARIANT = (1 << 20) + 16578
 W5_VARIANT = 5259458 + (1 << 27)  # the default kernel selection with the renumbered copy switched off (bit 27)
 
 
-@pytest.mark.parametrize("shuffle", [64, 512])
+@pytest.mark.parametrize("shuffle", [160, 512])
 @pytest.mark.parametrize("form", ["w5", "rcm"])
 def test_csr_matvec_scattered_numbering_bit_exact(oracle, shuffle, form):
     """Irregular numbering (FEM-like stand-in with shuffled node ids): chunks reference more than 64 x blocks,
