@@ -52,6 +52,8 @@ PY
 # (4) the other measurements quoted in DESIGN.md
 rm -f $OUT/r2_fem_standin.txt
 for s in 1 32 512; do timeout 300 python3 tools/fem_standin.py --shuffle $s --variants 16513 >> $OUT/r2_fem_standin.txt 2>> $OUT/tools.err; done
+# the same stand-in with rows that couple to unknowns anywhere (outlier chunks / hubs)
+for sw in "1 200" "1 4000" "512 200"; do set -- $sw; timeout 300 python3 tools/fem_standin.py --shuffle $1 --wild $2 >> $OUT/r2_fem_standin.txt 2>> $OUT/tools.err; done
 timeout 300 python3 tools/small_solver_timing.py > $OUT/r2_small_solvers.txt 2>> $OUT/tools.err
 timeout 300 python3 tools/minres_timing.py > $OUT/r2_minres_timing.txt 2>> $OUT/tools.err
 timeout 300 python3 tools/bench_configs.py > $OUT/r2_configs.json 2>> $OUT/tools.err
