@@ -2229,7 +2229,7 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
     const char *e = getenv("PSP_SPMV_W3_OUTLIERS");
     return e ? atoi(e) != 0 : true;
   }();
-  // (the shorter list is worth having: the 64-slot kernel is ~13 % slower on a matrix that fits 32)
+  // (the shorter list is worth having: the 64-slot kernel is ~4 % slower on a matrix that fits 32)
   int nb = 0;
   if (mb <= 32 && cap >= 32) nb = 32;
   else if (outl_on && cap >= 32 && st[2] > 0 && (long)st[2] * 50 <= (long)t->nchunks) {
@@ -2239,12 +2239,13 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   else if (mb <= 128 && cap >= 128) nb = 128;
   else if (outl_on && cap >= 64) {
     // Some chunks need more than 64 blocks.  Estimated cost per chunk against the 32-slot kernel on a matrix that
-    // fits it: an outlier chunk (x gathered through the int32 columns, like csr_spmv_w2) ~1.4, a 64-slot chunk ~1.13.
+    // fits it: an outlier chunk (x gathered through the int32 columns, like csr_spmv_w2) ~1.4, a 64-slot chunk ~1.045
+    // (0.0723 vs 0.0693 ms on the natural-order stand-in; 1.13 before unused list slots stopped costing a load).
     // Worth it up to 1.2 -- what the renumbered copy costs with its two permutation passes -- and up to 1.25 for that
     // copy itself (csr_spmv_w5 on the stored numbering, ~1.3-1.45, is the alternative then).  Measured on the FEM stand-in with
     // 1000 / 4000 wild rows in natural order: 0.103 / 0.105 ms through the copy, 0.075 / 0.08 directly.
     const double f32 = (double)st[2] / t->nchunks, f64 = (double)st[1] / t->nchunks;
-    const double c32 = cap >= 32 ? 1.0 + 0.4 * f32 : 1e9, c64 = 1.13 + 0.27 * f64;
+    const double c32 = cap >= 32 ? 1.0 + 0.4 * f32 : 1e9, c64 = 1.045 + 0.355 * f64;
     const double limit = A->no_reorder ? 1.25 : 1.20;
     if (c32 <= c64 && c32 <= limit) {
       nb = 32;
