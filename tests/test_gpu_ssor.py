@@ -174,3 +174,19 @@ def test_dropin_module_ssor(oracle):
     ref = oracle.pcg_ssor(So, b, xo, 1e-6, 2 * n, 1.0, 1)
     assert res[:2] == ref[:2] and abs(res[2] - ref[2]) <= 1e-9 * ref[2]
     assert np.abs(xs - xo).max() <= 1e-12 * np.abs(xo).max()
+
+
+def test_ssor_levels_by_relaxation_fallback():
+    """The level schedule comes from Kahn's algorithm on the device; the relaxation sweeps it replaced remain as the
+    fallback for dependency graphs deeper than its counter table (PSP_SSOR_KAHN=0 selects them; read once per process):
+    the bit-exactness tests of this file once more in a fresh interpreter with that switch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PSP_SSOR_KAHN="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", here, "-k",
+                        "bit_exact and not relaxation"], env=env, cwd=os.path.dirname(os.path.dirname(here)),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
