@@ -82,6 +82,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--count", type=int, default=60)
 ap.add_argument("--seconds", type=float, default=400.0)
+ap.add_argument("--ssor", action="store_true", help="also the sss form + precon.ssor on the SPD cases up to n = 40000")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 t0 = time.time()
@@ -121,6 +122,31 @@ for it in range(a.count):
                 print("MISMATCH", name, desc, kern, got, ref, err, flush=True)
                 sys.exit(1)
             msg += " %s %d/%d %.1e" % (name, got[1], ref[1], err)
+    if spd and a.ssor and n <= 40000:
+        # the same matrix as an sss_mat: product + precon.ssor (level schedule by Kahn's algorithm) against the oracle
+        low = A.col < np.repeat(np.arange(n), np.diff(A.ind))
+        rows = np.repeat(np.arange(n), np.diff(A.ind))
+        lind = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rows[low], minlength=n), out=lind[1:])
+        dg = A.val[A.col == rows]
+        So = O.SSS(n, np.ascontiguousarray(A.val[low]), np.ascontiguousarray(dg), np.ascontiguousarray(A.col[low]), lind)
+        Sd = dev.DeviceSSS.from_arrays(n, So.ind, So.col, So.val, So.diag)
+        ys, yso = np.full(n, np.nan), np.empty(n)
+        Sd.matvec(x, ys)
+        So.matvec(x, yso)
+        if not np.array_equal(ys, yso):
+            print("MISMATCH sss y", desc, Sd.kernel_info(), flush=True)
+            sys.exit(1)
+        for omega in (1.0, 1.3):
+            K = dev.DeviceSSOR(Sd, omega, 1)
+            z, zo = np.full(n, np.nan), np.zeros(n)
+            K.precon(x, z)
+            O.ssor_apply(So, x, zo, omega, 1)
+            if not np.array_equal(z, zo):
+                print("MISMATCH ssor", desc, omega, K.levels, flush=True)
+                sys.exit(1)
+        msg += " ssor levels %s" % (K.levels,)
+        Sd.close()
     D.close()
     print(it, desc, kern, info["nb"], info["max_blocks"], msg, flush=True)
 print("kernels:", kinds, "seconds %.0f" % (time.time() - t0))
