@@ -2781,6 +2781,8 @@ namespace psp {
 int reorder_rcm_host(int n, const int *ind, const int *col, const double *val, std::vector<int> &perm,
                      std::vector<int> &rind, std::vector<int> &rcol, std::vector<double> &rval);
 int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, int **inv_dev, int *status);
+int reorder_symmetrize_device(int n, int nnz, const int *ind, const int *col, int **sind_out, int **scol_out,
+                              long *snnz, int *ok);
 int reorder_build_device(int n, const int *ind, const int *col, const double *val, const int *perm_dev,
                          const int *inv_dev, int *rind, int *rcol, double *rval);
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);
@@ -2821,7 +2823,22 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
   }();
   int *dperm = nullptr, *dinv = nullptr;
   int on_device = 0;
-  if (!host_forced) PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
+  if (!host_forced) {
+    PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
+    if (on_device < 0) {  // unsymmetric pattern or unsorted rows: number the pattern of A + A^T, built on the device
+      int *sind = nullptr, *scol = nullptr, ok_sym = 0;
+      long snnz = 0;
+      on_device = 0;
+      PSP_TRY(psp::reorder_symmetrize_device(n, A->nnz, A->ind, A->col, &sind, &scol, &snnz, &ok_sym));
+      if (ok_sym) {
+        const int rc_sym = psp::reorder_rcm_device(n, sind, scol, &dperm, &dinv, &on_device);
+        (void)hipFree(sind);
+        (void)hipFree(scol);
+        PSP_TRY(rc_sym);
+        if (on_device < 0) on_device = 0;
+      }
+    }
+  }
   psp_csr *R = nullptr;
   int rc = alloc_csr(n, n, (long)nnz, &R);
   if (rc != PSP_OK) {  // no room: stay with the gather kernels

@@ -469,6 +469,34 @@ __global__ __launch_bounds__(256) void rcm_copy_rows_kernel(int n, const int *__
   }
 }
 
+// ---- pattern of A + A^T on the device (unsymmetric patterns, unsorted rows): every entry (r, c), c != r, gives the
+// keys r*2^32 + c and c*2^32 + r; sorted and made unique they are the rows of the symmetrised pattern, ascending
+__global__ __launch_bounds__(256) void sym_keys_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
+                                                       unsigned long long *__restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+  if (r >= n) return;
+  for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) {
+    const int c = col[k];
+    // entries on the diagonal (and out-of-range columns, which a square operator does not have) map to the
+    // all-ones key, which sorts last and is dropped
+    const bool keep = c != r && c >= 0 && c < n;
+    keys[2 * (size_t)k] = keep ? ((unsigned long long)(unsigned)r << 32) | (unsigned)c : ~0ull;
+    keys[2 * (size_t)k + 1] = keep ? ((unsigned long long)(unsigned)c << 32) | (unsigned)r : ~0ull;
+  }
+}
+
+// from the sorted unique keys: scol[i] and the row offsets (rows without entries included)
+__global__ __launch_bounds__(256) void sym_rows_kernel(long m, int n, const unsigned long long *__restrict__ keys,
+                                                       int *__restrict__ sind, int *__restrict__ scol) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i > m) return;
+  const int lo = i == 0 ? 0 : (int)(keys[i - 1] >> 32) + 1;  // rows (prev, cur] start at i
+  const int hi = i == m ? n : (int)(keys[i] >> 32);
+  for (int r = lo; r <= hi; ++r) sind[r] = (int)i;
+  if (i < m) scol[i] = (int)(keys[i] & 0xffffffffull);
+}
+
 struct DevBuf {  // frees on scope exit
   void *p = nullptr;
   ~DevBuf() {
@@ -486,9 +514,9 @@ struct DevBuf {  // frees on scope exit
 namespace psp {
 
 // The numbering on the device.  *status: 1 = perm_dev / inv_dev hold it (n ints each, hipMalloc'ed, the caller
-// frees); 0 = not done -- the pattern is not structurally symmetric with ascending rows, or the graph has more
-// levels / components than the device loop is willing to walk (one host look per level): the caller takes the
-// host path above.
+// frees); -1 = the pattern is not structurally symmetric with ascending rows (reorder_symmetrize_device gives one
+// that is); 0 = not done -- the graph has more levels / components than the device loop is willing to walk (one
+// host look per level): the caller takes the host path above.
 int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, int **inv_dev, int *status) {
   *status = 0;
   *perm_dev = *inv_dev = nullptr;
@@ -524,7 +552,10 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
     int res[8];
     PSP_HIP(hipMemcpyAsync(res, d_ok, sizeof(res), hipMemcpyDeviceToHost, st));
     PSP_HIP(hipStreamSynchronize(st));
-    if (!res[0]) return PSP_OK;
+    if (!res[0]) {
+      *status = -1;  // not structurally symmetric with ascending rows: reorder_symmetrize_device first
+      return PSP_OK;
+    }
     // hubs (see struct Graph): the same threshold and the same 1 % rule as the host code
     long long degsum = 0;
     memcpy(&degsum, res + 6, sizeof(degsum));
@@ -670,6 +701,68 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
   *perm_dev = perm;
   *inv_dev = inv;
   *status = 1;
+  return PSP_OK;
+}
+
+// Pattern of A + A^T without the diagonal as a CSR pair on the device (sind: n + 1 ints, scol: *snnz ints, both
+// hipMalloc'ed, the caller frees); *ok = 0 when there is no room for the scratch (8 bytes x 4 per entry)
+int reorder_symmetrize_device(int n, int nnz, const int *ind, const int *col, int **sind_out, int **scol_out,
+                              long *snnz, int *ok) {
+  *ok = 0;
+  *sind_out = *scol_out = nullptr;
+  hipStream_t st = stream();
+  const size_t nk = 2 * (size_t)nnz;
+  if (nk >= 0x7fffffffull) return PSP_OK;
+  DevBuf b_keys, b_sorted, b_uniq, b_tmp, b_cnt;
+  if (b_keys.alloc(sizeof(unsigned long long) * nk) != hipSuccess ||
+      b_sorted.alloc(sizeof(unsigned long long) * nk) != hipSuccess ||
+      b_uniq.alloc(sizeof(unsigned long long) * nk) != hipSuccess || b_cnt.alloc(sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSP_OK;
+  }
+  unsigned long long *keys = b_keys.as<unsigned long long>(), *sorted = b_sorted.as<unsigned long long>();
+  unsigned long long *uniq = b_uniq.as<unsigned long long>();
+  if (nnz > 0) {
+    hipLaunchKernelGGL(sym_keys_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, ind, col, keys);
+    PSP_LAUNCH_CHECK();
+  }
+  int bits = 1;
+  while (bits < 32 && (1L << bits) < n) ++bits;
+  size_t b1 = 0, b2 = 0;
+  // (the all-ones keys of dropped entries need all 64 bits to sort last)
+  PSP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, b1, keys, sorted, (int)nk, 0, 64, st));
+  PSP_HIP(hipcub::DeviceSelect::Unique(nullptr, b2, sorted, uniq, b_cnt.as<int>(), (int)nk, st));
+  if (b_tmp.alloc(std::max(b1, b2)) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSP_OK;
+  }
+  size_t tb = std::max(b1, b2);
+  PSP_HIP(hipcub::DeviceRadixSort::SortKeys(b_tmp.p, tb, keys, sorted, (int)nk, 0, 64, st));
+  tb = std::max(b1, b2);
+  PSP_HIP(hipcub::DeviceSelect::Unique(b_tmp.p, tb, sorted, uniq, b_cnt.as<int>(), (int)nk, st));
+  int m = 0;
+  PSP_HIP(hipMemcpyAsync(&m, b_cnt.as<int>(), sizeof(int), hipMemcpyDeviceToHost, st));
+  PSP_HIP(hipStreamSynchronize(st));
+  if (m > 0) {  // the all-ones key, if any entry was dropped, is the last one
+    unsigned long long last = 0;
+    PSP_HIP(hipMemcpy(&last, uniq + (m - 1), sizeof(last), hipMemcpyDeviceToHost));
+    if (last == ~0ull) --m;
+  }
+  int *sind = nullptr, *scol = nullptr;
+  if (hipMalloc((void **)&sind, sizeof(int) * ((size_t)n + 1)) != hipSuccess ||
+      hipMalloc((void **)&scol, sizeof(int) * (size_t)(m ? m : 1)) != hipSuccess) {
+    if (sind) (void)hipFree(sind);
+    (void)hipGetLastError();
+    return PSP_OK;
+  }
+  hipLaunchKernelGGL(sym_rows_kernel, dim3((unsigned)(((long)m + 1 + 255) / 256)), dim3(256), 0, st, (long)m, n, uniq, sind,
+                     scol);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(st));
+  *sind_out = sind;
+  *scol_out = scol;
+  *snnz = m;
+  *ok = 1;
   return PSP_OK;
 }
 

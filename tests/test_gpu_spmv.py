@@ -552,15 +552,15 @@ def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
     """The reverse Cuthill-McKee numbering is computed on the device for structurally symmetric patterns
     (psp_reorder.hip: level-synchronous, every tie decided by (degree, id)) and on the host otherwise; the two
     implement the same rules, so a fresh process with PSP_SPMV_REORDER_HOST=1 must produce the identical
-    permutation -- one component, several components with isolated rows, and an unsymmetric pattern (which the
-    device path declines: both processes then run the host code).  y has the oracle's bits either way."""
+    permutation -- one component, several components with isolated rows, hub rows, and an unsymmetric pattern (the
+    device path numbers the pattern of A + A^T, which it forms itself).  y has the oracle's bits either way."""
     import subprocess
     import sys
     from tests.renumber_helper import case_arrays, renumbering_of
     kern, perm, y, where = renumbering_of(name)
     n, ind, col, val = case_arrays(name)
     assert kern == "csr_spmv_w3_rcm" and perm is not None
-    assert where == ("host" if name == "unsymmetric" else "device")
+    assert where == "device"  # also the unsymmetric pattern: A + A^T is formed on the device first
     assert np.array_equal(np.sort(perm), np.arange(n))
     yo = np.empty(n)
     oracle.CSR((n, n), val, col, ind).matvec(np.random.default_rng(5).standard_normal(n), yo)

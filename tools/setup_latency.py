@@ -16,6 +16,8 @@ from pysparse_amd.tools.standins import fem_sss_arrays  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shuffle", type=int, default=512)
+ap.add_argument("--unsym", action="store_true", help="the stand-in as a csr_mat with every 7th upper entry dropped "
+                                                     "(unsymmetric pattern: A + A^T is formed before the numbering)")
 ap.add_argument("--others", action="store_true", help="also: generated 512^3 csr / sss, 256^3 csr from host arrays, "
                                                       "the log-spaced stand-in")
 a = ap.parse_args()
@@ -69,8 +71,19 @@ if a.others:
     S.close()
 n, ind, col, val, diag = fem_sss_arrays(68, 68, 67, a.shuffle, 0)
 res = {"n": n, "nnz_lower": len(col), "shuffle": a.shuffle}
+if a.unsym:
+    from pysparse_amd.distributed import sss_rows_expanded
+    f_ind, f_col, f_val = sss_rows_expanded(n, ind, col, val, diag)
+    rows = np.repeat(np.arange(n), np.diff(f_ind))
+    upper = np.nonzero(f_col > rows)[0]
+    keep = np.ones(f_col.size, dtype=bool)
+    keep[upper[::7]] = False
+    f_col, f_val, rows = f_col[keep], f_val[keep], rows[keep]
+    f_ind = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=f_ind[1:])
+    res["unsymmetric_csr_nnz"] = int(f_col.size)
 t = time.perf_counter()
-S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+S = dev.DeviceCSR.from_arrays((n, n), f_ind, f_col, f_val) if a.unsym else dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
 check(L.psp_synchronize())
 res["create_s"] = time.perf_counter() - t
 x = np.random.default_rng(1).standard_normal(n)
@@ -80,6 +93,11 @@ for k in ("first_matvec_s", "second_matvec_s"):
     S.matvec(x, y)
     res[k] = time.perf_counter() - t
 res["kernel"] = S.kernel_info()[0]
+if a.unsym:
+    S.renumbering()
+    res["numbered_on"] = S.renumbered_on
+    print(json.dumps(res), flush=True)
+    sys.exit(0)
 b = np.zeros(n)
 b[0] = 1.0
 K = dev.DeviceJacobi(S)
