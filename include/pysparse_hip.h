@@ -167,7 +167,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
  *   to right (csr_mat.c:49-54), so the choice never changes a bit of y. */
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
 /* The renumbering behind "csr_spmv_w3_rcm" (irregular square operators): perm_host[new] = old row
- * (nrows ints) and *available = 2 (numbering computed on the device) or 1 (on the host: unsymmetric pattern) when
+ * (nrows ints) and *available = 2 (numbering computed on the device) or 1 (on the host: fallback, A/B switch) when
  * psp_csr_kernel_info / a product has built one for this handle; *available = 0 otherwise (perm_host untouched).
  * Diagnostic: no product needs it. */
 int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available);

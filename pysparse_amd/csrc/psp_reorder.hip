@@ -5,10 +5,10 @@
 // (FEM meshes as they come out of a mesh generator, shuffled node ids) breaks that: the same matrix
 // references 100-140 blocks per chunk and falls back to csr_spmv_w2, whose x gathers are bound by the
 // per-CU L1 (0.61-0.67 of the HBM roofline, profiles/r1_fem_standin.txt).  This file computes a reverse
-// Cuthill-McKee numbering once per handle -- on the device for structurally symmetric patterns (reorder_rcm_device:
-// 48 ms to the first product at n = 9.3e5, 41 M nonzeros), on the host otherwise (reorder_rcm_host: 1.25 s for the
-// same matrix; same rules, same permutation) -- and builds the symmetrically permuted matrix R = P A P^T as a
-// second device handle:
+// Cuthill-McKee numbering once per handle -- on the device (reorder_rcm_device: 36-48 ms to the first product at
+// n = 9.3e5, 41 M nonzeros; an unsymmetric pattern is symmetrised on the device first), with the host code it
+// replaced (reorder_rcm_host: 1.25 s for the same matrix; same rules, same permutation) as the fallback for graphs
+// with very many levels -- and builds the symmetrically permuted matrix R = P A P^T as a second device handle:
 //     row i of R   = row perm[i] of A, entries in A's stored order (NOT re-sorted: the reference adds a
 //                    row's products left to right, csr_mat.c:49-54, and so must we -- same products,
 //                    same order, same bits in y);
