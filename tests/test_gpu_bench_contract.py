@@ -53,10 +53,13 @@ def test_bench_json_contract_small_grid():
     assert d["sss_mat"]["kernel"] == "sss_spmv_w4" and d["sss_mat"]["frac"] <= 1.0
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9  # tol = 0: exactly 8 iterations
     assert d["pcg_iters_per_s"] > 0 and d["value"] > 0
-    # roofline.traffic: measured by rocprofv3 --pmc child runs of the same operator in this job
-    assert r["traffic_source"] and r["traffic_source"].startswith("measured in this job"), r["traffic_source"]
-    assert 0.5 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 2.0 * r["algorithmic_bytes_per_launch"]
-    assert r["traffic_counters"]["fetch_correction"] == 2.0
+    # roofline.traffic: measured by rocprofv3 --pmc child runs of the same operator in this job -- where the box lets
+    # an ordinary user read the counters; otherwise null (no committed pass exists for this grid), never a guess
+    if r["traffic_source"] and r["traffic_source"].startswith("measured in this job"):
+        assert 0.5 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 2.0 * r["algorithmic_bytes_per_launch"]
+        assert r["traffic_counters"]["fetch_correction"] == 2.0
+    else:
+        assert r["traffic"] is None
     c = d["device_ceiling_same_run"]
     assert c["read_only_dot"]["bytes"] == 16 * n and c["read2_write1"]["bytes"] == 24 * n
     assert c["read_only_dot"]["GBps"] > 0 and c["read2_write1"]["GBps"] > 0
