@@ -18,6 +18,10 @@ What is pinned, and by what:
                      analytic invariants the reference's tests assert
                      (test/test_spmatrix.py:77-78,186-187).
   tendigit.json      K1: examples/tendigit.py known answer (Trefethen challenge #7).
+  ref_krylov.json    the module's OWN six kernels -- pysparse/itsolvers/src/{pcg,minres,cgs,bicgstab,
+                     qmrs,gmres}.c compiled unmodified into oracle/_ref/libref_krylov.so -- on the
+                     cases of tests/krylov_cases.py: info / iter / relres / kernel return value and
+                     samples of x; ref_krylov_iterates.npz holds whole x vectors.
 """
 import json
 import os
@@ -32,6 +36,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import krylov_cases as KC  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -49,9 +56,39 @@ def run_ref(A, b, tol, maxit, dinv=None):
     return x, {"info": info, "iter": it, "relres": relres, "x": samples(x)}
 
 
+def _num(v):
+    """JSON has no NaN: spell it"""
+    return "nan" if v != v else float(v)
+
+
+def krylov_goldens():
+    """tests/golden/ref_krylov.json + ref_krylov_iterates.npz from oracle/_ref/libref_krylov.so"""
+    out, iterates = {}, {}
+    whole_big = {"minres_csr_1e-08_none", "minres_sss_1e-12_jacobi", "minres_fixed_10", "minres_fixed_50",
+                 "minres_fixed_jacobi_10", "pcg_fixed_50"}
+    for name, case in KC.CASES.items():
+        info, it, rr, x, rc = KC.run_reference(O, case)
+        e = {"info": info, "iter": it, "relres": _num(rr), "rc": rc}
+        if np.isfinite(x).all():
+            e["x"] = samples(x)
+            if len(x) <= 3000 or name in whole_big:
+                iterates[name] = x
+        else:
+            e["x"] = "nan" if np.isnan(x).all() else "nonfinite"
+        out[name] = {"case": case, "expect": e}
+    with open(os.path.join(OUT, "ref_krylov.json"), "w") as f:
+        json.dump({"source": "pysparse/itsolvers/src/{pcg,minres,cgs,bicgstab,qmrs,gmres}.c compiled unmodified "
+                             "(oracle/Makefile: _ref/libref_krylov.so, OpenBLAS BLAS-1, one thread)",
+                   "cases": out}, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "ref_krylov_iterates.npz"), **iterates)
+
+
 def main():
     O.build(ref=True)
     os.makedirs(OUT, exist_ok=True)
+    krylov_goldens()
+    if "--krylov-only" in sys.argv:
+        return
     cases = {}
     iterates = {}
 

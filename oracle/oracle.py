@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_LIB_PATH = os.path.join(REF_DIR, "libref_pcg.so")
 REF_BIN_PATH = os.path.join(REF_DIR, "poisson_test")
+REF_KRYLOV_PATH = os.path.join(REF_DIR, "libref_krylov.so")
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, ndim=1, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, ndim=1, flags="C_CONTIGUOUS")
@@ -29,6 +30,8 @@ def build(ref=None):
     if ref:
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
 
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # the reference is single-threaded; so is its BLAS here
 
 _lib = None
 
@@ -119,6 +122,9 @@ def _declare(L):
     L.orc_bind_sss.argtypes = [C.c_int, _dp, _dp, _ip, _ip]
     L.orc_bind_dinv.restype = None
     L.orc_bind_dinv.argtypes = [C.c_int, _dp]
+    L.orc_solve_cb.restype = C.c_int
+    L.orc_solve_cb.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, ipt, dpt, ipt, _dp,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 # ----------------------------------------------------------------------------- containers
@@ -415,3 +421,106 @@ def ref_pcg(A, b, x, tol, maxit, dinv=None):
     work = np.zeros(4 * n)
     R.pcg(n, x, b, tol, maxit, 0, C.byref(it), C.byref(rr), C.byref(fl), work, mv, pc)
     return REF_FLAG_TO_INFO[fl.value], it.value, rr.value
+
+
+# ----------------------------------------------------------------------------- compiled reference, module kernels
+
+class _CsrCtx(C.Structure):  # orc_csr_t
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("va", C.c_void_p), ("ja", C.c_void_p), ("ia", C.c_void_p)]
+
+
+class _SssCtx(C.Structure):  # orc_sss_t
+    _fields_ = [("n", C.c_int), ("va", C.c_void_p), ("da", C.c_void_p), ("ja", C.c_void_p), ("ia", C.c_void_p)]
+
+
+class _JacobiCtx(C.Structure):  # orc_jacobi_t
+    _fields_ = [("n", C.c_int), ("dinv", C.c_void_p), ("steps", C.c_int), ("temp", C.c_void_p),
+                ("matvec", C.c_void_p), ("mctx", C.c_void_p)]
+
+
+class _SsorCtx(C.Structure):  # orc_ssor_t
+    _fields_ = [("n", C.c_int), ("va", C.c_void_p), ("da", C.c_void_p), ("ja", C.c_void_p), ("ia", C.c_void_p),
+                ("omega", C.c_double), ("steps", C.c_int), ("temp", C.c_void_p), ("temp2", C.c_void_p)]
+
+
+REF_SOLVERS = {"pcg": 0, "minres": 1, "cgs": 2, "bicgstab": 3, "qmrs": 4, "gmres": 5}
+_refk = None
+
+
+def have_ref_krylov():
+    return os.path.exists(REF_KRYLOV_PATH)
+
+
+def ref_krylov_lib():
+    """oracle/_ref/libref_krylov.so = pysparse/itsolvers/src/{pcg,minres,cgs,bicgstab,qmrs,gmres}.c
+    compiled unmodified + oracle/ref_krylov_harness.c (the itsolvers_spmatrix table)."""
+    global _refk
+    if _refk is None:
+        _refk = C.CDLL(REF_KRYLOV_PATH)
+        ipt, dpt = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        _refk.refk_solve.restype = C.c_int
+        _refk.refk_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, ipt, dpt, ipt, _dp,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    return _refk
+
+
+def _operator_ctx(A):
+    """(callback address, context struct, keep-alive list) of the oracle's matvec for A."""
+    L = lib()
+    if isinstance(A, CSR):
+        ctx = _CsrCtx(A.shape[0], A.shape[1], A.val.ctypes.data, A.col.ctypes.data, A.ind.ctypes.data)
+        return C.cast(L.orc_csr_matvec_cb, C.c_void_p), ctx
+    ctx = _SssCtx(A.n, A.val.ctypes.data, A.diag.ctypes.data, A.col.ctypes.data, A.ind.ctypes.data)
+    return C.cast(L.orc_sss_matvec_cb, C.c_void_p), ctx
+
+
+def _precon_ctx(A, K, mv, mctx):
+    """(callback address, context struct, keep-alive list) for K = None | ("jacobi", dinv[, steps]) |
+    ("ssor", omega, steps) -- the oracle's restatements of preconmodule.c"""
+    L = lib()
+    n = A.shape[0]
+    if K is None:
+        return None, None, []
+    if K[0] == "jacobi":
+        dinv = np.ascontiguousarray(K[1], dtype=np.float64)
+        steps = K[2] if len(K) > 2 else 1
+        temp = np.zeros(max(n, 1))
+        ctx = _JacobiCtx(n, dinv.ctypes.data, steps, temp.ctypes.data, mv, C.addressof(mctx))
+        return C.cast(L.orc_jacobi_apply, C.c_void_p), ctx, [dinv, temp]
+    if K[0] == "ssor":
+        assert isinstance(A, SSS)
+        t1, t2 = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        ctx = _SsorCtx(A.n, A.val.ctypes.data, A.diag.ctypes.data, A.col.ctypes.data, A.ind.ctypes.data,
+                       float(K[1]), int(K[2]), t1.ctypes.data, t2.ctypes.data)
+        return C.cast(L.orc_ssor_apply, C.c_void_p), ctx, [t1, t2]
+    raise ValueError(K[0])
+
+
+def _solve_cb(fn, has_fail, solver, A, b, x, tol, maxit, K, dim, fails=()):
+    n = A.shape[0]
+    mv, mctx = _operator_ctx(A)
+    pc, pctx, keep = _precon_ctx(A, K, mv, mctx)
+    it, info, rr = C.c_int(0), C.c_int(0), C.c_double(np.nan)
+    work = np.zeros(8 * max(n, 1))
+    bb = np.ascontiguousarray(b, dtype=np.float64).copy()  # the reference kernels take a non-const b
+    args = [REF_SOLVERS[solver], n, x, bb, tol, maxit, dim, C.byref(it), C.byref(rr), C.byref(info), work,
+            mv, C.addressof(mctx), pc, C.addressof(pctx) if pctx is not None else None]
+    rc = fn(*(args + list(fails))) if has_fail else fn(*args)
+    del keep
+    return info.value, it.value, rr.value, rc
+
+
+def ref_krylov(solver, A, b, x, tol, maxit, K=None, dim=20, mv_fail_after=-1, pc_fail_after=-1):
+    """info, iter, relres, rc = the COMPILED REFERENCE kernel `solver` (module sources, unmodified) on
+    operator A (CSR or SSS; the matvec is the oracle's restatement -- csr_mat.c / sss_mat.c do not
+    compile here) with K = None, ("jacobi", dinv[, steps]) or ("ssor", omega, steps) on an SSS matrix.
+    relres comes back NaN when the kernel never wrote it (minres on -3 / -6; minres.c:79-80,158-159).
+    rc is the kernel's own return value (-1 also means "a callback raised", e.g. pcg.c:8-11)."""
+    return _solve_cb(ref_krylov_lib().refk_solve, True, solver, A, b, x, tol, maxit, K, dim,
+                     (mv_fail_after, pc_fail_after))
+
+
+def solve(solver, A, b, x, tol, maxit, K=None, dim=20):
+    """info, iter, relres, rc = the oracle's RESTATEMENT of `solver`, on the same operator / preconditioner
+    contexts and with the same calling convention as ref_krylov."""
+    return _solve_cb(lib().orc_solve_cb, False, solver, A, b, x, tol, maxit, K, dim)

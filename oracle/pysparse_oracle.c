@@ -1350,3 +1350,35 @@ ORC_API int orc_minres_sss(int n, const double *va, const double *da, const int 
   free(work);
   return info;
 }
+
+/* Generic driver with the argument list of refk_solve (oracle/ref_krylov_harness.c), so that the
+ * restatements above and the compiled reference kernels can be run on the very same operator /
+ * preconditioner contexts.  solver: 0 pcg, 1 minres, 2 cgs, 3 bicgstab, 4 qmrs, 5 gmres;
+ * work: 8n doubles.  *info = what the module wrapper would return as `info`. */
+ORC_API int orc_solve_cb(int solver, int n, double *x, const double *b, double tol, int maxit, int dim,
+                         int *iter, double *relres, int *info, double *work, orc_matvec_fn mv,
+                         void *mctx, orc_precon_fn pc, void *pctx) {
+  int rc;
+  switch (solver) {
+  case 0:
+    return orc_pcg(n, x, b, tol, maxit, iter, relres, info, work, mv, mctx, pc, pctx, NULL);
+  case 1:
+    rc = orc_minres(n, tol, maxit, iter, relres, x, b, work, mv, mctx, pc, pctx, NULL);
+    break;
+  case 2:
+    rc = orc_cgs(n, b, x, maxit, tol, work, iter, relres, mv, mctx, pc, pctx);
+    break;
+  case 3:
+    return orc_bicgstab(n, x, b, tol, maxit, iter, relres, info, work, mv, mctx, pc, pctx);
+  case 4:
+    rc = orc_qmrs(n, b, x, work, tol, maxit, iter, relres, mv, mctx, pc, pctx);
+    break;
+  case 5:
+    rc = orc_gmres(n, tol, maxit, iter, relres, dim, x, b, mv, mctx, pc, pctx);
+    break;
+  default:
+    return -101;
+  }
+  *info = rc;
+  return rc;
+}
