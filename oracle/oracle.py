@@ -369,7 +369,7 @@ _MORE = {"cgs": 0, "bicgstab": 1, "qmrs": 2, "gmres": 3}
 
 
 def krylov_more(solver, A, b, x, tol, maxit, dinv=None, dim=20):
-    """cgs / bicgstab / qmrs / gmres restatements (parity UNPINNED, see pysparse_oracle.c)."""
+    """cgs / bicgstab / qmrs / gmres restatements (pinned by oracle/_ref/libref_krylov.so, see pysparse_oracle.c)."""
     n = A.shape[0]
     it, rr = C.c_int(0), C.c_double(0.0)
     info = lib().orc_krylov_more(_MORE[solver], n, A.val, _opt(A.diag) if isinstance(A, SSS) else None, A.col, A.ind,

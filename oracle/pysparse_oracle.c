@@ -8,11 +8,18 @@
  *
  * Parity status: PINNED.  Every solver routine below is checked (tests/
  * test_oracle_*.py, oracle/make_golden.py) against
- *   (1) the reference's own compilable PCG kernel, examples/poisson_test/pcg.c,
- *       built unmodified into oracle/_ref/ by oracle/Makefile and driven through
- *       the bound-callback shims at the bottom of this file, and
- *   (2) the golden vectors committed under tests/golden/ that were produced by
- *       that build (G1..G5 of BASELINE.md) plus the ten-digit known answer K1.
+ *   (1) the reference's own six Krylov kernels, pysparse/itsolvers/src/{pcg,minres,cgs,
+ *       bicgstab,qmrs,gmres}.c, compiled unmodified into oracle/_ref/libref_krylov.so
+ *       (oracle/Makefile + oracle/ref_krylov_harness.c, which supplies the reference's
+ *       itsolvers_spmatrix callback table), and the standalone examples/poisson_test/
+ *       pcg.c built the same way into oracle/_ref/libref_pcg.so, and
+ *   (2) the golden vectors committed under tests/golden/ that those builds produced
+ *       (ref_krylov.json: 104 cases over the six solvers; ref_pcg.json: G1..G5 of
+ *       BASELINE.md) plus the ten-digit known answer K1.
+ * The matrix-vector products and the preconditioners (csr_mat.c, sss_mat.c,
+ * preconmodule.c) do not compile in this image (numpy/noprefix.h, Python-2 C API):
+ * they are restated here from the cited lines and are what the compiled kernels are
+ * driven with.
  *
  * Each function cites the reference file:line (relative to /root/reference) whose
  * arithmetic -- operation order included -- it restates.  Plain C, single thread,
@@ -903,11 +910,12 @@ ORC_API long orc_poisson_sss(int nx, int ny, int nz, double *val, double *diag, 
 /* ============================================================================
  * The four other Krylov kernels of pysparse/itsolvers.
  *
- * Parity status of THIS block: UNPINNED.  The reference ships no compilable copy of
- * these kernels (bicgstab.c, cgs.c, qmrs.c, gmres.c need the Python-2 C API) and no
- * golden vectors for them; the functions below restate the published loops line by
- * line and are checked only against each other, against PCG on SPD systems and
- * against direct solves (tests/test_oracle_krylov_more.py).
+ * Parity status of THIS block: PINNED (round 3).  cgs.c, bicgstab.c, qmrs.c and gmres.c
+ * compile unmodified against the image's Python.h / NumPy headers and need only BLAS-1
+ * and the itsolvers_spmatrix table at link time: oracle/Makefile builds them into
+ * oracle/_ref/libref_krylov.so (harness: oracle/ref_krylov_harness.c), tests/golden/
+ * ref_krylov.json holds what they return on the cases of tests/krylov_cases.py, and
+ * tests/test_oracle_krylov_golden.py checks every function below against both.
  * ==========================================================================*/
 
 ORC_API void orc_dscal(int n, double a, double *x) {

@@ -2199,7 +2199,7 @@ struct ScratchDev {
 // block lists + 16-bit columns of csr_spmv_w3 (built on first use; needs the w2 tables)
 static int w3_nb_cap() {
   static const int cap = [] {
-    const char *e = getenv("PSP_SPMV_W3_NB");  // largest block list tried (32 / 64 / 128), 0 = never
+    const char *e = psp::tuning_env("PSP_SPMV_W3_NB");  // largest block list tried (32 / 64 / 128), 0 = never
     return e ? atoi(e) : 64;
   }();
   return cap;
@@ -2226,7 +2226,7 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   // a matrix that is banded except for a few rows (constraint / boundary rows, a handful of long-range
   // couplings) keeps the LDS-staged kernel: up to 2 % of the chunks may be outliers (PSP_SPMV_W3_OUTLIERS=0: none)
   static const bool outl_on = [] {
-    const char *e = getenv("PSP_SPMV_W3_OUTLIERS");
+    const char *e = psp::tuning_env("PSP_SPMV_W3_OUTLIERS");
     return e ? atoi(e) != 0 : true;
   }();
   // (the shorter list is worth having: the 64-slot kernel is ~4 % slower on a matrix that fits 32)
@@ -2292,7 +2292,7 @@ static int ensure_w5(const psp_csr *A, ChunkTable *t) {
   if (t->nu >= 0) return PSP_OK;
   t->nu = 0;
   static const bool off = [] {
-    const char *e = getenv("PSP_SPMV_W5");
+    const char *e = psp::tuning_env("PSP_SPMV_W5");
     return e && atoi(e) == 0;
   }();
   if (off || t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
@@ -2375,7 +2375,7 @@ static int sched_strip_rows() {
     // schedule cuts fabric reads from 13.2 to 11.3 GB per launch (L2 hits 29 M -> 44 M) and is
     // 0.5-10 % SLOWER -- the re-fetches it removes were Infinity-Cache hits, and DRAM bytes, not
     // fabric bytes, bound the kernel (profiles/r1_spmv_w3_schedule.txt)
-    const char *e = getenv("PSP_SPMV_STRIP_ROWS");
+    const char *e = psp::tuning_env("PSP_SPMV_STRIP_ROWS");
     return e ? atoi(e) : 0;
   }();
   return v;
@@ -2452,7 +2452,7 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   if (ex.dia_state >= 0) return PSP_OK;
   ex.dia_state = 0;
   static const bool off = [] {
-    const char *e = getenv("PSP_SPMV_W4");
+    const char *e = psp::tuning_env("PSP_SPMV_W4");
     return e && atoi(e) == 0;
   }();
   if (off || A->nrows < 1 || A->ncols < 2 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
@@ -2583,7 +2583,7 @@ static int ensure_sss_w4(psp_sss *S) {
   if (S->w4_state >= 0) return PSP_OK;
   S->w4_state = 0;
   static const bool off = [] {
-    const char *e = getenv("PSP_SSS_W4");
+    const char *e = psp::tuning_env("PSP_SSS_W4");
     return e && atoi(e) == 0;
   }();
   if (off || S->n < 2 || S->nnz_lower < 1) return PSP_OK;
@@ -2651,7 +2651,7 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
   hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
                      S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv, xdiv_dev)
   static const bool shfl = [] {
-    const char *e = getenv("PSP_SSS_SHFL");  // A/B: 0 = every offset by its own loads (round 1)
+    const char *e = psp::tuning_env("PSP_SSS_SHFL");  // A/B: 0 = every offset by its own loads (round 1)
     return e ? atoi(e) != 0 : true;
   }();
 #define PSP_SW4(NOL)                                                                                 \
@@ -2799,14 +2799,14 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     ex->orig_max_blocks = orig_max_blocks;
   }
   static const bool off = [] {
-    const char *e = getenv("PSP_SPMV_REORDER");
+    const char *e = psp::tuning_env("PSP_SPMV_REORDER");
     return e && atoi(e) == 0;
   }();
   // worth it when the gather pass (20 n bytes) is small against the matrix stream (12 nnz); the numbering is
   // computed on the host from a copy of the arrays (seconds and 30 bytes of host memory per nonzero): not attempted
   // beyond PSP_SPMV_REORDER_MAX_NNZ nonzeros (default 3e8)
   static const long max_nnz = [] {
-    const char *e = getenv("PSP_SPMV_REORDER_MAX_NNZ");
+    const char *e = psp::tuning_env("PSP_SPMV_REORDER_MAX_NNZ");
     return e ? atol(e) : 300000000L;
   }();
   if (off || A->no_reorder || A->w4_only || A->nrows != A->ncols || A->nrows < 1024 ||
@@ -2818,7 +2818,7 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
   // milliseconds at n = 1e6), else on the host from a copy of the arrays (a second or more; also what
   // PSP_SPMV_REORDER_HOST=1 forces -- the two give the same permutation, tests/test_gpu_spmv.py)
   static const bool host_forced = [] {
-    const char *e = getenv("PSP_SPMV_REORDER_HOST");
+    const char *e = psp::tuning_env("PSP_SPMV_REORDER_HOST");
     return e && atoi(e) != 0;
   }();
   int *dperm = nullptr, *dinv = nullptr;
@@ -2914,7 +2914,7 @@ namespace psp {
 static int colmask() {
 #ifdef PSP_TUNING
   static const int m = [] {
-    const char *e = getenv("PSP_SPMV_COLMASK");
+    const char *e = psp::tuning_env("PSP_SPMV_COLMASK");
     return e ? atoi(e) : -1;
   }();
   return m;
@@ -2926,7 +2926,7 @@ static int colmask() {
 // workgroups per XCD stripe of csr_spmv_w1 (0 = plain dispatch order); PSP_SPMV_STRIPE overrides
 static int spmv_stripe() {
   static const int m = [] {
-    const char *e = getenv("PSP_SPMV_STRIPE");
+    const char *e = psp::tuning_env("PSP_SPMV_STRIPE");
     return e ? atoi(e) : -1;
   }();
   return m;
@@ -3062,7 +3062,7 @@ static int launch_reordered(const psp_csr *A, psp::CsrExtra *ex, int stripe, con
   double *xp = ex->xp, *yp = ex->xp + n;
   // the permutations as scatters (one load round trip instead of two dependent ones); PSP_SPMV_REORDER_GATHER=1: A/B
   static const bool gather_form = [] {
-    const char *e = getenv("PSP_SPMV_REORDER_GATHER");
+    const char *e = psp::tuning_env("PSP_SPMV_REORDER_GATHER");
     return e && atoi(e) != 0;
   }();
   if (gather_form) PSP_TRY(psp::reorder_gather(n, ex->perm, x, xp, skip));
@@ -3094,7 +3094,7 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
                            int *nparts, int *available, const int *skip, const double *xdiv_dev) {
   *available = 0;
   static const bool on = [] {
-    const char *e = getenv("PSP_MINRES_SCALED");
+    const char *e = psp::tuning_env("PSP_MINRES_SCALED");
     return e ? atoi(e) != 0 : true;
   }();
   Variant v = decode_variant(A->variant);
@@ -3148,7 +3148,7 @@ int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv
   // without, alternating processes) -- the 8 bytes per row of DRAM traffic it saves are paid
   // back by reading two arrays instead of one at every neighbour position.  PSP_PCG_PFUSED=1 enables.
   static const bool on = [] {
-    const char *e = getenv("PSP_PCG_PFUSED");
+    const char *e = psp::tuning_env("PSP_PCG_PFUSED");
     return e ? atoi(e) != 0 : false;
   }();
   Variant v = decode_variant(A->variant);
@@ -3895,7 +3895,7 @@ static int create_part(int ncols, int64_t r0, int64_t r1, const int64_t *ind, co
 // nonzeros per part of a partitioned matrix; PSP_PART_NNZ lowers it so that the tests can cut small matrices
 static int64_t part_nnz() {
   static const int64_t v = [] {
-    const char *e = getenv("PSP_PART_NNZ");
+    const char *e = psp::tuning_env("PSP_PART_NNZ");
     const long long t = e ? atoll(e) : 0;
     return (int64_t)((t >= 64 && t < (1LL << 30)) ? t : (1LL << 30));
   }();

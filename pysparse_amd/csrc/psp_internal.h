@@ -13,6 +13,11 @@
 namespace psp {
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// The A/B switches of the kernels and loops (PSP_SPMV_*, PSP_PCG_*, ... -- INTEGRATION.md section 7) are read
+// through this function only: it returns getenv(name) when the process was started with PSP_TUNING=1 and
+// nullptr otherwise, so a stray PSP_* variable in a user's environment cannot change the code path of the
+// drop-in.  Tests and tools that select a variant set both.
+const char *tuning_env(const char *name);
 // One library-wide lock around every compute entry point of the C ABI: the reduction workspace, the
 // stream and the per-handle side tables are process-global, and the extension modules release the GIL
 // around solves (the reference serialises the same calls by holding it).  Recursive: jacobi(steps > 1),

@@ -25,6 +25,14 @@ int fail(int code, const char *fmt, ...) {
 
 const char *last_error() { return g_err.c_str(); }
 
+const char *tuning_env(const char *name) {
+  static const bool on = [] {
+    const char *e = getenv("PSP_TUNING");
+    return e && e[0] == '1' && e[1] == 0;
+  }();
+  return on ? getenv(name) : nullptr;
+}
+
 std::recursive_mutex &api_mutex() {
   static std::recursive_mutex mu;
   return mu;

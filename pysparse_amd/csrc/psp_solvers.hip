@@ -287,7 +287,7 @@ static int pcg_reduce_then(const double *partials, int nparts, int nvals, double
 
 static int pcg_async_enabled() {
   static const int on = [] {
-    const char *e = getenv("PSP_PCG_ASYNC");
+    const char *e = psp::tuning_env("PSP_PCG_ASYNC");
     return e ? atoi(e) : 1;
   }();
   return on;
@@ -298,7 +298,7 @@ static int pcg_async_enabled() {
 // iterations/s) and capture + instantiate costs ~5 ms per solve.  PSP_PCG_GRAPH=1 enables it.
 static int pcg_graph_enabled() {
   static const int on = [] {
-    const char *e = getenv("PSP_PCG_GRAPH");
+    const char *e = psp::tuning_env("PSP_PCG_GRAPH");
     return e ? atoi(e) : 0;
   }();
   return on;
@@ -546,7 +546,7 @@ static int pcg_reduce_then(const double *partials, int nparts, int nvals, double
 
 static int pcg_lazy_enabled() {
   static const int on = [] {
-    const char *e = getenv("PSP_PCG_LAZYX");
+    const char *e = psp::tuning_env("PSP_PCG_LAZYX");
     return e ? atoi(e) : 1;
   }();
   return on;
@@ -845,7 +845,7 @@ struct PermutedSystem {
   int enter(const psp_op *A, const psp_op *K, int n, DevVecs &mem, const double *x, const double *b, int *active) {
     *active = 0;
     static const bool off = [] {
-      const char *e = getenv("PSP_SOLVE_PERMUTED");
+      const char *e = psp::tuning_env("PSP_SOLVE_PERMUTED");
       return e && atoi(e) == 0;
     }();
     psp_csr *Acsr = op_native_csr(A);
@@ -1001,7 +1001,7 @@ static int minres_reduce_then(const double *partials, int nparts, double *out_de
 
 static int minres_async_enabled() {
   static const int on = [] {
-    const char *e = getenv("PSP_MINRES_ASYNC");
+    const char *e = psp::tuning_env("PSP_MINRES_ASYNC");
     return e ? atoi(e) : 1;
   }();
   return on;
@@ -1325,8 +1325,9 @@ static int abs_max(int n, const double *v, double *out) {
 // the four other kernels of pysparse/itsolvers on the same
 // operator protocol and the same device vector ops.  Unfused on purpose: each BLAS-1 call /
 // hand loop of the reference is one kernel with the reference's rounding order, the scalar
-// recurrences run on the host in IEEE double like the C code.  (Parity: checked against the
-// oracle restatement, which for these four solvers is itself unpinned -- DESIGN.md section 7.)
+// recurrences run on the host in IEEE double like the C code.  (Parity: checked against vectors
+// produced by the reference's own cgs.c / bicgstab.c / qmrs.c / gmres.c compiled unmodified --
+// tests/golden/ref_krylov.json, tests/test_gpu_krylov_golden.py)
 
 namespace {
 
@@ -1394,7 +1395,7 @@ static int cgs_device(const psp_op *A, const psp_op *K, int n, double *x, const 
   // daxpy pairs of the reference, quick returns included), v.r0 on the first product: ~17 instead of ~44 vector
   // streams per iteration.  PSP_CGS_FUSED=0 keeps the unfused sequence below (A/B).
   static const bool fuse_on = [] {
-    const char *e = getenv("PSP_CGS_FUSED");
+    const char *e = psp::tuning_env("PSP_CGS_FUSED");
     return e ? atoi(e) != 0 : true;
   }();
   psp_csr *Acsr = op_native_csr(A);
@@ -1498,7 +1499,7 @@ static int bicgstab_device(const psp_op *A, const psp_op *K, int n, double *x, c
   // products, the next rho on the last pass: ~21 instead of 32 vector streams per iteration.
   // PSP_BICGSTAB_FUSED=0 keeps the unfused sequence below (A/B; same iterates up to the order of the dot sums).
   static const bool fuse_on = [] {
-    const char *e = getenv("PSP_BICGSTAB_FUSED");
+    const char *e = psp::tuning_env("PSP_BICGSTAB_FUSED");
     return e ? atoi(e) != 0 : true;
   }();
   psp_csr *Acsr = op_native_csr(A);
@@ -1596,7 +1597,7 @@ static int qmrs_device(const psp_op *A, const psp_op *K, int n, double *x, const
   // rounded operations per element), g.t on the product, K v1 and its dot for the next iteration on the last pass:
   // 17 instead of 25 vector streams per iteration.  PSP_QMRS_FUSED=0 keeps the unfused sequence below (A/B).
   static const bool fuse_on = [] {
-    const char *e = getenv("PSP_QMRS_FUSED");
+    const char *e = psp::tuning_env("PSP_QMRS_FUSED");
     return e ? atoi(e) != 0 : true;
   }();
   psp_csr *Acsr = op_native_csr(A);
@@ -1753,7 +1754,7 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
       // modified Gram-Schmidt (gmres.c:110-116): the axpy of step k and the dot of step k + 1 (at the end: the norm)
       // share one pass over V[i + 1]
       static const bool mgs_fused = [] {
-        const char *e = getenv("PSP_GMRES_FUSED");  // 0: one dot and one axpy kernel per step (A/B)
+        const char *e = psp::tuning_env("PSP_GMRES_FUSED");  // 0: one dot and one axpy kernel per step (A/B)
         return e ? atoi(e) != 0 : true;
       }();
       if (mgs_fused) {

@@ -420,7 +420,7 @@ int build_schedule(const psp_csr *F, int dir, int **rows_out, std::vector<int> *
     // Kahn's algorithm, one launch per level, kLevBatch levels between two looks at the counters
     // (PSP_SSOR_KAHN=0: the relaxation sweeps below, the round-1 method -- same levels)
     static const bool kahn = [] {
-      const char *e = getenv("PSP_SSOR_KAHN");
+      const char *e = psp::tuning_env("PSP_SSOR_KAHN");
       return e ? atoi(e) != 0 : true;
     }();
     bool have_levels = false;
@@ -595,7 +595,7 @@ static void ensure_graph(psp_ssor *K) {
   if (K->graph_state >= 0) return;
   K->graph_state = 0;
   static const bool off = [] {
-    const char *e = getenv("PSP_SSOR_GRAPH");
+    const char *e = psp::tuning_env("PSP_SSOR_GRAPH");
     return e && atoi(e) == 0;
   }();
   const long launches = (long)K->steps * ((long)K->ptr_f.size() + (long)K->ptr_b.size());
@@ -718,7 +718,7 @@ int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
       (void)hipFree(dmax);
       if (rc != PSP_OK) break;
       static const bool ell_off = [] {
-        const char *e = getenv("PSP_SSOR_ELL");
+        const char *e = psp::tuning_env("PSP_SSOR_ELL");
         return e && atoi(e) == 0;
       }();
       int W = 0;

@@ -826,7 +826,7 @@ namespace psp {
 
 int dinv_register(const double *v, long n) {
   static const bool off = [] {
-    const char *e = getenv("PSP_DINV_CONST");
+    const char *e = psp::tuning_env("PSP_DINV_CONST");
     return e && atoi(e) == 0;
   }();
   if (off || !v || n < 1) return PSP_OK;

@@ -92,7 +92,7 @@ print(json.dumps(out))
 
 @pytest.mark.parametrize("part_nnz", [1000, 7777])
 def test_partitioned_csr_small(part_nnz):
-    env = dict(os.environ, PSP_PART_NNZ=str(part_nnz))
+    env = dict(os.environ, PSP_TUNING="1", PSP_PART_NNZ=str(part_nnz))
     p = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])

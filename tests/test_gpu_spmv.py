@@ -566,7 +566,7 @@ def test_device_renumbering_equals_host_renumbering(oracle, name, tmp_path):
     oracle.CSR((n, n), val, col, ind).matvec(np.random.default_rng(5).standard_normal(n), yo)
     assert np.array_equal(y, yo)
     out = str(tmp_path / "host.npz")
-    env = dict(os.environ, PSP_SPMV_REORDER_HOST="1")
+    env = dict(os.environ, PSP_TUNING="1", PSP_SPMV_REORDER_HOST="1")
     subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "renumber_helper.py"), name, out],
                    check=True, env=env, timeout=300)
     h = np.load(out)

@@ -183,7 +183,7 @@ def test_ssor_levels_by_relaxation_fallback():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, PSP_SSOR_KAHN="0")
+    env = dict(os.environ, PSP_TUNING="1", PSP_SSOR_KAHN="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", here, "-k",
                         "bit_exact and not relaxation"], env=env, cwd=os.path.dirname(os.path.dirname(here)),

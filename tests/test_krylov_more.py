@@ -1,7 +1,7 @@
 """cgs / bicgstab / qmrs / gmres.
 
 CPU part: the oracle restatements agree with PCG / a direct solve (their parity against the
-reference is UNPINNED: no compilable reference kernel or golden vector exists for them).
+reference's own compiled kernels is pinned in tests/test_oracle_krylov_golden.py).
 GPU part: the device loops reproduce the oracle's info / iteration counts and iterates."""
 import numpy as np
 import pytest
@@ -142,7 +142,7 @@ def test_gpu_more_solvers_unfused_paths_still_match_oracle():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, PSP_CGS_FUSED="0", PSP_BICGSTAB_FUSED="0", PSP_QMRS_FUSED="0", PSP_GMRES_FUSED="0")
+    env = dict(os.environ, PSP_TUNING="1", PSP_CGS_FUSED="0", PSP_BICGSTAB_FUSED="0", PSP_QMRS_FUSED="0", PSP_GMRES_FUSED="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", here, "-k",
                         "test_gpu_more_solvers_match_oracle"], env=env, cwd=os.path.dirname(os.path.dirname(here)),

@@ -48,6 +48,19 @@ def test_module_surface():
         assert hasattr(spmatrix, name)
     assert callable(krylov.pcg) and callable(krylov.minres) and callable(precon.jacobi)
     assert "pcg(A, b, x, tol, maxit" in krylov.pcg.__doc__
+    assert callable(precon.ssor)
+
+
+def test_package_level_precon_forwarders_warn_and_call_through():
+    """pysparse.precon.jacobi / pysparse.precon.ssor: deprecated forwarders of the reference's package
+    (pysparse/precon/__init__.py:7-17) -- a DeprecationWarning, then the module function's own behaviour"""
+    import pysparse.precon as pkg
+    for name in ("jacobi", "ssor"):
+        fn = getattr(pkg, name)
+        assert fn.__name__ == name
+        with pytest.warns(DeprecationWarning, match="pysparse.precon.precon.%s" % name):
+            with pytest.raises(TypeError):
+                fn()  # argument parsing of the extension function: reached after the warning
 
 
 def test_create_entries_negative_index():

@@ -41,7 +41,7 @@ if __name__ == "__main__":
         print(json.dumps(run()))
     else:
         res = {"device_scalars": run()}
-        env = dict(os.environ, PSP_MINRES_ASYNC="0")
+        env = dict(os.environ, PSP_TUNING="1", PSP_MINRES_ASYNC="0")
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
         res["minres_host_scalars"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else p.stderr[-500:]
         for size, row in res["device_scalars"].items():
