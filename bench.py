@@ -560,6 +560,15 @@ def main():
             ceiling[name] = {"bytes": nbytes, "avg_launch_ms": avg, "GBps": nbytes / (avg * 1e-3) / 1e9}
         zb.free()
         ob.free()
+        # the access shape of the dominant kernel as a plain streaming kernel, in this process: 7 read streams + 1
+        # write stream of 1 GiB each (psp_stream_probe; csr_spmv_w4 on the 7-point operator reads 7 value streams
+        # and writes y).  Round 3: processes / boxes differ by up to 8 % on every store-carrying kernel (DESIGN.md
+        # section 6, profiles/r3_modes.txt); this probe moves with them, so it names the mode a number comes from.
+        import ctypes as _C
+        pa, pm = _C.c_float(), _C.c_float()
+        check(L.psp_stream_probe(7, 1, 1 << 30, 10, _C.byref(pa), _C.byref(pm)))
+        ceiling["read7_write1_probe"] = {"bytes": 8 << 30, "avg_launch_ms": pa.value, "min_launch_ms": pm.value,
+                                         "GBps": (8 << 30) / (pa.value * 1e-3) / 1e9}
 
     clocks = None
     if not a.no_clocks and not dry:
@@ -727,6 +736,17 @@ def main():
                 out["vs_n1"] = (1.0 / pcg_s_per_iter) / strong_n1["pcg_iters_per_s"]
         if ceiling is not None:
             out["device_ceiling_same_run"] = ceiling
+            probe = ceiling.get("read7_write1_probe")
+            if probe:
+                out["roofline"]["stream_ceiling_GBps"] = probe["GBps"]
+                out["roofline"]["frac_of_stream_ceiling"] = achieved / probe["GBps"]
+                out["process_mode"] = {
+                    "read7_write1_GBps": probe["GBps"],
+                    "class": "fast" if probe["GBps"] >= 6200.0 else "slow",
+                    "note": "what a plain 7-read + 1-write streaming kernel reaches in this process; boxes / processes "
+                            "land between ~5.9 and ~6.5 TB/s (profiles/r3_modes.txt) and every store-carrying kernel "
+                            "moves with it",
+                }
         if clocks is not None:
             out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:

@@ -81,6 +81,16 @@ int psp_event_create(void **event);
 int psp_event_destroy(void *event);
 int psp_event_record(void *event);                       /* on the library stream */
 int psp_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+/* measurement hook ("timing hooks (hipEvent ms, bytes moved)"): what this GPU's memory
+ * system gives a plain streaming kernel of a given shape right now, in THIS process -- `reads` (0..8) read
+ * streams and `writes` (0..1) write streams of bytes_per_stream bytes each (a multiple of 4096), one 16-byte
+ * element per thread and stream, one workgroup per 4 KiB span, `reps` timed launches after two untimed ones.
+ * reads = 7, writes = 1 is the access shape of csr_spmv_w4 on the 7-point operator without its x re-reads:
+ * bench.py prints it beside the SpMV as the ceiling of that shape.  The buffers are the call's own. */
+int psp_stream_probe(int reads, int writes, size_t bytes_per_stream, int reps, float *avg_ms, float *min_ms);
+/* hash of the sources this binary was built from (__graft_entry__.source_hash(); "unstamped" for a hand build):
+ * tests compare it with the hash of the sources on disk, so a stale prebuilt library cannot pass for a fresh one */
+const char *psp_build_id(void);
 
 /* ------------------------------------------------------------------ csr_mat */
 

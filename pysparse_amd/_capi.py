@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("PSP_LIB_OVERRIDE") or os.path.join(HERE, "libpysparse
 SYMBOLS = """
 psp_last_error psp_version psp_device_count psp_set_device psp_set_stream psp_synchronize
 psp_device_info psp_mem_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset psp_trim
-psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms
+psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_stream_probe psp_build_id
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
@@ -103,6 +103,7 @@ def _declare(L):
         "psp_memcpy_d2h": [vp, vp, sz], "psp_memset": [vp, i, sz],
         "psp_event_create": [pvp], "psp_event_destroy": [vp], "psp_event_record": [vp],
         "psp_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "psp_stream_probe": [i, i, sz, i, C.POINTER(C.c_float), C.POINTER(C.c_float)],
         "psp_csr_create": [i, i, i, vp, vp, vp, pvp],
         "psp_csr_poisson": [i, i, i, pvp], "psp_csr_poisson_big": [i, i, i, pvp],
         "psp_csr_poisson_slab": [i, i, i, i64, i64, i64, i, pvp],
@@ -164,6 +165,8 @@ def _declare(L):
         f = getattr(L, name)
         f.restype = i
         f.argtypes = argtypes
+    L.psp_build_id.restype = C.c_char_p
+    L.psp_build_id.argtypes = []
     L.psp_csr_device_bytes.restype = i64
     L.psp_csr_device_bytes.argtypes = [vp]
     L.psp_csr_nnz64.restype = i64

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <vector>
 
 #include "psp_internal.h"
@@ -2821,63 +2822,90 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     const char *e = psp::tuning_env("PSP_SPMV_REORDER_HOST");
     return e && atoi(e) != 0;
   }();
-  int *dperm = nullptr, *dinv = nullptr;
-  int on_device = 0;
-  if (!host_forced) {
-    PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
-    if (on_device < 0) {  // unsymmetric pattern or unsorted rows: number the pattern of A + A^T, built on the device
-      int *sind = nullptr, *scol = nullptr, ok_sym = 0;
-      long snnz = 0;
-      on_device = 0;
-      PSP_TRY(psp::reorder_symmetrize_device(n, A->nnz, A->ind, A->col, &sind, &scol, &snnz, &ok_sym));
-      if (ok_sym) {
-        const int rc_sym = psp::reorder_rcm_device(n, sind, scol, &dperm, &dinv, &on_device);
-        (void)hipFree(sind);
-        (void)hipFree(scol);
-        PSP_TRY(rc_sym);
-        if (on_device < 0) on_device = 0;
-      }
-    }
-  }
+  // The renumbered copy is a pure optimisation: whatever goes wrong while building it (no room for the copy or
+  // for the scratch of the numbering, a failed copy to / from the host) means "no renumbering" -- the product
+  // then runs on csr_spmv_w5 / csr_spmv_w2 -- and never fails the caller's y = A x.  An out-of-memory attempt is
+  // repeated once after the work-vector pool has been emptied.
   psp_csr *R = nullptr;
-  int rc = alloc_csr(n, n, (long)nnz, &R);
-  if (rc != PSP_OK) {  // no room: stay with the gather kernels
-    if (dperm) (void)hipFree(dperm);
-    if (dinv) (void)hipFree(dinv);
-    return PSP_OK;
-  }
-  R->no_reorder = true;
+  int *dperm = nullptr, *dinv = nullptr;
   double *xp = nullptr;
-  bool ok;
-  if (on_device) {
-    ok = psp::reorder_build_device(n, A->ind, A->col, A->val, dperm, dinv, R->ind, R->col, R->val) == PSP_OK;
-  } else {
-    std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
-    std::vector<double> val(nnz), rval;
-    PSP_HIP(hipMemcpy(ind.data(), A->ind, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
-    PSP_HIP(hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
-    PSP_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-    PSP_TRY(psp::reorder_rcm_host(n, ind.data(), col.data(), val.data(), perm, rind, rcol, rval));
-    std::vector<int> inv((size_t)n);
-    for (int i = 0; i < n; ++i) inv[perm[i]] = i;
-    ok = hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMalloc((void **)&dperm, sizeof(int) * (size_t)n) == hipSuccess &&
-         hipMalloc((void **)&dinv, sizeof(int) * (size_t)n) == hipSuccess &&
-         hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(dinv, inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
-  }
-  ok = ok && hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n) == hipSuccess && finalize_csr(R) == PSP_OK;
-  ChunkTable *t = nullptr;
-  if (ok) ok = get_chunk_table(R, 1024, &t) == PSP_OK && ensure_rowoff(R, t) == PSP_OK && t->np != 0 &&
-               ensure_w3(R, t) == PSP_OK && t->nb > 0;
-  if (!ok) {  // the new numbering does not qualify either
+  int on_device = 0;
+  auto release = [&]() {
     (void)hipGetLastError();
-    psp_csr_destroy(R);
+    if (R) psp_csr_destroy(R);
     if (dperm) (void)hipFree(dperm);
     if (dinv) (void)hipFree(dinv);
     if (xp) (void)hipFree(xp);
+    R = nullptr;
+    dperm = dinv = nullptr;
+    xp = nullptr;
+    on_device = 0;
+  };
+  auto attempt = [&]() -> int {
+    if (!host_forced) {
+      PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
+      if (on_device < 0) {  // unsymmetric pattern or unsorted rows: number the pattern of A + A^T, built on the device
+        int *sind = nullptr, *scol = nullptr, ok_sym = 0;
+        long snnz = 0;
+        on_device = 0;
+        PSP_TRY(psp::reorder_symmetrize_device(n, A->nnz, A->ind, A->col, &sind, &scol, &snnz, &ok_sym));
+        if (ok_sym) {
+          const int rc_sym = psp::reorder_rcm_device(n, sind, scol, &dperm, &dinv, &on_device);
+          (void)hipFree(sind);
+          (void)hipFree(scol);
+          PSP_TRY(rc_sym);
+          if (on_device < 0) on_device = 0;
+        }
+      }
+    }
+    PSP_TRY(alloc_csr(n, n, (long)nnz, &R));
+    R->no_reorder = true;
+    if (on_device) {
+      PSP_TRY(psp::reorder_build_device(n, A->ind, A->col, A->val, dperm, dinv, R->ind, R->col, R->val));
+    } else {
+      std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
+      std::vector<double> val(nnz), rval;
+      PSP_HIP(hipMemcpy(ind.data(), A->ind, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+      PSP_HIP(hipMemcpy(col.data(), A->col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+      PSP_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+      PSP_TRY(psp::reorder_rcm_host(n, ind.data(), col.data(), val.data(), perm, rind, rcol, rval));
+      std::vector<int> inv((size_t)n);
+      for (int i = 0; i < n; ++i) inv[perm[i]] = i;
+      PSP_HIP(hipMemcpy(R->ind, rind.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+      PSP_HIP(hipMemcpy(R->col, rcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+      PSP_HIP(hipMemcpy(R->val, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+      if (dperm) (void)hipFree(dperm);
+      if (dinv) (void)hipFree(dinv);
+      dperm = dinv = nullptr;
+      PSP_HIP(hipMalloc((void **)&dperm, sizeof(int) * (size_t)n));
+      PSP_HIP(hipMalloc((void **)&dinv, sizeof(int) * (size_t)n));
+      PSP_HIP(hipMemcpy(dperm, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+      PSP_HIP(hipMemcpy(dinv, inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    PSP_HIP(hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n));
+    PSP_TRY(finalize_csr(R));
+    ChunkTable *t = nullptr;
+    PSP_TRY(get_chunk_table(R, 1024, &t));
+    PSP_TRY(ensure_rowoff(R, t));
+    if (t->np == 0) return PSP_EINVAL;  // the new numbering does not qualify either
+    PSP_TRY(ensure_w3(R, t));
+    return t->nb > 0 ? PSP_OK : PSP_EINVAL;
+  };
+  auto guarded = [&]() -> int {
+    try {
+      return attempt();
+    } catch (const std::bad_alloc &) {  // the host path keeps copies of the arrays in std::vector
+      return PSP_ENOMEM;
+    }
+  };
+  int rc = guarded();
+  if (rc == PSP_ENOMEM) {
+    release();
+    psp_trim();
+    rc = guarded();
+  }
+  if (rc != PSP_OK) {
+    release();
     return PSP_OK;
   }
   std::lock_guard<std::mutex> lk(g_extra_mu);

@@ -86,6 +86,27 @@ int workspace(Workspace **out) {
   return PSP_OK;
 }
 
+// psp_stream_probe: R read streams (the first with ordinary loads, the others non-temporal, like the value streams
+// of csr_spmv_w4) and optionally one non-temporal write stream; one 16-byte element per thread and stream, full grid
+template <int R, bool W>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const double2 *__restrict__ a, double2 *__restrict__ b,
+                                                           long n2) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2) return;
+  const d2 *p = reinterpret_cast<const d2 *>(a);
+  d2 s = d2{1.5, 2.5};
+  if (R > 0) s = p[i];
+#pragma unroll
+  for (int k = 1; k < R; ++k) {
+    const d2 v = __builtin_nontemporal_load(p + i + (long)k * n2);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  if (W) __builtin_nontemporal_store(s, reinterpret_cast<d2 *>(b) + i);
+  else if (s.x + s.y == 12345.678) b[0] = double2{s.x, s.y};  // never true: keeps the loads alive
+}
+
 // fold: out[j*kFold + o] = sum over b == o (mod kFold) of in[j*kMaxParts + b].  16 lanes share
 // one output: lane g adds b = o + kFold*(g + 16*i) in ascending i, then a fixed xor-tree over
 // the 16 lanes -- same order every run.  64 workgroups per value keep the 1-3 MB of partials
@@ -265,6 +286,67 @@ int psp_event_record(void *event) {
 int psp_event_elapsed_ms(void *start, void *stop, float *ms) {
   PSP_HIP(hipEventSynchronize((hipEvent_t)stop));
   PSP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PSP_OK;
+}
+
+const char *psp_build_id(void) {
+#ifdef PSP_BUILD_ID
+  return PSP_BUILD_ID;
+#else
+  return "unstamped";
+#endif
+}
+
+int psp_stream_probe(int reads, int writes, size_t bytes_per_stream, int reps, float *avg_ms, float *min_ms) {
+  PSP_API_GUARD;
+  if (reads < 0 || reads > 8 || writes < 0 || writes > 1 || reads + writes == 0 || reps < 1 || !avg_ms ||
+      bytes_per_stream < 4096 || (bytes_per_stream & 4095))
+    return psp::fail(PSP_EINVAL, "psp_stream_probe: 0..8 reads, 0..1 writes, stream size a multiple of 4096 bytes");
+  PSP_TRY(psp::ensure_device());
+  double2 *a = nullptr, *b = nullptr;
+  const long n2 = (long)(bytes_per_stream / 16);
+  hipError_t e = hipMalloc((void **)&a, bytes_per_stream * (size_t)(reads ? reads : 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&b, bytes_per_stream);
+  if (e != hipSuccess) {
+    if (a) (void)hipFree(a);
+    return psp::fail(PSP_ENOMEM, "psp_stream_probe: %s", hipGetErrorString(e));
+  }
+  (void)hipMemsetAsync(a, 0, bytes_per_stream * (size_t)(reads ? reads : 1), psp::stream());
+  (void)hipMemsetAsync(b, 0, bytes_per_stream, psp::stream());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const unsigned grid = (unsigned)((n2 + 255) / 256);
+  float sum = 0.f, best = 3.4e38f;
+  int rc = PSP_OK;
+  for (int r = -2; r < reps && rc == PSP_OK; ++r) {  // two untimed launches first
+    (void)hipEventRecord(e0, psp::stream());
+    switch (reads) {
+#define PSP_PROBE_CASE(R)                                                                                          \
+  case R:                                                                                                          \
+    if (writes) hipLaunchKernelGGL((psp::stream_probe_kernel<R, true>), dim3(grid), dim3(256), 0, psp::stream(), a, b, n2); \
+    else hipLaunchKernelGGL((psp::stream_probe_kernel<R, false>), dim3(grid), dim3(256), 0, psp::stream(), a, b, n2);       \
+    break;
+      PSP_PROBE_CASE(0) PSP_PROBE_CASE(1) PSP_PROBE_CASE(2) PSP_PROBE_CASE(3) PSP_PROBE_CASE(4) PSP_PROBE_CASE(5)
+      PSP_PROBE_CASE(6) PSP_PROBE_CASE(7) PSP_PROBE_CASE(8)
+#undef PSP_PROBE_CASE
+    }
+    (void)hipEventRecord(e1, psp::stream());
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+      rc = psp::fail(PSP_ENODEV, "psp_stream_probe: %s", hipGetErrorString(hipGetLastError()));
+    if (r >= 0) {
+      sum += ms;
+      if (ms < best) best = ms;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (rc != PSP_OK) return rc;
+  *avg_ms = sum / (float)reps;
+  if (min_ms) *min_ms = best;
   return PSP_OK;
 }
 

@@ -1026,6 +1026,7 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
     if (hst) (void)hipHostFree(hst);
     return fail(PSP_ENOMEM, "minres: state allocation failed: %s", hipGetErrorString(e));
   }
+  if (hist_dev) (void)hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)it_max + 1), stream());  // NaN, like the PCG loops
   int rc = PSP_OK;
   int enqueued = 0, np = 0;
 #define MR_TRY(call)             \
@@ -1088,10 +1089,10 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
   *iter = hst->iter;
   if (hst->info == 0 || hst->info == -1) *relres = hst->relres;  // untouched on -3 / -6, as in the reference
   if (hist) {
-    const int cnt = std::min(hst->iter, it_max);
+    // -3 / -6 end the running iteration before its history slot is written: that slot keeps the caller's fill
+    const int cnt = std::min(hst->iter, it_max) - ((hst->info == -3 || hst->info == -6) ? 1 : 0);
     if (cnt >= 1)
       MR_HIP(hipMemcpy(hist + 1, hist_dev + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
-    // -3 / -6 leave the history slot of the running iteration unwritten
   }
 done:
 #undef MR_TRY
@@ -1168,8 +1169,7 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   if (hist) hist[0] = norm_rmr;
 
   if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
-    if (hist)  // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
-      for (int i = 1; i <= it_max; ++i) hist[i] = hist[i];
+    // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
     return minres_async_loop(Acsr, dinv, hasK, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
                              beta, errtol, it_max, info, iter, relres, hist);
   }
@@ -2066,6 +2066,11 @@ int psp_kd_minres_matvec(const psp_minresstate_t *s, psp_csr_t *A, const double 
   Workspace *w;
   PSP_TRY(workspace(&w));
   int np = 0;
+  if (A->nrows == 0) {  // a rank that owns no rows: nothing to multiply, alpha's local part is 0 (as in the PCG variant)
+    if (wait && wait(ctx)) return fail(PSP_ECALLBACK, "halo wait callback failed");
+    PSP_HIP(hipMemsetAsync(dot_out_dev, 0, sizeof(double), stream()));
+    return PSP_OK;
+  }
   PSP_TRY(csr_spmv_overlap(A, v_dev, av_dev, v_dev + v_offset, w->partials, &np, row_a, row_b, wait, ctx,
                            &s->dev->skip));
   return finish_partials(w->partials, np, 1, dot_out_dev);

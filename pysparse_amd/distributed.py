@@ -175,8 +175,15 @@ class HipBackend:
         torch.cuda.set_device(self.device)
         _capi.check(self.L.psp_set_device(device_index))
         # enqueue our kernels on torch's current stream so that collectives order with them
-        _capi.check(self.L.psp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self.bind_current_stream()
         self._scal = torch.zeros(8, dtype=torch.float64, device=self.device)
+
+    def bind_current_stream(self):
+        """(Re)pin the library's stream to the torch stream that is current NOW.  The device-scalar drivers rely on
+        stream order alone between the psp_kd_* kernels and the NCCL collectives / P2P batches, which synchronise
+        with torch.cuda.current_stream() at call time: dist_pcg / dist_minres call this on entry so that a solve
+        started under another `torch.cuda.stream(...)` context does not race."""
+        self._capi.check(self.L.psp_set_stream(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def zeros(self, n):
         return torch.zeros(n, dtype=torch.float64, device=self.device)
@@ -744,8 +751,9 @@ class DistCSR:
 
     @classmethod
     def from_global_sss(cls, n, ind, col, val, diag, comm, backend, make_local):
-        """An sss_mat (strict lower triangle + diagonal, sss_mat.h:6-14) on row blocks: every rank expands ITS rows
-        of the full matrix in the order sss_matvec adds them (sss_mat.c:45-55: lower entries by ascending column,
+        """An sss_mat (strict lower triangle + diagonal, sss_mat.h:6-14) on row blocks: every rank expands the
+        GLOBAL matrix (it is handed the global arrays, as from_global_csr is) into full rows in the order
+        sss_matvec adds them (sss_mat.c:45-55: lower entries by ascending column,
         the diagonal, then the mirrored entries by ascending row), so the distributed product has the bits of the
         single-GPU sss_mat.matvec."""
         f_ind, f_col, f_val = sss_rows_expanded(n, ind, col, val, diag)
@@ -815,6 +823,8 @@ def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices; see
     _dist_pcg.  A dinv slice that holds one value everywhere (constant-diagonal operator) is
     announced to the vector kernels for the duration of the solve (psp_k_hint_constant)."""
+    if hasattr(A.be, "bind_current_stream"):
+        A.be.bind_current_stream()
     hint = getattr(A.be, "hint_constant", None) if dinv is not None else None
     if hint is not None:
         hint(dinv)
@@ -1040,9 +1050,11 @@ def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None):
                 info, it = (-5, maxit) if stag else (-1, maxit + 1)  # pcg.c:159-165
                 relres = f.normr / f.n2b
         if hist is not None:
+            # -2 / -6 leave at the head of iteration `it` (or at p.q == 0) before its residual norm exists: that
+            # slot was never written (NaN fill) and the host-scalar loops append nothing for it either
             cnt = min(it, maxit)
             if cnt >= 1:
-                hist.extend(float(v) for v in st.hist(1, cnt))
+                hist.extend(float(v) for v in st.hist(1, cnt) if not np.isnan(v))
         return info, it, relres
     finally:
         st.close()
@@ -1056,6 +1068,8 @@ def dist_minres(A, b, x, tol, maxit, dinv=None, hist=None):
     recurrences run on the device (psp_minresstate_*), the host reads the state once per PCG_BATCH
     iterations.  x is updated in place; every rank returns the same triple."""
     be, comm = A.be, A.comm
+    if hasattr(be, "bind_current_stream"):
+        be.bind_current_stream()
     n = A.n_local
     v_hat, v_hat_old = be.zeros(n), be.zeros(n)
     wv, w_old, av = be.zeros(n), be.zeros(n), be.zeros(n)

@@ -25,6 +25,16 @@ def test_header_symbols_are_exported():
     assert b"gfx950" in L.psp_version()
 
 
+def test_library_was_built_from_the_sources_on_disk():
+    """psp_build_id() is the hash the build stamped into the binary; __graft_entry__.source_hash() hashes the HIP
+    sources, headers and flags on disk.  Equal <=> the prebuilt .so that travels to the GPU box is these sources."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as G
+    from pysparse_amd import _capi
+    assert _capi.lib().psp_build_id().decode() == G.source_hash()
+
+
 def test_no_cpu_fallback_without_gpu():
     from pysparse_amd import _capi, device
     if device.device_count() > 0:

@@ -144,12 +144,57 @@ def _worker(rank, world, port, case, q):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def _run(world, case):
+def _worker_breakdown(rank, world, port, case, q):
+    """-6 (p.q == 0) and -2 (rho == 0) through the three PCG drivers: same triple, same iterate, same history --
+    the slot of the iteration that broke down is never written and must not be reported (no NaN entry)"""
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import oracle as O
+        from pysparse_amd import distributed as D
+        from dist_oracle_backend import OracleBackend
+        be, comm = OracleBackend(), D.Comm()
+        n = 64
+        out = {}
+        for name, diag, dinv_g in (("pq0", np.r_[np.ones(n // 2), -np.ones(n // 2)], None),
+                                   ("rho0", np.ones(n), np.r_[np.ones(n // 2), -np.ones(n // 2)]),
+                                   # two clean iterations first, then p.q == 0 is not reached: plain convergence
+                                   ("spd", np.arange(1.0, n + 1), None)):
+            G = O.CSR((n, n), diag, np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32))
+            lo, hi = D.row_range(n, world, rank)
+            a, b_ = G.ind[lo], G.ind[hi]
+            plan, col_local = D.general_halo_plan(n, lo, hi, G.col[a:b_], world, rank, comm.all_gather_object,
+                                                  ind=G.ind[lo:hi + 1] - a)
+            A = D.DistCSR(O.CSR((hi - lo, plan.n_ext), G.val[a:b_], col_local, G.ind[lo:hi + 1] - a), plan, comm, be)
+            bg = np.ones(n)
+            xo = np.zeros(n)
+            ho = O.pcg(G, bg, xo, 1e-10, 50, dinv_g, hist=True)
+            runs = []
+            for fn in (D._dist_pcg, D._dist_pcg_lazy, D._dist_pcg_dev):
+                x, h = be.zeros(hi - lo), []
+                r = fn(A, be.from_numpy(bg[lo:hi]), x, 1e-10, 50,
+                       be.from_numpy(dinv_g[lo:hi]) if dinv_g is not None else None, h)
+                runs.append((tuple(r), x.numpy().copy(), h))
+            out[name] = {"ref": ho[:3], "runs": [(r, bool(np.array_equal(x, runs[0][1])), h) for r, x, h in runs],
+                         "x_ok": bool(np.allclose(runs[0][1], xo[lo:hi], rtol=1e-13, atol=0)),
+                         "ref_hist": [float(v) for v in ho[3] if not np.isnan(v)]}
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def _run(world, case, target=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=target or _worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=180) for _ in range(world))
@@ -187,6 +232,22 @@ def test_row_partitioned_spmv_and_pcg(world, case):
     # every rank reports the same triple
     r0 = results[0]["pcg"]["jacobi"][1]
     assert all(results[r]["pcg"]["jacobi"][1] == r0 for r in results)
+
+
+def test_breakdown_exits_agree_between_the_three_drivers():
+    results = _run(2, None, _worker_breakdown)
+    for rank, out in results.items():
+        assert "error" not in out, out.get("error")
+        for name, want in (("pq0", -6), ("rho0", -2), ("spd", 0)):
+            o = out[name]
+            assert o["ref"][0] == want, (name, o["ref"])
+            first = o["runs"][0]
+            for r, same_x, h in o["runs"]:
+                assert r[:2] == tuple(o["ref"][:2]), (name, r, o["ref"])
+                assert r == first[0] and same_x and h == first[2], (name, r, first[0], h, first[2])
+                assert not any(v != v for v in h), (name, h)  # no NaN entry for the iteration that broke down
+                assert len(h) == len(o["ref_hist"]), (name, h, o["ref_hist"])
+            assert o["x_ok"], name
 
 
 def test_partition_helpers():

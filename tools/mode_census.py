@@ -30,6 +30,9 @@ WANT = [
     ["GRBM_GUI_ACTIVE", "GRBM_COUNT", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAVES"],
     ["TCC_CYCLE_sum", "TCC_BUSY_sum", "TCC_REQ_sum", "TCC_STREAMING_REQ_sum"],
     ["TCC_EA0_RDREQ", "TCC_EA0_WRREQ"],  # unsummed: one value per TCC instance when the tool reports dimensions
+    # 10: clocks of three blocks + memory-side occupancy in ONE process (GRBM, SQ and TCC slots are independent)
+    ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "TCC_CYCLE_sum", "TCC_BUSY_sum",
+     "TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_WRREQ_LEVEL_sum"],
 ]
 KERNELS = ("csr_spmv_w4", "px_update", "r_update", "pupdate", "x_update")
 
@@ -104,6 +107,8 @@ def main():
         f.write(raw)
     groups = [[c for c in g if c in names] for g in WANT]
     groups = [g for g in groups if g]
+    if os.environ.get("CENSUS_GROUPS"):  # e.g. "10" or "2,10": indices into WANT
+        groups = [groups[int(i)] for i in os.environ["CENSUS_GROUPS"].split(",")]
     print("counter groups:", groups, flush=True)
     idx = 0
     with open(os.path.join(out, "census.jsonl"), "a") as jf:
