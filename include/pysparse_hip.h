@@ -121,6 +121,24 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out);
 int psp_csr_poisson_big_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi, int64_t col_shift,
                              int ncols_local, psp_csr_t **out);
 int64_t psp_csr_nnz64(const psp_csr_t *A);
+/* Multi-GPU variants taking a device list (reference loops pcg.c:91-163,
+ * minres.c:96-193, csr_mat.c:49-54): the rows of the operator -- and the matching slices of every solver
+ * vector -- live as contiguous row blocks on devices[0..ndev), one rank per entry, ONE process (one host
+ * thread enqueues for all ranks; a device may be listed more than once: ranks sharing a GPU).  The result is
+ * an ordinary psp_csr_t: psp_csr_matvec(_stride), psp_csr_diagonal, psp_csr_shape, psp_csr_kernel_info,
+ * psp_op_from_csr, psp_jacobi_create_csr (steps = 1), psp_pcg and psp_minres accept it -- K = NULL or the
+ * jacobi of the same matrix -- and every other entry point answers PSP_EINVAL.  Ghost entries travel by peer
+ * copies on a second stream per rank, overlapped with the rows that need none; the two packed reductions of
+ * an iteration go through RCCL (ncclAllReduce in stream order; librccl is loaded on first use) when every
+ * rank has its own device, else through a fixed-order fold kernel over peer pointers.
+ *   poisson: z-slabs (y-slabs in 2-D) of whole grid planes, index-free slab operators (psp_csr_poisson_big_slab)
+ *   create : any square CSR matrix from host arrays, n / ndev rows per rank, ghost lists found here */
+int psp_csr_poisson_multi(int nx, int ny, int nz, const int *devices, int ndev, psp_csr_t **out);
+int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind_host, const int *col_host,
+                         const double *val_host, const int *devices, int ndev, psp_csr_t **out);
+/* ranks / distinct devices behind a handle (0 / 0 for a single-device matrix); uses_rccl: the reductions go
+ * through RCCL rather than the fold kernel */
+int psp_csr_multi_info(const psp_csr_t *A, int *nranks, int *distinct_devices, int *uses_rccl);
 /* General CSR beyond the reference's C int (csr_mat.h:6-13: `int nnz`, `int *ind`): row offsets are 64-bit at
  * this boundary, column indices stay 32-bit.  Above 2^30 nonzeros the rows are cut into parts of < 2^30
  * nonzeros that share x and write disjoint row ranges of y ("64-bit row offsets ... or

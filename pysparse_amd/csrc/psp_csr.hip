@@ -4024,6 +4024,7 @@ int psp_csr_random_banded(int nrows, int ncols, int m, int stride, uint64_t seed
 
 int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *ind_host, int *col_host,
                           double *val_host) {
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_download_rows");
   if (!A || !ind_host) return fail(PSP_EINVAL, "psp_csr_download_rows: NULL argument");
   if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download_rows: the operator has no CSR arrays");
   if (row_lo < 0 || row_hi > A->nrows || row_lo > row_hi) return fail(PSP_EINVAL, "psp_csr_download_rows: bad row range");
@@ -4050,6 +4051,12 @@ int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *i
 
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
+  if (A->multi) {  // the row blocks, streams and communicators live with the multi-device object (psp_multi.hip)
+    PSP_API_GUARD;
+    const int rc = psp::multi_destroy(A->multi);
+    delete A;
+    return rc;
+  }
   psp_csr *transposed = nullptr, *reordered = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_extra_mu);
@@ -4098,6 +4105,7 @@ int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz) {
 }
 
 int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host) {
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_download");
   if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
   if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big)");
   if (A->nparts) return fail(PSP_EINVAL, "psp_csr_download: more than 2^31 nonzeros: use psp_csr_download_rows");
@@ -4116,6 +4124,7 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
 
 int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
   PSP_API_GUARD;
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_diagonal_dev");
   if (A->nrows == 0) return PSP_OK;
   if (A->nparts) {
     for (int p = 0; p < A->nparts; ++p) {
@@ -4146,6 +4155,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
 int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
   PSP_API_GUARD;
   if (!A || !diag_host) return fail(PSP_EINVAL, "psp_csr_diagonal: NULL argument");
+  if (A->multi) return psp::multi_diagonal_host(A->multi, diag_host);
   DevBuf d;
   PSP_TRY(d.alloc(A->nrows));
   PSP_TRY(psp_csr_diagonal_dev(A, d.p));
@@ -4154,6 +4164,7 @@ int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
 
 int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
   PSP_API_GUARD;
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_dev");
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_dev: NULL argument");
   if (A->nrows == 0) return PSP_OK;
   return csr_spmv_launch(A, x_dev, y_dev, nullptr, nullptr, nullptr);
@@ -4163,6 +4174,7 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
                           ptrdiff_t incy) {
   PSP_API_GUARD;
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
+  if (A->multi) return psp::multi_matvec_host(A->multi, x_host, incx, y_host, incy);
   PSP_TRY(ensure_device());
   DevBuf x, y;
   PSP_TRY(x.alloc(A->ncols));
@@ -4179,6 +4191,7 @@ int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
 
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
   PSP_API_GUARD;
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_transp");
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
   {  // offset-structured operators: exact gather in the reference's order, no atomics
     int done = 0;
@@ -4199,6 +4212,7 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
 int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
                                  double *y_host, ptrdiff_t incy) {
   PSP_API_GUARD;
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_transp");
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec_transp: NULL argument");
   PSP_TRY(ensure_device());
   DevBuf x, y;
@@ -4215,6 +4229,7 @@ int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host) {
 }
 
 int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_set_schedule");
   if (!A) return fail(PSP_EINVAL, "psp_csr_set_schedule: NULL handle");
   A->sched_strip_rows = strip_rows;
   std::lock_guard<std::mutex> lk(g_extra_mu);
@@ -4230,6 +4245,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
 
 int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
   PSP_API_GUARD;
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_renumbering");
   if (!A || !perm_host || !available) return fail(PSP_EINVAL, "psp_csr_renumbering: NULL argument");
   *available = 0;
   const int *dperm = nullptr;
@@ -4251,6 +4267,13 @@ int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   PSP_API_GUARD;
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
+  if (A->multi) {
+    char buf[160];
+    psp::multi_describe(A->multi, buf, sizeof buf);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", buf);
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    return PSP_OK;
+  }
   if (A->nparts) return psp_csr_kernel_info(A->parts[0], name, name_cap, info);  // every part by its own rules
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
@@ -4326,6 +4349,7 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
 }
 
 int psp_csr_set_variant(psp_csr_t *A, int variant) {
+  if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_set_variant");
   if (!A) return fail(PSP_EINVAL, "psp_csr_set_variant: NULL handle");
   A->variant = variant;
   for (int p = 0; p < A->nparts; ++p) A->parts[p]->variant = variant;
@@ -4333,7 +4357,7 @@ int psp_csr_set_variant(psp_csr_t *A, int variant) {
 }
 
 int64_t psp_csr_device_bytes(const psp_csr_t *A) {
-  if (!A) return 0;
+  if (!A || A->multi) return 0;
   if (A->nparts) {
     int64_t b = 0;
     for (int p = 0; p < A->nparts; ++p) b += psp_csr_device_bytes(A->parts[p]);

@@ -29,6 +29,13 @@ std::recursive_mutex &api_mutex();
 hipStream_t stream();
 hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
+// multi-device driver (psp_multi.hip): make `device` current (hipSetDevice) and enqueue on `s` from now on; the
+// reduction workspace is per device, so the phase kernels can be driven for one rank after another
+// ws_slot selects the reduction workspace (0 = the process's ordinary one): ranks of a multi-device matrix that share
+// a device enqueue on different streams and so must not share partial-sum buffers
+int use_device(int device, hipStream_t s, int ws_slot = 0);
+int current_device();
+int current_ws_slot();
 
 #define PSP_HIP(call)                                                                    \
   do {                                                                                   \
@@ -131,6 +138,9 @@ struct psp_csr {
   int nparts = 0;
   psp_csr **parts = nullptr;
   int *part_row0 = nullptr;
+  // psp_csr_poisson_multi / psp_csr_create_multi (psp_multi.hip): the rows live on several devices as row blocks;
+  // this handle then only carries the shape -- matvec, the diagonal, jacobi, pcg and minres go through `multi`
+  struct psp_mcsr *multi = nullptr;
 };
 
 struct psp_sss {
@@ -171,6 +181,7 @@ struct psp_jacobi {
   double *dinv = nullptr;
   double *temp = nullptr;  // steps > 1
   psp_op A;                // operator for the extra sweeps (kind == 0 when absent)
+  struct psp_mcsr *multi = nullptr;  // jacobi of a multi-device matrix: dinv lives with the row blocks (psp_multi.hip)
 };
 
 namespace psp {
@@ -239,5 +250,16 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+// psp_multi.hip: row-partitioned operators on a list of devices, one process
+int multi_destroy(psp_mcsr *M);
+int multi_matvec_host(psp_mcsr *M, const double *x_host, ptrdiff_t incx, double *y_host, ptrdiff_t incy);
+int multi_diagonal_host(psp_mcsr *M, double *diag_host);
+int multi_jacobi_setup(psp_mcsr *M, double omega);  // dinv slices = omega / diag on every rank (PSP_ESINGULAR)
+int multi_jacobi_apply_host(psp_mcsr *M, const double *x_host, double *y_host);
+int multi_pcg(psp_mcsr *M, bool jacobi, int n, double *x_host, const double *b_host, double tol, int maxit,
+              int *info, int *iter, double *relres, double *hist_host);
+int multi_minres(psp_mcsr *M, bool jacobi, int n, double *x_host, const double *b_host, double tol, int maxit,
+                 int *info, int *iter, double *relres, double *hist_host);
+int multi_describe(const psp_mcsr *M, char *buf, int cap);
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip
 }  // namespace psp

@@ -1,5 +1,6 @@
 // psp_runtime.hip -- device selection, stream, memory, events, reduction workspace.
 #include <cstring>
+#include <map>
 #include <mutex>
 
 #include "psp_internal.h"
@@ -10,7 +11,10 @@ static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
 static int g_device = 0;
 static int g_dev_state = 0;  // 0 unknown, 1 ok, -1 none
-static Workspace g_ws;
+// one reduction workspace per (device, slot): the multi-device driver switches devices, and gives every rank its own
+// slot -- ranks that share a device run on different streams and must not share partial-sum buffers
+static std::map<long, Workspace> g_wss;
+static int g_ws_slot = 0;
 static std::mutex g_mu;
 
 int fail(int code, const char *fmt, ...) {
@@ -65,26 +69,32 @@ int ensure_device() {
 int workspace(Workspace **out) {
   PSP_TRY(ensure_device());
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ws.device != g_device) {
-    if (g_ws.partials) {
-      (void)hipFree(g_ws.partials);
-      (void)hipFree(g_ws.folded);
-      (void)hipFree(g_ws.scal_dev);
-      (void)hipHostFree(g_ws.scal_host);
-      g_ws = Workspace();
-    }
+  Workspace &ws = g_wss[(long)g_device * 4096 + g_ws_slot];
+  if (ws.device != g_device) {
     hipDeviceProp_t prop;
     PSP_HIP(hipGetDeviceProperties(&prop, g_device));
-    g_ws.num_cu = prop.multiProcessorCount;
-    PSP_HIP(hipMalloc((void **)&g_ws.partials, sizeof(double) * kSlots * kMaxParts));
-    PSP_HIP(hipMalloc((void **)&g_ws.folded, sizeof(double) * kSlots * kFold));
-    PSP_HIP(hipMalloc((void **)&g_ws.scal_dev, sizeof(double) * 16));
-    PSP_HIP(hipHostMalloc((void **)&g_ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
-    g_ws.device = g_device;
+    ws.num_cu = prop.multiProcessorCount;
+    PSP_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
+    PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kFold));
+    PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
+    PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
+    ws.device = g_device;
   }
-  *out = &g_ws;
+  *out = &ws;
   return PSP_OK;
 }
+
+int use_device(int device, hipStream_t s, int ws_slot) {
+  PSP_HIP(hipSetDevice(device));  // unconditionally: the multi-device driver also switches with plain hipSetDevice
+  g_device = device;
+  g_dev_state = 1;
+  g_stream = s;
+  g_ws_slot = ws_slot;
+  return PSP_OK;
+}
+
+int current_device() { return g_device; }
+int current_ws_slot() { return g_ws_slot; }
 
 // psp_stream_probe: R read streams (the first with ordinary loads, the others non-temporal, like the value streams
 // of csr_spmv_w4) and optionally one non-temporal write stream; one 16-byte element per thread and stream, full grid

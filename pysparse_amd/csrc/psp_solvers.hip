@@ -2108,12 +2108,22 @@ int psp_kd_minres_wx(const psp_minresstate_t *s, int n, const double *v_dev, con
 
 // ====================================================================== C ABI
 
+// multi-device operands (psp_multi.hip): *multi = the row-partitioned matrix behind A (nullptr: an ordinary operand
+// pair); K must then be absent or the jacobi of that very matrix (*jac).  Only psp_pcg / psp_minres accept them.
 static int check_solver_args(const psp_op *A, const psp_op *K, int n, const void *x, const void *b,
-                             int *info, int *iter, double *relres) {
+                             int *info, int *iter, double *relres, psp_mcsr **multi = nullptr, bool *jac = nullptr) {
   if (!A || !x || !b || !info || !iter || !relres) return fail(PSP_EINVAL, "solver: NULL argument");
   if (n <= 0) return fail(PSP_EINVAL, "solver: n must be positive");
   if (A->n != n) return fail(PSP_EINVAL, "solver: operator order %d != n %d", A->n, n);
   if (K && K->n != n) return fail(PSP_EINVAL, "solver: preconditioner order %d != n %d", K->n, n);
+  psp_mcsr *ma = (A->kind == PSP_OP_CSR && A->csr) ? A->csr->multi : nullptr;
+  psp_mcsr *mk = (K && K->kind == PSP_OP_JACOBI && K->jac) ? K->jac->multi : nullptr;
+  if (multi) *multi = ma;
+  if (jac) *jac = mk != nullptr;
+  if (!ma && !mk) return PSP_OK;
+  if (!multi) return fail(PSP_EINVAL, "only pcg and minres (host vectors) run on a multi-device matrix");
+  if (!ma || (K && mk != ma))
+    return fail(PSP_EINVAL, "a multi-device matrix takes K = None or precon.jacobi of that same matrix");
   return PSP_OK;
 }
 
@@ -2233,6 +2243,17 @@ int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_csr: NULL argument");
   if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  if (A->multi) {  // dinv lives with the row blocks; the handle only says "jacobi of THIS matrix"
+    if (steps != 1) return fail(PSP_EINVAL, "jacobi of a multi-device matrix: steps must be 1");
+    PSP_TRY(multi_jacobi_setup(A->multi, omega));
+    psp_jacobi *K = new psp_jacobi();
+    K->n = A->nrows;
+    K->omega = omega;
+    K->steps = 1;
+    K->multi = A->multi;
+    *out = K;
+    return PSP_OK;
+  }
   PSP_TRY(ensure_device());
   double *d;
   PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(A->nrows ? A->nrows : 1)));
@@ -2290,6 +2311,10 @@ int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int ste
 
 int psp_jacobi_destroy(psp_jacobi_t *K) {
   if (!K) return PSP_OK;
+  if (K->multi) {
+    delete K;
+    return PSP_OK;
+  }
   dinv_unregister(K->dinv);
   (void)hipFree(K->dinv);
   if (K->temp) (void)hipFree(K->temp);
@@ -2306,12 +2331,14 @@ int psp_jacobi_shape(const psp_jacobi_t *K, int *n) {
 int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev) {
   PSP_API_GUARD;
   if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_jacobi_precon_dev: NULL argument");
+  if (K->multi) return fail(PSP_EINVAL, "psp_jacobi_precon_dev is not available on a multi-device matrix");
   return jacobi_apply_dev(K, x_dev, y_dev);
 }
 
 int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
   PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
+  if (K->multi) return multi_jacobi_apply_host(K->multi, x_host, y_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *y;
@@ -2338,7 +2365,10 @@ int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, cons
 int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
             double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
   PSP_API_GUARD;
-  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
+  psp_mcsr *multi = nullptr;
+  bool multi_jac = false;
+  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
+  if (multi) return multi_pcg(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *b;
@@ -2365,7 +2395,10 @@ int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
 int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
                double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
   PSP_API_GUARD;
-  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
+  psp_mcsr *multi = nullptr;
+  bool multi_jac = false;
+  PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
+  if (multi) return multi_minres(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *b;

@@ -124,6 +124,37 @@ class DeviceCSR:
         return cls(h)
 
     @classmethod
+    def poisson_multi(cls, nx, ny, nz=0, devices=(0,)):
+        """the Poisson operator as row slabs on a LIST of devices, one process (psp_csr_poisson_multi): matvec,
+        DeviceJacobi(A), pcg and minres work on it; a device may be listed more than once"""
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().psp_csr_poisson_multi(nx, ny, nz, _ptr(dv), len(dv), C.byref(h)))
+        A = cls(h)
+        A.nnz = int(lib().psp_csr_nnz64(h))
+        return A
+
+    @classmethod
+    def from_arrays_multi(cls, shape, ind, col, val, devices=(0,)):
+        """any square CSR matrix as row blocks on a list of devices (psp_csr_create_multi)"""
+        ind = np.ascontiguousarray(ind, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        if ind.shape[0] != shape[0] + 1 or col.shape[0] != val.shape[0]:
+            raise ValueError("inconsistent CSR arrays")
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().psp_csr_create_multi(shape[0], shape[1], val.shape[0], _ptr(ind), _ptr(col), _ptr(val),
+                                         _ptr(dv), len(dv), C.byref(h)))
+        return cls(h)
+
+    def multi_info(self):
+        """(ranks, distinct devices, reductions through RCCL) -- (0, 0, False) for a single-device matrix"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().psp_csr_multi_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, bool(c.value)
+
+    @classmethod
     def poisson_big(cls, nx, ny, nz=0):
         """the Poisson operator in the index-free w4 layout only (nnz may exceed 32 bits: 1024^3)"""
         h = C.c_void_p()
@@ -183,9 +214,9 @@ class DeviceCSR:
 
     def kernel_info(self):
         """(kernel name, {nb, max_blocks, scheduled, half_band}) of the product y = A x."""
-        name = C.create_string_buffer(64)
+        name = C.create_string_buffer(160)
         info = (C.c_int * 4)()
-        check(lib().psp_csr_kernel_info(self._h, name, 64, info))
+        check(lib().psp_csr_kernel_info(self._h, name, 160, info))
         return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
                                      "half_band": info[3]}
 

@@ -1171,13 +1171,43 @@ fail:
 }
 
 /* csr_from_arrays(indptr, indices, data, shape): scalable constructor without an ll_mat */
-static PyObject *CSR_from_arrays(PyObject *module, PyObject *args) {
+/* devices=[...] of poisson_csr / csr_from_arrays: a sequence of device ordinals (one rank per entry; may repeat).
+ * Returns the count (0: None / absent -> single device), -1 with an exception set. */
+static int parse_devices(PyObject *o, int *dev, int cap) {
+  PyObject *seq, *it;
+  Py_ssize_t i, n;
+  if (o == NULL || o == Py_None) return 0;
+  seq = PySequence_Fast(o, "devices must be a sequence of device ordinals");
+  if (seq == NULL) return -1;
+  n = PySequence_Fast_GET_SIZE(seq);
+  if (n < 1 || n > cap) {
+    Py_DECREF(seq);
+    PyErr_Format(PyExc_ValueError, "devices must list 1..%d device ordinals", cap);
+    return -1;
+  }
+  for (i = 0; i < n; i++) {
+    it = PySequence_Fast_GET_ITEM(seq, i);
+    dev[i] = (int)PyLong_AsLong(it);
+    if (dev[i] == -1 && PyErr_Occurred()) {
+      Py_DECREF(seq);
+      return -1;
+    }
+  }
+  Py_DECREF(seq);
+  return (int)n;
+}
+
+static PyObject *CSR_from_arrays(PyObject *module, PyObject *args, PyObject *kwds) {
   PyObject *oi, *oc, *ov;
   PyArrayObject *ind = NULL, *col = NULL, *val = NULL;
-  int dim[2], rc, keep_host = 0;
+  int dim[2], rc, keep_host = 0, ndev, devs[64];
   CSRMatObject *op = NULL;
   npy_intp nnz;
-  if (!PyArg_ParseTuple(args, "OOO(ii)|i", &oi, &oc, &ov, dim, dim + 1, &keep_host)) return NULL;
+  PyObject *odev = NULL;
+  static char *kwlist[] = {"indptr", "indices", "data", "shape", "keep_host", "devices", NULL};
+  if (!PyArg_ParseTupleAndKeywords(args, kwds, "OOO(ii)|iO", kwlist, &oi, &oc, &ov, dim, dim + 1, &keep_host, &odev))
+    return NULL;
+  if ((ndev = parse_devices(odev, devs, 64)) < 0) return NULL;
   ind = (PyArrayObject *)PyArray_FROM_OTF(oi, NPY_INT32, NPY_ARRAY_IN_ARRAY);
   col = ind ? (PyArrayObject *)PyArray_FROM_OTF(oc, NPY_INT32, NPY_ARRAY_IN_ARRAY) : NULL;
   val = col ? (PyArrayObject *)PyArray_FROM_OTF(ov, NPY_DOUBLE, NPY_ARRAY_IN_ARRAY) : NULL;
@@ -1196,8 +1226,12 @@ static PyObject *CSR_from_arrays(PyObject *module, PyObject *args) {
     memcpy(op->val, PyArray_DATA(val), sizeof(double) * (size_t)nnz);
   }
   Py_BEGIN_ALLOW_THREADS
-  rc = psp_csr_create(dim[0], dim[1], (int)nnz, (int *)PyArray_DATA(ind), (int *)PyArray_DATA(col),
-                      (double *)PyArray_DATA(val), &op->dev);
+  if (ndev > 0) /* row blocks on a list of devices: matvec / jacobi / pcg / minres (psp_csr_create_multi) */
+    rc = psp_csr_create_multi(dim[0], dim[1], (int)nnz, (int *)PyArray_DATA(ind), (int *)PyArray_DATA(col),
+                              (double *)PyArray_DATA(val), devs, ndev, &op->dev);
+  else
+    rc = psp_csr_create(dim[0], dim[1], (int)nnz, (int *)PyArray_DATA(ind), (int *)PyArray_DATA(col),
+                        (double *)PyArray_DATA(val), &op->dev);
   Py_END_ALLOW_THREADS
   if (rc != PSP_OK) {
     Py_DECREF(op);
@@ -1254,15 +1288,21 @@ done:
 
 /* poisson_csr(nx, ny, nz=0) / poisson_sss(...): generated on the device in the ordering of
  * pysparse/tools/poisson.py:22-50 (k = i + nx*j + nx*ny*l) */
-static PyObject *Poisson_csr(PyObject *module, PyObject *args) {
-  int nx, ny, nz = 0, rc, dim[2], nnz;
+static PyObject *Poisson_csr(PyObject *module, PyObject *args, PyObject *kwds) {
+  int nx, ny, nz = 0, rc, dim[2], nnz, ndev, devs[64];
   CSRMatObject *op;
-  if (!PyArg_ParseTuple(args, "ii|i", &nx, &ny, &nz)) return NULL;
+  PyObject *odev = NULL;
+  static char *kwlist[] = {"nx", "ny", "nz", "devices", NULL};
+  if (!PyArg_ParseTupleAndKeywords(args, kwds, "ii|iO", kwlist, &nx, &ny, &nz, &odev)) return NULL;
+  if ((ndev = parse_devices(odev, devs, 64)) < 0) return NULL;
   dim[0] = dim[1] = 0;
   op = (CSRMatObject *)newCSRMatObject(dim, 0, 0);
   if (op == NULL) return NULL;
   Py_BEGIN_ALLOW_THREADS
-  rc = psp_csr_poisson(nx, ny, nz, &op->dev);
+  if (ndev > 0) /* z-slabs on a list of devices, one process (psp_csr_poisson_multi) */
+    rc = psp_csr_poisson_multi(nx, ny, nz, devs, ndev, &op->dev);
+  else
+    rc = psp_csr_poisson(nx, ny, nz, &op->dev);
   Py_END_ALLOW_THREADS
   if (rc != PSP_OK) {
     Py_DECREF(op);
@@ -1299,9 +1339,12 @@ static PyMethodDef spmatrix_methods[] = {
     {"ll_mat", LLMat_zeros, METH_VARARGS, "ll_mat(n, m, sizeHint=1000, storeZeros=0): empty n x m linked-list matrix"},
     {"ll_mat_sym", LLMat_sym_zeros, METH_VARARGS, "ll_mat_sym(n, sizeHint=1000, storeZeros=0): empty symmetric matrix"},
     {"ll_mat_from_mtx", LLMat_from_mtx, METH_VARARGS, "ll_mat_from_mtx(fileName): read a MatrixMarket coordinate file"},
-    {"csr_from_arrays", CSR_from_arrays, METH_VARARGS, "csr_from_arrays(indptr, indices, data, shape[, keep_host]) -> csr_mat"},
+    {"csr_from_arrays", (PyCFunction)(void (*)(void))CSR_from_arrays, METH_VARARGS | METH_KEYWORDS,
+     "csr_from_arrays(indptr, indices, data, shape[, keep_host, devices=[...]]) -> csr_mat (devices: row blocks on several GPUs)"},
     {"sss_from_arrays", SSS_from_arrays, METH_VARARGS, "sss_from_arrays(indptr, indices, data, diag) -> sss_mat"},
-    {"poisson_csr", Poisson_csr, METH_VARARGS, "poisson_csr(nx, ny, nz=0) -> csr_mat of the 5-/7-point operator, built on the GPU"},
+    {"poisson_csr", (PyCFunction)(void (*)(void))Poisson_csr, METH_VARARGS | METH_KEYWORDS,
+     "poisson_csr(nx, ny, nz=0, devices=None) -> csr_mat of the 5-/7-point operator, built on the GPU(s); devices=[0, 1, ...] "
+     "partitions it into slabs over those GPUs: matvec, precon.jacobi, krylov.pcg and krylov.minres then run on all of them"},
     {"poisson_sss", Poisson_sss, METH_VARARGS, "poisson_sss(nx, ny, nz=0) -> sss_mat of the 5-/7-point operator, built on the GPU"},
     {"device_count", Device_count, METH_NOARGS, "number of visible GPUs"},
     {NULL, NULL, 0, NULL}};
