@@ -359,6 +359,70 @@ def strong_n1_leg(L, check, dev, grid, iters):
     return out
 
 
+def single_process_main(a):
+    """--single-process: the N-GPU job as ONE process through the C ABI's device-list variant
+    (psp_csr_poisson_multi: one rank per entry of the list, peer copies for the ghost planes, RCCL for the two
+    packed reductions of an iteration) -- what `krylov.pcg(A, ...)` of a drop-in script runs when A was made with
+    devices=[...].  Same workload and the same JSON line as the torch.distributed launch (strong scaling at 1024^3
+    for N > 1).  --share-gpu lists device 0 N times: a rehearsal on a one-GPU box, not a measurement."""
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    from pysparse_amd import _capi, device as dev
+    L, check = _capi.lib(), _capi.check
+    N = a.gpus
+    devices = [0] * N if a.share_gpu else list(range(N))
+    if a.grid:
+        nx, ny, nz = (int(t) for t in a.grid.split(","))
+    else:
+        nx = ny = nz = 1024 if N > 1 else 512
+    A = dev.DeviceCSR.poisson_multi(nx, ny, nz, devices=devices)
+    n, nnz = A.shape[0], A.nnz
+    ranks, distinct, rccl_used = A.multi_info()
+    ms = C.c_double()
+    t0 = time.perf_counter()
+    check(L.psp_csr_multi_spmv_time(A._h, a.warmup, a.steps, C.byref(ms)))
+    wall = time.perf_counter() - t0
+    kbytes = 8 * 7 * n + 2 * n + 16 * n  # csr_spmv_w4 on the 7-point operator (kernel_bytes)
+    if nz == 0:
+        kbytes = 8 * 5 * n + 2 * n + 16 * n
+    # Jacobi-PCG iterations/s: tol = 0 runs exactly k iterations; two runs, the difference cancels the host
+    # transfers of b and x and the set-up products (the vectors cross PCIe once per solve)
+    K = dev.DeviceJacobi(A)
+    ones = np.ones(n)
+    b = np.empty(n)
+    A.matvec(ones, b)
+    k1, k2 = 4, 4 + max(8, min(a.pcg_iters, 64))
+    times = {}
+    for k in (k1, k1, k2):
+        x = np.zeros(n)
+        t = time.perf_counter()
+        res = dev.pcg(A, b, x, 0.0, k, K)
+        times[k] = time.perf_counter() - t
+    s_per_iter = (times[k2] - times[k1]) / (k2 - k1)
+    out = {
+        "metric": "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s",
+        "value": kbytes / (ms.value * 1e-3) / 1e9, "unit": "GB/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms.value, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "3D Poisson 7-pt %dx%dx%d fp64 csr_mat, y = A x; z-slab row partition over a device list, "
+                               "ONE process (psp_csr_poisson_multi)" % (nx, ny, nz),
+                   "n": n, "nnz": nnz, "rows_per_gpu": n // N, "parallelism": "row-range x%d, single process" % N,
+                   "scaling_mode": "strong", "devices": devices},
+        "launcher": "single process, C ABI device list",
+        "ranks": ranks, "distinct_devices": distinct,
+        "reductions": "rccl" if rccl_used else ("none" if ranks == 1 else "fold kernel over peer pointers"),
+        "pct_hbm_peak": 100.0 * kbytes / (ms.value * 1e-3) / 1e9 / (HBM_PEAK_GBPS * max(distinct, 1)),
+        "pcg_iters_per_s": 1.0 / s_per_iter,
+        "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k2 - k1,
+                      "path": "psp_pcg on a multi-device matrix (psp_multi.hip)", "solve_s": times},
+        "wall_s_spmv_leg": wall,
+    }
+    if a.share_gpu:
+        out["dry_run"] = "%d ranks sharing device 0 in one process: a rehearsal of the N > 1 path, NOT a measurement" % N
+    print(json.dumps(out), file=real_stdout, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,8 +450,13 @@ def main():
                          "row-range driver over gloo (tests/); the line it prints is marked dry_run, not a measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed driver even at world size 1 (plumbing check)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through the C ABI's device-list variant (psp_csr_poisson_multi) "
+                         "instead of one torch.distributed rank per GPU")
     a = ap.parse_args()
 
+    if a.single_process:
+        return single_process_main(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], a.gpus))
 

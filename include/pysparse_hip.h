@@ -139,6 +139,10 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind_host, con
 /* ranks / distinct devices behind a handle (0 / 0 for a single-device matrix); uses_rccl: the reductions go
  * through RCCL rather than the fold kernel */
 int psp_csr_multi_info(const psp_csr_t *A, int *nranks, int *distinct_devices, int *uses_rccl);
+/* timing hook: `reps` products y = A x on resident slices, each done the way a solver iteration does it (ghost
+ * copies on the copy streams, the rows that need none meanwhile, then the boundary rows); *ms_per_product is the
+ * slowest rank's stream time per product (HIP events on every rank's compute stream) */
+int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_product);
 /* General CSR beyond the reference's C int (csr_mat.h:6-13: `int nnz`, `int *ind`): row offsets are 64-bit at
  * this boundary, column indices stay 32-bit.  Above 2^30 nonzeros the rows are cut into parts of < 2^30
  * nonzeros that share x and write disjoint row ranges of y ("64-bit row offsets ... or

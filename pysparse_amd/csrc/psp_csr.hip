@@ -27,8 +27,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "psp_internal.h"
@@ -3762,7 +3764,143 @@ int download_strided(double *host, const double *dev, size_t n, ptrdiff_t inc) {
   return PSP_OK;
 }
 
+// ---- host-pointer products at the PCIe rate (the reference boundary: csr_mat.c:141-163 hands NumPy buffers over)
+//
+// A product on host vectors is 8 n bytes up, one kernel, 8 n bytes down: at 512^3 two 1 GiB transfers of ~19 ms each
+// (56 GB/s each way, pageable or pinned alike on this platform -- tools/pcie_probe.py) around 1.65 ms of kernel.  The
+// link is full duplex (95 GB/s both ways at once), so for an offset-structured operator -- rows [r0, r1) need
+// x[r0 + min offset, r1 + max offset] only -- the product is pipelined in row chunks: one helper thread uploads x
+// chunk by chunk, this thread launches the row blocks of a chunk as soon as the x entries it reads have arrived,
+// a second helper thread downloads each finished chunk of y while later chunks are still going up.  Same kernel,
+// same rows, same bits; about 2 n * 8 / 95 GB/s instead of 2 n * 8 / 56 GB/s + kernel.
+struct HostStage {
+  double *x = nullptr, *y = nullptr;
+  size_t nx = 0, ny = 0;
+  int device = -1;
+  hipStream_t up = nullptr, dn = nullptr;
+};
+HostStage g_stage;
+
+constexpr long kPipeChunk = 1L << 22;  // rows per chunk: 32 MiB each way
+
+int host_matvec_pipelined(psp_csr *A, const double *xh, double *yh, double *xd, double *yd, bool *done) {
+  *done = false;
+  if (A->nparts || A->nrows < 2 * kPipeChunk || A->nrows != A->ncols) return PSP_OK;
+  static const bool off = [] {
+    const char *e = psp::tuning_env("PSP_HOST_PIPELINE");
+    return e && atoi(e) == 0;
+  }();
+  if (off) return PSP_OK;
+  Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
+  if (!v.w4) return PSP_OK;
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1) return PSP_OK;
+  int omax = 0;
+  for (int i = 0; i < ex->dia_no; ++i) omax = std::max(omax, ex->dia_offs.o[i]);
+  const long n = A->nrows;
+  const int K = (int)((n + kPipeChunk - 1) / kPipeChunk);
+  const int device = psp::current_device();
+  if (!g_stage.up) {
+    PSP_HIP(hipStreamCreateWithFlags(&g_stage.up, hipStreamNonBlocking));
+    PSP_HIP(hipStreamCreateWithFlags(&g_stage.dn, hipStreamNonBlocking));
+  }
+  std::vector<hipEvent_t> ev_up(K, nullptr), ev_k(K, nullptr);
+  for (int k = 0; k < K; ++k) {
+    PSP_HIP(hipEventCreateWithFlags(&ev_up[k], hipEventDisableTiming));
+    PSP_HIP(hipEventCreateWithFlags(&ev_k[k], hipEventDisableTiming));
+  }
+  PSP_HIP(hipStreamSynchronize(stream()));  // earlier work on the staging vectors is done
+  std::atomic<int> up_done{0}, k_done{0}, err{0};
+  hipStream_t s_up = g_stage.up, s_dn = g_stage.dn;
+  std::thread uploader([&] {
+    if (hipSetDevice(device) != hipSuccess) err = 1;
+    for (int c = 0; c < K && !err; ++c) {
+      const long lo = c * kPipeChunk, hi = std::min(n, lo + kPipeChunk);
+      if (hipMemcpyAsync(xd + lo, xh + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, s_up) != hipSuccess ||
+          hipEventRecord(ev_up[c], s_up) != hipSuccess)
+        err = 1;
+      up_done.store(c + 1, std::memory_order_release);
+    }
+    up_done.store(K, std::memory_order_release);
+  });
+  std::thread downloader([&] {
+    if (hipSetDevice(device) != hipSuccess) err = 1;
+    for (int k = 0; k < K && !err; ++k) {
+      while (k_done.load(std::memory_order_acquire) <= k && !err) std::this_thread::yield();
+      if (err) break;
+      const long lo = k * kPipeChunk, hi = std::min(n, lo + kPipeChunk);
+      if (hipStreamWaitEvent(s_dn, ev_k[k], 0) != hipSuccess ||
+          hipMemcpyAsync(yh + lo, yd + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, s_dn) != hipSuccess)
+        err = 1;
+    }
+    if (hipStreamSynchronize(s_dn) != hipSuccess) err = 1;
+  });
+  const int stripe = w4_stripe(A, v);
+  int rc = PSP_OK;
+  for (int k = 0; k < K && rc == PSP_OK && !err; ++k) {
+    const long r0 = k * kPipeChunk, r1 = std::min(n, r0 + kPipeChunk);
+    const long xhi = std::min(n, r1 + omax + 2);  // a lane reads the x pair of its two rows at every offset
+    const int need = (int)((xhi + kPipeChunk - 1) / kPipeChunk);
+    while (up_done.load(std::memory_order_acquire) < need && !err) std::this_thread::yield();
+    if (err) break;
+    if (hipStreamWaitEvent(stream(), ev_up[need - 1], 0) != hipSuccess) {
+      err = 1;
+      break;
+    }
+    const int b0 = (int)(r0 / kDiaRows), b1 = (int)((r1 + kDiaRows - 1) / kDiaRows);
+    rc = launch_w4(A, ex, stripe, b0, b1, xd, yd, nullptr, nullptr, nullptr, w4_grid(b1 - b0, stripe));
+    if (rc == PSP_OK && hipEventRecord(ev_k[k], stream()) != hipSuccess) err = 1;
+    k_done.store(k + 1, std::memory_order_release);
+  }
+  if (rc != PSP_OK || err) err = 1;  // releases the helper threads' waits
+  k_done.store(K, std::memory_order_release);
+  uploader.join();
+  downloader.join();
+  (void)hipStreamSynchronize(stream());
+  for (int k = 0; k < K; ++k) {
+    (void)hipEventDestroy(ev_up[k]);
+    (void)hipEventDestroy(ev_k[k]);
+  }
+  if (rc != PSP_OK) return rc;
+  if (err) return fail(PSP_ENODEV, "host-pointer matvec pipeline: %s", hipGetErrorString(hipGetLastError()));
+  *done = true;
+  return PSP_OK;
+}
+
 }  // namespace
+
+namespace psp {
+int host_stage(size_t nx, size_t ny, double **x, double **y) {
+  const int device = current_device();
+  if (g_stage.device != device || g_stage.nx < nx || g_stage.ny < ny) {
+    host_stage_trim();
+    hipError_t e = hipMalloc((void **)&g_stage.x, sizeof(double) * (nx ? nx : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&g_stage.y, sizeof(double) * (ny ? ny : 1));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      host_stage_trim();
+      (void)psp_trim();
+      PSP_HIP(hipMalloc((void **)&g_stage.x, sizeof(double) * (nx ? nx : 1)));
+      PSP_HIP(hipMalloc((void **)&g_stage.y, sizeof(double) * (ny ? ny : 1)));
+    }
+    g_stage.nx = nx;
+    g_stage.ny = ny;
+    g_stage.device = device;
+  }
+  *x = g_stage.x;
+  *y = g_stage.y;
+  return PSP_OK;
+}
+void host_stage_trim() {
+  if (g_stage.x) (void)hipFree(g_stage.x);
+  if (g_stage.y) (void)hipFree(g_stage.y);
+  g_stage.x = g_stage.y = nullptr;
+  g_stage.nx = g_stage.ny = 0;
+  g_stage.device = -1;
+}
+}  // namespace psp
 
 // ------------------------------------------------------------------ C ABI: csr
 
@@ -4176,12 +4314,18 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
   if (A->multi) return psp::multi_matvec_host(A->multi, x_host, incx, y_host, incy);
   PSP_TRY(ensure_device());
-  DevBuf x, y;
-  PSP_TRY(x.alloc(A->ncols));
-  PSP_TRY(y.alloc(A->nrows));
-  PSP_TRY(upload_strided(x.p, x_host, A->ncols, incx));
-  PSP_TRY(psp_csr_matvec_dev(A, x.p, y.p));
-  return download_strided(y_host, y.p, A->nrows, incy);
+  // device staging for the caller's host vectors: kept between calls (hipMalloc + hipFree of two GB-sized vectors cost
+  // milliseconds per product); psp_trim() releases it
+  double *xd, *yd;
+  PSP_TRY(psp::host_stage(A->ncols, A->nrows, &xd, &yd));
+  if (incx == 1 && incy == 1) {
+    bool done = false;
+    PSP_TRY(host_matvec_pipelined(A, x_host, y_host, xd, yd, &done));
+    if (done) return PSP_OK;
+  }
+  PSP_TRY(upload_strided(xd, x_host, A->ncols, incx));
+  PSP_TRY(psp_csr_matvec_dev(A, xd, yd));
+  return download_strided(y_host, yd, A->nrows, incy);
 }
 
 int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {

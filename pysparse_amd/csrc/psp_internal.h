@@ -250,6 +250,9 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+// psp_csr.hip: device staging of the host-pointer products (kept between calls, released by psp_trim)
+int host_stage(size_t nx, size_t ny, double **x, double **y);
+void host_stage_trim();
 // psp_multi.hip: row-partitioned operators on a list of devices, one process
 int multi_destroy(psp_mcsr *M);
 int multi_matvec_host(psp_mcsr *M, const double *x_host, ptrdiff_t incx, double *y_host, ptrdiff_t incy);

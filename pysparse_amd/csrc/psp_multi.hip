@@ -958,6 +958,67 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind, const in
   return PSP_OK;
 }
 
+int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_product) {
+  PSP_API_GUARD;
+  if (!A || !A->multi || reps < 1 || warmup < 0 || !ms_per_product)
+    return fail(PSP_EINVAL, "psp_csr_multi_spmv_time: needs a multi-device matrix and reps >= 1");
+  psp_mcsr *M = A->multi;
+  DeviceRestore keep;
+  Vecs mem;
+  std::vector<double *> vext(M->nranks), y(M->nranks);
+  for (int r = 0; r < M->nranks; ++r) {
+    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n_ext, &vext[r]));
+    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n, &y[r]));
+    PSP_TRY(use(M, r));
+    if (M->r[r].n) PSP_TRY(psp_k_jacobi(M->r[r].n, y[r], y[r], y[r]));  // touch
+  }
+  std::vector<hipEvent_t> e0(M->nranks), e1(M->nranks);
+  for (int r = 0; r < M->nranks; ++r) {
+    M_HIP(hipSetDevice(M->r[r].dev));
+    M_HIP(hipEventCreate(&e0[r]));
+    M_HIP(hipEventCreate(&e1[r]));
+  }
+  int rc = PSP_OK;
+  for (int k = -warmup; k < reps && rc == PSP_OK; ++k) {
+    if (k == 0) {
+      rc = sync_all(M);
+      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r)
+        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e0[r], M->r[r].s) != hipSuccess) rc = PSP_ENODEV;
+    }
+    // one product the way a solver iteration does it: exchange on the copy streams, interior rows meanwhile
+    for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+      rc = use(M, r);
+      if (rc == PSP_OK) rc = guard_overwrite(M, r);
+    }
+    if (rc == PSP_OK) rc = exchange(M, vext.data());
+    for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+      RankOp &R = M->r[r];
+      rc = use(M, r);
+      if (rc != PSP_OK || !R.n) continue;
+      if (M->nranks == 1)
+        rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr);
+      else
+        rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], R.ia, R.ib, wait_halo, &R, nullptr);
+    }
+  }
+  double worst = 0.0;
+  for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+    float ms = 0.f;
+    if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e1[r], M->r[r].s) != hipSuccess ||
+        hipEventSynchronize(e1[r]) != hipSuccess || hipEventElapsedTime(&ms, e0[r], e1[r]) != hipSuccess)
+      rc = fail(PSP_ENODEV, "psp_csr_multi_spmv_time: %s", hipGetErrorString(hipGetLastError()));
+    worst = std::max(worst, (double)ms);
+  }
+  for (int r = 0; r < M->nranks; ++r) {
+    (void)hipEventDestroy(e0[r]);
+    (void)hipEventDestroy(e1[r]);
+  }
+  if (rc != PSP_OK) return rc;
+  PSP_TRY(sync_all(M));
+  *ms_per_product = worst / reps;  // the slowest rank's stream time: what an iteration waits for
+  return PSP_OK;
+}
+
 int psp_csr_multi_info(const psp_csr_t *A, int *nranks, int *distinct_devices, int *uses_rccl) {
   if (!A) return fail(PSP_EINVAL, "psp_csr_multi_info: NULL argument");
   const psp_mcsr *M = A->multi;

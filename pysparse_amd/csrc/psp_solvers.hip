@@ -2131,6 +2131,7 @@ extern "C" {
 
 int psp_trim(void) {
   g_pool.trim();
+  host_stage_trim();
   return PSP_OK;
 }
 

@@ -140,3 +140,24 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and "dry_run" in d
     assert d["config"]["n"] == 12 * 10 * 8 and d["config"]["rows_per_gpu"] == 12 * 10 * 4
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 6
+
+
+@pytest.mark.gpu
+def test_bench_single_process_device_list_rehearsal():
+    """`bench.py --gpus N --single-process`: the N-GPU job as ONE process through psp_csr_poisson_multi (the C ABI's
+    device-list variant, pysparse_amd/csrc/psp_multi.hip).  On this one-GPU box --share-gpu lists device 0 three times:
+    every piece of the path but peer copies / RCCL between different devices; the line says so (dry_run)."""
+    d = run_bench("--gpus", "3", "--single-process", "--share-gpu", "--grid", "64,64,66", "--steps", "5", "--warmup", "2",
+                  "--pcg-iters", "16")
+    for k in CONTRACT[:-1]:
+        assert k in d, k
+    assert d["n_gpus"] == 3 and d["ranks"] == 3 and d["distinct_devices"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["n"] == 64 * 64 * 66 and d["config"]["devices"] == [0, 0, 0]
+    assert "dry_run" in d and d["reductions"].startswith("fold kernel")
+    assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 4 + 16 + 1  # tol = 0: exactly k2 iterations
+    assert d["pcg_iters_per_s"] > 0 and d["value"] > 0 and d["pct_hbm_peak"] <= 100.0
+    one = run_bench("--gpus", "1", "--single-process", "--grid", "64,64,66", "--steps", "5", "--warmup", "2",
+                    "--pcg-iters", "16")
+    assert one["ranks"] == 1 and one["reductions"] == "none" and "dry_run" not in one
+    # same right-hand side, same iteration count: the recurred residual agrees to rounding between 1 and 3 ranks
+    assert abs(one["pcg_check"]["relres"] - d["pcg_check"]["relres"]) <= 1e-9 * one["pcg_check"]["relres"]

@@ -396,3 +396,27 @@ def test_config4_1024_cubed_four_ranks_rehearsal():
     one, four = d["strong_n1"]["pcg_check"], d["pcg_check"]
     assert (one["info"], one["iter"]) == (four["info"], four["iter"]) == (-1, 21)
     assert abs(one["relres"] - four["relres"]) <= 1e-12 * one["relres"]
+
+
+@pytest.mark.gpu
+def test_host_pointer_matvec_pipeline_is_the_device_product():
+    """A.matvec(x, y) on NumPy buffers of a large offset-structured operator runs chunked -- x going up, row blocks
+    launched as their x entries arrive, y coming down, all at once (psp_csr.hip host_matvec_pipelined; the reference
+    boundary csr_mat.c:141-163).  Same kernel per row: the bits of the whole-vector device product; the chunk edges
+    (rows whose offsets reach into the next chunk, the last partial chunk) are where a mistake would show."""
+    from pysparse_amd import device as dev
+    for grid in ((300, 300, 120), (4096, 2500, 0)):  # 10.8e6 rows (3 chunks, last partial), 10.2e6 rows in 2-D
+        A = dev.DeviceCSR.poisson(*grid)
+        n = A.shape[0]
+        assert n >= 2 * (1 << 22) and A.kernel_info()[0] == "csr_spmv_w4"
+        x = np.random.default_rng(3).standard_normal(n)
+        y = np.full(n, np.nan)
+        A.matvec(x, y)
+        xd, yd = dev.DeviceBuffer.from_host(x), dev.DeviceBuffer(n)
+        A.matvec_dev(xd.ptr, yd.ptr)
+        assert np.array_equal(y, yd.download())
+        y2 = np.full(n, np.nan)
+        A.matvec(x, y2)  # staging vectors are reused between calls
+        assert np.array_equal(y, y2)
+        A.matvec(np.ones(n), y)  # exact row sums: the number of missing neighbours (small integers)
+        assert np.array_equal(y, missing_neighbours(*grid).ravel())
