@@ -3781,11 +3781,18 @@ struct HostStage {
 };
 HostStage g_stage;
 
-constexpr long kPipeChunk = 1L << 22;  // rows per chunk: 32 MiB each way
+constexpr long kPipeMinRows = 1L << 23;  // below 64 MiB per vector the plain path wins (thread start-up, pipeline fill)
+// rows per chunk: a sixteenth of the vector, between 8 and 32 MiB each way, whole 128-row blocks
+inline long pipe_chunk(long n) {
+  long c = n / 16;
+  c = std::max(1L << 20, std::min(1L << 22, c));
+  return c / 4096 * 4096;
+}
 
 int host_matvec_pipelined(psp_csr *A, const double *xh, double *yh, double *xd, double *yd, bool *done) {
   *done = false;
-  if (A->nparts || A->nrows < 2 * kPipeChunk || A->nrows != A->ncols) return PSP_OK;
+  if (A->nparts || A->nrows < kPipeMinRows || A->nrows != A->ncols) return PSP_OK;
+  const long kPipeChunk = pipe_chunk(A->nrows);
   static const bool off = [] {
     const char *e = psp::tuning_env("PSP_HOST_PIPELINE");
     return e && atoi(e) == 0;
@@ -3908,6 +3915,7 @@ extern "C" {
 
 int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int *col_host,
                    const double *val_host, psp_csr_t **out) {
+  if (psp::cpu_mode()) return psp::cpu::csr_create(nrows, ncols, nnz, ind_host, col_host, val_host, out);
   if (!out || !ind_host || (nnz > 0 && (!col_host || !val_host)))
     return fail(PSP_EINVAL, "psp_csr_create: NULL argument");
   if (nrows < 0 || ncols < 0 || nnz < 0) return fail(PSP_EINVAL, "psp_csr_create: negative size");
@@ -3964,6 +3972,7 @@ int psp_csr_poisson_slab(int nx, int ny, int nz, int64_t row_lo, int64_t row_hi,
 }
 
 int psp_csr_poisson(int nx, int ny, int nz, psp_csr_t **out) {
+  if (psp::cpu_mode()) return out ? psp::cpu::csr_poisson(nx, ny, nz, out) : fail(PSP_EINVAL, "psp_csr_poisson: NULL argument");
   const long n = (long)nx * ny * (nz > 0 ? nz : 1);
   if (n > 0x7fffffffL) return fail(PSP_EINVAL, "psp_csr_poisson: n exceeds 32-bit indices");
   return psp_csr_poisson_slab(nx, ny, nz, 0, n, 0, (int)n, out);
@@ -4189,6 +4198,7 @@ int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *i
 
 int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
+  if (A->host) return psp::cpu::csr_destroy(A);
   if (A->multi) {  // the row blocks, streams and communicators live with the multi-device object (psp_multi.hip)
     PSP_API_GUARD;
     const int rc = psp::multi_destroy(A->multi);
@@ -4243,6 +4253,7 @@ int psp_csr_shape(const psp_csr_t *A, int *nrows, int *ncols, int *nnz) {
 }
 
 int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *val_host) {
+  if (A && A->host) return psp::cpu::csr_download(A, ind_host, col_host, val_host);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_download");
   if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
   if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big)");
@@ -4293,6 +4304,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
 int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
   PSP_API_GUARD;
   if (!A || !diag_host) return fail(PSP_EINVAL, "psp_csr_diagonal: NULL argument");
+  if (A->host) return psp::cpu::csr_diagonal(A, diag_host);
   if (A->multi) return psp::multi_diagonal_host(A->multi, diag_host);
   DevBuf d;
   PSP_TRY(d.alloc(A->nrows));
@@ -4312,6 +4324,7 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
                           ptrdiff_t incy) {
   PSP_API_GUARD;
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
+  if (A->host) return psp::cpu::csr_matvec(A, x_host, incx, y_host, incy, false);
   if (A->multi) return psp::multi_matvec_host(A->multi, x_host, incx, y_host, incy);
   PSP_TRY(ensure_device());
   // device staging for the caller's host vectors: kept between calls (hipMalloc + hipFree of two GB-sized vectors cost
@@ -4358,6 +4371,7 @@ int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t i
   PSP_API_GUARD;
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_transp");
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec_transp: NULL argument");
+  if (A->host) return psp::cpu::csr_matvec(A, x_host, incx, y_host, incy, true);
   PSP_TRY(ensure_device());
   DevBuf x, y;
   PSP_TRY(x.alloc(A->nrows));
@@ -4411,6 +4425,11 @@ int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   PSP_API_GUARD;
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
+  if (A->host) {
+    if (name && name_cap > 0) snprintf(name, name_cap, "cpu loops (PSP_DEVICE=cpu)");
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    return PSP_OK;
+  }
   if (A->multi) {
     char buf[160];
     psp::multi_describe(A->multi, buf, sizeof buf);
@@ -4501,7 +4520,7 @@ int psp_csr_set_variant(psp_csr_t *A, int variant) {
 }
 
 int64_t psp_csr_device_bytes(const psp_csr_t *A) {
-  if (!A || A->multi) return 0;
+  if (!A || A->multi || A->host) return 0;
   if (A->nparts) {
     int64_t b = 0;
     for (int p = 0; p < A->nparts; ++p) b += psp_csr_device_bytes(A->parts[p]);
@@ -4549,6 +4568,7 @@ __global__ __launch_bounds__(256) void sss_full_fill_kernel(
 
 int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_host,
                    const double *val_host, const double *diag_host, psp_sss_t **out) {
+  if (psp::cpu_mode()) return psp::cpu::sss_create(n, nnz_lower, ind_host, col_host, val_host, diag_host, out);
   if (!out || !ind_host || !diag_host || (nnz_lower > 0 && (!col_host || !val_host)))
     return fail(PSP_EINVAL, "psp_sss_create: NULL argument");
   if (n < 0 || nnz_lower < 0) return fail(PSP_EINVAL, "psp_sss_create: negative size");
@@ -4639,6 +4659,7 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
 
 int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out) {
   if (!out || nx < 1 || ny < 1 || nz < 0) return fail(PSP_EINVAL, "psp_sss_poisson: bad grid");
+  if (psp::cpu_mode()) return psp::cpu::sss_poisson(nx, ny, nz, out);
   const long n = (long)nx * ny * (nz > 0 ? nz : 1);
   if (n > 0x7fffffffL) return fail(PSP_EINVAL, "psp_sss_poisson: n exceeds 32-bit indices");
   const long nnzl = poisson_lower_prefix(n, nx, ny, nz);
@@ -4671,6 +4692,7 @@ int psp_sss_poisson(int nx, int ny, int nz, psp_sss_t **out) {
 
 int psp_sss_destroy(psp_sss_t *S) {
   if (!S) return PSP_OK;
+  if (S->host) return psp::cpu::sss_destroy(S);
   psp_csr_destroy(S->full);
   if (S->w4_val) (void)hipFree(S->w4_val);
   if (S->w4_mask) (void)hipFree(S->w4_mask);
@@ -4692,6 +4714,7 @@ int psp_sss_shape(const psp_sss_t *S, int *n, int *nnz_reported) {
 int psp_sss_download(const psp_sss_t *S, int *ind_host, int *col_host, double *val_host,
                      double *diag_host) {
   if (!S) return fail(PSP_EINVAL, "psp_sss_download: NULL handle");
+  if (S->host) return psp::cpu::sss_download(S, ind_host, col_host, val_host, diag_host);
   if (ind_host)
     PSP_HIP(hipMemcpyAsync(ind_host, S->ind, sizeof(int) * ((size_t)S->n + 1),
                            hipMemcpyDeviceToHost, stream()));
@@ -4712,6 +4735,7 @@ int psp_sss_getitem(const psp_sss_t *S, int i, int j, double *value) {
   if (!S || !value) return fail(PSP_EINVAL, "psp_sss_getitem: NULL argument");
   if (i < 0 || j < 0 || i >= S->n || j >= S->n)
     return fail(PSP_EINVAL, "psp_sss_getitem: indices out of range");
+  if (S->host) return psp::cpu::sss_getitem(S, i, j, value);
   if (i == j) {
     PSP_HIP(hipMemcpy(value, S->diag + i, sizeof(double), hipMemcpyDeviceToHost));
     return PSP_OK;
@@ -4743,6 +4767,8 @@ int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, do
                           ptrdiff_t incy) {
   PSP_API_GUARD;
   if (!S) return fail(PSP_EINVAL, "psp_sss_matvec: NULL handle");
+  if (S->host) return (x_host && y_host) ? psp::cpu::sss_matvec(S, x_host, incx, y_host, incy)
+                                         : fail(PSP_EINVAL, "psp_sss_matvec: NULL argument");
   return psp_csr_matvec_stride(S->full, x_host, incx, y_host, incy);
 }
 
@@ -4754,6 +4780,11 @@ int psp_sss_matvec(psp_sss_t *S, const double *x_host, double *y_host) {
 int psp_sss_kernel_info(psp_sss_t *S, char *name, int name_cap, int *info) {
   PSP_API_GUARD;
   if (!S) return fail(PSP_EINVAL, "psp_sss_kernel_info: NULL handle");
+  if (S->host) {
+    if (name && name_cap > 0) snprintf(name, name_cap, "cpu loops (PSP_DEVICE=cpu)");
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    return PSP_OK;
+  }
   return psp_csr_kernel_info(S->full, name, name_cap, info);
 }
 
@@ -4763,7 +4794,7 @@ int psp_sss_set_variant(psp_sss_t *S, int variant) {
 }
 
 int64_t psp_sss_device_bytes(const psp_sss_t *S) {
-  if (!S) return 0;
+  if (!S || S->host) return 0;
   return psp_csr_device_bytes(S->full) + (int64_t)sizeof(int) * (S->n + 1) +
          (int64_t)(sizeof(int) + sizeof(double)) * S->nnz_lower + (int64_t)sizeof(double) * S->n;
 }

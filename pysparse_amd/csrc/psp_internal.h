@@ -29,6 +29,8 @@ std::recursive_mutex &api_mutex();
 hipStream_t stream();
 hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
+// PSP_DEVICE=cpu (read once): the opt-in host mode of psp_cpu.hip -- never a fallback, see that file
+bool cpu_mode();
 // multi-device driver (psp_multi.hip): make `device` current (hipSetDevice) and enqueue on `s` from now on; the
 // reduction workspace is per device, so the phase kernels can be driven for one rank after another
 // ws_slot selects the reduction workspace (0 = the process's ordinary one): ranks of a multi-device matrix that share
@@ -141,6 +143,7 @@ struct psp_csr {
   // psp_csr_poisson_multi / psp_csr_create_multi (psp_multi.hip): the rows live on several devices as row blocks;
   // this handle then only carries the shape -- matvec, the diagonal, jacobi, pcg and minres go through `multi`
   struct psp_mcsr *multi = nullptr;
+  bool host = false;  // PSP_DEVICE=cpu: ind / col / val are host arrays (psp_cpu.hip)
 };
 
 struct psp_sss {
@@ -157,6 +160,7 @@ struct psp_sss {
   int w4_offs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double *w4_val = nullptr;
   unsigned short *w4_mask = nullptr;
+  bool host = false;  // PSP_DEVICE=cpu: ind / col / val / diag are host arrays (psp_cpu.hip)
 };
 
 enum psp_op_kind { PSP_OP_CSR = 1, PSP_OP_SSS = 2, PSP_OP_JACOBI = 3, PSP_OP_CALLBACK = 4, PSP_OP_SSOR = 5 };
@@ -182,6 +186,7 @@ struct psp_jacobi {
   double *temp = nullptr;  // steps > 1
   psp_op A;                // operator for the extra sweeps (kind == 0 when absent)
   struct psp_mcsr *multi = nullptr;  // jacobi of a multi-device matrix: dinv lives with the row blocks (psp_multi.hip)
+  bool host = false;                 // PSP_DEVICE=cpu: dinv / temp are host arrays (psp_cpu.hip)
 };
 
 namespace psp {
@@ -250,6 +255,28 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+// psp_cpu.hip: the host loops behind the entry points when PSP_DEVICE=cpu
+namespace cpu {
+int csr_create(int nrows, int ncols, int nnz, const int *ind, const int *col, const double *val, psp_csr **out);
+int csr_destroy(psp_csr *A);
+int csr_poisson(int nx, int ny, int nz, psp_csr **out);
+int csr_download(const psp_csr *A, int *ind, int *col, double *val);
+int csr_diagonal(const psp_csr *A, double *diag);
+int csr_matvec(const psp_csr *A, const double *x, ptrdiff_t incx, double *y, ptrdiff_t incy, bool transp);
+int sss_create(int n, int nnz, const int *ind, const int *col, const double *val, const double *diag, psp_sss **out);
+int sss_destroy(psp_sss *S);
+int sss_poisson(int nx, int ny, int nz, psp_sss **out);
+int sss_download(const psp_sss *S, int *ind, int *col, double *val, double *diag);
+int sss_getitem(const psp_sss *S, int i, int j, double *value);
+int sss_matvec(const psp_sss *S, const double *x, ptrdiff_t incx, double *y, ptrdiff_t incy);
+int jacobi_create(int n, const double *diag, double omega, int steps, const psp_op *A, psp_jacobi **out);
+int jacobi_destroy(psp_jacobi *K);
+int jacobi_precon(const psp_jacobi *K, const double *x, double *y);
+int pcg(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit, int *info,
+        int *iter, double *relres, double *hist);
+int minres(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit, int *info,
+           int *iter, double *relres, double *hist);
+}  // namespace cpu
 // psp_csr.hip: device staging of the host-pointer products (kept between calls, released by psp_trim)
 int host_stage(size_t nx, size_t ny, double **x, double **y);
 void host_stage_trim();
@@ -265,4 +292,5 @@ int multi_minres(psp_mcsr *M, bool jacobi, int n, double *x_host, const double *
                  int *info, int *iter, double *relres, double *hist_host);
 int multi_describe(const psp_mcsr *M, char *buf, int cap);
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip
+int ssor_apply_host(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip: PSP_DEVICE=cpu, host arrays
 }  // namespace psp

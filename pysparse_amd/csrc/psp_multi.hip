@@ -788,6 +788,7 @@ int psp_csr_poisson_multi(int nx, int ny, int nz, const int *devices, int ndev, 
   PSP_API_GUARD;
   if (!out || !devices || ndev < 1 || ndev > 64) return fail(PSP_EINVAL, "psp_csr_poisson_multi: bad device list");
   if (nx < 1 || ny < 1 || nz < 0) return fail(PSP_EINVAL, "psp_csr_poisson_multi: bad grid");
+  PSP_TRY(psp::ensure_device());
   const bool three_d = nz > 0;
   const int planes = three_d ? nz : ny;
   const int64_t plane_rows = three_d ? (int64_t)nx * ny : nx;
@@ -853,6 +854,7 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind, const in
   if (!ind || (nnz > 0 && (!col || !val)) || nrows < 0 || nnz < 0 || ind[0] != 0 || ind[nrows] != nnz)
     return fail(PSP_EINVAL, "psp_csr_create_multi: bad CSR arrays");
   if (nrows != ncols) return fail(PSP_EINVAL, "a multi-device matrix must be square (rows and vector slices share the partition)");
+  PSP_TRY(psp::ensure_device());
   DeviceRestore keep;
   psp_mcsr *M = new psp_mcsr();
   snprintf(M->kind, sizeof M->kind, "csr row blocks");

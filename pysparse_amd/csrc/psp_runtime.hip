@@ -50,6 +50,9 @@ hipStream_t swap_stream(hipStream_t s) {
 }
 
 int ensure_device() {
+  if (cpu_mode())
+    return fail(PSP_ENODEV, "PSP_DEVICE=cpu: this entry point has no host loop (it runs on the GPU only); the host mode "
+                            "covers csr_mat / sss_mat products, jacobi, pcg and minres");
   if (g_dev_state == 1) return PSP_OK;
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
@@ -186,7 +189,9 @@ using namespace psp;
 extern "C" {
 
 const char *psp_last_error(void) { return psp::last_error(); }
-const char *psp_version(void) { return "pysparse_hip 0.1 (gfx950)"; }
+const char *psp_version(void) {
+  return psp::cpu_mode() ? "pysparse_hip 0.1 (gfx950; PSP_DEVICE=cpu: host loops, no GPU used)" : "pysparse_hip 0.1 (gfx950)";
+}
 
 int psp_device_count(void) {
   int cnt = 0;
@@ -212,6 +217,7 @@ int psp_set_stream(void *hip_stream) {
 }
 
 int psp_synchronize(void) {
+  if (psp::cpu_mode()) return PSP_OK;
   PSP_TRY(ensure_device());
   PSP_HIP(hipStreamSynchronize(stream()));
   return PSP_OK;

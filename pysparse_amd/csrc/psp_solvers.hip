@@ -2180,6 +2180,15 @@ int psp_op_from_ssor(psp_ssor_t *K, psp_op_t **out) {
 
 int psp_op_from_callback(int n, psp_host_apply_fn fn, void *ctx, psp_op_t **out) {
   if (!fn || !out || n <= 0) return fail(PSP_EINVAL, "psp_op_from_callback: bad argument");
+  if (cpu_mode()) {  // host mode: the callback is applied to the solver's host vectors directly, no staging
+    psp_op *op = new psp_op();
+    op->kind = PSP_OP_CALLBACK;
+    op->n = n;
+    op->fn = fn;
+    op->ctx = ctx;
+    *out = op;
+    return PSP_OK;
+  }
   PSP_TRY(ensure_device());
   psp_op *op = new psp_op();
   op->kind = PSP_OP_CALLBACK;
@@ -2244,6 +2253,15 @@ int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_csr: NULL argument");
   if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  if (A->host) {
+    std::vector<double> d((size_t)(A->nrows ? A->nrows : 1));
+    PSP_TRY(cpu::csr_diagonal(A, d.data()));
+    psp_op op;
+    op.kind = PSP_OP_CSR;
+    op.n = A->nrows;
+    op.csr = A;
+    return cpu::jacobi_create(A->nrows, d.data(), omega, steps, &op, out);
+  }
   if (A->multi) {  // dinv lives with the row blocks; the handle only says "jacobi of THIS matrix"
     if (steps != 1) return fail(PSP_EINVAL, "jacobi of a multi-device matrix: steps must be 1");
     PSP_TRY(multi_jacobi_setup(A->multi, omega));
@@ -2274,6 +2292,13 @@ int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **
   PSP_API_GUARD;
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_sss: NULL argument");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
+  if (A->host) {
+    psp_op op;
+    op.kind = PSP_OP_SSS;
+    op.n = A->n;
+    op.sss = A;
+    return cpu::jacobi_create(A->n, A->diag, omega, steps, &op, out);
+  }
   PSP_TRY(ensure_device());
   double *d;
   PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(A->n ? A->n : 1)));
@@ -2297,6 +2322,7 @@ int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int ste
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
   if (steps > 1 && !A_or_null)
     return fail(PSP_EINVAL, "jacobi: steps > 1 needs the matrix operator");
+  if (cpu_mode()) return cpu::jacobi_create(n, diag_host, omega, steps, A_or_null, out);
   PSP_TRY(ensure_device());
   double *d;
   PSP_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)n));
@@ -2312,6 +2338,7 @@ int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int ste
 
 int psp_jacobi_destroy(psp_jacobi_t *K) {
   if (!K) return PSP_OK;
+  if (K->host) return cpu::jacobi_destroy(K);
   if (K->multi) {
     delete K;
     return PSP_OK;
@@ -2339,6 +2366,7 @@ int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev) {
 int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
   PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
+  if (K->host) return cpu::jacobi_precon(K, x_host, y_host);
   if (K->multi) return multi_jacobi_apply_host(K->multi, x_host, y_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -2370,6 +2398,7 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
   if (multi) return multi_pcg(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  if (cpu_mode()) return cpu::pcg(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *b;
@@ -2400,6 +2429,7 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
   if (multi) return multi_minres(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  if (cpu_mode()) return cpu::minres(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *b;

@@ -67,6 +67,9 @@ struct psp_ssor {
   hipGraphExec_t exec = nullptr;
   hipStream_t cap_stream = nullptr;
   int graph_state = -1;  // -1 not tried, 0 unavailable (direct launches), 1 captured
+  // PSP_DEVICE=cpu (psp_cpu.hip): the reference's two sequential sweeps on the host arrays of S; two n-vectors of work
+  bool host = false;
+  std::vector<double> h_temp, h_temp2;
 };
 
 namespace {
@@ -767,12 +770,84 @@ int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
 
 }  // namespace
 
+namespace psp {
+// PSP_DEVICE=cpu: SSOR_precon (preconmodule.c:199-223) with its two kernels, symgs_kernel (:149-193, omega == 1) and
+// ssor_kernel (:95-146), as sequential sweeps over the host arrays of the sss_mat; x is the output
+int ssor_apply_host(psp_ssor *K, const double *b, double *x) {
+  const psp_sss *S = K->S;
+  const int n = K->n;
+  const double *va = S->val, *da = S->diag;
+  const int *ja = S->col, *ia = S->ind;
+  if (K->omega == 1.0) {
+    double *y = K->h_temp.data();
+    for (int k = 0; k < n; ++k) y[k] = 0.0;
+    for (int step = 0; step < K->steps; ++step) {
+      for (int i = 0; i < n; ++i) {  // x = (L + D) \ (b - y), y = L x
+        double s = 0.0;
+        for (int k = ia[i]; k < ia[i + 1]; ++k) s += va[k] * x[ja[k]];
+        x[i] = (b[i] - y[i] - s) / da[i];
+        y[i] = s;
+      }
+      for (int k = 0; k < n; ++k) {
+        x[k] = y[k];
+        y[k] = 0.0;
+      }
+      for (int i = n - 1; i >= 0; --i) {  // x = (L^T + D) \ (b - y), y = L^T x
+        x[i] = (b[i] - x[i] - y[i]) / da[i];
+        const double s = x[i];
+        for (int k = ia[i]; k < ia[i + 1]; ++k) y[ja[k]] += va[k] * s;
+      }
+    }
+    return PSP_OK;
+  }
+  const double omega = K->omega;
+  double *temp = K->h_temp.data(), *h = K->h_temp2.data();
+  for (int step = 0; step < K->steps; ++step) {
+    if (step == 0)
+      for (int i = 0; i < n; ++i) temp[i] = omega * b[i];
+    else
+      for (int i = 0; i < n; ++i) temp[i] = (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];
+    for (int i = 0; i < n; ++i) {
+      double s = 0.0;
+      for (int k = ia[i]; k < ia[i + 1]; ++k) s -= va[k] * x[ja[k]];
+      h[i] = omega * s;
+      x[i] = (temp[i] + h[i]) / da[i];
+    }
+    for (int i = 0; i < n; ++i) {
+      temp[i] = (1.0 - omega) * x[i] * da[i] + h[i] + omega * b[i];
+      h[i] = 0.0;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      h[i] = omega * h[i];
+      x[i] = (temp[i] + h[i]) / da[i];
+      const double s = x[i];
+      for (int k = ia[i]; k < ia[i + 1]; ++k) h[ja[k]] -= va[k] * s;
+    }
+  }
+  return PSP_OK;
+}
+}  // namespace psp
+
 extern "C" {
 
 int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
   PSP_API_GUARD;
   if (!S || !out) return fail(PSP_EINVAL, "psp_ssor_create: NULL argument");
   if (steps < 0) return fail(PSP_EINVAL, "ssor: steps must be >= 0");
+  if (S->host) {
+    psp_ssor *K = new psp_ssor();
+    K->n = S->n;
+    K->omega = omega;
+    K->steps = steps;
+    K->S = S;
+    K->host = true;
+    K->h_temp.assign((size_t)S->n, 0.0);
+    K->h_temp2.assign((size_t)S->n, 0.0);
+    K->ptr_f.assign(1, 0);
+    K->ptr_b.assign(1, 0);
+    *out = K;
+    return PSP_OK;
+  }
   PSP_TRY(ensure_device());
   psp_ssor *K = new psp_ssor();
   K->n = S->n;
@@ -812,6 +887,10 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
 
 int psp_ssor_destroy(psp_ssor_t *K) {
   if (!K) return PSP_OK;
+  if (K->host) {
+    delete K;
+    return PSP_OK;
+  }
   if (K->exec) (void)hipGraphExecDestroy(K->exec);
   if (K->graph) (void)hipGraphDestroy(K->graph);
   if (K->cap_stream) (void)hipStreamDestroy(K->cap_stream);
@@ -843,6 +922,7 @@ int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host) {
   PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_ssor_precon: NULL argument");
   if (K->n == 0) return PSP_OK;
+  if (K->host) return psp::ssor_apply_host(K, x_host, y_host);
   PSP_TRY(ensure_device());
   double *x = nullptr, *y = nullptr;
   const size_t bytes = sizeof(double) * (size_t)K->n;
