@@ -255,6 +255,14 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+// psp_coop.hip: the whole loop as one kernel for small systems (grid barriers instead of dependent launches)
+bool coop_applicable(const psp_csr *A, int n);
+int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
+                  double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres,
+                  double *hist);
+int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old,
+                     double *y, double *w, double *w_old, double *v, double *av, double norm_r0, double beta0,
+                     double errtol, int it_max, int *info, int *iter, double *relres, double *hist);
 // psp_cpu.hip: the host loops behind the entry points when PSP_DEVICE=cpu
 namespace cpu {
 int csr_create(int nrows, int ncols, int nnz, const int *ind, const int *col, const double *val, psp_csr **out);

@@ -731,6 +731,8 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     return PSP_OK;
   }
 
+  if (fused && maxit >= 1 && coop_applicable(Acsr, n))  // small system: the whole loop is one kernel (psp_coop.hip)
+    return pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
   if (fused && maxit >= 1 && pcg_async_enabled() && csr_spmv_has_skip(Acsr)) {
     if (rho_next == 0.0) {  // pcg.c:101-104 in iteration 1
       *info = -2;
@@ -1168,6 +1170,10 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   double norm_rmr = norm_r0;
   if (hist) hist[0] = norm_rmr;
 
+  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n))
+    // small system: the whole loop is one kernel (psp_coop.hip)
+    return minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0, beta,
+                            errtol, it_max, info, iter, relres, hist);
   if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
     // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
     return minres_async_loop(Acsr, dinv, hasK, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,

@@ -407,7 +407,9 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
                 {"PSP_PCG_PFUSED": "1", "PSP_PCG_ASYNC": "0"}, {"PSP_DINV_CONST": "0"},
                 {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}, {"PSP_PCG_LAZYX": "2"},
                 {"PSP_PCG_LAZYX": "2", "PSP_DINV_CONST": "0"}):
-        e = dict(os.environ, PSP_TUNING="1")  # the master switch that makes the library read its A/B variables
+        # PSP_TUNING: the master switch that makes the library read its A/B variables; PSP_COOP=0: these tests compare
+        # the launch-per-phase loops with each other (at this size the default is the single-kernel loop, psp_coop.hip)
+        e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
         outs.append(json.loads(out.strip().splitlines()[-1]))
@@ -444,7 +446,9 @@ def test_minres_loop_variants_agree(oracle):
     outs = []
     for env in ({"PSP_MINRES_ASYNC": "0"}, {}, {"PSP_MINRES_SCALED": "0"},
                 {"PSP_MINRES_SCALED": "0", "PSP_MINRES_ASYNC": "0"}):
-        e = dict(os.environ, PSP_TUNING="1")  # the master switch that makes the library read its A/B variables
+        # PSP_TUNING: the master switch that makes the library read its A/B variables; PSP_COOP=0: these tests compare
+        # the launch-per-phase loops with each other (at this size the default is the single-kernel loop, psp_coop.hip)
+        e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
         outs.append(json.loads(out.strip().splitlines()[-1]))
@@ -560,7 +564,9 @@ def test_pcg_lazy_x_update_exit_semantics_match_eager_loop():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "2"}, {"PSP_PCG_ASYNC": "0"}):
-        e = dict(os.environ, PSP_TUNING="1")  # the master switch that makes the library read its A/B variables
+        # PSP_TUNING: the master switch that makes the library read its A/B variables; PSP_COOP=0: these tests compare
+        # the launch-per-phase loops with each other (at this size the default is the single-kernel loop, psp_coop.hip)
+        e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
         outs.append(json.loads(out.strip().splitlines()[-1]))
