@@ -8,8 +8,9 @@
 //   PCG   : [p update] | [q = A p, p.q] | [stagnation scan, x, r, r.r, r.z]        3 barriers per iteration
 //   MINRES: [v = y/beta] | [Av = A v, v.Av] | [Lanczos update, y = K v_hat, v_hat.y] | (w, x: rows of their own)
 // -- and every workgroup evaluates the scalar recurrences itself from the same reduced values (the same operations
-// on the same bits, so all of them take the same branch and leave the loop together).  Up to 16384 rows ONE workgroup
-// does it all and the barriers are plain __syncthreads().
+// on the same bits, so all of them take the same branch and leave the loop together).  A thread owns 1, 2 or 4 rows for
+// the whole solve: their matrix entries (up to 8 per row) and their slices of x, r, ... stay in REGISTERS; the only
+// vector that crosses workgroups is the one the product gathers (p, resp. v), and the partial sums.
 //
 // Arithmetic: per element the reference's operations, multiply and add rounded separately (-ffp-contract=off); a row's
 // products are added left to right (csr_mat.c:49-54); a reduction is: a thread adds its rows in ascending order, the
@@ -20,7 +21,7 @@
 // Grid barrier (MI355X_MICROARCH.md "Correctness boundaries", cdna_hip_programming.md G16): the per-XCD L2s are not
 // coherent with each other, so data handed from one workgroup to another goes through an agent-scope release by every
 // storing thread before the workgroup barrier, one arrival counter (device-scope atomics), and an agent-scope acquire
-// before the first load after the barrier.  The grid is at most 64 workgroups of 256 threads -- far below one per CU --
+// before the first load after the barrier.  The grid is at most 128 workgroups of 256 threads -- half a workgroup per CU --
 // and every spin is bounded: a barrier that does not complete sets an error flag that ends all workgroups.
 #include <algorithm>
 #include <vector>
@@ -31,11 +32,8 @@ namespace psp {
 
 namespace {
 
-constexpr int kCoopBlock = 1024;     // one workgroup: 16 waves
-constexpr int kCoopMultiBlock = 256;
-constexpr int kCoopOneWgRows = 16384;
 constexpr int kCoopMaxRows = 1 << 17;  // beyond that the asynchronous loops (whole-chip kernels) are faster
-constexpr int kCoopMaxWg = 64;
+constexpr int kCoopMaxWg = 128;  // workgroups of 256 threads: far below one per CU slot, all co-resident
 
 struct CoopCtl {
   unsigned count;
@@ -111,22 +109,76 @@ __device__ __forceinline__ void grid_sum(double (&v)[NV], const double *part, in
   __syncthreads();
 }
 
-__device__ __forceinline__ double row_product(const int *__restrict__ ind, const int *__restrict__ col,
-                                              const double *__restrict__ val, const double *x, int i) {
-  double s = 0.0;  // csr_mat.c:49-54: left to right from 0.0
-  for (int k = ind[i]; k < ind[i + 1]; ++k) s += val[k] * x[col[k]];
-  return s;
-}
+constexpr int kRegNz = 8;  // entries of a row kept in registers (every 5- / 7-point row); longer rows are re-read
 
-// pcg.c:91-166 from the head of iteration 1: r = b - A x, rho = r.z and ||r|| > tolb are the caller's
-__global__ void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind, const int *__restrict__ col,
-                                const double *__restrict__ val, const double *__restrict__ dinv, double *x,
-                                double *r, double *p, double *q, double n2b, double tolb, double normr0, double rho0,
-                                int maxit, CoopCtl *ctl, double *part, double *hist) {
+// The rows a thread owns for the whole solve: row j of thread t in workgroup wg is (wg * blockDim + t) + j * stride,
+// stride = nwg * blockDim (consecutive threads on consecutive rows).  The matrix is constant across iterations, so a
+// row's entries are loaded ONCE into registers; per iteration a product costs only the gathers of the shared vector.
+template <int R>
+struct OwnedRows {
+  int row[R];
+  int cnt[R];    // entries of the row (0 for a slot past the end)
+  int first[R];  // ind[row]
+  double val[R][kRegNz];
+  int col[R][kRegNz];
+  __device__ __forceinline__ void load(int n, int nwg, const int *__restrict__ ind, const int *__restrict__ cidx,
+                                       const double *__restrict__ v) {
+    const int stride = nwg * (int)blockDim.x;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x + j * stride;
+      row[j] = i;
+      cnt[j] = 0;
+      first[j] = 0;
+      if (i < n) {
+        first[j] = ind[i];
+        cnt[j] = ind[i + 1] - first[j];
+      }
+#pragma unroll
+      for (int k = 0; k < kRegNz; ++k) {
+        const bool have = k < cnt[j];
+        val[j][k] = have ? v[first[j] + k] : 0.0;
+        col[j][k] = have ? cidx[first[j] + k] : 0;
+      }
+    }
+  }
+  // csr_mat.c:49-54: the row's stored products added left to right from 0.0 (absent slots are not touched)
+  __device__ __forceinline__ double product(int j, const int *__restrict__ cidx, const double *__restrict__ v,
+                                            const double *x) const {
+    double g[kRegNz];
+#pragma unroll
+    for (int k = 0; k < kRegNz; ++k) g[k] = k < cnt[j] ? x[col[j][k]] : 0.0;  // independent gathers
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRegNz; ++k)
+      if (k < cnt[j]) s += val[j][k] * g[k];
+    for (int k = kRegNz; k < cnt[j]; ++k) s += v[first[j] + k] * x[cidx[first[j] + k]];  // a longer row: from memory
+    return s;
+  }
+};
+
+// pcg.c:91-166 from the head of iteration 1: r = b - A x, rho = r.z and ||r|| > tolb are the caller's.
+// x, r and q live in registers for the whole solve; p is the one vector other workgroups read.
+template <int R>
+__global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind,
+                                                       const int *__restrict__ col, const double *__restrict__ val,
+                                                       const double *__restrict__ dinv, double *x, const double *r,
+                                                       double *p, double n2b, double tolb, double normr0, double rho0,
+                                                       int maxit, CoopCtl *ctl, double *part, double *hist) {
   __shared__ double sh[16 * 3 + 8];
   const int wg = blockIdx.x;
-  const int per = (n + nwg - 1) / nwg;
-  const int r0 = wg * per, r1 = min(n, r0 + per);
+  OwnedRows<R> rows;
+  rows.load(n, nwg, ind, col, val);
+  double xr[R], rr[R], pr[R], qr[R], dr[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const bool in = rows.row[j] < n;
+    xr[j] = in ? x[rows.row[j]] : 0.0;
+    rr[j] = in ? r[rows.row[j]] : 0.0;
+    dr[j] = (in && dinv) ? dinv[rows.row[j]] : 1.0;
+    pr[j] = 0.0;
+    qr[j] = 0.0;
+  }
   unsigned gen = 0;
   double rho = rho0, rho1 = 1.0, normr = normr0, alpha, beta = 0.0;
   int flag = -1, it;
@@ -142,16 +194,18 @@ __global__ void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind, con
         break;
       }
     }
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {  // pcg.c:93-97, :106, :113-114
-      const double z = dinv ? r[i] * dinv[i] : r[i];
-      p[i] = it == 1 ? z : z + beta * p[i];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // pcg.c:93-97, :106, :113-114
+      const double z = dinv ? rr[j] * dr[j] : rr[j];
+      pr[j] = it == 1 ? z : z + beta * pr[j];
+      if (rows.row[j] < n) p[rows.row[j]] = pr[j];
     }
     if (!coop_barrier(ctl, nwg, gen)) return;
     double v1[1] = {0.0};
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {  // pcg.c:116-117
-      const double s = row_product(ind, col, val, p, i);
-      q[i] = s;
-      v1[0] += p[i] * s;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // pcg.c:116-117
+      qr[j] = rows.product(j, col, val, p);
+      v1[0] += pr[j] * qr[j];
     }
     block_sum<1>(v1, sh);
     if (nwg > 1) {
@@ -167,27 +221,25 @@ __global__ void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind, con
     alpha = rho / pq;
     const int stag0 = alpha == 0.0;  // pcg.c:124-125
     double v3[3] = {0.0, 0.0, 0.0};  // r.r, r.z, number of rows that did not stagnate
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {
-      const double xi = x[i], pi = p[i];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (rows.row[j] >= n) continue;
       if (!stag0) {  // pcg.c:127-139 (the scan reads x before the update)
-        if (xi != 0.0) {
-          if (1.0 + fabs(alpha * pi / xi) != 1.0) v3[2] += 1.0;
-        } else if (pi != 0.0) {
+        if (xr[j] != 0.0) {
+          if (1.0 + fabs(alpha * pr[j] / xr[j]) != 1.0) v3[2] += 1.0;
+        } else if (pr[j] != 0.0) {
           v3[2] += 1.0;
         }
       }
-      double ri = r[i];
       if (alpha != 0.0) {  // daxpy returns at once for a zero coefficient
-        x[i] = xi + alpha * pi;
-        ri = ri + (-alpha) * q[i];
-        r[i] = ri;
+        xr[j] = xr[j] + alpha * pr[j];
+        rr[j] = rr[j] + (-alpha) * qr[j];
       }
-      v3[0] += ri * ri;
-      v3[1] += ri * (dinv ? ri * dinv[i] : ri);
+      v3[0] += rr[j] * rr[j];
+      v3[1] += rr[j] * (dinv ? rr[j] * dr[j] : rr[j]);
     }
     block_sum<3>(v3, sh);
     if (nwg > 1) {
-      // a second set of slots: a fast workgroup may already be here while a slow one still adds the p.q slots
       if (threadIdx.x < 3) part[(1 + threadIdx.x) * kCoopMaxWg + wg] = v3[threadIdx.x];
       if (!coop_barrier(ctl, nwg, gen)) return;
       grid_sum<3>(v3, part + kCoopMaxWg, nwg, sh);
@@ -205,6 +257,9 @@ __global__ void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind, con
     rho1 = rho;
     rho = v3[1];
   }
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (rows.row[j] < n) x[rows.row[j]] = xr[j];
   if (wg == 0 && threadIdx.x == 0) {
     ctl->info = flag;
     ctl->iter = it;  // maxit + 1 when the loop ran out (pcg.c:165)
@@ -212,30 +267,47 @@ __global__ void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind, con
   }
 }
 
-// minres.c:96-193; v_hat = b - A x, y = K v_hat (hasK), beta = sqrt(v_hat.y), w = w_old = v_hat_old = 0 are the caller's
-__global__ void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind, const int *__restrict__ col,
-                                   const double *__restrict__ val, const double *__restrict__ dinv, double *x,
-                                   double *v_hat, double *v_hat_old, double *y, double *w, double *w_old, double *v,
-                                   double *av, double norm_r0, double beta0, double errtol, int it_max, CoopCtl *ctl,
-                                   double *part, double *hist) {
+// minres.c:96-193; v_hat = b - A x, y = K v_hat (dinv), beta = sqrt(v_hat.y) are the caller's; w = w_old = v_hat_old = 0.
+// Everything but v (the vector other workgroups read) lives in registers.
+template <int R>
+__global__ __launch_bounds__(256) void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind,
+                                                          const int *__restrict__ col, const double *__restrict__ val,
+                                                          const double *__restrict__ dinv, double *x,
+                                                          const double *v_hat, const double *y, double *v,
+                                                          double norm_r0, double beta0, double errtol, int it_max,
+                                                          CoopCtl *ctl, double *part, double *hist) {
   __shared__ double sh[16 + 8];
   const int wg = blockIdx.x;
-  const int per = (n + nwg - 1) / nwg;
-  const int r0 = wg * per, r1 = min(n, r0 + per);
+  OwnedRows<R> rows;
+  rows.load(n, nwg, ind, col, val);
+  double xr[R], vh[R], vho[R], yr[R], wr[R], wo[R], vr[R], dr[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const bool in = rows.row[j] < n;
+    xr[j] = in ? x[rows.row[j]] : 0.0;
+    vh[j] = in ? v_hat[rows.row[j]] : 0.0;
+    dr[j] = (in && dinv) ? dinv[rows.row[j]] : 1.0;
+    yr[j] = dinv ? (in ? y[rows.row[j]] : 0.0) : vh[j];
+    vho[j] = wr[j] = wo[j] = vr[j] = 0.0;
+  }
   unsigned gen = 0;
   double beta = beta0, beta_old = 1.0, c = 1.0, c_old = 1.0, s = 0.0, s_old = 0.0, eta = beta0, norm_rmr = norm_r0;
   int it = 0, info = 1;  // 1: left by the loop test (0 / -1 decided below)
-  const double *ysrc = dinv ? y : v_hat;
   for (;;) {
     if (it >= it_max || norm_rmr < errtol * norm_r0) break;  // minres.c:114
     it += 1;
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) v[i] = ysrc[i] / beta;  // :123-124
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // :123-124
+      vr[j] = yr[j] / beta;
+      if (rows.row[j] < n) v[rows.row[j]] = vr[j];
+    }
     if (!coop_barrier(ctl, nwg, gen)) return;
     double a1[1] = {0.0};
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {  // :127-129
-      const double t = row_product(ind, col, val, v, i);
-      av[i] = t;
-      a1[0] += v[i] * t;
+    double avr[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // :127-129
+      avr[j] = rows.product(j, col, val, v);
+      a1[0] += vr[j] * avr[j];
     }
     block_sum<1>(a1, sh);
     if (nwg > 1) {
@@ -246,17 +318,13 @@ __global__ void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind, 
     const double alpha = a1[0];
     const double c1 = alpha / beta, c2 = beta / beta_old;  // :131
     double b1[1] = {0.0};
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {  // :132-143
-      const double vh = v_hat[i];
-      const double t = av[i] - c1 * vh - c2 * v_hat_old[i];
-      v_hat_old[i] = vh;
-      v_hat[i] = t;
-      double yi = t;
-      if (dinv) {
-        yi = t * dinv[i];
-        y[i] = yi;
-      }
-      b1[0] += t * yi;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // :132-143
+      const double t = avr[j] - c1 * vh[j] - c2 * vho[j];
+      vho[j] = vh[j];
+      vh[j] = t;
+      yr[j] = dinv ? t * dr[j] : t;
+      b1[0] += t * yr[j];
     }
     block_sum<1>(b1, sh);
     if (nwg > 1) {
@@ -285,17 +353,20 @@ __global__ void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind, 
     c = r1_hat / rr1;
     s = beta / rr1;
     const double ce = c * eta;
-    for (int i = r0 + (int)threadIdx.x; i < r1; i += blockDim.x) {  // :172-180
-      const double tmp = w[i];
-      const double wn = (v[i] - rr3 * w_old[i] - rr2 * tmp) / rr1;
-      w[i] = wn;
-      w_old[i] = tmp;
-      x[i] += ce * wn;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {  // :172-180
+      const double tmp = wr[j];
+      wr[j] = (vr[j] - rr3 * wo[j] - rr2 * tmp) / rr1;
+      wo[j] = tmp;
+      xr[j] += ce * wr[j];
     }
     eta = -s * eta;
     norm_rmr *= fabs(s);  // :192
     if (hist && wg == 0 && threadIdx.x == 0) hist[it] = norm_rmr;
   }
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (rows.row[j] < n) x[rows.row[j]] = xr[j];
   if (wg == 0 && threadIdx.x == 0) {
     ctl->iter = it;
     if (info == 1) {
@@ -334,14 +405,12 @@ struct CoopMem {
   }
 };
 
-void coop_grid(int n, int *nwg, int *block) {
-  if (n <= kCoopOneWgRows) {
-    *nwg = 1;
-    *block = kCoopBlock;
-  } else {
-    *nwg = std::min(kCoopMaxWg, (n + 1023) / 1024);  // >= 4 rows per thread
-    *block = kCoopMultiBlock;
-  }
+// rows per thread (1, 2 or 4) so that at most kCoopMaxWg workgroups of 256 threads cover the rows
+void coop_grid(int n, int *nwg, int *rpt) {
+  int r = 1;
+  while (r < 4 && (n + 256 * r - 1) / (256 * r) > kCoopMaxWg) r *= 2;
+  *rpt = r;
+  *nwg = std::max(1, (n + 256 * r - 1) / (256 * r));
 }
 
 bool coop_enabled() {
@@ -365,10 +434,16 @@ int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double
                   double *hist) {
   CoopMem m;
   PSP_TRY(m.init(maxit, hist != nullptr));
-  int nwg, block;
-  coop_grid(n, &nwg, &block);
-  hipLaunchKernelGGL(pcg_coop_kernel, dim3(nwg), dim3(block), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x, r, p,
-                     q, n2b, tolb, normr0, rho0, maxit, m.ctl, m.part, m.hist);
+  int nwg, rpt;
+  coop_grid(n, &nwg, &rpt);
+  (void)q;
+#define PSP_COOP_PCG(R)                                                                                              \
+  hipLaunchKernelGGL((pcg_coop_kernel<R>), dim3(nwg), dim3(256), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x, \
+                     r, p, n2b, tolb, normr0, rho0, maxit, m.ctl, m.part, m.hist)
+  if (rpt == 1) PSP_COOP_PCG(1);
+  else if (rpt == 2) PSP_COOP_PCG(2);
+  else PSP_COOP_PCG(4);
+#undef PSP_COOP_PCG
   PSP_LAUNCH_CHECK();
   CoopCtl c;
   PSP_TRY(m.fetch(&c));
@@ -392,10 +467,19 @@ int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, dou
                      double errtol, int it_max, int *info, int *iter, double *relres, double *hist) {
   CoopMem m;
   PSP_TRY(m.init(it_max, hist != nullptr));
-  int nwg, block;
-  coop_grid(n, &nwg, &block);
-  hipLaunchKernelGGL(minres_coop_kernel, dim3(nwg), dim3(block), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x,
-                     v_hat, v_hat_old, y, w, w_old, v, av, norm_r0, beta0, errtol, it_max, m.ctl, m.part, m.hist);
+  int nwg, rpt;
+  coop_grid(n, &nwg, &rpt);
+  (void)v_hat_old;
+  (void)w;
+  (void)w_old;
+  (void)av;
+#define PSP_COOP_MR(R)                                                                                               \
+  hipLaunchKernelGGL((minres_coop_kernel<R>), dim3(nwg), dim3(256), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, \
+                     x, v_hat, y, v, norm_r0, beta0, errtol, it_max, m.ctl, m.part, m.hist)
+  if (rpt == 1) PSP_COOP_MR(1);
+  else if (rpt == 2) PSP_COOP_MR(2);
+  else PSP_COOP_MR(4);
+#undef PSP_COOP_MR
   PSP_LAUNCH_CHECK();
   CoopCtl c;
   PSP_TRY(m.fetch(&c));

@@ -269,7 +269,12 @@ def test_poisson_big_equals_csr_operator(oracle, grid):
     xa, xb = np.zeros(n), np.zeros(n)
     ra = dev.pcg(A, b, xa, 1e-10, 2000, dev.DeviceJacobi(A))
     rb = dev.pcg(B, b, xb, 1e-10, 2000, dev.DeviceJacobi(B))
-    assert ra == rb and np.array_equal(xa, xb)
+    # the same operator in two layouts: identical counts; bit-identical iterates when both run the same loop (an operator
+    # with CSR arrays and <= 2^17 rows takes the single-kernel loop of psp_coop.hip, the index-free one never does)
+    assert ra[:2] == rb[:2] and abs(ra[2] - rb[2]) <= 1e-6 * rb[2]
+    assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xb).max()
+    if n > (1 << 17):
+        assert ra == rb and np.array_equal(xa, xb)
     with pytest.raises(PspError):
         B.download()
     ta, tb, to = np.empty(n), np.empty(n), np.empty(n)
