@@ -8,8 +8,8 @@
 //   PCG   : [p update] | [q = A p, p.q] | [stagnation scan, x, r, r.r, r.z]        3 barriers per iteration
 //   MINRES: [v = y/beta] | [Av = A v, v.Av] | [Lanczos update, y = K v_hat, v_hat.y] | (w, x: rows of their own)
 // -- and every workgroup evaluates the scalar recurrences itself from the same reduced values (the same operations
-// on the same bits, so all of them take the same branch and leave the loop together).  A thread owns 1, 2 or 4 rows for
-// the whole solve: their matrix entries (up to 8 per row) and their slices of x, r, ... stay in REGISTERS; the only
+// on the same bits, so all of them take the same branch and leave the loop together).  A thread owns its rows for
+// the whole solve (1 or 2 rows): their matrix entries (up to 8 per row) and their slices of x, r, ... stay in REGISTERS; the only
 // vector that crosses workgroups is the one the product gathers (p, resp. v), and the partial sums.
 //
 // Arithmetic: per element the reference's operations, multiply and add rounded separately (-ffp-contract=off); a row's
@@ -18,10 +18,9 @@
 // every workgroup -- fixed for a given matrix size, so runs are bitwise reproducible.  (The order differs from the
 // asynchronous loops': iterates agree with theirs to rounding, not bit for bit; counts and goldens are tested.)
 //
-// Grid barrier (MI355X_MICROARCH.md "Correctness boundaries", cdna_hip_programming.md G16): the per-XCD L2s are not
-// coherent with each other, so data handed from one workgroup to another goes through an agent-scope release by every
-// storing thread before the workgroup barrier, one arrival counter (device-scope atomics), and an agent-scope acquire
-// before the first load after the barrier.  The grid is at most 128 workgroups of 256 threads -- half a workgroup per CU --
+// Grid barrier (MI355X_MICROARCH.md "Correctness boundaries", cdna_hip_programming.md G16, second form): the per-XCD
+// L2s are not coherent with each other, so every byte handed from one workgroup to another is stored AND loaded with
+// agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 16 workgroups of 1024 threads --
 // and every spin is bounded: a barrier that does not complete sets an error flag that ends all workgroups.
 #include <algorithm>
 #include <vector>
@@ -32,8 +31,9 @@ namespace psp {
 
 namespace {
 
-constexpr int kCoopMaxRows = 1 << 17;  // beyond that the asynchronous loops (whole-chip kernels) are faster
-constexpr int kCoopMaxWg = 128;  // workgroups of 256 threads: far below one per CU slot, all co-resident
+constexpr int kCoopBlock = 1024;
+constexpr int kCoopMaxRows = 1 << 14;  // 16 workgroups; beyond that the asynchronous loops (whole-chip kernels) win
+constexpr int kCoopMaxWg = 16;  // workgroups of 1024 threads: far fewer than CUs, all co-resident
 
 struct CoopCtl {
   unsigned count;
@@ -43,32 +43,43 @@ struct CoopCtl {
   double relres;
 };
 
+// Vectors and partial sums that cross workgroups are written and read with agent-scope (device-coherent) accesses --
+// relaxed atomics, i.e. plain global_store / global_load with the sc1 bit: they go past the non-coherent levels, so no
+// cache-wide write-back (release) or invalidate (acquire) is needed around the barrier, which cost ~8 us per barrier
+// when every wave issued them.
+__device__ __forceinline__ void coh_store(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coh_load(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ bool coop_barrier(CoopCtl *c, int nwg, unsigned &gen) {
   if (nwg == 1) {
     __syncthreads();
     return true;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's stores are visible device-wide ...
-  __syncthreads();                                    // ... before the workgroup announces itself
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores have completed (s_waitcnt) ...
+  __syncthreads();                                        // ... before the workgroup announces itself
   if (threadIdx.x == 0) {
-    const unsigned arrived = __hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned arrived = __hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (arrived == (unsigned)nwg - 1u) {
       __hip_atomic_store(&c->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&c->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the reset is out before the generation moves
+      __hip_atomic_fetch_add(&c->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       long spins = 0;
-      while (__hip_atomic_load(&c->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         if (++spins > (1L << 26) || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
       }
     }
   }
   gen += 1;
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached from before the barrier is read after it
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // orders the coherent loads below after the barrier
   return __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
@@ -100,7 +111,7 @@ template <int NV>
 __device__ __forceinline__ void grid_sum(double (&v)[NV], const double *part, int nwg, double *sh) {
   if (threadIdx.x < NV) {
     double t = 0.0;
-    for (int w = 0; w < nwg; ++w) t += part[threadIdx.x * kCoopMaxWg + w];
+    for (int w = 0; w < nwg; ++w) t += coh_load(part + threadIdx.x * kCoopMaxWg + w);
     sh[threadIdx.x] = t;
   }
   __syncthreads();
@@ -111,73 +122,57 @@ __device__ __forceinline__ void grid_sum(double (&v)[NV], const double *part, in
 
 constexpr int kRegNz = 8;  // entries of a row kept in registers (every 5- / 7-point row); longer rows are re-read
 
-// The rows a thread owns for the whole solve: row j of thread t in workgroup wg is (wg * blockDim + t) + j * stride,
-// stride = nwg * blockDim (consecutive threads on consecutive rows).  The matrix is constant across iterations, so a
-// row's entries are loaded ONCE into registers; per iteration a product costs only the gathers of the shared vector.
-template <int R>
-struct OwnedRows {
-  int row[R];
-  int cnt[R];    // entries of the row (0 for a slot past the end)
-  int first[R];  // ind[row]
-  double val[R][kRegNz];
-  int col[R][kRegNz];
-  __device__ __forceinline__ void load(int n, int nwg, const int *__restrict__ ind, const int *__restrict__ cidx,
+// The row a thread owns for the whole solve: row = wg * 1024 + t.  The matrix is constant across iterations, so the
+// row's entries (and the Jacobi factors of its COLUMNS) are loaded once into registers; per iteration a product costs
+// only the gathers of the one vector that crosses workgroups.
+struct OwnedRow {
+  int row, cnt, first;
+  double val[kRegNz];
+  int col[kRegNz];
+  __device__ __forceinline__ void load(int n, const int *__restrict__ ind, const int *__restrict__ cidx,
                                        const double *__restrict__ v) {
-    const int stride = nwg * (int)blockDim.x;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x + j * stride;
-      row[j] = i;
-      cnt[j] = 0;
-      first[j] = 0;
-      if (i < n) {
-        first[j] = ind[i];
-        cnt[j] = ind[i + 1] - first[j];
-      }
-#pragma unroll
-      for (int k = 0; k < kRegNz; ++k) {
-        const bool have = k < cnt[j];
-        val[j][k] = have ? v[first[j] + k] : 0.0;
-        col[j][k] = have ? cidx[first[j] + k] : 0;
-      }
+    row = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+    cnt = 0;
+    first = 0;
+    if (row < n) {
+      first = ind[row];
+      cnt = ind[row + 1] - first;
     }
-  }
-  // csr_mat.c:49-54: the row's stored products added left to right from 0.0 (absent slots are not touched)
-  __device__ __forceinline__ double product(int j, const int *__restrict__ cidx, const double *__restrict__ v,
-                                            const double *x) const {
-    double g[kRegNz];
 #pragma unroll
-    for (int k = 0; k < kRegNz; ++k) g[k] = k < cnt[j] ? x[col[j][k]] : 0.0;  // independent gathers
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < kRegNz; ++k)
-      if (k < cnt[j]) s += val[j][k] * g[k];
-    for (int k = kRegNz; k < cnt[j]; ++k) s += v[first[j] + k] * x[cidx[first[j] + k]];  // a longer row: from memory
-    return s;
+    for (int k = 0; k < kRegNz; ++k) {
+      const bool have = k < cnt;
+      val[k] = have ? v[first + k] : 0.0;
+      col[k] = have ? cidx[first + k] : 0;
+    }
   }
 };
 
 // pcg.c:91-166 from the head of iteration 1: r = b - A x, rho = r.z and ||r|| > tolb are the caller's.
-// x, r and q live in registers for the whole solve; p is the one vector other workgroups read.
-template <int R>
-__global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind,
-                                                       const int *__restrict__ col, const double *__restrict__ val,
-                                                       const double *__restrict__ dinv, double *x, const double *r,
-                                                       double *p, double n2b, double tolb, double normr0, double rho0,
-                                                       int maxit, CoopCtl *ctl, double *part, double *hist) {
+// x, r, p, q of the thread's row live in registers for the whole solve.  What crosses workgroups per iteration is r
+// alone, published at the SAME barrier as the partial sums of r.r / r.z: a thread forms the entries of p it multiplies
+// with, p[c] = z[c] + beta p_old[c] with z[c] = r[c] dinv[c], itself -- the owner's own two rounded operations on the
+// same operands, so the same bits -- from the gathered r[c] and the p[c] it kept from the previous iteration.  Two grid
+// barriers per iteration (p.q; r.r / r.z) instead of three.
+__global__ __launch_bounds__(kCoopBlock) void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind,
+                                                              const int *__restrict__ col,
+                                                              const double *__restrict__ val,
+                                                              const double *__restrict__ dinv, double *x, double *r,
+                                                              double n2b, double tolb, double normr0, double rho0,
+                                                              int maxit, CoopCtl *ctl, double *part, double *hist) {
   __shared__ double sh[16 * 3 + 8];
   const int wg = blockIdx.x;
-  OwnedRows<R> rows;
-  rows.load(n, nwg, ind, col, val);
-  double xr[R], rr[R], pr[R], qr[R], dr[R];
+  OwnedRow a;
+  a.load(n, ind, col, val);
+  const bool in = a.row < n;
+  double xr = in ? x[a.row] : 0.0, rr = in ? r[a.row] : 0.0, pr = 0.0, qr = 0.0;
+  const double dr = (in && dinv) ? dinv[a.row] : 1.0;
+  double dc[kRegNz], rc[kRegNz], pc[kRegNz];  // Jacobi factor, r and p at the row's columns
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const bool in = rows.row[j] < n;
-    xr[j] = in ? x[rows.row[j]] : 0.0;
-    rr[j] = in ? r[rows.row[j]] : 0.0;
-    dr[j] = (in && dinv) ? dinv[rows.row[j]] : 1.0;
-    pr[j] = 0.0;
-    qr[j] = 0.0;
+  for (int k = 0; k < kRegNz; ++k) {
+    const bool have = k < a.cnt;
+    dc[k] = (have && dinv) ? dinv[a.col[k]] : 1.0;
+    rc[k] = have ? r[a.col[k]] : 0.0;
+    pc[k] = 0.0;
   }
   unsigned gen = 0;
   double rho = rho0, rho1 = 1.0, normr = normr0, alpha, beta = 0.0;
@@ -194,22 +189,27 @@ __global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int
         break;
       }
     }
+    {  // pcg.c:93-97, :106, :113-114 -- for the own row and for the row's columns
+      const double z = dinv ? rr * dr : rr;
+      pr = it == 1 ? z : z + beta * pr;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {  // pcg.c:93-97, :106, :113-114
-      const double z = dinv ? rr[j] * dr[j] : rr[j];
-      pr[j] = it == 1 ? z : z + beta * pr[j];
-      if (rows.row[j] < n) p[rows.row[j]] = pr[j];
+      for (int k = 0; k < kRegNz; ++k) {
+        const double zc = dinv ? rc[k] * dc[k] : rc[k];
+        pc[k] = it == 1 ? zc : zc + beta * pc[k];
+      }
     }
-    if (!coop_barrier(ctl, nwg, gen)) return;
-    double v1[1] = {0.0};
+    double v1[1];
+    {  // pcg.c:116-117; csr_mat.c:49-54: the stored products left to right from 0.0
+      double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {  // pcg.c:116-117
-      qr[j] = rows.product(j, col, val, p);
-      v1[0] += pr[j] * qr[j];
+      for (int k = 0; k < kRegNz; ++k)
+        if (k < a.cnt) sum += a.val[k] * pc[k];
+      qr = sum;
+      v1[0] = pr * qr;
     }
     block_sum<1>(v1, sh);
     if (nwg > 1) {
-      if (threadIdx.x == 0) part[wg] = v1[0];
+      if (threadIdx.x == 0) coh_store(part + wg, v1[0]);
       if (!coop_barrier(ctl, nwg, gen)) return;
       grid_sum<1>(v1, part, nwg, sh);
     }
@@ -220,27 +220,27 @@ __global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int
     }
     alpha = rho / pq;
     const int stag0 = alpha == 0.0;  // pcg.c:124-125
-    double v3[3] = {0.0, 0.0, 0.0};  // r.r, r.z, number of rows that did not stagnate
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      if (rows.row[j] >= n) continue;
-      if (!stag0) {  // pcg.c:127-139 (the scan reads x before the update)
-        if (xr[j] != 0.0) {
-          if (1.0 + fabs(alpha * pr[j] / xr[j]) != 1.0) v3[2] += 1.0;
-        } else if (pr[j] != 0.0) {
-          v3[2] += 1.0;
-        }
+    double v3[3] = {0.0, 0.0, 0.0};  // r.r, r.z, number of threads whose row did not stagnate
+    if (in) {
+      double dmax = 0.0;
+      if (!stag0) {  // pcg.c:127-139 (the scan reads x before the update); a NaN never replaces dmax, like `if (ddum > dmax)`;
+                     // x == 0 and p != 0 ASSIGNS dmax = 1.0, which for the test 1 + dmax == 1 is max(dmax, 1.0)
+        const double ddum = xr != 0.0 ? fabs(alpha * pr / xr) : (pr != 0.0 ? 1.0 : 0.0);
+        dmax = (ddum > dmax) ? ddum : dmax;
       }
       if (alpha != 0.0) {  // daxpy returns at once for a zero coefficient
-        xr[j] = xr[j] + alpha * pr[j];
-        rr[j] = rr[j] + (-alpha) * qr[j];
+        xr = xr + alpha * pr;
+        rr = rr + (-alpha) * qr;
       }
-      v3[0] += rr[j] * rr[j];
-      v3[1] += rr[j] * (dinv ? rr[j] * dr[j] : rr[j]);
+      v3[0] = rr * rr;
+      v3[1] = rr * (dinv ? rr * dr : rr);
+      v3[2] = (1.0 + dmax != 1.0) ? 1.0 : 0.0;
+      if (nwg > 1) coh_store(r + a.row, rr);  // the one vector other workgroups read
+      else r[a.row] = rr;
     }
-    block_sum<3>(v3, sh);
+    block_sum<3>(v3, sh);  // (one workgroup: its barriers also publish r)
     if (nwg > 1) {
-      if (threadIdx.x < 3) part[(1 + threadIdx.x) * kCoopMaxWg + wg] = v3[threadIdx.x];
+      if (threadIdx.x < 3) coh_store(part + (1 + threadIdx.x) * kCoopMaxWg + wg, v3[threadIdx.x]);
       if (!coop_barrier(ctl, nwg, gen)) return;
       grid_sum<3>(v3, part + kCoopMaxWg, nwg, sh);
     }
@@ -256,10 +256,12 @@ __global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int
     }
     rho1 = rho;
     rho = v3[1];
-  }
 #pragma unroll
-  for (int j = 0; j < R; ++j)
-    if (rows.row[j] < n) x[rows.row[j]] = xr[j];
+    for (int k = 0; k < kRegNz; ++k)
+      if (k < a.cnt) rc[k] = nwg > 1 ? coh_load(r + a.col[k]) : r[a.col[k]];
+    if (nwg == 1) __syncthreads();  // nobody overwrites r before every thread has gathered
+  }
+  if (in) x[a.row] = xr;
   if (wg == 0 && threadIdx.x == 0) {
     ctl->info = flag;
     ctl->iter = it;  // maxit + 1 when the loop ran out (pcg.c:165)
@@ -268,70 +270,66 @@ __global__ __launch_bounds__(256) void pcg_coop_kernel(int n, int nwg, const int
 }
 
 // minres.c:96-193; v_hat = b - A x, y = K v_hat (dinv), beta = sqrt(v_hat.y) are the caller's; w = w_old = v_hat_old = 0.
-// Everything but v (the vector other workgroups read) lives in registers.
-template <int R>
-__global__ __launch_bounds__(256) void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind,
-                                                          const int *__restrict__ col, const double *__restrict__ val,
-                                                          const double *__restrict__ dinv, double *x,
-                                                          const double *v_hat, const double *y, double *v,
-                                                          double norm_r0, double beta0, double errtol, int it_max,
-                                                          CoopCtl *ctl, double *part, double *hist) {
+// Everything lives in registers; what crosses workgroups is the unnormalised Lanczos vector y (= K v_hat), published at
+// the barrier of the v_hat.y reduction -- a thread divides the entries it gathers by beta itself (the owner's own
+// correctly rounded division) -- so an iteration has two grid barriers (v.Av; v_hat.y).
+__global__ __launch_bounds__(kCoopBlock) void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind,
+                                                                 const int *__restrict__ col,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ dinv, double *x,
+                                                                 const double *v_hat, double *yv, double norm_r0,
+                                                                 double beta0, double errtol, int it_max, CoopCtl *ctl,
+                                                                 double *part, double *hist) {
   __shared__ double sh[16 + 8];
   const int wg = blockIdx.x;
-  OwnedRows<R> rows;
-  rows.load(n, nwg, ind, col, val);
-  double xr[R], vh[R], vho[R], yr[R], wr[R], wo[R], vr[R], dr[R];
+  OwnedRow a;
+  a.load(n, ind, col, val);
+  const bool in = a.row < n;
+  double xr = in ? x[a.row] : 0.0, vh = in ? v_hat[a.row] : 0.0, vho = 0.0, wr = 0.0, wo = 0.0;
+  const double dr = (in && dinv) ? dinv[a.row] : 1.0;
+  double yr = in ? yv[a.row] : 0.0;  // yv holds K v_hat (the caller copies v_hat into it when there is no K)
+  double yc[kRegNz];
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const bool in = rows.row[j] < n;
-    xr[j] = in ? x[rows.row[j]] : 0.0;
-    vh[j] = in ? v_hat[rows.row[j]] : 0.0;
-    dr[j] = (in && dinv) ? dinv[rows.row[j]] : 1.0;
-    yr[j] = dinv ? (in ? y[rows.row[j]] : 0.0) : vh[j];
-    vho[j] = wr[j] = wo[j] = vr[j] = 0.0;
-  }
+  for (int k = 0; k < kRegNz; ++k) yc[k] = k < a.cnt ? yv[a.col[k]] : 0.0;
   unsigned gen = 0;
   double beta = beta0, beta_old = 1.0, c = 1.0, c_old = 1.0, s = 0.0, s_old = 0.0, eta = beta0, norm_rmr = norm_r0;
   int it = 0, info = 1;  // 1: left by the loop test (0 / -1 decided below)
   for (;;) {
     if (it >= it_max || norm_rmr < errtol * norm_r0) break;  // minres.c:114
     it += 1;
+    const double vr = yr / beta;  // :123-124
+    double avr = 0.0;             // :127-129, csr_mat.c:49-54
 #pragma unroll
-    for (int j = 0; j < R; ++j) {  // :123-124
-      vr[j] = yr[j] / beta;
-      if (rows.row[j] < n) v[rows.row[j]] = vr[j];
-    }
-    if (!coop_barrier(ctl, nwg, gen)) return;
-    double a1[1] = {0.0};
-    double avr[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {  // :127-129
-      avr[j] = rows.product(j, col, val, v);
-      a1[0] += vr[j] * avr[j];
-    }
+    for (int k = 0; k < kRegNz; ++k)
+      if (k < a.cnt) avr += a.val[k] * (yc[k] / beta);
+    double a1[1] = {vr * avr};
     block_sum<1>(a1, sh);
     if (nwg > 1) {
-      if (threadIdx.x == 0) part[wg] = a1[0];
+      if (threadIdx.x == 0) coh_store(part + wg, a1[0]);
       if (!coop_barrier(ctl, nwg, gen)) return;
       grid_sum<1>(a1, part, nwg, sh);
     }
     const double alpha = a1[0];
     const double c1 = alpha / beta, c2 = beta / beta_old;  // :131
-    double b1[1] = {0.0};
-#pragma unroll
-    for (int j = 0; j < R; ++j) {  // :132-143
-      const double t = avr[j] - c1 * vh[j] - c2 * vho[j];
-      vho[j] = vh[j];
-      vh[j] = t;
-      yr[j] = dinv ? t * dr[j] : t;
-      b1[0] += t * yr[j];
+    const double t = avr - c1 * vh - c2 * vho;              // :132-143
+    vho = vh;
+    vh = t;
+    yr = dinv ? t * dr : t;
+    double b1[1] = {t * yr};
+    if (in) {
+      if (nwg > 1) coh_store(yv + a.row, yr);
+      else yv[a.row] = yr;
     }
     block_sum<1>(b1, sh);
     if (nwg > 1) {
-      if (threadIdx.x == 0) part[kCoopMaxWg + wg] = b1[0];
+      if (threadIdx.x == 0) coh_store(part + kCoopMaxWg + wg, b1[0]);
       if (!coop_barrier(ctl, nwg, gen)) return;
       grid_sum<1>(b1, part + kCoopMaxWg, nwg, sh);
     }
+#pragma unroll
+    for (int k = 0; k < kRegNz; ++k)
+      if (k < a.cnt) yc[k] = nwg > 1 ? coh_load(yv + a.col[k]) : yv[a.col[k]];
+    if (nwg == 1) __syncthreads();
     beta_old = beta;
     beta = b1[0];
     if (beta < 0.0) {  // :144-146
@@ -353,20 +351,17 @@ __global__ __launch_bounds__(256) void minres_coop_kernel(int n, int nwg, const 
     c = r1_hat / rr1;
     s = beta / rr1;
     const double ce = c * eta;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {  // :172-180
-      const double tmp = wr[j];
-      wr[j] = (vr[j] - rr3 * wo[j] - rr2 * tmp) / rr1;
-      wo[j] = tmp;
-      xr[j] += ce * wr[j];
+    {  // :172-180
+      const double tmp = wr;
+      wr = (vr - rr3 * wo - rr2 * tmp) / rr1;
+      wo = tmp;
+      xr += ce * wr;
     }
     eta = -s * eta;
     norm_rmr *= fabs(s);  // :192
     if (hist && wg == 0 && threadIdx.x == 0) hist[it] = norm_rmr;
   }
-#pragma unroll
-  for (int j = 0; j < R; ++j)
-    if (rows.row[j] < n) x[rows.row[j]] = xr[j];
+  if (in) x[a.row] = xr;
   if (wg == 0 && threadIdx.x == 0) {
     ctl->iter = it;
     if (info == 1) {
@@ -405,13 +400,10 @@ struct CoopMem {
   }
 };
 
-// rows per thread (1, 2 or 4) so that at most kCoopMaxWg workgroups of 256 threads cover the rows
-void coop_grid(int n, int *nwg, int *rpt) {
-  int r = 1;
-  while (r < 4 && (n + 256 * r - 1) / (256 * r) > kCoopMaxWg) r *= 2;
-  *rpt = r;
-  *nwg = std::max(1, (n + 256 * r - 1) / (256 * r));
-}
+// one row per thread, workgroups of 1024: the cost of a grid barrier grows with the number of workgroups that arrive on
+// its counter (measured: ~6 us at 40 workgroups of 256, ~3 us at 10 of 1024), so the workgroups are as large as the
+// hardware allows
+int coop_grid(int n) { return std::max(1, (n + kCoopBlock - 1) / kCoopBlock); }
 
 bool coop_enabled() {
   static const bool on = [] {
@@ -426,7 +418,7 @@ bool coop_enabled() {
 // the operator as plain CSR arrays on this device, small enough for the single-kernel loops?
 bool coop_applicable(const psp_csr *A, int n) {
   return coop_enabled() && A && !A->w4_only && !A->nparts && !A->multi && !A->host && A->ind && A->nrows == n &&
-         A->ncols == n && n >= 1 && n <= kCoopMaxRows;
+         A->ncols == n && n >= 1 && n <= kCoopMaxRows && A->max_row_nnz <= kRegNz;  // every row fits the registers
 }
 
 int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
@@ -434,16 +426,11 @@ int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double
                   double *hist) {
   CoopMem m;
   PSP_TRY(m.init(maxit, hist != nullptr));
-  int nwg, rpt;
-  coop_grid(n, &nwg, &rpt);
+  const int nwg = coop_grid(n);
+  (void)p;
   (void)q;
-#define PSP_COOP_PCG(R)                                                                                              \
-  hipLaunchKernelGGL((pcg_coop_kernel<R>), dim3(nwg), dim3(256), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x, \
-                     r, p, n2b, tolb, normr0, rho0, maxit, m.ctl, m.part, m.hist)
-  if (rpt == 1) PSP_COOP_PCG(1);
-  else if (rpt == 2) PSP_COOP_PCG(2);
-  else PSP_COOP_PCG(4);
-#undef PSP_COOP_PCG
+  hipLaunchKernelGGL(pcg_coop_kernel, dim3(nwg), dim3(kCoopBlock), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x, r,
+                     n2b, tolb, normr0, rho0, maxit, m.ctl, m.part, m.hist);
   PSP_LAUNCH_CHECK();
   CoopCtl c;
   PSP_TRY(m.fetch(&c));
@@ -467,19 +454,18 @@ int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, dou
                      double errtol, int it_max, int *info, int *iter, double *relres, double *hist) {
   CoopMem m;
   PSP_TRY(m.init(it_max, hist != nullptr));
-  int nwg, rpt;
-  coop_grid(n, &nwg, &rpt);
+  const int nwg = coop_grid(n);
   (void)v_hat_old;
   (void)w;
   (void)w_old;
   (void)av;
-#define PSP_COOP_MR(R)                                                                                               \
-  hipLaunchKernelGGL((minres_coop_kernel<R>), dim3(nwg), dim3(256), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, \
-                     x, v_hat, y, v, norm_r0, beta0, errtol, it_max, m.ctl, m.part, m.hist)
-  if (rpt == 1) PSP_COOP_MR(1);
-  else if (rpt == 2) PSP_COOP_MR(2);
-  else PSP_COOP_MR(4);
-#undef PSP_COOP_MR
+  double *yv = y;  // the vector that crosses workgroups: K v_hat, or v_hat itself without a preconditioner
+  if (!dinv) {
+    yv = v;
+    PSP_HIP(hipMemcpyAsync(yv, v_hat, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  }
+  hipLaunchKernelGGL(minres_coop_kernel, dim3(nwg), dim3(kCoopBlock), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x,
+                     v_hat, yv, norm_r0, beta0, errtol, it_max, m.ctl, m.part, m.hist);
   PSP_LAUNCH_CHECK();
   CoopCtl c;
   PSP_TRY(m.fetch(&c));

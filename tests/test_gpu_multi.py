@@ -25,9 +25,11 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("grid", [(24, 20, 0), (12, 11, 10), (64, 64, 0)])
 def test_one_rank_is_the_single_gpu_solver_bit_for_bit(grid):
-    """devices=[0]: same kernels, same reductions, same state machine as psp_pcg / psp_minres"""
+    """devices=[0]: same kernels, same reductions, same state machine as psp_pcg / psp_minres.  The single-GPU operand is
+    the index-free operator (psp_csr_poisson_big, what a rank's slab is): a small csr_mat with CSR arrays would take the
+    single-kernel loop of psp_coop.hip, whose reductions are ordered differently (agreement to rounding, tested there)."""
     from pysparse_amd import device as dev
-    A1 = dev.DeviceCSR.poisson(*grid)
+    A1 = dev.DeviceCSR.poisson_big(*grid)
     AM = dev.DeviceCSR.poisson_multi(*grid, devices=[0])
     assert AM.multi_info() == (1, 1, False) and A1.multi_info() == (0, 0, False)
     assert AM.shape == A1.shape and AM.nnz == A1.nnz
