@@ -177,6 +177,7 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
     always; C3 (512^3, 14 GB of matrix) when host memory and the time budget allow, else 256^3."""
     from oracle import oracle as O
     t0 = time.time()
+    c1 = _cpu_case(O, (100, 100, 0), 200, 2000, True)  # configs[0]: the reference's own CPU-runnable case
     c2 = _cpu_case(O, c2_grid, 10, 10, True)
     # C3 costs ~11x C2's generation + ~10x its per-pass time
     predicted = 11.2 * c2["generate_s"] + 10.5 * (5 * c2["spmv_ms"] * 1e-3 + 2 * 5 / c2["pcg_iters_per_s"])
@@ -192,6 +193,7 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
                   "CSR SpMV, 5-pt Poisson %d^2 (n=%d, nnz=%d): %s; %d^3 skipped (host memory / time budget), "
                   "%d^3 below" % (c2_grid[0], c2["n"], c2["nnz"], c2["sample"], c3_grid[0], c3_small[0]),
         "pcg_iters_per_s": head["pcg_iters_per_s"], "host_cpu": model, "host_nproc": nproc,
+        "C1_poisson2d_100": c1,
         "C2_poisson2d_%d" % c2_grid[0]: c2, ("C3_poisson3d_%d" % c3_grid[0] if big else "poisson3d_%d" % c3_small[0]): c3,
         "seconds": time.time() - t0,
     }
@@ -822,6 +824,22 @@ def main():
             base, ref = cpu_baseline()
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = out["effective_csr_model_GBps"] / base["value"]
+            # configs[0] (poisson2d(100)) on the GPU beside the CPU's C1 figure: the single-kernel loop of psp_coop.hip
+            try:
+                A1 = dev.DeviceCSR.poisson(100, 100)
+                K1 = dev.DeviceJacobi(A1)
+                b1 = np.empty(10000)
+                A1.matvec(np.ones(10000), b1)
+                dev.pcg(A1, b1, np.zeros(10000), 0.0, 50, K1)
+                best = 1e9
+                for _ in range(3):
+                    t = time.perf_counter()
+                    dev.pcg(A1, b1, np.zeros(10000), 0.0, 2000, K1)
+                    best = min(best, time.perf_counter() - t)
+                out["cpu_baseline"]["C1_poisson2d_100"]["gpu_pcg_iters_per_s"] = 2001 / best
+                out["cpu_baseline"]["C1_poisson2d_100"]["gpu_pcg_us_per_iter"] = best / 2001 * 1e6
+            except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the bench line
+                out["cpu_baseline"]["C1_poisson2d_100"]["gpu_error"] = str(e)[:200]
             if ref is not None:
                 out["cpu_baseline_reference_pcg"] = ref
         print(json.dumps(out), file=real_stdout, flush=True)

@@ -3,14 +3,15 @@
 // A system of 10^4 unknowns (BASELINE.json configs[0]: poisson2d(100)) fits the caches many times over; what its
 // iteration costs on the GPU is the chain of ~9 dependent launches of the asynchronous loops (psp_solvers.hip):
 // 20.7 us per PCG iteration at 100^2 in round 2, all of it launch latency.  Here the loop of pcg.c:91-163 (resp.
-// minres.c:96-193) runs inside one kernel: a handful of co-resident workgroups, each owning a contiguous row range,
-// separated by grid-wide barriers where the reference has a data dependency across rows --
-//   PCG   : [p update] | [q = A p, p.q] | [stagnation scan, x, r, r.r, r.z]        3 barriers per iteration
-//   MINRES: [v = y/beta] | [Av = A v, v.Av] | [Lanczos update, y = K v_hat, v_hat.y] | (w, x: rows of their own)
-// -- and every workgroup evaluates the scalar recurrences itself from the same reduced values (the same operations
-// on the same bits, so all of them take the same branch and leave the loop together).  A thread owns its rows for
-// the whole solve (1 or 2 rows): their matrix entries (up to 8 per row) and their slices of x, r, ... stay in REGISTERS; the only
-// vector that crosses workgroups is the one the product gathers (p, resp. v), and the partial sums.
+// minres.c:96-193) runs inside one kernel: a few co-resident workgroups of 1024 threads, one ROW PER THREAD for the whole
+// solve -- the row's matrix entries (up to 8) and its slices of x, r, p, ... stay in registers -- and grid-wide barriers
+// only where the reference has a dependency across rows:
+//   PCG   : [p (own row and the row's columns), q = A p, p.q] | [stagnation scan, x, r, r.r, r.z; r published] | ...
+//   MINRES: [v = y / beta at the row's columns, Av, v.Av] | [Lanczos update, y = K v_hat, v_hat.y; y published] | ...
+// two barriers per iteration: the one vector that crosses workgroups (r, resp. y) is published at the barrier of a
+// reduction, and a thread forms the entries of p (resp. v) it multiplies with itself from the gathered values -- the
+// owner's own rounded operations on the same operands, hence the same bits.  Every workgroup evaluates the scalar
+// recurrences itself from the same reduced values, so all of them take the same branch and leave the loop together.
 //
 // Arithmetic: per element the reference's operations, multiply and add rounded separately (-ffp-contract=off); a row's
 // products are added left to right (csr_mat.c:49-54); a reduction is: a thread adds its rows in ascending order, the
@@ -20,7 +21,7 @@
 //
 // Grid barrier (MI355X_MICROARCH.md "Correctness boundaries", cdna_hip_programming.md G16, second form): the per-XCD
 // L2s are not coherent with each other, so every byte handed from one workgroup to another is stored AND loaded with
-// agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 16 workgroups of 1024 threads --
+// agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 128 workgroups of 1024 threads (one row per thread) --
 // and every spin is bounded: a barrier that does not complete sets an error flag that ends all workgroups.
 #include <algorithm>
 #include <vector>
@@ -31,9 +32,9 @@ namespace psp {
 
 namespace {
 
+constexpr int kCoopMaxWg = 128;  // workgroups of 1024 threads: one per two CUs, all co-resident
 constexpr int kCoopBlock = 1024;
-constexpr int kCoopMaxRows = 1 << 14;  // 16 workgroups; beyond that the asynchronous loops (whole-chip kernels) win
-constexpr int kCoopMaxWg = 16;  // workgroups of 1024 threads: far fewer than CUs, all co-resident
+constexpr int kCoopMaxRows = 128 * 1024;  // 2^17 rows; beyond that the asynchronous loops (whole-chip kernels) take over
 
 struct CoopCtl {
   unsigned count;
@@ -54,6 +55,8 @@ __device__ __forceinline__ double coh_load(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One monotone arrival counter: a workgroup adds 1 (no value returned: nothing to wait for) and polls until the count
+// reaches nwg * (barriers so far) -- one memory round trip after the last arrival instead of two.
 __device__ __forceinline__ bool coop_barrier(CoopCtl *c, int nwg, unsigned &gen) {
   if (nwg == 1) {
     __syncthreads();
@@ -61,23 +64,18 @@ __device__ __forceinline__ bool coop_barrier(CoopCtl *c, int nwg, unsigned &gen)
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores have completed (s_waitcnt) ...
   __syncthreads();                                        // ... before the workgroup announces itself
+  gen += 1;
   if (threadIdx.x == 0) {
-    const unsigned arrived = __hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == (unsigned)nwg - 1u) {
-      __hip_atomic_store(&c->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the reset is out before the generation moves
-      __hip_atomic_fetch_add(&c->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      long spins = 0;
-      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        if (++spins > (1L << 26) || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
+    (void)__hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = gen * (unsigned)nwg;
+    long spins = 0;
+    while ((int)(__hip_atomic_load(&c->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      if (++spins > (1L << 26) || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
       }
     }
   }
-  gen += 1;
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // orders the coherent loads below after the barrier
   return __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
@@ -106,17 +104,23 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *sh /* >= 16 *
   __syncthreads();
 }
 
-// the workgroups' partial sums (already in part[j * kCoopMaxWg + wg]) added in workgroup order by every workgroup
+// the workgroups' partial sums (in part[j * kCoopMaxWg + wg]) added in workgroup order by every workgroup: all of them
+// are fetched at once (one round trip), then thread j adds value j's in order
 template <int NV>
 __device__ __forceinline__ void grid_sum(double (&v)[NV], const double *part, int nwg, double *sh) {
+  if (threadIdx.x < NV * kCoopMaxWg) {
+    const int j = threadIdx.x / kCoopMaxWg, w = threadIdx.x % kCoopMaxWg;
+    sh[threadIdx.x] = w < nwg ? coh_load(part + j * kCoopMaxWg + w) : 0.0;
+  }
+  __syncthreads();
   if (threadIdx.x < NV) {
     double t = 0.0;
-    for (int w = 0; w < nwg; ++w) t += coh_load(part + threadIdx.x * kCoopMaxWg + w);
-    sh[threadIdx.x] = t;
+    for (int w = 0; w < nwg; ++w) t += sh[threadIdx.x * kCoopMaxWg + w];
+    sh[NV * kCoopMaxWg + threadIdx.x] = t;
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < NV; ++j) v[j] = sh[j];
+  for (int j = 0; j < NV; ++j) v[j] = sh[NV * kCoopMaxWg + j];
   __syncthreads();
 }
 
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kCoopBlock) void pcg_coop_kernel(int n, int nwg, co
                                                               const double *__restrict__ dinv, double *x, double *r,
                                                               double n2b, double tolb, double normr0, double rho0,
                                                               int maxit, CoopCtl *ctl, double *part, double *hist) {
-  __shared__ double sh[16 * 3 + 8];
+  __shared__ double sh[3 * kCoopMaxWg + 8];
   const int wg = blockIdx.x;
   OwnedRow a;
   a.load(n, ind, col, val);
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(kCoopBlock) void minres_coop_kernel(int n, int nwg,
                                                                  const double *v_hat, double *yv, double norm_r0,
                                                                  double beta0, double errtol, int it_max, CoopCtl *ctl,
                                                                  double *part, double *hist) {
-  __shared__ double sh[16 + 8];
+  __shared__ double sh[kCoopMaxWg + 8];
   const int wg = blockIdx.x;
   OwnedRow a;
   a.load(n, ind, col, val);
@@ -400,9 +404,9 @@ struct CoopMem {
   }
 };
 
-// one row per thread, workgroups of 1024: the cost of a grid barrier grows with the number of workgroups that arrive on
-// its counter (measured: ~6 us at 40 workgroups of 256, ~3 us at 10 of 1024), so the workgroups are as large as the
-// hardware allows
+// one row per thread, workgroups of 1024 (as few arrivals per barrier as the hardware allows).  Measured (MI355X,
+// profiles/r3_small_solvers.txt): poisson2d(100) 9.0 us per PCG iteration / 6.4 per MINRES iteration against 25 / 19 with
+// one launch per phase; poisson2d(300), 88 workgroups: 12.1 / 9.7 against 22 / 16
 int coop_grid(int n) { return std::max(1, (n + kCoopBlock - 1) / kCoopBlock); }
 
 bool coop_enabled() {

@@ -270,7 +270,7 @@ def test_poisson_big_equals_csr_operator(oracle, grid):
     ra = dev.pcg(A, b, xa, 1e-10, 2000, dev.DeviceJacobi(A))
     rb = dev.pcg(B, b, xb, 1e-10, 2000, dev.DeviceJacobi(B))
     # the same operator in two layouts: identical counts; bit-identical iterates when both run the same loop (an operator
-    # with CSR arrays and <= 2^14 rows takes the single-kernel loop of psp_coop.hip, the index-free one never does)
+    # with CSR arrays and <= 2^17 rows takes the single-kernel loop of psp_coop.hip, the index-free one never does)
     assert ra[:2] == rb[:2] and abs(ra[2] - rb[2]) <= 1e-6 * rb[2]
     assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xb).max()
     if n > (1 << 17):

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def run():
     from pysparse_amd import device as dev
     out = {}
-    for N in (64, 100, 128, 300, 1000, 2048):
+    for N in (100, 200, 300, 362, 500, 1000, 2048):
         A = dev.DeviceCSR.poisson(N, N)
         K = dev.DeviceJacobi(A)
         n = A.shape[0]
@@ -47,7 +47,7 @@ if __name__ == "__main__":
         if isinstance(res["launch_per_phase_loops"], dict):
             for size, row in res["device_scalars"].items():
                 a = res["launch_per_phase_loops"][size]
-                print("%s: single-kernel loop (default up to 2^14 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
+                print("%s: single-kernel loop (default up to 2^17 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
                       "pcg %.1f / minres %.1f" % (size, row["pcg"]["us_per_iter"], row["minres"]["us_per_iter"],
                                                    a["pcg"]["us_per_iter"], a["minres"]["us_per_iter"]), flush=True)
         env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0", PSP_MINRES_ASYNC="0")
