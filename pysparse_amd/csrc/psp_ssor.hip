@@ -323,98 +323,6 @@ __global__ __launch_bounds__(256) void ssor_levels_ell_kernel(int l0, int l1, in
   }
 }
 
-// ---- a run of levels of up to kWideLevel rows in ONE launch of ONE workgroup of 1024 threads, software-pipelined.
-// A 2-D grid operator has as many levels as a 3-D one has planes through its diagonal and a thousandth of the rows per
-// level (2048^2: 4095 levels of <= 2048 rows): one launch per level is pure dependent-launch latency there (2.6 us per
-// level, 21.6 ms per application in round 2).  Everything a level needs that does NOT depend on the previous level --
-// its entries, counts, right-hand side, diagonal, its rows' own y / x of the previous sweep -- is loaded one level ahead,
-// so that after the workgroup barrier only the gathers of x stand between two levels.  Same per-row operations in the
-// same order as the per-level kernels (ssor_row_ell): the same bits.
-constexpr int kWideThreads = 1024;
-template <int KIND, int W>
-struct WideSlot {
-  double v[W];
-  int p[W];
-  int cnt, t;
-  double bt, dt, yt, xt;
-  __device__ __forceinline__ void load(int u, bool have, int n, const int *__restrict__ rowmap,
-                                       const unsigned char *__restrict__ cnt8, const int *__restrict__ pos,
-                                       const double *__restrict__ val, const double *__restrict__ da,
-                                       const double *__restrict__ b, const double *x, const double *y, int first) {
-    cnt = -1;
-    if (!have) return;
-    t = rowmap ? rowmap[u] : u;
-    cnt = cnt8[u];
-#pragma unroll
-    for (int s = 0; s < W; ++s) {
-      v[s] = val[(size_t)s * n + u];
-      p[s] = pos[(size_t)s * n + u];
-    }
-    bt = b[t];
-    dt = da[t];
-    yt = y[t];  // written by this row alone (earlier sweep): does not depend on the running sweep
-    xt = (KIND >= 2 && !(KIND == 2 && first)) ? x[t] : 0.0;
-  }
-  __device__ __forceinline__ void run(double *x, double *y, double omega, int first) const {
-    if (cnt < 0) return;
-    double xs[W];
-#pragma unroll
-    for (int s = 0; s < W; ++s) xs[s] = x[p[s]];
-    if constexpr (KIND == 0 || KIND == 1) {
-      double acc = 0.0;
-#pragma unroll
-      for (int s = 0; s < W; ++s) {
-        const double tt = acc + v[s] * xs[s];
-        acc = s < cnt ? tt : acc;
-      }
-      x[t] = (bt - yt - acc) / dt;
-      y[t] = acc;
-    } else {
-      const double temp = (KIND == 2 && first) ? omega * bt : (1.0 - omega) * xt * dt + yt + omega * bt;
-      double acc = 0.0;
-#pragma unroll
-      for (int s = 0; s < W; ++s) {
-        const double tt = acc - v[s] * xs[s];
-        acc = s < cnt ? tt : acc;
-      }
-      const double hi = omega * acc;
-      y[t] = hi;
-      x[t] = (temp + hi) / dt;
-    }
-  }
-};
-
-template <int KIND, int W, int SLOTS>
-__global__ __launch_bounds__(kWideThreads) void ssor_levels_wide_kernel(
-    int l0, int l1, int n, const int *__restrict__ lptr, const int *__restrict__ rowmap,
-    const unsigned char *__restrict__ cnt8, const int *__restrict__ pos, const double *__restrict__ val,
-    const double *__restrict__ da, const double *__restrict__ b, double *x, double *y, double omega, int first) {
-  WideSlot<KIND, W> cur[SLOTS], nxt[SLOTS];
-  {
-    const int a = lptr[l0], e = lptr[l0 + 1];
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-      const int u = a + (int)threadIdx.x + j * kWideThreads;
-      cur[j].load(u, u < e, n, rowmap, cnt8, pos, val, da, b, x, y, first);
-    }
-  }
-  for (int l = l0; l < l1; ++l) {
-    if (l + 1 < l1) {  // the next level's own data, issued before this level's dependent gathers
-      const int a = lptr[l + 1], e = lptr[l + 2];
-#pragma unroll
-      for (int j = 0; j < SLOTS; ++j) {
-        const int u = a + (int)threadIdx.x + j * kWideThreads;
-        nxt[j].load(u, u < e, n, rowmap, cnt8, pos, val, da, b, x, y, first);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) cur[j].run(x, y, omega, first);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) cur[j] = nxt[j];
-  }
-}
-
 __global__ void row_len_kernel(int n, const int *__restrict__ ptr, int *__restrict__ len) {
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) len[u] = ptr[u + 1] - ptr[u];
 }
@@ -618,14 +526,6 @@ namespace psp {
 
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // psp_reorder.hip
 
-static bool ssor_wide_enabled() {
-  static const bool on = [] {
-    const char *e = psp::tuning_env("PSP_SSOR_WIDE");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
-
 // the launches of one sweep on stream st, everything by position
 template <int KIND, int W>
 static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) {
@@ -639,17 +539,6 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
   const int nl = (int)lp.size() - 1;
   int l = 0;
   while (l < nl) {
-    if constexpr (W > 0) {  // a run of levels narrow enough for one 1024-thread workgroup: one pipelined launch
-      constexpr int kSlots = W <= 4 ? 2 : 1;
-      int e = l;
-      while (e < nl && lp[e + 1] - lp[e] <= kSlots * kWideThreads) ++e;
-      if (e - l >= 2 && ssor_wide_enabled()) {
-        hipLaunchKernelGGL((ssor_levels_wide_kernel<KIND, W, kSlots>), dim3(1), dim3(kWideThreads), 0, st, l, e, K->n, dlp,
-                           rowmap, c8, pos, val, K->da, K->bp, K->xp, K->temp, K->omega, first);
-        l = e;
-        continue;
-      }
-    }
     int e = l;  // maximal run of small levels starting at l
     while (e < nl && lp[e + 1] - lp[e] <= kSmallLevel) ++e;
     if (e - l >= 2) {
