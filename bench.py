@@ -255,6 +255,38 @@ def live_traffic(grid, variant):
                 return None, "no %s samples of an SpMV kernel" % ctr
             for name, v in acc.items():
                 vals.setdefault(name, {})[ctr] = sum(v) / len(v)
+        # third pass (round 3, profiles/r3_modes.txt): what differs between a fast and a slow process of the same launch
+        # is not bytes, clocks or the latency of a memory request but HOW MANY read requests the L2s keep in flight:
+        # TCC_EA0_RDREQ_LEVEL / TCC_CYCLE (reads in flight, summed over the channels) and RDREQ_LEVEL / RDREQ (cycles per
+        # request), with the kernel's duration in that process.  Best effort: a failure only drops the field.
+        try:
+            grp = ["TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_sum", "TCC_CYCLE_sum", "GRBM_GUI_ACTIVE"]
+            outd = os.path.join(tmp, "mode")
+            cmd = [prof, "--pmc"] + grp + ["--output-format", "csv", "-d", outd, "--", sys.executable,
+                                           os.path.join(ROOT, "tools", "prof_spmv.py"), "--reps", "5", "--grid",
+                                           "%d,%d,%d" % grid, "--variant", str(variant)]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
+            if r.returncode == 0:
+                acc, dur = {}, {}
+                for f in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        name = row.get("Kernel_Name", "")
+                        if "_spmv_" in name:
+                            acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                            dur.setdefault(name, {})[row.get("Dispatch_Id")] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                for name, c in acc.items():
+                    m = {k: sum(v) / len(v) for k, v in c.items()}
+                    d = sorted(dur[name].values())
+                    if m.get("TCC_EA0_RDREQ_sum") and m.get("TCC_CYCLE_sum"):
+                        vals.setdefault(name, {})["mode"] = {
+                            "kernel_ms_in_that_process": d[len(d) // 2],
+                            # both are sums over the 128 channel instances: their ratio is the average per channel
+                            "ea_reads_in_flight_per_channel": m["TCC_EA0_RDREQ_LEVEL_sum"] / m["TCC_CYCLE_sum"],
+                            "ea_read_latency_tcc_cycles": m["TCC_EA0_RDREQ_LEVEL_sum"] / m["TCC_EA0_RDREQ_sum"],
+                            "gpu_cycles": m.get("GRBM_GUI_ACTIVE"),
+                        }
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+            pass
     except (OSError, subprocess.SubprocessError, ValueError) as e:
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
@@ -264,6 +296,8 @@ def live_traffic(grid, variant):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             out[name] = {"bytes": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KB": v["FETCH_SIZE"],
                          "WRITE_SIZE_KB": v["WRITE_SIZE"], "fetch_correction": 2.0}
+            if "mode" in v:
+                out[name]["mode_counters"] = v["mode"]
     return (out, None) if out else (None, "counters incomplete")
 
 
@@ -811,13 +845,21 @@ def main():
             if probe:
                 out["roofline"]["stream_ceiling_GBps"] = probe["GBps"]
                 out["roofline"]["frac_of_stream_ceiling"] = achieved / probe["GBps"]
-                out["process_mode"] = {
-                    "read7_write1_GBps": probe["GBps"],
-                    "class": "fast" if probe["GBps"] >= 6200.0 else "slow",
-                    "note": "what a plain 7-read + 1-write streaming kernel reaches in this process; boxes / processes "
-                            "land between ~5.9 and ~6.5 TB/s (profiles/r3_modes.txt) and every store-carrying kernel "
-                            "moves with it",
-                }
+                # which timing mode this process is in (profiles/r3_modes.txt): named from the
+                # dominant kernel's own median launch (512^3 csr_spmv_w4: <= 1.60 ms fast, >= 1.64 ms slow); the counter
+                # that moves with it -- read requests the L2s keep in flight, at an unchanged latency per request --
+                # comes from this job's profiled child process (`counters`), which may sit in the other mode
+                mc = traffic_detail.get("mode_counters") if isinstance(traffic_detail, dict) else None
+                if kernel == "csr_spmv_w4" and (nx, ny, nz) == (512, 512, 512):
+                    cls = "fast" if med_ms <= 1.60 else ("slow" if med_ms >= 1.64 else "between")
+                else:
+                    cls = None
+                out["process_mode"] = {"class": cls, "median_launch_ms": med_ms, "read7_write1_GBps": probe["GBps"],
+                                       "counters": mc,
+                                       "note": "fast / slow processes of the same launch differ by up to 8 %: same bytes, "
+                                               "same clocks, same cycles per memory request, fewer requests in flight "
+                                               "(profiles/r3_modes.txt); a plain 7-read + 1-write streaming kernel does "
+                                               "NOT move with it"}
         if clocks is not None:
             out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:
