@@ -43,8 +43,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3-6.8 achievable)
 W3_VARIANT = (1 << 20) + 128 + 64 + 2 + (64 << 8)  # csr_spmv_w3 (general banded CSR), see psp_csr.hip
 W2_VARIANT = 128 + 64 + 2 + (64 << 8)              # csr_spmv_w2 (int32 col + fp64 val streamed as stored)
-PMC_FILES = {"csr_spmv_w4": "r2_spmv_pmc.json", "csr_spmv_w3": "r2_spmv_w3_pmc.json",
-             "csr_spmv_w2": "r2_spmv_w2_pmc.json"}
+PMC_FILES = {"csr_spmv_w4": "r3_spmv_pmc.json", "csr_spmv_w3": "r3_spmv_w3_pmc.json",
+             "csr_spmv_w2": "r3_spmv_w2_pmc.json"}
 
 
 def csr_model_bytes(n, nnz):
