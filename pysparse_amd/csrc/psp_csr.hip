@@ -3781,13 +3781,11 @@ struct HostStage {
 };
 HostStage g_stage;
 
-constexpr long kPipeMinRows = 1L << 23;  // below 64 MiB per vector the plain path wins (thread start-up, pipeline fill)
-// rows per chunk: a sixteenth of the vector, between 8 and 32 MiB each way, whole 128-row blocks
-inline long pipe_chunk(long n) {
-  long c = n / 16;
-  c = std::max(1L << 20, std::min(1L << 22, c));
-  return c / 4096 * 4096;
-}
+// Measured (profiles/r3_host_matvec.json): 512^3, 32 chunks of 32 MiB: 23.7 ms against 39.7 ms plain (0.94 of the link's
+// full-duplex rate); 4096^2 (16.7e6 rows) loses -- 6.4-7.1 ms in 4 x 32 MiB or 16 x 8 MiB chunks against 4.9 ms plain: a
+// pageable copy has ~0.2 ms of fixed cost, so the pipeline needs many large chunks.  From 2^26 rows (512 MiB per vector) on.
+constexpr long kPipeMinRows = 1L << 26;
+inline long pipe_chunk(long) { return 1L << 22; }  // rows per chunk: 32 MiB each way, whole 128-row blocks
 
 int host_matvec_pipelined(psp_csr *A, const double *xh, double *yh, double *xd, double *yd, bool *done) {
   *done = false;

@@ -410,10 +410,10 @@ def test_host_pointer_matvec_pipeline_is_the_device_product():
     boundary csr_mat.c:141-163).  Same kernel per row: the bits of the whole-vector device product; the chunk edges
     (rows whose offsets reach into the next chunk, the last partial chunk) are where a mistake would show."""
     from pysparse_amd import device as dev
-    for grid in ((300, 300, 120), (4096, 2500, 0)):  # 10.8e6 rows (3 chunks, last partial), 10.2e6 rows in 2-D
+    for grid in ((512, 512, 270), (8192, 8200, 0)):  # 70.8e6 rows (17 chunks, last partial), 67.2e6 rows in 2-D
         A = dev.DeviceCSR.poisson(*grid)
         n = A.shape[0]
-        assert n >= 2 * (1 << 22) and A.kernel_info()[0] == "csr_spmv_w4"
+        assert n >= (1 << 26) and A.kernel_info()[0] == "csr_spmv_w4"
         x = np.random.default_rng(3).standard_normal(n)
         y = np.full(n, np.nan)
         A.matvec(x, y)
