@@ -812,11 +812,16 @@ def _matvec_state(A, kd, st, v_ext, y):
     kd(st, A.A, v_ext, A.plan.p_offset, y, A.plan.interior, wait)
 
 
+def _tuning(name, default):
+    """A/B switches are read only when the process was started with PSP_TUNING=1"""
+    return os.environ.get(name, default) if os.environ.get("PSP_TUNING") == "1" else default
+
+
 def dist_pcg_mode():
     """which loop dist_pcg runs (bench.py prints it)"""
-    if os.environ.get("PSP_DIST_DEVSCALARS", "1") != "0":
+    if _tuning("PSP_DIST_DEVSCALARS", "1") != "0":
         return "device-resident scalars, in-stream all-reduces, lazy x update"
-    return "host scalars, lazy x update" if os.environ.get("PSP_DIST_LAZYX", "1") != "0" else "host scalars, eager"
+    return "host scalars, lazy x update" if _tuning("PSP_DIST_LAZYX", "1") != "0" else "host scalars, eager"
 
 
 def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
@@ -828,8 +833,8 @@ def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     hint = getattr(A.be, "hint_constant", None) if dinv is not None else None
     if hint is not None:
         hint(dinv)
-    lazy = hasattr(A.be, "px_update") and os.environ.get("PSP_DIST_LAZYX", "1") != "0"
-    devs = hasattr(A.be, "kd_px_update") and os.environ.get("PSP_DIST_DEVSCALARS", "1") != "0"
+    lazy = hasattr(A.be, "px_update") and _tuning("PSP_DIST_LAZYX", "1") != "0"
+    devs = hasattr(A.be, "kd_px_update") and _tuning("PSP_DIST_DEVSCALARS", "1") != "0"
     try:
         return (_dist_pcg_dev if devs else _dist_pcg_lazy if lazy else _dist_pcg)(A, b, x, tol, maxit, dinv, hist)
     finally:
