@@ -139,6 +139,15 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind_host, con
 /* ranks / distinct devices behind a handle (0 / 0 for a single-device matrix); uses_rccl: the reductions go
  * through RCCL rather than the fold kernel */
 int psp_csr_multi_info(const psp_csr_t *A, int *nranks, int *distinct_devices, int *uses_rccl);
+/* The partition psp_csr_create_multi computes for rank `rank` of `ndev`, as pure host code (no device needed: the CPU tests
+ * compare it with general_halo_plan of pysparse_amd/distributed.py): row_range_out = {row_lo, row_hi}; counts_out =
+ * {ghost_lo, ghost_hi, interior_a, interior_b, nlinks}; ghost_ids (may be NULL) = the sorted global ids of the ghost entries;
+ * links (may be NULL) = nlinks x {sending rank, offset in the extended vector, count, send offset in the sender's owned
+ * entries or -1 for a gathered index list}; col_local (may be NULL, ind[row_hi] - ind[row_lo] ints) = the block's columns in
+ * [ghost_lo | owned | ghost_hi] numbering. */
+int psp_multi_plan(int nrows, int ncols, const int *ind_host, const int *col_host, int ndev, int rank,
+                   int64_t *row_range_out, int *counts_out, int *ghost_ids, int ghost_cap, int *links, int links_cap,
+                   int *col_local);
 /* timing hook: `reps` products y = A x on resident slices, each done the way a solver iteration does it (ghost
  * copies on the copy streams, the rows that need none meanwhile, then the boundary rows); *ms_per_product is the
  * slowest rank's stream time per product (HIP events on every rank's compute stream) */

@@ -24,7 +24,7 @@ psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
 psp_csr_set_schedule psp_csr_kernel_info psp_csr_renumbering psp_csr_device_bytes
-psp_csr_poisson_multi psp_csr_create_multi psp_csr_multi_info psp_csr_multi_spmv_time
+psp_csr_poisson_multi psp_csr_create_multi psp_csr_multi_info psp_csr_multi_spmv_time psp_multi_plan
 psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
 psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
 psp_sss_kernel_info psp_sss_set_variant
@@ -112,6 +112,7 @@ def _declare(L):
         "psp_csr_create64": [i, i, i64, vp, vp, vp, pvp],
         "psp_csr_poisson_multi": [i, i, i, vp, i, pvp], "psp_csr_create_multi": [i, i, i, vp, vp, vp, vp, i, pvp],
         "psp_csr_multi_info": [vp, pi, pi, pi], "psp_csr_multi_spmv_time": [vp, i, i, pd],
+        "psp_multi_plan": [i, i, vp, vp, i, i, C.POINTER(i64), vp, vp, i, vp, i, vp],
         "psp_csr_random_banded": [i, i, i, i, C.c_uint64, pvp],
         "psp_csr_download_rows": [vp, i, i, vp, vp, vp],
         "psp_csr_destroy": [vp], "psp_csr_shape": [vp, pi, pi, pi],

@@ -386,6 +386,94 @@ void row_range(int64_t n, int world, int rank, int64_t *lo, int64_t *hi) {  // d
   *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
+// ---- the partition of a general CSR matrix, pure host code (no device is touched): what rank r of ndev owns, which ghost
+// entries it needs from whom, its columns in [ghost_lo | owned | ghost_hi] numbering, and its widest ghost-free row range.
+// Exported for the CPU tests as psp_multi_plan (the twin of general_halo_plan in pysparse_amd/distributed.py).
+struct HostLink {
+  int q, recv_off, count;
+  int send_off;          // >= 0: q's owned entries [send_off, send_off + count); -1: the index list below
+  std::vector<int> idx;  // q's owned-local indices, ascending
+};
+struct HostPlan {
+  int64_t lo = 0, hi = 0;
+  int n = 0, ghost_lo = 0, ghost_hi = 0, ia = 0, ib = 0;
+  std::vector<int> ghosts;  // sorted global ids
+  std::vector<int> lind, lcol;
+  std::vector<HostLink> links;
+};
+
+int plan_block(int nrows, int ncols, const int *ind, const int *col, int ndev, int r, HostPlan *P) {
+  std::vector<int64_t> lo(ndev), hi(ndev);
+  for (int q = 0; q < ndev; ++q) row_range(nrows, ndev, q, &lo[q], &hi[q]);
+  auto owner = [&](int g) {
+    int a = 0, b = ndev - 1;
+    while (a < b) {
+      const int m = (a + b) / 2;
+      if (g >= hi[m]) a = m + 1; else b = m;
+    }
+    return a;
+  };
+  P->lo = lo[r];
+  P->hi = hi[r];
+  P->n = (int)(hi[r] - lo[r]);
+  const int a = ind[lo[r]], b = ind[hi[r]];
+  std::vector<int> &g = P->ghosts;
+  g.clear();
+  for (int k = a; k < b; ++k) {
+    if (col[k] < 0 || col[k] >= ncols) return fail(PSP_EINVAL, "column index %d out of range", col[k]);
+    if (col[k] < lo[r] || col[k] >= hi[r]) g.push_back(col[k]);
+  }
+  std::sort(g.begin(), g.end());
+  g.erase(std::unique(g.begin(), g.end()), g.end());
+  P->ghost_lo = (int)(std::lower_bound(g.begin(), g.end(), (int)lo[r]) - g.begin());
+  P->ghost_hi = (int)g.size() - P->ghost_lo;
+  P->lind.assign((size_t)P->n + 1, 0);
+  P->lcol.assign((size_t)(b - a), 0);
+  // widest run of rows that reference no ghost entry (overlaps the exchange with the product)
+  int best_a = 0, best_b = 0, run_a = 0;
+  for (int i = 0; i < P->n; ++i) {
+    P->lind[i] = ind[lo[r] + i] - a;
+    bool touches = false;
+    for (int k = ind[lo[r] + i]; k < ind[lo[r] + i + 1]; ++k) {
+      const int c = col[k];
+      int lc;
+      if (c >= lo[r] && c < hi[r]) {
+        lc = P->ghost_lo + (int)(c - lo[r]);
+      } else {
+        const int pos = (int)(std::lower_bound(g.begin(), g.end(), c) - g.begin());
+        lc = pos < P->ghost_lo ? pos : P->n + pos;
+        touches = true;
+      }
+      P->lcol[k - a] = lc;
+    }
+    if (touches) {
+      if (i - run_a > best_b - best_a) best_a = run_a, best_b = i;
+      run_a = i + 1;
+    }
+  }
+  if (P->n - run_a > best_b - best_a) best_a = run_a, best_b = P->n;
+  P->lind[P->n] = b - a;
+  P->ia = best_a;
+  P->ib = best_b;
+  // one link per owner of my ghosts (they are contiguous in the sorted list)
+  P->links.clear();
+  for (size_t i = 0; i < g.size();) {
+    const int q = owner(g[i]);
+    size_t j = i;
+    while (j < g.size() && g[j] < hi[q]) ++j;
+    HostLink L;
+    L.q = q;
+    L.recv_off = (int)i < P->ghost_lo ? (int)i : P->n + (int)i;
+    L.count = (int)(j - i);
+    L.idx.resize((size_t)L.count);
+    for (int t = 0; t < L.count; ++t) L.idx[t] = g[i + t] - (int)lo[q];
+    L.send_off = (L.idx.back() - L.idx.front() + 1 == L.count) ? L.idx.front() : -1;
+    P->links.push_back(L);
+    i = j;
+  }
+  return PSP_OK;
+}
+
 psp_csr *wrap(psp_mcsr *M, int nrows, int ncols) {
   psp_csr *A = new psp_csr();
   A->nrows = nrows;
@@ -861,93 +949,37 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind, const in
   M->n_global = nrows;
   M->nnz = nnz;
   int rc = new_ranks(M, devices, ndev);
-  std::vector<int64_t> lo(ndev), hi(ndev);
-  for (int r = 0; r < ndev; ++r) row_range(nrows, ndev, r, &lo[r], &hi[r]);
-  auto owner = [&](int g) {
-    int a = 0, b = ndev - 1;
-    while (a < b) {
-      const int m = (a + b) / 2;
-      if (g >= hi[m]) a = m + 1; else b = m;
-    }
-    return a;
-  };
-  // per rank: sorted ghost ids, local column numbers, links; the senders' index lists are filled afterwards
-  std::vector<std::vector<int>> ghosts(ndev);
   for (int r = 0; r < ndev && rc == PSP_OK; ++r) {
     RankOp &R = M->r[r];
-    const int a = ind[lo[r]], b = ind[hi[r]];
-    std::vector<int> &g = ghosts[r];
-    for (int k = a; k < b; ++k) {
-      if (col[k] < 0 || col[k] >= ncols) rc = fail(PSP_EINVAL, "column index %d out of range", col[k]);
-      if (col[k] < lo[r] || col[k] >= hi[r]) g.push_back(col[k]);
-    }
+    HostPlan P;
+    rc = plan_block(nrows, ncols, ind, col, ndev, r, &P);
     if (rc != PSP_OK) break;
-    std::sort(g.begin(), g.end());
-    g.erase(std::unique(g.begin(), g.end()), g.end());
-    R.row_lo = lo[r];
-    R.n = (int)(hi[r] - lo[r]);
-    R.ghost_lo = (int)(std::lower_bound(g.begin(), g.end(), (int)lo[r]) - g.begin());
-    R.ghost_hi = (int)g.size() - R.ghost_lo;
-    R.n_ext = R.ghost_lo + R.n + R.ghost_hi;
-    std::vector<int> lind((size_t)R.n + 1), lcol((size_t)(b - a));
-    // widest run of rows that reference no ghost entry (overlaps the exchange with the product)
-    int best_a = 0, best_b = 0, run_a = 0;
-    for (int i = 0; i < R.n; ++i) {
-      lind[i] = ind[lo[r] + i] - a;
-      bool touches = false;
-      for (int k = ind[lo[r] + i]; k < ind[lo[r] + i + 1]; ++k) {
-        const int c = col[k];
-        int lc;
-        if (c >= lo[r] && c < hi[r]) {
-          lc = R.ghost_lo + (int)(c - lo[r]);
-        } else {
-          const int pos = (int)(std::lower_bound(g.begin(), g.end(), c) - g.begin());
-          lc = pos < R.ghost_lo ? pos : R.n + pos;
-          touches = true;
-        }
-        lcol[k - a] = lc;
-      }
-      if (touches) {
-        if (i - run_a > best_b - best_a) best_a = run_a, best_b = i;
-        run_a = i + 1;
-      }
-    }
-    if (R.n - run_a > best_b - best_a) best_a = run_a, best_b = R.n;
-    lind[R.n] = b - a;
-    R.ia = best_a;
-    R.ib = best_b;
-    // one link per owner of my ghosts (they are contiguous in the sorted list)
-    for (size_t i = 0; i < g.size();) {
-      const int q = owner(g[i]);
-      size_t j = i;
-      while (j < g.size() && g[j] < hi[q]) ++j;
-      Link L;
-      L.q = q;
-      L.recv_off = (int)i < R.ghost_lo ? (int)i : R.n + (int)i;
-      L.count = (int)(j - i);
-      R.links.push_back(L);
-      i = j;
-    }
+    R.row_lo = P.lo;
+    R.n = P.n;
+    R.ghost_lo = P.ghost_lo;
+    R.ghost_hi = P.ghost_hi;
+    R.n_ext = P.ghost_lo + P.n + P.ghost_hi;
+    R.ia = P.ia;
+    R.ib = P.ib;
     rc = use(M, r);
-    if (rc == PSP_OK) rc = psp_csr_create(R.n, R.n_ext, b - a, lind.data(), lcol.data(), val + a, &R.A);
+    if (rc == PSP_OK)
+      rc = psp_csr_create(R.n, R.n_ext, (int)P.lcol.size(), P.lind.data(), P.lcol.data(), val + ind[P.lo], &R.A);
     if (rc == PSP_OK) R.A->no_reorder = true;  // the renumbered copy would need x in another numbering per rank
-  }
-  for (int r = 0; r < ndev && rc == PSP_OK; ++r) {
-    size_t gi = 0;
-    for (Link &L : M->r[r].links) {
-      RankOp &Q = M->r[L.q];
-      std::vector<int> idx((size_t)L.count);
-      for (int i = 0; i < L.count; ++i) idx[i] = ghosts[r][gi + i] - (int)Q.row_lo;
-      gi += L.count;
-      const bool contiguous = idx.back() - idx.front() + 1 == L.count;
-      if (contiguous) {
-        L.send_off = idx.front();
-        continue;
+    for (const HostLink &H : P.links) {
+      if (rc != PSP_OK) break;
+      Link L;
+      L.q = H.q;
+      L.recv_off = H.recv_off;
+      L.count = H.count;
+      L.send_off = H.send_off;
+      if (H.send_off < 0) {  // scattered: the sender packs them with psp_k_gather into a buffer on ITS device
+        const int qdev = M->r[H.q].dev;
+        if (hipSetDevice(qdev) != hipSuccess || hipMalloc((void **)&L.send_idx, sizeof(int) * (size_t)H.count) != hipSuccess ||
+            hipMalloc((void **)&L.send_buf, sizeof(double) * (size_t)H.count) != hipSuccess ||
+            hipMemcpy(L.send_idx, H.idx.data(), sizeof(int) * (size_t)H.count, hipMemcpyHostToDevice) != hipSuccess)
+          rc = fail(PSP_ENOMEM, "psp_csr_create_multi: send list allocation failed");
       }
-      if (hipSetDevice(Q.dev) != hipSuccess || hipMalloc((void **)&L.send_idx, sizeof(int) * (size_t)L.count) != hipSuccess ||
-          hipMalloc((void **)&L.send_buf, sizeof(double) * (size_t)L.count) != hipSuccess ||
-          hipMemcpy(L.send_idx, idx.data(), sizeof(int) * (size_t)L.count, hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(PSP_ENOMEM, "psp_csr_create_multi: send list allocation failed");
+      R.links.push_back(L);
     }
   }
   if (rc == PSP_OK) rc = finish_setup(M, devices, ndev);
@@ -1018,6 +1050,37 @@ int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_p
   if (rc != PSP_OK) return rc;
   PSP_TRY(sync_all(M));
   *ms_per_product = worst / reps;  // the slowest rank's stream time: what an iteration waits for
+  return PSP_OK;
+}
+
+int psp_multi_plan(int nrows, int ncols, const int *ind, const int *col, int ndev, int rank, int64_t *row_range_out,
+                   int *counts_out, int *ghost_ids, int ghost_cap, int *links, int links_cap, int *col_local) {
+  if (!ind || nrows < 0 || ndev < 1 || rank < 0 || rank >= ndev || !row_range_out || !counts_out)
+    return fail(PSP_EINVAL, "psp_multi_plan: bad argument");
+  if (ind[nrows] > 0 && !col) return fail(PSP_EINVAL, "psp_multi_plan: NULL column array");
+  HostPlan P;
+  PSP_TRY(plan_block(nrows, ncols, ind, col, ndev, rank, &P));
+  row_range_out[0] = P.lo;
+  row_range_out[1] = P.hi;
+  counts_out[0] = P.ghost_lo;
+  counts_out[1] = P.ghost_hi;
+  counts_out[2] = P.ia;
+  counts_out[3] = P.ib;
+  counts_out[4] = (int)P.links.size();
+  if (ghost_ids) {
+    if ((int)P.ghosts.size() > ghost_cap) return fail(PSP_EINVAL, "psp_multi_plan: ghost_cap too small");
+    std::copy(P.ghosts.begin(), P.ghosts.end(), ghost_ids);
+  }
+  if (links) {
+    if ((int)P.links.size() > links_cap) return fail(PSP_EINVAL, "psp_multi_plan: links_cap too small");
+    for (size_t i = 0; i < P.links.size(); ++i) {
+      links[4 * i] = P.links[i].q;
+      links[4 * i + 1] = P.links[i].recv_off;
+      links[4 * i + 2] = P.links[i].count;
+      links[4 * i + 3] = P.links[i].send_off;
+    }
+  }
+  if (col_local) std::copy(P.lcol.begin(), P.lcol.end(), col_local);
   return PSP_OK;
 }
 

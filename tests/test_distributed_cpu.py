@@ -267,3 +267,65 @@ def test_partition_helpers():
         assert sorted(p.recv) == sorted(p.send) == [q for q in (r - 1, r + 1) if 0 <= q < 8]
     with pytest.raises(ValueError):
         D.poisson_halo_plan(4, 4, 2, 4, 0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_one_process_driver_partition_equals_the_torch_drivers_plan(world):
+    """psp_multi_plan (pysparse_amd/csrc/psp_multi.hip: the partition behind psp_csr_create_multi, pure host code) against
+    general_halo_plan of pysparse_amd/distributed.py on the same matrices: same row ranges, same ghost sets, same local column
+    numbers, same receive slices and senders' index lists, same ghost-free row range -- so what the gloo tests above establish
+    for the one-process-per-GPU driver's partition holds for the one-process driver too (its device side runs under -m gpu)."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from pysparse_amd import _capi, distributed as D
+    import krylov_cases as KC
+    L = _capi.lib()
+    rng = np.random.default_rng(9)
+    S = O.tendigit_sss(700)
+    mats = [O.poisson_csr(7, 6, 5), O.sss_to_csr(S), KC.nonsym_csr(O, 333, 4), O.poisson_csr(23, 9)]
+    for G in mats:
+        n = G.shape[0]
+        ranges = [D.row_range(n, world, r) for r in range(world)]
+        wanted_all = []
+        plans = []
+        for r in range(world):  # the torch driver's plan, with its two all-gathers emulated
+            lo, hi = ranges[r]
+            a, b = G.ind[lo], G.ind[hi]
+            calls = []
+
+            def gather(obj, r=r, calls=calls):
+                calls.append(obj)
+                if len(calls) == 1:
+                    return ranges
+                return wanted_all if len(wanted_all) == world else [obj if q == r else {} for q in range(world)]
+            plan, col_local = D.general_halo_plan(n, lo, hi, G.col[a:b], world, r, gather, ind=G.ind[lo:hi + 1] - a)
+            wanted_all.append(calls[1])
+            plans.append((plan, col_local))
+        for r in range(world):
+            plan, col_local = plans[r]
+            lo, hi = ranges[r]
+            rr = (C.c_int64 * 2)()
+            cnt = (C.c_int * 5)()
+            ghosts = np.zeros(n, dtype=np.int32)
+            links = np.zeros(4 * world, dtype=np.int32)
+            lcol = np.zeros(G.ind[hi] - G.ind[lo], dtype=np.int32)
+            _capi.check(L.psp_multi_plan(n, n, G.ind.ctypes.data, G.col.ctypes.data, world, r, rr, cnt, ghosts.ctypes.data, n,
+                                         links.ctypes.data, world, lcol.ctypes.data))
+            assert (rr[0], rr[1]) == (lo, hi)
+            assert (cnt[0], cnt[1]) == (plan.ghost_lo, plan.ghost_hi)
+            assert (cnt[2], cnt[3]) == tuple(plan.interior) or cnt[3] - cnt[2] == plan.interior[1] - plan.interior[0]
+            assert np.array_equal(lcol, col_local)
+            ext = np.concatenate([ghosts[:cnt[0]], np.arange(lo, hi), ghosts[cnt[0]:cnt[0] + cnt[1]]])
+            assert np.array_equal(ext[col_local], G.col[G.ind[lo]:G.ind[hi]])  # local numbers point at the right entries
+            got = {int(links[4 * i]): (int(links[4 * i + 1]), int(links[4 * i + 1] + links[4 * i + 2]), int(links[4 * i + 3]))
+                   for i in range(cnt[4])}
+            assert set(got) == set(plan.recv)
+            for q, (s0, s1) in plan.recv.items():
+                assert got[q][:2] == (s0, s1)
+                ids = ext[s0:s1] - ranges[q][0]  # what q must send: its owned-local indices
+                if got[q][2] >= 0:
+                    assert np.array_equal(ids, np.arange(got[q][2], got[q][2] + len(ids)))
+                else:
+                    assert not np.array_equal(ids, np.arange(ids[0], ids[0] + len(ids)))
