@@ -664,14 +664,14 @@ typedef unsigned short us4v __attribute__((ext_vector_type(4)));
 
 // SHIFT = 4: ids are 16-entry x blocks (csr_spmv_w3); SHIFT = 0: ids are the columns themselves and the
 // 16-bit value is the column's rank in the chunk's sorted list of distinct columns (csr_spmv_w5)
-template <int NB, int SHIFT = 4, int WT = 1024>
+template <int NB, int SHIFT = 4>
 __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, int write,
                                                       const int2 *__restrict__ tab,
                                                       const int *__restrict__ col,
                                                       int *__restrict__ blist,
                                                       unsigned short *__restrict__ col16,
                                                       int *__restrict__ maxblocks) {
-  static_assert(WT == 1024 || WT == 512, "chunk of 1024 or 512 nonzeros");
+  constexpr int WT = 1024;
   constexpr int kNone = 0x7fffffff;
   __shared__ int keys[WT];
   __shared__ int ulist[WT];
@@ -760,7 +760,7 @@ typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 // from memory through the int32 columns `colfull`, like csr_spmv_w2 -- same products, same order
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef int i4v __attribute__((ext_vector_type(4)));
-template <int NP, int NB, int WPB, bool NTS, bool NTL = false, bool PAIRS = false, bool OUTL = false, int WT = 1024>
+template <int NP, int NB, int WPB, bool NTS, bool NTL = false, bool PAIRS = false, bool OUTL = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     int chunk0, int nchunks, int stripe, int target, int kmax, int ncols,
     const int2 *__restrict__ tab, const unsigned short *__restrict__ rowoff,
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const int *__restrict__ perm, const int *__restrict__ rowperm, const int *__restrict__ colfull = nullptr) {
   // rowperm (renumbered operators, psp_reorder.hip): row r of this matrix is row rowperm[r] of the
   // caller's: its sum is stored to y[rowperm[r]] and meets dotv[rowperm[r]]
-  static_assert(WT == 1024 || WT == 512, "chunk of 1024 or 512 nonzeros");
+  constexpr int WT = 1024;
   constexpr int STEPS = WT / 256;
   constexpr int E = 64 * NP;
   constexpr int XW = NB * 16;             // doubles in the x window
@@ -2212,18 +2212,13 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   std::lock_guard<std::mutex> lk(g_extra_mu);
   if (t->nb >= 0) return PSP_OK;
   t->nb = 0;
-  if ((t->tile != 1024 && t->tile != 512) || t->np == 0 || A->nnz == 0) return PSP_OK;
-  const bool half = t->tile == 512;  // chunks of 512 nonzeros (round 3): for numberings whose 1024-entry chunks need 65-128 blocks
+  if (t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
   int *d_max;
   PSP_HIP(hipMalloc((void **)&d_max, 4 * sizeof(int)));
   PSP_HIP(hipMemsetAsync(d_max, 0, 4 * sizeof(int), stream()));
   // pass 1: most distinct x blocks referenced by one chunk, and how many chunks need more than 64
-  if (half)
-    hipLaunchKernelGGL((build_w3_kernel<64, 4, 512>), dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
-                       0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
-  else
-    hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
-                       0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
+  hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target,
+                     0, t->tab, A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
   PSP_LAUNCH_CHECK();
   int st[3] = {0, 0, 0};
   PSP_HIP(hipMemcpyAsync(st, d_max, sizeof(st), hipMemcpyDeviceToHost, stream()));
@@ -2239,10 +2234,7 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   }();
   // (the shorter list is worth having: the 64-slot kernel is ~4 % slower on a matrix that fits 32)
   int nb = 0;
-  if (half) {  // one form only: every chunk fits the list, no outlier chunks
-    if (mb <= 32 && cap >= 32) nb = 32;
-    else if (mb <= 64 && cap >= 64) nb = 64;
-  } else if (mb <= 32 && cap >= 32) nb = 32;
+  if (mb <= 32 && cap >= 32) nb = 32;
   else if (outl_on && cap >= 32 && st[2] > 0 && (long)st[2] * 50 <= (long)t->nchunks) {
     nb = 32;
     t->outliers = st[2];
@@ -2271,7 +2263,7 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
     return PSP_OK;
   }
   hipError_t e1 = hipMalloc((void **)&t->blist, sizeof(int) * (size_t)t->nchunks * nb);
-  hipError_t e2 = hipMalloc((void **)&t->col16, sizeof(unsigned short) * (size_t)t->nchunks * t->tile);
+  hipError_t e2 = hipMalloc((void **)&t->col16, sizeof(unsigned short) * (size_t)t->nchunks * 1024);
   if (e1 != hipSuccess || e2 != hipSuccess) {  // no room for the extra tables: stay on w2
     (void)hipGetLastError();
     if (e1 == hipSuccess) (void)hipFree(t->blist);
@@ -2285,15 +2277,9 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
 #define PSP_BUILD_W3(NB)                                                                          \
   hipLaunchKernelGGL(build_w3_kernel<NB>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks,     \
                      t->target, 1, t->tab, A->col, t->blist, t->col16, d_max)
-#define PSP_BUILD_W3H(NB)                                                                               \
-  hipLaunchKernelGGL((build_w3_kernel<NB, 4, 512>), dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, \
-                     t->target, 1, t->tab, A->col, t->blist, t->col16, d_max)
-  if (half && nb == 32) PSP_BUILD_W3H(32);
-  else if (half) PSP_BUILD_W3H(64);
-  else if (nb == 32) PSP_BUILD_W3(32);
+  if (nb == 32) PSP_BUILD_W3(32);
   else if (nb == 64) PSP_BUILD_W3(64);
   else PSP_BUILD_W3(128);
-#undef PSP_BUILD_W3H
 #undef PSP_BUILD_W3
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(stream()));
@@ -3008,12 +2994,6 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
                      A->val, x, y, dotv, pbuf, skip, perm, rowperm)
   const int ab = w3_ab(A);
   if constexpr (NB == 32 || NB == 64) {
-    if (t->tile == 512) {  // chunks of 512 nonzeros: the default stream layout only
-      hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, false, 512>), dim3(grid), dim3(256), 0, stream(), c0,
-                         c1, stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                         A->val, x, y, dotv, pbuf, skip, perm, rowperm);
-      return;
-    }
     if (t->outliers > 0) {  // one form only: the default stream layout, with the per-chunk fallback compiled in
       hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, true>), dim3(grid), dim3(256), 0, stream(), c0, c1,
                          stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
@@ -3070,25 +3050,6 @@ static void launch_w5(const psp_csr *A, const ChunkTable *t, int grid, int strip
   if (t->np == 2) launch_w5_np<2>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
   else if (t->np == 3) launch_w5_np<3>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
   else launch_w5_np<4>(A, t, grid, stripe, c0, c1, x, y, dotv, pbuf, skip);
-}
-
-// csr_spmv_w3 with chunks of 512 nonzeros (round 3): for a stored numbering whose 1024-entry chunks reference more than 64 x
-// blocks while its 512-entry chunks fit the list -- twice the per-chunk tables, none of the gathers of csr_spmv_w2, no
-// renumbered copy and no permutation passes.  *out = the 512-entry chunk table, or nullptr.  PSP_SPMV_W3_HALF=0: A/B switch.
-static int w3_half_table(const psp_csr *A, const Variant &v, const ChunkTable *t, ChunkTable **out) {
-  *out = nullptr;
-  static const bool off = [] {
-    const char *e = psp::tuning_env("PSP_SPMV_W3_HALF");
-    return e && atoi(e) == 0;
-  }();
-  if (off || v.tile != 1024 || t->nb != 0 || t->max_blocks <= 64 || A->max_row_nnz > 256) return PSP_OK;
-  ChunkTable *h;
-  PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), 512, &h));
-  PSP_TRY(ensure_rowoff(A, h));
-  if (h->np == 0) return PSP_OK;
-  PSP_TRY(ensure_w3(A, h));
-  if (h->nb > 0) *out = h;
-  return PSP_OK;
 }
 
 // What multiplies a matrix whose stored numbering scatters a chunk's columns over more x blocks than
@@ -3314,11 +3275,6 @@ int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const in
   PSP_TRY(ensure_rowoff(A, t));
   if (t->np == 0) return PSP_OK;
   PSP_TRY(ensure_w3(A, t));
-  {
-    ChunkTable *h = nullptr;
-    PSP_TRY(w3_half_table(A, v, t, &h));
-    if (h) return PSP_OK;  // csr_spmv_w3 on 512-entry chunks of the stored numbering: nothing to permute
-  }
   psp::CsrExtra *exs = nullptr;
   int mode = 0;
   PSP_TRY(pick_scattered(A, t, &exs, &mode));
@@ -3443,16 +3399,6 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
         if (t->sched_state == 1) {
           perm = t->perm;
           grid = t->sched_grid;
-        }
-      }
-      if (!use_w3) {  // too many x blocks per 1024-entry chunk: do the 512-entry chunks fit the list?
-        ChunkTable *h = nullptr;
-        PSP_TRY(w3_half_table(A, v, t, &h));
-        if (h) {
-          t = h;
-          use_w3 = true;
-          grid = (t->nchunks + 3) / 4;
-          if (stripe > 0) grid = (grid + 8 * stripe - 1) / (8 * stripe) * (8 * stripe);
         }
       }
     }
@@ -4524,14 +4470,7 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
         if (v.w3) {
           PSP_TRY(ensure_w3(A, t));
           vals[1] = t->max_blocks;
-          ChunkTable *h = nullptr;
-          PSP_TRY(w3_half_table(A, v, t, &h));
-          if (h) {
-            k = "csr_spmv_w3_half";
-            vals[0] = h->nb;
-            vals[1] = h->max_blocks;
-            vals[3] = t->max_blocks;  // what the 1024-entry chunks need
-          } else {
+          {
             psp::CsrExtra *exs = nullptr;
             int mode = 0;
             PSP_TRY(pick_scattered(A, t, &exs, &mode));
