@@ -485,10 +485,17 @@ static int ll_csr_nnz(LLMatObject *self) {
   return 2 * lo + dg; /* ll_mat.c:1592-1593 */
 }
 
-static PyObject *LLMat_to_csr(LLMatObject *self, PyObject *args) {
+static int parse_devices(PyObject *o, int *dev, int cap);
+
+/* to_csr() as in the reference (ll_mat.c:1577-1648); to_csr(devices=[...]) puts the rows on several GPUs as row blocks
+ * (psp_csr_create_multi): matvec, precon.jacobi, krylov.pcg and krylov.minres then run on all of them */
+static PyObject *LLMat_to_csr(LLMatObject *self, PyObject *args, PyObject *kwds) {
   CSRMatObject *op;
-  int rc;
-  if (!PyArg_ParseTuple(args, "")) return NULL;
+  int rc, ndev, devs[64];
+  PyObject *odev = NULL;
+  static char *kwlist[] = {"devices", NULL};
+  if (!PyArg_ParseTupleAndKeywords(args, kwds, "|O", kwlist, &odev)) return NULL;
+  if ((ndev = parse_devices(odev, devs, 64)) < 0) return NULL;
   op = (CSRMatObject *)newCSRMatObject(self->dim, ll_csr_nnz(self), 1);
   if (op == NULL) return NULL;
   if (ll_fill_csr(self, op->val, op->col, op->ind) < 0) {
@@ -496,7 +503,10 @@ static PyObject *LLMat_to_csr(LLMatObject *self, PyObject *args) {
     return NULL;
   }
   Py_BEGIN_ALLOW_THREADS
-  rc = psp_csr_create(op->dim[0], op->dim[1], op->nnz, op->ind, op->col, op->val, &op->dev);
+  if (ndev > 0)
+    rc = psp_csr_create_multi(op->dim[0], op->dim[1], op->nnz, op->ind, op->col, op->val, devs, ndev, &op->dev);
+  else
+    rc = psp_csr_create(op->dim[0], op->dim[1], op->nnz, op->ind, op->col, op->val, &op->dev);
   Py_END_ALLOW_THREADS
   if (rc != PSP_OK) {
     Py_DECREF(op);
@@ -863,7 +873,8 @@ static PyObject *LLMat_repr(LLMatObject *a) {
 static PyMethodDef LLMat_methods[] = {
     {"matvec", (PyCFunction)LLMat_matvec, METH_VARARGS, "a.matvec(x, y): y := a * x (on the GPU)"},
     {"matvec_transp", (PyCFunction)LLMat_matvec_transp, METH_VARARGS, "a.matvec_transp(x, y): y := a^T * x"},
-    {"to_csr", (PyCFunction)LLMat_to_csr, METH_VARARGS, "A.to_csr(): new csr_mat from the data of A"},
+    {"to_csr", (PyCFunction)(void (*)(void))LLMat_to_csr, METH_VARARGS | METH_KEYWORDS,
+     "A.to_csr(): new csr_mat from the data of A; A.to_csr(devices=[0, 1, ...]): its rows on several GPUs"},
     {"to_sss", (PyCFunction)LLMat_to_sss, METH_VARARGS, "a.to_sss(): new sss_mat from the lower triangle of a"},
     {"to_csr_arrays", (PyCFunction)LLMat_to_csr_arrays, METH_VARARGS, "(indptr, indices, data) of to_csr(), on the host"},
     {"to_sss_arrays", (PyCFunction)LLMat_to_sss_arrays, METH_VARARGS, "(indptr, indices, data, diag) of to_sss(), on the host"},

@@ -403,6 +403,31 @@ def test_config4_1024_cubed_four_ranks_rehearsal():
     assert abs(one["relres"] - four["relres"]) <= 1e-12 * one["relres"]
 
 
+def test_config4_1024_cubed_one_process_device_list_rehearsal():
+    """The same configs[3] operator through the ONE-process driver behind the C ABI (psp_csr_poisson_multi, psp_multi.hip):
+    four ranks = four entries of the device list, all device 0 here (2^28 rows, 1.9e9 nonzeros per rank), bench.py
+    --single-process.  20 Jacobi-PCG iterations must reproduce the recurred residual of the same problem on ONE rank of the
+    same driver (which is bit for bit the single-GPU solver, tests/test_gpu_multi.py) to rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = {}
+    for ranks, extra in ((4, ["--share-gpu"]), (1, ["--grid", "1024,1024,1024"])):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--single-process",
+                              "--steps", "3", "--warmup", "1", "--pcg-iters", "16"] + extra, capture_output=True, text=True,
+                             cwd=root, env=env, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res[ranks] = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    four, one = res[4], res[1]
+    assert four["config"]["n"] == one["config"]["n"] == 1 << 30 and four["config"]["nnz"] == 7509901312
+    assert four["ranks"] == 4 and four["config"]["rows_per_gpu"] == 1 << 28 and "dry_run" in four and one["ranks"] == 1
+    assert (four["pcg_check"]["info"], four["pcg_check"]["iter"]) == (one["pcg_check"]["info"], one["pcg_check"]["iter"]) == (-1, 21)
+    assert abs(four["pcg_check"]["relres"] - one["pcg_check"]["relres"]) <= 1e-12 * one["pcg_check"]["relres"]
+
+
 @pytest.mark.gpu
 def test_host_pointer_matvec_pipeline_is_the_device_product():
     """A.matvec(x, y) on NumPy buffers of a large offset-structured operator runs chunked -- x going up, row blocks

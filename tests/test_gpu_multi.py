@@ -177,6 +177,16 @@ def test_drop_in_modules_with_a_device_list(oracle):
     bb = np.random.default_rng(2).standard_normal(G.shape[0])
     assert krylov.pcg(B, bb, x, 1e-10, 500, precon.jacobi(B))[:2] == oracle.pcg(G, bb, xo, 1e-10, 500, oracle.jacobi_dinv(G.diagonal()))[:2]
     assert relerr(x, xo) < 1e-12
+    # ll_mat.to_csr(devices=[...]): the reference's own construction route (ll_mat.c:1577-1648) onto a device list
+    Lm = spmatrix.ll_mat_sym(G.shape[0], 10 * G.shape[0])
+    for i in range(G.shape[0]):
+        for k in range(G.ind[i], G.ind[i + 1]):
+            if G.col[k] <= i:
+                Lm[i, int(G.col[k])] = float(G.val[k])
+    Cm = Lm.to_csr(devices=[0, 0, 0])
+    xm = np.zeros(G.shape[0])
+    assert krylov.pcg(Cm, bb, xm, 1e-10, 500, precon.jacobi(Cm))[:2] == krylov.pcg(B, bb, np.zeros(G.shape[0]), 1e-10, 500, precon.jacobi(B))[:2]
+    assert relerr(xm, xo) < 1e-12
     for bad in (lambda: A.matvec_transp(b, y), lambda: A.to_arrays(), lambda: krylov.cgs(A, b, x1, 1e-8, 10),
                 lambda: krylov.pcg(A, b, x1, 1e-8, 10, K1), lambda: krylov.pcg(A1, b, x1, 1e-8, 10, K),
                 lambda: precon.jacobi(A, 1.0, 2), lambda: spmatrix.poisson_csr(8, 8, devices=[7]),
