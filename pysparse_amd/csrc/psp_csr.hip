@@ -4052,7 +4052,7 @@ int psp_csr_poisson_big(int nx, int ny, int nz, psp_csr_t **out) {
 }
 
 int64_t psp_csr_nnz64(const psp_csr_t *A) {
-  return A ? ((A->w4_only || A->nparts) ? A->nnz64 : (int64_t)A->nnz) : 0;
+  return A ? ((A->w4_only || A->nparts || A->multi) ? A->nnz64 : (int64_t)A->nnz) : 0;
 }
 
 // rows [r0, r1) of a host triple with 64-bit offsets as one ordinary handle
