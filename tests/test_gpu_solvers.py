@@ -512,7 +512,10 @@ def test_pcg_jacobi_constant_and_variable_diagonal(oracle):
         ref = oracle.pcg(B, b, xo, 1e-10, 2000, oracle.jacobi_dinv(B.diagonal()), hist=True)
         res = pcg(D, b, xs, 1e-10, 2000, DeviceJacobi(D), hist=True)
         assert res[:2] == ref[:2] and res[0] == 0
-        assert np.allclose(res[3][:res[1] + 1], ref[3][:ref[1] + 1], rtol=1e-9, atol=0)
+        # the recurred residual has dropped ten orders below ||r0|| at the end: its last digits are the rounding of the dot
+        # sums (whose order differs between the oracle's sequential loops and any device reduction)
+        assert np.allclose(res[3][:res[1] + 1], ref[3][:ref[1] + 1], rtol=1e-7, atol=0)
+        assert np.allclose(res[3][:res[1] // 2], ref[3][:ref[1] // 2], rtol=1e-10, atol=0)
         assert np.abs(xs - xo).max() <= 1e-12 * np.abs(xo).max()
 
 
