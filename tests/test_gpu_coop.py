@@ -1,7 +1,7 @@
 """GPU: the single-kernel PCG / MINRES loops for small systems (pysparse_amd/csrc/psp_coop.hip; pcg.c:91-166,
 minres.c:96-193): up to 2^17 rows with at most 8 entries each, native matrix, K = None or jacobi(1).
 
-  * against the oracle: identical info / iteration counts, iterates <= 1e-12, residual histories <= 1e-8, on sizes that
+  * against the oracle: identical info / iteration counts, iterates <= 1e-12, residual histories <= 1e-5 (at the rounding floor), on sizes that
     need 1, a few and many workgroups (every barrier path), 2-D / 3-D stencils and an irregular matrix;
   * against the launch-per-phase loops (PSP_COOP=0 under PSP_TUNING=1, child process): the same answers to rounding;
   * bitwise reproducible from run to run; matrices the kernel does not take (longer rows, more rows) are unaffected.
@@ -69,7 +69,9 @@ def test_single_kernel_loops_match_the_oracle(oracle, kind, arg):
                 assert abs(rg[2] - ro[2]) <= 1e-6 * ro[2]
                 assert relerr(xg, xo) < 1e-12
                 m = np.isfinite(ro[3])
-                assert np.array_equal(m, np.isfinite(rg[3])) and np.allclose(rg[3][m], ro[3][m], rtol=1e-8, atol=0)
+                assert np.array_equal(m, np.isfinite(rg[3]))
+                # (a recurred PCG residual ten orders below ||r0|| carries the rounding of the dot sums in its last digits)
+                assert np.allclose(rg[3][m], ro[3][m], rtol=1e-5, atol=0)
                 xg2 = np.full(n, 0.5)
                 rg2 = solver(D, b, xg2, tol, maxit, K, hist=True)
                 assert rg2[:3] == rg[:3] and np.array_equal(xg, xg2)  # fixed reduction order: the same bits every run
