@@ -848,12 +848,12 @@ def main():
                 out["roofline"]["stream_ceiling_GBps"] = probe["GBps"]
                 out["roofline"]["frac_of_stream_ceiling"] = achieved / probe["GBps"]
                 # which timing mode this process is in (profiles/r3_modes.txt): named from the
-                # dominant kernel's own median launch (512^3 csr_spmv_w4: <= 1.60 ms fast, >= 1.64 ms slow); the counter
+                # dominant kernel's own median launch (512^3 csr_spmv_w4 at the stripe-128 default: <= 1.56 ms fast, >= 1.63 ms slow, 1.60-1.62 usual; profiles/r3_w4_stripe.txt); the counter
                 # that moves with it -- read requests the L2s keep in flight, at an unchanged latency per request --
                 # comes from this job's profiled child process (`counters`), which may sit in the other mode
                 mc = traffic_detail.get("mode_counters") if isinstance(traffic_detail, dict) else None
                 if kernel == "csr_spmv_w4" and (nx, ny, nz) == (512, 512, 512):
-                    cls = "fast" if med_ms <= 1.60 else ("slow" if med_ms >= 1.64 else "between")
+                    cls = "fast" if med_ms <= 1.56 else ("slow" if med_ms >= 1.63 else "usual")
                 else:
                     cls = None
                 out["process_mode"] = {"class": cls, "median_launch_ms": med_ms, "read7_write1_GBps": probe["GBps"],

@@ -2964,9 +2964,39 @@ static int spmv_stripe() {
 
 // XCD stripe of w4 in workgroups of 512 rows: 32 measured best at 512^3 (0: -0.5 %, 64: -2 %,
 // 256: -4 %; profiles/r1_spmv_w4_knobs.txt); an explicit variant or PSP_SPMV_STRIPE overrides
+// XCD stripe of the index-free kernels: workgroup b runs on XCD b mod 8; the remap lets each XCD walk contiguous stripes of
+// `stripe` workgroups (512 rows each).  Round 3 sweep (profiles/r3_w4_stripe.txt; interleaved rounds inside one process,
+// 512^3 in eleven processes, the other grids in one each): on grids whose plane is a power of two -- every BASELINE config --
+// a stripe of 128 workgroups is 2.5-5 % faster than the 32 of rounds 1-2 (512^3: 1.60-1.62 vs 1.64-1.69 ms; 4096^2: 0.132 vs
+// 0.139; 1024^3: 13.03 vs 13.35) and flat elsewhere (320^3, 384^3, 640x640x300, 8192^2: +-1 %).  The one bad case measured
+// is a stripe of exactly one plane (256^3, plane = 128 workgroups: 0.204 vs 0.185 ms), which falls back to an eighth of the
+// plane (0.176).  sss_spmv_w4 keeps 32 (512^3: 1.20-1.22 ms at 16-32, 1.26 at 128).
+static int w4_auto_stripe(const psp_csr *A) {
+  if (A->sym_owner) return 32;
+  int plane_wgs = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    auto it = g_extra.find(A);
+    if (it != g_extra.end() && it->second.dia_state == 1) {
+      int omax = 0;
+      for (int i = 0; i < it->second.dia_no; ++i) omax = std::max(omax, std::abs(it->second.dia_offs.o[i]));
+      plane_wgs = omax / (4 * kDiaRows);
+    }
+  }
+  if (plane_wgs > 0) {
+    const double r = 128.0 / plane_wgs;
+    if (r > 0.7 && r < 1.5) {
+      int s = 16;
+      while (2 * s <= plane_wgs / 8) s *= 2;
+      return s;
+    }
+  }
+  return 128;
+}
+
 static int w4_stripe(const psp_csr *A, const Variant &v) {
   if (spmv_stripe() >= 0) return spmv_stripe();
-  return A->variant < 0 ? 32 : v.stripe;
+  return A->variant < 0 ? w4_auto_stripe(A) : v.stripe;
 }
 
 template <int TILE, int VEC, bool NT>
