@@ -273,6 +273,11 @@ int psp_ssor_create(psp_sss_t *A, double omega, int steps, psp_ssor_t **out);
 int psp_ssor_destroy(psp_ssor_t *K);
 /* n and the number of dependency levels of the forward / backward sweep */
 int psp_ssor_info(const psp_ssor_t *K, int *n, int *levels_forward, int *levels_backward);
+/* how much of the schedule runs as single-workgroup runs of narrow levels that exchange x through LDS (2-D operators,
+ * the thin ends of 3-D ones) instead of one launch per level: runs per direction, levels and slots covered; no
+ * reference analogue (the reference's sweeps are sequential, preconmodule.c:95-193) */
+int psp_ssor_run_info(const psp_ssor_t *K, int *runs_forward, int *runs_backward, long *levels_in_runs,
+                      long *slots_in_runs);
 /* y := K x.  SSOR_precon, preconmodule.c:199-223 */
 int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host);
 int psp_ssor_precon_dev(psp_ssor_t *K, const double *x_dev, double *y_dev);

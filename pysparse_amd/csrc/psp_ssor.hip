@@ -67,6 +67,26 @@ struct psp_ssor {
   hipGraphExec_t exec = nullptr;
   hipStream_t cap_stream = nullptr;
   int graph_state = -1;  // -1 not tried, 0 unavailable (direct launches), 1 captured
+  // Round 3: RUNS of narrow levels walked by one workgroup that hands x from level to level through LDS
+  // (ssor_run_kernel below).  A run = consecutive levels of at most kRunWide rows whose dependencies all lie at most
+  // kRunMaxDist slots back; its slots get compact copies of what the kernel streams (index c = coff + slot - s0).
+  struct Run {
+    int l0 = 0, l1 = 0;  // levels [l0, l1)
+    int s0 = 0, s1 = 0;  // slots [s0, s1)
+    int coff = 0;        // offset of slot s0 in the compact arrays
+    int tick0 = 0, nticks = 0;
+  };
+  struct RunSet {
+    std::vector<Run> runs;
+    int m = 0;                 // slots in all runs = stride of dpk
+    unsigned *dpk = nullptr;   // distances to the dependencies' slots, two 16-bit fields per word, word-major
+    double2 *vp = nullptr;     // the row's values in pairs (entries 2k, 2k+1), pair-major: one 16-byte load per pair
+    double *dar = nullptr;     // diagonal by compact index
+    double2 *gd = nullptr;     // per application: (G, diagonal); G = everything of the row's formula that does not
+                               // depend on this sweep
+    int2 *ticks = nullptr;     // (first slot, count <= kRunTick), never across a level boundary; zero-padded per run
+  } run_f, run_b;
+  int *run_progress = nullptr;  // [0]: tick the walking workgroup has finished (throttles the L2 helpers), [1]: sink
   // PSP_DEVICE=cpu (psp_cpu.hip): the reference's two sequential sweeps on the host arrays of S; two n-vectors of work
   bool host = false;
   std::vector<double> h_temp, h_temp2;
@@ -323,6 +343,245 @@ __global__ __launch_bounds__(256) void ssor_levels_ell_kernel(int l0, int l1, in
   }
 }
 
+// ------------------------------------------------------------------ runs of narrow levels through LDS (round 3)
+//
+// A 2-D operator has as many levels as a 3-D one has diagonal planes and a thousandth of the rows per level
+// (2048^2: 4095 levels of <= 2048 rows); so have the thin ends of a 3-D schedule.  One launch per level costs a
+// dependent-launch boundary (~2.6 us); one workgroup walking the levels with __syncthreads() in between costs the same,
+// because what a level waits for is a global-memory round trip either way: its x values were stored by the level
+// before, and on gfx950 loads and stores share one counter, so making the stores visible also waits for whatever was
+// prefetched.  Here the only thing that crosses a level boundary is LDS:
+//   * a tick = up to 1024 slots of one level, one per thread; x of the last 8192 slots lives in an LDS ring
+//     (ring[slot & 8191]); a row reads its dependencies there -- the builder admits a level only if all of them lie at most
+//     kRunMaxDist = 7168 slots back, so a tick never overwrites what it still reads -- writes its own x there, and the
+//     tick ends with s_waitcnt lgkmcnt(0) + s_barrier: no vector-memory wait;
+//   * everything else a row needs is static for the sweep: its values, the distances to its dependencies (16 bits
+//     each), its diagonal, and G = the part of its formula that only involves the previous sweep (b - y resp. the
+//     `temp` of ssor_kernel, preconmodule.c:110-140; formed by run_pre_kernel with the reference's own expression).
+//     A thread loads them D ticks ahead into registers (the tick table tells it which slot it will own), so the loads
+//     of D ticks are in flight while a tick computes; x and y go to global memory as plain stores nobody waits for;
+//   * one CU pulls 62 GB/s from HBM and 125 GB/s from its L2 (tools/cu_stream_probe.hip), and a sweep streams ~50
+//     bytes per row: helper workgroups on the same XCD (blockIdx % 8 == 0) read the same static data a bounded number
+//     of ticks ahead of the walker, so that its loads are L2 hits.
+// Same operations in the same order per row as ssor_row_ell => the reference's bits.
+constexpr int kRunWide = 4096;     // widest level that may join a run
+constexpr int kRunTick = 1024;     // slots per tick = threads of the walking workgroup
+constexpr int kRunRing = 8192;     // LDS ring (doubles): 64 KiB
+constexpr int kRunMaxDist = kRunRing - kRunTick;
+constexpr int kRunMinLevels = 8;   // shorter runs stay on the per-level launches
+constexpr int kRunLead = 48;       // ticks the helpers may run ahead (~2 MB of static data: half an XCD's L2)
+constexpr int kRunPad = 32;        // empty ticks behind a run's table (>= 3 * D)
+
+template <int W>
+struct RunPre {
+  double2 v[(W + 1) / 2];
+  unsigned dw[(W + 1) / 2];
+  double2 gd;  // (G, diagonal)
+  int u, t;    // u < 0: this thread has no row in the tick
+};
+
+template <int W>
+constexpr int run_depth() {
+  return W <= 2 ? 6 : W <= 4 ? 5 : W <= 6 ? 4 : 3;  // vector-memory operations of D ticks stay under vmcnt's 63
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// the largest distance (in slots) from a row of a narrow level to one of its dependencies, per level
+template <int W>
+__global__ __launch_bounds__(256) void run_dist_kernel(int a, int e, int l0, int l1, const int *__restrict__ lptr, int n,
+                                                       const unsigned char *__restrict__ cnt8,
+                                                       const int *__restrict__ pos, const int *__restrict__ slot_of,
+                                                       int *__restrict__ lev_maxd) {
+  const int u = a + blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= e) return;
+  int lo = l0, hi = l1;  // lptr[lo] <= u < lptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (lptr[mid] <= u) lo = mid; else hi = mid;
+  }
+  const int cnt = cnt8[u];
+  int d = 0;
+  for (int s = 0; s < W; ++s)
+    if (s < cnt) {
+      const int p = pos[(size_t)s * n + u];
+      d = max(d, u - (slot_of ? slot_of[p] : p));
+    }
+  if (d > 0) atomicMax(lev_maxd + lo, d);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void run_pack_kernel(int a, int e, int coff, int m, int n,
+                                                       const unsigned char *__restrict__ cnt8,
+                                                       const int *__restrict__ pos, const int *__restrict__ slot_of,
+                                                       const int *__restrict__ rowmap, const double *__restrict__ da,
+                                                       const double *__restrict__ val, unsigned *__restrict__ dpk,
+                                                       double2 *__restrict__ vp, double *__restrict__ dar) {
+  const int u = a + blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= e) return;
+  const int c = coff + (u - a);
+  const int cnt = cnt8[u];
+  unsigned w[(W + 1) / 2] = {};
+  double v[2 * ((W + 1) / 2)] = {};
+  for (int s = 0; s < W; ++s)
+    if (s < cnt) {
+      const int p = pos[(size_t)s * n + u];
+      const unsigned d = (unsigned)(u - (slot_of ? slot_of[p] : p));  // 1 .. kRunMaxDist
+      w[s >> 1] |= d << ((s & 1) * 16);
+      v[s] = val[(size_t)s * n + u];
+    }
+  for (int k = 0; k < (W + 1) / 2; ++k) {
+    dpk[(size_t)k * m + c] = w[k];
+    vp[(size_t)k * m + c] = make_double2(v[2 * k], v[2 * k + 1]);
+  }
+  dar[c] = da[rowmap ? rowmap[u] : u];
+}
+
+// G of a run's slots: forward / backward Gauss-Seidel: b - y (preconmodule.c:171-193); ssor_kernel: temp (:110-140)
+template <int KIND>
+__global__ __launch_bounds__(256) void run_pre_kernel(int a, int e, int coff, const int *__restrict__ rowmap,
+                                                      const double *__restrict__ b, const double *__restrict__ x,
+                                                      const double *__restrict__ y, const double *__restrict__ da,
+                                                      double omega, int first, const double *__restrict__ dar,
+                                                      double2 *__restrict__ gd, int *__restrict__ progress) {
+  const int u = a + blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) progress[0] = -1;
+  if (u >= e) return;
+  const int t = rowmap ? rowmap[u] : u;
+  const double bt = b[t];
+  double g;
+  if constexpr (KIND <= 1) {
+    g = bt - y[t];
+  } else {
+    if (KIND == 2 && first) {
+      g = omega * bt;
+    } else {
+      const double xt = x[t], dt = da[t], yt = y[t];
+      g = (1.0 - omega) * xt * dt + yt + omega * bt;
+    }
+  }
+  const int c = coff + (u - a);
+  gd[c] = make_double2(g, dar[c]);
+}
+
+template <bool MINUS, bool BACK, int W, int D>
+__global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *__restrict__ ticks, int n, int m, int s0,
+                                                        int coff, const int *__restrict__ rowmap,
+                                                        const double2 *__restrict__ vp,
+                                                        const unsigned *__restrict__ dpk,
+                                                        const double2 *__restrict__ gd, double *x, double *y,
+                                                        double omega, int *progress, int nhelp) {
+  static_assert(3 * D <= kRunPad, "the tick table's padding must cover the prefetch distance");
+  constexpr int DW = (W + 1) / 2;
+  if (blockIdx.x & 7) return;  // only the workgroups of the walker's XCD stay (they share its L2)
+  const int tid = threadIdx.x;
+  const int role = blockIdx.x >> 3;
+  if (role > 0) {
+    // ---- helper: touch the static data of ticks ahead of the walker, four ticks per round, never more than
+    // kRunLead ticks ahead of it; every spin is bounded (a helper that loses the walker just stops throttling)
+    double sink = 0.0;
+    for (int kb = (role - 1) * 4; kb < nticks; kb += nhelp * 4) {
+      int spins = 0;
+      while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kb - kRunLead && ++spins < 100000)
+        __builtin_amdgcn_s_sleep(8);
+      double2 v[4][DW + 1];
+      unsigned dwv[4][DW];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int s = 0; s < DW + 1; ++s) v[q][s] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s < DW; ++s) dwv[q][s] = 0;
+        const int2 tk = ticks[kb + q];  // padded behind the run
+        if (tid < tk.y) {
+          const int c = coff + (tk.x + tid - s0);
+#pragma unroll
+          for (int s = 0; s < DW; ++s) v[q][s] = vp[(size_t)s * m + c];
+#pragma unroll
+          for (int s = 0; s < DW; ++s) dwv[q][s] = dpk[(size_t)s * m + c];
+          v[q][DW] = gd[c];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int s = 0; s < DW + 1; ++s) sink += v[q][s].x + v[q][s].y;
+#pragma unroll
+        for (int s = 0; s < DW; ++s) sink += (double)dwv[q][s];
+      }
+    }
+    if (sink == 1.2345678e300) progress[1] = 1;  // keeps the loads alive
+    return;
+  }
+  // ---- the walker
+  __shared__ double ring[kRunRing];
+  for (int q = s0 - kRunRing + tid; q < s0; q += kRunTick)
+    if (q >= 0) ring[q & (kRunRing - 1)] = x[BACK ? rowmap[q] : q];  // dependencies from before the run
+  __syncthreads();
+  RunPre<W> pre[D];
+  int2 ti[D];
+  // every lane loads, whether it owns a row of the tick or not (lanes past the tick's end repeat its last slot, an empty
+  // padding tick its first): with the loads under a branch the compiler has to assume the path on which none was
+  // issued and waits for all but the last one or two (s_waitcnt vmcnt(2)) -- which is the prefetch gone
+  auto issue = [&](RunPre<W> &p, const int2 tk) {
+    const int u = tk.x + min(tid, max(tk.y - 1, 0)), c = coff + (u - s0);
+    p.u = tid < tk.y ? u : -1;
+    if constexpr (BACK) p.t = rowmap[u]; else p.t = u;
+#pragma unroll
+    for (int s = 0; s < DW; ++s) p.v[s] = vp[(size_t)s * m + c];
+#pragma unroll
+    for (int s = 0; s < DW; ++s) p.dw[s] = dpk[(size_t)s * m + c];
+    p.gd = gd[c];
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    issue(pre[j], ticks[j]);
+    ti[j] = ticks[j + D];
+  }
+  // let the prologue's loads land (once): the scheduler regroups them by array, and the wait counts the compiler derives
+  // at the loop header are the worse of the two ways in -- with the prologue pending that is vmcnt(0) in every tick
+  __syncthreads();
+  for (int k = 0; k < nticks; k += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const RunPre<W> p = pre[j];
+      const int2 tn = ti[j];            // tick k + j + D
+      ti[j] = ticks[k + j + 2 * D];     // (the table is padded with empty ticks)
+      if (p.u >= 0) {
+        double xs[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          const int d = (int)((p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu);
+          xs[s] = ring[(p.u - d) & (kRunRing - 1)];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          const unsigned d = (p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu;
+          const double vs = (s & 1) ? p.v[s >> 1].y : p.v[s >> 1].x;
+          const double tt = MINUS ? acc - vs * xs[s] : acc + vs * xs[s];
+          acc = d ? tt : acc;
+        }
+        double xn, yn;
+        if constexpr (!MINUS) {
+          xn = (p.gd.x - acc) / p.gd.y;
+          yn = acc;
+        } else {
+          const double hi = omega * acc;
+          yn = hi;
+          xn = (p.gd.x + hi) / p.gd.y;
+        }
+        ring[p.u & (kRunRing - 1)] = xn;
+        x[p.t] = xn;
+        y[p.t] = yn;
+      }
+      issue(pre[j], tn);
+      lds_barrier();
+      if (tid == 0 && nhelp > 0) __hip_atomic_store(progress, k + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void row_len_kernel(int n, const int *__restrict__ ptr, int *__restrict__ len) {
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) len[u] = ptr[u + 1] - ptr[u];
 }
@@ -526,6 +785,15 @@ namespace psp {
 
 int reorder_gather(int n, const int *perm_dev, const double *x, double *xp, const int *skip);  // psp_reorder.hip
 
+// helper workgroups beside the walker of a run (PSP_SSOR_LDS_HELPERS, tuning only)
+static int run_helpers() {
+  static const int h = [] {
+    const char *e = psp::tuning_env("PSP_SSOR_LDS_HELPERS");
+    return e ? std::max(0, std::min(atoi(e), 15)) : 3;
+  }();
+  return h;
+}
+
 // the launches of one sweep on stream st, everything by position
 template <int KIND, int W>
 static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) {
@@ -537,10 +805,30 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
   const double *val = forward ? K->f_val : K->b_val;
   const unsigned char *c8 = forward ? K->fc8 : K->bc8;
   const int nl = (int)lp.size() - 1;
+  const psp_ssor::RunSet &rs = forward ? K->run_f : K->run_b;
+  size_t ri = 0;
   int l = 0;
   while (l < nl) {
+    if constexpr (W > 0) {
+      if (ri < rs.runs.size() && rs.runs[ri].l0 == l) {  // a run of narrow levels: one workgroup, x through LDS
+        const psp_ssor::Run &r = rs.runs[ri++];
+        const int cnt = r.s1 - r.s0, nh = run_helpers();
+        hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((cnt + 255) / 256), dim3(256), 0, st, r.s0, r.s1, r.coff, rowmap,
+                           K->bp, K->xp, K->temp, K->da, K->omega, first, rs.dar, rs.gd, K->run_progress);
+        if (forward)
+          hipLaunchKernelGGL((ssor_run_kernel<(KIND >= 2), false, W, run_depth<W>()>), dim3(8 * (1 + nh)), dim3(kRunTick),
+                             0, st, r.nticks, rs.ticks + r.tick0, K->n, rs.m, r.s0, r.coff, rowmap, rs.vp, rs.dpk, rs.gd,
+                             K->xp, K->temp, K->omega, K->run_progress, nh);
+        else
+          hipLaunchKernelGGL((ssor_run_kernel<(KIND >= 2), true, W, run_depth<W>()>), dim3(8 * (1 + nh)), dim3(kRunTick),
+                             0, st, r.nticks, rs.ticks + r.tick0, K->n, rs.m, r.s0, r.coff, rowmap, rs.vp, rs.dpk, rs.gd,
+                             K->xp, K->temp, K->omega, K->run_progress, nh);
+        l = r.l1;
+        continue;
+      }
+    }
     int e = l;  // maximal run of small levels starting at l
-    while (e < nl && lp[e + 1] - lp[e] <= kSmallLevel) ++e;
+    while (e < nl && lp[e + 1] - lp[e] <= kSmallLevel && !(ri < rs.runs.size() && rs.runs[ri].l0 == e)) ++e;
     if (e - l >= 2) {
       if constexpr (W > 0)
         hipLaunchKernelGGL((ssor_levels_ell_kernel<KIND, W>), dim3(1), dim3(256), 0, st, l, e, K->n, dlp, rowmap, c8,
@@ -768,6 +1056,137 @@ int build_level_ordered(psp_ssor *K, int *rows_f, int *rows_b) {
   return rc;
 }
 
+// runs of narrow levels for ssor_run_kernel (see there).  Never fails the handle: whatever goes wrong here leaves
+// the direction on its per-level launches.
+template <int W>
+void build_runs_w(psp_ssor *K, int dir) {
+  const std::vector<int> &lp = dir ? K->ptr_b : K->ptr_f;
+  const int *dlp = dir ? K->dptr_b : K->dptr_f;
+  const int *pos = dir ? K->b_pos : K->f_pos;
+  const unsigned char *c8 = dir ? K->bc8 : K->fc8;
+  const int *rowmap = dir ? K->b_row : nullptr;
+  psp_ssor::RunSet &rs = dir ? K->run_b : K->run_f;
+  const int nl = (int)lp.size() - 1, n = K->n;
+  // candidates: maximal stretches of levels of at most kRunWide rows
+  std::vector<std::pair<int, int>> cand;
+  for (int l = 0; l < nl;) {
+    if (lp[l + 1] - lp[l] > kRunWide) {
+      ++l;
+      continue;
+    }
+    int e = l;
+    while (e < nl && lp[e + 1] - lp[e] <= kRunWide) ++e;
+    if (e - l >= kRunMinLevels) cand.emplace_back(l, e);
+    l = e;
+  }
+  if (cand.empty()) return;
+  int *slot_of = nullptr, *lev_maxd = nullptr;
+  std::vector<int> maxd((size_t)nl, 0);
+  bool ok = true;
+  if (dir) {  // a backward row's dependencies are positions; the ring is indexed by backward slots
+    ok = hipMalloc((void **)&slot_of, sizeof(int) * (size_t)n) == hipSuccess;
+    if (ok) hipLaunchKernelGGL(invert_perm_kernel, dim3(std::min((n + 255) / 256, 65536)), dim3(256), 0, stream(), n,
+                               K->b_row, slot_of);
+  }
+  ok = ok && hipMalloc((void **)&lev_maxd, sizeof(int) * (size_t)nl) == hipSuccess &&
+       hipMemsetAsync(lev_maxd, 0, sizeof(int) * (size_t)nl, stream()) == hipSuccess;
+  if (ok) {
+    for (const auto &c : cand) {
+      const int a = lp[c.first], e = lp[c.second];
+      hipLaunchKernelGGL(run_dist_kernel<W>, dim3((e - a + 255) / 256), dim3(256), 0, stream(), a, e, c.first, c.second,
+                         dlp, n, c8, pos, slot_of, lev_maxd);
+    }
+    ok = hipGetLastError() == hipSuccess &&
+         hipMemcpyAsync(maxd.data(), lev_maxd, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         hipStreamSynchronize(stream()) == hipSuccess;
+  }
+  if (ok) {
+    // split the candidates at levels that reach further back than the ring allows
+    std::vector<int2> ticks;
+    for (const auto &c : cand) {
+      for (int l = c.first; l < c.second;) {
+        if (maxd[l] > kRunMaxDist) {
+          ++l;
+          continue;
+        }
+        int e = l;
+        while (e < c.second && maxd[e] <= kRunMaxDist) ++e;
+        if (e - l >= kRunMinLevels) {
+          psp_ssor::Run r;
+          r.l0 = l;
+          r.l1 = e;
+          r.s0 = lp[l];
+          r.s1 = lp[e];
+          r.coff = rs.m;
+          r.tick0 = (int)ticks.size();
+          for (int q = l; q < e; ++q)
+          {  // a level of w rows = ceil(w / 1024) ticks of (nearly) equal size
+            const int w = lp[q + 1] - lp[q], nt = (w + kRunTick - 1) / kRunTick;
+            for (int i = 0, a = lp[q]; i < nt; ++i) {
+              const int c = w / nt + (i < w % nt ? 1 : 0);
+              ticks.push_back(make_int2(a, c));
+              a += c;
+            }
+          }
+          r.nticks = (int)ticks.size() - r.tick0;
+          for (int q = 0; q < kRunPad; ++q) ticks.push_back(make_int2(r.s0, 0));  // empty, but a valid slot to load from
+          rs.m += r.s1 - r.s0;
+          rs.runs.push_back(r);
+        }
+        l = e;
+      }
+    }
+    if (!rs.runs.empty()) {
+      constexpr int DW = (W + 1) / 2;
+      ok = hipMalloc((void **)&rs.dpk, sizeof(unsigned) * (size_t)DW * rs.m) == hipSuccess &&
+           hipMalloc((void **)&rs.vp, sizeof(double2) * (size_t)DW * rs.m) == hipSuccess &&
+           hipMalloc((void **)&rs.dar, sizeof(double) * (size_t)rs.m) == hipSuccess &&
+           hipMalloc((void **)&rs.gd, sizeof(double2) * (size_t)rs.m) == hipSuccess &&
+           hipMalloc((void **)&rs.ticks, sizeof(int2) * ticks.size()) == hipSuccess &&
+           hipMemcpyAsync(rs.ticks, ticks.data(), sizeof(int2) * ticks.size(), hipMemcpyHostToDevice, stream()) ==
+               hipSuccess;
+      if (ok && !K->run_progress)
+        ok = hipMalloc((void **)&K->run_progress, 2 * sizeof(int)) == hipSuccess &&
+             hipMemsetAsync(K->run_progress, 0, 2 * sizeof(int), stream()) == hipSuccess;
+      if (ok) {
+        for (const psp_ssor::Run &r : rs.runs)
+          hipLaunchKernelGGL(run_pack_kernel<W>, dim3((r.s1 - r.s0 + 255) / 256), dim3(256), 0, stream(), r.s0, r.s1,
+                             r.coff, rs.m, n, c8, pos, slot_of, rowmap, K->da, dir ? K->b_val : K->f_val, rs.dpk, rs.vp,
+                             rs.dar);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream()) == hipSuccess;
+      }
+    }
+  }
+  (void)hipFree(slot_of);
+  (void)hipFree(lev_maxd);
+  if (!ok) {
+    (void)hipGetLastError();
+    (void)hipFree(rs.dpk);
+    (void)hipFree(rs.vp);
+    (void)hipFree(rs.dar);
+    (void)hipFree(rs.gd);
+    (void)hipFree(rs.ticks);
+    rs = psp_ssor::RunSet();
+  }
+}
+
+void build_runs(psp_ssor *K) {
+  static const bool off = [] {
+    const char *e = psp::tuning_env("PSP_SSOR_LDS");
+    return e && atoi(e) == 0;
+  }();
+  if (off) return;
+  for (int dir = 0; dir < 2; ++dir) switch (dir ? K->ell_b : K->ell_f) {
+      case 1: build_runs_w<1>(K, dir); break;
+      case 2: build_runs_w<2>(K, dir); break;
+      case 3: build_runs_w<3>(K, dir); break;
+      case 4: build_runs_w<4>(K, dir); break;
+      case 6: build_runs_w<6>(K, dir); break;
+      case 8: build_runs_w<8>(K, dir); break;
+      default: break;  // rows with more than 8 entries per sweep keep the ptr / pos / val form and its launches
+    }
+}
+
 }  // namespace
 
 namespace psp {
@@ -873,6 +1292,7 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
           hipMemcpy(K->dptr_b, K->ptr_b.data(), bb, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(PSP_ENOMEM, "ssor: level table allocation failed");
     }
+    if (rc == PSP_OK) build_runs(K);
   } else {
     K->ptr_f.assign(1, 0);
     K->ptr_b.assign(1, 0);
@@ -897,7 +1317,10 @@ int psp_ssor_destroy(psp_ssor_t *K) {
   for (void *p : {(void *)K->pos2row, (void *)K->row2pos, (void *)K->dptr_f, (void *)K->dptr_b, (void *)K->f_ptr,
                   (void *)K->f_pos, (void *)K->f_val, (void *)K->b_row, (void *)K->b_ptr, (void *)K->b_pos,
                   (void *)K->b_val, (void *)K->da, (void *)K->bp, (void *)K->xp, (void *)K->temp, (void *)K->fc8,
-                  (void *)K->bc8})
+                  (void *)K->bc8, (void *)K->run_f.dpk, (void *)K->run_f.dar, (void *)K->run_f.gd, (void *)K->run_f.ticks,
+                  (void *)K->run_f.vp, (void *)K->run_b.dpk, (void *)K->run_b.dar, (void *)K->run_b.gd,
+                  (void *)K->run_b.ticks, (void *)K->run_b.vp,
+                  (void *)K->run_progress})
     (void)hipFree(p);
   delete K;
   return PSP_OK;
@@ -908,6 +1331,19 @@ int psp_ssor_info(const psp_ssor_t *K, int *n, int *levels_forward, int *levels_
   if (n) *n = K->n;
   if (levels_forward) *levels_forward = (int)K->ptr_f.size() - 1;
   if (levels_backward) *levels_backward = (int)K->ptr_b.size() - 1;
+  return PSP_OK;
+}
+
+int psp_ssor_run_info(const psp_ssor_t *K, int *runs_forward, int *runs_backward, long *levels_in_runs,
+                      long *slots_in_runs) {
+  if (!K) return fail(PSP_EINVAL, "psp_ssor_run_info: NULL handle");
+  long lv = 0;
+  for (const psp_ssor::RunSet *rs : {&K->run_f, &K->run_b})
+    for (const psp_ssor::Run &r : rs->runs) lv += r.l1 - r.l0;
+  if (runs_forward) *runs_forward = (int)K->run_f.runs.size();
+  if (runs_backward) *runs_backward = (int)K->run_b.runs.size();
+  if (levels_in_runs) *levels_in_runs = lv;
+  if (slots_in_runs) *slots_in_runs = (long)K->run_f.m + K->run_b.m;
   return PSP_OK;
 }
 

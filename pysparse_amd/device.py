@@ -444,6 +444,10 @@ class DeviceSSOR:
         lf, lb = C.c_int(), C.c_int()
         check(lib().psp_ssor_info(h, None, C.byref(lf), C.byref(lb)))
         self.levels = (lf.value, lb.value)
+        rf, rb, lv, sl = C.c_int(), C.c_int(), C.c_long(), C.c_long()
+        check(lib().psp_ssor_run_info(h, C.byref(rf), C.byref(rb), C.byref(lv), C.byref(sl)))
+        # (runs forward, runs backward, levels covered, slots covered) of the LDS-exchange runs of narrow levels
+        self.lds_runs = (rf.value, rb.value, lv.value, sl.value)
 
     def precon(self, x, y):
         n = self.shape[0]

@@ -190,3 +190,62 @@ def test_ssor_levels_by_relaxation_fallback():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.25, 2)])
+@pytest.mark.parametrize("grid,keep", [((1500, 700, 0), 1.0), ((700, 1500, 0), 1.0), ((64, 64, 64), 1.0),
+                                       ((128, 128, 64), 1.0), ((3000, 9, 9), 1.0), ((5000, 3, 0), 1.0),
+                                       ((900, 800, 0), 0.85), ((900, 800, 0), 0.999), ((80, 70, 60), 0.9995),
+                                       ((2100, 2100, 0), 1.0)])
+def test_ssor_runs_of_narrow_levels_bit_exact(oracle, grid, keep, omega, steps):
+    """Round 3: runs of narrow levels are walked by one workgroup that hands x from level to level through an LDS ring
+    (ssor_run_kernel): levels of more than one tick (1500 / 2100 rows), whole 3-D schedules (64^3: every level <= 3072
+    rows), runs at both thin ends of a schedule whose middle is launched level by level (128 x 128 x 64: the second run
+    starts with dependencies computed by other kernels), long grid lines (dependencies 3000 slots back), rows with missing
+    couplings (levels that reach further back than the ring split the runs).  Same bits as the oracle's sequential
+    sweeps (preconmodule.c:95-193)."""
+    from pysparse_amd.device import DeviceSSOR, DeviceSSS
+    S = grid_sss(oracle, *grid, seed=7 + sum(grid), keep=keep)
+    D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    K = DeviceSSOR(D, omega, steps)
+    rf, rb, levels, slots = K.lds_runs
+    if keep > 0.9:
+        assert rf >= 1 and rb >= 1 and slots > 0
+    if keep == 0.999:
+        assert rf > 1 and levels < sum(K.levels)  # split at the levels that reach too far back
+    if grid == (128, 128, 64):
+        assert rf == 2 and rb == 2 and levels < sum(K.levels)  # thin ends only
+    if grid in ((1500, 700, 0), (700, 1500, 0), (64, 64, 64), (2100, 2100, 0)):
+        assert levels == sum(K.levels) and slots == 2 * S.n      # the whole schedule
+    x = rng_vec(S.n, 3)
+    y_ref = np.full(S.n, -1.5)
+    oracle.ssor_apply(S, x, y_ref, omega, steps)
+    y = np.full(S.n, -1.5)
+    K.precon(x, y)
+    assert np.array_equal(y, y_ref)
+    K.precon(x, y)  # the replayed graph
+    assert np.array_equal(y, y_ref)
+
+
+def test_ssor_runs_switch_is_an_ab_switch(oracle):
+    """PSP_TUNING=1 PSP_SSOR_LDS=0 keeps every level on its own launch (the round-2 path); both give the oracle's bits"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from pysparse_amd.device import DeviceSSOR, DeviceSSS\n"
+        "D = DeviceSSS.poisson(300, 200)\n"
+        "K = DeviceSSOR(D, 1.0, 1)\n"
+        "x = np.random.default_rng(1).standard_normal(60000); y = np.zeros(60000)\n"
+        "K.precon(x, y)\n"
+        "print(K.lds_runs[0], repr(float(y @ y)), repr(float(y[12345])))\n" % os.path.dirname(os.path.dirname(__file__)))
+    outs = []
+    for env in ({}, {"PSP_TUNING": "1", "PSP_SSOR_LDS": "0"}):
+        e = dict(os.environ)
+        e.pop("PSP_TUNING", None)
+        e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split())
+    assert int(outs[0][0]) >= 1 and int(outs[1][0]) == 0
+    assert outs[0][1:] == outs[1][1:]

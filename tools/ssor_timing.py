@@ -16,6 +16,7 @@ from pysparse_amd._capi import check, lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", default="256,256,256")
 ap.add_argument("--tol", type=float, default=1e-8)
+ap.add_argument("--no-pcg", action="store_true")
 a = ap.parse_args()
 nx, ny, nz = (int(t) for t in a.grid.split(","))
 L = lib()
@@ -38,8 +39,9 @@ t_apply = (time.perf_counter() - t) / 3
 ones = dev.DeviceBuffer.from_host(np.ones(n))
 b = dev.DeviceBuffer(n)
 S.matvec_dev(ones.ptr, b.ptr)
-out = {"grid": [nx, ny, nz], "n": n, "levels": K.levels, "schedule_build_s": t_build, "apply_ms": t_apply * 1e3}
-for name, P in (("jacobi", dev.DeviceJacobi(S)), ("ssor", K)):
+out = {"grid": [nx, ny, nz], "n": n, "levels": K.levels, "lds_runs": K.lds_runs, "schedule_build_s": t_build,
+       "apply_ms": t_apply * 1e3}
+for name, P in (() if a.no_pcg else (("jacobi", dev.DeviceJacobi(S)), ("ssor", K))):
     aop, kop = dev._Op(S, "matvec"), dev._Op(P, "precon")
     x.zero()
     info, it, rr = C.c_int(), C.c_int(), C.c_double()
