@@ -546,14 +546,17 @@ __global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *
     for (int j = 0; j < D; ++j) {
       const RunPre<W> p = pre[j];
       const int2 tn = ti[j];            // tick k + j + D
-      ti[j] = ticks[k + j + 2 * D];     // (the table is padded with empty ticks)
-      if (p.u >= 0) {
-        double xs[W];
+      ti[j] = ticks[k + j + 2 * D];   // (the table is padded with empty ticks)
+      // the ring reads of every lane (a lane without a row reads some slot and drops it), then the next loads: their
+      // address arithmetic runs while the LDS answers
+      double xs[W];
 #pragma unroll
-        for (int s = 0; s < W; ++s) {
-          const int d = (int)((p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu);
-          xs[s] = ring[(p.u - d) & (kRunRing - 1)];
-        }
+      for (int s = 0; s < W; ++s) {
+        const int d = (int)((p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu);
+        xs[s] = ring[(p.u - d) & (kRunRing - 1)];
+      }
+      issue(pre[j], tn);
+      if (p.u >= 0) {
         double acc = 0.0;
 #pragma unroll
         for (int s = 0; s < W; ++s) {
@@ -575,7 +578,6 @@ __global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *
         x[p.t] = xn;
         y[p.t] = yn;
       }
-      issue(pre[j], tn);
       lds_barrier();
       if (tid == 0 && nhelp > 0) __hip_atomic_store(progress, k + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
