@@ -431,13 +431,19 @@ def single_process_main(a):
     b = np.empty(n)
     A.matvec(ones, b)
     k1, k2 = 4, 4 + max(8, min(a.pcg_iters, 64))
+    # the difference of two solves of k1 and k2 iterations (best of three each, after a warm-up solve): on a problem
+    # of a few hundred thousand rows the host-side noise of a single pair can exceed the k2 - k1 iterations themselves
     times = {}
-    for k in (k1, k1, k2):
+    for k in (k1, k1, k2, k1, k2, k1, k2):
         x = np.zeros(n)
         t = time.perf_counter()
         res = dev.pcg(A, b, x, 0.0, k, K)
-        times[k] = time.perf_counter() - t
-    s_per_iter = (times[k2] - times[k1]) / (k2 - k1)
+        dt = time.perf_counter() - t
+        times[k] = min(times.get(k, dt), dt) if k in times or k != k1 else dt
+    if times[k2] > times[k1]:
+        s_per_iter = (times[k2] - times[k1]) / (k2 - k1)
+    else:  # still inside the noise: price the whole longer solve (an upper bound of the iteration time)
+        s_per_iter = times[k2] / k2
     out = {
         "metric": "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s",
         "value": kbytes / (ms.value * 1e-3) / 1e9, "unit": "GB/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
@@ -845,8 +851,15 @@ def main():
             out["device_ceiling_same_run"] = ceiling
             probe = ceiling.get("read7_write1_probe")
             if probe:
-                out["roofline"]["stream_ceiling_GBps"] = probe["GBps"]
-                out["roofline"]["frac_of_stream_ceiling"] = achieved / probe["GBps"]
+                # the ceiling = the best rate any of this job's plain streaming kernels reached (the 7-read + 1-write
+                # probe has the SpMV's shape but csr_spmv_w4 with the round-3 XCD stripe is faster than it; the read-only
+                # dot is the fastest of them); a kernel that beats all three is reported at 1.0, not above
+                rates = {k: v["GBps"] for k, v in ceiling.items() if isinstance(v, dict) and "GBps" in v}
+                best = max(rates, key=rates.get)
+                out["roofline"]["stream_ceiling_GBps"] = rates[best]
+                out["roofline"]["stream_ceiling_kernel"] = best
+                out["roofline"]["frac_of_stream_ceiling"] = min(1.0, achieved / rates[best])
+                out["roofline"]["vs_read7_write1_probe"] = achieved / probe["GBps"]
                 # which timing mode this process is in (profiles/r3_modes.txt): named from the
                 # dominant kernel's own median launch (512^3 csr_spmv_w4 at the stripe-128 default: <= 1.56 ms fast, >= 1.63 ms slow, 1.60-1.62 usual; profiles/r3_w4_stripe.txt); the counter
                 # that moves with it -- read requests the L2s keep in flight, at an unchanged latency per request --

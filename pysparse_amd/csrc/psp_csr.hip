@@ -1096,15 +1096,16 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w5(
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // x pairs: 8-byte aligned
 
 constexpr int kDiaRows = 128;      // rows per block (one wave: two rows per lane)
-constexpr int kDiaMaxOffs = 32;  // 1..16: 16-bit row masks (csr_spmv_w4), 17..32: 32-bit (csr_spmv_w4x)
+constexpr int kDiaMaxOffs = 64;  // 1..16: 16-bit row masks (csr_spmv_w4), 17..32: 32-bit (csr_spmv_w4x), 33..64: 64-bit (csr_spmv_w4y)
+constexpr int kDiaTable = 128;   // slots of the offset hash table (twice the offsets it has to hold)
 constexpr int kDiaEmpty = -0x7fffffff - 1;
 
 struct DiaOffs {
   int o[kDiaMaxOffs];
 };
 
-// distinct values of col - row into a 64-slot open-addressing table; *overflow when there
-// are more than the table (and so certainly more than 16) or a row is not strictly ascending
+// distinct values of col - row into a kDiaTable-slot open-addressing table; *overflow when there
+// are more than the table holds (and so certainly more than kDiaMaxOffs) or a row is not strictly ascending
 __global__ void dia_offsets_kernel(int nrows, const int *__restrict__ ind, const int *__restrict__ col,
                                    int *table, int *overflow) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
@@ -1118,9 +1119,9 @@ __global__ void dia_offsets_kernel(int nrows, const int *__restrict__ ind, const
       }
       prev = c;
       const int o = c - r;
-      unsigned h = ((unsigned)o * 2654435761u) >> 26;
+      unsigned h = ((unsigned)o * 2654435761u) >> 25;
       int probes = 0;
-      for (; probes < 64; ++probes, h = (h + 1) & 63) {
+      for (; probes < kDiaTable; ++probes, h = (h + 1) & (kDiaTable - 1)) {
         int v = *(volatile int *)(table + h);
         if (v == o) break;
         if (v == kDiaEmpty) {
@@ -1128,7 +1129,7 @@ __global__ void dia_offsets_kernel(int nrows, const int *__restrict__ ind, const
           if (v == kDiaEmpty || v == o) break;
         }
       }
-      if (probes == 64) {
+      if (probes == kDiaTable) {
         *overflow = 1;
         return;
       }
@@ -1143,12 +1144,12 @@ __global__ void dia_build_kernel(int nrows, int no, DiaOffs offs, const int *__r
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
     const long blk = r / kDiaRows;
     const int i = (int)(r % kDiaRows);
-    unsigned m = 0;
+    unsigned long long m = 0;
     for (int k = ind[r]; k < ind[r + 1]; ++k) {
       const int o = col[k] - (int)r;
       int b = 0;
       while (b < no - 1 && offs.o[b] != o) ++b;
-      m |= 1u << b;
+      m |= 1ull << b;
       valT[((size_t)blk * no + b) * kDiaRows + i] = val[k];
     }
     mask[r] = (MaskT)m;
@@ -1584,6 +1585,92 @@ __global__ __launch_bounds__(256) void csr_spmv_w4x(
           a0 = ((m0 >> (g + u)) & 1u) ? t0 : a0;
           a1 = ((m1 >> (g + u)) & 1u) ? t1 : a1;
         }
+      }
+    }
+    if (r + 1 < nrows) {
+      d2u outu;
+      outu.x = a0;
+      outu.y = a1;
+      __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
+      if (dotv) {
+        const d2u u = *reinterpret_cast<const d2u *>(dotv + r);
+        dsum += u.x * a0;
+        dsum += u.y * a1;
+      }
+    } else {
+      y[r] = a0;
+      if (dotv) dsum += dotv[r] * a0;
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// csr_spmv_w4 for 33..64 offsets (round 3: the log-spaced pattern of examples/tendigit.py scaled to 10^6 rows has 41;
+// its CSR form sat on the gather kernel csr_spmv_w2 at 0.6 of the roofline): 64-bit row masks, the offsets in device
+// memory (a run-time index into a by-value struct would put it into scratch), groups of 8 in a run-time loop.  Same
+// products in the same order as csr_spmv_w4 / w4x.
+__global__ __launch_bounds__(256) void csr_spmv_w4y(
+    int blk0, int blk1, int nrows, int ncols, int stripe, int no, const int *__restrict__ offs,
+    const double *__restrict__ valT, const unsigned long long *__restrict__ mask, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ dotv, double *__restrict__ partials,
+    const int *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int vb = (int)blockIdx.x;
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int blk = blk0 + vb * 4 + wid;
+  const long r = (long)blk * kDiaRows + 2 * lane;
+  double dsum = 0.0;
+  if (blk < blk1 && r < nrows) {
+    const ulonglong2 mm = *reinterpret_cast<const ulonglong2 *>(mask + r);  // padded to a whole block
+    const unsigned long long m0 = mm.x, m1 = mm.y;
+    const double *vp = valT + (size_t)blk * no * kDiaRows + 2 * lane;
+    const long cmax = (long)ncols - 2;
+    double a0 = 0.0, a1 = 0.0;
+    for (int g = 0; g < no; g += 8) {
+      constexpr int G = 8;
+      d2v v[G], xv[G];
+      int og[G];
+      bool edge = false;
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int gu = g + u < no ? g + u : no - 1;  // the tail group repeats the last offset (loaded, never added)
+        og[u] = offs[gu];
+        v[u] = ldg<true>(reinterpret_cast<const d2v *>(vp + (size_t)gu * kDiaRows));
+        const long c = r + og[u];
+        const long cc = c < 0 ? 0 : (c > cmax ? cmax : c);
+        const d2u t = *reinterpret_cast<const d2u *>(x + cc);
+        xv[u].x = t.x;
+        xv[u].y = t.y;
+        edge |= cc != c;
+      }
+      if (edge) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const long c = r + og[u];
+          if (c < 0 || c > cmax) {
+            xv[u].x = (c >= 0 && c < ncols) ? x[c] : 0.0;
+            xv[u].y = (c + 1 >= 0 && c + 1 < ncols) ? x[c + 1] : 0.0;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const double t0 = a0 + v[u].x * xv[u].x;
+        const double t1 = a1 + v[u].y * xv[u].y;
+        const bool live = g + u < no;
+        a0 = (live && ((m0 >> (g + u)) & 1ull)) ? t0 : a0;
+        a1 = (live && ((m1 >> (g + u)) & 1ull)) ? t1 : a1;
       }
     }
     if (r + 1 < nrows) {
@@ -2096,7 +2183,9 @@ struct CsrExtra {
   DiaOffs dia_offs;
   double *dia_val = nullptr;
   unsigned short *dia_mask = nullptr;  // dia_no <= 16
-  unsigned *dia_mask32 = nullptr;      // dia_no > 16
+  unsigned *dia_mask32 = nullptr;      // 16 < dia_no <= 32
+  unsigned long long *dia_mask64 = nullptr;  // dia_no > 32 (csr_spmv_w4y), with the offsets in device memory:
+  int *dia_offs_dev = nullptr;
   psp_csr *transposed = nullptr;       // A^T as its own handle (matvec_transp on irregular matrices)
   // renumbered copy R = P A P^T for csr_spmv_w3 (psp_reorder.hip): state -1 not examined, 0 none, 1 built
   int reorder_state = -1;
@@ -2460,21 +2549,21 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   }();
   if (off || A->nrows < 1 || A->ncols < 2 || A->nnz < 1 || A->max_row_nnz > kDiaMaxOffs) return PSP_OK;
   ScratchDev tab_mem;
-  PSP_HIP(hipMalloc(&tab_mem.p, 65 * sizeof(int)));
+  PSP_HIP(hipMalloc(&tab_mem.p, (kDiaTable + 1) * sizeof(int)));
   int *d_tab = (int *)tab_mem.p;
-  int init[65];
-  for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
-  init[64] = 0;
+  int init[kDiaTable + 1];
+  for (int i = 0; i < kDiaTable; ++i) init[i] = kDiaEmpty;
+  init[kDiaTable] = 0;
   PSP_HIP(hipMemcpyAsync(d_tab, init, sizeof(init), hipMemcpyHostToDevice, stream()));
   hipLaunchKernelGGL(dia_offsets_kernel, dim3(std::min((A->nrows + 255) / 256, 8192)), dim3(256), 0, stream(),
-                     A->nrows, A->ind, A->col, d_tab, d_tab + 64);
+                     A->nrows, A->ind, A->col, d_tab, d_tab + kDiaTable);
   PSP_LAUNCH_CHECK();
-  int tab[65];
+  int tab[kDiaTable + 1];
   PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  if (tab[64]) return PSP_OK;
+  if (tab[kDiaTable]) return PSP_OK;
   std::vector<int> offs;
-  for (int i = 0; i < 64; ++i)
+  for (int i = 0; i < kDiaTable; ++i)
     if (tab[i] != kDiaEmpty) offs.push_back(tab[i]);
   if (offs.empty() || (int)offs.size() > kDiaMaxOffs) return PSP_OK;
   std::sort(offs.begin(), offs.end());
@@ -2486,7 +2575,7 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   if (slots * 8.0 > 11.0 * (double)A->nnz) return PSP_OK;
   for (int i = 0; i < kDiaMaxOffs; ++i) ex.dia_offs.o[i] = i < no ? offs[i] : 0;
   const size_t nval = nblk * kDiaRows * no;
-  const bool m32 = no > 16;
+  const bool m32 = no > 16 && no <= 32, m64 = no > 32;
   const size_t nmask = nblk * kDiaRows + 2;
   hipError_t e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
   if (e1 != hipSuccess) {  // cached solver work vectors may be in the way: drop them and try once more
@@ -2494,20 +2583,31 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
     (void)psp_trim();
     e1 = hipMalloc((void **)&ex.dia_val, sizeof(double) * nval);
   }
-  hipError_t e2 = m32 ? hipMalloc((void **)&ex.dia_mask32, sizeof(unsigned) * nmask)
-                      : hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * nmask);
-  if (e1 != hipSuccess || e2 != hipSuccess) {  // no room: stay with the CSR kernels
+  hipError_t e2 = m64   ? hipMalloc((void **)&ex.dia_mask64, sizeof(unsigned long long) * nmask)
+                  : m32 ? hipMalloc((void **)&ex.dia_mask32, sizeof(unsigned) * nmask)
+                        : hipMalloc((void **)&ex.dia_mask, sizeof(unsigned short) * nmask);
+  hipError_t e3 = m64 ? hipMalloc((void **)&ex.dia_offs_dev, sizeof(int) * kDiaMaxOffs) : hipSuccess;
+  if (e3 == hipSuccess && m64)
+    e3 = hipMemcpyAsync(ex.dia_offs_dev, ex.dia_offs.o, sizeof(int) * kDiaMaxOffs, hipMemcpyHostToDevice, stream());
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {  // no room: stay with the CSR kernels
     (void)hipGetLastError();
     if (e1 == hipSuccess) (void)hipFree(ex.dia_val);
-    if (e2 == hipSuccess) (void)hipFree(m32 ? (void *)ex.dia_mask32 : (void *)ex.dia_mask);
+    if (e2 == hipSuccess) (void)hipFree(m64 ? (void *)ex.dia_mask64 : m32 ? (void *)ex.dia_mask32 : (void *)ex.dia_mask);
+    if (ex.dia_offs_dev) (void)hipFree(ex.dia_offs_dev);
     ex.dia_val = nullptr;
     ex.dia_mask = nullptr;
     ex.dia_mask32 = nullptr;
+    ex.dia_mask64 = nullptr;
+    ex.dia_offs_dev = nullptr;
     return PSP_OK;
   }
   PSP_HIP(hipMemsetAsync(ex.dia_val, 0, sizeof(double) * nval, stream()));
   const int bgrid = std::min((A->nrows + 255) / 256, 65536);
-  if (m32) {
+  if (m64) {
+    PSP_HIP(hipMemsetAsync(ex.dia_mask64, 0, sizeof(unsigned long long) * nmask, stream()));
+    hipLaunchKernelGGL(dia_build_kernel<unsigned long long>, dim3(bgrid), dim3(256), 0, stream(), A->nrows, no,
+                       ex.dia_offs, A->ind, A->col, A->val, ex.dia_val, ex.dia_mask64);
+  } else if (m32) {
     PSP_HIP(hipMemsetAsync(ex.dia_mask32, 0, sizeof(unsigned) * nmask, stream()));
     hipLaunchKernelGGL(dia_build_kernel<unsigned>, dim3(bgrid), dim3(256), 0, stream(), A->nrows, no, ex.dia_offs,
                        A->ind, A->col, A->val, ex.dia_val, ex.dia_mask32);
@@ -2553,6 +2653,11 @@ static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int 
     PSP_W4X(25); PSP_W4X(26); PSP_W4X(27); PSP_W4X(28); PSP_W4X(29); PSP_W4X(30); PSP_W4X(31); PSP_W4X(32);
 #undef PSP_W4X
     default:
+      if (ex->dia_no > 32 && ex->dia_no <= kDiaMaxOffs && ex->dia_mask64) {
+        hipLaunchKernelGGL(csr_spmv_w4y, dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows, A->ncols, stripe,
+                           ex->dia_no, ex->dia_offs_dev, ex->dia_val, ex->dia_mask64, x, y, dotv, pbuf, skip);
+        break;
+      }
       return fail(PSP_EINVAL, "csr_spmv_w4: %d offsets", ex->dia_no);
   }
 #undef PSP_W4
@@ -2591,21 +2696,21 @@ static int ensure_sss_w4(psp_sss *S) {
   }();
   if (off || S->n < 2 || S->nnz_lower < 1) return PSP_OK;
   ScratchDev tab_mem;
-  PSP_HIP(hipMalloc(&tab_mem.p, 65 * sizeof(int)));
+  PSP_HIP(hipMalloc(&tab_mem.p, (kDiaTable + 1) * sizeof(int)));
   int *d_tab = (int *)tab_mem.p;
-  int init[65];
-  for (int i = 0; i < 64; ++i) init[i] = kDiaEmpty;
-  init[64] = 0;
+  int init[kDiaTable + 1];
+  for (int i = 0; i < kDiaTable; ++i) init[i] = kDiaEmpty;
+  init[kDiaTable] = 0;
   PSP_HIP(hipMemcpyAsync(d_tab, init, sizeof(init), hipMemcpyHostToDevice, stream()));
   hipLaunchKernelGGL(dia_offsets_kernel, dim3(std::min((S->n + 255) / 256, 8192)), dim3(256), 0, stream(), S->n,
-                     S->ind, S->col, d_tab, d_tab + 64);
+                     S->ind, S->col, d_tab, d_tab + kDiaTable);
   PSP_LAUNCH_CHECK();
-  int tab[65];
+  int tab[kDiaTable + 1];
   PSP_HIP(hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  if (tab[64]) return PSP_OK;
+  if (tab[kDiaTable]) return PSP_OK;
   std::vector<int> offs;
-  for (int i = 0; i < 64; ++i)
+  for (int i = 0; i < kDiaTable; ++i)
     if (tab[i] != kDiaEmpty) offs.push_back(tab[i]);
   if (offs.empty() || offs.size() > 8) return PSP_OK;
   std::sort(offs.begin(), offs.end());
@@ -4257,6 +4362,8 @@ int psp_csr_destroy(psp_csr_t *A) {
       if (it->second.dia_val) (void)hipFree(it->second.dia_val);
       if (it->second.dia_mask) (void)hipFree(it->second.dia_mask);
       if (it->second.dia_mask32) (void)hipFree(it->second.dia_mask32);
+      if (it->second.dia_mask64) (void)hipFree(it->second.dia_mask64);
+      if (it->second.dia_offs_dev) (void)hipFree(it->second.dia_offs_dev);
       g_extra.erase(it);
     }
   }

@@ -338,7 +338,12 @@ def offset_structured_csr(O, m, n, seed, offsets, keep=0.93, empty_frac=0.02):
     (3001, 3001, tuple(range(-8, 9))), (5000, 5000, tuple(range(-16, 16))),
     # the 27-point stencil of a 12 x 11 x 10 grid
     (1320, 1320, tuple(sorted(di + 12 * dj + 132 * dk for di in (-1, 0, 1) for dj in (-1, 0, 1) for dk in (-1, 0, 1)))),
-    (2049, 2100, tuple(range(0, 290, 10)))])
+    (2049, 2100, tuple(range(0, 290, 10))),
+    # 33..64 offsets: csr_spmv_w4y (64-bit row masks, offsets from device memory, run-time groups of 8; round 3)
+    (3000, 3000, tuple(range(-20, 20))), (2500, 2600, tuple(range(-16, 17))), (4097, 4097, tuple(range(-32, 32))),
+    # the log-spaced pattern of examples/tendigit.py, mirrored: offsets +-2^k (25 offsets at n = 5000)
+    (5000, 5000, tuple(sorted([0] + [s * 2 ** k for k in range(13) for s in (-1, 1) if 2 ** k < 5000]))),
+    (9001, 9001, tuple(sorted([0] + [s * (3 * k * k + 1) for k in range(1, 21) for s in (-1, 1)])))])
 def test_csr_matvec_w4_offset_structured_bit_exact(oracle, case):
     """csr_spmv_w4 (masked offset-major layout): random subsets of <= 16 offsets, empty rows, odd row
     counts, rectangular shapes, stored zeros; NaN / Inf in x reach exactly the rows that store an
@@ -371,7 +376,7 @@ def test_csr_matvec_w4_offset_structured_bit_exact(oracle, case):
 
 
 def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
-    """unsorted columns (storage order is not offset order), more than 32 offsets, too much padding"""
+    """unsorted columns (storage order is not offset order), more than 64 offsets, too much padding"""
     from pysparse_amd.device import DeviceCSR
     n = 500
     ind = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
@@ -387,8 +392,16 @@ def test_csr_matvec_w4_refuses_what_it_cannot_represent(oracle):
     A.matvec(x, y_ref)
     D.matvec(x, y)
     assert np.array_equal(y, y_ref)
-    B = offset_structured_csr(oracle, 600, 600, 3, tuple(range(-20, 20)))  # 40 offsets
+    B = offset_structured_csr(oracle, 900, 900, 3, tuple(range(-35, 35)))  # 70 offsets: more than csr_spmv_w4y's 64
     assert DeviceCSR.from_arrays(B.shape, B.ind, B.col, B.val).kernel_info()[0] != "csr_spmv_w4"
+    B2 = offset_structured_csr(oracle, 900, 900, 3, tuple(range(-70, 70, 1)), keep=0.3)  # 140 offsets, <= 64 per row
+    DB2 = DeviceCSR.from_arrays(B2.shape, B2.ind, B2.col, B2.val)
+    assert DB2.kernel_info()[0] != "csr_spmv_w4"
+    y_ref, y = np.empty(900), np.empty(900)
+    xx = rng_vec(900, 6)
+    B2.matvec(xx, y_ref)
+    DB2.matvec(xx, y)
+    assert np.array_equal(y, y_ref)
     Cm = offset_structured_csr(oracle, 3000, 3000, 4, tuple(range(0, 160, 10)), keep=0.1)  # 90 % padding
     DC = DeviceCSR.from_arrays(Cm.shape, Cm.ind, Cm.col, Cm.val)
     assert DC.kernel_info()[0] != "csr_spmv_w4"
