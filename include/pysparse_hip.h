@@ -278,6 +278,9 @@ int psp_ssor_info(const psp_ssor_t *K, int *n, int *levels_forward, int *levels_
  * reference analogue (the reference's sweeps are sequential, preconmodule.c:95-193) */
 int psp_ssor_run_info(const psp_ssor_t *K, int *runs_forward, int *runs_backward, long *levels_in_runs,
                       long *slots_in_runs);
+/* 3-D grid operators whose levels are too wide for such runs are swept brick by brick (bricks of `edge`^3 grid points, a
+ * coarse wavefront of workgroups): the number of bricks, 0 when the handle does not use them */
+int psp_ssor_brick_info(const psp_ssor_t *K, int *bricks, int *edge);
 /* y := K x.  SSOR_precon, preconmodule.c:199-223 */
 int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host);
 int psp_ssor_precon_dev(psp_ssor_t *K, const double *x_dev, double *y_dev);

@@ -30,7 +30,7 @@ psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
 psp_sss_kernel_info psp_sss_set_variant
 psp_jacobi_create_csr psp_jacobi_create_sss psp_jacobi_create_diag psp_jacobi_destroy
 psp_jacobi_shape psp_jacobi_precon psp_jacobi_precon_dev
-psp_ssor_create psp_ssor_destroy psp_ssor_info psp_ssor_run_info psp_ssor_precon psp_ssor_precon_dev
+psp_ssor_create psp_ssor_destroy psp_ssor_info psp_ssor_run_info psp_ssor_brick_info psp_ssor_precon psp_ssor_precon_dev
 psp_op_from_csr psp_op_from_sss psp_op_from_jacobi psp_op_from_ssor psp_op_from_callback psp_op_destroy
 psp_pcg psp_pcg_dev psp_minres psp_minres_dev psp_cgs psp_bicgstab psp_qmrs psp_gmres
 psp_k_dot psp_k_residual psp_k_pupdate psp_k_csr_matvec_dot psp_k_xr_update psp_k_gather
@@ -133,7 +133,7 @@ def _declare(L):
         "psp_jacobi_create_diag": [i, vp, d, i, vp, pvp], "psp_jacobi_destroy": [vp],
         "psp_jacobi_shape": [vp, pi], "psp_jacobi_precon": [vp, vp, vp],
         "psp_jacobi_precon_dev": [vp, vp, vp],
-        "psp_ssor_create": [vp, d, i, pvp], "psp_ssor_destroy": [vp], "psp_ssor_info": [vp, pi, pi, pi], "psp_ssor_run_info": [vp, pi, pi, vp, vp],
+        "psp_ssor_create": [vp, d, i, pvp], "psp_ssor_destroy": [vp], "psp_ssor_info": [vp, pi, pi, pi], "psp_ssor_run_info": [vp, pi, pi, vp, vp], "psp_ssor_brick_info": [vp, pi, pi],
         "psp_ssor_precon": [vp, vp, vp], "psp_ssor_precon_dev": [vp, vp, vp], "psp_op_from_ssor": [vp, pvp],
         "psp_op_from_csr": [vp, pvp], "psp_op_from_sss": [vp, pvp], "psp_op_from_jacobi": [vp, pvp],
         "psp_op_from_callback": [i, HOST_APPLY_FN, vp, pvp], "psp_op_destroy": [vp],

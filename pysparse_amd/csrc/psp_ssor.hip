@@ -22,6 +22,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <initializer_list>
 #include <vector>
@@ -87,6 +88,23 @@ struct psp_ssor {
     int2 *ticks = nullptr;     // (first slot, count <= kRunTick), never across a level boundary; zero-padded per run
   } run_f, run_b;
   int *run_progress = nullptr;  // [0]: tick the walking workgroup has finished (throttles the L2 helpers), [1]: sink
+  // Round 3: BRICKS for 3-D grid operators whose levels are too wide for the runs (ssor_brick_kernel below).  The
+  // positions are then ordered (brick, level, row) instead of (level, row): a brick of 32^3 grid points is one run for
+  // one workgroup, the bricks themselves are a coarse wavefront handed out in dependency order.
+  struct BrickSet {
+    int nbricks = 0;
+    int2 *ticks = nullptr;     // every brick's ticks, each brick's followed by kRunPad empty ones
+    int4 *info = nullptr;      // per brick in processing order: first tick, ticks, first halo entry, halo entries
+    int4 *pred = nullptr;      // per brick: up to three bricks it waits for (processing-order indices, -1: none)
+    int *halo_pos = nullptr;   // positions of the dependencies outside the brick, brick-major
+    unsigned *dpk = nullptr;   // per entry 16 bits: 0 none, 1..0x7fff distance back in slots, 0x8000 | i: halo entry i
+    double2 *vp = nullptr;
+    double *dar = nullptr;
+    double2 *gd = nullptr;
+    int *flags = nullptr;      // [0 .. nbricks): done; [nbricks]: next brick to hand out; [nbricks + 1]: error;
+                               // [nbricks + 2]: scratch word of run_pre_kernel
+  } brick_f, brick_b;
+  bool brick_mode = false;
   // PSP_DEVICE=cpu (psp_cpu.hip): the reference's two sequential sweeps on the host arrays of S; two n-vectors of work
   bool host = false;
   std::vector<double> h_temp, h_temp2;
@@ -584,6 +602,282 @@ __global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *
   }
 }
 
+// ------------------------------------------------------------------ bricks: 3-D grid operators with wide levels (round 3)
+//
+// A 512^3 operator has 1534 levels of up to 196 608 rows: too wide for a run, and one launch per level costs 5.2 us
+// where the level's data stream in 1.5 (16 ms per application against 3.5 ms of streaming).  For a grid operator -- lower
+// offsets {-1, -nx, -nx*ny}, no coupling that wraps around a grid line or plane; detected and verified at set-up -- the
+// rows are grouped into bricks of 32^3 grid points and ordered (brick, level, row).  Inside a brick every level has at
+// most 768 rows and its dependencies lie one or two levels back: a brick is a run (ssor_run_kernel above) for one
+// workgroup, with two differences: the dependencies outside the brick -- the three faces towards lower (backward sweep:
+// higher) indices, finished before the brick starts -- are gathered once, at the start, into an LDS halo, and x is stored
+// with agent-scope stores, because another XCD's workgroup gathers it.  The bricks form a coarse wavefront (a brick
+// needs its three face neighbours): they are handed out in that order through a counter, a workgroup waits for its
+// brick's three predecessors on flags in memory (bounded spins) -- no deadlock whatever is resident, because whoever took
+// an earlier brick is running.  Same operations in the same order per row as ssor_row_ell => the reference's bits.
+constexpr int kBrickEdge = 32;
+constexpr int kBrickRing = 4096;   // LDS ring (doubles), 32 KiB
+constexpr int kBrickHalo = 4080;   // LDS halo (doubles): ring + halo + the hand-out word stay inside 64 KiB of static LDS
+constexpr int kBrickTick = 768;    // threads of a brick's workgroup = the widest level of a 32^3 brick
+constexpr int kBrickMaxDist = kBrickRing - kBrickTick;
+
+// distinct values of row - col over the strict lower entries: smallest / largest, then the range of the others
+__global__ __launch_bounds__(256) void grid_offsets_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
+                                                           int pass, int *mm) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int lo = mm[0], hi = mm[1];
+  for (int k = ind[r]; k < ind[r + 1]; ++k) {
+    const int o = r - col[k];
+    if (pass == 0) {
+      atomicMin(mm + 0, o);
+      atomicMax(mm + 1, o);
+    } else if (o != lo && o != hi) {
+      atomicMin(mm + 2, o);
+      atomicMax(mm + 3, o);
+    }
+  }
+}
+
+// couplings that wrap around a grid line / plane (the row is the first point of its line / plane) are not grid couplings
+__global__ __launch_bounds__(256) void grid_verify_kernel(int n, int nx, int nxy, const int *__restrict__ ind,
+                                                          const int *__restrict__ col, int *bad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int k = ind[r]; k < ind[r + 1]; ++k) {
+    const int o = r - col[k];
+    const bool ok = (o == 1 && r % nx >= 1) || (o == nx && (r % nxy) / nx >= 1) || (o == nxy);
+    if (!ok) atomicAdd(bad, 1);
+  }
+}
+
+// sort key of a row: (processing rank of its brick, its level)
+__global__ __launch_bounds__(256) void brick_key_kernel(int n, int nx, int ny, int nxy, int ba, int bb,
+                                                        const int *__restrict__ rank, const int *__restrict__ level,
+                                                        unsigned long long *__restrict__ key, int *__restrict__ iota) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int i = r % nx, j = (r % nxy) / nx, k = r / nxy;
+  const int b = ((k / kBrickEdge) * bb + j / kBrickEdge) * ba + i / kBrickEdge;
+  key[r] = ((unsigned long long)(unsigned)rank[b] << 32) | (unsigned)level[r];
+  iota[r] = r;
+}
+
+// slot -> first slot of each brick (every brick of the grid is non-empty), starts of the (brick, level) groups
+__global__ __launch_bounds__(256) void brick_bounds_kernel(int n, const unsigned long long *__restrict__ key,
+                                                           int *__restrict__ brick_start, int *__restrict__ group_flag) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const unsigned long long k = key[u], kp = u ? key[u - 1] : ~0ull;
+  group_flag[u] = k != kp;
+  if ((k >> 32) != (kp >> 32)) brick_start[(int)(k >> 32)] = u;
+}
+
+__device__ __forceinline__ int brick_of_slot(int u, int nb, const int *__restrict__ brick_start) {
+  int lo = 0, hi = nb;  // brick_start[lo] <= u < brick_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (brick_start[mid] <= u) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// feasibility of one direction before anything is committed: per lower entry (i, c) the forward sweep has row i depend
+// on row c, the backward sweep row c on row i.  Inside a brick the dependency must lie 1 .. kBrickMaxDist slots back,
+// outside it must belong to an earlier brick; counts the outside dependencies per brick
+__global__ __launch_bounds__(256) void brick_check_kernel(int n, int dir, const int *__restrict__ ind,
+                                                          const int *__restrict__ col, const int *__restrict__ slot_of,
+                                                          int nb, const int *__restrict__ brick_start,
+                                                          int *__restrict__ ext_cnt, int *bad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int k = ind[r]; k < ind[r + 1]; ++k) {
+    const int row = dir ? col[k] : r, dep = dir ? r : col[k];
+    const int u = slot_of[row], q = slot_of[dep];
+    const int bu = brick_of_slot(u, nb, brick_start), bq = brick_of_slot(q, nb, brick_start);
+    if (bu == bq) {
+      if (u - q < 1 || u - q > kBrickMaxDist) atomicAdd(bad, 1);
+    } else {
+      if (bq > bu) atomicAdd(bad, 1);
+      atomicAdd(ext_cnt + bu, 1);
+    }
+  }
+}
+
+// per slot: the 16-bit codes of its entries, its value pairs, its diagonal; outside dependencies get a halo entry each
+template <int W>
+__global__ __launch_bounds__(256) void brick_pack_kernel(int n, const unsigned char *__restrict__ cnt8,
+                                                         const int *__restrict__ pos, const double *__restrict__ val,
+                                                         const int *__restrict__ slot_of, const int *__restrict__ rowmap,
+                                                         const double *__restrict__ da, int nb,
+                                                         const int *__restrict__ brick_start,
+                                                         const int *__restrict__ halo_base, int *__restrict__ halo_fill,
+                                                         int *__restrict__ halo_pos, unsigned *__restrict__ dpk,
+                                                         double2 *__restrict__ vp, double *__restrict__ dar) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const int b = brick_of_slot(u, nb, brick_start);
+  const int bs = brick_start[b], be = brick_start[b + 1];
+  const int cnt = cnt8[u];
+  unsigned w[(W + 1) / 2] = {};
+  double v[2 * ((W + 1) / 2)] = {};
+  for (int s = 0; s < W; ++s)
+    if (s < cnt) {
+      const int p = pos[(size_t)s * n + u];
+      const int q = slot_of ? slot_of[p] : p;
+      unsigned code;
+      if (q >= bs && q < be) {
+        code = (unsigned)(u - q);
+      } else {
+        const int h = atomicAdd(halo_fill + b, 1);
+        halo_pos[halo_base[b] + h] = p;
+        code = 0x8000u | (unsigned)h;
+      }
+      w[s >> 1] |= code << ((s & 1) * 16);
+      v[s] = val[(size_t)s * n + u];
+    }
+  for (int k = 0; k < (W + 1) / 2; ++k) {
+    dpk[(size_t)k * n + u] = w[k];
+    vp[(size_t)k * n + u] = make_double2(v[2 * k], v[2 * k + 1]);
+  }
+  dar[u] = da[rowmap ? rowmap[u] : u];
+}
+
+template <bool MINUS, bool BACK, int W, int D>
+__global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, const int4 *__restrict__ info,
+                                                          const int4 *__restrict__ pred, const int2 *__restrict__ ticks,
+                                                          const int *__restrict__ halo_pos, int m,
+                                                          const int *__restrict__ rowmap, const double2 *__restrict__ vp,
+                                                          const unsigned *__restrict__ dpk,
+                                                          const double2 *__restrict__ gd, double *x, double *y,
+                                                          double omega, int *flags) {
+  static_assert(3 * D <= kRunPad, "the tick table's padding must cover the prefetch distance");
+  constexpr int DW = (W + 1) / 2;
+  __shared__ double ring[kBrickRing];
+  __shared__ double halo[kBrickHalo];
+  __shared__ int next_s;
+  const int tid = threadIdx.x;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (;;) {
+    // ---- the next brick in dependency order.  Wave 0 hands out and waits with wave-uniform control flow (every lane
+    // polls the same word, the values are made uniform explicitly): written as `if (tid == 0) { ... }` the compiler split
+    // this loop by lanes and let the other lanes run ahead through the barriers without thread 0
+    if (wid == 0) {
+      int nb_ = 0;
+      if (tid == 0) nb_ = atomicAdd(flags + nbricks, 1);
+      nb_ = __builtin_amdgcn_readfirstlane(nb_);
+      if (tid == 0) next_s = nb_;
+    }
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(next_s);
+    if (b >= nbricks) return;
+    const int4 bi = info[b];
+    // everything that does not depend on the predecessors is requested before waiting for them: the positions of the
+    // halo entries and the static data of the first D ticks
+    constexpr int NH = (kBrickHalo + kBrickTick - 1) / kBrickTick;
+    int hp[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int h = tid + i * kBrickTick;
+      hp[i] = h < bi.w ? halo_pos[bi.z + h] : -1;
+    }
+    const int2 *tk = ticks + bi.x;
+    const int nticks = bi.y;
+    RunPre<W> pre[D];
+    int2 ti[D];
+    auto issue = [&](RunPre<W> &p, const int2 t2) {  // every lane loads (see ssor_run_kernel)
+      const int u = t2.x + min(tid, max(t2.y - 1, 0));
+      p.u = tid < t2.y ? u : -1;
+      if constexpr (BACK) p.t = rowmap[u]; else p.t = u;
+#pragma unroll
+      for (int s = 0; s < DW; ++s) p.v[s] = vp[(size_t)s * m + u];
+#pragma unroll
+      for (int s = 0; s < DW; ++s) p.dw[s] = dpk[(size_t)s * m + u];
+      p.gd = gd[u];
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      issue(pre[j], tk[j]);
+      ti[j] = tk[j + D];
+    }
+    if (wid == 0) {  // the three face neighbours
+      const int4 pr = pred[b];
+      const int ps[3] = {pr.x, pr.y, pr.z};
+      bool lost = false;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (ps[i] < 0 || lost) continue;
+        int spins = 0;
+        for (;;) {
+          const int f = __builtin_amdgcn_readfirstlane(
+              __hip_atomic_load(flags + ps[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (f != 0) break;
+          __builtin_amdgcn_s_sleep(2);
+          const int err = __builtin_amdgcn_readfirstlane(
+              __hip_atomic_load(flags + nbricks + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (++spins > (1 << 22) || err) {  // gives up (seconds): every workgroup ends, the error word says so
+            lost = true;
+            break;
+          }
+        }
+      }
+      if (tid == 0) {
+        if (lost) __hip_atomic_store(flags + nbricks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next_s = lost ? -1 : b;
+      }
+    }
+    __syncthreads();  // (also lets the prologue's loads land, see ssor_run_kernel)
+    if (__builtin_amdgcn_readfirstlane(next_s) < 0) return;
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      if (hp[i] >= 0)
+        halo[tid + i * kBrickTick] = __hip_atomic_load(x + hp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // the halo is in place
+    for (int k = 0; k < nticks; k += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const RunPre<W> p = pre[j];
+        const int2 tn = ti[j];
+        ti[j] = tk[k + j + 2 * D];
+        double xs[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          const unsigned c = (p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu;
+          xs[s] = (c & 0x8000u) ? halo[c & 0x7fffu] : ring[(p.u - (int)c) & (kBrickRing - 1)];
+        }
+        issue(pre[j], tn);
+        if (p.u >= 0) {
+          double acc = 0.0;
+#pragma unroll
+          for (int s = 0; s < W; ++s) {
+            const unsigned c = (p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu;
+            const double vs = (s & 1) ? p.v[s >> 1].y : p.v[s >> 1].x;
+            const double tt = MINUS ? acc - vs * xs[s] : acc + vs * xs[s];
+            acc = c ? tt : acc;
+          }
+          double xn, yn;
+          if constexpr (!MINUS) {
+            xn = (p.gd.x - acc) / p.gd.y;
+            yn = acc;
+          } else {
+            const double hi = omega * acc;
+            yn = hi;
+            xn = (p.gd.x + hi) / p.gd.y;
+          }
+          ring[p.u & (kBrickRing - 1)] = xn;
+          __hip_atomic_store(x + p.t, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // another XCD gathers it
+          y[p.t] = yn;
+        }
+        lds_barrier();
+      }
+    }
+    // ---- done: this brick's x has left the CU before the flag says so
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void row_len_kernel(int n, const int *__restrict__ ptr, int *__restrict__ len) {
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) len[u] = ptr[u + 1] - ptr[u];
 }
@@ -662,7 +956,7 @@ __global__ void ssor_fill_backward_kernel(int n, const int *__restrict__ rows, c
 }
 
 // longest-path levels of the lower (dir 0) / upper (dir 1) dependency graph, rows sorted by level
-int build_schedule(const psp_csr *F, int dir, int **rows_out, std::vector<int> *ptr_out) {
+int build_schedule(const psp_csr *F, int dir, int **rows_out, std::vector<int> *ptr_out, int **level_out = nullptr) {
   const int n = F->nrows;
   int *level = nullptr, *changed = nullptr, *keys = nullptr, *vals = nullptr, *rows = nullptr, *dptr = nullptr;
   void *tmp = nullptr;
@@ -768,6 +1062,10 @@ int build_schedule(const psp_csr *F, int dir, int **rows_out, std::vector<int> *
     (*ptr_out)[(size_t)nlev] = n;
     *rows_out = rows;
     rows = nullptr;
+    if (level_out) {  // the caller keeps the level of every row (brick ordering)
+      *level_out = level;
+      level = nullptr;
+    }
   }
 done:
 #undef SS_HIP
@@ -806,6 +1104,24 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
   const int *pos = forward ? K->f_pos : K->b_pos;
   const double *val = forward ? K->f_val : K->b_val;
   const unsigned char *c8 = forward ? K->fc8 : K->bc8;
+  if constexpr (W >= 1 && W <= 3) {
+    if (K->brick_mode) {  // a 3-D grid operator with wide levels: bricks of 32^3 points, a coarse wavefront of workgroups
+      const psp_ssor::BrickSet &bs = forward ? K->brick_f : K->brick_b;
+      const int n = K->n, nwg = std::min(bs.nbricks, 256);
+      (void)hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)bs.nbricks + 3), st);
+      hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((n + 255) / 256), dim3(256), 0, st, 0, n, 0, rowmap, K->bp, K->xp,
+                         K->temp, K->da, K->omega, first, bs.dar, bs.gd, bs.flags + bs.nbricks + 2);
+      if (forward)
+        hipLaunchKernelGGL((ssor_brick_kernel<(KIND >= 2), false, W, run_depth<W>()>), dim3(nwg), dim3(kBrickTick), 0, st,
+                           bs.nbricks, bs.info, bs.pred, bs.ticks, bs.halo_pos, n, rowmap, bs.vp, bs.dpk, bs.gd, K->xp,
+                           K->temp, K->omega, bs.flags);
+      else
+        hipLaunchKernelGGL((ssor_brick_kernel<(KIND >= 2), true, W, run_depth<W>()>), dim3(nwg), dim3(kBrickTick), 0, st,
+                           bs.nbricks, bs.info, bs.pred, bs.ticks, bs.halo_pos, n, rowmap, bs.vp, bs.dpk, bs.gd, K->xp,
+                           K->temp, K->omega, bs.flags);
+      return;
+    }
+  }
   const int nl = (int)lp.size() - 1;
   const psp_ssor::RunSet &rs = forward ? K->run_f : K->run_b;
   size_t ri = 0;
@@ -1172,6 +1488,254 @@ void build_runs_w(psp_ssor *K, int dir) {
   }
 }
 
+// ---- bricks (see ssor_brick_kernel): the plan of one direction, made before anything is committed
+struct BrickPlan {
+  int nb = 0;
+  int *rows = nullptr;            // device: rows in (brick, level, row) order = the direction's slot order
+  std::vector<int> brick_start;   // slot ranges by processing index (nb + 1)
+  std::vector<int2> ticks;
+  std::vector<int4> info, pred;
+  std::vector<int> halo_base;     // nb + 1
+  ~BrickPlan() { (void)hipFree(rows); }
+};
+
+struct GridShape {
+  int nx = 0, ny = 0, nz = 0;
+};
+
+// is the strict lower triangle that of a 3-D grid operator in natural ordering (offsets 1, nx, nx * ny; nothing wraps)?
+bool detect_grid(const psp_sss *S, GridShape *g) {
+  const int n = S->n;
+  if (n < 8 || S->nnz_lower < 1) return false;
+  int *mm = nullptr;
+  if (hipMalloc((void **)&mm, 5 * sizeof(int)) != hipSuccess) return false;
+  const int init[5] = {0x7fffffff, 0, 0x7fffffff, 0, 0};
+  int h[5] = {0, 0, 0, 0, 0};
+  const dim3 grid((n + 255) / 256), block(256);
+  bool ok = hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream()) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(grid_offsets_kernel, grid, block, 0, stream(), n, S->ind, S->col, 0, mm);
+    hipLaunchKernelGGL(grid_offsets_kernel, grid, block, 0, stream(), n, S->ind, S->col, 1, mm);
+    ok = hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         hipStreamSynchronize(stream()) == hipSuccess;
+  }
+  // smallest offset 1, exactly one value strictly between the smallest and the largest
+  ok = ok && h[0] == 1 && h[2] == h[3] && h[2] > 1 && h[1] > h[2] && h[1] % h[2] == 0 && n % h[1] == 0;
+  if (ok) {
+    g->nx = h[2];
+    g->ny = h[1] / h[2];
+    g->nz = n / h[1];
+    ok = g->ny >= 2 && g->nz >= 2;
+  }
+  if (ok) {
+    hipLaunchKernelGGL(grid_verify_kernel, grid, block, 0, stream(), n, g->nx, g->nx * g->ny, S->ind, S->col, mm + 4);
+    ok = hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         hipStreamSynchronize(stream()) == hipSuccess && h[4] == 0;
+  }
+  (void)hipGetLastError();
+  (void)hipFree(mm);
+  return ok;
+}
+
+// one direction's plan; `level` = the level of every row in this direction.  false: not feasible (nothing changed)
+bool plan_bricks(const psp_sss *S, const GridShape &g, int dir, const int *level, BrickPlan *P) {
+  const int n = S->n, nx = g.nx, ny = g.ny, nxy = g.nx * g.ny;
+  const int ba = (g.nx + kBrickEdge - 1) / kBrickEdge, bb = (g.ny + kBrickEdge - 1) / kBrickEdge,
+            bc = (g.nz + kBrickEdge - 1) / kBrickEdge;
+  const int nb = ba * bb * bc;
+  // processing order: coarse wavefront a + b + c (forward ascending, backward the reverse)
+  std::vector<int> order((size_t)nb), rank((size_t)nb);
+  for (int i = 0; i < nb; ++i) order[(size_t)i] = i;
+  auto wave = [&](int id) { return id % ba + (id / ba) % bb + id / (ba * bb); };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wave(a) < wave(b); });
+  if (dir) std::reverse(order.begin(), order.end());
+  for (int i = 0; i < nb; ++i) rank[(size_t)order[(size_t)i]] = i;
+  int *d_rank = nullptr, *d_iota = nullptr, *d_slot = nullptr, *d_bstart = nullptr, *d_flag = nullptr, *d_starts = nullptr,
+      *d_cnt = nullptr, *d_ext = nullptr;
+  unsigned long long *d_key = nullptr, *d_key2 = nullptr;
+  void *tmp = nullptr;
+  bool ok = true;
+  const dim3 grid((n + 255) / 256), block(256);
+  auto A = [&](void **p, size_t bytes) { ok = ok && hipMalloc(p, bytes ? bytes : 1) == hipSuccess; };
+  A((void **)&d_rank, sizeof(int) * (size_t)nb);
+  A((void **)&d_iota, sizeof(int) * (size_t)n);
+  A((void **)&P->rows, sizeof(int) * (size_t)n);
+  A((void **)&d_key, sizeof(unsigned long long) * (size_t)n);
+  A((void **)&d_key2, sizeof(unsigned long long) * (size_t)n);
+  A((void **)&d_slot, sizeof(int) * (size_t)n);
+  A((void **)&d_bstart, sizeof(int) * ((size_t)nb + 1));
+  A((void **)&d_flag, sizeof(int) * (size_t)n);
+  A((void **)&d_starts, sizeof(int) * (size_t)n);
+  A((void **)&d_cnt, sizeof(int) * 2);
+  A((void **)&d_ext, sizeof(int) * (size_t)nb);
+  ok = ok && hipMemcpyAsync(d_rank, rank.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice, stream()) == hipSuccess;
+  int nbits = 1;
+  while ((1 << nbits) < nb) ++nbits;
+  if (ok) {
+    hipLaunchKernelGGL(brick_key_kernel, grid, block, 0, stream(), n, nx, ny, nxy, ba, bb, d_rank, level, d_key, d_iota);
+    size_t bytes = 0;
+    ok = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key, d_key2, d_iota, P->rows, n, 0, 32 + nbits, stream()) ==
+         hipSuccess;
+    A(&tmp, bytes);
+    ok = ok && hipcub::DeviceRadixSort::SortPairs(tmp, bytes, d_key, d_key2, d_iota, P->rows, n, 0, 32 + nbits, stream()) ==
+                   hipSuccess;  // stable: rows ascending inside a (brick, level) group
+  }
+  int ngroups = 0;
+  std::vector<int> starts, ext;
+  if (ok) {
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(std::min((n + 255) / 256, 65536)), dim3(256), 0, stream(), n, P->rows,
+                       d_slot);
+    hipLaunchKernelGGL(brick_bounds_kernel, grid, block, 0, stream(), n, d_key2, d_bstart, d_flag);
+    ok = hipMemcpyAsync(d_bstart + nb, &n, sizeof(int), hipMemcpyHostToDevice, stream()) == hipSuccess &&
+         hipMemsetAsync(d_ext, 0, sizeof(int) * (size_t)nb, stream()) == hipSuccess &&
+         hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), stream()) == hipSuccess;
+  }
+  if (ok) {
+    hipLaunchKernelGGL(brick_check_kernel, grid, block, 0, stream(), n, dir, S->ind, S->col, d_slot, nb, d_bstart, d_ext,
+                       d_cnt + 1);
+    (void)hipFree(tmp);
+    tmp = nullptr;
+    size_t bytes = 0;
+    ok = hipcub::DeviceSelect::Flagged(nullptr, bytes, d_iota, d_flag, d_starts, d_cnt, n, stream()) == hipSuccess;
+    A(&tmp, bytes);
+    // d_iota was the sort's input buffer and still holds 0 .. n-1
+    ok = ok && hipcub::DeviceSelect::Flagged(tmp, bytes, d_iota, d_flag, d_starts, d_cnt, n, stream()) == hipSuccess;
+    int cnt[2] = {0, 0};
+    ok = ok && hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+         hipStreamSynchronize(stream()) == hipSuccess && cnt[1] == 0 && cnt[0] > 0;
+    ngroups = cnt[0];
+  }
+  if (ok) {
+    starts.resize((size_t)ngroups + 1);
+    ext.resize((size_t)nb);
+    P->brick_start.resize((size_t)nb + 1);
+    ok = hipMemcpy(starts.data(), d_starts, sizeof(int) * (size_t)ngroups, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(ext.data(), d_ext, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(P->brick_start.data(), d_bstart, sizeof(int) * ((size_t)nb + 1), hipMemcpyDeviceToHost) == hipSuccess;
+    starts[(size_t)ngroups] = n;
+  }
+  if (ok) {
+    P->nb = nb;
+    P->halo_base.assign((size_t)nb + 1, 0);
+    for (int b = 0; b < nb && ok; ++b) {
+      ok = ext[(size_t)b] <= kBrickHalo && ext[(size_t)b] < 0x8000;
+      P->halo_base[(size_t)b + 1] = P->halo_base[(size_t)b] + ext[(size_t)b];
+    }
+  }
+  if (ok) {
+    P->info.resize((size_t)nb);
+    P->pred.resize((size_t)nb);
+    size_t gi = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int bs = P->brick_start[(size_t)b], be = P->brick_start[(size_t)b + 1];
+      const int t0 = (int)P->ticks.size();
+      while (gi < (size_t)ngroups && starts[gi] < be) {  // the (brick, level) groups of this brick
+        const int a = starts[gi], e = std::min(starts[gi + 1], be), w = e - a, nt = (w + kBrickTick - 1) / kBrickTick;
+        for (int i = 0, u = a; i < nt; ++i) {
+          const int c = w / nt + (i < w % nt ? 1 : 0);
+          P->ticks.push_back(make_int2(u, c));
+          u += c;
+        }
+        ++gi;
+      }
+      const int nt = (int)P->ticks.size() - t0;
+      for (int q = 0; q < kRunPad; ++q) P->ticks.push_back(make_int2(bs, 0));
+      P->info[(size_t)b] = make_int4(t0, nt, P->halo_base[(size_t)b], ext[(size_t)b]);
+      // the three face neighbours this brick waits for
+      const int id = order[(size_t)b];
+      const int ia = id % ba, ib = (id / ba) % bb, ic = id / (ba * bb);
+      const int st = dir ? 1 : -1;
+      int pr[3] = {-1, -1, -1};
+      if (ia + st >= 0 && ia + st < ba) pr[0] = rank[(size_t)(id + st)];
+      if (ib + st >= 0 && ib + st < bb) pr[1] = rank[(size_t)(id + st * ba)];
+      if (ic + st >= 0 && ic + st < bc) pr[2] = rank[(size_t)(id + st * ba * bb)];
+      P->pred[(size_t)b] = make_int4(pr[0], pr[1], pr[2], 0);
+    }
+  }
+  (void)hipGetLastError();
+  for (void *q : {(void *)d_rank, (void *)d_iota, (void *)d_key, (void *)d_key2, (void *)d_slot, (void *)d_bstart,
+                  (void *)d_flag, (void *)d_starts, (void *)d_cnt, (void *)d_ext, tmp})
+    (void)hipFree(q);
+  return ok;
+}
+
+// after build_level_ordered (whose slot orders came from the plans): the arrays the brick kernel streams
+template <int W>
+int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
+  psp_ssor::BrickSet &bs = dir ? K->brick_b : K->brick_f;
+  const int n = K->n, nb = P.nb;
+  constexpr int DW = (W + 1) / 2;
+  const int *pos = dir ? K->b_pos : K->f_pos;
+  const double *val = dir ? K->b_val : K->f_val;
+  const unsigned char *c8 = dir ? K->bc8 : K->fc8;
+  const int *rowmap = dir ? K->b_row : nullptr;
+  int *slot_of = nullptr, *d_bstart = nullptr, *d_hbase = nullptr, *d_hfill = nullptr;
+  int rc = PSP_OK;
+  bs.nbricks = nb;
+  const int nhalo = P.halo_base[(size_t)nb];
+  bool ok = hipMalloc((void **)&bs.ticks, sizeof(int2) * P.ticks.size()) == hipSuccess &&
+            hipMalloc((void **)&bs.info, sizeof(int4) * (size_t)nb) == hipSuccess &&
+            hipMalloc((void **)&bs.pred, sizeof(int4) * (size_t)nb) == hipSuccess &&
+            hipMalloc((void **)&bs.halo_pos, sizeof(int) * (size_t)std::max(nhalo, 1)) == hipSuccess &&
+            hipMalloc((void **)&bs.dpk, sizeof(unsigned) * (size_t)DW * n) == hipSuccess &&
+            hipMalloc((void **)&bs.vp, sizeof(double2) * (size_t)DW * n) == hipSuccess &&
+            hipMalloc((void **)&bs.dar, sizeof(double) * (size_t)n) == hipSuccess &&
+            hipMalloc((void **)&bs.gd, sizeof(double2) * (size_t)n) == hipSuccess &&
+            hipMalloc((void **)&bs.flags, sizeof(int) * ((size_t)nb + 3)) == hipSuccess &&
+            hipMalloc((void **)&d_bstart, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
+            hipMalloc((void **)&d_hbase, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
+            hipMalloc((void **)&d_hfill, sizeof(int) * (size_t)nb) == hipSuccess &&
+            (!dir || hipMalloc((void **)&slot_of, sizeof(int) * (size_t)n) == hipSuccess);
+  ok = ok &&
+       hipMemcpyAsync(bs.ticks, P.ticks.data(), sizeof(int2) * P.ticks.size(), hipMemcpyHostToDevice, stream()) ==
+           hipSuccess &&
+       hipMemcpyAsync(bs.info, P.info.data(), sizeof(int4) * (size_t)nb, hipMemcpyHostToDevice, stream()) == hipSuccess &&
+       hipMemcpyAsync(bs.pred, P.pred.data(), sizeof(int4) * (size_t)nb, hipMemcpyHostToDevice, stream()) == hipSuccess &&
+       hipMemcpyAsync(d_bstart, P.brick_start.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, stream()) ==
+           hipSuccess &&
+       hipMemcpyAsync(d_hbase, P.halo_base.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, stream()) ==
+           hipSuccess &&
+       hipMemsetAsync(d_hfill, 0, sizeof(int) * (size_t)nb, stream()) == hipSuccess &&
+       hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)nb + 3), stream()) == hipSuccess;
+  if (ok) {
+    if (dir)
+      hipLaunchKernelGGL(invert_perm_kernel, dim3(std::min((n + 255) / 256, 65536)), dim3(256), 0, stream(), n, K->b_row,
+                         slot_of);
+    hipLaunchKernelGGL(brick_pack_kernel<W>, dim3((n + 255) / 256), dim3(256), 0, stream(), n, c8, pos, val, slot_of,
+                       rowmap, K->da, nb, d_bstart, d_hbase, d_hfill, bs.halo_pos, bs.dpk, bs.vp, bs.dar);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream()) == hipSuccess;
+  }
+  if (!ok) rc = fail(PSP_ENOMEM, "ssor: the brick schedule could not be built");
+  (void)hipFree(slot_of);
+  (void)hipFree(d_bstart);
+  (void)hipFree(d_hbase);
+  (void)hipFree(d_hfill);
+  return rc;
+}
+
+int finish_bricks(psp_ssor *K, int dir, const BrickPlan &P) {
+  switch (dir ? K->ell_b : K->ell_f) {
+    case 1: return finish_bricks_w<1>(K, dir, P);
+    case 2: return finish_bricks_w<2>(K, dir, P);
+    case 3: return finish_bricks_w<3>(K, dir, P);
+    default: return fail(PSP_EINVAL, "ssor: a grid operator with %d entries per sweep row", dir ? K->ell_b : K->ell_f);
+  }
+}
+
+// bricks are for schedules the runs do not cover: some level wider than a run takes (PSP_SSOR_BRICK=0 / 1 under
+// PSP_TUNING: never / whenever the operator is a 3-D grid operator)
+bool bricks_wanted(const std::vector<int> &ptr_f) {
+  static const int mode = [] {
+    const char *e = psp::tuning_env("PSP_SSOR_BRICK");
+    return e ? atoi(e) : -1;
+  }();
+  if (mode == 0) return false;
+  if (mode > 0) return true;
+  for (size_t l = 0; l + 1 < ptr_f.size(); ++l)
+    if (ptr_f[l + 1] - ptr_f[l] > kRunWide) return true;
+  return false;
+}
+
 void build_runs(psp_ssor *K) {
   static const bool off = [] {
     const char *e = psp::tuning_env("PSP_SSOR_LDS");
@@ -1277,9 +1841,20 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
   K->S = S;
   int rc = PSP_OK;
   if (S->n > 0) {
-    int *rows_f = nullptr, *rows_b = nullptr;
-    rc = build_schedule(S->full, 0, &rows_f, &K->ptr_f);
-    if (rc == PSP_OK) rc = build_schedule(S->full, 1, &rows_b, &K->ptr_b);
+    int *rows_f = nullptr, *rows_b = nullptr, *lev_f = nullptr, *lev_b = nullptr;
+    rc = build_schedule(S->full, 0, &rows_f, &K->ptr_f, &lev_f);
+    if (rc == PSP_OK) rc = build_schedule(S->full, 1, &rows_b, &K->ptr_b, &lev_b);
+    BrickPlan plan_f, plan_b;
+    GridShape shape;
+    if (rc == PSP_OK && bricks_wanted(K->ptr_f) && detect_grid(S, &shape) && plan_bricks(S, shape, 0, lev_f, &plan_f) &&
+        plan_bricks(S, shape, 1, lev_b, &plan_b)) {
+      // both directions are feasible: the slot orders become (brick, level, row)
+      std::swap(rows_f, plan_f.rows);
+      std::swap(rows_b, plan_b.rows);
+      K->brick_mode = true;
+    }
+    (void)hipFree(lev_f);
+    (void)hipFree(lev_b);
     if (rc == PSP_OK) {
       // backward slots are (level, row)-sorted rows; ptr_b indexes slots
       rc = build_level_ordered(K, rows_f, rows_b);
@@ -1287,6 +1862,10 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     }
     (void)hipFree(rows_f);
     (void)hipFree(rows_b);
+    if (rc == PSP_OK && K->brick_mode) {
+      rc = finish_bricks(K, 0, plan_f);
+      if (rc == PSP_OK) rc = finish_bricks(K, 1, plan_b);
+    }
     if (rc == PSP_OK) {
       const size_t bf = sizeof(int) * K->ptr_f.size(), bb = sizeof(int) * K->ptr_b.size();
       if (hipMalloc((void **)&K->dptr_f, bf) != hipSuccess || hipMalloc((void **)&K->dptr_b, bb) != hipSuccess ||
@@ -1294,7 +1873,7 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
           hipMemcpy(K->dptr_b, K->ptr_b.data(), bb, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(PSP_ENOMEM, "ssor: level table allocation failed");
     }
-    if (rc == PSP_OK) build_runs(K);
+    if (rc == PSP_OK && !K->brick_mode) build_runs(K);
   } else {
     K->ptr_f.assign(1, 0);
     K->ptr_b.assign(1, 0);
@@ -1324,6 +1903,10 @@ int psp_ssor_destroy(psp_ssor_t *K) {
                   (void *)K->run_b.ticks, (void *)K->run_b.vp,
                   (void *)K->run_progress})
     (void)hipFree(p);
+  for (psp_ssor::BrickSet *b : {&K->brick_f, &K->brick_b})
+    for (void *p : {(void *)b->ticks, (void *)b->info, (void *)b->pred, (void *)b->halo_pos, (void *)b->dpk, (void *)b->vp,
+                    (void *)b->dar, (void *)b->gd, (void *)b->flags})
+      (void)hipFree(p);
   delete K;
   return PSP_OK;
 }
@@ -1346,6 +1929,13 @@ int psp_ssor_run_info(const psp_ssor_t *K, int *runs_forward, int *runs_backward
   if (runs_backward) *runs_backward = (int)K->run_b.runs.size();
   if (levels_in_runs) *levels_in_runs = lv;
   if (slots_in_runs) *slots_in_runs = (long)K->run_f.m + K->run_b.m;
+  return PSP_OK;
+}
+
+int psp_ssor_brick_info(const psp_ssor_t *K, int *bricks, int *edge) {
+  if (!K) return fail(PSP_EINVAL, "psp_ssor_brick_info: NULL handle");
+  if (bricks) *bricks = K->brick_mode ? K->brick_f.nbricks : 0;
+  if (edge) *edge = kBrickEdge;
   return PSP_OK;
 }
 

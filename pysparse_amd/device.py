@@ -448,6 +448,9 @@ class DeviceSSOR:
         check(lib().psp_ssor_run_info(h, C.byref(rf), C.byref(rb), C.byref(lv), C.byref(sl)))
         # (runs forward, runs backward, levels covered, slots covered) of the LDS-exchange runs of narrow levels
         self.lds_runs = (rf.value, rb.value, lv.value, sl.value)
+        nbr, edge = C.c_int(), C.c_int()
+        check(lib().psp_ssor_brick_info(h, C.byref(nbr), C.byref(edge)))
+        self.bricks = nbr.value  # 3-D grid operators with wide levels: bricks of edge^3 points, 0 otherwise
 
     def precon(self, x, y):
         n = self.shape[0]

@@ -209,12 +209,14 @@ def test_ssor_runs_of_narrow_levels_bit_exact(oracle, grid, keep, omega, steps):
     D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
     K = DeviceSSOR(D, omega, steps)
     rf, rb, levels, slots = K.lds_runs
-    if keep > 0.9:
+    if keep > 0.9 and not K.bricks:
         assert rf >= 1 and rb >= 1 and slots > 0
     if keep == 0.999:
         assert rf > 1 and levels < sum(K.levels)  # split at the levels that reach too far back
-    if grid == (128, 128, 64):
-        assert rf == 2 and rb == 2 and levels < sum(K.levels)  # thin ends only
+    if grid == (128, 128, 64):  # levels of up to 8192 rows: a 3-D grid operator like this one is swept brick by brick ...
+        assert K.bricks == 4 * 4 * 2 and rf == 0 and rb == 0
+    if grid == (80, 70, 60) and keep < 1.0:  # ... unless a dependency inside a brick lies too far back (missing couplings)
+        assert K.bricks == 0
     if grid in ((1500, 700, 0), (700, 1500, 0), (64, 64, 64), (2100, 2100, 0)):
         assert levels == sum(K.levels) and slots == 2 * S.n      # the whole schedule
     x = rng_vec(S.n, 3)
@@ -249,3 +251,52 @@ def test_ssor_runs_switch_is_an_ab_switch(oracle):
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split())
     assert int(outs[0][0]) >= 1 and int(outs[1][0]) == 0
     assert outs[0][1:] == outs[1][1:]
+
+
+@pytest.mark.parametrize("omega,steps", [(1.0, 1), (1.0, 2), (1.3, 1), (0.8, 2)])
+@pytest.mark.parametrize("grid,keep", [((128, 128, 64), 1.0), ((100, 90, 80), 1.0), ((65, 200, 70), 1.0),
+                                       ((130, 40, 140), 1.0), ((96, 96, 96), 0.97), ((160, 150, 33), 1.0)])
+def test_ssor_bricks_bit_exact(oracle, grid, keep, omega, steps):
+    """Round 3: 3-D grid operators whose levels are too wide for a run (more than 4096 rows) are swept in bricks of 32^3
+    grid points -- a run per brick for one workgroup, the faces towards the finished neighbours gathered into an LDS halo,
+    the bricks a coarse wavefront handed out in dependency order (ssor_brick_kernel): whole and partial bricks, a brick
+    layer one point thick (33 planes), variable coefficients, all four sweep kinds, the replayed graph.  With missing
+    couplings a dependency can lie further back than the brick's ring holds; the handle then keeps its level schedule.
+    Same bits as the oracle's sequential sweeps (preconmodule.c:95-193)."""
+    from pysparse_amd.device import DeviceSSOR, DeviceSSS
+    S = grid_sss(oracle, *grid, seed=11 + sum(grid), keep=keep)
+    D = DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    K = DeviceSSOR(D, omega, steps)
+    nb = -(-grid[0] // 32) * -(-grid[1] // 32) * -(-grid[2] // 32)
+    if keep == 1.0:
+        assert K.bricks == nb, (K.bricks, nb, K.lds_runs)
+    x = rng_vec(S.n, 3)
+    y_ref = np.full(S.n, -1.5)
+    oracle.ssor_apply(S, x, y_ref, omega, steps)
+    y = np.full(S.n, -1.5)
+    K.precon(x, y)
+    assert np.array_equal(y, y_ref)
+    K.precon(x, y)  # the replayed graph
+    assert np.array_equal(y, y_ref)
+
+
+def test_ssor_bricks_refuse_what_is_not_a_grid_operator(oracle):
+    """a coupling that wraps around a grid line, a 2-D operator, an operator without the offset -1: no bricks, same bits"""
+    from pysparse_amd.device import DeviceSSOR, DeviceSSS
+    S = grid_sss(oracle, 128, 128, 64, seed=5, keep=1.0)
+    r = 128  # first point of the second grid line: its offset -1 neighbour is the end of the first line
+    hi = S.ind[r + 1]
+    col = np.insert(S.col, hi, r - 1)
+    val = np.insert(S.val, hi, -0.25)
+    ind = S.ind.copy()
+    ind[r + 1:] += 1
+    S2 = oracle.SSS(S.n, val, S.diag, col, ind)
+    x = rng_vec(S.n, 3)
+    for T in (S2, grid_sss(oracle, 2100, 2100, 0, seed=6, keep=1.0)):
+        K = DeviceSSOR(DeviceSSS.from_arrays(T.n, T.ind, T.col, T.val, T.diag), 1.0, 1)
+        assert K.bricks == 0
+        xx = x[:T.n] if T.n <= x.size else rng_vec(T.n, 4)
+        y_ref, y = np.zeros(T.n), np.zeros(T.n)
+        oracle.ssor_apply(T, xx, y_ref, 1.0, 1)
+        K.precon(xx, y)
+        assert np.array_equal(y, y_ref)
