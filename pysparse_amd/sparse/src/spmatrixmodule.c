@@ -24,6 +24,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #define SPMATRIX_MODULE
 #include "spmatrix_api.h"
@@ -1181,6 +1183,415 @@ fail:
   return NULL;
 }
 
+/* mtx_read_coordinate(fileName, threads=0) -> (m, n, symmetric, rows, cols, vals): the entries of a coordinate
+ * MatrixMarket file in file order, 0-based int64 indices and float64 values, parsed by `threads` threads (0: up to 8).
+ * Same banner rules as ll_mat_from_mtx (LLMat_from_mtx, ll_mat.c:3390-3456).  What pysparse_amd.tools.mtx builds
+ * csr_mat / sss_mat from without one sorted list insertion per entry: SuiteSparse
+ * Emilia_923 has 2.1e7 entries in its file; the values go through strtod, i.e. correctly rounded like the
+ * reference's fscanf("%lg"). */
+typedef struct {
+  const char *p, *e;
+  long cnt, off, m, n;
+  npy_int64 *ri, *ci;
+  double *v;
+  int err; /* 1: malformed line, 2: index out of range */
+} MtxChunk;
+
+static const char *mtx_skip_blank(const char *p, const char *e) {
+  while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+  return p;
+}
+
+static void *mtx_count_worker(void *arg) {
+  MtxChunk *c = (MtxChunk *)arg;
+  const char *p = c->p;
+  long cnt = 0;
+  while (p < c->e) {
+    const char *q = mtx_skip_blank(p, c->e);
+    const char *nl = (const char *)memchr(q, '\n', (size_t)(c->e - q));
+    if (q < c->e && *q != '\n' && *q != '%') cnt++;
+    p = nl ? nl + 1 : c->e;
+  }
+  c->cnt = cnt;
+  return NULL;
+}
+
+static void *mtx_parse_worker(void *arg) {
+  MtxChunk *c = (MtxChunk *)arg;
+  const char *p = c->p;
+  long k = c->off;
+  while (p < c->e) {
+    const char *q = mtx_skip_blank(p, c->e);
+    const char *nl = (const char *)memchr(q, '\n', (size_t)(c->e - q));
+    if (q < c->e && *q != '\n' && *q != '%') {
+      char *end;
+      long r, cc;
+      double val;
+      r = strtol(q, &end, 10);
+      if (end == q) { c->err = 1; return NULL; }
+      q = end;
+      cc = strtol(q, &end, 10);
+      if (end == q) { c->err = 1; return NULL; }
+      q = end;
+      val = strtod(q, &end); /* the buffer ends with a NUL behind the last line */
+      if (end == q) { c->err = 1; return NULL; }
+      if (r < 1 || r > c->m || cc < 1 || cc > c->n) { c->err = 2; return NULL; }
+      c->ri[k] = r - 1;
+      c->ci[k] = cc - 1;
+      c->v[k] = val;
+      k++;
+    }
+    p = nl ? nl + 1 : c->e;
+  }
+  return NULL;
+}
+
+static PyObject *Mtx_read_coordinate(PyObject *module, PyObject *args) {
+  const char *fileName;
+  int threads = 0, T, t, is_sym, err = 0;
+  char banner[64], mtx[64], crd[64], dtype[64], sym[64];
+  char *buf = NULL, *p, *data;
+  long size, got, m, n, nz, total = 0;
+  FILE *f;
+  MtxChunk ch[64];
+  pthread_t th[64];
+  PyArrayObject *ri = NULL, *ci = NULL, *va = NULL;
+  npy_intp dims[1];
+  PyObject *res;
+  if (!PyArg_ParseTuple(args, "s|i", &fileName, &threads)) return NULL;
+  f = fopen(fileName, "rb");
+  if (f == NULL) return PyErr_SetFromErrnoWithFilename(PyExc_IOError, fileName);
+  if (fseek(f, 0, SEEK_END) != 0 || (size = ftell(f)) < 0 || fseek(f, 0, SEEK_SET) != 0) {
+    fclose(f);
+    PyErr_SetString(PyExc_IOError, "error reading MTX file");
+    return NULL;
+  }
+  buf = (char *)malloc((size_t)size + 2);
+  if (buf == NULL) {
+    fclose(f);
+    return PyErr_NoMemory();
+  }
+  Py_BEGIN_ALLOW_THREADS
+  got = (long)fread(buf, 1, (size_t)size, f);
+  Py_END_ALLOW_THREADS
+  fclose(f);
+  if (got != size) {
+    free(buf);
+    PyErr_SetString(PyExc_IOError, "error reading MTX file");
+    return NULL;
+  }
+  buf[size] = '\n';
+  buf[size + 1] = '\0';
+  if (sscanf(buf, "%63s %63s %63s %63s %63s", banner, mtx, crd, dtype, sym) != 5 ||
+      strcmp(banner, "%%MatrixMarket") != 0) {
+    free(buf);
+    PyErr_SetString(PyExc_IOError, "error reading MTX file header");
+    return NULL;
+  }
+  for (p = mtx; *p; p++) *p = (char)tolower(*p);
+  for (p = crd; *p; p++) *p = (char)tolower(*p);
+  for (p = dtype; *p; p++) *p = (char)tolower(*p);
+  for (p = sym; *p; p++) *p = (char)tolower(*p);
+  is_sym = strcmp(sym, "symmetric") == 0;
+  if (strcmp(mtx, "matrix") != 0 || strcmp(crd, "coordinate") != 0 ||
+      (strcmp(dtype, "real") != 0 && strcmp(dtype, "integer") != 0) || (!is_sym && strcmp(sym, "general") != 0)) {
+    free(buf);
+    PyErr_SetString(SpMatrix_ErrorObject, "must be real, sparse matrix");
+    return NULL;
+  }
+  /* the size line: the first line behind the banner that is neither a comment nor blank */
+  p = (char *)memchr(buf, '\n', (size_t)size + 1);
+  for (;;) {
+    const char *q;
+    if (p == NULL || p + 1 >= buf + size) {
+      free(buf);
+      PyErr_SetString(PyExc_IOError, "error reading MTX file size information");
+      return NULL;
+    }
+    p++;
+    q = mtx_skip_blank(p, buf + size);
+    if (*q != '%' && *q != '\n') break;
+    p = (char *)memchr(p, '\n', (size_t)(buf + size + 1 - p));
+  }
+  if (sscanf(p, "%ld %ld %ld", &m, &n, &nz) != 3 || m < 0 || n < 0 || nz < 0) {
+    free(buf);
+    PyErr_SetString(PyExc_IOError, "error reading MTX file size information");
+    return NULL;
+  }
+  data = (char *)memchr(p, '\n', (size_t)(buf + size + 1 - p)) + 1;
+  T = threads > 0 ? threads : (int)sysconf(_SC_NPROCESSORS_ONLN);
+  if (threads <= 0 && T > 8) T = 8;
+  if (T < 1) T = 1;
+  if (T > 64) T = 64;
+  if ((buf + size + 1) - data < (1 << 16)) T = 1;
+  { /* chunks end behind a newline */
+    const char *e = buf + size + 1;
+    const char *cur = data;
+    for (t = 0; t < T; t++) {
+      const char *stop = t == T - 1 ? e : data + (long)((double)(e - data) * (t + 1) / T);
+      if (stop < cur) stop = cur;
+      if (t < T - 1) {
+        const char *nl = (const char *)memchr(stop, '\n', (size_t)(e - stop));
+        stop = nl ? nl + 1 : e;
+      }
+      memset(&ch[t], 0, sizeof ch[t]);
+      ch[t].p = cur;
+      ch[t].e = stop;
+      ch[t].m = m;
+      ch[t].n = n;
+      cur = stop;
+    }
+  }
+  Py_BEGIN_ALLOW_THREADS
+  for (t = 1; t < T; t++)
+    if (pthread_create(&th[t], NULL, mtx_count_worker, &ch[t]) != 0) err = 3;
+  if (!err) {
+    mtx_count_worker(&ch[0]);
+    for (t = 1; t < T; t++) pthread_join(th[t], NULL);
+  }
+  Py_END_ALLOW_THREADS
+  if (err) {
+    free(buf);
+    PyErr_SetString(PyExc_RuntimeError, "mtx_read_coordinate: cannot start a thread");
+    return NULL;
+  }
+  for (t = 0; t < T; t++) {
+    ch[t].off = total;
+    total += ch[t].cnt;
+  }
+  if (total != nz) {
+    free(buf);
+    PyErr_Format(SpMatrix_ErrorObject, "file holds %ld entries, the size line promises %ld", total, nz);
+    return NULL;
+  }
+  dims[0] = (npy_intp)nz;
+  ri = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_INT64);
+  ci = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_INT64);
+  va = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_DOUBLE);
+  if (ri == NULL || ci == NULL || va == NULL) {
+    free(buf);
+    Py_XDECREF(ri);
+    Py_XDECREF(ci);
+    Py_XDECREF(va);
+    return NULL;
+  }
+  for (t = 0; t < T; t++) {
+    ch[t].ri = (npy_int64 *)PyArray_DATA(ri);
+    ch[t].ci = (npy_int64 *)PyArray_DATA(ci);
+    ch[t].v = (double *)PyArray_DATA(va);
+  }
+  Py_BEGIN_ALLOW_THREADS
+  for (t = 1; t < T; t++)
+    if (pthread_create(&th[t], NULL, mtx_parse_worker, &ch[t]) != 0) {
+      mtx_parse_worker(&ch[t]); /* no thread: parse it here */
+      th[t] = 0;
+    }
+  mtx_parse_worker(&ch[0]);
+  for (t = 1; t < T; t++)
+    if (th[t]) pthread_join(th[t], NULL);
+  Py_END_ALLOW_THREADS
+  free(buf);
+  for (t = 0; t < T; t++)
+    if (ch[t].err > err) err = ch[t].err;
+  if (err) {
+    Py_DECREF(ri);
+    Py_DECREF(ci);
+    Py_DECREF(va);
+    if (err == 2)
+      PyErr_SetString(PyExc_IndexError, "matrix indices out of range");
+    else
+      PyErr_SetString(PyExc_IOError, "error reading MTX file data");
+    return NULL;
+  }
+  res = Py_BuildValue("llONNN", m, n, is_sym ? Py_True : Py_False, (PyObject *)ri, (PyObject *)ci, (PyObject *)va);
+  return res;
+}
+
+/* coo_sort_unique(rows, cols, vals, nrows) -> (rows, cols, vals) sorted by (row, col); of entries with the same (row, col)
+ * the LAST in input order survives -- what repeated ll_mat assignments leave behind (SpMatrix_LLMatSetItem, ll_mat.c:250-356).
+ * A counting sort by row (stable), then every row's entries by column (stable insertion / merge sort: rows are short),
+ * rows split over threads. */
+typedef struct {
+  long r0, r1;
+  const npy_int64 *start; /* nrows + 1 */
+  npy_int64 *c;
+  double *v;
+  npy_int64 *tc;
+  double *tv;
+  long *keep; /* per row: entries kept */
+} CooRows;
+
+static void coo_merge_sort(npy_int64 *c, double *v, npy_int64 *tc, double *tv, long n) {
+  long w, i;
+  if (n <= 32) { /* insertion sort, stable */
+    for (i = 1; i < n; i++) {
+      npy_int64 kc = c[i];
+      double kv = v[i];
+      long j = i - 1;
+      while (j >= 0 && c[j] > kc) {
+        c[j + 1] = c[j];
+        v[j + 1] = v[j];
+        j--;
+      }
+      c[j + 1] = kc;
+      v[j + 1] = kv;
+    }
+    return;
+  }
+  for (w = 1; w < n; w *= 2) { /* bottom-up merge sort, stable */
+    for (i = 0; i < n; i += 2 * w) {
+      long a = i, am = i + w < n ? i + w : n, b = am, bm = i + 2 * w < n ? i + 2 * w : n, k = i;
+      while (a < am && b < bm) {
+        if (c[b] < c[a]) { tc[k] = c[b]; tv[k++] = v[b++]; }
+        else { tc[k] = c[a]; tv[k++] = v[a++]; }
+      }
+      while (a < am) { tc[k] = c[a]; tv[k++] = v[a++]; }
+      while (b < bm) { tc[k] = c[b]; tv[k++] = v[b++]; }
+    }
+    memcpy(c, tc, sizeof(npy_int64) * (size_t)n);
+    memcpy(v, tv, sizeof(double) * (size_t)n);
+  }
+}
+
+static void *coo_rows_worker(void *arg) {
+  CooRows *w = (CooRows *)arg;
+  long r;
+  for (r = w->r0; r < w->r1; r++) {
+    const long a = (long)w->start[r], n = (long)w->start[r + 1] - a;
+    npy_int64 *c = w->c + a;
+    double *v = w->v + a;
+    long i, k = 0;
+    if (n > 1) coo_merge_sort(c, v, w->tc + a, w->tv + a, n);
+    for (i = 0; i < n; i++) /* of equal columns the last one (= last in input order) stays */
+      if (i + 1 == n || c[i + 1] != c[i]) {
+        c[k] = c[i];
+        v[k++] = v[i];
+      }
+    w->keep[r] = k;
+  }
+  return NULL;
+}
+
+static PyObject *Coo_sort_unique(PyObject *module, PyObject *args) {
+  PyObject *orows, *ocols, *ovals;
+  PyArrayObject *rows = NULL, *cols = NULL, *vals = NULL, *R = NULL, *Cc = NULL, *V = NULL;
+  long nrows, nz, i, r, T, t, total;
+  npy_int64 *start = NULL, *fill = NULL, *c = NULL, *tc = NULL;
+  double *v = NULL, *tv = NULL;
+  long *keep = NULL;
+  const npy_int64 *ri, *ci;
+  const double *vi;
+  CooRows ws[64];
+  pthread_t th[64];
+  npy_intp dims[1];
+  int bad = 0;
+  if (!PyArg_ParseTuple(args, "OOOl", &orows, &ocols, &ovals, &nrows)) return NULL;
+  rows = (PyArrayObject *)PyArray_FROM_OTF(orows, NPY_INT64, NPY_ARRAY_IN_ARRAY);
+  cols = (PyArrayObject *)PyArray_FROM_OTF(ocols, NPY_INT64, NPY_ARRAY_IN_ARRAY);
+  vals = (PyArrayObject *)PyArray_FROM_OTF(ovals, NPY_DOUBLE, NPY_ARRAY_IN_ARRAY);
+  if (rows == NULL || cols == NULL || vals == NULL) goto fail;
+  nz = (long)PyArray_SIZE(rows);
+  if (PyArray_NDIM(rows) != 1 || PyArray_SIZE(cols) != nz || PyArray_SIZE(vals) != nz || nrows < 0) {
+    PyErr_SetString(PyExc_ValueError, "coo_sort_unique: rows, cols, vals must be 1-D arrays of one length");
+    goto fail;
+  }
+  ri = (const npy_int64 *)PyArray_DATA(rows);
+  ci = (const npy_int64 *)PyArray_DATA(cols);
+  vi = (const double *)PyArray_DATA(vals);
+  start = (npy_int64 *)calloc((size_t)nrows + 2, sizeof(npy_int64));
+  fill = (npy_int64 *)malloc(sizeof(npy_int64) * ((size_t)nrows + 1));
+  c = (npy_int64 *)malloc(sizeof(npy_int64) * (size_t)(nz ? nz : 1));
+  tc = (npy_int64 *)malloc(sizeof(npy_int64) * (size_t)(nz ? nz : 1));
+  v = (double *)malloc(sizeof(double) * (size_t)(nz ? nz : 1));
+  tv = (double *)malloc(sizeof(double) * (size_t)(nz ? nz : 1));
+  keep = (long *)calloc((size_t)nrows + 1, sizeof(long));
+  if (!start || !fill || !c || !tc || !v || !tv || !keep) {
+    PyErr_NoMemory();
+    goto fail;
+  }
+  Py_BEGIN_ALLOW_THREADS
+  for (i = 0; i < nz; i++) {
+    if (ri[i] < 0 || ri[i] >= nrows) { bad = 1; break; }
+    start[ri[i] + 1]++;
+  }
+  if (!bad) {
+    for (r = 0; r < nrows; r++) start[r + 1] += start[r];
+    memcpy(fill, start, sizeof(npy_int64) * (size_t)nrows);
+    for (i = 0; i < nz; i++) { /* stable: input order inside a row */
+      const npy_int64 k = fill[ri[i]]++;
+      c[k] = ci[i];
+      v[k] = vi[i];
+    }
+    T = sysconf(_SC_NPROCESSORS_ONLN);
+    if (T > 8) T = 8;
+    if (T < 1 || nz < (1 << 16)) T = 1;
+    for (t = 0; t < T; t++) { /* rows split by entry count */
+      ws[t].start = start;
+      ws[t].c = c;
+      ws[t].v = v;
+      ws[t].tc = tc;
+      ws[t].tv = tv;
+      ws[t].keep = keep;
+    }
+    {
+      long rr = 0;
+      for (t = 0; t < T; t++) {
+        const long want = (long)((double)nz * (t + 1) / T);
+        ws[t].r0 = rr;
+        while (rr < nrows && (t == T - 1 || (long)start[rr + 1] <= want)) rr++;
+        ws[t].r1 = rr;
+      }
+    }
+    for (t = 1; t < T; t++)
+      if (pthread_create(&th[t], NULL, coo_rows_worker, &ws[t]) != 0) {
+        coo_rows_worker(&ws[t]);
+        th[t] = 0;
+      }
+    coo_rows_worker(&ws[0]);
+    for (t = 1; t < T; t++)
+      if (th[t]) pthread_join(th[t], NULL);
+  }
+  Py_END_ALLOW_THREADS
+  if (bad) {
+    PyErr_SetString(PyExc_IndexError, "indices out of range");
+    goto fail;
+  }
+  total = 0;
+  for (r = 0; r < nrows; r++) total += keep[r];
+  dims[0] = (npy_intp)total;
+  R = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_INT64);
+  Cc = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_INT64);
+  V = (PyArrayObject *)PyArray_SimpleNew(1, dims, NPY_DOUBLE);
+  if (R == NULL || Cc == NULL || V == NULL) goto fail;
+  {
+    npy_int64 *ro = (npy_int64 *)PyArray_DATA(R), *co = (npy_int64 *)PyArray_DATA(Cc);
+    double *vo = (double *)PyArray_DATA(V);
+    long k = 0;
+    for (r = 0; r < nrows; r++) {
+      const long a = (long)start[r];
+      for (i = 0; i < keep[r]; i++, k++) {
+        ro[k] = r;
+        co[k] = c[a + i];
+        vo[k] = v[a + i];
+      }
+    }
+  }
+  free(start); free(fill); free(c); free(tc); free(v); free(tv); free(keep);
+  Py_DECREF(rows);
+  Py_DECREF(cols);
+  Py_DECREF(vals);
+  return Py_BuildValue("NNN", (PyObject *)R, (PyObject *)Cc, (PyObject *)V);
+fail:
+  free(start); free(fill); free(c); free(tc); free(v); free(tv); free(keep);
+  Py_XDECREF(rows);
+  Py_XDECREF(cols);
+  Py_XDECREF(vals);
+  Py_XDECREF(R);
+  Py_XDECREF(Cc);
+  Py_XDECREF(V);
+  return NULL;
+}
+
 /* csr_from_arrays(indptr, indices, data, shape): scalable constructor without an ll_mat */
 /* devices=[...] of poisson_csr / csr_from_arrays: a sequence of device ordinals (one rank per entry; may repeat).
  * Returns the count (0: None / absent -> single device), -1 with an exception set. */
@@ -1350,6 +1761,11 @@ static PyMethodDef spmatrix_methods[] = {
     {"ll_mat", LLMat_zeros, METH_VARARGS, "ll_mat(n, m, sizeHint=1000, storeZeros=0): empty n x m linked-list matrix"},
     {"ll_mat_sym", LLMat_sym_zeros, METH_VARARGS, "ll_mat_sym(n, sizeHint=1000, storeZeros=0): empty symmetric matrix"},
     {"ll_mat_from_mtx", LLMat_from_mtx, METH_VARARGS, "ll_mat_from_mtx(fileName): read a MatrixMarket coordinate file"},
+    {"coo_sort_unique", Coo_sort_unique, METH_VARARGS,
+     "coo_sort_unique(rows, cols, vals, nrows) -> (rows, cols, vals) sorted by (row, col); a repeated (row, col) keeps its last value"},
+    {"mtx_read_coordinate", Mtx_read_coordinate, METH_VARARGS,
+     "mtx_read_coordinate(fileName, threads=0) -> (m, n, symmetric, rows, cols, vals): the entries of a coordinate MatrixMarket "
+     "file in file order (0-based int64 / float64), parsed in parallel"},
     {"csr_from_arrays", (PyCFunction)(void (*)(void))CSR_from_arrays, METH_VARARGS | METH_KEYWORDS,
      "csr_from_arrays(indptr, indices, data, shape[, keep_host, devices=[...]]) -> csr_mat (devices: row blocks on several GPUs)"},
     {"sss_from_arrays", SSS_from_arrays, METH_VARARGS, "sss_from_arrays(indptr, indices, data, diag) -> sss_mat"},

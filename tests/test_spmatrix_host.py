@@ -380,3 +380,67 @@ def test_mtx_direct_ingest_equals_ll_mat_route(tmp_path):
         f.write("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
     with pytest.raises(Exception):
         mtx.read_mtx(str(tmp_path / "c.mtx"))
+
+
+def test_native_mtx_reader_equals_the_python_parse(tmp_path):
+    """spmatrix.mtx_read_coordinate (native, threaded; what tools.mtx builds csr_mat / sss_mat from) against a plain
+    Python parse of the same file: number formats (exponents, signs, leading blanks, integers), CRLF line ends, blank and
+    comment lines, a file large enough for several parser threads, every thread count; and spmatrix.coo_sort_unique against
+    a stable NumPy sort (duplicates keep their last value, ll_mat.c:250-356)."""
+    from pysparse_amd.sparse import spmatrix
+    from pysparse_amd.tools import mtx
+    rng = np.random.default_rng(7)
+    n, nz = 5000, 60000
+    i = rng.integers(1, n + 1, size=nz)
+    j = rng.integers(1, n + 1, size=nz)
+    v = rng.standard_normal(nz) * 10.0 ** rng.integers(-300, 300, size=nz)
+    fmts = ["%d %d %.17g", "  %d\t%d   %+.16e", "%d %d %.3f", "%d %d %d"]
+    p = tmp_path / "a.mtx"
+    with open(p, "w", newline="") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\r\n% a comment\n%another\n\n" + "%d %d %d\n" % (n, n, nz))
+        for k in range(nz):
+            fmt = fmts[k % 4]
+            val = int(v[k] % 1000) if fmt.endswith("%d") else v[k]
+            f.write(fmt % (i[k], j[k], val) + ("\r\n" if k % 7 == 0 else "\n"))
+            if k % 5000 == 0:
+                f.write("\n% comment in the data\n")
+    ref = mtx._read_mtx_python(str(p))
+    for threads in (0, 1, 2, 3, 8, 64):
+        m_, n_, sym, ri, ci, va = spmatrix.mtx_read_coordinate(str(p), threads)
+        assert (m_, n_, bool(sym)) == (ref[0], ref[1], ref[5])
+        assert ri.dtype == np.int64 and ci.dtype == np.int64 and va.dtype == np.float64
+        assert np.array_equal(ri, ref[2]) and np.array_equal(ci, ref[3]) and np.array_equal(va, ref[4])
+    got = mtx.read_mtx(str(p))
+    assert all(np.array_equal(a, b) for a, b in zip(got[2:5], ref[2:5]))
+    # sort + last-wins duplicates
+    a = spmatrix.coo_sort_unique(ref[2], ref[3], ref[4], n)
+    b = mtx._sorted_unique_numpy(ref[2], ref[3], ref[4], n)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].size < nz  # 60000 draws from 25e6 cells: some repeat
+    dup = spmatrix.coo_sort_unique(np.array([2, 0, 2, 2]), np.array([1, 0, 1, 0]), np.array([1.0, 2.0, 3.0, 4.0]), 3)
+    assert dup[0].tolist() == [0, 2, 2] and dup[1].tolist() == [0, 0, 1] and dup[2].tolist() == [2.0, 4.0, 3.0]
+    with pytest.raises(IndexError):
+        spmatrix.coo_sort_unique(np.array([3]), np.array([0]), np.array([1.0]), 3)
+    # symmetric banner, integer field
+    q = tmp_path / "s.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate integer symmetric\n3 3 2\n2 1 5\n3 3 -7\n")
+    m_, n_, sym, ri, ci, va = spmatrix.mtx_read_coordinate(str(q))
+    assert (m_, n_, bool(sym)) == (3, 3, True) and ri.tolist() == [1, 2] and ci.tolist() == [0, 2] and va.tolist() == [5.0, -7.0]
+    # errors: entry count, index range, malformed line, banner
+    bad = tmp_path / "b.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 1.0\n2 2 2.0\n")
+    with pytest.raises(spmatrix.error):
+        spmatrix.mtx_read_coordinate(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 1\n4 1 1.0\n")
+    with pytest.raises(IndexError):
+        spmatrix.mtx_read_coordinate(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 1\n1 x 1.0\n")
+    with pytest.raises(IOError):
+        spmatrix.mtx_read_coordinate(str(bad))
+    bad.write_text("%%MatrixMarket matrix array real general\n3 3\n1.0\n")
+    with pytest.raises(spmatrix.error):
+        spmatrix.mtx_read_coordinate(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate complex general\n3 3 1\n1 1 1.0 0.0\n")
+    with pytest.raises(spmatrix.error):
+        spmatrix.mtx_read_coordinate(str(bad))
+    with pytest.raises(IOError):
+        spmatrix.mtx_read_coordinate(str(tmp_path / "missing.mtx"))
