@@ -743,6 +743,19 @@ __global__ __launch_bounds__(256) void brick_pack_kernel(int n, const unsigned c
   dar[u] = da[rowmap ? rowmap[u] : u];
 }
 
+// the first forward Gauss-Seidel sweep of an application starts from y = 0 (preconmodule.c:164-165), so its G is b itself
+// (b - 0.0 is b, bit for bit): the pass that brings b into position order writes (G, diagonal) along with it, and neither
+// the whole-chip pass that forms G nor the clearing of y is needed for that sweep
+__global__ __launch_bounds__(256) void brick_first_gd_kernel(int n, const int *__restrict__ pos2row,
+                                                             const double *__restrict__ b, const double *__restrict__ dar,
+                                                             double *__restrict__ bp, double2 *__restrict__ gd) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double bt = b[pos2row[t]];
+  bp[t] = bt;
+  gd[t] = make_double2(bt - 0.0, dar[t]);
+}
+
 template <bool MINUS, bool BACK, int W, int D>
 __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, const int4 *__restrict__ info,
                                                           const int4 *__restrict__ pred, const int2 *__restrict__ ticks,
@@ -1109,8 +1122,9 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
       const psp_ssor::BrickSet &bs = forward ? K->brick_f : K->brick_b;
       const int n = K->n, nwg = std::min(bs.nbricks, 256);
       (void)hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)bs.nbricks + 3), st);
-      hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((n + 255) / 256), dim3(256), 0, st, 0, n, 0, rowmap, K->bp, K->xp,
-                         K->temp, K->da, K->omega, first, bs.dar, bs.gd, bs.flags + bs.nbricks + 2);
+      if (!(KIND == 0 && first))  // (the application's first Gauss-Seidel sweep got its G from brick_first_gd_kernel)
+        hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((n + 255) / 256), dim3(256), 0, st, 0, n, 0, rowmap, K->bp, K->xp,
+                           K->temp, K->da, K->omega, first, bs.dar, bs.gd, bs.flags + bs.nbricks + 2);
       if (forward)
         hipLaunchKernelGGL((ssor_brick_kernel<(KIND >= 2), false, W, run_depth<W>()>), dim3(nwg), dim3(kBrickTick), 0, st,
                            bs.nbricks, bs.info, bs.pred, bs.ticks, bs.halo_pos, n, rowmap, bs.vp, bs.dpk, bs.gd, K->xp,
@@ -1188,7 +1202,7 @@ static void enqueue_sweeps(const psp_ssor *K, hipStream_t st) {
   const bool gs = K->omega == 1.0;
   for (int step = 0; step < K->steps; ++step) {
     if (gs) {
-      sweep<0>(K, st, true, 0);
+      sweep<0>(K, st, true, (K->brick_mode && step == 0) ? 1 : 0);
       sweep<1>(K, st, false, 0);
     } else {
       sweep<2>(K, st, true, step == 0 ? 1 : 0);
@@ -1232,8 +1246,15 @@ static void ensure_graph(psp_ssor *K) {
 
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
   if (K->steps <= 0) return PSP_OK;  // the reference leaves y untouched
-  PSP_TRY(reorder_gather(K->n, K->pos2row, b, K->bp, nullptr));  // bp[t] = b[pos2row[t]]
-  if (K->omega == 1.0) PSP_HIP(hipMemsetAsync(K->temp, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
+  if (K->brick_mode && K->omega == 1.0) {
+    // bp[t] = b[pos2row[t]] and the first sweep's (G, diagonal) in one pass; y need not be cleared (every row of the
+    // first sweep writes its y before anything reads it)
+    hipLaunchKernelGGL(brick_first_gd_kernel, dim3((K->n + 255) / 256), dim3(256), 0, stream(), K->n, K->pos2row, b,
+                       K->brick_f.dar, K->bp, K->brick_f.gd);
+  } else {
+    PSP_TRY(reorder_gather(K->n, K->pos2row, b, K->bp, nullptr));  // bp[t] = b[pos2row[t]]
+    if (K->omega == 1.0) PSP_HIP(hipMemsetAsync(K->temp, 0, sizeof(double) * (size_t)K->n, stream()));  // :164-165
+  }
   ensure_graph(K);
   if (K->graph_state == 1 && hipGraphLaunch(K->exec, stream()) != hipSuccess) {
     (void)hipGetLastError();
