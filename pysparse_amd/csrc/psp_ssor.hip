@@ -105,6 +105,11 @@ struct psp_ssor {
                                // [nbricks + 2]: scratch word of run_pre_kernel
   } brick_f, brick_b;
   bool brick_mode = false;
+  // a brick sweep that gave up waiting for a predecessor (bounded spins: never seen, but then the result is wrong) leaves
+  // a word behind; it is copied to pinned memory behind every application and looked at by the next call on this handle
+  int *brick_err_host = nullptr;
+  hipEvent_t brick_ev = nullptr;
+  bool brick_ev_pending = false;
   // PSP_DEVICE=cpu (psp_cpu.hip): the reference's two sequential sweeps on the host arrays of S; two n-vectors of work
   bool host = false;
   std::vector<double> h_temp, h_temp2;
@@ -756,6 +761,14 @@ __global__ __launch_bounds__(256) void brick_first_gd_kernel(int n, const int *_
   gd[t] = make_double2(bt - 0.0, dar[t]);
 }
 
+// clears a sweep's flags (done words, hand-out counter, error word).  A kernel, not a memset: inside the captured graph
+// of an application a memset node was not ordered before the brick kernel behind it on every HIP runtime (the one PyTorch
+// brings along replayed them concurrently: a second application then found its predecessors "done" from the first)
+__global__ __launch_bounds__(256) void brick_begin_kernel(int count, int *__restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) flags[i] = 0;
+}
+
 template <bool MINUS, bool BACK, int W, int D>
 __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, const int4 *__restrict__ info,
                                                           const int4 *__restrict__ pred, const int2 *__restrict__ ticks,
@@ -1121,7 +1134,8 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
     if (K->brick_mode) {  // a 3-D grid operator with wide levels: bricks of 32^3 points, a coarse wavefront of workgroups
       const psp_ssor::BrickSet &bs = forward ? K->brick_f : K->brick_b;
       const int n = K->n, nwg = std::min(bs.nbricks, 256);
-      (void)hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)bs.nbricks + 3), st);
+      hipLaunchKernelGGL(brick_begin_kernel, dim3((bs.nbricks + 3 + 255) / 256), dim3(256), 0, st, bs.nbricks + 3,
+                         bs.flags);
       if (!(KIND == 0 && first))  // (the application's first Gauss-Seidel sweep got its G from brick_first_gd_kernel)
         hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((n + 255) / 256), dim3(256), 0, st, 0, n, 0, rowmap, K->bp, K->xp,
                            K->temp, K->da, K->omega, first, bs.dar, bs.gd, bs.flags + bs.nbricks + 2);
@@ -1244,8 +1258,23 @@ static void ensure_graph(psp_ssor *K) {
   K->graph_state = 1;
 }
 
+static int brick_error_check(psp_ssor *K, bool wait) {
+  if (!K->brick_mode || !K->brick_ev_pending) return PSP_OK;
+  const hipError_t e = wait ? hipEventSynchronize(K->brick_ev) : hipEventQuery(K->brick_ev);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    return PSP_OK;
+  }
+  K->brick_ev_pending = false;
+  if (e != hipSuccess) return fail(PSP_ENODEV, "ssor: %s", hipGetErrorString(e));
+  if (K->brick_err_host[0] | K->brick_err_host[1])
+    return fail(PSP_ENODEV, "ssor: a brick sweep gave up waiting for its predecessors; the preconditioned vector is invalid");
+  return PSP_OK;
+}
+
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
   if (K->steps <= 0) return PSP_OK;  // the reference leaves y untouched
+  PSP_TRY(brick_error_check(K, false));
   if (K->brick_mode && K->omega == 1.0) {
     // bp[t] = b[pos2row[t]] and the first sweep's (G, diagonal) in one pass; y need not be cleared (every row of the
     // first sweep writes its y before anything reads it)
@@ -1264,8 +1293,17 @@ int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
     enqueue_sweeps(K, stream());
     PSP_LAUNCH_CHECK();
   }
+  if (K->brick_mode && K->brick_err_host && K->brick_ev) {
+    (void)hipMemcpyAsync(K->brick_err_host, K->brick_f.flags + K->brick_f.nbricks + 1, sizeof(int), hipMemcpyDeviceToHost,
+                         stream());
+    (void)hipMemcpyAsync(K->brick_err_host + 1, K->brick_b.flags + K->brick_b.nbricks + 1, sizeof(int),
+                         hipMemcpyDeviceToHost, stream());
+    K->brick_ev_pending = hipEventRecord(K->brick_ev, stream()) == hipSuccess;
+  }
   return reorder_gather(K->n, K->row2pos, K->xp, x, nullptr);  // x[i] = xp[row2pos[i]]
 }
+
+int ssor_error_check(psp_ssor *K) { return brick_error_check(K, true); }
 
 }  // namespace psp
 
@@ -1834,6 +1872,8 @@ int ssor_apply_host(psp_ssor *K, const double *b, double *x) {
 }
 }  // namespace psp
 
+static int ssor_create_device(psp_sss_t *S, double omega, int steps, bool allow_bricks, psp_ssor_t **out);
+
 extern "C" {
 
 int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
@@ -1855,6 +1895,12 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     return PSP_OK;
   }
   PSP_TRY(ensure_device());
+  return ssor_create_device(S, omega, steps, true, out);
+}
+
+// (allow_bricks = false: the retry after the brick arrays of a grid operator could not be built -- bricks are an
+// optimisation, the handle must not fail because of them)
+static int ssor_create_device(psp_sss_t *S, double omega, int steps, bool allow_bricks, psp_ssor_t **out) {
   psp_ssor *K = new psp_ssor();
   K->n = S->n;
   K->omega = omega;
@@ -1867,7 +1913,8 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     if (rc == PSP_OK) rc = build_schedule(S->full, 1, &rows_b, &K->ptr_b, &lev_b);
     BrickPlan plan_f, plan_b;
     GridShape shape;
-    if (rc == PSP_OK && bricks_wanted(K->ptr_f) && detect_grid(S, &shape) && plan_bricks(S, shape, 0, lev_f, &plan_f) &&
+    if (rc == PSP_OK && allow_bricks && bricks_wanted(K->ptr_f) && detect_grid(S, &shape) &&
+        plan_bricks(S, shape, 0, lev_f, &plan_f) &&
         plan_bricks(S, shape, 1, lev_b, &plan_b)) {
       // both directions are feasible: the slot orders become (brick, level, row)
       std::swap(rows_f, plan_f.rows);
@@ -1886,6 +1933,23 @@ int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
     if (rc == PSP_OK && K->brick_mode) {
       rc = finish_bricks(K, 0, plan_f);
       if (rc == PSP_OK) rc = finish_bricks(K, 1, plan_b);
+      if (rc != PSP_OK) {  // the slot orders are the bricks' by now: start over on the level schedule
+        (void)hipGetLastError();
+        psp_ssor_destroy(K);
+        (void)psp_trim();
+        return ssor_create_device(S, omega, steps, false, out);
+      }
+    }
+    if (rc == PSP_OK && K->brick_mode) {
+      if (hipHostMalloc((void **)&K->brick_err_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&K->brick_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();  // no error report then; the sweeps themselves do not need it
+        if (K->brick_err_host) (void)hipHostFree(K->brick_err_host);
+        K->brick_err_host = nullptr;
+        K->brick_ev = nullptr;
+      } else {
+        K->brick_err_host[0] = K->brick_err_host[1] = 0;
+      }
     }
     if (rc == PSP_OK) {
       const size_t bf = sizeof(int) * K->ptr_f.size(), bb = sizeof(int) * K->ptr_b.size();
@@ -1924,6 +1988,8 @@ int psp_ssor_destroy(psp_ssor_t *K) {
                   (void *)K->run_b.ticks, (void *)K->run_b.vp,
                   (void *)K->run_progress})
     (void)hipFree(p);
+  if (K->brick_ev) (void)hipEventDestroy(K->brick_ev);
+  if (K->brick_err_host) (void)hipHostFree(K->brick_err_host);
   for (psp_ssor::BrickSet *b : {&K->brick_f, &K->brick_b})
     for (void *p : {(void *)b->ticks, (void *)b->info, (void *)b->pred, (void *)b->halo_pos, (void *)b->dpk, (void *)b->vp,
                     (void *)b->dar, (void *)b->gd, (void *)b->flags})
@@ -1991,7 +2057,7 @@ int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host) {
   (void)hipFree(y);
   if (rc != PSP_OK) return rc;
   if (e != hipSuccess) return fail(PSP_ENODEV, "psp_ssor_precon: %s", hipGetErrorString(e));
-  return PSP_OK;
+  return psp::ssor_error_check(K);
 }
 
 }  // extern "C"
