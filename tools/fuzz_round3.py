@@ -18,6 +18,8 @@ from pysparse_amd import device as dev  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--count", type=int, default=40)
+ap.add_argument("--ssor-only", action="store_true")
+ap.add_argument("--bricks", action="store_true", help="3-D grids with levels wider than a run only: the brick sweeps")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 
@@ -34,12 +36,14 @@ def grid_sss(nx, ny, nz, keep):
 
 bad = 0
 for t in range(a.count):
-    if rng.random() < 0.5:
+    if a.bricks:
+        nx, ny, nz = (int(v) for v in rng.integers(70, 230, size=3))
+    elif rng.random() < 0.5:
         nx, ny, nz = int(rng.integers(50, 2600)), int(rng.integers(3, 700)), 0
         if nx * ny > 2_000_000:
             ny = max(3, 2_000_000 // nx)
     else:
-        nx, ny, nz = (int(v) for v in rng.integers(8, 140, size=3))
+        nx, ny, nz = (int(v) for v in rng.integers(8, 200, size=3))
     keep = float(rng.choice([1.0, 1.0, 0.9995, 0.99, 0.85]))
     omega = float(rng.choice([1.0, 1.0, 1.3, 0.75]))
     steps = int(rng.choice([1, 1, 2, 3]))
@@ -51,11 +55,13 @@ for t in range(a.count):
     O.ssor_apply(S, x, y_ref, omega, steps)
     K.precon(x, y)
     ok = np.array_equal(y, y_ref)
-    print("ssor grid %s keep %.4f omega %.2f steps %d levels %s lds_runs %s %s" % (
-        (nx, ny, nz), keep, omega, steps, K.levels, K.lds_runs, "ok" if ok else "MISMATCH"), flush=True)
+    K.precon(x, y)  # the replayed graph
+    ok = ok and np.array_equal(y, y_ref)
+    print("ssor grid %s keep %.4f omega %.2f steps %d levels %s lds_runs %s bricks %d %s" % (
+        (nx, ny, nz), keep, omega, steps, K.levels, K.lds_runs, K.bricks, "ok" if ok else "MISMATCH"), flush=True)
     bad += not ok
     del K, D
-for t in range(a.count):
+for t in range(0 if a.ssor_only else a.count):
     n = int(rng.integers(600, 60000))
     no = int(rng.integers(33, 65))
     span = int(rng.choice([40, 400, n // 2]))
