@@ -18,7 +18,11 @@
 //     over the upper entries guarantees the x[i] it reads are final.
 // One small kernel per level (a 512^3 grid has 1534 levels in each direction).  Round 2: the triangle,
 // the diagonal and the vectors are kept in LEVEL ORDER (struct psp_ssor), so a level sweep streams, and
-// the launches of one application are replayed from a hipGraph; see DESIGN.md.
+// the launches of one application are replayed from a hipGraph; see DESIGN.md.  Round 3: runs of narrow
+// levels (2-D operators, the thin ends of 3-D ones) are walked by ONE workgroup that hands x from level to
+// level through an LDS ring (ssor_run_kernel), and 3-D grid operators with wide levels are swept in bricks
+// of 32^3 points, a coarse wavefront of workgroups (ssor_brick_kernel); the per-level launches remain for
+// everything else (rows with more than 8 entries per sweep, dependencies that reach too far back).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
