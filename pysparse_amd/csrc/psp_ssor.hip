@@ -713,21 +713,50 @@ __global__ __launch_bounds__(256) void brick_check_kernel(int n, int dir, const 
   }
 }
 
-// per slot: the 16-bit codes of its entries, its value pairs, its diagonal; outside dependencies get a halo entry each
+// number of a slot's dependencies outside its brick (ext[n] = 0: the scan's last element)
+template <int W>
+__global__ __launch_bounds__(256) void brick_extcnt_kernel(int n, const unsigned char *__restrict__ cnt8,
+                                                           const int *__restrict__ pos, const int *__restrict__ slot_of,
+                                                           int nb, const int *__restrict__ brick_start,
+                                                           int *__restrict__ ext) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u > n) return;
+  if (u == n) {
+    ext[n] = 0;
+    return;
+  }
+  const int b = brick_of_slot(u, nb, brick_start);
+  const int bs = brick_start[b], be = brick_start[b + 1];
+  const int cnt = cnt8[u];
+  int c = 0;
+  for (int s = 0; s < W; ++s)
+    if (s < cnt) {
+      const int p = pos[(size_t)s * n + u];
+      const int q = slot_of ? slot_of[p] : p;
+      c += !(q >= bs && q < be);
+    }
+  ext[u] = c;
+}
+
+// per slot: the 16-bit codes of its entries, its value pairs, its diagonal; outside dependencies get a halo entry each,
+// numbered in slot order inside the brick (eoff = exclusive scan of brick_extcnt_kernel's counts): the entries a tick
+// needs are then a contiguous range of the brick's halo
 template <int W>
 __global__ __launch_bounds__(256) void brick_pack_kernel(int n, const unsigned char *__restrict__ cnt8,
                                                          const int *__restrict__ pos, const double *__restrict__ val,
                                                          const int *__restrict__ slot_of, const int *__restrict__ rowmap,
                                                          const double *__restrict__ da, int nb,
                                                          const int *__restrict__ brick_start,
-                                                         const int *__restrict__ halo_base, int *__restrict__ halo_fill,
-                                                         int *__restrict__ halo_pos, unsigned *__restrict__ dpk,
-                                                         double2 *__restrict__ vp, double *__restrict__ dar) {
+                                                         const int *__restrict__ eoff, int *__restrict__ halo_pos,
+                                                         unsigned *__restrict__ dpk, double2 *__restrict__ vp,
+                                                         double *__restrict__ dar) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const int b = brick_of_slot(u, nb, brick_start);
   const int bs = brick_start[b], be = brick_start[b + 1];
   const int cnt = cnt8[u];
+  int h = eoff[u] - eoff[bs];
+  int hg = eoff[u];
   unsigned w[(W + 1) / 2] = {};
   double v[2 * ((W + 1) / 2)] = {};
   for (int s = 0; s < W; ++s)
@@ -738,9 +767,8 @@ __global__ __launch_bounds__(256) void brick_pack_kernel(int n, const unsigned c
       if (q >= bs && q < be) {
         code = (unsigned)(u - q);
       } else {
-        const int h = atomicAdd(halo_fill + b, 1);
-        halo_pos[halo_base[b] + h] = p;
-        code = 0x8000u | (unsigned)h;
+        halo_pos[hg++] = p;
+        code = 0x8000u | (unsigned)h++;
       }
       w[s >> 1] |= code << ((s & 1) * 16);
       v[s] = val[(size_t)s * n + u];
@@ -1732,7 +1760,8 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
   const double *val = dir ? K->b_val : K->f_val;
   const unsigned char *c8 = dir ? K->bc8 : K->fc8;
   const int *rowmap = dir ? K->b_row : nullptr;
-  int *slot_of = nullptr, *d_bstart = nullptr, *d_hbase = nullptr, *d_hfill = nullptr;
+  int *slot_of = nullptr, *d_bstart = nullptr, *d_ext = nullptr, *d_eoff = nullptr;
+  void *scan_tmp = nullptr;
   int rc = PSP_OK;
   bs.nbricks = nb;
   const int nhalo = P.halo_base[(size_t)nb];
@@ -1746,8 +1775,8 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
             hipMalloc((void **)&bs.gd, sizeof(double2) * (size_t)n) == hipSuccess &&
             hipMalloc((void **)&bs.flags, sizeof(int) * ((size_t)nb + 3)) == hipSuccess &&
             hipMalloc((void **)&d_bstart, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
-            hipMalloc((void **)&d_hbase, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
-            hipMalloc((void **)&d_hfill, sizeof(int) * (size_t)nb) == hipSuccess &&
+            hipMalloc((void **)&d_ext, sizeof(int) * ((size_t)n + 1)) == hipSuccess &&
+            hipMalloc((void **)&d_eoff, sizeof(int) * ((size_t)n + 1)) == hipSuccess &&
             (!dir || hipMalloc((void **)&slot_of, sizeof(int) * (size_t)n) == hipSuccess);
   ok = ok &&
        hipMemcpyAsync(bs.ticks, P.ticks.data(), sizeof(int2) * P.ticks.size(), hipMemcpyHostToDevice, stream()) ==
@@ -1756,23 +1785,29 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
        hipMemcpyAsync(bs.pred, P.pred.data(), sizeof(int4) * (size_t)nb, hipMemcpyHostToDevice, stream()) == hipSuccess &&
        hipMemcpyAsync(d_bstart, P.brick_start.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, stream()) ==
            hipSuccess &&
-       hipMemcpyAsync(d_hbase, P.halo_base.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, stream()) ==
-           hipSuccess &&
-       hipMemsetAsync(d_hfill, 0, sizeof(int) * (size_t)nb, stream()) == hipSuccess &&
        hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)nb + 3), stream()) == hipSuccess;
   if (ok) {
     if (dir)
       hipLaunchKernelGGL(invert_perm_kernel, dim3(std::min((n + 255) / 256, 65536)), dim3(256), 0, stream(), n, K->b_row,
                          slot_of);
+    hipLaunchKernelGGL(brick_extcnt_kernel<W>, dim3((n + 256) / 256), dim3(256), 0, stream(), n, c8, pos, slot_of, nb,
+                       d_bstart, d_ext);
+    size_t bytes = 0;
+    ok = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_ext, d_eoff, n + 1, stream()) == hipSuccess &&
+         hipMalloc(&scan_tmp, bytes ? bytes : 1) == hipSuccess &&
+         hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, d_ext, d_eoff, n + 1, stream()) == hipSuccess;
+  }
+  if (ok) {
     hipLaunchKernelGGL(brick_pack_kernel<W>, dim3((n + 255) / 256), dim3(256), 0, stream(), n, c8, pos, val, slot_of,
-                       rowmap, K->da, nb, d_bstart, d_hbase, d_hfill, bs.halo_pos, bs.dpk, bs.vp, bs.dar);
+                       rowmap, K->da, nb, d_bstart, d_eoff, bs.halo_pos, bs.dpk, bs.vp, bs.dar);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream()) == hipSuccess;
   }
   if (!ok) rc = fail(PSP_ENOMEM, "ssor: the brick schedule could not be built");
   (void)hipFree(slot_of);
   (void)hipFree(d_bstart);
-  (void)hipFree(d_hbase);
-  (void)hipFree(d_hfill);
+  (void)hipFree(d_ext);
+  (void)hipFree(d_eoff);
+  (void)hipFree(scan_tmp);
   return rc;
 }
 
