@@ -105,10 +105,13 @@ struct psp_ssor {
     double2 *vp = nullptr;
     double *dar = nullptr;
     double2 *gd = nullptr;
+    int4 *tick_ext = nullptr;  // pipelined sweeps: per tick its range of the brick's halo (first, count) and, 10 bits per
+                               // predecessor, how many ticks of that predecessor must be complete before it is gathered
     int *flags = nullptr;      // [0 .. nbricks): done; [nbricks]: next brick to hand out; [nbricks + 1]: error;
                                // [nbricks + 2]: scratch word of run_pre_kernel
   } brick_f, brick_b;
   bool brick_mode = false;
+  bool brick_pipe = false;  // both directions have tick_ext: bricks start before their predecessors have finished
   // a brick sweep that gave up waiting for a predecessor (bounded spins: never seen, but then the result is wrong) leaves
   // a word behind; it is copied to pinned memory behind every application and looked at by the next call on this handle
   int *brick_err_host = nullptr;
@@ -627,6 +630,14 @@ __global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *
 constexpr int kBrickEdge = 32;
 constexpr int kBrickRing = 4096;   // LDS ring (doubles), 32 KiB
 constexpr int kBrickHalo = 4080;   // LDS halo (doubles): ring + halo + the hand-out word stay inside 64 KiB of static LDS
+// flag words of a sweep, one 128-byte line each (hundreds of workgroups poll them): [0] next brick to hand out,
+// [1] error, [2] scratch word of run_pre_kernel, [3 + b] brick b (done / ticks published)
+constexpr int kFlagStride = 32;
+__host__ __device__ constexpr size_t flag_words(int bricks) { return (size_t)(bricks + 3) * kFlagStride; }
+#define PSP_FLAG_NEXT(f) (f)
+#define PSP_FLAG_ERR(f) ((f) + kFlagStride)
+#define PSP_FLAG_SCRATCH(f) ((f) + 2 * kFlagStride)
+#define PSP_FLAG_BRICK(f, b) ((f) + (size_t)(3 + (b)) * kFlagStride)
 constexpr int kBrickTick = 768;    // threads of a brick's workgroup = the widest level of a 32^3 brick
 constexpr int kBrickMaxDist = kBrickRing - kBrickTick;
 
@@ -780,6 +791,66 @@ __global__ __launch_bounds__(256) void brick_pack_kernel(int n, const unsigned c
   dar[u] = da[rowmap ? rowmap[u] : u];
 }
 
+// ---- set-up of the pipelined brick sweeps: a slot's tick inside its brick, what a tick needs of the predecessors
+__global__ __launch_bounds__(256) void brick_ticklocal_kernel(int nticks, const int2 *__restrict__ ticks,
+                                                              const int *__restrict__ tick_brick,
+                                                              const int4 *__restrict__ info, int *__restrict__ ticklocal) {
+  const int g = blockIdx.x;
+  if (g >= nticks) return;
+  const int2 t = ticks[g];
+  const int local = g - info[tick_brick[g]].x;
+  for (int i = threadIdx.x; i < t.y; i += blockDim.x) ticklocal[t.x + i] = local;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void brick_need_kernel(int n, const unsigned char *__restrict__ cnt8,
+                                                         const int *__restrict__ pos, const int *__restrict__ slot_of,
+                                                         int nb, const int *__restrict__ brick_start,
+                                                         const int4 *__restrict__ info, const int4 *__restrict__ pred,
+                                                         const int *__restrict__ ticklocal, int *__restrict__ need,
+                                                         int *bad) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const int b = brick_of_slot(u, nb, brick_start);
+  const int bs = brick_start[b], be = brick_start[b + 1];
+  const int g = info[b].x + ticklocal[u];
+  const int4 pr = pred[b];
+  const int cnt = cnt8[u];
+  for (int s = 0; s < W; ++s)
+    if (s < cnt) {
+      const int p = pos[(size_t)s * n + u];
+      const int q = slot_of ? slot_of[p] : p;
+      if (q >= bs && q < be) continue;
+      const int bq = brick_of_slot(q, nb, brick_start);
+      const int k = bq == pr.x ? 0 : bq == pr.y ? 1 : bq == pr.z ? 2 : -1;
+      if (k < 0) {
+        atomicAdd(bad, 1);  // a dependency in a brick that is not a face neighbour
+        continue;
+      }
+      atomicMax(need + 3 * (size_t)g + k, ticklocal[q] + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void brick_tickext_kernel(int nticks, const int2 *__restrict__ ticks,
+                                                            const int *__restrict__ tick_brick,
+                                                            const int *__restrict__ brick_start,
+                                                            const int *__restrict__ eoff, const int *__restrict__ need,
+                                                            int4 *__restrict__ tick_ext, int *bad) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nticks) return;
+  const int2 t = ticks[g];
+  int4 e = make_int4(0, 0, 0, 0);
+  if (t.y > 0) {
+    const int bs = brick_start[tick_brick[g]];
+    e.x = eoff[t.x] - eoff[bs];
+    e.y = eoff[t.x + t.y] - eoff[t.x];
+    const int a = need[3 * (size_t)g], b = need[3 * (size_t)g + 1], c = need[3 * (size_t)g + 2];
+    if (a > 1023 || b > 1023 || c > 1023 || e.y > kBrickTick) atomicAdd(bad, 1);
+    e.z = a | (b << 10) | (c << 20);
+  }
+  tick_ext[g] = e;
+}
+
 // the first forward Gauss-Seidel sweep of an application starts from y = 0 (preconmodule.c:164-165), so its G is b itself
 // (b - 0.0 is b, bit for bit): the pass that brings b into position order writes (G, diagonal) along with it, and neither
 // the whole-chip pass that forms G nor the clearing of y is needed for that sweep
@@ -822,7 +893,7 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
     // this loop by lanes and let the other lanes run ahead through the barriers without thread 0
     if (wid == 0) {
       int nb_ = 0;
-      if (tid == 0) nb_ = atomicAdd(flags + nbricks, 1);
+      if (tid == 0) nb_ = atomicAdd(PSP_FLAG_NEXT(flags), 1);
       nb_ = __builtin_amdgcn_readfirstlane(nb_);
       if (tid == 0) next_s = nb_;
     }
@@ -868,11 +939,11 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
         int spins = 0;
         for (;;) {
           const int f = __builtin_amdgcn_readfirstlane(
-              __hip_atomic_load(flags + ps[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              __hip_atomic_load(PSP_FLAG_BRICK(flags, ps[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (f != 0) break;
           __builtin_amdgcn_s_sleep(2);
           const int err = __builtin_amdgcn_readfirstlane(
-              __hip_atomic_load(flags + nbricks + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              __hip_atomic_load(PSP_FLAG_ERR(flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (++spins > (1 << 22) || err) {  // gives up (seconds): every workgroup ends, the error word says so
             lost = true;
             break;
@@ -880,7 +951,7 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
         }
       }
       if (tid == 0) {
-        if (lost) __hip_atomic_store(flags + nbricks + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lost) __hip_atomic_store(PSP_FLAG_ERR(flags), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         next_s = lost ? -1 : b;
       }
     }
@@ -932,7 +1003,189 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
     // ---- done: this brick's x has left the CU before the flag says so
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(PSP_FLAG_BRICK(flags, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The same sweep with the bricks PIPELINED (PSP_SSOR_BRICK_PIPE, experimental): a brick does not wait for its three
+// predecessors to finish, only for each of them to be far enough ahead.  flags[b] = number of b's ticks whose x is
+// visible; a tick's halo entries are a contiguous range of the brick's halo (tick_ext), and they travel through a
+// pipeline of their own, D ticks per stage: [positions + a poll of the predecessors' progress] -> [wave 0 checks the poll
+// against what the tick needs and waits if a predecessor is behind; then the gathers] -> [LDS] -> the tick.  A brick
+// publishes tick t - D once every wave has seen its static data of tick t arrive (loads return in order: what was issued
+// before them, the stores of tick t - D, has then left the CU), so the wavefront of bricks is skewed by ~50 ticks
+// instead of a whole brick's 94+.
+template <bool MINUS, bool BACK, int W, int D>
+__global__ __launch_bounds__(kBrickTick) void ssor_brick_pipe_kernel(
+    int nbricks, const int4 *__restrict__ info, const int4 *__restrict__ pred, const int2 *__restrict__ ticks,
+    const int4 *__restrict__ tick_ext, const int *__restrict__ halo_pos, int m, const int *__restrict__ rowmap,
+    const double2 *__restrict__ vp, const unsigned *__restrict__ dpk, const double2 *__restrict__ gd, double *x, double *y,
+    double omega, int *flags) {
+  static_assert(3 * D <= kRunPad, "the tick tables' padding must cover the prefetch distance");
+  constexpr int DW = (W + 1) / 2;
+  constexpr int kOps = D * (2 * DW + 3 + (BACK ? 1 : 0));  // vector-memory operations every wave issues in D ticks
+  static_assert(kOps < 60, "vmcnt");
+  __shared__ double ring[kBrickRing];
+  __shared__ double halo[kBrickHalo];
+  __shared__ int next_s;
+  const int tid = threadIdx.x;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (;;) {
+    if (wid == 0) {
+      int nb_ = 0;
+      if (tid == 0) nb_ = atomicAdd(PSP_FLAG_NEXT(flags), 1);
+      nb_ = __builtin_amdgcn_readfirstlane(nb_);
+      if (tid == 0) next_s = nb_;
+    }
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(next_s);
+    if (b >= nbricks) return;
+    const int4 bi = info[b];
+    const int4 pr = pred[b];
+    const int ps[3] = {pr.x, pr.y, pr.z};
+    const int2 *tk = ticks + bi.x;
+    const int4 *te = tick_ext + bi.x;
+    const int nticks = bi.y, hb = bi.z;
+    // wave 0: wait until predecessor k has published at least `nd` ticks (bounded; gives up with the error word set)
+    auto wait_for = [&](int k, int nd, int have) {
+      int spins = 0;
+      while (have < nd) {
+        __builtin_amdgcn_s_sleep(1);
+        have = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(PSP_FLAG_BRICK(flags, ps[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (++spins > (1 << 22)) {
+          if (tid == 0) __hip_atomic_store(PSP_FLAG_ERR(flags), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    };
+    RunPre<W> pre[D];
+    int2 ti[D];
+    auto issue = [&](RunPre<W> &p, const int2 t2) {  // every lane loads (see ssor_run_kernel)
+      const int u = t2.x + min(tid, max(t2.y - 1, 0));
+      p.u = tid < t2.y ? u : -1;
+      if constexpr (BACK) p.t = rowmap[u]; else p.t = u;
+#pragma unroll
+      for (int s = 0; s < DW; ++s) p.v[s] = vp[(size_t)s * m + u];
+#pragma unroll
+      for (int s = 0; s < DW; ++s) p.dw[s] = dpk[(size_t)s * m + u];
+      p.gd = gd[u];
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      issue(pre[j], tk[j]);
+      ti[j] = tk[j + D];
+    }
+    // ---- the halo of the first 2 D ticks the plain way: wait for what they need, gather it
+    {
+      int n0 = 0, n1 = 0, n2 = 0, hcnt = 0;
+#pragma unroll
+      for (int t = 0; t < 2 * D; ++t) {
+        const int4 e = te[t];  // (the tables are padded with empty ticks)
+        n0 = max(n0, e.z & 1023);
+        n1 = max(n1, (e.z >> 10) & 1023);
+        n2 = max(n2, (e.z >> 20) & 1023);
+        hcnt = max(hcnt, e.x + e.y);
+      }
+      if (wid == 0) {
+        if (ps[0] >= 0 && n0) wait_for(0, n0, -1);
+        if (ps[1] >= 0 && n1) wait_for(1, n1, -1);
+        if (ps[2] >= 0 && n2) wait_for(2, n2, -1);
+      }
+      __syncthreads();
+      for (int h = tid; h < hcnt; h += kBrickTick)
+        halo[h] = __hip_atomic_load(x + halo_pos[hb + h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();  // (also lets the prologue's loads land, see ssor_run_kernel)
+    }
+    int4 teB[D], teC[D];
+    int hpB[D], hpC[D], pollB[D][3];
+    double xg[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      teB[j] = teC[j] = make_int4(0, 0, 0, 0);
+      hpB[j] = hpC[j] = halo_pos[hb];  // some valid position
+      pollB[j][0] = pollB[j][1] = pollB[j][2] = 0;
+      xg[j] = 0.0;
+    }
+    for (int k = 0; k < nticks; k += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int jm = (j + D - 1) % D, jn = (j + 1) % D;
+        // (1) the tick itself
+        const RunPre<W> p = pre[j];
+        const int2 tn = ti[j];
+        ti[j] = tk[k + j + 2 * D];
+        const int4 e2 = te[k + j + 2 * D];  // (requested here, used in (5): a scalar load's round trip off the chain)
+        double xs[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          const unsigned c = (p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu;
+          xs[s] = (c & 0x8000u) ? halo[c & 0x7fffu] : ring[(p.u - (int)c) & (kBrickRing - 1)];
+        }
+        // (2) the static data of tick k + j + D
+        issue(pre[j], tn);
+        if (p.u >= 0) {
+          double acc = 0.0;
+#pragma unroll
+          for (int s = 0; s < W; ++s) {
+            const unsigned c = (p.dw[s >> 1] >> ((s & 1) * 16)) & 0xffffu;
+            const double vs = (s & 1) ? p.v[s >> 1].y : p.v[s >> 1].x;
+            const double tt = MINUS ? acc - vs * xs[s] : acc + vs * xs[s];
+            acc = c ? tt : acc;
+          }
+          double xn, yn;
+          if constexpr (!MINUS) {
+            xn = (p.gd.x - acc) / p.gd.y;
+            yn = acc;
+          } else {
+            const double hi = omega * acc;
+            yn = hi;
+            xn = (p.gd.x + hi) / p.gd.y;
+          }
+          ring[p.u & (kBrickRing - 1)] = xn;
+          __hip_atomic_store(x + p.t, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          y[p.t] = yn;
+        }
+        // (3) the gathers of tick k + j + D - 1: its check was made before the previous barrier
+        xg[jm] = __hip_atomic_load(x + hpC[jm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (4) tick k + j + D: are its predecessors far enough?  (polled D ticks ago; wave 0 waits if not, the others at
+        // the barrier below)
+        if (wid == 0) {
+          const int z = __builtin_amdgcn_readfirstlane(teB[j].z);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int nd = (z >> (10 * q)) & 1023;
+            if (nd > 0 && ps[q] >= 0) wait_for(q, nd, __builtin_amdgcn_readfirstlane(pollB[j][q]));
+          }
+        }
+        teC[j] = teB[j];
+        hpC[j] = hpB[j];
+        // (5) tick k + j + 2 D: where its halo entries come from, and a poll of the predecessors
+        {
+          const int4 e = e2;
+          teB[j] = e;
+          hpB[j] = halo_pos[hb + e.x + min(tid, max(e.y - 1, 0))];
+          if (wid == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              pollB[j][q] = ps[q] >= 0 ? __hip_atomic_load(PSP_FLAG_BRICK(flags, ps[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          }
+        }
+        // (6) the halo entries of the next tick into LDS
+        if (tid < teC[jn].y) halo[teC[jn].x + tid] = xg[jn];
+        // (7) every wave: at most kOps vector-memory operations outstanding, i.e. the stores of tick k + j - D have left
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps));
+        lds_barrier();
+        // (8) ... so ticks 0 .. k + j - D are complete
+        if (tid == 0 && k + j >= D)
+          __hip_atomic_store(PSP_FLAG_BRICK(flags, b), min(k + j - D + 1, nticks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(PSP_FLAG_BRICK(flags, b), nticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1166,11 +1419,22 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
     if (K->brick_mode) {  // a 3-D grid operator with wide levels: bricks of 32^3 points, a coarse wavefront of workgroups
       const psp_ssor::BrickSet &bs = forward ? K->brick_f : K->brick_b;
       const int n = K->n, nwg = std::min(bs.nbricks, 256);
-      hipLaunchKernelGGL(brick_begin_kernel, dim3((bs.nbricks + 3 + 255) / 256), dim3(256), 0, st, bs.nbricks + 3,
-                         bs.flags);
+      hipLaunchKernelGGL(brick_begin_kernel, dim3((int)((flag_words(bs.nbricks) + 255) / 256)), dim3(256), 0, st,
+                         (int)flag_words(bs.nbricks), bs.flags);
       if (!(KIND == 0 && first))  // (the application's first Gauss-Seidel sweep got its G from brick_first_gd_kernel)
         hipLaunchKernelGGL(run_pre_kernel<KIND>, dim3((n + 255) / 256), dim3(256), 0, st, 0, n, 0, rowmap, K->bp, K->xp,
-                           K->temp, K->da, K->omega, first, bs.dar, bs.gd, bs.flags + bs.nbricks + 2);
+                           K->temp, K->da, K->omega, first, bs.dar, bs.gd, PSP_FLAG_SCRATCH(bs.flags));
+      if (K->brick_pipe) {
+        if (forward)
+          hipLaunchKernelGGL((ssor_brick_pipe_kernel<(KIND >= 2), false, W, 5>), dim3(nwg), dim3(kBrickTick), 0, st,
+                             bs.nbricks, bs.info, bs.pred, bs.ticks, bs.tick_ext, bs.halo_pos, n, rowmap, bs.vp, bs.dpk,
+                             bs.gd, K->xp, K->temp, K->omega, bs.flags);
+        else
+          hipLaunchKernelGGL((ssor_brick_pipe_kernel<(KIND >= 2), true, W, 5>), dim3(nwg), dim3(kBrickTick), 0, st,
+                             bs.nbricks, bs.info, bs.pred, bs.ticks, bs.tick_ext, bs.halo_pos, n, rowmap, bs.vp, bs.dpk,
+                             bs.gd, K->xp, K->temp, K->omega, bs.flags);
+        return;
+      }
       if (forward)
         hipLaunchKernelGGL((ssor_brick_kernel<(KIND >= 2), false, W, run_depth<W>()>), dim3(nwg), dim3(kBrickTick), 0, st,
                            bs.nbricks, bs.info, bs.pred, bs.ticks, bs.halo_pos, n, rowmap, bs.vp, bs.dpk, bs.gd, K->xp,
@@ -1326,9 +1590,9 @@ int ssor_apply_dev(psp_ssor *K, const double *b, double *x) {
     PSP_LAUNCH_CHECK();
   }
   if (K->brick_mode && K->brick_err_host && K->brick_ev) {
-    (void)hipMemcpyAsync(K->brick_err_host, K->brick_f.flags + K->brick_f.nbricks + 1, sizeof(int), hipMemcpyDeviceToHost,
+    (void)hipMemcpyAsync(K->brick_err_host, PSP_FLAG_ERR(K->brick_f.flags), sizeof(int), hipMemcpyDeviceToHost,
                          stream());
-    (void)hipMemcpyAsync(K->brick_err_host + 1, K->brick_b.flags + K->brick_b.nbricks + 1, sizeof(int),
+    (void)hipMemcpyAsync(K->brick_err_host + 1, PSP_FLAG_ERR(K->brick_b.flags), sizeof(int),
                          hipMemcpyDeviceToHost, stream());
     K->brick_ev_pending = hipEventRecord(K->brick_ev, stream()) == hipSuccess;
   }
@@ -1585,6 +1849,7 @@ struct BrickPlan {
   int *rows = nullptr;            // device: rows in (brick, level, row) order = the direction's slot order
   std::vector<int> brick_start;   // slot ranges by processing index (nb + 1)
   std::vector<int2> ticks;
+  std::vector<int> tick_brick;    // per (padded) tick: the brick it belongs to
   std::vector<int4> info, pred;
   std::vector<int> halo_base;     // nb + 1
   ~BrickPlan() { (void)hipFree(rows); }
@@ -1731,6 +1996,7 @@ bool plan_bricks(const psp_sss *S, const GridShape &g, int dir, const int *level
       }
       const int nt = (int)P->ticks.size() - t0;
       for (int q = 0; q < kRunPad; ++q) P->ticks.push_back(make_int2(bs, 0));
+      P->tick_brick.resize(P->ticks.size(), b);
       P->info[(size_t)b] = make_int4(t0, nt, P->halo_base[(size_t)b], ext[(size_t)b]);
       // the three face neighbours this brick waits for
       const int id = order[(size_t)b];
@@ -1748,6 +2014,15 @@ bool plan_bricks(const psp_sss *S, const GridShape &g, int dir, const int *level
                   (void *)d_flag, (void *)d_starts, (void *)d_cnt, (void *)d_ext, tmp})
     (void)hipFree(q);
   return ok;
+}
+
+// pipelined brick sweeps (a brick starts before its predecessors have finished; PSP_SSOR_BRICK_PIPE under PSP_TUNING)
+bool brick_pipe_wanted() {
+  static const int mode = [] {
+    const char *e = psp::tuning_env("PSP_SSOR_BRICK_PIPE");
+    return e ? atoi(e) : 0;
+  }();
+  return mode != 0;
 }
 
 // after build_level_ordered (whose slot orders came from the plans): the arrays the brick kernel streams
@@ -1768,12 +2043,12 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
   bool ok = hipMalloc((void **)&bs.ticks, sizeof(int2) * P.ticks.size()) == hipSuccess &&
             hipMalloc((void **)&bs.info, sizeof(int4) * (size_t)nb) == hipSuccess &&
             hipMalloc((void **)&bs.pred, sizeof(int4) * (size_t)nb) == hipSuccess &&
-            hipMalloc((void **)&bs.halo_pos, sizeof(int) * (size_t)std::max(nhalo, 1)) == hipSuccess &&
+            hipMalloc((void **)&bs.halo_pos, sizeof(int) * ((size_t)nhalo + 1)) == hipSuccess &&  // (+1: padding ticks read one)
             hipMalloc((void **)&bs.dpk, sizeof(unsigned) * (size_t)DW * n) == hipSuccess &&
             hipMalloc((void **)&bs.vp, sizeof(double2) * (size_t)DW * n) == hipSuccess &&
             hipMalloc((void **)&bs.dar, sizeof(double) * (size_t)n) == hipSuccess &&
             hipMalloc((void **)&bs.gd, sizeof(double2) * (size_t)n) == hipSuccess &&
-            hipMalloc((void **)&bs.flags, sizeof(int) * ((size_t)nb + 3)) == hipSuccess &&
+            hipMalloc((void **)&bs.flags, sizeof(int) * flag_words(nb)) == hipSuccess &&
             hipMalloc((void **)&d_bstart, sizeof(int) * ((size_t)nb + 1)) == hipSuccess &&
             hipMalloc((void **)&d_ext, sizeof(int) * ((size_t)n + 1)) == hipSuccess &&
             hipMalloc((void **)&d_eoff, sizeof(int) * ((size_t)n + 1)) == hipSuccess &&
@@ -1785,7 +2060,8 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
        hipMemcpyAsync(bs.pred, P.pred.data(), sizeof(int4) * (size_t)nb, hipMemcpyHostToDevice, stream()) == hipSuccess &&
        hipMemcpyAsync(d_bstart, P.brick_start.data(), sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, stream()) ==
            hipSuccess &&
-       hipMemsetAsync(bs.flags, 0, sizeof(int) * ((size_t)nb + 3), stream()) == hipSuccess;
+       hipMemsetAsync(bs.flags, 0, sizeof(int) * flag_words(nb), stream()) == hipSuccess &&
+       hipMemsetAsync(bs.halo_pos + nhalo, 0, sizeof(int), stream()) == hipSuccess;
   if (ok) {
     if (dir)
       hipLaunchKernelGGL(invert_perm_kernel, dim3(std::min((n + 255) / 256, 65536)), dim3(256), 0, stream(), n, K->b_row,
@@ -1801,6 +2077,39 @@ int finish_bricks_w(psp_ssor *K, int dir, const BrickPlan &P) {
     hipLaunchKernelGGL(brick_pack_kernel<W>, dim3((n + 255) / 256), dim3(256), 0, stream(), n, c8, pos, val, slot_of,
                        rowmap, K->da, nb, d_bstart, d_eoff, bs.halo_pos, bs.dpk, bs.vp, bs.dar);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream()) == hipSuccess;
+  }
+  if (ok && brick_pipe_wanted()) {  // never fails the handle: without tick_ext the sweeps wait for whole bricks
+    const int nt = (int)P.ticks.size();
+    int *d_tb = nullptr, *d_tl = nullptr, *d_need = nullptr, *d_bad = nullptr;
+    int bad = 1;
+    bool pk = hipMalloc((void **)&d_tb, sizeof(int) * (size_t)nt) == hipSuccess &&
+              hipMalloc((void **)&d_tl, sizeof(int) * (size_t)n) == hipSuccess &&
+              hipMalloc((void **)&d_need, sizeof(int) * 3 * (size_t)nt) == hipSuccess &&
+              hipMalloc((void **)&d_bad, sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&bs.tick_ext, sizeof(int4) * (size_t)nt) == hipSuccess &&
+              hipMemcpyAsync(d_tb, P.tick_brick.data(), sizeof(int) * (size_t)nt, hipMemcpyHostToDevice, stream()) ==
+                  hipSuccess &&
+              hipMemsetAsync(d_need, 0, sizeof(int) * 3 * (size_t)nt, stream()) == hipSuccess &&
+              hipMemsetAsync(d_bad, 0, sizeof(int), stream()) == hipSuccess;
+    if (pk) {
+      hipLaunchKernelGGL(brick_ticklocal_kernel, dim3(nt), dim3(256), 0, stream(), nt, bs.ticks, d_tb, bs.info, d_tl);
+      hipLaunchKernelGGL(brick_need_kernel<W>, dim3((n + 255) / 256), dim3(256), 0, stream(), n, c8, pos, slot_of, nb,
+                         d_bstart, bs.info, bs.pred, d_tl, d_need, d_bad);
+      hipLaunchKernelGGL(brick_tickext_kernel, dim3((nt + 255) / 256), dim3(256), 0, stream(), nt, bs.ticks, d_tb, d_bstart,
+                         d_eoff, d_need, bs.tick_ext, d_bad);
+      pk = hipGetLastError() == hipSuccess &&
+           hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+           hipStreamSynchronize(stream()) == hipSuccess && bad == 0;
+    }
+    if (!pk) {
+      (void)hipGetLastError();
+      (void)hipFree(bs.tick_ext);
+      bs.tick_ext = nullptr;
+    }
+    (void)hipFree(d_tb);
+    (void)hipFree(d_tl);
+    (void)hipFree(d_need);
+    (void)hipFree(d_bad);
   }
   if (!ok) rc = fail(PSP_ENOMEM, "ssor: the brick schedule could not be built");
   (void)hipFree(slot_of);
@@ -1972,6 +2281,7 @@ static int ssor_create_device(psp_sss_t *S, double omega, int steps, bool allow_
     if (rc == PSP_OK && K->brick_mode) {
       rc = finish_bricks(K, 0, plan_f);
       if (rc == PSP_OK) rc = finish_bricks(K, 1, plan_b);
+      K->brick_pipe = rc == PSP_OK && K->brick_f.tick_ext && K->brick_b.tick_ext;
       if (rc != PSP_OK) {  // the slot orders are the bricks' by now: start over on the level schedule
         (void)hipGetLastError();
         psp_ssor_destroy(K);
@@ -2031,7 +2341,7 @@ int psp_ssor_destroy(psp_ssor_t *K) {
   if (K->brick_err_host) (void)hipHostFree(K->brick_err_host);
   for (psp_ssor::BrickSet *b : {&K->brick_f, &K->brick_b})
     for (void *p : {(void *)b->ticks, (void *)b->info, (void *)b->pred, (void *)b->halo_pos, (void *)b->dpk, (void *)b->vp,
-                    (void *)b->dar, (void *)b->gd, (void *)b->flags})
+                    (void *)b->dar, (void *)b->gd, (void *)b->flags, (void *)b->tick_ext})
       (void)hipFree(p);
   delete K;
   return PSP_OK;
