@@ -627,9 +627,15 @@ __global__ __launch_bounds__(1024) void ssor_run_kernel(int nticks, const int2 *
 // needs its three face neighbours): they are handed out in that order through a counter, a workgroup waits for its
 // brick's three predecessors on flags in memory (bounded spins) -- no deadlock whatever is resident, because whoever took
 // an earlier brick is running.  Same operations in the same order per row as ssor_row_ell => the reference's bits.
-constexpr int kBrickEdge = 32;
-constexpr int kBrickRing = 4096;   // LDS ring (doubles), 32 KiB
-constexpr int kBrickHalo = 4080;   // LDS halo (doubles): ring + halo + the hand-out word stay inside 64 KiB of static LDS
+#ifndef PSP_BRICK_EDGE
+#define PSP_BRICK_EDGE 32  // (24: 256^3 2.64 instead of 2.89 ms per application, 512^3 unchanged; 16: 2.71 / 10.5 against 10.3)
+#endif
+constexpr int kBrickEdge = PSP_BRICK_EDGE;
+// LDS ring (doubles; at least three of the widest levels) and halo (the three faces): with the hand-out word inside
+// 64 KiB of static LDS for edge 32
+constexpr int kBrickRing = kBrickEdge >= 32 ? 4096 : kBrickEdge >= 20 ? 2048 : 1024;
+constexpr int kBrickHalo = kBrickEdge >= 32 ? 4080 : 3 * kBrickEdge * kBrickEdge + 48;
+constexpr int kBrickWgs = kBrickEdge >= 32 ? 256 : kBrickEdge >= 20 ? 512 : 1280;  // workgroups of a sweep (<= resident)
 // flag words of a sweep, one 128-byte line each (hundreds of workgroups poll them): [0] next brick to hand out,
 // [1] error, [2] scratch word of run_pre_kernel, [3 + b] brick b (done / ticks published)
 constexpr int kFlagStride = 32;
@@ -638,7 +644,8 @@ __host__ __device__ constexpr size_t flag_words(int bricks) { return (size_t)(br
 #define PSP_FLAG_ERR(f) ((f) + kFlagStride)
 #define PSP_FLAG_SCRATCH(f) ((f) + 2 * kFlagStride)
 #define PSP_FLAG_BRICK(f, b) ((f) + (size_t)(3 + (b)) * kFlagStride)
-constexpr int kBrickTick = 768;    // threads of a brick's workgroup = the widest level of a 32^3 brick
+constexpr int kBrickTick = (3 * kBrickEdge * kBrickEdge / 4 + 63) / 64 * 64;  // threads of a brick's workgroup = the widest
+                                                                               // level of a brick (768 for 32^3)
 constexpr int kBrickMaxDist = kBrickRing - kBrickTick;
 
 // distinct values of row - col over the strict lower entries: smallest / largest, then the range of the others
@@ -994,7 +1001,9 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
             xn = (p.gd.x + hi) / p.gd.y;
           }
           ring[p.u & (kBrickRing - 1)] = xn;
-          __hip_atomic_store(x + p.t, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // another XCD gathers it
+          // another XCD gathers it.  (Agent-scope stores only for the rows another brick gathers -- one in ten -- and plain
+          // stores for the rest was measured and is SLOWER: 256^3 3.03 against 2.89 ms, 512^3 10.97 against 10.3.)
+          __hip_atomic_store(x + p.t, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           y[p.t] = yn;
         }
         lds_barrier();
@@ -1422,7 +1431,7 @@ static void sweep_w(const psp_ssor *K, hipStream_t st, bool forward, int first) 
   if constexpr (W >= 1 && W <= 3) {
     if (K->brick_mode) {  // a 3-D grid operator with wide levels: bricks of 32^3 points, a coarse wavefront of workgroups
       const psp_ssor::BrickSet &bs = forward ? K->brick_f : K->brick_b;
-      const int n = K->n, nwg = std::min(bs.nbricks, 256);
+      const int n = K->n, nwg = std::min(bs.nbricks, kBrickWgs);
       hipLaunchKernelGGL(brick_begin_kernel, dim3((int)((flag_words(bs.nbricks) + 255) / 256)), dim3(256), 0, st,
                          (int)flag_words(bs.nbricks), bs.flags);
       if (!(KIND == 0 && first))  // (the application's first Gauss-Seidel sweep got its G from brick_first_gd_kernel)
