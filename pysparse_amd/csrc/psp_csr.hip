@@ -4684,20 +4684,21 @@ __global__ __launch_bounds__(256) void sss_full_fill_kernel(
     const double *__restrict__ tval, const int *__restrict__ find, int *__restrict__ fcol,
     double *__restrict__ fval) {
   const int lane = threadIdx.x & 63;
-  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
-  if (i >= n) return;
-  const int l0 = lind[i], ll = lind[i + 1] - l0, t0 = tind[i], tl = tind[i + 1] - t0, f0 = find[i];
-  for (int k = lane; k < ll; k += 64) {
-    fcol[f0 + k] = lcol[l0 + k];
-    fval[f0 + k] = lval[l0 + k];
-  }
-  if (lane == 0) {
-    fcol[f0 + ll] = (int)i;
-    fval[f0 + ll] = diag[i];
-  }
-  for (int k = lane; k < tl; k += 64) {
-    fcol[f0 + ll + 1 + k] = tcol[t0 + k];
-    fval[f0 + ll + 1 + k] = tval[t0 + k];
+  // one wave per row; grid-stride: a launch may not have 2^32 threads (n = 512^3 rows would ask for 8.6e9)
+  for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4) {
+    const int l0 = lind[i], ll = lind[i + 1] - l0, t0 = tind[i], tl = tind[i + 1] - t0, f0 = find[i];
+    for (int k = lane; k < ll; k += 64) {
+      fcol[f0 + k] = lcol[l0 + k];
+      fval[f0 + k] = lval[l0 + k];
+    }
+    if (lane == 0) {
+      fcol[f0 + ll] = (int)i;
+      fval[f0 + ll] = diag[i];
+    }
+    for (int k = lane; k < tl; k += 64) {
+      fcol[f0 + ll + 1 + k] = tcol[t0 + k];
+      fval[f0 + ll + 1 + k] = tval[t0 + k];
+    }
   }
 }
 
@@ -4777,7 +4778,7 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
     SSS_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
     SSS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, flen, F->ind, n + 1, stream()));
     if (n > 0)
-      hipLaunchKernelGGL(sss_full_fill_kernel, dim3((n + 3) / 4), dim3(256), 0, stream(), n, S->ind, S->col, S->val,
+      hipLaunchKernelGGL(sss_full_fill_kernel, dim3(std::min((n + 3) / 4, 1 << 22)), dim3(256), 0, stream(), n, S->ind, S->col, S->val,
                          S->diag, T->ind, T->col, T->val, F->ind, F->col, F->val);
     SSS_HIP(hipGetLastError());
     SSS_HIP(hipStreamSynchronize(stream()));

@@ -459,13 +459,14 @@ __global__ __launch_bounds__(256) void rcm_copy_rows_kernel(int n, const int *__
                                                             const int *__restrict__ rind, int *__restrict__ rcol,
                                                             double *__restrict__ rval) {
   const int lane = threadIdx.x & 63;
-  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
-  if (i >= n) return;
-  const int o = perm[i];
-  const int src = ind[o], len = ind[o + 1] - src, dst = rind[i];
-  for (int k = lane; k < len; k += 64) {
-    rcol[dst + k] = inv[col[src + k]];
-    rval[dst + k] = val[src + k];
+  // one wave per row; grid-stride: a launch may not have 2^32 threads
+  for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4) {
+    const int o = perm[i];
+    const int src = ind[o], len = ind[o + 1] - src, dst = rind[i];
+    for (int k = lane; k < len; k += 64) {
+      rcol[dst + k] = inv[col[src + k]];
+      rval[dst + k] = val[src + k];
+    }
   }
 }
 
@@ -474,15 +475,16 @@ __global__ __launch_bounds__(256) void rcm_copy_rows_kernel(int n, const int *__
 __global__ __launch_bounds__(256) void sym_keys_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
                                                        unsigned long long *__restrict__ keys) {
   const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
-  if (r >= n) return;
-  for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) {
-    const int c = col[k];
-    // entries on the diagonal (and out-of-range columns, which a square operator does not have) map to the
-    // all-ones key, which sorts last and is dropped
-    const bool keep = c != r && c >= 0 && c < n;
-    keys[2 * (size_t)k] = keep ? ((unsigned long long)(unsigned)r << 32) | (unsigned)c : ~0ull;
-    keys[2 * (size_t)k + 1] = keep ? ((unsigned long long)(unsigned)c << 32) | (unsigned)r : ~0ull;
+  // one wave per row; grid-stride: a launch may not have 2^32 threads
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (long)gridDim.x * 4) {
+    for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) {
+      const int c = col[k];
+      // entries on the diagonal (and out-of-range columns, which a square operator does not have) map to the
+      // all-ones key, which sorts last and is dropped
+      const bool keep = c != r && c >= 0 && c < n;
+      keys[2 * (size_t)k] = keep ? ((unsigned long long)(unsigned)r << 32) | (unsigned)c : ~0ull;
+      keys[2 * (size_t)k + 1] = keep ? ((unsigned long long)(unsigned)c << 32) | (unsigned)r : ~0ull;
+    }
   }
 }
 
@@ -723,7 +725,7 @@ int reorder_symmetrize_device(int n, int nnz, const int *ind, const int *col, in
   unsigned long long *keys = b_keys.as<unsigned long long>(), *sorted = b_sorted.as<unsigned long long>();
   unsigned long long *uniq = b_uniq.as<unsigned long long>();
   if (nnz > 0) {
-    hipLaunchKernelGGL(sym_keys_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, ind, col, keys);
+    hipLaunchKernelGGL(sym_keys_kernel, dim3(std::min((n + 3) / 4, 1 << 22)), dim3(256), 0, st, n, ind, col, keys);
     PSP_LAUNCH_CHECK();
   }
   int bits = 1;
@@ -777,7 +779,7 @@ int reorder_build_device(int n, const int *ind, const int *col, const double *va
   PSP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, b_len.as<int>(), rind, n + 1, st));
   PSP_HIP(b_tmp.alloc(bytes));
   PSP_HIP(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, bytes, b_len.as<int>(), rind, n + 1, st));
-  hipLaunchKernelGGL(rcm_copy_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, ind, col, val, perm_dev, inv_dev,
+  hipLaunchKernelGGL(rcm_copy_rows_kernel, dim3(std::min((n + 3) / 4, 1 << 22)), dim3(256), 0, st, n, ind, col, val, perm_dev, inv_dev,
                      rind, rcol, rval);
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(st));

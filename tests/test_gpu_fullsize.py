@@ -450,3 +450,28 @@ def test_host_pointer_matvec_pipeline_is_the_device_product():
         assert np.array_equal(y, y2)
         A.matvec(np.ones(n), y)  # exact row sums: the number of missing neighbours (small integers)
         assert np.array_equal(y, missing_neighbours(*grid).ravel())
+
+
+@pytest.mark.gpu
+def test_sss_from_arrays_at_c3_size(oracle):
+    """sss_from_arrays at 512^3 (1.3e8 rows, 4.0e8 lower entries handed over as host arrays): the mirror is built with one
+    wave per row, which at this size used to ask for a launch of 8.6e9 threads ("invalid configuration argument"; the
+    generators never go that way).  Same bits as the device-generated operator for a random x; precon.ssor on it (bricks)
+    applies."""
+    from pysparse_amd import device as dev
+    nx = 512
+    S = oracle.poisson_sss(nx, nx, nx)
+    D = dev.DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    G = dev.DeviceSSS.poisson(nx, nx, nx)
+    n = S.n
+    x = dev.DeviceBuffer.from_host(np.random.default_rng(2).standard_normal(n))
+    y1, y2 = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+    D.matvec_dev(x.ptr, y1.ptr)
+    G.matvec_dev(x.ptr, y2.ptr)
+    assert np.array_equal(y1.download(), y2.download())
+    del G, y2
+    K = dev.DeviceSSOR(D, 1.0, 1)
+    assert K.bricks == 16 ** 3
+    K.precon_dev(x.ptr, y1.ptr)
+    z = y1.download()
+    assert np.isfinite(z).all() and abs(z).max() > 0
