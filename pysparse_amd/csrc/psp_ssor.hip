@@ -2296,6 +2296,13 @@ static int ssor_create_device(psp_sss_t *S, double omega, int steps, bool allow_
       rc = finish_bricks(K, 0, plan_f);
       if (rc == PSP_OK) rc = finish_bricks(K, 1, plan_b);
       K->brick_pipe = rc == PSP_OK && K->brick_f.tick_ext && K->brick_b.tick_ext;
+      if (rc == PSP_OK) {  // the brick sweeps stream their own copies: the slot-major triangle is not needed any more
+        for (void **q : {(void **)&K->f_pos, (void **)&K->f_val, (void **)&K->b_pos, (void **)&K->b_val, (void **)&K->fc8,
+                         (void **)&K->bc8}) {
+          (void)hipFree(*q);
+          *q = nullptr;
+        }
+      }
       if (rc != PSP_OK) {  // the slot orders are the bricks' by now: start over on the level schedule
         (void)hipGetLastError();
         psp_ssor_destroy(K);
