@@ -959,7 +959,10 @@ static void CSRMat_dealloc(CSRMatObject *a) {
 static PyObject *CSRMat_get_shape(CSRMatObject *a, void *c) {
   return Py_BuildValue("(i,i)", a->dim[0], a->dim[1]);
 }
-static PyObject *CSRMat_get_nnz(CSRMatObject *a, void *c) { return PyLong_FromLong(a->nnz); }
+static PyObject *CSRMat_get_nnz(CSRMatObject *a, void *c) {
+  if (a->nnz < 0 && a->dev != NULL) return PyLong_FromLongLong((long long)psp_csr_nnz64(a->dev)); /* beyond the struct's int */
+  return PyLong_FromLong(a->nnz);
+}
 
 static PyObject *CSRMat_get_psp_op(CSRMatObject *a, void *c) {
   if (a->op == NULL) {
@@ -1723,6 +1726,10 @@ static PyObject *Poisson_csr(PyObject *module, PyObject *args, PyObject *kwds) {
   Py_BEGIN_ALLOW_THREADS
   if (ndev > 0) /* z-slabs on a list of devices, one process (psp_csr_poisson_multi) */
     rc = psp_csr_poisson_multi(nx, ny, nz, devs, ndev, &op->dev);
+  else if (7.0 * (double)nx * (double)ny * (double)(nz > 0 ? nz : 1) > 2147483647.0)
+    /* more than 2^31 stored entries (1024^3: 7.5e9) on ONE device: the index-free operator with 64-bit row offsets
+     * (configs[3]'s one-GPU baseline); nnz then reads through psp_csr_nnz64 */
+    rc = psp_csr_poisson_big(nx, ny, nz, &op->dev);
   else
     rc = psp_csr_poisson(nx, ny, nz, &op->dev);
   Py_END_ALLOW_THREADS

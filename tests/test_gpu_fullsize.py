@@ -475,3 +475,30 @@ def test_sss_from_arrays_at_c3_size(oracle):
     K.precon_dev(x.ptr, y1.ptr)
     z = y1.download()
     assert np.isfinite(z).all() and abs(z).max() > 0
+
+
+@pytest.mark.gpu
+def test_dropin_module_holds_1024_cubed_on_one_gpu():
+    """`spmatrix.poisson_csr(1024, 1024, 1024)` without a device list: 7.5e9 stored entries do not fit the 32-bit CSR of
+    csr_mat.h:6-13, so the module builds the index-free operator with 64-bit row offsets (psp_csr_poisson_big) -- the one-GPU
+    baseline of configs[3] -- and `nnz` reads through psp_csr_nnz64.  Exact row sums, a few Jacobi-PCG / MINRES iterations
+    through krylov with host vectors."""
+    from pysparse.itsolvers import krylov
+    from pysparse.precon import precon
+    from pysparse.sparse import spmatrix
+    N = 1024
+    A = spmatrix.poisson_csr(N, N, N)
+    n = N ** 3
+    assert A.shape == (n, n) and A.nnz == 7 * n - 6 * N * N
+    e = np.ones(n)
+    b = np.empty(n)
+    A.matvec(e, b)
+    assert b[0] == 3.0 and b[n - 1] == 3.0 and b[n // 2 + N * N // 2 + N // 2] == 0.0
+    assert b.sum() == 6.0 * N * N  # one missing neighbour per boundary face point
+    K = precon.jacobi(A, 1.0, 1)
+    x = np.zeros(n)
+    info, it, rr = krylov.pcg(A, b, x, 1e-30, 4, K)
+    assert (info, it) == (-1, 5) and 0.0 < rr < 1.0 and np.isfinite(x).all()
+    x[:] = 0.0
+    info, it, rr = krylov.minres(A, b, x, 1e-30, 4, K)
+    assert (info, it) == (-1, 4) and 0.0 < rr < 1.0 and np.isfinite(x).all()
