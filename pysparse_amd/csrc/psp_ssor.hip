@@ -652,17 +652,24 @@ constexpr int kBrickMaxDist = kBrickRing - kBrickTick;
 __global__ __launch_bounds__(256) void grid_offsets_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
                                                            int pass, int *mm) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
   const int lo = mm[0], hi = mm[1];
-  for (int k = ind[r]; k < ind[r + 1]; ++k) {
-    const int o = r - col[k];
-    if (pass == 0) {
-      atomicMin(mm + 0, o);
-      atomicMax(mm + 1, o);
-    } else if (o != lo && o != hi) {
-      atomicMin(mm + 2, o);
-      atomicMax(mm + 3, o);
+  int a = 0x7fffffff, b = 0;  // the thread's own range first, one pair of atomics per wave (4e8 entries at 512^3)
+  if (r < n)
+    for (int k = ind[r]; k < ind[r + 1]; ++k) {
+      const int o = r - col[k];
+      if (pass == 0 || (o != lo && o != hi)) {
+        a = min(a, o);
+        b = max(b, o);
+      }
     }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a = min(a, __shfl_xor(a, off, 64));
+    b = max(b, __shfl_xor(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && b > 0) {
+    atomicMin(mm + (pass ? 2 : 0), a);
+    atomicMax(mm + (pass ? 3 : 1), b);
   }
 }
 
