@@ -328,23 +328,191 @@ def gpu_clocks():
 
 # ------------------------------------------------------------------------------------ launcher
 
-def self_launch(argv, n):
-    """N > 1 called as a plain script: start N fresh ranks BEFORE this process touches the GPU or
-    imports torch, relay their output, exit with their code."""
+METRIC = "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s"
+PARITY_ITERS = 20      # iterations of the in-job parity solves (tol = 0)
+PARITY_TOL = 1e-9      # N-rank solve against the one-GPU solve of the same problem: relres and x checksums
+# The ladder of an N > 1 run started as a plain script: every stage is a FRESH child process (this process never
+# touches the GPU, and a process that has is never re-executed); the first stage that prints a valid line wins.
+#   torch_rccl_ranks     one torch.distributed rank per GPU; halos = RCCL send/recv, reductions = RCCL all-reduce
+#   single_process_rccl  ONE process, device list (psp_csr_poisson_multi); halos = peer copies, reductions = RCCL
+#                        inside the library (ncclCommInitAll)
+#   single_process_fold  the same with the reductions through the fold kernel over peer pointers (no RCCL at all)
+LADDER = ("torch_rccl_ranks", "single_process_rccl", "single_process_fold")
+STAGE_CAP_S = {"torch_rccl_ranks": 300.0, "single_process_rccl": 200.0, "single_process_fold": 200.0}
+
+
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return port
 
 
-def pcg_single(L, check, dev, A, n, iters, sync):
+def _stage_cmd(stage, argv, n):
+    """(command, extra environment) of one ladder stage"""
+    me = os.path.abspath(__file__)
+    if stage == "torch_rccl_ranks":
+        return ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), me] + argv + ["--stage", stage], {})
+    env = {}
+    if stage == "single_process_fold":
+        env = {"PSP_TUNING": "1", "PSP_MULTI_REDUCE": "local"}
+    return [sys.executable, me] + argv + ["--single-process", "--stage", stage], env
+
+
+def _run_stage(cmd, env, timeout_s, log):
+    """run one stage in its own process group; (rc, stdout, stderr tail, wall seconds, timed_out).  On a time-out
+    the whole group is ended -- SIGTERM, then SIGKILL -- by its group id: the ranks are grandchildren."""
+    import signal
+    import tempfile
+    t0 = time.time()
+    with tempfile.TemporaryFile() as fo, tempfile.TemporaryFile() as fe:
+        p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True)
+        timed_out = False
+        last = t0
+        while True:
+            try:
+                p.wait(timeout=5.0)
+                break
+            except subprocess.TimeoutExpired:
+                now = time.time()
+                if now - last >= 30.0:  # a line now and then: a silent job looks hung to whoever runs it
+                    log("... %.0f s" % (now - t0))
+                    last = now
+                if now - t0 > timeout_s:
+                    timed_out = True
+                    for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+                        try:
+                            os.killpg(p.pid, sig)
+                        except ProcessLookupError:
+                            pass
+                        try:
+                            p.wait(timeout=grace)
+                            break
+                        except subprocess.TimeoutExpired:
+                            continue
+                    break
+        fo.seek(0)
+        fe.seek(0)
+        out = fo.read().decode("utf-8", "replace")
+        err = fe.read().decode("utf-8", "replace")
+    return (p.returncode if p.returncode is not None else -9), out, err[-3000:], time.time() - t0, timed_out
+
+
+def orchestrate(a, argv):
+    """`python bench.py --gpus N` (N > 1) called as a plain script.  Runs the ladder inside `--deadline` seconds, prints
+    ONE JSON line -- the winning stage's, with `launcher` saying which stage produced it and what the earlier ones
+    died of -- or, when every stage failed, an error line (value null) and a non-zero exit code."""
+    t_start = time.time()
+    stages = [st for st in (a.ladder.split(",") if a.ladder else LADDER)]
+    for st in stages:
+        if st not in LADDER:
+            raise SystemExit("unknown ladder stage %r (known: %s)" % (st, ", ".join(LADDER)))
+
+    def log(msg):
+        print("[bench ladder] " + msg, file=sys.stderr, flush=True)
+
+    failed = []
+    for k, stage in enumerate(stages):
+        remaining = a.deadline - (time.time() - t_start) - 5.0
+        cap = a.stage_timeout if a.stage_timeout > 0 else STAGE_CAP_S[stage]
+        # the last stage may use whatever is left; earlier ones leave room for those behind them
+        budget = remaining if k == len(stages) - 1 else min(cap, remaining - 45.0 * (len(stages) - 1 - k))
+        if a.stage_timeout > 0:
+            budget = min(a.stage_timeout, remaining)
+        if budget < 15.0:
+            failed.append({"stage": stage, "rc": None, "reason": "skipped: %.0f s left of the %.0f s deadline"
+                           % (max(remaining, 0.0), a.deadline)})
+            continue
+        cmd, extra = _stage_cmd(stage, argv, a.gpus)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra)
+        log("stage %s (time-out %.0f s)" % (stage, budget))
+        rc, out, err, wall, timed_out = _run_stage(cmd, env, budget, log)
+        lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+        rec = None
+        if lines:
+            try:
+                rec = json.loads(lines[-1])
+            except ValueError:
+                rec = None
+        if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
+            rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": stages,
+                               "deadline_s": a.deadline, "total_wall_s": time.time() - t_start}
+            print(json.dumps(rec), flush=True)
+            return 0
+        reason = ("timed out after %.0f s" % wall) if timed_out else (
+            (rec or {}).get("error") or "exit code %d" % rc)
+        tail = [l for l in err.strip().splitlines() if l.strip()][-6:]
+        failed.append({"stage": stage, "rc": rc, "reason": reason, "wall_s": wall, "stderr_tail": tail})
+        log("stage %s failed: %s" % (stage, reason))
+        for l in tail:
+            log("    " + l[:300])
+    print(json.dumps({"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": a.gpus, "steps": a.steps,
+                      "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                      "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "error": "every stage of the launch ladder failed",
+                      "launcher": {"stage": None, "fallback_from": failed, "ladder": stages, "deadline_s": a.deadline,
+                                   "total_wall_s": time.time() - t_start}}), flush=True)
+    return 1
+
+
+def peer_matrix(L, ndev):
+    """pre-flight: can device i reach device j's memory directly (psp_peer_access; no context is created)"""
+    m = []
+    for i in range(ndev):
+        row = []
+        for j in range(ndev):
+            c = C.c_int(-1)
+            row.append(c.value if L.psp_peer_access(i, j, C.byref(c)) == 0 else -1)
+        m.append(row)
+    return m
+
+
+def link_topology():
+    """pre-flight: how the GPUs are wired (rocm-smi --showtopotype: XGMI / PCIE per pair), best effort"""
+    try:
+        p = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=20)
+        return json.loads(p.stdout)
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": str(e)[:200]}
+
+
+def provenance(L):
+    """which sources the library that ran was built from (tests/test_capi_symbols.py holds the two equal)"""
+    out = {"build_id": L.psp_build_id().decode()}
+    try:
+        import __graft_entry__ as G
+        out["source_hash"] = G.source_hash()
+        out["match"] = out["build_id"] == out["source_hash"]
+    except Exception as e:  # noqa: BLE001 - the sources may not lie next to an installed library
+        out["source_hash"] = None
+        out["match"] = None
+        out["note"] = str(e)[:120]
+    return out
+
+
+def rel_diff(a, b):
+    return abs(a - b) / max(abs(a), abs(b), 1e-300)
+
+
+def parity_object(n1, nr, what):
+    """`parity_vs_n1`: the N-rank Jacobi-PCG against the one-GPU solve of the same system after PARITY_ITERS
+    iterations (tol = 0): the recurred residual and two checksums of x.  The two differ by the order of the
+    reductions only (<= 1e-13 on the probes)."""
+    d = {k: rel_diff(n1[k], nr[k]) for k in ("relres", "x_dot_b", "x_dot_x")}
+    worst = max(d.values())
+    return {"iters": PARITY_ITERS, "n1": n1, what: nr, "rel_diff": d, "max_rel_diff": worst, "tol": PARITY_TOL,
+            "same_info_iter": n1["info_iter"] == nr["info_iter"], "ok": bool(worst <= PARITY_TOL and
+                                                                               n1["info_iter"] == nr["info_iter"])}
+
+
+def pcg_single(L, check, dev, A, n, iters, sync, parity=False):
     """Jacobi-PCG through the library's device-resident loop: b = A*ones, x0 = 0, tol = 0 (exactly
-    `iters` iterations; ||b|| and r = b - A x0 are inside the timed region)."""
+    `iters` iterations; ||b|| and r = b - A x0 are inside the timed region).  parity: the warm-up solve runs
+    PARITY_ITERS iterations and leaves (relres, x.b, x.x) as the third result."""
     K = dev.DeviceJacobi(A)
     aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
     bb, xb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
@@ -353,7 +521,8 @@ def pcg_single(L, check, dev, A, n, iters, sync):
         check(L.psp_memcpy_h2d(xb.ptr + 8 * k, ones.ctypes.data, 8 * min(ones.size, n - k)))
     A.matvec_dev(xb.ptr, bb.ptr)
     sync()
-    for kk in (2, iters):  # first call = warm-up
+    par = None
+    for kk in ((PARITY_ITERS if parity else 2), iters):  # first call = warm-up
         xb.zero()
         info, it, rr = C.c_int(), C.c_int(), C.c_double()
         sync()
@@ -362,9 +531,20 @@ def pcg_single(L, check, dev, A, n, iters, sync):
                             C.byref(rr), None))
         sync()
         dt = time.perf_counter() - t
+        if parity and par is None:
+            ob = dev.DeviceBuffer(2)
+            check(L.psp_k_dot(n, xb.ptr, bb.ptr, ob.ptr))
+            check(L.psp_k_dot(n, xb.ptr, xb.ptr, ob.ptr + 8))
+            sync()
+            v = ob.download()
+            ob.free()
+            par = {"relres": rr.value, "x_dot_b": float(v[0]), "x_dot_x": float(v[1]),
+                   "info_iter": [info.value, it.value]}
     del aop, kop, K
     bb.free()
     xb.free()
+    if parity:
+        return dt / iters, (info.value, it.value, rr.value), par
     return dt / iters, (info.value, it.value, rr.value)
 
 
@@ -386,11 +566,12 @@ def strong_n1_leg(L, check, dev, grid, iters):
     kern, info = A.kernel_info()
     x.free()
     y.free()
-    s_per_it, chk = pcg_single(L, check, dev, A, n, iters, sync)
+    s_per_it, chk, par = pcg_single(L, check, dev, A, n, iters, sync, parity=True)
     kb = kernel_bytes(kern, info, n, nnz)
     out = {"grid": [nx, ny, nz], "n": n, "nnz": nnz, "kernel": kern, "spmv_ms": med,
            "spmv_GBps": kb / (med * 1e-3) / 1e9, "spmv_frac_of_peak": kb / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "pcg_iters_per_s": 1.0 / s_per_it, "pcg_check": {"info": chk[0], "iter": chk[1], "relres": chk[2]},
+           "parity_solve": par,  # after PARITY_ITERS iterations: what an N-rank solve of the same system is held to
            "path": "psp_pcg_dev (single-GPU device-resident loop)"}
     A.close()
     check(L.psp_trim())
@@ -414,6 +595,14 @@ def single_process_main(a):
         nx, ny, nz = (int(t) for t in a.grid.split(","))
     else:
         nx = ny = nz = 1024 if N > 1 else 512
+    preflight = {"device_count": L.psp_device_count(), "peer_access": peer_matrix(L, 1 if a.share_gpu else N)}
+    if N > 1 and not a.share_gpu:
+        preflight["link_topology"] = link_topology()
+    # the 1-GPU end of the strong-scaling ratio and of the parity check: the whole problem on device 0, first
+    strong_n1 = None
+    if N > 1 and not a.no_strong_n1:
+        check(L.psp_set_device(0))
+        strong_n1 = strong_n1_leg(L, check, dev, (nx, ny, nz), min(a.pcg_iters, 24))
     A = dev.DeviceCSR.poisson_multi(nx, ny, nz, devices=devices)
     n, nnz = A.shape[0], A.nnz
     ranks, distinct, rccl_used = A.multi_info()
@@ -424,12 +613,31 @@ def single_process_main(a):
     kbytes = 8 * 7 * n + 2 * n + 16 * n  # csr_spmv_w4 on the 7-point operator (kernel_bytes)
     if nz == 0:
         kbytes = 8 * 5 * n + 2 * n + 16 * n
+    # the pieces of that product and of an iteration on their own (psp_csr_multi_phase_time)
+    phases = {}
+    for what, name in ((0, "halo_ms"), (1, "spmv_local_ms"), (2, "allreduce_ms")):
+        v = C.c_double()
+        check(L.psp_csr_multi_phase_time(A._h, what, 2, max(5, min(a.steps, 20)), C.byref(v)))
+        phases[name] = v.value
+    phases["spmv_with_halo_ms"] = ms.value
+    phases["allreduce_us"] = phases["allreduce_ms"] * 1e3
+    if phases["halo_ms"] > 0:
+        phases["overlap_frac"] = max(0.0, min(1.0, (phases["halo_ms"] + phases["spmv_local_ms"] - ms.value)
+                                              / phases["halo_ms"]))
     # Jacobi-PCG iterations/s: tol = 0 runs exactly k iterations; two runs, the difference cancels the host
     # transfers of b and x and the set-up products (the vectors cross PCIe once per solve)
     K = dev.DeviceJacobi(A)
     ones = np.ones(n)
     b = np.empty(n)
     A.matvec(ones, b)
+    del ones
+    # in-job parity: PARITY_ITERS iterations against the one-GPU solve of the same system (strong_n1)
+    parity = None
+    x = np.zeros(n)
+    rp = dev.pcg(A, b, x, 0.0, PARITY_ITERS, K)
+    mine = {"relres": rp[2], "x_dot_b": float(np.dot(x, b)), "x_dot_x": float(np.dot(x, x)), "info_iter": [rp[0], rp[1]]}
+    if strong_n1 is not None:
+        parity = parity_object(strong_n1["parity_solve"], mine, "n_ranks")
     k1, k2 = 4, 4 + max(8, min(a.pcg_iters, 64))
     # the difference of two solves of k1 and k2 iterations (best of three each, after a warm-up solve): on a problem
     # of a few hundred thousand rows the host-side noise of a single pair can exceed the k2 - k1 iterations themselves
@@ -444,8 +652,9 @@ def single_process_main(a):
         s_per_iter = (times[k2] - times[k1]) / (k2 - k1)
     else:  # still inside the noise: price the whole longer solve (an upper bound of the iteration time)
         s_per_iter = times[k2] / k2
+    reductions = "rccl" if rccl_used else ("none" if ranks == 1 else "fold kernel over peer pointers")
     out = {
-        "metric": "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s",
+        "metric": METRIC,
         "value": kbytes / (ms.value * 1e-3) / 1e9, "unit": "GB/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms.value, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
@@ -453,18 +662,34 @@ def single_process_main(a):
                                "ONE process (psp_csr_poisson_multi)" % (nx, ny, nz),
                    "n": n, "nnz": nnz, "rows_per_gpu": n // N, "parallelism": "row-range x%d, single process" % N,
                    "scaling_mode": "strong", "devices": devices},
-        "launcher": "single process, C ABI device list",
-        "ranks": ranks, "distinct_devices": distinct,
-        "reductions": "rccl" if rccl_used else ("none" if ranks == 1 else "fold kernel over peer pointers"),
+        "launcher_kind": "single process, C ABI device list",
+        "stage": a.stage or None,
+        "transport": {"halo": "hipMemcpyPeerAsync on a copy stream per rank" if distinct > 1 else
+                              "device-to-device copies (ranks share a GPU)",
+                      "reductions": reductions},
+        "ranks": ranks, "distinct_devices": distinct, "rccl_ranks": ranks if rccl_used else 0,
+        "reductions": reductions,
         "pct_hbm_peak": 100.0 * kbytes / (ms.value * 1e-3) / 1e9 / (HBM_PEAK_GBPS * max(distinct, 1)),
         "pcg_iters_per_s": 1.0 / s_per_iter,
         "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k2 - k1,
                       "path": "psp_pcg on a multi-device matrix (psp_multi.hip)", "solve_s": times},
+        "phases": phases,
+        "preflight": preflight,
+        "parity_solve": mine,
+        "provenance": provenance(L),
         "wall_s_spmv_leg": wall,
     }
+    if strong_n1 is not None:
+        out["strong_n1"] = strong_n1
+        out["vs_n1"] = (1.0 / s_per_iter) / strong_n1["pcg_iters_per_s"]
+    if parity is not None:
+        out["parity_vs_n1"] = parity
+        if not parity["ok"]:
+            out["error"] = "parity_vs_n1 failed: max relative difference %.3e > %.1e" % (parity["max_rel_diff"], PARITY_TOL)
     if a.share_gpu:
         out["dry_run"] = "%d ranks sharing device 0 in one process: a rehearsal of the N > 1 path, NOT a measurement" % N
     print(json.dumps(out), file=real_stdout, flush=True)
+    return 1 if "error" in out else 0
 
 
 def main():

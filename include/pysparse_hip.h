@@ -60,6 +60,10 @@ const char *psp_version(void);
 int psp_device_count(void);
 /* select the device all later calls use (hipSetDevice) */
 int psp_set_device(int device);
+/* *can_access = 1 when `device` can read / write `peer`'s memory directly (xGMI or PCIe peer path; what the
+ * halo copies of a multi-device matrix need), 1 for device == peer.  Creates no context: bench.py's pre-flight
+ * matrix of an N-GPU run */
+int psp_peer_access(int device, int peer, int *can_access);
 /* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = null stream */
 int psp_set_stream(void *hip_stream);
 int psp_synchronize(void);
@@ -152,6 +156,11 @@ int psp_multi_plan(int nrows, int ncols, const int *ind_host, const int *col_hos
  * copies on the copy streams, the rows that need none meanwhile, then the boundary rows); *ms_per_product is the
  * slowest rank's stream time per product (HIP events on every rank's compute stream) */
 int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_product);
+/* the pieces of that product and of an iteration on their own, same timing: what 0 = the ghost exchange alone,
+ * 1 = the local product alone (no exchange), 2 = one packed reduction of two doubles (RCCL all-reduce or the fold
+ * kernel).  bench.py reports them as `phases` of the single-process line; the halo time hidden behind the interior
+ * rows is (t0 + t1 - t_product) / t0. */
+int psp_csr_multi_phase_time(psp_csr_t *A, int what, int warmup, int reps, double *ms_per_rep);
 /* General CSR beyond the reference's C int (csr_mat.h:6-13: `int nnz`, `int *ind`): row offsets are 64-bit at
  * this boundary, column indices stay 32-bit.  Above 2^30 nonzeros the rows are cut into parts of < 2^30
  * nonzeros that share x and write disjoint row ranges of y ("64-bit row offsets ... or

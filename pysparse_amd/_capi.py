@@ -17,14 +17,14 @@ LIB_PATH = os.environ.get("PSP_LIB_OVERRIDE") or os.path.join(HERE, "libpysparse
 
 # every symbol include/pysparse_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = """
-psp_last_error psp_version psp_device_count psp_set_device psp_set_stream psp_synchronize
+psp_last_error psp_version psp_device_count psp_set_device psp_peer_access psp_set_stream psp_synchronize
 psp_device_info psp_mem_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset psp_trim
 psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_stream_probe psp_build_id
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
 psp_csr_set_schedule psp_csr_kernel_info psp_csr_renumbering psp_csr_device_bytes
-psp_csr_poisson_multi psp_csr_create_multi psp_csr_multi_info psp_csr_multi_spmv_time psp_multi_plan
+psp_csr_poisson_multi psp_csr_create_multi psp_csr_multi_info psp_csr_multi_spmv_time psp_csr_multi_phase_time psp_multi_plan
 psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
 psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
 psp_sss_kernel_info psp_sss_set_variant
@@ -97,7 +97,7 @@ def _declare(L):
     L.psp_device_count.restype = i
     L.psp_device_count.argtypes = []
     sig = {
-        "psp_set_device": [i], "psp_set_stream": [vp], "psp_synchronize": [], "psp_trim": [],
+        "psp_set_device": [i], "psp_peer_access": [i, i, pi], "psp_set_stream": [vp], "psp_synchronize": [], "psp_trim": [],
         "psp_device_info": [C.c_char_p, i, pi, C.POINTER(i64)],
         "psp_mem_info": [C.POINTER(i64), C.POINTER(i64)],
         "psp_malloc": [pvp, sz], "psp_free": [vp], "psp_memcpy_h2d": [vp, vp, sz],
@@ -111,7 +111,7 @@ def _declare(L):
         "psp_csr_poisson_big_slab": [i, i, i, i64, i64, i64, i, pvp],
         "psp_csr_create64": [i, i, i64, vp, vp, vp, pvp],
         "psp_csr_poisson_multi": [i, i, i, vp, i, pvp], "psp_csr_create_multi": [i, i, i, vp, vp, vp, vp, i, pvp],
-        "psp_csr_multi_info": [vp, pi, pi, pi], "psp_csr_multi_spmv_time": [vp, i, i, pd],
+        "psp_csr_multi_info": [vp, pi, pi, pi], "psp_csr_multi_spmv_time": [vp, i, i, pd], "psp_csr_multi_phase_time": [vp, i, i, i, pd],
         "psp_multi_plan": [i, i, vp, vp, i, i, C.POINTER(i64), vp, vp, i, vp, i, vp],
         "psp_csr_random_banded": [i, i, i, i, C.c_uint64, pvp],
         "psp_csr_download_rows": [vp, i, i, vp, vp, vp],

@@ -24,6 +24,8 @@
 // agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 128 workgroups of 1024 threads (one row per thread) --
 // and every spin is bounded: a barrier that does not complete sets an error flag that ends all workgroups.
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "psp_internal.h"
@@ -57,20 +59,30 @@ __device__ __forceinline__ double coh_load(const double *p) {
 
 // One monotone arrival counter: a workgroup adds 1 (no value returned: nothing to wait for) and polls until the count
 // reaches nwg * (barriers so far) -- one memory round trip after the last arrival instead of two.
+// Publishing: every wave drains its own vector-memory counter before the workgroup barrier that precedes the arrival.
+// A workgroup-scope release fence does NOT do that on gfx9 (non-tgsplit mode): it emits no s_waitcnt vmcnt, so the sc1
+// stores of the other waves could still be in flight when a remote workgroup passes the barrier and sc1-loads them.
+// Waiting: bounded by the 100 MHz wall clock (kCoopSpinTicks = 20 ms), not by a poll count -- a barrier among
+// co-resident workgroups completes in microseconds; one that cannot complete (a workgroup that is not resident) ends
+// every workgroup through the error word and the host falls back to the launch-per-phase loop from the saved vectors.
+constexpr long long kCoopSpinTicks = 2000000;  // s_memrealtime ticks (100 MHz): 20 ms
 __device__ __forceinline__ bool coop_barrier(CoopCtl *c, int nwg, unsigned &gen) {
   if (nwg == 1) {
     __syncthreads();
     return true;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores have completed (s_waitcnt) ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's coherent stores have left the CU ...
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();                                        // ... before the workgroup announces itself
   gen += 1;
   if (threadIdx.x == 0) {
     (void)__hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = gen * (unsigned)nwg;
-    long spins = 0;
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
     while ((int)(__hip_atomic_load(&c->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      if (++spins > (1L << 26) || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      if ((++spins & 15u) == 0 &&
+          (wall_clock64() - t0 > kCoopSpinTicks || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -396,11 +408,12 @@ struct CoopMem {
     }
     return PSP_OK;
   }
+  // PSP_OK, kCoopFallback (a grid barrier gave up: the caller restores its vectors and runs the launch-per-phase loop)
+  // or an error
   int fetch(CoopCtl *out) {
     PSP_HIP(hipMemcpyAsync(out, ctl, sizeof(CoopCtl), hipMemcpyDeviceToHost, stream()));
     PSP_HIP(hipStreamSynchronize(stream()));
-    if (out->error) return fail(PSP_ENODEV, "single-kernel solver: a grid barrier did not complete");
-    return PSP_OK;
+    return out->error ? kCoopFallback : PSP_OK;
   }
 };
 
@@ -417,27 +430,77 @@ bool coop_enabled() {
   return on;
 }
 
-}  // namespace
-
-// the operator as plain CSR arrays on this device, small enough for the single-kernel loops?
-bool coop_applicable(const psp_csr *A, int n) {
-  return coop_enabled() && A && !A->w4_only && !A->nparts && !A->multi && !A->host && A->ind && A->nrows == n &&
-         A->ncols == n && n >= 1 && n <= kCoopMaxRows && A->max_row_nnz <= kRegNz;  // every row fits the registers
+// How many workgroups of the two kernels the current device can hold AT ONCE (occupancy x compute units; the smaller
+// of the two kernels): a grid barrier among more workgroups than that cannot complete.  A partitioned (CPX) device
+// reports its own CU count here.  Cached per device; 0 when the runtime cannot tell (the single-kernel loops are
+// then not used).  PSP_COOP_CAPACITY (tuning switch) overrides the figure -- the tests use it to force the refusal.
+int coop_capacity() {
+  static std::mutex mu;
+  static std::map<int, int> cap;
+  if (const char *e = tuning_env("PSP_COOP_CAPACITY")) return atoi(e);
+  std::lock_guard<std::mutex> lk(mu);
+  const int dev = current_device();
+  auto it = cap.find(dev);
+  if (it != cap.end()) return it->second;
+  int c = 0;
+  Workspace *w = nullptr;
+  if (workspace(&w) == PSP_OK && w->num_cu > 0) {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)pcg_coop_kernel, kCoopBlock, 0) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)minres_coop_kernel, kCoopBlock, 0) == hipSuccess)
+      c = std::min(a, b) * w->num_cu;
+    else
+      (void)hipGetLastError();
+  }
+  cap[dev] = c;
+  return c;
 }
 
+// Cooperative launch: the runtime refuses a grid it cannot make co-resident (hipErrorCooperativeLaunchTooLarge)
+// instead of letting its barriers spin.  A refusal is not an error of the solve: kCoopFallback.
+int coop_launch(const void *kernel, int nwg, void **args) {
+  hipError_t e = hipLaunchCooperativeKernel(kernel, dim3(nwg), dim3(kCoopBlock), args, 0, stream());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return kCoopFallback;
+  }
+  return PSP_OK;
+}
+
+bool coop_force_fail() {  // tests: behave as if a grid barrier had given up (PSP_TUNING=1 PSP_COOP_FAIL=1)
+  const char *e = tuning_env("PSP_COOP_FAIL");
+  return e && atoi(e) == 1;
+}
+
+}  // namespace
+
+// the operator as plain CSR arrays on this device, small enough for the single-kernel loops, and the grid fits the
+// device at once?
+bool coop_applicable(const psp_csr *A, int n) {
+  return coop_enabled() && A && !A->w4_only && !A->nparts && !A->multi && !A->host && A->ind && A->nrows == n &&
+         A->ncols == n && n >= 1 && n <= kCoopMaxRows && A->max_row_nnz <= kRegNz &&  // every row fits the registers
+         coop_grid(n) <= std::min(kCoopMaxWg, coop_capacity());
+}
+
+// On kCoopFallback x and r are what they were on entry (x is only written by a kernel that finished; r is restored from
+// the copy kept in q, which the single-kernel loop does not use) and the caller continues with its other loops.
 int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                   double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres,
                   double *hist) {
   CoopMem m;
   PSP_TRY(m.init(maxit, hist != nullptr));
-  const int nwg = coop_grid(n);
+  int nwg = coop_grid(n);
   (void)p;
-  (void)q;
-  hipLaunchKernelGGL(pcg_coop_kernel, dim3(nwg), dim3(kCoopBlock), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x, r,
-                     n2b, tolb, normr0, rho0, maxit, m.ctl, m.part, m.hist);
-  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipMemcpyAsync(q, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  const int *ind = A->ind, *col = A->col;
+  const double *val = A->val;
+  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &x, &r, &n2b, &tolb, &normr0, &rho0, &maxit, &m.ctl, &m.part, &m.hist};
+  int rc = coop_force_fail() ? kCoopFallback : coop_launch((const void *)pcg_coop_kernel, nwg, args);
   CoopCtl c;
-  PSP_TRY(m.fetch(&c));
+  if (rc == PSP_OK) rc = m.fetch(&c);
+  if (rc == kCoopFallback)
+    PSP_HIP(hipMemcpyAsync(r, q, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  if (rc != PSP_OK) return rc;
   *info = c.info;
   *iter = c.iter;
   *relres = c.relres;
@@ -453,26 +516,33 @@ int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double
   return PSP_OK;
 }
 
+// On kCoopFallback x, v_hat and y are what they were on entry (y is restored from the copy kept in av).
 int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old,
                      double *y, double *w, double *w_old, double *v, double *av, double norm_r0, double beta0,
                      double errtol, int it_max, int *info, int *iter, double *relres, double *hist) {
   CoopMem m;
   PSP_TRY(m.init(it_max, hist != nullptr));
-  const int nwg = coop_grid(n);
+  int nwg = coop_grid(n);
   (void)v_hat_old;
   (void)w;
   (void)w_old;
-  (void)av;
   double *yv = y;  // the vector that crosses workgroups: K v_hat, or v_hat itself without a preconditioner
   if (!dinv) {
     yv = v;
     PSP_HIP(hipMemcpyAsync(yv, v_hat, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  } else {
+    PSP_HIP(hipMemcpyAsync(av, y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   }
-  hipLaunchKernelGGL(minres_coop_kernel, dim3(nwg), dim3(kCoopBlock), 0, stream(), n, nwg, A->ind, A->col, A->val, dinv, x,
-                     v_hat, yv, norm_r0, beta0, errtol, it_max, m.ctl, m.part, m.hist);
-  PSP_LAUNCH_CHECK();
+  const int *ind = A->ind, *col = A->col;
+  const double *val = A->val;
+  const double *vh = v_hat;
+  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &x, &vh, &yv, &norm_r0, &beta0, &errtol, &it_max, &m.ctl, &m.part, &m.hist};
+  int rc = coop_force_fail() ? kCoopFallback : coop_launch((const void *)minres_coop_kernel, nwg, args);
   CoopCtl c;
-  PSP_TRY(m.fetch(&c));
+  if (rc == PSP_OK) rc = m.fetch(&c);
+  if (rc == kCoopFallback && dinv)
+    PSP_HIP(hipMemcpyAsync(y, av, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  if (rc != PSP_OK) return rc;
   *info = c.info;
   *iter = c.iter;
   if (c.info == 0 || c.info == -1) *relres = c.relres;

@@ -255,7 +255,10 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
-// psp_coop.hip: the whole loop as one kernel for small systems (grid barriers instead of dependent launches)
+// psp_coop.hip: the whole loop as one kernel for small systems (grid barriers instead of dependent launches).
+// The two loops return kCoopFallback (not an error; nothing was changed) when the cooperative launch is refused or a
+// grid barrier gives up: the caller then runs its launch-per-phase loop from the same vectors.
+constexpr int kCoopFallback = 1;
 bool coop_applicable(const psp_csr *A, int n);
 int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                   double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres,
@@ -300,5 +303,7 @@ int multi_minres(psp_mcsr *M, bool jacobi, int n, double *x_host, const double *
                  int *info, int *iter, double *relres, double *hist_host);
 int multi_describe(const psp_mcsr *M, char *buf, int cap);
 int ssor_apply_dev(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip
+// waits for the error word of the last application's brick sweeps (sticky across applications until reported)
+int ssor_error_check(psp_ssor *K);
 int ssor_apply_host(psp_ssor *K, const double *b, double *x);  // psp_ssor.hip: PSP_DEVICE=cpu, host arrays
 }  // namespace psp

@@ -1053,6 +1053,75 @@ int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_p
   return PSP_OK;
 }
 
+// The pieces of one iteration on their own (bench.py: `phases` of the single-process line): the slowest rank's stream
+// time per repetition of
+//   what 0  the ghost exchange alone (packing, peer copies on the copy streams, the compute streams wait for evH)
+//   what 1  the local product alone (all owned rows, ghost entries as they are: no exchange, no wait)
+//   what 2  one packed reduction of two doubles (RCCL all-reduce or the fold kernel), in stream order
+// psp_csr_multi_spmv_time is the product as a solver does it (0 overlapped with 1); overlap = (t0 + t1 - t_spmv) / t0.
+int psp_csr_multi_phase_time(psp_csr_t *A, int what, int warmup, int reps, double *ms_per_rep) {
+  PSP_API_GUARD;
+  if (!A || !A->multi || reps < 1 || warmup < 0 || !ms_per_rep || what < 0 || what > 2)
+    return fail(PSP_EINVAL, "psp_csr_multi_phase_time: needs a multi-device matrix, what in 0..2 and reps >= 1");
+  psp_mcsr *M = A->multi;
+  DeviceRestore keep;
+  Vecs mem;
+  std::vector<double *> vext(M->nranks), y(M->nranks);
+  for (int r = 0; r < M->nranks; ++r) {
+    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n_ext, &vext[r]));
+    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n, &y[r]));
+  }
+  std::vector<hipEvent_t> e0(M->nranks), e1(M->nranks);
+  for (int r = 0; r < M->nranks; ++r) {
+    M_HIP(hipSetDevice(M->r[r].dev));
+    M_HIP(hipEventCreate(&e0[r]));
+    M_HIP(hipEventCreate(&e1[r]));
+  }
+  int rc = PSP_OK;
+  for (int k = -warmup; k < reps && rc == PSP_OK; ++k) {
+    if (k == 0) {
+      rc = sync_all(M);
+      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r)
+        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e0[r], M->r[r].s) != hipSuccess) rc = PSP_ENODEV;
+    }
+    if (what == 0) {
+      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+        rc = use(M, r);
+        if (rc == PSP_OK) rc = guard_overwrite(M, r);
+      }
+      if (rc == PSP_OK) rc = exchange(M, vext.data());
+      for (int r = 0; r < M->nranks && rc == PSP_OK && M->nranks > 1; ++r)
+        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipStreamWaitEvent(M->r[r].s, M->r[r].evH, 0) != hipSuccess)
+          rc = PSP_ENODEV;
+    } else if (what == 1) {
+      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+        RankOp &R = M->r[r];
+        rc = use(M, r);
+        if (rc == PSP_OK && R.n)
+          rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr);
+      }
+    } else {
+      rc = allreduce(M, 0, 2);
+    }
+  }
+  double worst = 0.0;
+  for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+    float ms = 0.f;
+    if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e1[r], M->r[r].s) != hipSuccess ||
+        hipEventSynchronize(e1[r]) != hipSuccess || hipEventElapsedTime(&ms, e0[r], e1[r]) != hipSuccess)
+      rc = fail(PSP_ENODEV, "psp_csr_multi_phase_time: %s", hipGetErrorString(hipGetLastError()));
+    worst = std::max(worst, (double)ms);
+  }
+  for (int r = 0; r < M->nranks; ++r) {
+    (void)hipEventDestroy(e0[r]);
+    (void)hipEventDestroy(e1[r]);
+  }
+  if (rc != PSP_OK) return rc;
+  PSP_TRY(sync_all(M));
+  *ms_per_rep = worst / reps;
+  return PSP_OK;
+}
+
 int psp_multi_plan(int nrows, int ncols, const int *ind, const int *col, int ndev, int rank, int64_t *row_range_out,
                    int *counts_out, int *ghost_ids, int ghost_cap, int *links, int links_cap, int *col_local) {
   if (!ind || nrows < 0 || ndev < 1 || rank < 0 || rank >= ndev || !row_range_out || !counts_out)

@@ -199,6 +199,21 @@ int psp_device_count(void) {
   return cnt;
 }
 
+int psp_peer_access(int device, int peer, int *can_access) {
+  if (!can_access) return fail(PSP_EINVAL, "psp_peer_access: NULL argument");
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+    return fail(PSP_ENODEV, "no HIP device available; libpysparse_hip has no CPU fallback");
+  if (device < 0 || device >= cnt || peer < 0 || peer >= cnt)
+    return fail(PSP_EINVAL, "device %d / peer %d out of range (0..%d)", device, peer, cnt - 1);
+  if (device == peer) {
+    *can_access = 1;
+    return PSP_OK;
+  }
+  PSP_HIP(hipDeviceCanAccessPeer(can_access, device, peer));
+  return PSP_OK;
+}
+
 int psp_set_device(int device) {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)

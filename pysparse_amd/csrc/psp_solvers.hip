@@ -731,8 +731,10 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     return PSP_OK;
   }
 
-  if (fused && maxit >= 1 && coop_applicable(Acsr, n))  // small system: the whole loop is one kernel (psp_coop.hip)
-    return pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
+  if (fused && maxit >= 1 && coop_applicable(Acsr, n)) {  // small system: the whole loop is one kernel (psp_coop.hip)
+    const int rc = pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
+  }
   if (fused && maxit >= 1 && pcg_async_enabled() && csr_spmv_has_skip(Acsr)) {
     if (rho_next == 0.0) {  // pcg.c:101-104 in iteration 1
       *info = -2;
@@ -1170,10 +1172,12 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   double norm_rmr = norm_r0;
   if (hist) hist[0] = norm_rmr;
 
-  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n))
+  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n)) {
     // small system: the whole loop is one kernel (psp_coop.hip)
-    return minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0, beta,
-                            errtol, it_max, info, iter, relres, hist);
+    const int rc = minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
+                                    beta, errtol, it_max, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;  // refused / gave up: x, v_hat, y are untouched, the loops below take over
+  }
   if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
     // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
     return minres_async_loop(Acsr, dinv, hasK, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
@@ -2133,6 +2137,15 @@ static int check_solver_args(const psp_op *A, const psp_op *K, int n, const void
   return PSP_OK;
 }
 
+// After a solve: did every application of the preconditioner produce a valid vector?  The SSOR brick sweeps report a
+// sweep that gave up waiting through an error word that is read back asynchronously (psp_ssor.hip); the word is sticky
+// across applications, so one waited-for look after the solver's last launch covers all of them.
+static int precon_status(const psp_op *K) {
+  if (!K || K->kind != PSP_OP_SSOR || !K->ssor) return PSP_OK;
+  PSP_HIP(hipStreamSynchronize(stream()));
+  return ssor_error_check(K->ssor);
+}
+
 extern "C" {
 
 int psp_trim(void) {
@@ -2268,7 +2281,9 @@ int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **
     op.csr = A;
     return cpu::jacobi_create(A->nrows, d.data(), omega, steps, &op, out);
   }
-  if (A->multi) {  // dinv lives with the row blocks; the handle only says "jacobi of THIS matrix"
+  if (A->multi) {  // dinv lives with the row blocks; the handle says "jacobi of THIS matrix with THIS omega" -- every
+                   // use of the handle re-establishes its own omega there (multi_jacobi_setup is a no-op when the
+                   // factors in place are the handle's), so two handles with different omega never see each other's
     if (steps != 1) return fail(PSP_EINVAL, "jacobi of a multi-device matrix: steps must be 1");
     PSP_TRY(multi_jacobi_setup(A->multi, omega));
     psp_jacobi *K = new psp_jacobi();
@@ -2373,7 +2388,10 @@ int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
   PSP_API_GUARD;
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
   if (K->host) return cpu::jacobi_precon(K, x_host, y_host);
-  if (K->multi) return multi_jacobi_apply_host(K->multi, x_host, y_host);
+  if (K->multi) {
+    PSP_TRY(multi_jacobi_setup(K->multi, K->omega));
+    return multi_jacobi_apply_host(K->multi, x_host, y_host);
+  }
   PSP_TRY(ensure_device());
   DevVecs mem;
   double *x, *y;
@@ -2394,7 +2412,8 @@ int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, cons
   PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
-  return pcg_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
+  PSP_TRY(pcg_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host));
+  return precon_status(K);
 }
 
 int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
@@ -2403,7 +2422,10 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
   psp_mcsr *multi = nullptr;
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
-  if (multi) return multi_pcg(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  if (multi) {
+    if (multi_jac) PSP_TRY(multi_jacobi_setup(multi, K->jac->omega));  // this handle's omega, whatever was used last
+    return multi_pcg(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  }
   if (cpu_mode()) return cpu::pcg(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -2416,7 +2438,7 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
   PSP_TRY(pcg_device(A, K, n, x, b, tol, maxit, info, iter, relres, hist_host));
   PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  return PSP_OK;
+  return precon_status(K);
 }
 
 int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
@@ -2425,7 +2447,8 @@ int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
   PSP_API_GUARD;
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
-  return minres_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host);
+  PSP_TRY(minres_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host));
+  return precon_status(K);
 }
 
 int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
@@ -2434,7 +2457,10 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
   psp_mcsr *multi = nullptr;
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
-  if (multi) return multi_minres(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  if (multi) {
+    if (multi_jac) PSP_TRY(multi_jacobi_setup(multi, K->jac->omega));
+    return multi_minres(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
+  }
   if (cpu_mode()) return cpu::minres(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -2447,7 +2473,7 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
   PSP_TRY(minres_device(A, K, n, x, b, tol, maxit, info, iter, relres, hist_host));
   PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  return PSP_OK;
+  return precon_status(K);
 }
 
 // ---------------------------------------------------------------- cgs / bicgstab / qmrs / gmres
@@ -2468,7 +2494,7 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
     PSP_TRY(CALL);                                                                               \
     PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));                  \
     PSP_HIP(hipStreamSynchronize(stream()));                                                     \
-    return PSP_OK;                                                                               \
+    return precon_status(K);                                                                     \
   }
 
 PSP_HOST_SOLVER(psp_cgs, cgs_device(A, K, n, x, b, tol, maxit, info, iter, relres))
@@ -2491,7 +2517,7 @@ int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const
   PSP_TRY(gmres_device(A, K, n, x, b, tol, maxit, dim, info, iter, relres));
   PSP_HIP(hipMemcpyAsync(x_host, x, bytes, hipMemcpyDeviceToHost, stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
-  return PSP_OK;
+  return precon_status(K);
 }
 
 }  // extern "C"

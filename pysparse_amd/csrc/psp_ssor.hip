@@ -878,12 +878,14 @@ __global__ __launch_bounds__(256) void brick_first_gd_kernel(int n, const int *_
   gd[t] = make_double2(bt - 0.0, dar[t]);
 }
 
-// clears a sweep's flags (done words, hand-out counter, error word).  A kernel, not a memset: inside the captured graph
+// clears a sweep's flags (done words, hand-out counter) -- NOT the error word: that one is sticky across applications
+// until the host has reported it (brick_error_check), so that a solver, which looks once after its last application,
+// cannot miss a sweep that gave up earlier in the solve.  A kernel, not a memset: inside the captured graph
 // of an application a memset node was not ordered before the brick kernel behind it on every HIP runtime (the one PyTorch
 // brings along replayed them concurrently: a second application then found its predecessors "done" from the first)
 __global__ __launch_bounds__(256) void brick_begin_kernel(int count, int *__restrict__ flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) flags[i] = 0;
+  if (i < count && i != kFlagStride) flags[i] = 0;
 }
 
 template <bool MINUS, bool BACK, int W, int D>
@@ -1016,7 +1018,10 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_kernel(int nbricks, con
         lds_barrier();
       }
     }
-    // ---- done: this brick's x has left the CU before the flag says so
+    // ---- done: this brick's x has left the CU before the flag says so.  Every wave drains its own vector-memory
+    // counter: a workgroup-scope release fence emits no s_waitcnt vmcnt on gfx9 (non-tgsplit mode), so without this the
+    // sc1 stores of waves other than the publishing one could still be in flight when another XCD sc1-loads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(PSP_FLAG_BRICK(flags, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1203,6 +1208,7 @@ __global__ __launch_bounds__(kBrickTick) void ssor_brick_pipe_kernel(
           __hip_atomic_store(PSP_FLAG_BRICK(flags, b), min(k + j - D + 1, nticks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its last ticks' stores have left (see above)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(PSP_FLAG_BRICK(flags, b), nticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1583,8 +1589,13 @@ static int brick_error_check(psp_ssor *K, bool wait) {
   }
   K->brick_ev_pending = false;
   if (e != hipSuccess) return fail(PSP_ENODEV, "ssor: %s", hipGetErrorString(e));
-  if (K->brick_err_host[0] | K->brick_err_host[1])
+  if (K->brick_err_host[0] | K->brick_err_host[1]) {
+    // reported once: the words are cleared so that the handle can be used again
+    K->brick_err_host[0] = K->brick_err_host[1] = 0;
+    (void)hipMemsetAsync(PSP_FLAG_ERR(K->brick_f.flags), 0, sizeof(int), stream());
+    (void)hipMemsetAsync(PSP_FLAG_ERR(K->brick_b.flags), 0, sizeof(int), stream());
     return fail(PSP_ENODEV, "ssor: a brick sweep gave up waiting for its predecessors; the preconditioned vector is invalid");
+  }
   return PSP_OK;
 }
 

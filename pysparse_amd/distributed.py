@@ -786,6 +786,25 @@ class DistCSR:
         sends, recvs = self._halo_ops(v_ext)
         self.comm.exchange(sends, recvs)
 
+    def halo_time(self, v_ext, reps=10, warmup=2):
+        """milliseconds per ghost exchange on its own (posted, completed, nothing else in flight): what the interior
+        rows have to hide.  Collective: every rank calls it."""
+        import time
+        cuda = bool(getattr(v_ext, "is_cuda", False))
+        for k in range(-warmup, reps):
+            if k == 0:
+                if cuda:
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                t0 = time.perf_counter()
+            self.halo_exchange(v_ext)
+        if cuda:
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        return (time.perf_counter() - t0) * 1e3 / reps
+
     def matvec(self, v_ext, y, want_dot=False):
         """y = A v for the owned rows; v_ext's owned part must be current.  The ghost
         exchange is started first and overlapped with the rows that need no ghost entry.
@@ -800,16 +819,73 @@ class DistCSR:
         return self.be.matvec_overlap(self.A, v_ext, self.plan.p_offset, y, self.plan.interior, wait, want_dot)
 
 
-def _matvec_state(A, kd, st, v_ext, y):
+class PhaseTimer:
+    """Where the time of one iteration goes (bench.py `phases`): marks between the phases of the device-scalar loops.
+    Device tensors: a torch.cuda.Event per mark on the current stream -- the stream the library's kernels are
+    enqueued on and the RCCL collectives synchronise with -- so a difference of two marks is time on the GPU's own
+    timeline (a mark behind `wait()` completes when the ghost entries have arrived AND the interior rows are done: what
+    is left of it after the interior rows is the part of the halo exchange the interior rows did not hide).  CPU
+    tensors (the gloo dry runs): host clock."""
+
+    PHASES = ("px_update", "spmv_interior", "halo_exposed", "spmv_boundary", "allreduce_1", "scalar_1", "r_update",
+              "allreduce_2", "scalar_2")
+
+    def __init__(self, cuda):
+        self.cuda = bool(cuda)
+        self.iters = []
+        self.cur = None
+
+    def begin(self):
+        self.cur = []
+        self.iters.append(self.cur)
+        self.mark("begin")
+
+    def mark(self, name):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.cur.append((name, e))
+        else:
+            import time
+            self.cur.append((name, time.perf_counter()))
+
+    def summary(self, skip=2):
+        """mean milliseconds per phase over the recorded iterations (the first `skip` are warm-up)"""
+        if self.cuda:
+            torch.cuda.synchronize()
+        acc, cnt = {}, 0
+        for marks in self.iters[skip:] or self.iters:
+            cnt += 1
+            for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+                dt = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+                acc[name] = acc.get(name, 0.0) + dt
+        out = {k: v / max(cnt, 1) for k, v in acc.items()}
+        out["iteration"] = sum(out.values())
+        out["iterations_timed"] = cnt
+        return out
+
+
+def _matvec_state(A, kd, st, v_ext, y, timer=None):
     """y = A v for the owned rows through a state-driven kernel (kd = be.kd_matvec_overlap or
     be.kd_minres_matvec): the ghost exchange is started first and overlapped with the interior rows;
     the local v_owned . y lands in be.scal[0]"""
     if A.comm.world == 1:
         kd(st, A.A, v_ext, A.plan.p_offset, y, (0, A.n_local), None)
+        if timer is not None:
+            timer.mark("spmv_interior")
         return
     sends, recvs = A._halo_ops(v_ext)
     wait = A.comm.exchange_start(sends, recvs)
+    if timer is not None:
+        inner = wait
+
+        def wait():  # called by the kernel driver between the interior and the boundary rows
+            timer.mark("spmv_interior")
+            inner()
+            timer.mark("halo_exposed")
     kd(st, A.A, v_ext, A.plan.p_offset, y, A.plan.interior, wait)
+    if timer is not None:
+        timer.mark("spmv_boundary")
 
 
 def _tuning(name, default):
@@ -824,10 +900,11 @@ def dist_pcg_mode():
     return "host scalars, lazy x update" if _tuning("PSP_DIST_LAZYX", "1") != "0" else "host scalars, eager"
 
 
-def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
+def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None, timer=None):
     """info, iter, relres = dist_pcg(A: DistCSR, b, x, tol, maxit, dinv) on the owned slices; see
     _dist_pcg.  A dinv slice that holds one value everywhere (constant-diagonal operator) is
-    announced to the vector kernels for the duration of the solve (psp_k_hint_constant)."""
+    announced to the vector kernels for the duration of the solve (psp_k_hint_constant).
+    timer: a PhaseTimer that receives one set of marks per iteration (device-scalar loop only)."""
     if hasattr(A.be, "bind_current_stream"):
         A.be.bind_current_stream()
     hint = getattr(A.be, "hint_constant", None) if dinv is not None else None
@@ -836,7 +913,9 @@ def dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
     lazy = hasattr(A.be, "px_update") and _tuning("PSP_DIST_LAZYX", "1") != "0"
     devs = hasattr(A.be, "kd_px_update") and _tuning("PSP_DIST_DEVSCALARS", "1") != "0"
     try:
-        return (_dist_pcg_dev if devs else _dist_pcg_lazy if lazy else _dist_pcg)(A, b, x, tol, maxit, dinv, hist)
+        if devs:
+            return _dist_pcg_dev(A, b, x, tol, maxit, dinv, hist, timer)
+        return (_dist_pcg_lazy if lazy else _dist_pcg)(A, b, x, tol, maxit, dinv, hist)
     finally:
         if hint is not None:
             A.be.unhint(dinv)
@@ -999,7 +1078,7 @@ def _dist_pcg(A, b, x, tol, maxit, dinv=None, hist=None):
 PCG_BATCH = 16  # iterations enqueued between two reads of the device state
 
 
-def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None):
+def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None, timer=None):
     """_dist_pcg_lazy with the scalars on the device: per iteration the host only enqueues -- px update,
     SpMV around the halo exchange, all-reduce #1 {p.q, nonstag} (in stream order), the scalar step that
     takes pcg.c:159-162 / :101-125's branches, r update, all-reduce #2 {r.r, r.z}, the scalar step of
@@ -1036,13 +1115,27 @@ def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None):
         while True:
             batch = max(1, min(PCG_BATCH, maxit - enq))
             for _ in range(batch):
+                if timer is not None:
+                    timer.begin()
                 be.kd_px_update(st, r, dinv, p, x)                      # -> scal[1]
-                _matvec_state(A, be.kd_matvec_overlap, st, p_ext, q)    # -> scal[0]
+                if timer is not None:
+                    timer.mark("px_update")
+                _matvec_state(A, be.kd_matvec_overlap, st, p_ext, q, timer)  # -> scal[0]
                 comm.allreduce_sum(be.scal[0:2])                        # all-reduce #1
+                if timer is not None:
+                    timer.mark("allreduce_1")
                 be.kd_pcg_scalar_xpq(st)
+                if timer is not None:
+                    timer.mark("scalar_1")
                 be.kd_r_update(st, q, dinv, r)                          # -> scal[2:4]
+                if timer is not None:
+                    timer.mark("r_update")
                 comm.allreduce_sum(be.scal[2:4])                        # all-reduce #2
+                if timer is not None:
+                    timer.mark("allreduce_2")
                 be.kd_pcg_scalar_r(st)
+                if timer is not None:
+                    timer.mark("scalar_2")
             enq += batch
             f = st.fetch()
             if f.status:

@@ -1347,17 +1347,14 @@ static PyObject *Mtx_read_coordinate(PyObject *module, PyObject *args) {
   }
   Py_BEGIN_ALLOW_THREADS
   for (t = 1; t < T; t++)
-    if (pthread_create(&th[t], NULL, mtx_count_worker, &ch[t]) != 0) err = 3;
-  if (!err) {
-    mtx_count_worker(&ch[0]);
-    for (t = 1; t < T; t++) pthread_join(th[t], NULL);
-  }
+    if (pthread_create(&th[t], NULL, mtx_count_worker, &ch[t]) != 0) {
+      mtx_count_worker(&ch[t]); /* no thread: count this chunk here; buf stays alive until every started thread is joined */
+      th[t] = 0;
+    }
+  mtx_count_worker(&ch[0]);
+  for (t = 1; t < T; t++)
+    if (th[t]) pthread_join(th[t], NULL);
   Py_END_ALLOW_THREADS
-  if (err) {
-    free(buf);
-    PyErr_SetString(PyExc_RuntimeError, "mtx_read_coordinate: cannot start a thread");
-    return NULL;
-  }
   for (t = 0; t < T; t++) {
     ch[t].off = total;
     total += ch[t].cnt;

@@ -35,6 +35,13 @@ def test_library_was_built_from_the_sources_on_disk():
     assert _capi.lib().psp_build_id().decode() == G.source_hash()
 
 
+@pytest.mark.gpu
+def test_library_on_the_gpu_box_was_built_from_the_sources_on_disk():
+    """the same check where it matters: under `-m gpu` on the GPU box, where the .so is a prebuilt file that travelled
+    with the snapshot -- the library the GPU tests load must answer the hash of the sources lying next to it."""
+    test_library_was_built_from_the_sources_on_disk()
+
+
 def test_no_cpu_fallback_without_gpu():
     from pysparse_amd import _capi, device
     if device.device_count() > 0:

@@ -91,16 +91,24 @@ def test_single_kernel_loops_against_the_launch_per_phase_loops():
         "print(json.dumps(out))"
     ) % ROOT
     res = []
-    for env in ({}, {"PSP_TUNING": "1", "PSP_COOP": "0"}):
+    # {}: the single-kernel loops; PSP_COOP=0: the launch-per-phase loops; PSP_COOP_FAIL=1: a grid barrier "gave up" (the
+    # kernel is not launched, the fall-back path restores r / y and runs the launch-per-phase loops); PSP_COOP_CAPACITY=4:
+    # the device "holds" four workgroups at once, so only systems of <= 4096 rows are taken
+    for env in ({}, {"PSP_TUNING": "1", "PSP_COOP": "0"}, {"PSP_TUNING": "1", "PSP_COOP_FAIL": "1"},
+                {"PSP_TUNING": "1", "PSP_COOP_CAPACITY": "4"}):
         e = dict(os.environ)
         e.update(env)
         p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
         res.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    for a, b in zip(*res):
+    for a, b in zip(res[0], res[1]):
         assert a[:2] == b[:2], (a[:3], b[:3])
         assert abs(a[2] - b[2]) <= 1e-6 * b[2]
         assert np.abs(np.array(a[4]) - np.array(b[4])).max() <= 1e-12 * b[3]
+    # a refused / failed single-kernel loop IS the launch-per-phase loop from the same vectors: the same bits
+    assert res[2] == res[1]
+    # capacity 4: every system here has more than 4096 rows -> launch-per-phase loops throughout
+    assert res[3] == res[1]
 
 
 def test_reference_goldens_at_config0_size(oracle, golden_dir):

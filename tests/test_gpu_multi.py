@@ -94,6 +94,31 @@ def test_poisson_slabs_on_ranks_sharing_the_gpu(oracle, ranks):
         assert dev.minres(AM, b, np.ones(n), 1e-9, 0)[:2] == oracle.minres(O, b, np.ones(n), 1e-9, 0)[:2]
 
 
+def test_two_jacobi_handles_of_one_multi_device_matrix_keep_their_own_omega(oracle):
+    """the Jacobi factors of a multi-device matrix live with its row blocks; a second precon.jacobi(A, omega2) must not
+    change what the first handle applies (preconmodule.c:352-412: dinv belongs to the jacobi object)"""
+    from pysparse_amd import device as dev
+    O = oracle.poisson_csr(24, 20, 0)
+    n = O.shape[0]
+    AM = dev.DeviceCSR.poisson_multi(24, 20, devices=[0, 0, 0])
+    K1 = dev.DeviceJacobi(AM, 1.0)
+    K2 = dev.DeviceJacobi(AM, 0.5)   # replaces the factors on the row blocks ...
+    x = np.random.default_rng(2).standard_normal(n)
+    for K, omega in ((K1, 1.0), (K2, 0.5), (K1, 1.0)):   # ... and every use re-establishes the handle's own
+        y = np.empty(n)
+        K.precon(x, y)
+        assert np.array_equal(y, x * oracle.jacobi_dinv(O.diagonal(), omega))
+    b = np.empty(n)
+    O.matvec(np.ones(n), b)
+    for K, omega in ((K2, 0.5), (K1, 1.0), (K2, 0.5)):
+        for solver, osolver in ((dev.pcg, oracle.pcg), (dev.minres, oracle.minres)):
+            xo, xm = np.zeros(n), np.zeros(n)
+            ro = osolver(O, b, xo, 1e-30, 7, oracle.jacobi_dinv(O.diagonal(), omega))
+            rm = solver(AM, b, xm, 1e-30, 7, K)
+            assert rm[:2] == ro[:2]
+            assert relerr(xm, xo) < 1e-12
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_general_csr_row_blocks(oracle, ranks):
     """irregular coupling across the partition (log-spaced bands: scattered ghost sets, gathered send lists) and a
