@@ -131,7 +131,70 @@ def _mem_available_gb():
 REF_PCG_TOL = 1e-9  # max-norm relative difference allowed between the reference's and the port's PCG iterates
 
 
-def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref):
+def parity_bound(n, k):
+    """How far two correct implementations of the same k Krylov iterations may be apart at n unknowns when they differ
+    only in the ORDER of their dot-product sums (sequential loop, OpenBLAS kernels, the GPU's fixed tree): every
+    reduction of n terms carries ~sqrt(n) eps of order-dependent rounding, each iteration passes it on through alpha /
+    beta, so the iterates drift apart like k sqrt(n) eps; 32 is the head-room over what is measured CPU-against-CPU
+    (the oracle against the compiled reference pcg.c with OpenBLAS: 4.9e-11 at 512^3 / k = 3 where this gives 2.5e-10;
+    1.0e-12 at 4096^2 / k = 10 where it gives 2.9e-10).  north_star's 1e-12 is what the golden-size cases (n <= 3e5)
+    are held to; this is the size-dependent form of the same bar."""
+    return 32.0 * k * float(np.sqrt(n)) * 2.220446049250313e-16  # eps = 2^-52
+
+
+def _maxrel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, with_ref=True, x_ref=None, res_ref=None):
+    """`parity_check` of the bench line and tests/test_gpu_reference_sizes.py: k iterations (tol = 0) of Jacobi-PCG and
+    Jacobi-MINRES on the GPU (through the host-pointer entry points, as the drop-in modules call them) against the
+    oracle's iterates on the same system -- and against the compiled reference PCG when oracle/_ref was built.
+    A / b / x_pcg / res_pcg: what the CPU leg already holds for this grid (else they are made here)."""
+    if A is None:
+        A = O.poisson_csr(*grid)
+    n = A.shape[0]
+    if b is None:
+        b = np.empty(n)
+        A.matvec(np.ones(n), b)
+    dinv = np.full(n, 1.0 / (6.0 if grid[2] else 4.0))
+    if x_pcg is None:
+        x_pcg = np.zeros(n)
+        res_pcg = O.pcg(A, b, x_pcg, 0.0, k, dinv)
+    x_min = np.zeros(n)
+    res_min = O.minres(A, b, x_min, 0.0, k, dinv)
+    G = dev.DeviceCSR.poisson(*grid)
+    K = dev.DeviceJacobi(G)
+    bound = parity_bound(n, k)
+    out = {"grid": list(grid), "n": n, "k": k, "bound": bound}
+    ok = True
+    for name, solver, ref_res, ref_x in (("pcg", dev.pcg, res_pcg, x_pcg), ("minres", dev.minres, res_min, x_min)):
+        xg = np.zeros(n)
+        rg = solver(G, b, xg, 0.0, k, K)
+        rec = {"info_iter_gpu": [rg[0], rg[1]], "info_iter_oracle": [ref_res[0], ref_res[1]],
+               "relres_rel_diff": rel_diff(rg[2], ref_res[2]), "x_max_rel_diff": _maxrel(xg, ref_x)}
+        rec["ok"] = bool(rec["info_iter_gpu"] == rec["info_iter_oracle"] and rec["relres_rel_diff"] <= bound
+                         and rec["x_max_rel_diff"] <= bound)
+        if name == "pcg" and with_ref and O.have_ref():
+            xr, rr = x_ref, res_ref
+            if xr is None:
+                xr = np.zeros(n)
+                rr = O.ref_pcg(A, b, xr, 0.0, k, dinv)
+            rec["vs_reference_pcg"] = {"info_iter_reference": [rr[0], rr[1]], "relres_rel_diff": rel_diff(rg[2], rr[2]),
+                                       "x_max_rel_diff": _maxrel(xg, xr),
+                                       "oracle_vs_reference_x_max_rel_diff": _maxrel(ref_x, xr)}
+            rec["ok"] = bool(rec["ok"] and [rr[0], rr[1]] == rec["info_iter_gpu"]
+                             and rec["vs_reference_pcg"]["x_max_rel_diff"] <= bound)
+        ok = ok and rec["ok"]
+        out[name] = rec
+        del xg
+    K.close()
+    G.close()
+    out["ok"] = ok
+    return out
+
+
+def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None):
     """oracle (C restatement of csr_mat.c:49-54 + pcg.c, gcc -O2, ONE thread) and, when it was built,
     the compiled reference PCG (oracle/_ref/libref_pcg.so = examples/poisson_test/pcg.c unmodified)"""
     t0 = time.perf_counter()
@@ -159,20 +222,25 @@ def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref):
     out = {"n": n, "nnz": nnz, "spmv_GBps": csr_model_bytes(n, nnz) / t_spmv / 1e9, "spmv_ms": t_spmv * 1e3,
            "pcg_iters_per_s": 1.0 / t_pcg, "generate_s": gen_s,
            "sample": "median of %d SpMV; %d Jacobi-PCG iterations (tol 0)" % (spmv_reps, min(res[1], pcg_iters))}
+    xr = rres = None
     if with_ref and O.have_ref():
         xr = np.zeros(n)
         t = time.perf_counter()
-        O.ref_pcg(A, b, xr, 0.0, pcg_iters, dinv)
+        rres = O.ref_pcg(A, b, xr, 0.0, pcg_iters, dinv)
         out["reference_pcg_iters_per_s"] = (min(res[1], pcg_iters) + 1) / (time.perf_counter() - t)
         # same algorithm, different BLAS-1 (OpenBLAS kernels vs the port's serial loops): the two dot products
         # of n terms differ by ~sqrt(n) eps relative, so the iterates agree to that, not to the bit
         diff = float(np.abs(xr - xs).max() / max(np.abs(xs).max(), 1e-300))
         out["reference_pcg_max_rel_diff_vs_port"] = diff
         out["reference_pcg_matches_port"] = bool(diff <= REF_PCG_TOL)
+    if dev is not None and res[1] == pcg_iters + 1:
+        # the same k iterations on the GPU against the iterates this leg already holds (`parity_check` of the line)
+        out["gpu_parity"] = gpu_parity_case(dev, O, grid, pcg_iters, A=A, b=b, x_pcg=xs, res_pcg=res, with_ref=with_ref,
+                                            x_ref=xr, res_ref=rres)
     return out
 
 
-def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256)):
+def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256), dev=None):
     """`cpu_baseline` (kind "port": the oracle's SpMV -- the reference's csr_mat.c needs the Python-2
     C API and cannot be compiled) and `cpu_baseline_reference_pcg` (kind "reference": the reference's
     own pcg.c, compiled unmodified, driven by the oracle's CSR matvec callback).  Sizes: C2 (4096^2)
@@ -180,12 +248,12 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
     from oracle import oracle as O
     t0 = time.time()
     c1 = _cpu_case(O, (100, 100, 0), 200, 2000, True)  # configs[0]: the reference's own CPU-runnable case
-    c2 = _cpu_case(O, c2_grid, 10, 10, True)
+    c2 = _cpu_case(O, c2_grid, 10, 10, True, dev)
     # C3 costs ~11x C2's generation + ~10x its per-pass time
     predicted = 11.2 * c2["generate_s"] + 10.5 * (5 * c2["spmv_ms"] * 1e-3 + 2 * 5 / c2["pcg_iters_per_s"])
     big = _mem_available_gb() > 48 and predicted < budget_s
     grid3 = c3_grid if big else c3_small
-    c3 = _cpu_case(O, grid3, 3 if big else 5, 3 if big else 10, True)
+    c3 = _cpu_case(O, grid3, 3 if big else 5, 3 if big else 10, True, dev)
     model, nproc = _cpu_model(), os.cpu_count()
     head = c3 if big else c2
     base = {
@@ -213,7 +281,17 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
                "iterates_tolerance": REF_PCG_TOL,
                "iterates_max_rel_diff": max(c2.get("reference_pcg_max_rel_diff_vs_port", 0.0),
                                             c3.get("reference_pcg_max_rel_diff_vs_port", 0.0))}
-    return base, ref
+    parity = None
+    if dev is not None:
+        cases = {name: c.pop("gpu_parity") for name, c in (("C2_poisson2d_%d" % c2_grid[0], c2),
+                                                           (("C3_poisson3d_%d" % c3_grid[0]) if big else
+                                                            "poisson3d_%d" % c3_small[0], c3)) if "gpu_parity" in c}
+        parity = {"what": "k iterations (tol = 0) of Jacobi-PCG and Jacobi-MINRES on the GPU against the oracle's iterates "
+                          "of the same system (b = A*ones, x0 = 0), and against the compiled reference pcg.c where "
+                          "oracle/_ref exists: equal (info, iter); relres and max-norm of x within `bound`",
+                  "bound": "32 k sqrt(n) eps, eps = 2^-52 (bench.parity_bound; DESIGN.md section 7)",
+                  "cases": cases, "ok": bool(cases) and all(c["ok"] for c in cases.values())}
+    return base, ref, parity
 
 
 def live_traffic(grid, variant):
@@ -400,6 +478,14 @@ def _run_stage(cmd, env, timeout_s, log):
     return (p.returncode if p.returncode is not None else -9), out, err[-3000:], time.time() - t0, timed_out
 
 
+def _err_tail(err, keep=14):
+    """the lines of a failed stage's stderr worth keeping: the last exception lines of the ranks before torchrun's
+    summary table, then the end"""
+    lines = [l for l in err.strip().splitlines() if l.strip()]
+    hits = [l for l in lines if ("Error" in l or "error:" in l.lower() or "injected failure" in l) and "error_file" not in l]
+    return (hits[-6:] + lines[-(keep - min(len(hits), 6)):])[-keep:]
+
+
 def orchestrate(a, argv):
     """`python bench.py --gpus N` (N > 1) called as a plain script.  Runs the ladder inside `--deadline` seconds, prints
     ONE JSON line -- the winning stage's, with `launcher` saying which stage produced it and what the earlier ones
@@ -445,7 +531,7 @@ def orchestrate(a, argv):
             return 0
         reason = ("timed out after %.0f s" % wall) if timed_out else (
             (rec or {}).get("error") or "exit code %d" % rc)
-        tail = [l for l in err.strip().splitlines() if l.strip()][-6:]
+        tail = _err_tail(err)
         failed.append({"stage": stage, "rc": rc, "reason": reason, "wall_s": wall, "stderr_tail": tail})
         log("stage %s failed: %s" % (stage, reason))
         for l in tail:
@@ -576,6 +662,29 @@ def strong_n1_leg(L, check, dev, grid, iters):
     A.close()
     check(L.psp_trim())
     return out
+
+
+def dry_strong_n1(test_backend, grid):
+    """CPU dry run of the launcher (tests): the parity reference = the same system solved by the test backend without
+    a partition (SingleComm), PARITY_ITERS iterations"""
+    import importlib
+    from pysparse_amd import distributed as D
+    mod, fn = test_backend.split(":")
+    be, make_local = getattr(importlib.import_module(mod), fn)()
+    nx, ny, nz = grid
+    A = D.DistCSR.poisson(nx, ny, nz, D.SingleComm(), be, make_local)
+    n = A.n_local
+    ones = A.new_ext()
+    ones.fill_(1.0)
+    b = be.zeros(n)
+    A.matvec(ones, b)
+    dinv = be.zeros(n)
+    dinv.fill_(1.0 / (6.0 if nz > 0 else 4.0))
+    x = be.zeros(n)
+    res = D.dist_pcg(A, b, x, 0.0, PARITY_ITERS, dinv)
+    return {"grid": [nx, ny, nz], "n": n, "path": "test backend, world size 1",
+            "parity_solve": {"relres": res[2], "x_dot_b": float(be.dot(x, b)[0]), "x_dot_x": float(be.dot(x, x)[0]),
+                             "info_iter": [res[0], res[1]]}}
 
 
 def single_process_main(a):
@@ -722,12 +831,26 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs from ONE process through the C ABI's device-list variant (psp_csr_poisson_multi) "
                          "instead of one torch.distributed rank per GPU")
+    ap.add_argument("--ladder", default="",
+                    help="N > 1 as a plain script: comma-separated stages to try in order (default: %s)" % ",".join(LADDER))
+    ap.add_argument("--deadline", type=float, default=540.0,
+                    help="N > 1 as a plain script: seconds the whole ladder may take; a line (result or error) is "
+                         "printed before it passes")
+    ap.add_argument("--stage-timeout", type=float, default=0.0,
+                    help="N > 1 as a plain script: time-out of every stage in seconds (default: per-stage caps inside "
+                         "--deadline)")
+    ap.add_argument("--stage", default="", help="set by the ladder: which stage this process is")
+    ap.add_argument("--inject", default="",
+                    help="failure injection for the launcher tests: exit:RANK (that rank leaves with code 3 after the "
+                         "process group formed) or hang:RANK (that rank sleeps instead of taking part)")
+    ap.add_argument("--no-phases", action="store_true", help="skip the per-phase timing of an N > 1 iteration")
     a = ap.parse_args()
 
     if a.single_process:
-        return single_process_main(a)
+        raise SystemExit(single_process_main(a))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(sys.argv[1:], a.gpus))
+        argv = [t for t in sys.argv[1:]]
+        raise SystemExit(orchestrate(a, argv))
 
     # ONE JSON line on stdout: RCCL / HIP print banners to file descriptor 1, so everything this process
     # (and the libraries it loads) writes to stdout goes to stderr, and rank 0's line to the real stdout
@@ -771,6 +894,7 @@ def main():
     L, check = _capi.lib(), _capi.check
 
     strong_n1 = None
+    exit_code = 0
     dry = bool(a.test_backend)
     if use_dist:
         from pysparse_amd import distributed as D
@@ -796,9 +920,30 @@ def main():
             make_local = dev.DeviceCSR.poisson_big_slab if scaling == "strong" else dev.DeviceCSR.poisson_slab
             dev_sync = torch.cuda.synchronize
         comm = D.Comm()
-        if scaling == "strong" and world > 1 and rank == 0 and not a.no_strong_n1 and not dry:
-            # the 1-GPU end of the strong-scaling ratio, measured in this job on rank 0's GPU
-            strong_n1 = strong_n1_leg(L, check, dev, (nx, ny, nz), min(a.pcg_iters, 24))
+        if a.inject:  # launcher tests: a rank that dies / a rank that never arrives, after the group has formed
+            kind, _, who = a.inject.partition(":")
+            if int(who or -1) == rank:
+                if kind == "exit":
+                    print("[bench] injected failure: rank %d exits" % rank, file=sys.stderr, flush=True)
+                    os._exit(3)
+                if kind == "hang":
+                    print("[bench] injected failure: rank %d sleeps" % rank, file=sys.stderr, flush=True)
+                    time.sleep(1e6)
+        preflight = None
+        if rank == 0:
+            preflight = {"world": world, "backend": dist.get_backend()}
+            if not dry:
+                ndev = L.psp_device_count()
+                preflight["device_count"] = ndev
+                preflight["peer_access"] = peer_matrix(L, 1 if a.share_gpu else min(ndev, world))
+                if world > 1 and not a.share_gpu:
+                    preflight["link_topology"] = link_topology()
+        if scaling == "strong" and world > 1 and rank == 0 and not a.no_strong_n1:
+            # the 1-GPU end of the strong-scaling ratio and of the parity check, measured in this job on rank 0's GPU
+            if dry:
+                strong_n1 = dry_strong_n1(a.test_backend, (nx, ny, nz))
+            else:
+                strong_n1 = strong_n1_leg(L, check, dev, (nx, ny, nz), min(a.pcg_iters, 24))
         comm.barrier()
         A = D.DistCSR.poisson(nx, ny, nz, comm, be, make_local)
         Aloc = A.A
@@ -929,18 +1074,48 @@ def main():
         del ones
         dinv = be.zeros(n_loc)
         dinv.fill_(1.0 / (6.0 if nz > 0 else 4.0))  # constant diagonal of the Poisson operator
-        for kk in (2, k):  # first call = warm-up
+        parity_mine = None
+        for kk in (PARITY_ITERS, k):  # first call = warm-up and the in-job parity solve
             xs = be.zeros(n_loc)
             sync()
             t = time.perf_counter()
             res = D.dist_pcg(A, b, xs, 0.0, kk, dinv)
             sync()
             pcg_t = time.perf_counter() - t
+            if parity_mine is None:
+                # checksums of x after PARITY_ITERS iterations: x.b and x.x, summed over the ranks
+                cs = torch.stack([be.dot(xs, b).reshape(()).clone(), be.dot(xs, xs).reshape(()).clone()])
+                comm.allreduce_sum(cs)
+                cs = cs.tolist()
+                parity_mine = {"relres": res[2], "x_dot_b": cs[0], "x_dot_x": cs[1], "info_iter": [res[0], res[1]]}
         pcg_s_per_iter = pcg_t / k
         pcg_path = "pysparse_amd.distributed.dist_pcg (row-range driver, %s)" % D.dist_pcg_mode()
+        # where the time of an iteration goes: marks between the phases of the same loop (events on the stream the
+        # kernels and the collectives are ordered on), + the ghost exchange on its own
+        phases = None
+        if not a.no_phases and world > 1:
+            timer = D.PhaseTimer(cuda=not dry)
+            xs = be.zeros(n_loc)
+            D.dist_pcg(A, b, xs, 0.0, 12, dinv, timer=timer)
+            phases = timer.summary(skip=2)
+            pe = A.new_ext()
+            phases["halo_ms"] = A.halo_time(pe, reps=10)
+            del pe
+            tp = torch.tensor([phases.get(kx, 0.0) for kx in D.PhaseTimer.PHASES] + [phases["halo_ms"], phases["iteration"]],
+                              dtype=torch.float64, device="cpu" if dry else "cuda")
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)  # the slowest rank per phase
+            tp = tp.tolist()
+            phases = {kx + "_ms": tp[i] for i, kx in enumerate(D.PhaseTimer.PHASES)}
+            phases["halo_ms"], phases["iteration_ms"] = tp[-2], tp[-1]
+            phases["allreduce_us"] = [phases["allreduce_1_ms"] * 1e3, phases["allreduce_2_ms"] * 1e3]
+            if phases["halo_ms"] > 0:
+                phases["overlap_frac"] = max(0.0, min(1.0, 1.0 - phases["halo_exposed_ms"] / phases["halo_ms"]))
+            phases["note"] = ("max over ranks of the mean per phase over 10 iterations; halo_exposed = what the boundary "
+                              "rows still wait for after the interior rows; halo_ms = one ghost exchange on its own")
     else:
         pcg_s_per_iter, res = pcg_single(L, check, dev, A, n_loc, k, sync)
         pcg_path = "psp_pcg_dev (single-GPU device-resident loop)"
+        parity_mine, phases, preflight = None, None, None
 
     # ---- beside it (N = 1): the same operator as an sss_mat (examples/poisson_test.py solves with
     # S = L.to_sss()): y = S x from the strict lower triangle only, and Jacobi-PCG on it
@@ -1021,7 +1196,7 @@ def main():
             except (OSError, ValueError):
                 traffic = None
         out = {
-            "metric": "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s",
+            "metric": METRIC,
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak" if scaling == "weak" else "strong", "vs_baseline": None,
@@ -1056,9 +1231,21 @@ def main():
                         "2 B row mask + x + y; no column indices) / avg launch time of the K timed launches",
             },
         }
+        out["provenance"] = provenance(L)
         if use_dist:
             out["rccl_ranks"] = dist.get_world_size()  # ranks the process group actually has
             out["backend"] = dist.get_backend()
+            out["stage"] = a.stage or None
+            out["launcher_kind"] = "one torch.distributed rank per GPU"
+            tr = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()
+            out["transport"] = {"halo": "%s send/recv (torch.distributed batch_isend_irecv)" % tr,
+                                "reductions": "%s all-reduce in stream order" % tr}
+            if preflight is not None:
+                out["preflight"] = preflight
+            if phases is not None:
+                out["phases"] = phases
+            if parity_mine is not None:
+                out["parity_solve"] = parity_mine
         if dry:
             out["dry_run"] = "launcher / driver plumbing over gloo with " + a.test_backend + ": NOT a measurement"
         if a.share_gpu:
@@ -1071,7 +1258,15 @@ def main():
         if strong_n1 is not None:
             out["strong_n1"] = strong_n1
             if use_dist and scaling == "strong" and strong_n1["grid"] == [nx, ny, nz]:
-                out["vs_n1"] = (1.0 / pcg_s_per_iter) / strong_n1["pcg_iters_per_s"]
+                if strong_n1.get("pcg_iters_per_s"):
+                    out["vs_n1"] = (1.0 / pcg_s_per_iter) / strong_n1["pcg_iters_per_s"]
+                if parity_mine is not None and strong_n1.get("parity_solve"):
+                    par = parity_object(strong_n1["parity_solve"], parity_mine, "n_ranks")
+                    out["parity_vs_n1"] = par
+                    if not par["ok"]:
+                        out["error"] = "parity_vs_n1 failed: max relative difference %.3e > %.1e" % (
+                            par["max_rel_diff"], PARITY_TOL)
+                        exit_code = 1
         if ceiling is not None:
             out["device_ceiling_same_run"] = ceiling
             probe = ceiling.get("read7_write1_probe")
@@ -1103,7 +1298,12 @@ def main():
         if clocks is not None:
             out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:
-            base, ref = cpu_baseline()
+            base, ref, parity = cpu_baseline(dev=dev)
+            if parity is not None:
+                out["parity_check"] = parity
+                if not parity["ok"]:
+                    out["error"] = "parity_check failed (GPU iterates against the oracle at BASELINE's sizes)"
+                    exit_code = 1
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_over_cpu"] = out["effective_csr_model_GBps"] / base["value"]
             # configs[0] (poisson2d(100)) on the GPU beside the CPU's C1 figure: the single-kernel loop of psp_coop.hip
@@ -1129,9 +1329,13 @@ def main():
                 out["cpu_baseline_reference_pcg"] = ref
         print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
+        code = torch.tensor([exit_code], dtype=torch.int32, device="cpu" if dry else "cuda")
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)  # every rank leaves with rank 0's verdict
+        exit_code = int(code.item())
         dist.barrier()
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

@@ -87,7 +87,7 @@ def test_bench_n_ranks_rehearsal_on_one_gpu(world):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo",
                           "--share-gpu", "--grid", "64,48,36", "--steps", "4", "--warmup", "2", "--pcg-iters", "40",
-                          "--no-cpu-baseline", "--no-clocks", "--no-strong-n1"],
+                          "--no-cpu-baseline", "--no-clocks"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -97,6 +97,12 @@ def test_bench_n_ranks_rehearsal_on_one_gpu(world):
         assert k in d, k
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and "dry_run" in d
     assert d["scaling"] == "strong" and d["config"]["n"] == 64 * 48 * 36
+    assert d["launcher"]["stage"] == "torch_rccl_ranks" and d["launcher"]["fallback_from"] == []
+    # the in-job parity check: 20 iterations of the N-rank solve against rank 0's one-GPU solve of the whole problem
+    assert d["parity_vs_n1"]["ok"] and d["parity_vs_n1"]["max_rel_diff"] <= 1e-9, d["parity_vs_n1"]
+    assert d["strong_n1"]["grid"] == [64, 48, 36] and d["vs_n1"] > 0
+    assert d["phases"]["iteration_ms"] > 0 and d["phases"]["halo_ms"] > 0 and 0.0 <= d["phases"]["overlap_frac"] <= 1.0
+    assert d["preflight"]["peer_access"] == [[1]]
     assert d["roofline"]["kernel"] == "csr_spmv_w4"
     # tol = 0: exactly 40 iterations; the same count and residual as the one-GPU solver on the whole problem
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 41
@@ -115,7 +121,8 @@ def test_bench_n_ranks_rehearsal_on_one_gpu(world):
 def test_bench_cpu_baseline_objects_small_sample():
     sys.path.insert(0, ROOT)
     import bench
-    base, ref = bench.cpu_baseline(c2_grid=(40, 40, 0), c3_grid=(24, 24, 24), c3_small=(16, 16, 16))
+    base, ref, parity = bench.cpu_baseline(c2_grid=(40, 40, 0), c3_grid=(24, 24, 24), c3_small=(16, 16, 16))
+    assert parity is None  # no device handed over: the GPU-against-oracle comparison is test_gpu_reference_sizes.py / the bench line
     assert base["kind"] == "port" and base["cores"] == 1 and base["unit"] == "GB/s" and base["value"] > 0
     assert base["pcg_iters_per_s"] > 0 and "C2_poisson2d_40" in base
     if ref is not None:  # oracle/_ref is built where /root/reference exists
@@ -140,6 +147,95 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and "dry_run" in d
     assert d["config"]["n"] == 12 * 10 * 8 and d["config"]["rows_per_gpu"] == 12 * 10 * 4
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 6
+    # the line names the stage of the ladder that produced it, the transport, and what the run was checked against
+    assert d["launcher"]["stage"] == "torch_rccl_ranks" == d["stage"] and d["launcher"]["fallback_from"] == []
+    assert d["launcher"]["ladder"] == ["torch_rccl_ranks", "single_process_rccl", "single_process_fold"]
+    assert "halo" in d["transport"] and "reductions" in d["transport"]
+    par = d["parity_vs_n1"]  # PARITY_ITERS iterations of the 2-rank solve against the unpartitioned solve
+    assert par["ok"] and par["iters"] == 20 and par["max_rel_diff"] <= 1e-9 and par["same_info_iter"]
+    ph = d["phases"]
+    for k in ("px_update_ms", "spmv_interior_ms", "halo_exposed_ms", "spmv_boundary_ms", "allreduce_1_ms", "scalar_1_ms",
+              "r_update_ms", "allreduce_2_ms", "scalar_2_ms", "halo_ms", "iteration_ms"):
+        assert ph[k] >= 0.0, k
+    assert len(ph["allreduce_us"]) == 2 and 0.0 <= ph["overlap_frac"] <= 1.0
+    assert d["preflight"]["world"] == 2
+    assert d["provenance"]["match"] is True
+
+
+def _run_ladder(*extra, timeout=240):
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "12,10,8",
+                          "--steps", "3", "--warmup", "1", "--pcg-iters", "5", "--no-cpu-baseline",
+                          "--test-backend", "tests.dist_oracle_backend:bench_factory"] + list(extra),
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr[-2000:]
+    return out.returncode, json.loads(lines[0]), time.time() - t0
+
+
+def test_bench_ladder_a_rank_that_exits_gives_an_error_line_and_a_nonzero_exit_code():
+    """first contact with N > 1 must not be all-or-nothing: a rank that dies after the process group has formed ends
+    the stage, and with no stage left the job prints ONE JSON error line (value null) and leaves with rc != 0"""
+    rc, d, wall = _run_ladder("--inject", "exit:1", "--ladder", "torch_rccl_ranks")
+    assert rc != 0 and d["value"] is None and "error" in d and d["n_gpus"] == 2
+    f = d["launcher"]["fallback_from"]
+    assert len(f) == 1 and f[0]["stage"] == "torch_rccl_ranks" and f[0]["rc"] != 0
+    assert any("injected failure: rank 1 exits" in l for l in f[0]["stderr_tail"])
+    assert wall < 120
+
+
+def test_bench_ladder_a_rank_that_hangs_is_ended_by_the_stage_timeout():
+    """a rank that never arrives (a hang in communicator set-up looks like this): the others block in the first
+    collective, the stage's time-out ends the whole process group, the line still comes, inside the limit"""
+    rc, d, wall = _run_ladder("--inject", "hang:1", "--ladder", "torch_rccl_ranks", "--stage-timeout", "25")
+    assert rc != 0 and d["value"] is None and "error" in d
+    f = d["launcher"]["fallback_from"]
+    assert len(f) == 1 and "timed out" in f[0]["reason"]
+    assert 25 <= wall < 90
+
+
+def test_bench_ladder_falls_through_every_stage_and_respects_the_deadline():
+    """all three stages: the torch ranks fail by injection; the two single-process stages need GPUs this container does
+    not have and say so; the error line lists what each stage died of"""
+    from pysparse_amd import device
+    if device.device_count() > 0:
+        pytest.skip("a GPU is present: the single-process stages would run")
+    rc, d, wall = _run_ladder("--inject", "exit:0", "--deadline", "200")
+    assert rc != 0 and d["value"] is None
+    f = d["launcher"]["fallback_from"]
+    assert [x["stage"] for x in f] == ["torch_rccl_ranks", "single_process_rccl", "single_process_fold"]
+    assert any("no HIP device" in l for l in f[1]["stderr_tail"])
+    assert wall < 200
+    # a deadline too short for anything: every stage is skipped, the line still comes
+    rc, d, wall = _run_ladder("--deadline", "10")
+    assert rc != 0 and all(x["reason"].startswith("skipped") for x in d["launcher"]["fallback_from"])
+
+
+@pytest.mark.gpu
+def test_bench_ladder_falls_back_to_the_single_process_stage_on_the_gpu():
+    """the ladder end to end on the one-GPU box: the torch ranks (gloo, sharing cuda:0) die by injection, the next stage --
+    ONE process, the device list through the C ABI -- produces the line, which says so; its 3-rank solve agrees with the
+    one-GPU solve of the same system (parity_vs_n1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--backend", "gloo",
+                          "--share-gpu", "--grid", "64,48,36", "--steps", "4", "--warmup", "2", "--pcg-iters", "24",
+                          "--no-cpu-baseline", "--no-clocks", "--inject", "exit:2"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["launcher"]["stage"] == "single_process_rccl" == d["stage"]
+    f = d["launcher"]["fallback_from"]
+    assert len(f) == 1 and f[0]["stage"] == "torch_rccl_ranks"
+    assert d["ranks"] == 3 and d["reductions"].startswith("fold kernel")  # three ranks on ONE device: no RCCL
+    assert d["parity_vs_n1"]["ok"] and d["parity_vs_n1"]["max_rel_diff"] <= 1e-9
+    assert d["strong_n1"]["grid"] == [64, 48, 36] and d["vs_n1"] > 0
+    for k in ("halo_ms", "spmv_local_ms", "allreduce_ms", "spmv_with_halo_ms", "allreduce_us"):
+        assert d["phases"][k] >= 0.0
+    assert d["preflight"]["peer_access"] == [[1]] and d["provenance"]["match"] is True
 
 
 @pytest.mark.gpu
@@ -151,6 +247,7 @@ def test_bench_single_process_device_list_rehearsal():
                   "--pcg-iters", "16")
     for k in CONTRACT[:-1]:
         assert k in d, k
+    assert d["parity_vs_n1"]["ok"] and d["phases"]["spmv_with_halo_ms"] > 0
     assert d["n_gpus"] == 3 and d["ranks"] == 3 and d["distinct_devices"] == 1 and d["scaling"] == "strong"
     assert d["config"]["n"] == 64 * 64 * 66 and d["config"]["devices"] == [0, 0, 0]
     assert "dry_run" in d and d["reductions"].startswith("fold kernel")
