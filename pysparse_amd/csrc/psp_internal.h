@@ -56,21 +56,34 @@ int current_ws_slot();
 
 #define PSP_LAUNCH_CHECK() PSP_HIP(hipGetLastError())
 
-// Reductions: every reducing kernel is launched with at most kMaxParts workgroups;
-// workgroup b leaves its partial sums in partials[slot*kMaxParts + b]; the finishing step
-// (a fixed-order fold to 1024 values when there are more, then one workgroup) adds them
-// in index order.  Fixed grid + fixed order => bitwise reproducible results, no atomics.
+// Reductions: every reducing kernel is launched with at most kMaxParts workgroups; workgroup b leaves its partial
+// sums in partials[slot*kMaxParts + b].  They are added in ONE canonical order, whichever kernel does the adding:
+//     R(v[0..m))        = wave_sum over the 64 lanes of ( v[l] + v[l+64] + v[l+128] + ... ), lane l, left to right
+//     reduce(parts, np) = np <= 256 ?  R(parts)  :  R( [ R(parts[256 g .. 256 g + 256)) for every group g ] )
+// (wave_sum = the fixed shuffle-down tree).  Fixed grid + fixed order => bitwise reproducible results, no
+// floating-point atomics.  Up to kOneBlockGroups groups ONE workgroup of 1024 threads does both levels (one wave per
+// group, then wave 0 over the group sums): a reduction is one small launch up to n = 2^25 (round 4; two before);
+// beyond that group_fold_kernel (one wave per group, many workgroups) + a finishing block.
+// Round 4 also tried the reduction inside the kernel that produces the partial sums (the workgroup that draws the
+// last ticket of its group adds the group, the last group adds the group sums and runs the solver's scalar step: three
+// launches per PCG iteration instead of nine).  Same bits, and 20 % SLOWER at 512^3 (profiles/
+// r4_reduce_tail_per_workgroup_ab.txt): the wave that waits for its ticket keeps its workgroup's slot ~3 us longer, a
+// quarter of the lifetime of a workgroup of these bandwidth-bound kernels, and 2.6e5 returning device-scope atomics
+// per kernel are not free either.  Backed out.
 constexpr int kMaxParts = 1 << 21;  // one span per workgroup up to n = 2^30 (64 MB of partial-sum slots); round 1: 2^18,
                                     // i.e. looping grids -- 10-20 % slower vector kernels -- from 2^27 + 1 elements on
 constexpr int kSlots = 4;
-constexpr int kFold = 1024;
+constexpr int kFold = 1024;  // outputs of the first-level folds of psp_csr.hip (grids beyond kMaxParts, parts of a big matrix)
+constexpr int kTailGroup = 256;                      // partials per group
+constexpr int kTailGroups = kMaxParts / kTailGroup;  // 8192
+constexpr int kOneBlockGroups = 256;                 // <= this many groups (65536 partials): one workgroup does it all
 // streaming vector kernels: one workgroup per contiguous span of kVecSpan elements
 // (non-persistent grids measured faster than grid-stride loops on MI355X, profiles/)
 constexpr int kVecSpan = 512;  // one 16-byte access per lane per array: measured best (profiles/)
 
 struct Workspace {
   double *partials = nullptr;   // kSlots * kMaxParts doubles (device)
-  double *folded = nullptr;     // kSlots * kFold doubles (device)
+  double *folded = nullptr;     // kSlots * kTailGroups doubles (device): the group sums
   double *scal_dev = nullptr;   // 16 doubles (device)
   double *scal_host = nullptr;  // 16 doubles (pinned host)
   int num_cu = 0;
@@ -86,27 +99,78 @@ inline int vec_grid(const Workspace &, long n) {
   return (int)(want < kMaxParts ? want : kMaxParts);
 }
 
-// finish: out_dev[j] = sum_b partials[j*kMaxParts + b], j < nvals, b < nparts
+// finish: out_dev[j] = reduce(partials + j*kMaxParts, nparts), j < nvals
 int finish_partials(const double *partials, int nparts, int nvals, double *out_dev);
-// its two stages separately (the solvers append their scalar recurrences to the finishing block):
-// fold_stage launches the fold when there are many partials and returns what the block reads
-int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride);
+// its two stages separately (the solvers append their scalar recurrences to the finishing block): fold_stage launches
+// the group fold when there are more than kOneBlockGroups groups and returns what the finishing block (1024 threads:
+// reduce_block below) reads
+int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride, bool *raw,
+               int fslot = 0);
+// two single-value reductions (different partial arrays / counts): one group-fold launch when either needs the stage
+int fold_stage2(const double *const partials[2], const int nparts[2], const int fslot[2], const double *src[2],
+                int count[2], int stride[2], bool raw[2]);
+struct FoldJobs {  // kernel argument of group_fold_kernel
+  const double *in[2] = {nullptr, nullptr};
+  int nparts[2] = {0, 0};
+  int nvals[2] = {0, 0};
+  double *out[2] = {nullptr, nullptr};
+};
+
 #ifdef __HIPCC__
-// the finishing block (256 threads): thread t adds parts t, t+256, ... in order, then a fixed tree;
-// out[j] is written by thread 0 and the block is synchronised on return
-__device__ __forceinline__ void finish_block(const double *__restrict__ partials, int nparts, int nvals,
-                                             int stride, double *__restrict__ out) {
-  __shared__ double sh[256];
-  for (int j = 0; j < nvals; ++j) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nparts; b += 256) s += partials[(size_t)j * stride + b];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-      __syncthreads();
+__device__ __forceinline__ double psp_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// R(v[0..count)) by one wave: lane l adds v[l], v[l+64], ... in order, then the shuffle tree; lane 0 holds the result.
+// COH: the values were written by other workgroups of the SAME launch -> device-coherent (sc1) loads
+template <bool COH>
+__device__ __forceinline__ double psp_wave_reduce(const double *__restrict__ v, int count) {
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int base = 0; base < count; base += 512) {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // eight loads in flight, added in order
+      const int i = base + lane + 64 * k;
+      if constexpr (COH)
+        t[k] = i < count ? __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      else
+        t[k] = i < count ? v[i] : 0.0;
     }
-    if (threadIdx.x == 0) out[j] = sh[0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += t[k];
+  }
+  return psp_wave_sum(s);
+}
+// the finishing block (1024 threads): out[j] = reduce(...) of value j.  raw: `partials` are per-workgroup partial sums,
+// nparts <= 256 * kOneBlockGroups of them -- wave w adds groups w, w + 16, ... (R over each group's <= 256 entries),
+// then wave 0 adds the group sums (R); one group (nparts <= 256) is added by wave 0 directly.  !raw: `partials` are the
+// group sums group_fold_kernel left: wave 0 adds them (R).  `sh`: kOneBlockGroups doubles of LDS.  The block is
+// synchronised on return and thread 0 has written out[].
+constexpr int kReduceBlock = 1024;
+__device__ __forceinline__ void reduce_block(const double *__restrict__ partials, int nparts, int nvals, int stride,
+                                             bool raw, double *__restrict__ out, double *__restrict__ sh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int ngroups = raw ? (nparts + kTailGroup - 1) / kTailGroup : 1;
+  for (int j = 0; j < nvals; ++j) {
+    const double *p = partials + (size_t)j * stride;
+    if (ngroups <= 1) {
+      if (wid == 0) {
+        const double s = psp_wave_reduce<false>(p, nparts);
+        if (lane == 0) out[j] = s;
+      }
+    } else {
+      for (int g = wid; g < ngroups; g += nw) {
+        const double s = psp_wave_reduce<false>(p + (size_t)g * kTailGroup, min(kTailGroup, nparts - g * kTailGroup));
+        if (lane == 0) sh[g] = s;
+      }
+      __syncthreads();
+      if (wid == 0) {
+        const double s = psp_wave_reduce<false>(sh, ngroups);
+        if (lane == 0) out[j] = s;
+      }
+    }
     __syncthreads();
   }
 }

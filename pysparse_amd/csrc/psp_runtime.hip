@@ -1,4 +1,5 @@
 // psp_runtime.hip -- device selection, stream, memory, events, reduction workspace.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -78,7 +79,7 @@ int workspace(Workspace **out) {
     PSP_HIP(hipGetDeviceProperties(&prop, g_device));
     ws.num_cu = prop.multiProcessorCount;
     PSP_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
-    PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kFold));
+    PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
     PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
     PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
     ws.device = g_device;
@@ -120,45 +121,91 @@ __global__ __launch_bounds__(256) void stream_probe_kernel(const double2 *__rest
   else if (s.x + s.y == 12345.678) b[0] = double2{s.x, s.y};  // never true: keeps the loads alive
 }
 
-// fold: out[j*kFold + o] = sum over b == o (mod kFold) of in[j*kMaxParts + b].  16 lanes share
-// one output: lane g adds b = o + kFold*(g + 16*i) in ascending i, then a fixed xor-tree over
-// the 16 lanes -- same order every run.  64 workgroups per value keep the 1-3 MB of partials
-// of a 2^27-element reduction from being read by only four workgroups (70 us -> ~10 us).
-__global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ in, int nparts,
-                                                   double *__restrict__ out) {
-  const int o = blockIdx.x * 16 + (threadIdx.x >> 4);  // < kFold
-  const int g = threadIdx.x & 15;
-  const int j = blockIdx.y;
-  double s = 0.0;
-  for (long b = o + (long)kFold * g; b < nparts; b += (long)kFold * 16) s += in[(size_t)j * kMaxParts + b];
-#pragma unroll
-  for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 16);
-  if (g == 0) out[(size_t)j * kFold + o] = s;
+// first level of reduce() (psp_internal.h) for up to two sets of partial sums in one launch (blockIdx.y = job * nvals
+// of job 0 ...): out[j*kTailGroups + g] = R(in[j*kMaxParts + 256 g .. + 256)), one wave per group, four groups per
+// workgroup
+__global__ __launch_bounds__(256) void group_fold_kernel(FoldJobs jobs) {
+  int y = blockIdx.y, k = 0;
+  if (y >= jobs.nvals[0]) {
+    y -= jobs.nvals[0];
+    k = 1;
+  }
+  const int nparts = jobs.nparts[k];
+  const int ngroups = (nparts + kTailGroup - 1) / kTailGroup;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+  const int gsize = min(kTailGroup, nparts - g * kTailGroup);
+  const double s = psp_wave_reduce<false>(jobs.in[k] + (size_t)y * kMaxParts + (size_t)g * kTailGroup, gsize);
+  if ((threadIdx.x & 63) == 0) jobs.out[k][(size_t)y * kTailGroups + g] = s;
 }
 
-// one block: thread t adds parts t, t+256, ... in order, then a fixed tree (finish_block, psp_internal.h)
-__global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ partials,
-                                                     int nparts, int nvals, int stride,
-                                                     double *__restrict__ out) {
-  finish_block(partials, nparts, nvals, stride, out);
+// one block of 1024 threads (reduce_block, psp_internal.h)
+__global__ __launch_bounds__(kReduceBlock) void finish_kernel(const double *__restrict__ partials, int nparts, int nvals,
+                                                              int stride, int raw, double *__restrict__ out) {
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(partials, nparts, nvals, stride, raw != 0, out, sh);
 }
 
-// first stage of a reduction over many partials: fold them to kFold values per slot; tells the
-// caller what the finishing block has to read
-int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride) {
-  Workspace *w;
-  PSP_TRY(workspace(&w));
-  if (nparts > 2 * kFold) {
-    hipLaunchKernelGGL(fold_kernel, dim3(kFold / 16, nvals), dim3(256), 0, stream(), partials,
-                       nparts, w->folded);
-    PSP_LAUNCH_CHECK();
-    *src = w->folded;
-    *count = kFold;
-    *stride = kFold;
+// first stage of a reduction over more partials than one block takes: the group sums (into slot `fslot` of the
+// workspace's group-sum array); tells the caller what the finishing block has to read (raw: still the per-workgroup
+// partial sums).  fold_stage2: two sets of partial sums, ONE launch when both need the stage.
+static void fold_plan(Workspace *w, const double *partials, int nparts, int fslot, const double **src, int *count,
+                      int *stride, bool *raw, bool *need) {
+  const int ngroups = (nparts + kTailGroup - 1) / kTailGroup;
+  *need = ngroups > kOneBlockGroups;
+  if (*need) {
+    *src = w->folded + (size_t)fslot * kTailGroups;
+    *count = ngroups;
+    *stride = kTailGroups;
+    *raw = false;
   } else {
     *src = partials;
     *count = nparts;
     *stride = kMaxParts;
+    *raw = true;
+  }
+}
+
+int fold_stage(const double *partials, int nparts, int nvals, const double **src, int *count, int *stride, bool *raw,
+               int fslot) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  bool need;
+  fold_plan(w, partials, nparts, fslot, src, count, stride, raw, &need);
+  if (need) {
+    FoldJobs jobs;
+    jobs.in[0] = partials;
+    jobs.nparts[0] = nparts;
+    jobs.nvals[0] = nvals;
+    jobs.out[0] = w->folded + (size_t)fslot * kTailGroups;
+    hipLaunchKernelGGL(group_fold_kernel, dim3((*count + 3) / 4, nvals), dim3(256), 0, stream(), jobs);
+    PSP_LAUNCH_CHECK();
+  }
+  return PSP_OK;
+}
+
+int fold_stage2(const double *const partials[2], const int nparts[2], const int fslot[2], const double *src[2],
+                int count[2], int stride[2], bool raw[2]) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  bool need[2];
+  for (int k = 0; k < 2; ++k)
+    fold_plan(w, partials[k], nparts[k], fslot[k], &src[k], &count[k], &stride[k], &raw[k], &need[k]);
+  if (need[0] || need[1]) {
+    FoldJobs jobs;
+    int nj = 0, maxg = 0;
+    for (int k = 0; k < 2; ++k)
+      if (need[k]) {
+        jobs.in[nj] = partials[k];
+        jobs.nparts[nj] = nparts[k];
+        jobs.nvals[nj] = 1;
+        jobs.out[nj] = w->folded + (size_t)fslot[k] * kTailGroups;
+        maxg = std::max(maxg, count[k]);
+        ++nj;
+      }
+    if (nj == 1) jobs.nvals[1] = 0;
+    hipLaunchKernelGGL(group_fold_kernel, dim3((maxg + 3) / 4, nj), dim3(256), 0, stream(), jobs);
+    PSP_LAUNCH_CHECK();
   }
   return PSP_OK;
 }
@@ -166,8 +213,10 @@ int fold_stage(const double *partials, int nparts, int nvals, const double **src
 int finish_partials(const double *partials, int nparts, int nvals, double *out_dev) {
   const double *src;
   int count, stride;
-  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride));
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream(), src, count, nvals, stride, out_dev);
+  bool raw;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride, &raw, 0));
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kReduceBlock), 0, stream(), src, count, nvals, stride, raw ? 1 : 0,
+                     out_dev);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

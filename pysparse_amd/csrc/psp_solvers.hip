@@ -273,14 +273,15 @@ __device__ __forceinline__ void pcg_scalar_xr(PcgDev *st, const double *__restri
 }
 
 // The scalar recurrences ride in the block that finishes the reduction they depend on (one launch
-// instead of finish_kernel + a one-thread kernel; the summation order is finish_block's, so the values
+// instead of finish_kernel + a one-thread kernel; the summation order is reduce_block's, so the values
 // are the ones the separate kernels produced).
 enum PcgScalarOp { kOpPq = 0, kOpXr = 1, kOpLazyX = 2, kOpLazyPq = 3, kOpLazyR = 4 };
 
 template <int OP>
-__global__ __launch_bounds__(256) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
-                                                                int nvals, int stride, double *__restrict__ out,
-                                                                PcgDev *st, double *__restrict__ hist);
+__global__ __launch_bounds__(kReduceBlock) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                         int nvals, int stride, int raw,
+                                                                         double *__restrict__ out, PcgDev *st,
+                                                                         double *__restrict__ hist);
 template <int OP>
 static int pcg_reduce_then(const double *partials, int nparts, int nvals, double *out_dev, PcgDev *st,
                            double *hist_dev);
@@ -517,11 +518,13 @@ __device__ __forceinline__ void pcg_lazy_scalar_r(PcgDev *st, const double *__re
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
-                                                                int nvals, int stride, double *__restrict__ out,
-                                                                PcgDev *st, double *__restrict__ hist) {
+__global__ __launch_bounds__(kReduceBlock) void pcg_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                         int nvals, int stride, int raw,
+                                                                         double *__restrict__ out, PcgDev *st,
+                                                                         double *__restrict__ hist) {
   if (st->status) return;  // loop already over: nothing to reduce either
-  finish_block(src, count, nvals, stride, out);
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(src, count, nvals, stride, raw != 0, out, sh);
   if (threadIdx.x == 0) {
     if constexpr (OP == kOpPq) pcg_scalar_pq(st, out);
     if constexpr (OP == kOpXr) pcg_scalar_xr(st, out, hist);
@@ -531,15 +534,49 @@ __global__ __launch_bounds__(256) void pcg_finish_scalar_kernel(const double *__
   }
 }
 
-// fold (when there are many partials) + the finishing block with scalar update OP
+// lazy loop: the scan of the px pass (`x`: nonstag, one value) and p.q of the product (`q`) reduced by ONE launch behind
+// the product; thread 0 then takes pcg_lazy_scalar_x's branches and, if the loop goes on, pcg_lazy_scalar_pq's -- the
+// order the separate launches run them in (and the order pcg_dist_scalar_xpq_kernel of the row-block drivers uses)
+__global__ __launch_bounds__(kReduceBlock) void pcg_finish_xpq_kernel(const double *__restrict__ src_x, int count_x,
+                                                                      int stride_x, int raw_x,
+                                                                      const double *__restrict__ src_q, int count_q,
+                                                                      int stride_q, int raw_q, double *__restrict__ out_x,
+                                                                      double *__restrict__ out_q, PcgDev *st) {
+  if (st->status) return;
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(src_x, count_x, 1, stride_x, raw_x != 0, out_x, sh);
+  reduce_block(src_q, count_q, 1, stride_q, raw_q != 0, out_q, sh);
+  if (threadIdx.x == 0) {
+    pcg_lazy_scalar_x(st, out_x);
+    pcg_lazy_scalar_pq(st, out_q);
+  }
+}
+
+// the group fold (when there are more partials than one block takes) + the finishing block with scalar update OP
 template <int OP>
 static int pcg_reduce_then(const double *partials, int nparts, int nvals, double *out_dev, PcgDev *st,
                            double *hist_dev) {
   const double *src;
   int count, stride;
-  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride));
-  hipLaunchKernelGGL((pcg_finish_scalar_kernel<OP>), dim3(1), dim3(256), 0, stream(), src, count, nvals, stride,
-                     out_dev, st, hist_dev);
+  bool raw;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride, &raw));
+  hipLaunchKernelGGL((pcg_finish_scalar_kernel<OP>), dim3(1), dim3(kReduceBlock), 0, stream(), src, count, nvals,
+                     stride, raw ? 1 : 0, out_dev, st, hist_dev);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+static int pcg_reduce_xpq(Workspace *w, const double *parts_x, int np_x, const double *parts_q, int np_q, double *out_x,
+                          double *out_q, PcgDev *st) {
+  const double *const parts[2] = {parts_x, parts_q};
+  const int np[2] = {np_x, np_q}, fslot[2] = {2, 0};
+  const double *src[2];
+  int count[2], stride[2];
+  bool raw[2];
+  (void)w;
+  PSP_TRY(fold_stage2(parts, np, fslot, src, count, stride, raw));
+  hipLaunchKernelGGL(pcg_finish_xpq_kernel, dim3(1), dim3(kReduceBlock), 0, stream(), src[0], count[0], stride[0],
+                     raw[0] ? 1 : 0, src[1], count[1], stride[1], raw[1] ? 1 : 0, out_x, out_q, st);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
@@ -571,6 +608,10 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
   int rc = PSP_OK;
   int enqueued = 0, np = 0;
   double *stag_parts = w->partials + 2 * (size_t)kMaxParts;  // slot 2: the scan's partials
+  const bool merge_xpq = [] {  // read per solve: tools/reduce_ab.py alternates it inside one process
+    const char *e = psp::tuning_env("PSP_PCG_MERGE_XPQ");
+    return e ? atoi(e) != 0 : true;
+  }();
 #define PCG_TRY(call)            \
   do {                           \
     rc = (call);                 \
@@ -597,10 +638,19 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
   do {
     const int batch = std::max(1, std::min(kBatch, maxit - enqueued));
     for (int i = 0; i < batch; ++i) {
-      PCG_TRY(k_px_update(n, r, dinv, p, x, w->partials, &np, st));
-      PCG_TRY(pcg_reduce_then<kOpLazyX>(stag_parts, np, 1, w->scal_dev + 8, st, nullptr));
+      // round 4: the scan of the px pass is reduced TOGETHER with p.q, behind the product (one launch for both up to
+      // n = 2^25, the group fold + one beyond) -- 5 launches per iteration instead of 9 (7 beyond 2^25).  The product
+      // then also runs in the one iteration that the scan ends (-5) or that starts with rho == 0 / beta == 0: its q is
+      // not used.  Same scalar steps in the same order on the same reduced values: the same bits
+      // (PSP_PCG_MERGE_XPQ=0 keeps the scan's reduction in front of the product: A/B and test_pcg_loop_variants_agree).
+      int np_x = 0;
+      PCG_TRY(k_px_update(n, r, dinv, p, x, w->partials, &np_x, st));
+      if (!merge_xpq) PCG_TRY(pcg_reduce_then<kOpLazyX>(stag_parts, np_x, 1, w->scal_dev + 8, st, nullptr));
       PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
-      PCG_TRY(pcg_reduce_then<kOpLazyPq>(w->partials, np, 1, w->scal_dev, st, nullptr));
+      if (merge_xpq)
+        PCG_TRY(pcg_reduce_xpq(w, stag_parts, np_x, w->partials, np, w->scal_dev + 8, w->scal_dev, st));
+      else
+        PCG_TRY(pcg_reduce_then<kOpLazyPq>(w->partials, np, 1, w->scal_dev, st, nullptr));
       PCG_TRY(k_r_update(n, 0.0, q, dinv, r, w->partials, &np, st));
       PCG_TRY(pcg_reduce_then<kOpLazyR>(w->partials, np, 2, w->scal_dev + 4, st, hist_dev));
     }
@@ -981,11 +1031,12 @@ __device__ __forceinline__ void minres_scalar_beta(MinresDev *st, const double *
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void minres_finish_scalar_kernel(const double *__restrict__ src, int count,
-                                                                   int stride, double *__restrict__ out,
-                                                                   MinresDev *st, double *__restrict__ hist) {
+__global__ __launch_bounds__(kReduceBlock) void minres_finish_scalar_kernel(const double *__restrict__ src, int count,
+                                                                            int stride, int raw, double *__restrict__ out,
+                                                                            MinresDev *st, double *__restrict__ hist) {
   if (st->status) return;
-  finish_block(src, count, 1, stride, out);
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(src, count, 1, stride, raw != 0, out, sh);
   if (threadIdx.x == 0) {
     if constexpr (OP == kMrAlpha) minres_scalar_alpha(st, out);
     if constexpr (OP == kMrBeta) minres_scalar_beta(st, out, hist);
@@ -996,9 +1047,10 @@ template <int OP>
 static int minres_reduce_then(const double *partials, int nparts, double *out_dev, MinresDev *st, double *hist_dev) {
   const double *src;
   int count, stride;
-  PSP_TRY(fold_stage(partials, nparts, 1, &src, &count, &stride));
-  hipLaunchKernelGGL((minres_finish_scalar_kernel<OP>), dim3(1), dim3(256), 0, stream(), src, count, stride, out_dev,
-                     st, hist_dev);
+  bool raw;
+  PSP_TRY(fold_stage(partials, nparts, 1, &src, &count, &stride, &raw));
+  hipLaunchKernelGGL((minres_finish_scalar_kernel<OP>), dim3(1), dim3(kReduceBlock), 0, stream(), src, count, stride,
+                     raw ? 1 : 0, out_dev, st, hist_dev);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
