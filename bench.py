@@ -1280,7 +1280,7 @@ def main():
                 out["roofline"]["stream_ceiling_kernel"] = best
                 out["roofline"]["frac_of_stream_ceiling"] = min(1.0, achieved / rates[best])
                 out["roofline"]["vs_read7_write1_probe"] = achieved / probe["GBps"]
-                # which timing mode this process is in (profiles/r3_modes.txt): named from the
+                # which timing level this job's allocations landed on (profiles/r4_modes.txt): named from the
                 # dominant kernel's own median launch (512^3 csr_spmv_w4 at the stripe-128 default: <= 1.56 ms fast, >= 1.63 ms slow, 1.60-1.62 usual; profiles/r3_w4_stripe.txt); the counter
                 # that moves with it -- read requests the L2s keep in flight, at an unchanged latency per request --
                 # comes from this job's profiled child process (`counters`), which may sit in the other mode
@@ -1291,10 +1291,12 @@ def main():
                     cls = None
                 out["process_mode"] = {"class": cls, "median_launch_ms": med_ms, "read7_write1_GBps": probe["GBps"],
                                        "counters": mc,
-                                       "note": "fast / slow processes of the same launch differ by up to 8 %: same bytes, "
-                                               "same clocks, same cycles per memory request, fewer requests in flight "
-                                               "(profiles/r3_modes.txt); a plain 7-read + 1-write streaming kernel does "
-                                               "NOT move with it"}
+                                       "note": "which LEVEL this job's allocations landed on, not a property of the process: "
+                                               "round 4 (profiles/r4_modes.txt) re-allocated nothing but y, or nothing but x, "
+                                               "inside one process and moved the same launch across the whole 1.52-1.70 ms range; "
+                                               "the byte offset inside an allocation and the memory type do not matter, the "
+                                               "dispatcher is ruled out (a persistent grid with a software-defined XCD order does "
+                                               "not follow it).  Placement in device memory decides; user space cannot choose it"}
         if clocks is not None:
             out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:
