@@ -58,13 +58,24 @@ const char *psp_last_error(void);
 const char *psp_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
 int psp_device_count(void);
-/* select the device all later calls use (hipSetDevice) */
+/* Threading: device, stream, reduction workspace and host staging belong to the CALLING THREAD.  The first thread
+ * that uses the library enqueues on the null stream (or on what it hands psp_set_stream); every other thread gets a
+ * non-blocking stream of its own on first use, so two threads with two handles overlap on the GPU.  A handle may be
+ * shared between threads: every entry point locks the handles it is given (operator, preconditioner and the matrix
+ * behind it), so calls on the SAME handle take turns.  (The reference holds the GIL across its whole solve.) */
+/* select the device the calling thread's later calls use (hipSetDevice); threads that first call the library later
+ * start on the device selected last */
 int psp_set_device(int device);
+/* which context the calling thread has: its slot (0 = the first thread), its device and the stream it enqueues on */
+int psp_thread_info(int *thread_slot, int *device, void **hip_stream);
+/* test hook of the locking discipline (tests/test_threading_cpu.py): takes the locks of the two handles exactly as an
+ * entry point that is handed them does (address order, recursive), holds them for `milliseconds`, releases them */
+int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds);
 /* *can_access = 1 when `device` can read / write `peer`'s memory directly (xGMI or PCIe peer path; what the
  * halo copies of a multi-device matrix need), 1 for device == peer.  Creates no context: bench.py's pre-flight
  * matrix of an N-GPU run */
 int psp_peer_access(int device, int peer, int *can_access);
-/* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = null stream */
+/* the calling thread enqueues on an externally owned hipStream_t (e.g. torch's current stream); NULL = null stream */
 int psp_set_stream(void *hip_stream);
 int psp_synchronize(void);
 /* name, CU count and HBM bytes of the current device */

@@ -3914,7 +3914,15 @@ struct HostStage {
   int device = -1;
   hipStream_t up = nullptr, dn = nullptr;
 };
-HostStage g_stage;
+// one staging pair per host thread (device, stream and workspace are the thread's too: psp_internal.h, "Threading
+// model"); a thread that ends gives its pair back
+struct HostStageOwner : HostStage {
+  ~HostStageOwner() {
+    if (x) (void)hipFree(x);
+    if (y) (void)hipFree(y);
+  }
+};
+thread_local HostStageOwner g_stage;
 
 // Measured (profiles/r3_host_matvec.json): 512^3, 32 chunks of 32 MiB: 23.7 ms against 39.7 ms plain (0.94 of the link's
 // full-duplex rate); 4096^2 (16.7e6 rows) loses -- 6.4-7.1 ms in 4 x 32 MiB or 16 x 8 MiB chunks against 4.9 ms plain: a
@@ -4333,7 +4341,7 @@ int psp_csr_destroy(psp_csr_t *A) {
   if (!A) return PSP_OK;
   if (A->host) return psp::cpu::csr_destroy(A);
   if (A->multi) {  // the row blocks, streams and communicators live with the multi-device object (psp_multi.hip)
-    PSP_API_GUARD;
+    PSP_API_GUARD_H(A);
     const int rc = psp::multi_destroy(A->multi);
     delete A;
     return rc;
@@ -4407,7 +4415,7 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
 }
 
 int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_diagonal_dev");
   if (A->nrows == 0) return PSP_OK;
   if (A->nparts) {
@@ -4437,7 +4445,7 @@ int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev) {
 }
 
 int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !diag_host) return fail(PSP_EINVAL, "psp_csr_diagonal: NULL argument");
   if (A->host) return psp::cpu::csr_diagonal(A, diag_host);
   if (A->multi) return psp::multi_diagonal_host(A->multi, diag_host);
@@ -4448,7 +4456,7 @@ int psp_csr_diagonal(const psp_csr_t *A, double *diag_host) {
 }
 
 int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_dev");
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_dev: NULL argument");
   if (A->nrows == 0) return PSP_OK;
@@ -4457,7 +4465,7 @@ int psp_csr_matvec_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
 
 int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, double *y_host,
                           ptrdiff_t incy) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec: NULL argument");
   if (A->host) return psp::cpu::csr_matvec(A, x_host, incx, y_host, incy, false);
   if (A->multi) return psp::multi_matvec_host(A->multi, x_host, incx, y_host, incy);
@@ -4477,12 +4485,12 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
 }
 
 int psp_csr_matvec(psp_csr_t *A, const double *x_host, double *y_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   return psp_csr_matvec_stride(A, x_host, 1, y_host, 1);
 }
 
 int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_transp");
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_csr_matvec_transp_dev: NULL argument");
   {  // offset-structured operators: exact gather in the reference's order, no atomics
@@ -4503,7 +4511,7 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
 
 int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx,
                                  double *y_host, ptrdiff_t incy) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_matvec_transp");
   if (!A || !x_host || !y_host) return fail(PSP_EINVAL, "psp_csr_matvec_transp: NULL argument");
   if (A->host) return psp::cpu::csr_matvec(A, x_host, incx, y_host, incy, true);
@@ -4517,7 +4525,7 @@ int psp_csr_matvec_transp_stride(psp_csr_t *A, const double *x_host, ptrdiff_t i
 }
 
 int psp_csr_matvec_transp(psp_csr_t *A, const double *x_host, double *y_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   return psp_csr_matvec_transp_stride(A, x_host, 1, y_host, 1);
 }
 
@@ -4537,7 +4545,7 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows) {
 }
 
 int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_renumbering");
   if (!A || !perm_host || !available) return fail(PSP_EINVAL, "psp_csr_renumbering: NULL argument");
   *available = 0;
@@ -4558,7 +4566,7 @@ int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
 }
 
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
   if (A->host) {
     if (name && name_cap > 0) snprintf(name, name_cap, "cpu loops (PSP_DEVICE=cpu)");
@@ -4894,14 +4902,14 @@ int psp_sss_getitem(const psp_sss_t *S, int i, int j, double *value) {
 }
 
 int psp_sss_matvec_dev(psp_sss_t *S, const double *x_dev, double *y_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(S);
   if (!S) return fail(PSP_EINVAL, "psp_sss_matvec_dev: NULL handle");
   return psp_csr_matvec_dev(S->full, x_dev, y_dev);
 }
 
 int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, double *y_host,
                           ptrdiff_t incy) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(S);
   if (!S) return fail(PSP_EINVAL, "psp_sss_matvec: NULL handle");
   if (S->host) return (x_host && y_host) ? psp::cpu::sss_matvec(S, x_host, incx, y_host, incy)
                                          : fail(PSP_EINVAL, "psp_sss_matvec: NULL argument");
@@ -4909,12 +4917,12 @@ int psp_sss_matvec_stride(psp_sss_t *S, const double *x_host, ptrdiff_t incx, do
 }
 
 int psp_sss_matvec(psp_sss_t *S, const double *x_host, double *y_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(S);
   return psp_sss_matvec_stride(S, x_host, 1, y_host, 1);
 }
 
 int psp_sss_kernel_info(psp_sss_t *S, char *name, int name_cap, int *info) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(S);
   if (!S) return fail(PSP_EINVAL, "psp_sss_kernel_info: NULL handle");
   if (S->host) {
     if (name && name_cap > 0) snprintf(name, name_cap, "cpu loops (PSP_DEVICE=cpu)");

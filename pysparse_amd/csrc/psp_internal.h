@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <initializer_list>
 #include <mutex>
 #include <string>
 
@@ -18,26 +19,73 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // nullptr otherwise, so a stray PSP_* variable in a user's environment cannot change the code path of the
 // drop-in.  Tests and tools that select a variant set both.
 const char *tuning_env(const char *name);
-// One library-wide lock around every compute entry point of the C ABI: the reduction workspace, the
-// stream and the per-handle side tables are process-global, and the extension modules release the GIL
-// around solves (the reference serialises the same calls by holding it).  Recursive: jacobi(steps > 1),
-// ssor and the solvers re-enter matvec entry points.  Callers must not hold the GIL while they wait for it
-// (ctypes and the extension modules release it first), because host-callback operators take the GIL
-// while the lock is held.
-std::recursive_mutex &api_mutex();
-#define PSP_API_GUARD std::lock_guard<std::recursive_mutex> psp_api_guard_(psp::api_mutex())
+// Threading model (round 4; SURVEY 8b: "one HIP stream per handle; handles not thread-safe").
+//   * What an entry point enqueues on -- device, stream, reduction workspace, host staging -- belongs to the CALLING
+//     THREAD (a thread-local context).  The first thread that touches the library keeps the null stream (or whatever it
+//     sets with psp_set_stream, e.g. torch's current stream); every other thread gets a non-blocking stream of its own on
+//     first use.  psp_set_device / psp_set_stream act on the calling thread; a new thread starts on the device the
+//     process selected last.  So two host threads with two handles overlap on the GPU instead of taking turns.
+//   * A HANDLE (csr / sss / jacobi / ssor / callback operator) carries scratch of its own (lazily built tables, the
+//     renumbered copy's vectors, SSOR's sweep vectors, pinned staging): every entry point locks the handles it is given
+//     (HandleLock: one recursive mutex per handle, taken in address order), so two threads that share a handle take turns
+//     on it -- the reference serialises the same calls by holding the GIL -- and never corrupt it.  Solvers lock the
+//     operator, the preconditioner and the matrix behind the preconditioner; host-callback operators take the GIL
+//     while those are held, so callers must not hold the GIL while they wait (ctypes and the extension modules
+//     release it first).
+//   * Entry points without a handle (the psp_k_* vector kernels, memory, events) lock nothing.
+std::recursive_mutex &handle_mutex(const void *handle);
+class HandleLock {
+ public:
+  HandleLock() {}
+  HandleLock(std::initializer_list<const void *> hs) {
+    for (const void *h : hs) add(h);
+    lock();
+  }
+  ~HandleLock() {
+    for (int i = n_ - 1; i >= 0; --i) mu_[i]->unlock();
+  }
+  HandleLock(const HandleLock &) = delete;
+  HandleLock &operator=(const HandleLock &) = delete;
+  void add(const void *h) {
+    if (!h || n_ >= kMax) return;
+    for (int i = 0; i < n_; ++i)
+      if (h_[i] == h) return;
+    h_[n_++] = h;
+  }
+  void lock() {  // address order: two threads that want the same set never wait for each other crosswise
+    for (int i = 1; i < n_; ++i)
+      for (int j = i; j > 0 && (uintptr_t)h_[j - 1] > (uintptr_t)h_[j]; --j) {
+        const void *t = h_[j];
+        h_[j] = h_[j - 1];
+        h_[j - 1] = t;
+      }
+    for (int i = 0; i < n_; ++i) {
+      mu_[i] = &handle_mutex(h_[i]);
+      mu_[i]->lock();
+    }
+  }
+
+ private:
+  static constexpr int kMax = 8;
+  const void *h_[kMax];
+  std::recursive_mutex *mu_[kMax];
+  int n_ = 0;
+};
+#define PSP_API_GUARD psp::HandleLock psp_api_guard_
+#define PSP_API_GUARD_H(...) psp::HandleLock psp_api_guard_({__VA_ARGS__})
 hipStream_t stream();
 hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
 // PSP_DEVICE=cpu (read once): the opt-in host mode of psp_cpu.hip -- never a fallback, see that file
 bool cpu_mode();
-// multi-device driver (psp_multi.hip): make `device` current (hipSetDevice) and enqueue on `s` from now on; the
-// reduction workspace is per device, so the phase kernels can be driven for one rank after another
-// ws_slot selects the reduction workspace (0 = the process's ordinary one): ranks of a multi-device matrix that share
-// a device enqueue on different streams and so must not share partial-sum buffers
+// multi-device driver (psp_multi.hip): make `device` current (hipSetDevice) for THIS THREAD and enqueue on `s` from now
+// on; the reduction workspace is per (device, thread, ws_slot), so the phase kernels can be driven for one rank after
+// another.  ws_slot selects the reduction workspace (0 = the thread's ordinary one): ranks of a multi-device matrix that
+// share a device enqueue on different streams and so must not share partial-sum buffers
 int use_device(int device, hipStream_t s, int ws_slot = 0);
 int current_device();
 int current_ws_slot();
+int current_thread_slot();  // 0 for the first thread that used the library, small integers (reused) for the others
 
 #define PSP_HIP(call)                                                                    \
   do {                                                                                   \
@@ -252,6 +300,38 @@ struct psp_jacobi {
   struct psp_mcsr *multi = nullptr;  // jacobi of a multi-device matrix: dinv lives with the row blocks (psp_multi.hip)
   bool host = false;                 // PSP_DEVICE=cpu: dinv / temp are host arrays (psp_cpu.hip)
 };
+
+namespace psp {
+// the handles a call touches through operator `op`: the operator object itself (a callback operator owns pinned staging),
+// the matrix / preconditioner behind it and, for a jacobi, the matrix its extra sweeps multiply with
+inline void op_lock_add(HandleLock &L, const psp_op *op) {
+  if (!op || op->kind == 0) return;
+  L.add(op);
+  L.add(op->csr);
+  L.add(op->sss);
+  L.add(op->ssor);
+  if (op->jac) {
+    L.add(op->jac);
+    L.add(op->jac->A.csr);
+    L.add(op->jac->A.sss);
+  }
+}
+inline void jacobi_lock_add(HandleLock &L, const psp_jacobi *K) {
+  if (!K) return;
+  L.add(K);
+  L.add(K->A.csr);
+  L.add(K->A.sss);
+}
+}  // namespace psp
+#define PSP_API_GUARD_OPS(A, K)      \
+  psp::HandleLock psp_api_guard_;    \
+  psp::op_lock_add(psp_api_guard_, A); \
+  psp::op_lock_add(psp_api_guard_, K); \
+  psp_api_guard_.lock()
+#define PSP_API_GUARD_JAC(K)            \
+  psp::HandleLock psp_api_guard_;       \
+  psp::jacobi_lock_add(psp_api_guard_, K); \
+  psp_api_guard_.lock()
 
 namespace psp {
 // Device-resident scalar state of the asynchronous PCG loop (psp_solvers.hip): the kernels

@@ -993,7 +993,7 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind, const in
 }
 
 int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_product) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !A->multi || reps < 1 || warmup < 0 || !ms_per_product)
     return fail(PSP_EINVAL, "psp_csr_multi_spmv_time: needs a multi-device matrix and reps >= 1");
   psp_mcsr *M = A->multi;
@@ -1060,7 +1060,7 @@ int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_p
 //   what 2  one packed reduction of two doubles (RCCL all-reduce or the fold kernel), in stream order
 // psp_csr_multi_spmv_time is the product as a solver does it (0 overlapped with 1); overlap = (t0 + t1 - t_spmv) / t0.
 int psp_csr_multi_phase_time(psp_csr_t *A, int what, int warmup, int reps, double *ms_per_rep) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !A->multi || reps < 1 || warmup < 0 || !ms_per_rep || what < 0 || what > 2)
     return fail(PSP_EINVAL, "psp_csr_multi_phase_time: needs a multi-device matrix, what in 0..2 and reps >= 1");
   psp_mcsr *M = A->multi;

@@ -1,22 +1,62 @@
 // psp_runtime.hip -- device selection, stream, memory, events, reduction workspace.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "psp_internal.h"
 
 namespace psp {
 
 static thread_local std::string g_err;
-static hipStream_t g_stream = nullptr;
-static int g_device = 0;
-static int g_dev_state = 0;  // 0 unknown, 1 ok, -1 none
-// one reduction workspace per (device, slot): the multi-device driver switches devices, and gives every rank its own
-// slot -- ranks that share a device run on different streams and must not share partial-sum buffers
-static std::map<long, Workspace> g_wss;
-static int g_ws_slot = 0;
 static std::mutex g_mu;
+// ---- the calling thread's context (psp_internal.h, "Threading model")
+static std::atomic<int> g_default_device{0};  // what a new thread starts on: the device the process selected last
+static std::vector<int> g_free_slots;         // thread slots given back by threads that ended (guarded by g_mu)
+static int g_next_slot = 0;
+struct ThreadCtx {
+  int device = -1;     // -1: not initialised yet (takes g_default_device on first use)
+  int dev_state = 0;   // 0 unknown, 1 ok, -1 none
+  hipStream_t stream = nullptr;
+  bool stream_given = false;  // psp_set_stream / use_device chose the stream: no automatic one
+  int thread_slot = -1;
+  int ws_slot = 0;
+  std::map<int, hipStream_t> own;  // automatic non-blocking streams of a secondary thread, by device
+  int slot() {
+    if (thread_slot < 0) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (!g_free_slots.empty()) {
+        thread_slot = g_free_slots.back();
+        g_free_slots.pop_back();
+        if (thread_slot == 0) thread_slot = g_next_slot++;  // slot 0 (null stream) belongs to the first thread for good
+      } else {
+        thread_slot = g_next_slot++;
+      }
+    }
+    return thread_slot;
+  }
+  int dev() {
+    if (device < 0) device = g_default_device.load();
+    return device;
+  }
+  ~ThreadCtx() {
+    for (auto &kv : own) (void)hipStreamDestroy(kv.second);  // (best effort: the runtime may already be shutting down)
+    if (thread_slot > 0) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      g_free_slots.push_back(thread_slot);  // its workspaces stay cached for the next thread that gets the slot
+    }
+  }
+};
+static thread_local ThreadCtx tl;
+// one reduction workspace per (device, thread slot, rank slot): the multi-device driver switches devices and gives every
+// rank its own slot -- ranks that share a device run on different streams and must not share partial-sum buffers
+static std::map<long, Workspace> g_wss;
 
 int fail(int code, const char *fmt, ...) {
   char buf[1024];
@@ -38,15 +78,35 @@ const char *tuning_env(const char *name) {
   return on ? getenv(name) : nullptr;
 }
 
-std::recursive_mutex &api_mutex() {
-  static std::recursive_mutex mu;
-  return mu;
+std::recursive_mutex &handle_mutex(const void *handle) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, std::unique_ptr<std::recursive_mutex>> tab;  // entries live as long as the process
+  std::lock_guard<std::mutex> lk(mu);
+  auto &e = tab[handle];
+  if (!e) e.reset(new std::recursive_mutex());
+  return *e;
 }
 
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() {
+  if (!tl.stream_given && tl.stream == nullptr && tl.slot() > 0 && !cpu_mode()) {
+    // a secondary thread: its own non-blocking stream on the device it is on (created once per device)
+    const int d = tl.dev();
+    auto it = tl.own.find(d);
+    if (it == tl.own.end()) {
+      hipStream_t s = nullptr;
+      if (hipSetDevice(d) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess)
+        it = tl.own.emplace(d, s).first;
+      else
+        (void)hipGetLastError();
+    }
+    if (it != tl.own.end()) tl.stream = it->second;
+  }
+  return tl.stream;
+}
 hipStream_t swap_stream(hipStream_t s) {
-  hipStream_t old = g_stream;
-  g_stream = s;
+  hipStream_t old = stream();
+  tl.stream = s;
+  tl.stream_given = true;
   return old;
 }
 
@@ -54,35 +114,37 @@ int ensure_device() {
   if (cpu_mode())
     return fail(PSP_ENODEV, "PSP_DEVICE=cpu: this entry point has no host loop (it runs on the GPU only); the host mode "
                             "covers csr_mat / sss_mat products, jacobi, pcg and minres");
-  if (g_dev_state == 1) return PSP_OK;
+  (void)tl.slot();
+  if (tl.dev_state == 1) return PSP_OK;
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
   if (e != hipSuccess || cnt <= 0) {
-    g_dev_state = -1;
+    tl.dev_state = -1;
     return fail(PSP_ENODEV,
                 "no HIP device available (%s); libpysparse_hip has no CPU fallback",
                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
   }
-  if (g_device >= cnt)
-    return fail(PSP_ENODEV, "device %d requested but only %d visible", g_device, cnt);
-  PSP_HIP(hipSetDevice(g_device));
-  g_dev_state = 1;
+  if (tl.dev() >= cnt)
+    return fail(PSP_ENODEV, "device %d requested but only %d visible", tl.dev(), cnt);
+  PSP_HIP(hipSetDevice(tl.dev()));  // the HIP runtime's current device is per host thread too
+  tl.dev_state = 1;
   return PSP_OK;
 }
 
 int workspace(Workspace **out) {
   PSP_TRY(ensure_device());
+  const int d = tl.dev();
   std::lock_guard<std::mutex> lk(g_mu);
-  Workspace &ws = g_wss[(long)g_device * 4096 + g_ws_slot];
-  if (ws.device != g_device) {
+  Workspace &ws = g_wss[((long)d << 40) | ((long)tl.thread_slot << 16) | (long)tl.ws_slot];
+  if (ws.device != d) {
     hipDeviceProp_t prop;
-    PSP_HIP(hipGetDeviceProperties(&prop, g_device));
+    PSP_HIP(hipGetDeviceProperties(&prop, d));
     ws.num_cu = prop.multiProcessorCount;
     PSP_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
     PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
     PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
     PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
-    ws.device = g_device;
+    ws.device = d;
   }
   *out = &ws;
   return PSP_OK;
@@ -90,15 +152,18 @@ int workspace(Workspace **out) {
 
 int use_device(int device, hipStream_t s, int ws_slot) {
   PSP_HIP(hipSetDevice(device));  // unconditionally: the multi-device driver also switches with plain hipSetDevice
-  g_device = device;
-  g_dev_state = 1;
-  g_stream = s;
-  g_ws_slot = ws_slot;
+  (void)tl.slot();
+  tl.device = device;
+  tl.dev_state = 1;
+  tl.stream = s;
+  tl.stream_given = true;
+  tl.ws_slot = ws_slot;
   return PSP_OK;
 }
 
-int current_device() { return g_device; }
-int current_ws_slot() { return g_ws_slot; }
+int current_device() { return tl.dev(); }
+int current_ws_slot() { return tl.ws_slot; }
+int current_thread_slot() { return tl.slot(); }
 
 // psp_stream_probe: R read streams (the first with ordinary loads, the others non-temporal, like the value streams
 // of csr_spmv_w4) and optionally one non-temporal write stream; one 16-byte element per thread and stream, full grid
@@ -270,13 +335,31 @@ int psp_set_device(int device) {
   if (device < 0 || device >= cnt)
     return fail(PSP_EINVAL, "device %d out of range (0..%d)", device, cnt - 1);
   PSP_HIP(hipSetDevice(device));
-  g_device = device;
-  g_dev_state = 1;
+  (void)tl.slot();
+  if (tl.device != device && !tl.stream_given) tl.stream = nullptr;  // a secondary thread's own stream is per device
+  tl.device = device;
+  tl.dev_state = 1;
+  g_default_device.store(device);  // threads that start later begin here
   return PSP_OK;
 }
 
 int psp_set_stream(void *hip_stream) {
-  g_stream = (hipStream_t)hip_stream;
+  (void)tl.slot();
+  tl.stream = (hipStream_t)hip_stream;
+  tl.stream_given = true;
+  return PSP_OK;
+}
+
+int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds) {
+  PSP_API_GUARD_H(h1, h2);
+  if (milliseconds > 0) std::this_thread::sleep_for(std::chrono::milliseconds(milliseconds));
+  return PSP_OK;
+}
+
+int psp_thread_info(int *thread_slot, int *device, void **hip_stream) {
+  if (thread_slot) *thread_slot = current_thread_slot();
+  if (device) *device = current_device();
+  if (hip_stream) *hip_stream = (void *)psp::stream();
   return PSP_OK;
 }
 
@@ -290,7 +373,7 @@ int psp_synchronize(void) {
 int psp_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes) {
   PSP_TRY(ensure_device());
   hipDeviceProp_t prop;
-  PSP_HIP(hipGetDeviceProperties(&prop, g_device));
+  PSP_HIP(hipGetDeviceProperties(&prop, tl.dev()));
   if (name && name_len > 0) {
     snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
   }

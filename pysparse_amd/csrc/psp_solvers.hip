@@ -83,6 +83,7 @@ struct ScratchPool {
   struct Item {
     double *p;
     size_t cap;
+    int dev;  // the device the vector lives on (threads may be on different devices)
   };
   std::vector<Item> free_;
   std::mutex mu;
@@ -102,8 +103,9 @@ struct ScratchPool {
     {
       std::lock_guard<std::mutex> lk(mu);
       int best = -1;
+      const int dev = current_device();
       for (int i = 0; i < (int)free_.size(); ++i)
-        if (free_[i].cap >= n && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
+        if (free_[i].dev == dev && free_[i].cap >= n && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
       if (best >= 0 && free_[best].cap <= 2 * n + 1024) {
         *out = free_[best].p;
         cached_bytes -= free_[best].cap * sizeof(double);
@@ -128,7 +130,7 @@ struct ScratchPool {
       (void)hipFree(p);
       return;
     }
-    free_.push_back({p, cap});
+    free_.push_back({p, cap, current_device()});
     cached_bytes += cap * sizeof(double);
   }
   void trim() {
@@ -2001,7 +2003,7 @@ int psp_kd_r_update(const psp_pcgstate_t *s, int n, const double *q_dev, const d
 int psp_kd_csr_matvec_overlap(const psp_pcgstate_t *s, psp_csr_t *A, const double *x_dev, int x_offset,
                               double *y_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx,
                               double *dot_out_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!s || !A || !x_dev || !y_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: NULL");
   if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_kd_csr_matvec_overlap: row range / offset out of bounds");
@@ -2121,7 +2123,7 @@ int psp_kd_minres_scale(const psp_minresstate_t *s, int n, const double *y_dev, 
 
 int psp_kd_minres_matvec(const psp_minresstate_t *s, psp_csr_t *A, const double *v_dev, int v_offset,
                          double *av_dev, int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!s || !A || !v_dev || !av_dev || !dot_out_dev) return fail(PSP_EINVAL, "psp_kd_minres_matvec: NULL");
   if (v_offset < 0 || v_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_kd_minres_matvec: row range / offset out of bounds");
@@ -2320,7 +2322,7 @@ static int jacobi_from_diag_dev(int n, double *diag_dev_owned, double omega, int
 }
 
 int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **out) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_csr: NULL argument");
   if (A->nrows != A->ncols) return fail(PSP_EINVAL, "matrix is not square");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
@@ -2362,7 +2364,7 @@ int psp_jacobi_create_csr(psp_csr_t *A, double omega, int steps, psp_jacobi_t **
 }
 
 int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **out) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !out) return fail(PSP_EINVAL, "psp_jacobi_create_sss: NULL argument");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
   if (A->host) {
@@ -2390,7 +2392,7 @@ int psp_jacobi_create_sss(psp_sss_t *A, double omega, int steps, psp_jacobi_t **
 
 int psp_jacobi_create_diag(int n, const double *diag_host, double omega, int steps,
                            const psp_op_t *A_or_null, psp_jacobi_t **out) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A_or_null, nullptr);
   if (!diag_host || !out || n <= 0) return fail(PSP_EINVAL, "psp_jacobi_create_diag: bad argument");
   if (steps < 1) return fail(PSP_EINVAL, "jacobi: steps must be >= 1");
   if (steps > 1 && !A_or_null)
@@ -2430,14 +2432,14 @@ int psp_jacobi_shape(const psp_jacobi_t *K, int *n) {
 }
 
 int psp_jacobi_precon_dev(psp_jacobi_t *K, const double *x_dev, double *y_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_JAC(K);
   if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_jacobi_precon_dev: NULL argument");
   if (K->multi) return fail(PSP_EINVAL, "psp_jacobi_precon_dev is not available on a multi-device matrix");
   return jacobi_apply_dev(K, x_dev, y_dev);
 }
 
 int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_JAC(K);
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_jacobi_precon: NULL argument");
   if (K->host) return cpu::jacobi_precon(K, x_host, y_host);
   if (K->multi) {
@@ -2461,7 +2463,7 @@ int psp_jacobi_precon(psp_jacobi_t *K, const double *x_host, double *y_host) {
 
 int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, const double *b_dev,
                 double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A, K);
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
   PSP_TRY(pcg_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host));
@@ -2470,7 +2472,7 @@ int psp_pcg_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev, cons
 
 int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
             double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A, K);
   psp_mcsr *multi = nullptr;
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
@@ -2496,7 +2498,7 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
 int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
                    const double *b_dev, double tol, int maxit, int *info, int *iter,
                    double *relres, double *hist_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A, K);
   PSP_TRY(check_solver_args(A, K, n, x_dev, b_dev, info, iter, relres));
   PSP_TRY(ensure_device());
   PSP_TRY(minres_device(A, K, n, x_dev, b_dev, tol, maxit, info, iter, relres, hist_host));
@@ -2505,7 +2507,7 @@ int psp_minres_dev(const psp_op_t *A, const psp_op_t *K, int n, double *x_dev,
 
 int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
                double tol, int maxit, int *info, int *iter, double *relres, double *hist_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A, K);
   psp_mcsr *multi = nullptr;
   bool multi_jac = false;
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
@@ -2533,7 +2535,7 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
 #define PSP_HOST_SOLVER(NAME, CALL)                                                              \
   int NAME(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,    \
            double tol, int maxit, int *info, int *iter, double *relres) {                        \
-    PSP_API_GUARD;                                                                               \
+    PSP_API_GUARD_OPS(A, K);                                                                     \
     PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));                     \
     PSP_TRY(ensure_device());                                                                    \
     DevVecs mem;                                                                                 \
@@ -2556,7 +2558,7 @@ PSP_HOST_SOLVER(psp_qmrs, qmrs_device(A, K, n, x, b, tol, maxit, info, iter, rel
 
 int psp_gmres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const double *b_host,
               double tol, int maxit, int dim, int *info, int *iter, double *relres) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_OPS(A, K);
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres));
   PSP_TRY(ensure_device());
   DevVecs mem;

@@ -2257,7 +2257,7 @@ static int ssor_create_device(psp_sss_t *S, double omega, int steps, bool allow_
 extern "C" {
 
 int psp_ssor_create(psp_sss_t *S, double omega, int steps, psp_ssor_t **out) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(S);
   if (!S || !out) return fail(PSP_EINVAL, "psp_ssor_create: NULL argument");
   if (steps < 0) return fail(PSP_EINVAL, "ssor: steps must be >= 0");
   if (S->host) {
@@ -2415,14 +2415,14 @@ int psp_ssor_brick_info(const psp_ssor_t *K, int *bricks, int *edge) {
 }
 
 int psp_ssor_precon_dev(psp_ssor_t *K, const double *x_dev, double *y_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(K);
   if (!K || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_ssor_precon_dev: NULL argument");
   if (K->n == 0) return PSP_OK;
   return ssor_apply_dev(K, x_dev, y_dev);
 }
 
 int psp_ssor_precon(psp_ssor_t *K, const double *x_host, double *y_host) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(K);
   if (!K || !x_host || !y_host) return fail(PSP_EINVAL, "psp_ssor_precon: NULL argument");
   if (K->n == 0) return PSP_OK;
   if (K->host) return psp::ssor_apply_host(K, x_host, y_host);

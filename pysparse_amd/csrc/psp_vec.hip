@@ -1364,7 +1364,7 @@ int psp_k_pupdate(int n, const double *r_dev, const double *dinv_dev, double bet
 
 int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double *q_dev,
                          double *out_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !p_dev || !q_dev || !out_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: NULL");
   if (p_offset < 0 || p_offset + A->nrows > A->ncols)
     return fail(PSP_EINVAL, "psp_k_csr_matvec_dot: owned rows do not fit the column space");
@@ -1381,7 +1381,7 @@ int psp_k_csr_matvec_dot(psp_csr_t *A, const double *p_dev, int p_offset, double
 
 int psp_k_csr_matvec_overlap(psp_csr_t *A, const double *x_dev, int x_offset, double *y_dev,
                              int row_a, int row_b, psp_wait_fn wait, void *ctx, double *dot_out_dev) {
-  PSP_API_GUARD;
+  PSP_API_GUARD_H(A);
   if (!A || !x_dev || !y_dev) return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: NULL");
   if (x_offset < 0 || x_offset + A->nrows > A->ncols || row_a < 0 || row_b > A->nrows)
     return fail(PSP_EINVAL, "psp_k_csr_matvec_overlap: row range / offset out of bounds");
