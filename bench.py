@@ -664,6 +664,124 @@ def strong_n1_leg(L, check, dev, grid, iters):
     return out
 
 
+def mtx_leg(spec, steps=50, minres_iters=200):
+    """BASELINE.json configs[4] (an unstructured symmetric matrix as sss_mat + MINRES; the reference's flow is
+    examples/demo_pcg.py:47-98 over a MatrixMarket file through ll_mat.c:3390-3456) for a matrix the user supplies:
+    spec = a .mtx path, or `standin:fem32` / `standin:fem512` / `standin:logspaced` (pysparse_amd/tools/standins.py; the
+    SuiteSparse file cannot be fetched here).  Reports: ingest (parse + sort + split into sss arrays) and upload times,
+    the time to the first product (tables, renumbering), the kernel chosen, SpMV time priced in SSS-model bytes
+    (12 nnz_lower + 28 n + 4) and in CSR-model bytes of the full matrix, Jacobi-MINRES microseconds per
+    iteration, and parity against the oracle: the product bit for bit, MINRES info / iterations / iterate."""
+    from pysparse_amd import _capi, device as dev
+    from oracle import oracle as O
+    L, check = _capi.lib(), _capi.check
+
+    def sync():
+        check(L.psp_synchronize())
+    t0 = time.perf_counter()
+    if spec.startswith("standin:"):
+        from pysparse_amd.tools import standins
+        kind = spec.split(":", 1)[1]
+        if kind == "logspaced":
+            n, ind, col, val, diag = standins.logspaced_sss_arrays(923136)
+        else:
+            n, ind, col, val, diag = standins.fem_sss_arrays(68, 68, 67, int(kind[3:] or 32))
+        source = "seeded stand-in %s (pysparse_amd/tools/standins.py), NOT the SuiteSparse file" % kind
+    else:
+        from pysparse_amd.tools import mtx
+        n, ind, col, val, diag = mtx.sss_arrays_from_mtx(spec)
+        source = "MatrixMarket file " + os.path.basename(spec)
+    ingest_s = time.perf_counter() - t0
+    nnz_lower = int(val.shape[0])
+    t0 = time.perf_counter()
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    sync()
+    upload_s = time.perf_counter() - t0
+    rng = np.random.default_rng(7)
+    xh = rng.standard_normal(n)
+    xb, yb = dev.DeviceBuffer.from_host(xh), dev.DeviceBuffer(n)
+    t0 = time.perf_counter()
+    S.matvec_dev(xb.ptr, yb.ptr)  # builds the product's tables (mirror, renumbered copy, ...)
+    sync()
+    first_product_s = time.perf_counter() - t0
+    kern, kinfo = S.kernel_info()
+    ev = Events(L, check, steps + 1)
+    timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, 5)
+    avg, med = timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, steps)
+    sss_bytes = 12 * nnz_lower + 28 * n + 4
+    csr_bytes = csr_model_bytes(n, 2 * nnz_lower + n)
+    # parity: the product against the oracle's sss_matvec loop (sss_mat.c:40-56), bit for bit
+    So = O.SSS(n, val, diag, col, ind)
+    yo = np.empty(n)
+    So.matvec(xh, yo)
+    yg = yb.download()
+    spmv_bits = bool(np.array_equal(yg, yo))
+    # Jacobi-MINRES (minres.c:43-200): to 1e-10 against the oracle, then a fixed iteration count for the rate
+    b = np.zeros(n)
+    b[0] = 1.0
+    b += 1e-3 * rng.standard_normal(n)
+    K = dev.DeviceJacobi(S)
+    xg, xo = np.zeros(n), np.zeros(n)
+    t0 = time.perf_counter()
+    got = dev.minres(S, b, xg, 1e-10, 500, K)
+    solve_s = time.perf_counter() - t0
+    ref = O.minres(So, b, xo, 1e-10, 500, O.jacobi_dinv(diag))
+    x_diff = _maxrel(xg, xo)
+    times = {}
+    for k in (20, 20 + minres_iters):  # the difference cancels the transfers of b and x and the set-up product
+        best = 1e9
+        for _ in range(3):
+            xg2 = np.zeros(n)
+            t0 = time.perf_counter()
+            dev.minres(S, b, xg2, 0.0, k, K)
+            best = min(best, time.perf_counter() - t0)
+        times[k] = best
+    us_iter = (times[20 + minres_iters] - times[20]) / minres_iters * 1e6
+    out = {"source": source, "n": n, "nnz_lower": nnz_lower, "nnz_full": 2 * nnz_lower + n,
+           "ingest_s": ingest_s, "upload_s": upload_s, "first_product_s": first_product_s,
+           "kernel": kern, "kernel_info": kinfo, "spmv_ms": avg, "spmv_median_ms": med,
+           "sss_model_bytes": sss_bytes, "sss_model_GBps": sss_bytes / (avg * 1e-3) / 1e9,
+           "sss_model_frac_of_peak": sss_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "csr_model_bytes": csr_bytes, "csr_model_GBps": csr_bytes / (avg * 1e-3) / 1e9,
+           "csr_model_frac_of_peak": csr_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "minres": {"info": got[0], "iter": got[1], "relres": got[2], "solve_s_with_transfers": solve_s,
+                      "us_per_iteration": us_iter, "iters_timed": minres_iters},
+           "parity": {"spmv_bit_exact_vs_oracle": spmv_bits, "minres_info_iter_oracle": [ref[0], ref[1]],
+                      "minres_info_iter_gpu": [got[0], got[1]], "x_max_rel_diff": x_diff, "x_tol": 1e-12,
+                      "ok": bool(spmv_bits and (got[0], got[1]) == (ref[0], ref[1]) and x_diff <= 1e-12)}}
+    K.close()
+    S.close()
+    xb.free()
+    yb.free()
+    return out
+
+
+def mtx_main(a):
+    """`python bench.py --mtx PATH|standin:NAME`: the configs[4] leg on its own, one JSON line"""
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    leg = mtx_leg(a.mtx, steps=a.steps)
+    from pysparse_amd import _capi
+    out = {"metric": "sss_mat SpMV GB/s in SSS-model bytes (% of 8 TB/s HBM peak) + Jacobi-MINRES us/iteration",
+           "value": leg["sss_model_GBps"], "unit": "GB/s", "n_gpus": 1, "steps": a.steps, "warmup": 5,
+           "ms_per_step": leg["spmv_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "user file" if not a.mtx.startswith("standin:") else "synthetic stand-in",
+           "config": {"workload": "BASELINE.json configs[4]: unstructured symmetric matrix as sss_mat, y = S x and "
+                                  "Jacobi-MINRES on 1 GPU -- " + leg["source"], "n": leg["n"], "nnz": leg["nnz_full"]},
+           "roofline": {"bound": "hbm", "kernel": leg["kernel"], "achieved": leg["sss_model_GBps"], "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": leg["sss_model_frac_of_peak"], "traffic": None,
+                        "algorithmic_bytes_per_launch": leg["sss_model_bytes"], "avg_launch_ms": leg["spmv_ms"],
+                        "note": "SSS model of SURVEY 8d (12 nnz_lower + 28 n + 4); an irregular sss_mat multiplies with its "
+                                "expanded mirror, which moves about twice that (DESIGN.md section 2): csr_model_* prices "
+                                "the same time in the full matrix's CSR bytes"},
+           "config5": leg, "provenance": provenance(_capi.lib())}
+    if not leg["parity"]["ok"]:
+        out["error"] = "parity against the oracle failed"
+    print(json.dumps(out), file=real_stdout, flush=True)
+    return 1 if "error" in out else 0
+
+
 def dry_strong_n1(test_backend, grid):
     """CPU dry run of the launcher (tests): the parity reference = the same system solved by the test backend without
     a partition (SingleComm), PARITY_ITERS iterations"""
@@ -844,7 +962,15 @@ def main():
                     help="failure injection for the launcher tests: exit:RANK (that rank leaves with code 3 after the "
                          "process group formed) or hang:RANK (that rank sleeps instead of taking part)")
     ap.add_argument("--no-phases", action="store_true", help="skip the per-phase timing of an N > 1 iteration")
+    ap.add_argument("--mtx", default="",
+                    help="configs[4] on its own: a symmetric MatrixMarket file (e.g. SuiteSparse Emilia_923.mtx) or "
+                         "standin:fem32 | standin:fem512 | standin:logspaced -- sss_mat product + Jacobi-MINRES on one "
+                         "GPU with parity against the oracle.  The default run adds the same object as `config5` when "
+                         "the environment variable EMILIA_MTX names a file")
     a = ap.parse_args()
+
+    if a.mtx:
+        raise SystemExit(mtx_main(a))
 
     if a.single_process:
         raise SystemExit(single_process_main(a))
@@ -1329,6 +1455,11 @@ def main():
                 out["cpu_baseline"]["C1_poisson2d_100"]["gpu_error"] = str(e)[:200]
             if ref is not None:
                 out["cpu_baseline_reference_pcg"] = ref
+        if world == 1 and not use_dist and os.environ.get("EMILIA_MTX"):
+            try:  # configs[4] on the user's file, beside the headline (its own failure never costs the line)
+                out["config5"] = mtx_leg(os.environ["EMILIA_MTX"])
+            except Exception as e:  # noqa: BLE001
+                out["config5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         code = torch.tensor([exit_code], dtype=torch.int32, device="cpu" if dry else "cuda")

@@ -767,7 +767,11 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const unsigned short *__restrict__ col16, const int *__restrict__ blist,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    const int *__restrict__ perm, const int *__restrict__ rowperm, const int *__restrict__ colfull = nullptr) {
+    const int *__restrict__ perm, const int *__restrict__ rowperm, const int *__restrict__ colfull = nullptr,
+    int colmod = 0) {
+  // colmod > 0 (PSP_W3_COLMOD under PSP_TUNING=1; WRONG RESULTS, timing only): chunk c reads the 16-bit columns of chunk
+  // c % colmod -- the column stream then comes out of L2 instead of HBM while every other access, the LDS gathers and the
+  // arithmetic stay what they are: the time this buys bounds what ANY compression of the columns can buy (round 4)
   // rowperm (renumbered operators, psp_reorder.hip): row r of this matrix is row rowperm[r] of the
   // caller's: its sum is stored to y[rowperm[r]] and meets dotv[rowperm[r]]
   constexpr int WT = 1024;
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     // --- independent loads: values, 16-bit columns, row offsets, block list, table entry
     d2v v0[STEPS], v1[STEPS];
     us4v c[STEPS];
-    const unsigned short *cp = col16 + (size_t)chunk * WT;
+    const unsigned short *cp = col16 + (size_t)(colmod > 0 ? chunk % colmod : chunk) * WT;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
       if constexpr (PAIRS) {  // v0 = nonzeros (2 st) * 128 + 2 lane .. +1, v1 = the same in the next 128
@@ -3126,13 +3130,15 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
 #define PSP_W3_AB(NTL, PAIRS)                                                                          \
   hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, NTL, PAIRS>), dim3(grid), dim3(256), 0, stream(), c0, c1, \
                      stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
-                     A->val, x, y, dotv, pbuf, skip, perm, rowperm)
+                     A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod)
   const int ab = w3_ab(A);
+  const char *cm = psp::tuning_env("PSP_W3_COLMOD");
+  const int colmod = cm ? atoi(cm) : 0;
   if constexpr (NB == 32 || NB == 64) {
     if (t->outliers > 0) {  // one form only: the default stream layout, with the per-chunk fallback compiled in
       hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, true>), dim3(grid), dim3(256), 0, stream(), c0, c1,
                          stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                         A->val, x, y, dotv, pbuf, skip, perm, rowperm, A->col);
+                         A->val, x, y, dotv, pbuf, skip, perm, rowperm, A->col, colmod);
       return;
     }
   }
@@ -3142,11 +3148,11 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
   else if (nts)
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm, rowperm);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod);
   else
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, false>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm, rowperm);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod);
 }
 
 template <int NP>

@@ -258,3 +258,34 @@ def test_bench_single_process_device_list_rehearsal():
     assert one["ranks"] == 1 and one["reductions"] == "none" and "dry_run" not in one
     # same right-hand side, same iteration count: the recurred residual agrees to rounding between 1 and 3 ranks
     assert abs(one["pcg_check"]["relres"] - d["pcg_check"]["relres"]) <= 1e-9 * one["pcg_check"]["relres"]
+
+
+@pytest.mark.gpu
+def test_bench_mtx_leg_on_a_matrix_market_file(tmp_path):
+    """`bench.py --mtx FILE` -- BASELINE.json configs[4] for a matrix the user supplies (the day Emilia_923.mtx is at hand):
+    ingest, kernel chosen, SpMV in SSS- and CSR-model bytes, Jacobi-MINRES us/iteration, parity against the oracle.  Here
+    on a small symmetric FEM-like file written on the spot."""
+    sys.path.insert(0, ROOT)
+    from pysparse_amd.tools import standins
+    n, ind, col, val, diag = standins.fem_sss_arrays(14, 13, 12, 16)
+    path = os.path.join(str(tmp_path), "fem_small.mtx")
+    import numpy as np
+    r = np.repeat(np.arange(n), np.diff(ind))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write("%d %d %d\n" % (n, n, val.size + n))
+        for i in range(n):
+            f.write("%d %d %.17g\n" % (i + 1, i + 1, diag[i]))
+        for i, j, v in zip(r, col, val):
+            f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
+    d = run_bench("--mtx", path, "--steps", "10")
+    for k in CONTRACT:
+        assert k in d, k
+    c = d["config5"]
+    assert c["n"] == n and c["nnz_lower"] == val.size and c["nnz_full"] == 2 * val.size + n
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 12 * val.size + 28 * n + 4 == c["sss_model_bytes"]
+    assert c["csr_model_bytes"] == 12 * (2 * val.size + n) + 20 * n + 4
+    assert c["parity"]["ok"] and c["parity"]["spmv_bit_exact_vs_oracle"] and c["parity"]["x_max_rel_diff"] <= 1e-12
+    assert c["minres"]["info"] == 0 and c["minres"]["us_per_iteration"] > 0 and c["kernel"]
+    assert 0 < d["roofline"]["frac"] <= 1.0 and c["csr_model_frac_of_peak"] <= 1.0
+    assert "error" not in d and d["data"] == "user file"
