@@ -972,8 +972,13 @@ static PyObject *CSRMat_get_psp_op(CSRMatObject *a, void *c) {
   return PyCapsule_New(a->op, PSP_OP_CAPSULE_NAME, NULL);
 }
 
+/* where the products of this process run: the GPU, or -- PSP_DEVICE=cpu, the opt-in host mode -- the host loops */
+static const char *psp_where(void) {
+  return strstr(psp_version(), "PSP_DEVICE=cpu") != NULL ? "in host memory (PSP_DEVICE=cpu)" : "on the GPU";
+}
+
 static PyObject *CSRMat_repr(CSRMatObject *a) {
-  return PyUnicode_FromFormat("<csr_mat object on the GPU, shape (%d,%d), nnz %d>", a->dim[0],
+  return PyUnicode_FromFormat("<csr_mat object %s, shape (%d,%d), nnz %d>", psp_where(), a->dim[0],
                               a->dim[1], a->nnz);
 }
 
@@ -1085,7 +1090,7 @@ static PyObject *SSSMat_get_psp_op(SSSMatObject *a, void *c) {
 }
 
 static PyObject *SSSMat_repr(SSSMatObject *a) {
-  return PyUnicode_FromFormat("<sss_mat object on the GPU, order %d, %d stored lower entries>",
+  return PyUnicode_FromFormat("<sss_mat object %s, order %d, %d stored lower entries>", psp_where(),
                               a->n, a->nnz);
 }
 

@@ -54,7 +54,7 @@ spmatrix.poisson_csr(30, 20).matvec_transp(x, yt)
 O.poisson_csr(30, 20).matvec_transp(x, yto)
 assert np.array_equal(yt, yto)
 assert S[3, 10] == S[10, 3] == -1.0 and S[5, 5] == 4.0 and S[0, 30] == 0.0
-assert "cpu loops" in repr(A) or True
+assert "PSP_DEVICE=cpu" in repr(A) and "on the GPU" not in repr(A) and "PSP_DEVICE=cpu" in repr(S)  # host-mode objects say where they live
 
 # ---- solvers against the goldens of the compiled reference kernels and, bit for bit, the oracle's sequential loops
 with open(os.path.join(ROOT, "tests", "golden", "ref_krylov.json")) as f:
