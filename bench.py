@@ -958,6 +958,9 @@ def main():
                     help="N > 1 as a plain script: time-out of every stage in seconds (default: per-stage caps inside "
                          "--deadline)")
     ap.add_argument("--stage", default="", help="set by the ladder: which stage this process is")
+    ap.add_argument("--rank-deadline", type=float, default=270.0,
+                    help="one rank of N started by an external torch.distributed.run: seconds after which the rank's "
+                         "watchdog gives up on the torch / RCCL path (rank 0 then runs the single-process stages)")
     ap.add_argument("--inject", default="",
                     help="failure injection for the launcher tests: exit:RANK (that rank leaves with code 3 after the "
                          "process group formed) or hang:RANK (that rank sleeps instead of taking part)")
@@ -983,6 +986,136 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not a.stage:
+        # started as one rank of N by somebody else's `torch.distributed.run` (the driver's scaling run), not by the
+        # ladder above: this rank guards itself
+        return guarded_rank(a, real_stdout)
+    return run_body(a, real_stdout)
+
+
+class RankGuard:
+    """One rank of an N-rank job that was NOT started by this file's ladder (the driver launches `python -m
+    torch.distributed.run ... bench.py --gpus N` itself): a hang in communicator set-up or a failing rank must still end
+    in ONE JSON line.  A watchdog thread per rank:
+      * `--rank-deadline` seconds without the job finishing, or an exception in the rank, or another rank's failure note
+        (a file keyed by the rendezvous port) -> ranks other than 0 leave QUIETLY with code 0 (a non-zero code would make
+        the launcher tear rank 0 down before it can answer); rank 0 waits a moment for their GPUs to be released, then
+        runs the rest of the ladder -- `single_process_rccl`, `single_process_fold` -- as FRESH child processes (this
+        process has touched the GPU and is never re-executed) and prints the winner's line with `launcher.fallback_from`
+        saying what the torch ranks died of, or the error line;
+      * SIGTERM from the launcher (some rank crashed hard): rank 0 prints the error line at once."""
+
+    def __init__(self, a, real_stdout):
+        import threading
+        self.a, self.out = a, real_stdout
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.flag = "/tmp/psp_bench_fail_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
+        self.t0 = time.time()
+        self.done = threading.Event()
+        self.lock = threading.Lock()
+        self.fired = False
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+
+    def start(self):
+        import signal
+        try:
+            if self.rank == 0 and os.path.exists(self.flag):
+                os.remove(self.flag)
+        except OSError:
+            pass
+        if self.rank == 0:
+            signal.signal(signal.SIGTERM, lambda *_: self._terminated())
+        self.thread.start()
+
+    def _watch(self):
+        while not self.done.wait(2.0):
+            if time.time() - self.t0 > self.a.rank_deadline:
+                self.fail("no result after %.0f s (--rank-deadline): a rank hangs" % self.a.rank_deadline)
+            if os.path.exists(self.flag):
+                try:
+                    why = open(self.flag).read()[:300]
+                except OSError:
+                    why = "another rank failed"
+                self.fail(why)
+
+    def _error_line(self, failed, msg):
+        a = self.a
+        return {"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic", "error": msg,
+                "launcher": {"stage": None, "fallback_from": failed, "ladder": list(LADDER), "started_by": "external launcher"}}
+
+    def _terminated(self):
+        with self.lock:
+            if self.fired:
+                return
+            self.fired = True
+        print(json.dumps(self._error_line([{"stage": "torch_rccl_ranks", "rc": None, "reason": "SIGTERM from the launcher "
+                                             "(another rank ended abnormally) after %.0f s" % (time.time() - self.t0)}],
+                                           "the launcher ended the job")), file=self.out, flush=True)
+        os._exit(1)
+
+    def fail(self, reason):
+        """called from the watchdog thread or from the rank's own exception handler; never returns"""
+        with self.lock:
+            if self.fired:
+                time.sleep(1e6)
+            self.fired = True
+        print("[bench rank %d] %s" % (self.rank, reason), file=sys.stderr, flush=True)
+        if self.rank != 0:
+            try:
+                with open(self.flag, "w") as f:
+                    f.write("rank %d: %s" % (self.rank, reason))
+            except OSError:
+                pass
+            os._exit(0)
+        failed = [{"stage": "torch_rccl_ranks", "rc": None, "reason": reason, "wall_s": time.time() - self.t0}]
+        time.sleep(6.0)  # the other ranks see the note / their own deadline and release their GPUs
+        argv = [t for t in sys.argv[1:]]
+        for stage in LADDER[1:]:
+            cmd, extra = _stage_cmd(stage, argv, self.world)
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+            env.update(extra)
+            budget = self.a.stage_timeout if self.a.stage_timeout > 0 else min(150.0, STAGE_CAP_S[stage])
+            rc, out, err, wall, timed_out = _run_stage(cmd, env, budget, lambda m: print("[bench rank 0] " + m, file=sys.stderr, flush=True))
+            lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+            rec = None
+            if lines:
+                try:
+                    rec = json.loads(lines[-1])
+                except ValueError:
+                    rec = None
+            if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
+                rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": list(LADDER),
+                                   "started_by": "external launcher (torch.distributed.run); rank 0 ran the fall-back "
+                                                 "stages as fresh child processes"}
+                print(json.dumps(rec), file=self.out, flush=True)
+                os._exit(0)
+            failed.append({"stage": stage, "rc": rc, "reason": ("timed out after %.0f s" % wall) if timed_out else
+                           ((rec or {}).get("error") or "exit code %d" % rc), "wall_s": wall, "stderr_tail": _err_tail(err)})
+        print(json.dumps(self._error_line(failed, "every stage of the launch ladder failed")), file=self.out, flush=True)
+        os._exit(1)
+
+    def finish(self):
+        self.done.set()
+
+
+def guarded_rank(a, real_stdout):
+    g = RankGuard(a, real_stdout)
+    g.start()
+    try:
+        rc = run_body(a, real_stdout)
+    except BaseException as e:  # noqa: BLE001 - whatever the rank died of becomes the reason
+        import traceback
+        traceback.print_exc()
+        g.fail("%s: %s" % (type(e).__name__, str(e)[:300]))
+    g.finish()
+    return rc
+
+
+def run_body(a, real_stdout):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -289,3 +289,55 @@ def test_bench_mtx_leg_on_a_matrix_market_file(tmp_path):
     assert c["minres"]["info"] == 0 and c["minres"]["us_per_iteration"] > 0 and c["kernel"]
     assert 0 < d["roofline"]["frac"] <= 1.0 and c["csr_model_frac_of_peak"] <= 1.0
     assert "error" not in d and d["data"] == "user file"
+
+
+def _run_external(*extra, timeout=240):
+    """bench.py as ONE RANK OF N under somebody else's torch.distributed.run -- how the driver's scaling run starts it"""
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--grid", "12,10,8", "--steps", "3", "--warmup", "1", "--pcg-iters", "5",
+                          "--no-cpu-baseline", "--test-backend", "tests.dist_oracle_backend:bench_factory"] + list(extra),
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    return out.returncode, lines, time.time() - t0, out.stderr
+
+
+def test_bench_as_a_rank_of_an_external_launcher_prints_its_line():
+    rc, lines, wall, err = _run_external()
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["parity_vs_n1"]["ok"] and d["pcg_check"]["iter"] == 6
+
+
+def test_bench_rank_guard_a_hanging_rank_still_ends_in_one_json_line():
+    """the driver starts the ranks itself (`python -m torch.distributed.run ... bench.py --gpus N`), so the ladder of
+    `python bench.py --gpus N` is not in play: every rank guards itself.  A rank that hangs lets its own watchdog leave
+    quietly and note why; rank 0 sees the note, runs the single-process stages as fresh children (they need GPUs this
+    container lacks and say so) and prints ONE error line; the job ends with rc != 0 well inside the limit"""
+    from pysparse_amd import device
+    if device.device_count() > 0:
+        pytest.skip("a GPU is present: rank 0's fall-back stages would run")
+    rc, lines, wall, err = _run_external("--inject", "hang:1", "--rank-deadline", "12")
+    assert rc != 0 and len(lines) == 1, err[-3000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and "error" in d and d["n_gpus"] == 2
+    f = d["launcher"]["fallback_from"]
+    assert [x["stage"] for x in f] == ["torch_rccl_ranks", "single_process_rccl", "single_process_fold"]
+    assert "hangs" in f[0]["reason"]  # rank 0's own deadline, or rank 1's note, whichever it sees first
+    assert wall < 120
+
+
+def test_bench_rank_guard_answers_the_launchers_sigterm_with_an_error_line():
+    """a rank that crashes hard makes the launcher end the others: rank 0 answers the SIGTERM with the error line"""
+    rc, lines, wall, err = _run_external("--inject", "exit:1")
+    assert rc != 0 and len(lines) == 1, err[-3000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and "SIGTERM" in d["launcher"]["fallback_from"][0]["reason"]
