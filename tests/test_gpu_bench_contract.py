@@ -341,3 +341,47 @@ def test_bench_rank_guard_answers_the_launchers_sigterm_with_an_error_line():
     assert rc != 0 and len(lines) == 1, err[-3000:]
     d = json.loads(lines[0])
     assert d["value"] is None and "SIGTERM" in d["launcher"]["fallback_from"][0]["reason"]
+
+
+@pytest.mark.gpu
+def test_bench_rank_guard_falls_back_to_the_single_process_stage_on_the_gpu():
+    """ranks started by an external torch.distributed.run (the driver's way), one of them hangs: its watchdog leaves
+    quietly, rank 0 runs the single-process stage as a fresh child on the GPU and prints THAT line, rc 0"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--share-gpu", "--grid", "64,48,36", "--steps", "4",
+                          "--warmup", "2", "--pcg-iters", "24", "--no-cpu-baseline", "--no-clocks", "--inject", "hang:1",
+                          "--rank-deadline", "45"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["launcher"]["stage"] == "single_process_rccl" and "external launcher" in d["launcher"]["started_by"]
+    assert d["launcher"]["fallback_from"][0]["stage"] == "torch_rccl_ranks" and "hangs" in d["launcher"]["fallback_from"][0]["reason"]
+    assert d["ranks"] == 2 and d["parity_vs_n1"]["ok"] and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_ladder_survives_a_real_rccl_failure():
+    """not an injected failure: two torch ranks over RCCL on ONE GPU -- RCCL refuses (duplicate device) and the ranks die with a
+    DistBackendError within seconds; the ladder's next stage (one process, device list, the GPU listed twice) produces the line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--grid", "64,48,36",
+                          "--steps", "4", "--warmup", "2", "--pcg-iters", "24", "--no-cpu-baseline", "--no-clocks",
+                          "--stage-timeout", "150"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["launcher"]["stage"] == "single_process_rccl"
+    f = d["launcher"]["fallback_from"]
+    assert len(f) == 1 and f[0]["stage"] == "torch_rccl_ranks" and f[0]["rc"] != 0
+    assert any("NCCL" in l or "DistBackendError" in l for l in f[0]["stderr_tail"]), f[0]["stderr_tail"]
+    assert d["parity_vs_n1"]["ok"] and d["ranks"] == 2
