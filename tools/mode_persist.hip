@@ -340,6 +340,25 @@ int main(int argc, char **argv) {
       printf("]");
     }
   }
+  // is the level a RELATION between the placements of x and y?  Both inside ONE allocation, x at its start, y at distances
+  // of 1 GiB + k * 96 MiB behind it
+  if (argc > 7) {
+    char *blk;
+    const size_t gib = (size_t)1 << 30;
+    CK(hipMalloc((void **)&blk, 5 * gib));
+    double *xs = (double *)blk;
+    fill_kernel<<<4096, 256>>>(n, xs);
+    CK(hipDeviceSynchronize());
+    printf(", \"xy_one_allocation_ms\": [");
+    for (int k = 0; k < 30; ++k) {
+      double *ys = (double *)(blk + gib + (size_t)k * (96 << 20));
+      auto run = [&]() { plain_kernel<<<grid, 256>>>(nblk, n, stripe, offs, A.valT, A.mask, xs, ys); };
+      printf("%s%.4f", k ? ", " : "", time_ms(run, 5, 30));
+    }
+    printf("]");
+    // and a block-structure test (VERDICT-independent): the same kernel without the 2 bytes of row mask per row for row
+    // blocks whose rows all store every offset (a per-block byte says so) -- what would a mask-free interior buy?
+  }
   printf("}\n");
   return 0;
 }

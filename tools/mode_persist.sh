@@ -4,5 +4,5 @@
 N=${1:-10}
 E=${2:-512}
 for i in $(seq 1 $N); do
-  ./tools/mode_persist $E 4 $3 $4 $5 $6 || exit 1
+  ./tools/mode_persist $E 4 $3 $4 $5 $6 $7 || exit 1
 done
