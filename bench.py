@@ -920,6 +920,8 @@ def single_process_main(a):
 
 
 def main():
+    import signal
+    signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})  # (a fall-back stage started by a guarded rank inherits its mask)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -1025,11 +1027,19 @@ class RankGuard:
         except OSError:
             pass
         if self.rank == 0:
-            signal.signal(signal.SIGTERM, lambda *_: self._terminated())
+            # SIGTERM is BLOCKED in this thread (and in every thread started from now on) and picked up by the watchdog with
+            # sigtimedwait: a Python-level handler would never run while the main thread sits inside a collective
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
         self.thread.start()
 
     def _watch(self):
-        while not self.done.wait(2.0):
+        import signal
+        while not self.done.is_set():
+            if self.rank == 0:
+                if signal.sigtimedwait({signal.SIGTERM}, 2.0) is not None:
+                    self._terminated()
+            elif self.done.wait(2.0):
+                break
             if time.time() - self.t0 > self.a.rank_deadline:
                 self.fail("no result after %.0f s (--rank-deadline): a rank hangs" % self.a.rank_deadline)
             if os.path.exists(self.flag):
@@ -1099,7 +1109,11 @@ class RankGuard:
         os._exit(1)
 
     def finish(self):
+        import signal
         self.done.set()
+        if self.rank == 0:
+            self.thread.join(timeout=5.0)
+            signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})
 
 
 def guarded_rank(a, real_stdout):
