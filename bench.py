@@ -689,6 +689,11 @@ def mtx_leg(spec, steps=50, minres_iters=200):
         source = "seeded stand-in %s (pysparse_amd/tools/standins.py), NOT the SuiteSparse file" % kind
     else:
         from pysparse_amd.tools import mtx
+        with open(spec, "r") as f:
+            banner = f.readline().lower().split()
+        if len(banner) < 5 or banner[4] != "symmetric":
+            # to_sss() of a general matrix silently drops its upper triangle (ll_mat.c:1654-1708): numbers for half a matrix
+            raise SystemExit("--mtx expects a SYMMETRIC coordinate file (configs[4] is an sss_mat); banner: " + " ".join(banner))
         n, ind, col, val, diag = mtx.sss_arrays_from_mtx(spec)
         source = "MatrixMarket file " + os.path.basename(spec)
     ingest_s = time.perf_counter() - t0
