@@ -479,11 +479,20 @@ def _run_stage(cmd, env, timeout_s, log):
 
 
 def _err_tail(err, keep=14):
-    """the lines of a failed stage's stderr worth keeping: the last exception lines of the ranks before torchrun's
-    summary table, then the end"""
+    """the lines of a failed stage's stderr worth keeping: the exception lines of the ranks (`SomeError: message`, the
+    first few -- the root cause comes first -- and the last), injected-failure notes, then the end of the stream"""
+    import re
     lines = [l for l in err.strip().splitlines() if l.strip()]
-    hits = [l for l in lines if ("Error" in l or "error:" in l.lower() or "injected failure" in l) and "error_file" not in l]
-    return (hits[-6:] + lines[-(keep - min(len(hits), 6)):])[-keep:]
+    pat = re.compile(r"\b\w*(Error|Exception)\b: \S")
+    hits = [l.strip()[:300] for l in lines if (pat.search(l) or "injected failure" in l)
+            and "ChildFailedError" not in l and "error_file" not in l]
+    seen, uniq = set(), []
+    for l in hits:
+        if l not in seen:
+            seen.add(l)
+            uniq.append(l)
+    head = uniq[:4] + [l for l in uniq[-2:] if l not in uniq[:4]]
+    return (head + lines[-max(2, keep - len(head)):])[:keep + 2]
 
 
 def orchestrate(a, argv):
