@@ -68,6 +68,9 @@ timeout 900 python3 bench.py --gpus 4 --single-process --share-gpu --steps 10 --
 #     dies (falls through to the single-process stage); configs[4] through bench.py --mtx on the three stand-ins
 timeout 900 python3 bench.py --gpus 3 --backend gloo --share-gpu --grid 256,256,255 --steps 10 --warmup 3 --pcg-iters 40 --no-cpu-baseline --no-clocks > $OUT/r4_ladder_3ranks_gloo_one_gpu.json 2>> $OUT/tools.err
 timeout 900 python3 bench.py --gpus 3 --backend gloo --share-gpu --grid 256,256,255 --steps 10 --warmup 3 --pcg-iters 40 --no-cpu-baseline --no-clocks --inject exit:1 > $OUT/r4_ladder_fallback_one_gpu.json 2>> $OUT/tools.err
+# eight ranks (the node's rank count) in ONE process sharing this GPU at configs[3]'s true size, and four torch ranks over gloo sharing it (the box allows six processes on its GPU at once: 6 ranks trip the guard)
+timeout 900 python3 bench.py --gpus 8 --single-process --share-gpu --steps 10 --warmup 3 --pcg-iters 16 > $OUT/r4_single_process_n8_1024_one_gpu.json 2>> $OUT/tools.err
+timeout 900 python3 bench.py --gpus 4 --backend gloo --share-gpu --grid 256,256,252 --steps 6 --warmup 2 --pcg-iters 30 --no-cpu-baseline --no-clocks --ladder torch_rccl_ranks > $OUT/r4_ladder_4ranks_gloo_one_gpu.json 2>> $OUT/tools.err
 rm -f $OUT/r4_mtx_leg_standins.jsonl
 for s in fem32 fem512 logspaced; do timeout 300 python3 bench.py --mtx standin:$s >> $OUT/r4_mtx_leg_standins.jsonl 2>> $OUT/tools.err; done
 timeout 600 python3 bench.py --gpus 1 --single-process --steps 20 --warmup 5 --pcg-iters 32 > $OUT/r4_single_process_n1_512.json 2>> $OUT/tools.err
