@@ -1515,7 +1515,11 @@ def run_body(a, real_stdout):
                 "csr_model_bytes_per_launch": csr_model_bytes(n_loc, nnz_loc),
                 "csr_model_equiv_GBps": csr_model_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9,
                 "note": "achieved = bytes this kernel's format needs (csr_spmv_w4: 8 B per stored-offset slot + "
-                        "2 B row mask + x + y; no column indices) / avg launch time of the K timed launches",
+                        "2 B row mask + x + y; no column indices) / avg launch time of the K timed launches.  traffic "
+                        "above the algorithmic bytes (1.11x at 512^3) is ONE extra pass over x served by the Infinity "
+                        "Cache, not DRAM: the per-matrix XCD stripe of 128 workgroups lets two XCDs fetch the same x "
+                        "plane at the same time and was chosen because it is 2.5 % FASTER than the stripe of 32 that "
+                        "reads 1.007x (DESIGN.md section 3, HISTORY.md 3.1c)",
             },
         }
         out["provenance"] = provenance(L)
