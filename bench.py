@@ -1530,7 +1530,8 @@ def run_body(a, real_stdout):
             out["launcher_kind"] = "one torch.distributed rank per GPU"
             tr = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()
             out["transport"] = {"halo": "%s send/recv (torch.distributed batch_isend_irecv)" % tr,
-                                "reductions": "%s all-reduce in stream order" % tr}
+                                "reductions": "%s all-reduce %s" % (tr, "in stream order" if tr == "RCCL" else
+                                                                    "(host-synchronised around every transfer: rehearsal only)")}
             if preflight is not None:
                 out["preflight"] = preflight
             if phases is not None:
