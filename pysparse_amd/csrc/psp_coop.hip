@@ -21,8 +21,11 @@
 //
 // Grid barrier (MI355X_MICROARCH.md "Correctness boundaries", cdna_hip_programming.md G16, second form): the per-XCD
 // L2s are not coherent with each other, so every byte handed from one workgroup to another is stored AND loaded with
-// agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 128 workgroups of 1024 threads (one row per thread) --
+// agent-scope accesses, drained (s_waitcnt) before the workgroup announces itself on one arrival counter.  The grid is at most 256 workgroups of 1024 threads (one row per thread, one workgroup per CU; 128 until round 4) --
 // and every spin is bounded: a barrier that does not complete sets an error flag that ends all workgroups.
+// Round 4: the range went from 2^17 to 2^18 rows once the launch was cooperative and checked against the device's capacity:
+// poisson2d(512), 256 workgroups: 21.8 / 19.0 us per PCG / MINRES iteration against 27 / 26 with one launch per phase
+// (tools/coop_range_probe.py, profiles/r4_coop_range.txt).
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -34,9 +37,9 @@ namespace psp {
 
 namespace {
 
-constexpr int kCoopMaxWg = 128;  // workgroups of 1024 threads: one per two CUs, all co-resident
+constexpr int kCoopMaxWg = 256;  // workgroups of 1024 threads: at most one per CU, all co-resident (round 4: 128 before)
 constexpr int kCoopBlock = 1024;
-constexpr int kCoopMaxRows = 128 * 1024;  // 2^17 rows; beyond that the asynchronous loops (whole-chip kernels) take over
+constexpr int kCoopMaxRows = 256 * 1024;  // 2^18 rows; beyond that the asynchronous loops (whole-chip kernels) take over
 
 struct CoopCtl {
   unsigned count;

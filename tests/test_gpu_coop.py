@@ -1,5 +1,5 @@
 """GPU: the single-kernel PCG / MINRES loops for small systems (pysparse_amd/csrc/psp_coop.hip; pcg.c:91-166,
-minres.c:96-193): up to 2^17 rows with at most 8 entries each, native matrix, K = None or jacobi(1).
+minres.c:96-193): up to 2^18 rows (2^17 until round 4) with at most 8 entries each, native matrix, K = None or jacobi(1).
 
   * against the oracle: identical info / iteration counts, iterates <= 1e-12, residual histories <= 1e-5 (at the rounding floor), on sizes that
     need 1, a few and many workgroups (every barrier path), 2-D / 3-D stencils and an irregular matrix;
@@ -47,7 +47,7 @@ def small_irregular(oracle, n, seed):
 
 
 CASES = [("p2d", (31, 29, 0)), ("p2d", (100, 100, 0)), ("p2d", (300, 300, 0)), ("p3d", (20, 19, 18)), ("p3d", (48, 47, 46)),
-         ("irr", 5000), ("irr", 70000)]
+         ("irr", 5000), ("irr", 70000), ("p2d", (512, 512, 0)), ("p3d", (64, 63, 62))]  # (the last two: 245 / 256 workgroups)
 
 
 @pytest.mark.parametrize("kind,arg", CASES)
@@ -55,7 +55,7 @@ def test_single_kernel_loops_match_the_oracle(oracle, kind, arg):
     from pysparse_amd import device as dev
     O = oracle.poisson_csr(*arg) if kind != "irr" else small_irregular(oracle, arg, 3)
     n = O.shape[0]
-    assert n <= (1 << 17) and np.diff(O.ind).max() <= 8
+    assert n <= (1 << 18) and np.diff(O.ind).max() <= 8
     D = dev.DeviceCSR.from_arrays(O.shape, O.ind, O.col, O.val)
     b = np.random.default_rng(1).standard_normal(n)
     dinv = oracle.jacobi_dinv(O.diagonal())
@@ -126,7 +126,7 @@ def test_reference_goldens_at_config0_size(oracle, golden_dir):
 
 
 def test_matrices_the_kernel_does_not_take(oracle):
-    """rows longer than 8 entries (27-point stencil) and systems beyond 2^17 rows run on the other loops, same answers"""
+    """rows longer than 8 entries (27-point stencil) and systems beyond 2^18 rows run on the other loops, same answers"""
     from pysparse_amd import device as dev
     A = oracle.poisson_csr(9, 8, 7)
     rows = np.repeat(np.arange(A.shape[0]), np.diff(A.ind))

@@ -270,10 +270,10 @@ def test_poisson_big_equals_csr_operator(oracle, grid):
     ra = dev.pcg(A, b, xa, 1e-10, 2000, dev.DeviceJacobi(A))
     rb = dev.pcg(B, b, xb, 1e-10, 2000, dev.DeviceJacobi(B))
     # the same operator in two layouts: identical counts; bit-identical iterates when both run the same loop (an operator
-    # with CSR arrays and <= 2^17 rows takes the single-kernel loop of psp_coop.hip, the index-free one never does)
+    # with CSR arrays and <= 2^18 rows takes the single-kernel loop of psp_coop.hip, the index-free one never does)
     assert ra[:2] == rb[:2] and abs(ra[2] - rb[2]) <= 1e-6 * rb[2]
     assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xb).max()
-    if n > (1 << 17):
+    if n > (1 << 18):
         assert ra == rb and np.array_equal(xa, xb)
     with pytest.raises(PspError):
         B.download()
@@ -379,6 +379,21 @@ def test_poisson_big_slab_rejects_bad_arguments():
         dev.DeviceCSR.poisson_big_slab(8, 8, 8, 128, 64, 0, 512)       # empty / inverted range
 
 
+def _release_this_process_gpu_memory():
+    """handles of earlier tests that await garbage collection, the solvers' scratch pool (up to a third of the device) and
+    torch's caching allocator all belong to THIS process; a test that starts children at configs[3]'s true size frees them"""
+    import gc
+    gc.collect()
+    from pysparse_amd._capi import lib
+    lib().psp_trim()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    except ImportError:
+        pass
+
+
 def test_config4_1024_cubed_four_ranks_rehearsal():
     """BASELINE.json configs[3] at its true size on the ranks' true shares: the 1024^3 operator cut into 4 z-slabs of
     2^28 rows (1.9e9 nonzeros each: beyond 32-bit CSR offsets, index-free slab operator), bench.py's own launcher
@@ -391,13 +406,16 @@ def test_config4_1024_cubed_four_ranks_rehearsal():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    _release_this_process_gpu_memory()  # the children need ~200 of the 288 GB: this process must not sit on its caches
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo",
                           "--share-gpu", "--steps", "3", "--warmup", "1", "--pcg-iters", "20", "--no-cpu-baseline",
                           "--no-clocks"], capture_output=True, text=True, cwd=root, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["config"]["n"] == 1 << 30 and d["config"]["nnz"] == 7509901312 and d["config"]["rows_per_gpu"] == 1 << 28
+    assert d["launcher"]["stage"] == "torch_rccl_ranks", d["launcher"]  # (what the torch ranks died of, if they did)
     assert d["rccl_ranks"] == 4 and d["scaling"] == "strong"
+    assert d["parity_vs_n1"]["ok"], d["parity_vs_n1"]
     one, four = d["strong_n1"]["pcg_check"], d["pcg_check"]
     assert (one["info"], one["iter"]) == (four["info"], four["iter"]) == (-1, 21)
     assert abs(one["relres"] - four["relres"]) <= 1e-12 * one["relres"]
@@ -415,6 +433,7 @@ def test_config4_1024_cubed_one_process_device_list_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     res = {}
+    _release_this_process_gpu_memory()
     for ranks, extra in ((4, ["--share-gpu"]), (1, ["--grid", "1024,1024,1024"])):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--single-process",
                               "--steps", "3", "--warmup", "1", "--pcg-iters", "16"] + extra, capture_output=True, text=True,
