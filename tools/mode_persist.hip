@@ -186,6 +186,34 @@ __global__ void full_flags_kernel(long nblk, long nrows, const unsigned short *_
   }
 }
 
+// translation probe: one 8-byte read per `stride` bytes of a buffer, every thread a different page -- the time is
+// dominated by address translation (few bytes move), so it tells buffers backed by large page fragments from others
+__global__ void touch_kernel(const double *__restrict__ v, long n, long stride_d, long phase, double *sink) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * stride_d + phase;
+  if (i < n && v[i] == 12345.678) *sink = 1.0;
+}
+static double touch_us(const double *v, long n, double *sink) {
+  const long stride_d = 4096 / 8;  // one read per 4 KiB
+  const long cnt = n / stride_d;
+  double best = 1e9;
+  for (int rep = 0; rep < 6; ++rep) {
+    auto run = [&]() { touch_kernel<<<(unsigned)((cnt + 255) / 256), 256>>>(v, n, stride_d, (rep * 37) % stride_d, sink); };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    run();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    if (rep) best = std::min(best, (double)ms * 1e3);
+  }
+  return best;
+}
+
 struct Op {
   void *pad = nullptr;
   double *valT = nullptr;
@@ -324,6 +352,10 @@ int main(int argc, char **argv) {
   // in between, everything stays alive)
   if (argc > 4) {
     std::vector<void *> keep;
+    double touch[2][8];
+    printf(", \"touch_us_x0_y0_yref_valT\": [%.1f, %.1f, %.1f, %.1f]", touch_us(x, n, (double *)counters),
+           touch_us(y, n, (double *)counters), touch_us(yref, n, (double *)counters),
+           touch_us(A.valT, n, (double *)counters));
     for (int which = 0; which < 2; ++which) {
       printf(", \"%s_lottery_ms\": [", which == 0 ? "y" : "x");
       for (int k = 0; k < 8; ++k) {
@@ -338,7 +370,11 @@ int main(int argc, char **argv) {
         double *xs = which == 1 ? v : x, *ys = which == 0 ? v : y;
         auto run = [&]() { plain_kernel<<<grid, 256>>>(nblk, n, stripe, offs, A.valT, A.mask, xs, ys); };
         printf("%s%.4f", k ? ", " : "", time_ms(run, 5, 30));
+        touch[which][k] = touch_us(v, n, (double *)counters);
       }
+      printf("]");
+      printf(", \"%s_lottery_touch_us\": [", which == 0 ? "y" : "x");
+      for (int k = 0; k < 8; ++k) printf("%s%.1f", k ? ", " : "", touch[which][k]);
       printf("]");
     }
   }
