@@ -475,7 +475,7 @@ def _run_stage(cmd, env, timeout_s, log):
         fe.seek(0)
         out = fo.read().decode("utf-8", "replace")
         err = fe.read().decode("utf-8", "replace")
-    return (p.returncode if p.returncode is not None else -9), out, err[-3000:], time.time() - t0, timed_out
+    return (p.returncode if p.returncode is not None else -9), out, err[-200000:], time.time() - t0, timed_out  # (_err_tail condenses it)
 
 
 def _err_tail(err, keep=14):
@@ -484,7 +484,8 @@ def _err_tail(err, keep=14):
     import re
     lines = [l for l in err.strip().splitlines() if l.strip()]
     pat = re.compile(r"\b\w*(Error|Exception)\b: \S")
-    hits = [l.strip()[:300] for l in lines if (pat.search(l) or "injected failure" in l)
+    hits = [l.strip()[:300] for k, l in enumerate(lines)
+            if (pat.search(l) or "injected failure" in l or (k and lines[k - 1].strip() == "Last error:"))  # (RCCL's own reason)
             and "ChildFailedError" not in l and "error_file" not in l]
     seen, uniq = set(), []
     for l in hits:
