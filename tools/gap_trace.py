@@ -14,9 +14,9 @@ import numpy as np
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
-    name = re.sub(r"<.*", "", name)
-    return name.split("::")[-1].replace("void ", "").strip()
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"[<(].*", "", name)
+    return name.split("::")[-1].strip()
 
 
 def main():
@@ -38,6 +38,26 @@ def main():
     for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
         if len(v) >= min_count:
             print("%-34s %7d %10.2f %10.2f" % (k, len(v), np.mean(v), np.median(v)))
+    # busy fraction of the stretches in which kernels follow each other without a host round trip (gap < 200 us)
+    seg_busy, seg_span, seg_n, cur0, cur_busy, n_in = 0.0, 0.0, 0, None, 0.0, 0
+    longest = []
+    for i, (s0, e0, k0) in enumerate(rows):
+        if cur0 is None:
+            cur0, cur_busy, n_in = s0, 0.0, 0
+        cur_busy += e0 - s0
+        n_in += 1
+        last = i == len(rows) - 1 or (rows[i + 1][0] - e0) / 1e3 >= 200.0
+        if last:
+            if n_in >= 50:
+                seg_busy += cur_busy
+                seg_span += e0 - cur0
+                seg_n += 1
+                longest.append(((e0 - cur0) / 1e6, cur_busy / (e0 - cur0), n_in))
+            cur0 = None
+    if seg_span:
+        print("# stretches of >= 50 back-to-back kernels: %d, kernel-busy fraction of their span %.4f" % (seg_n, seg_busy / seg_span))
+        for ms, frac, cnt in sorted(longest, reverse=True)[:6]:
+            print("#   stretch of %.2f ms, %d kernels, busy %.4f" % (ms, cnt, frac))
     print("# gaps between consecutive kernels (us): count mean median   [end of first -> start of second]")
     for (k0, k1), v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
         if len(v) >= min_count:
