@@ -1215,7 +1215,10 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
     int blk0, int blk1, int nrows, int ncols, int stripe, DiaOffs offs, const double *__restrict__ valT,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    int use_div, double xdiv, const double *__restrict__ xdiv_dev) {
+    int use_div, double xdiv, const double *__restrict__ xdiv_dev, int dot_slot) {
+  // dot_slot >= 0 (round 4): the dot's operand IS x seen through offset slot dot_slot (dotv == x + offs.o[dot_slot]: p.q
+  // of PCG, v.Av of MINRES) -- its pair is already in registers (xv[dot_slot], divided like dotv would be), so the
+  // epilogue loads nothing: the same values, hence the same bits, 3.5 % less time for the product inside the loops
   // use_div: multiply with x ./ xdiv instead of x (MINRES: v = y / beta formed on the fly,
   // minres.c:123-124 -- the same correctly rounded division as the separate pass)
   if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
@@ -1288,17 +1291,39 @@ __global__ __launch_bounds__(256) void csr_spmv_w4(
       else
         *reinterpret_cast<d2u *>(y + r) = outu;
       if (dotv) {
-        d2u u = *reinterpret_cast<const d2u *>(dotv + r);
-        if (use_div) {
-          u.x = u.x / xdiv;
-          u.y = u.y / xdiv;
+        d2u u;
+        if (dot_slot >= 0) {  // (wave-uniform) the operand's pair is xv[dot_slot]
+          u.x = 0.0;
+          u.y = 0.0;
+#pragma unroll
+          for (int o = 0; o < NO; ++o)
+            if (o == dot_slot) {
+              u.x = xv[o].x;
+              u.y = xv[o].y;
+            }
+        } else {
+          u = *reinterpret_cast<const d2u *>(dotv + r);
+          if (use_div) {
+            u.x = u.x / xdiv;
+            u.y = u.y / xdiv;
+          }
         }
         dsum += u.x * a0;
         dsum += u.y * a1;
       }
     } else {
       y[r] = a0;
-      if (dotv) dsum += (use_div ? dotv[r] / xdiv : dotv[r]) * a0;
+      if (dotv) {
+        double u0 = 0.0;
+        if (dot_slot >= 0) {
+#pragma unroll
+          for (int o = 0; o < NO; ++o)
+            if (o == dot_slot) u0 = xv[o].x;
+        } else {
+          u0 = use_div ? dotv[r] / xdiv : dotv[r];
+        }
+        dsum += u0 * a0;
+      }
     }
   }
   if (partials) {
@@ -1358,7 +1383,8 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     int n, int stripe, SssOffs offs, const double *__restrict__ valL, const double *__restrict__ diag,
     const unsigned short *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
-    int use_div, double xdiv, const double *__restrict__ xdiv_dev) {
+    int use_div, double xdiv, const double *__restrict__ xdiv_dev, int dot_is_x) {
+  // dot_is_x (round 4): dotv == x -- the dot's operand is the diagonal term's x pair (x0), already in registers
   if (skip && *skip) return;
   if (xdiv_dev) xdiv = *xdiv_dev;
   __shared__ double red[4];
@@ -1506,17 +1532,23 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
       outu.y = a1;
       __builtin_nontemporal_store(outu, reinterpret_cast<d2u *>(y + r));
       if (dotv) {
-        d2u u = *reinterpret_cast<const d2u *>(dotv + r);
-        if (use_div) {
-          u.x = u.x / xdiv;
-          u.y = u.y / xdiv;
+        d2u u;
+        if (dot_is_x) {  // x0 is final here (repaired at the edges, divided when use_div)
+          u.x = x0.x;
+          u.y = x0.y;
+        } else {
+          u = *reinterpret_cast<const d2u *>(dotv + r);
+          if (use_div) {
+            u.x = u.x / xdiv;
+            u.y = u.y / xdiv;
+          }
         }
         dsum += u.x * a0;
         dsum += u.y * a1;
       }
     } else {
       y[r] = a0;
-      if (dotv) dsum += (use_div ? dotv[r] / xdiv : dotv[r]) * a0;
+      if (dotv) dsum += (dot_is_x ? x0.x : (use_div ? dotv[r] / xdiv : dotv[r])) * a0;
     }
   }
   if (partials) {
@@ -2627,16 +2659,31 @@ static int ensure_w4(const psp_csr *A, psp::CsrExtra **out) {
   return PSP_OK;
 }
 
+// PSP_W4_DOT_RELOAD=1 (tuning switch, read per launch: tools/dot_reuse_ab.py alternates it in one process): the dot
+// epilogue of the index-free kernels loads its operand again even when it is x (rounds 1-3)
+static bool w4_dot_reload() {
+  const char *e = psp::tuning_env("PSP_W4_DOT_RELOAD");
+  return e && atoi(e) != 0;
+}
+
 // csr_spmv_w4 over row blocks [b0, b1)
 static int launch_w4(const psp_csr *A, const psp::CsrExtra *ex, int stripe, int b0, int b1, const double *x,
                      double *y, const double *dotv, double *pbuf, const int *skip, int grid, int use_div = 0,
                      double xdiv = 1.0, const double *xdiv_dev = nullptr) {
   if (use_div && ex->dia_no > 16) return fail(PSP_EINVAL, "csr_spmv_w4x has no scaled form");
   const int flags = (A->variant >= 0 ? A->variant : 0) >> 23 & 3;  // A/B knobs: bit 23 plain val loads, 24 plain y stores
+  // the dot's operand as a view of x: dotv == x + offs[k] for some stored offset k (p.q, v.Av: k = the diagonal's slot)
+  int dot_slot = -1;
+  if (dotv && ex->dia_no <= 16 && !w4_dot_reload()) {
+    const intptr_t diff = (intptr_t)dotv - (intptr_t)x;
+    if (diff % (intptr_t)sizeof(double) == 0)
+      for (int k = 0; k < ex->dia_no; ++k)
+        if ((intptr_t)ex->dia_offs.o[k] == diff / (intptr_t)sizeof(double)) dot_slot = k;
+  }
 #define PSP_W4_F(NO, NTL, NTS)                                                                       \
   hipLaunchKernelGGL((csr_spmv_w4<NO, NTL, NTS>), dim3(grid), dim3(256), 0, stream(), b0, b1, A->nrows, \
                      A->ncols, stripe, ex->dia_offs, ex->dia_val, ex->dia_mask, x, y, dotv, pbuf, skip,  \
-                     use_div, xdiv, xdiv_dev)
+                     use_div, xdiv, xdiv_dev, dot_slot)
 #define PSP_W4(NO)                                                                                   \
   case NO:                                                                                           \
     if (flags == 0) PSP_W4_F(NO, true, true);                                                        \
@@ -2761,7 +2808,8 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
   const int flags = (S->full->variant >= 0 ? S->full->variant : 0) >> 23 & 3;  // A/B: 1 NT lower loads (-6 %), 2 NT shifted loads (-25 %); profiles/r1_sss_spmv_w4_timing.txt
 #define PSP_SW4_F(NOL, F)                                                                            \
   hipLaunchKernelGGL((sss_spmv_w4<NOL, F>), dim3(grid), dim3(256), 0, stream(), S->n, stripe, so,     \
-                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv, xdiv_dev)
+                     S->w4_val, S->diag, S->w4_mask, x, y, dotv, pbuf, skip, use_div, xdiv, xdiv_dev,         \
+                     (dotv == x && !w4_dot_reload()) ? 1 : 0)
   static const bool shfl = [] {
     const char *e = psp::tuning_env("PSP_SSS_SHFL");  // A/B: 0 = every offset by its own loads (round 1)
     return e ? atoi(e) != 0 : true;
