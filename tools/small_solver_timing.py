@@ -47,7 +47,7 @@ if __name__ == "__main__":
         if isinstance(res["launch_per_phase_loops"], dict):
             for size, row in res["device_scalars"].items():
                 a = res["launch_per_phase_loops"][size]
-                print("%s: single-kernel loop (default up to 2^17 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
+                print("%s: single-kernel loop (default up to 2^18 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
                       "pcg %.1f / minres %.1f" % (size, row["pcg"]["us_per_iter"], row["minres"]["us_per_iter"],
                                                    a["pcg"]["us_per_iter"], a["minres"]["us_per_iter"]), flush=True)
         env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0", PSP_MINRES_ASYNC="0")
