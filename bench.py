@@ -1310,6 +1310,33 @@ def run_body(a, real_stdout):
                             "csr_model_frac": csr_model_bytes(n_loc, nnz_loc) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS})
         A.set_variant(-1)
 
+    # ---- beside it (N = 1): the placement levels (profiles/r4_modes.txt).  What a launch takes depends
+    # on where in device memory its operands lie; `value` above is THIS job's first allocation, as any job's would be.  Here y
+    # is re-allocated six times (pads of odd sizes in between, everything stays alive until the end) and the same launch is
+    # timed on each: the spread a user sees, in every bench line.  Reported only -- never used for `value` / `roofline`.
+    placement = None
+    if not use_dist and not dry and not a.no_kernels:
+        keep, ms_list = [], []
+        try:
+            for j in range(6):
+                keep.append(dev.DeviceBuffer((37 + 101 * j) * (1 << 17) + 512 * j))  # (37 + 101 j) MiB + 4 j KiB
+                yj = dev.DeviceBuffer(n_loc)
+                keep.append(yj)
+                fj = lambda yj=yj: A.matvec_dev(xb.ptr, yj.ptr)  # noqa: E731
+                timed_launches(fj, sync, ev, 3)
+                ms_list.append(timed_launches(fj, sync, ev, min(a.steps, 20))[0])
+            placement = {"what": "the same launch with y re-allocated six times (x and the operator stay): where the operands lie "
+                                 "decides up to 8 % (profiles/r4_modes.txt); `value` is the job's FIRST allocation",
+                         "y_realloc_avg_launch_ms": ms_list, "first_allocation_ms": None,
+                         "best_ms": min(ms_list), "worst_ms": max(ms_list),
+                         "best_frac_of_peak": kbytes_loc / (min(ms_list) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "worst_frac_of_peak": kbytes_loc / (max(ms_list) * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        except Exception as e:  # noqa: BLE001 - a reported extra (e.g. out of memory on a small device), never fatal
+            placement = {"error": str(e)[:200]}
+        for bfr in keep:
+            bfr.free()
+        del keep
+
     # ---- beside it (N = 1): what this GPU's memory system gives the library's own streaming kernels in
     # the same run ("a measured device ceiling from the same run") -- a read-only pass (the dot
     # product kernel: 16 n bytes) and a read-read-write pass (y = x o dinv: 24 n bytes) over the same vectors
@@ -1560,6 +1587,10 @@ def run_body(a, real_stdout):
                         out["error"] = "parity_vs_n1 failed: max relative difference %.3e > %.1e" % (
                             par["max_rel_diff"], PARITY_TOL)
                         exit_code = 1
+        if placement is not None:
+            if "first_allocation_ms" in placement:
+                placement["first_allocation_ms"] = kern_ms
+            out["placement_sweep"] = placement
         if ceiling is not None:
             out["device_ceiling_same_run"] = ceiling
             probe = ceiling.get("read7_write1_probe")

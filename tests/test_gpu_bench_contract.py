@@ -53,6 +53,10 @@ def test_bench_json_contract_small_grid():
     assert d["sss_mat"]["kernel"] == "sss_spmv_w4" and d["sss_mat"]["frac"] <= 1.0
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9  # tol = 0: exactly 8 iterations
     assert d["pcg_iters_per_s"] > 0 and d["value"] > 0
+    # the placement sweep rides along and never feeds `value`: the first allocation's launch time is roofline's
+    ps = d["placement_sweep"]
+    assert len(ps["y_realloc_avg_launch_ms"]) == 6 and ps["first_allocation_ms"] == r["avg_launch_ms"]
+    assert 0 < ps["best_ms"] <= ps["worst_ms"] and ps["best_frac_of_peak"] <= 1.0
     # roofline.traffic: measured by rocprofv3 --pmc child runs of the same operator in this job -- where the box lets
     # an ordinary user read the counters; otherwise null (no committed pass exists for this grid), never a guess
     if r["traffic_source"] and r["traffic_source"].startswith("measured in this job"):
