@@ -194,7 +194,7 @@ def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, w
     return out
 
 
-def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None):
+def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None, threads=1):
     """oracle (C restatement of csr_mat.c:49-54 + pcg.c, gcc -O2, ONE thread) and, when it was built,
     the compiled reference PCG (oracle/_ref/libref_pcg.so = examples/poisson_test/pcg.c unmodified)"""
     t0 = time.perf_counter()
@@ -210,6 +210,21 @@ def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None):
         A.matvec(x, y)
         ts.append(time.perf_counter() - t)
     t_spmv = float(np.median(ts))
+    mt = None
+    if threads > 1:
+        # labelled NON-reference (optional second line): the reference's product is one thread; here the same
+        # rows go to POSIX threads in contiguous ranges (oracle: orc_csr_matvec_threads), each row summed as before
+        y2 = np.empty(n)
+        ran = A.matvec_threads(x, y2, threads)  # warm (first touch of y2)
+        tm = []
+        for _ in range(max(spmv_reps, 5)):
+            t = time.perf_counter()
+            A.matvec_threads(x, y2, threads)
+            tm.append(time.perf_counter() - t)
+        mt = {"threads": ran, "spmv_ms": float(np.median(tm)) * 1e3,
+              "spmv_GBps": csr_model_bytes(n, nnz) / float(np.median(tm)) / 1e9,
+              "same_bits_as_one_thread": bool(np.array_equal(y, y2))}
+        del y2
     b = np.empty(n)
     A.matvec(np.ones(n), b)
     dinv = np.full(n, 1.0 / (6.0 if grid[2] else 4.0))  # jacobi(A, 1.0, 1) of the constant diagonal
@@ -222,6 +237,8 @@ def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None):
     out = {"n": n, "nnz": nnz, "spmv_GBps": csr_model_bytes(n, nnz) / t_spmv / 1e9, "spmv_ms": t_spmv * 1e3,
            "pcg_iters_per_s": 1.0 / t_pcg, "generate_s": gen_s,
            "sample": "median of %d SpMV; %d Jacobi-PCG iterations (tol 0)" % (spmv_reps, min(res[1], pcg_iters))}
+    if mt:
+        out["all_cores_non_reference"] = mt
     xr = rres = None
     if with_ref and O.have_ref():
         xr = np.zeros(n)
@@ -240,6 +257,31 @@ def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None):
     return out
 
 
+def _usable_cores():
+    """threads the "all host cores" line may use: the affinity mask, cut to the cgroup's CPU quota where one is set (a GPU
+    box shows all 256 hardware threads to a job that owns 16 of them) and to 64 (one thread's ranges stay >= 2 MB at C2)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = min(cores, max(1, int(quota + 0.5)))
+    return max(1, min(cores, 64))
+
+
 def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256), dev=None):
     """`cpu_baseline` (kind "port": the oracle's SpMV -- the reference's csr_mat.c needs the Python-2
     C API and cannot be compiled) and `cpu_baseline_reference_pcg` (kind "reference": the reference's
@@ -248,12 +290,13 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
     from oracle import oracle as O
     t0 = time.time()
     c1 = _cpu_case(O, (100, 100, 0), 200, 2000, True)  # configs[0]: the reference's own CPU-runnable case
-    c2 = _cpu_case(O, c2_grid, 10, 10, True, dev)
+    cores = _usable_cores()
+    c2 = _cpu_case(O, c2_grid, 10, 10, True, dev, cores)
     # C3 costs ~11x C2's generation + ~10x its per-pass time
     predicted = 11.2 * c2["generate_s"] + 10.5 * (5 * c2["spmv_ms"] * 1e-3 + 2 * 5 / c2["pcg_iters_per_s"])
     big = _mem_available_gb() > 48 and predicted < budget_s
     grid3 = c3_grid if big else c3_small
-    c3 = _cpu_case(O, grid3, 3 if big else 5, 3 if big else 10, True, dev)
+    c3 = _cpu_case(O, grid3, 3 if big else 5, 3 if big else 10, True, dev, cores)
     model, nproc = _cpu_model(), os.cpu_count()
     head = c3 if big else c2
     base = {
@@ -1653,6 +1696,18 @@ def run_body(a, real_stdout):
                 out["cpu_baseline"]["C1_poisson2d_100"]["gpu_error"] = str(e)[:200]
             if ref is not None:
                 out["cpu_baseline_reference_pcg"] = ref
+            # SURVEY 8d's optional second line, labelled: NOT the reference (which is one thread) -- the headline case's rows
+            # over every host core this job may use; never the baseline, it only places the one-core figure
+            heads = [v for k, v in base.items() if isinstance(v, dict) and k.startswith(("C3_", "poisson3d_"))]
+            mt = heads[0].get("all_cores_non_reference") if heads else None
+            if mt:
+                out["cpu_all_cores_non_reference"] = {
+                    "value": mt["spmv_GBps"], "unit": "GB/s", "cores": mt["threads"], "kind": "port",
+                    "sample": "the same CSR SpMV (n=%d), rows in contiguous ranges over %d POSIX threads, median of >= 5"
+                              % (heads[0]["n"], mt["threads"]),
+                    "note": "non-reference: pysparse's product is single-threaded (no OpenMP, GIL held); every y[i] has the "
+                            "one-thread bits (%s)" % mt["same_bits_as_one_thread"],
+                    "gpu_over_all_cores": out["effective_csr_model_GBps"] / mt["spmv_GBps"]}
         if world == 1 and not use_dist and os.environ.get("EMILIA_MTX"):
             try:  # configs[4] on the user's file, beside the headline (its own failure never costs the line)
                 out["config5"] = mtx_leg(os.environ["EMILIA_MTX"])

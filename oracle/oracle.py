@@ -57,6 +57,8 @@ def _declare(L):
     L.orc_dnrm2.argtypes = [C.c_int, _dp]
     L.orc_csr_matvec.restype = None
     L.orc_csr_matvec.argtypes = [C.c_int, _dp, _dp, _dp, _ip, _ip]
+    L.orc_csr_matvec_threads.restype = C.c_int
+    L.orc_csr_matvec_threads.argtypes = [C.c_int, _dp, _dp, _dp, _ip, _ip, C.c_int]
     L.orc_csr_matvec_stride.restype = None
     L.orc_csr_matvec_stride.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _dp, _ip, _ip]
     L.orc_csr_matvec_transp.restype = None
@@ -141,6 +143,10 @@ class CSR:
 
     def matvec(self, x, y):
         lib().orc_csr_matvec(self.shape[0], x, y, self.val, self.col, self.ind)
+
+    def matvec_threads(self, x, y, nthreads):
+        """NOT the reference (single-threaded): the same rows over POSIX threads, same bits; -> threads that ran"""
+        return lib().orc_csr_matvec_threads(self.shape[0], x, y, self.val, self.col, self.ind, nthreads)
 
     def matvec_transp(self, x, y):
         lib().orc_csr_matvec_transp(self.shape[0], self.shape[1], x, y, self.val, self.col, self.ind)

@@ -118,6 +118,24 @@ def test_sss_and_csr_matvec_agree_and_structure(oracle, golden_dir):
     assert np.allclose(yt, y2, rtol=1e-13, atol=1e-13)
 
 
+def test_row_parallel_matvec_has_the_one_thread_bits(oracle):
+    """bench.py's labelled "all host cores" line (NOT the reference, which is one thread): the rows go to POSIX threads in
+    contiguous ranges, each row summed exactly as csr_mat.c:49-54 -- same bits for any thread count, ragged rows, m < threads."""
+    rng = np.random.default_rng(5)
+    C = oracle.sss_to_csr(oracle.tendigit_sss(3000))  # 1 .. 25 entries per row
+    x = rng.standard_normal(3000)
+    y1 = np.empty(3000)
+    C.matvec(x, y1)
+    for t in (1, 2, 3, 7, 16, 300):
+        y2 = np.full(3000, np.nan)
+        assert C.matvec_threads(x, y2, t) == min(t, 256)
+        assert np.array_equal(y1, y2), t
+    A = oracle.poisson_csr(2, 2)
+    xs, ya, yb = np.arange(4.0), np.empty(4), np.empty(4)
+    A.matvec(xs, ya)
+    assert A.matvec_threads(xs, yb, 64) == 4 and np.array_equal(ya, yb)
+
+
 def test_tendigit_known_answer(oracle, golden_dir):
     with open(os.path.join(golden_dir, "tendigit.json")) as f:
         g = json.load(f)
