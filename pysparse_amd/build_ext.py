@@ -36,7 +36,9 @@ def build(force=False):
         deps = [srcp, lib, os.path.join(ROOT, "include", "pysparse_hip.h")] + [os.path.join(PKG, h) for h in HEADERS]
         if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
             continue
-        cmd = [cc, "-O2", "-fPIC", "-shared", "-pthread", "-std=gnu99", "-Wall", "-Wno-unused-function"] + incs + \
+        # PSP_EXT_CFLAGS: extra flags, e.g. "-fsanitize=address,undefined -g -O1" for tools/sanitize_host.sh
+        cmd = [cc, "-O2", "-fPIC", "-shared", "-pthread", "-std=gnu99", "-Wall", "-Wno-unused-function"] + \
+              os.environ.get("PSP_EXT_CFLAGS", "").split() + incs + \
               [srcp, "-o", out, "-L" + PKG, "-lpysparse_hip", "-Wl,-rpath,$ORIGIN/.."]
         subprocess.check_call(cmd)
 

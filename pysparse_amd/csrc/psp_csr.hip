@@ -1350,7 +1350,8 @@ struct SssOffs {
 
 __global__ void sss_lowmask_kernel(int n, int nol, SssOffs offs, const int *__restrict__ ind,
                                    const int *__restrict__ col, const double *__restrict__ val,
-                                   double *__restrict__ valL, unsigned char *__restrict__ low) {
+                                   double *__restrict__ valL, unsigned char *__restrict__ low, long soa_npad) {
+  // soa_npad > 0: one array of soa_npad values per offset (every stream of the product contiguous) instead of blocks
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
     const long blk = r / kDiaRows;
     const int i = (int)(r % kDiaRows);
@@ -1360,7 +1361,8 @@ __global__ void sss_lowmask_kernel(int n, int nol, SssOffs offs, const int *__re
       int b = 0;
       while (b < nol - 1 && offs.o[b] != o) ++b;
       m |= 1u << b;
-      valL[((size_t)blk * nol + b) * kDiaRows + i] = val[k];
+      if (soa_npad > 0) valL[(size_t)b * soa_npad + r] = val[k];
+      else valL[((size_t)blk * nol + b) * kDiaRows + i] = val[k];
     }
     low[r] = (unsigned char)m;
   }
@@ -1407,9 +1409,14 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     const long npad = ((long)n + kDiaRows - 1) / kDiaRows * kDiaRows;
     const long xmax = (long)n - 2;  // n >= 2 (ensure_sss_w4)
     bool edge = !two;
+    // FLAGS & 8: valL is one array of npad values per offset; otherwise blocks of kDiaRows rows, offset-major inside
+    constexpr bool SOA = (FLAGS & 8) != 0;
+    auto vaddr = [&](long row, int j) -> const double * {
+      return SOA ? valL + (size_t)j * npad + row
+                 : valL + ((size_t)(row / kDiaRows) * NOL + j) * kDiaRows + (size_t)(row % kDiaRows);
+    };
     // lower entries of rows r, r+1 and the x they multiply
     d2v vl[NOL], xl[NOL];
-    const double *vp = valL + (size_t)blk * NOL * kDiaRows + 2 * lane;
     // FLAGS & 4: the offset -1 (always the last one when present) takes no loads of its own -- x[r-1], x[r+2] and
     // the mirrored values L[r+1, r], L[r+2, r+1] are the neighbouring lanes' x0 / vl registers (lanes 0 and 63
     // fetch their one halo element) -- and the mirrored pair of an EVEN offset is one aligned 16-byte load:
@@ -1418,7 +1425,7 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
     const bool off1 = SHFL && offs.o[NOL - 1] == -1;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {
-      vl[j] = ldg<(FLAGS & 1) != 0>(reinterpret_cast<const d2v *>(vp + j * kDiaRows));  // plain: the line is usually in L2 already (shifted read), NT costs 6 %
+      vl[j] = ldg<(FLAGS & 1) != 0>(reinterpret_cast<const d2v *>(vaddr(r, j)));  // plain: the line is usually in L2 already (shifted read), NT costs 6 %
       if (off1 && j == NOL - 1) continue;
       const long c = r + offs.o[j];  // < r
       const long cc = c < 0 ? 0 : c;
@@ -1433,7 +1440,7 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
       if (lane == 63) {
         if (r + 2 < n) halo_x2 = x[r + 2];
         if (r + 2 < npad)
-          halo_v2 = valL[((size_t)((r + 2) / kDiaRows) * NOL + (NOL - 1)) * kDiaRows + (size_t)((r + 2) % kDiaRows)];
+          halo_v2 = *vaddr(r + 2, NOL - 1);
       }
     }
     // diagonal
@@ -1452,12 +1459,11 @@ __global__ __launch_bounds__(256) void sss_spmv_w4(
       const long ru = r - offs.o[j];
       if (SHFL && (offs.o[j] & 1) == 0) {  // ru even: rows ru, ru + 1 sit side by side in one block
         const long v0 = ru < npad ? ru : npad - 2;
-        vu[j] = ldg<(FLAGS & 2) != 0>(reinterpret_cast<const d2v *>(
-            valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows)));
+        vu[j] = ldg<(FLAGS & 2) != 0>(reinterpret_cast<const d2v *>(vaddr(v0, j)));
       } else {
         const long v0 = ru < npad ? ru : npad - 1, v1 = ru + 1 < npad ? ru + 1 : npad - 1;
-        vu[j].x = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v0 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v0 % kDiaRows));
-        vu[j].y = ldg<(FLAGS & 2) != 0>(valL + ((size_t)(v1 / kDiaRows) * NOL + j) * kDiaRows + (size_t)(v1 % kDiaRows));
+        vu[j].x = ldg<(FLAGS & 2) != 0>(vaddr(v0, j));
+        vu[j].y = ldg<(FLAGS & 2) != 0>(vaddr(v1, j));
       }
       const long xr = ru > xmax ? xmax : ru;
       const d2u t = *reinterpret_cast<const d2u *>(x + xr);
@@ -2788,8 +2794,11 @@ static int ensure_sss_w4(psp_sss *S) {
   PSP_HIP(hipMemsetAsync(S->w4_val, 0, sizeof(double) * nval, stream()));
   PSP_HIP(hipMemsetAsync(S->w4_mask, 0, sizeof(unsigned short) * (nblk * kDiaRows + 2), stream()));
   const int grid = std::min((S->n + 255) / 256, 65536);
+  bool soa = false;
+  if (const char *e = psp::tuning_env("PSP_SSS_SOA")) soa = atoi(e) != 0;  // A/B, read per handle: one value array per offset
+  S->w4_soa = soa;
   hipLaunchKernelGGL(sss_lowmask_kernel, dim3(grid), dim3(256), 0, stream(), S->n, nol, so, S->ind, S->col,
-                     S->val, S->w4_val, low);
+                     S->val, S->w4_val, low, soa ? (long)(nblk * kDiaRows) : 0L);
   hipLaunchKernelGGL(sss_mask_kernel, dim3(grid), dim3(256), 0, stream(), S->n, nol, so, low, S->w4_mask);
   PSP_LAUNCH_CHECK();
   PSP_HIP(hipStreamSynchronize(stream()));
@@ -2816,7 +2825,8 @@ static int launch_sss_w4(const psp_sss *S, int stripe, const double *x, double *
   }();
 #define PSP_SW4(NOL)                                                                                 \
   case NOL:                                                                                          \
-    if (flags == 0 && shfl) PSP_SW4_F(NOL, 4);                                                       \
+    if (S->w4_soa) PSP_SW4_F(NOL, 12);                                                               \
+    else if (flags == 0 && shfl) PSP_SW4_F(NOL, 4);                                                  \
     else if (flags == 0) PSP_SW4_F(NOL, 0);                                                          \
     else if (flags == 1) PSP_SW4_F(NOL, 1);                                                          \
     else if (flags == 2) PSP_SW4_F(NOL, 2);                                                          \

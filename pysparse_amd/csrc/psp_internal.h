@@ -270,6 +270,7 @@ struct psp_sss {
   int w4_state = -1;
   int w4_nol = 0;
   int w4_offs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool w4_soa = false;  // w4_val: one array per offset (PSP_SSS_SOA) instead of 128-row blocks
   double *w4_val = nullptr;
   unsigned short *w4_mask = nullptr;
   bool host = false;  // PSP_DEVICE=cpu: ind / col / val / diag are host arrays (psp_cpu.hip)
