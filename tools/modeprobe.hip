@@ -49,7 +49,39 @@ __global__ void mp_census_k(unsigned *hw, unsigned *xcc) {
   }
 }
 
+// one lane walks `steps` dependent loads through [p, p + n) doubles, `stride` doubles apart (wrapping): every address
+// depends on the value loaded before it, so the time per step is one full load latency -- L2 / HBM plus, when consecutive
+// addresses lie in different translation fragments, whatever the translation costs.  out[0] = device clock ticks (100 MHz).
+__global__ void mp_chase_k(const double *__restrict__ p, long n, long stride, int warm, int steps, long long *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long idx = 0;
+  double acc = 0.0;
+  for (int i = 0; i < warm; ++i) {  // untimed: the code path, and (warm = one wrap) the caches / translations of a first pass
+    const double v = __builtin_nontemporal_load(p + idx);
+    idx = (idx + stride + (v == 12345.678 ? 1 : 0)) % n;
+    acc += v;
+  }
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < steps; ++i) {
+    const double v = __builtin_nontemporal_load(p + idx);
+    idx = (idx + stride + (v == 12345.678 ? 1 : 0)) % n;
+    acc += v;
+  }
+  const long long t1 = wall_clock64();
+  out[0] = t1 - t0;
+  out[1] = (long long)acc + idx;
+}
+
 extern "C" {
+// average nanoseconds per dependent load (wall_clock64 ticks at 100 MHz)
+double mp_chase_ns(void *buf, long n_doubles, long stride_doubles, int warm, int steps) {
+  long long *out = nullptr, host[2] = {0, 0};
+  if (hipMalloc(&out, 16) != hipSuccess) return -1.0;
+  mp_chase_k<<<1, 64>>>((const double *)buf, n_doubles, stride_doubles, warm, steps, out);
+  hipMemcpy(host, out, 16, hipMemcpyDeviceToHost);
+  hipFree(out);
+  return (double)host[0] * 10.0 / steps;
+}
 void *mp_alloc(size_t bytes) {
   void *p = nullptr;
   if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
