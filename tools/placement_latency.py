@@ -43,6 +43,13 @@ keep, cands = [], []
 for j in range(8):
     keep.append(dev.DeviceBuffer((37 + 211 * j) * (1 << 17) + 512 * j))
     cands.append(dev.DeviceBuffer(n))
+# a trivial kernel with the same number of streams (tools/modeprobe.hip mp_r7w1_k: seven read streams 1 GiB apart in one
+# allocation of its own + one write stream = the candidate): does IT see the candidate's level?
+M.mp_alloc.restype = C.c_void_p
+M.mp_alloc.argtypes = [C.c_size_t]
+M.mp_stream_ms.restype = C.c_double
+M.mp_stream_ms.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+seven = M.mp_alloc(7 * n * 8)
 strides = (("256B", 32), ("4KiB+64", 512 + 8), ("64KiB+64", 8192 + 8), ("2MiB+64", 262144 + 8))
 for j, y in enumerate(cands):
     row = {"y": j, "addr": hex(y.ptr), "spmv_ms": spmv_ms(y)}
@@ -51,5 +58,6 @@ for j, y in enumerate(cands):
         wrap = min(n // st, 20000)
         row[name + "_cold_ns"] = round(M.mp_chase_ns(y.ptr, n, st, 64, wrap), 1)
         row[name + "_2nd_ns"] = round(M.mp_chase_ns(y.ptr, n, st, wrap, wrap), 1)
+    row["r7w1_ms"] = round(M.mp_stream_ms(4, seven, y.ptr, n // 2, 8), 4) if seven else None
     row["spmv_ms_again"] = spmv_ms(y)
     print(json.dumps(row), flush=True)
