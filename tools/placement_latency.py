@@ -49,7 +49,7 @@ M.mp_alloc.restype = C.c_void_p
 M.mp_alloc.argtypes = [C.c_size_t]
 M.mp_stream_ms.restype = C.c_double
 M.mp_stream_ms.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
-seven = M.mp_alloc(7 * n * 8)
+seven = M.mp_alloc(7 * n * 8) if os.environ.get("PLACE_R7W1") else None
 strides = (("256B", 32), ("4KiB+64", 512 + 8), ("64KiB+64", 8192 + 8), ("2MiB+64", 262144 + 8))
 for j, y in enumerate(cands):
     row = {"y": j, "addr": hex(y.ptr), "spmv_ms": spmv_ms(y)}
@@ -58,6 +58,12 @@ for j, y in enumerate(cands):
         wrap = min(n // st, 20000)
         row[name + "_cold_ns"] = round(M.mp_chase_ns(y.ptr, n, st, 64, wrap), 1)
         row[name + "_2nd_ns"] = round(M.mp_chase_ns(y.ptr, n, st, wrap, wrap), 1)
+    # the same launch with write-back instead of non-temporal stores of y / plain instead of non-temporal value loads
+    DV = 194 + (64 << 8) + (1 << 20) + (1 << 22)
+    for nm, f in (("plain_y_stores_ms", 2), ("plain_val_loads_ms", 1)):
+        A.set_variant(DV + (f << 23))
+        row[nm] = spmv_ms(y)
+    A.set_variant(-1)
     row["r7w1_ms"] = round(M.mp_stream_ms(4, seven, y.ptr, n // 2, 8), 4) if seven else None
     row["spmv_ms_again"] = spmv_ms(y)
     print(json.dumps(row), flush=True)
