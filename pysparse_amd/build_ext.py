@@ -34,6 +34,8 @@ def build(force=False):
         out = os.path.join(PKG, sub, name + suffix)
         srcp = os.path.join(PKG, src)
         deps = [srcp, lib, os.path.join(ROOT, "include", "pysparse_hip.h")] + [os.path.join(PKG, h) for h in HEADERS]
+        if name == "spmatrix":
+            deps.append(os.path.join(PKG, "sparse/src/ll_mat_edit.c"))  # textually included by spmatrixmodule.c
         if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
             continue
         # PSP_EXT_CFLAGS: extra flags, e.g. "-fsanitize=address,undefined -g -O1" for tools/sanitize_host.sh

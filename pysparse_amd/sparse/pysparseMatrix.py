@@ -3,10 +3,10 @@ pysparse/sparse/pysparseMatrix.py:61-545 (and its base class sparseMatrix.py:49-
 
 `A * x` with a NumPy vector is the matrix-vector product and runs on the GPU (ll_mat.matvec, as in
 pysparseMatrix.py:224-272); everything that edits or combines matrices (copy, +, -, scalar *, matrix *
-matrix, row / column scaling, take, find, dense export, MatrixMarket export) is host-side sugar built
-on the ll_mat primitives this build has (element get / set, put, update_add_at, the CSR / SSS array
-views) -- the reference's ll_mat editing methods (shift, scale, matrixmultiply, ...) are outside the
-SpMV + Krylov path and are not re-implemented in C; matrix * matrix goes through scipy.sparse.
+matrix, row / column scaling, take, find, dense export, MatrixMarket export) is host-side sugar over the
+ll_mat methods (round 4: copy, scale, row_scale, col_scale, matrixmultiply, export_mtx are the C methods
+of pysparse_amd/sparse/src/ll_mat_edit.c; a symmetric right factor of matrix * matrix, which the reference
+refuses, goes through scipy.sparse).
 """
 import numpy as np
 
@@ -92,11 +92,7 @@ class PysparseMatrix:
     nnz = property(getNnz)
 
     def copy(self):
-        L = _new_like(self.matrix)
-        r, c, v = _triplets(self.matrix)
-        if v.size:
-            L.put(v, r, c)
-        return PysparseMatrix(matrix=L)
+        return PysparseMatrix(matrix=self.matrix.copy())  # pysparseMatrix.py:98-100
 
     def __getitem__(self, index):
         m = self.matrix[index]
@@ -163,9 +159,11 @@ class PysparseMatrix:
     def __mul__(self, other):
         """matrix * scalar, matrix * vector (on the GPU) or matrix * matrix"""
         if isinstance(other, PysparseMatrix):
-            import scipy.sparse as sp
             if self.shape[1] != other.shape[0]:
                 raise TypeError("matrix dimensions do not match for multiplication")
+            if not other.isSymmetric():  # what spmatrix.matrixmultiply offers (ll_mat.c:3461-3660), in its summation order
+                return PysparseMatrix(matrix=spmatrix.matrixmultiply(self.matrix, other.matrix))
+            import scipy.sparse as sp  # a symmetric right factor: NotImplementedError in the reference
             a = sp.csr_matrix((_general_triplets(self.matrix)[2], _general_triplets(self.matrix)[:2]), shape=self.shape)
             b = sp.csr_matrix((_general_triplets(other.matrix)[2], _general_triplets(other.matrix)[:2]), shape=other.shape)
             p = (a @ b).tocoo()
@@ -180,11 +178,8 @@ class PysparseMatrix:
             y = np.empty(self.shape[0])
             self.matrix.matvec(x, y)
             return y
-        sigma = float(other)
-        L = _new_like(self.matrix)
-        r, c, v = _triplets(self.matrix)
-        if v.size:
-            L.put(sigma * v, r, c)
+        L = self.matrix.copy()
+        L.scale(float(other))
         return PysparseMatrix(matrix=L)
 
     def __rmul__(self, other):
@@ -206,22 +201,17 @@ class PysparseMatrix:
         return self * x
 
     # ---- scaling
-    def _rebuild_scaled(self, row_fac, col_fac):
-        if self.isSymmetric():
-            raise TypeError("row / column scaling of a symmetric ll_mat is not supported")
-        r, c, v = _triplets(self.matrix)
-        L = _new_like(self.matrix)
-        if v.size:
-            L.put(v * row_fac[r] * col_fac[c], r, c)
-        self.matrix = L
-
     def col_scale(self, v):
         """A := A diag(v)"""
-        self._rebuild_scaled(np.ones(self.shape[0]), np.asarray(v, dtype=np.float64))
+        if self.isSymmetric():
+            raise TypeError("row / column scaling of a symmetric ll_mat is not supported")
+        self.matrix.col_scale(np.ascontiguousarray(v, dtype=np.float64))
 
     def row_scale(self, v):
         """A := diag(v) A"""
-        self._rebuild_scaled(np.asarray(v, dtype=np.float64), np.ones(self.shape[1]))
+        if self.isSymmetric():
+            raise TypeError("row / column scaling of a symmetric ll_mat is not supported")
+        self.matrix.row_scale(np.ascontiguousarray(v, dtype=np.float64))
 
     # ---- bulk access
     def find(self):
@@ -280,14 +270,8 @@ class PysparseMatrix:
         return a
 
     def exportMmf(self, filename):
-        """MatrixMarket coordinate file (the counterpart of ll_mat.export_mtx, ll_mat.c:1757-1810)"""
-        r, c, v = _triplets(self.matrix)
-        order = np.lexsort((c, r))
-        with open(filename, "w") as f:
-            f.write("%%%%MatrixMarket matrix coordinate real %s\n" % ("symmetric" if self.isSymmetric() else "general"))
-            f.write("%d %d %d\n" % (self.shape[0], self.shape[1], v.size))
-            for k in order:
-                f.write("%d %d %.16e\n" % (r[k] + 1, c[k] + 1, v[k]))
+        """MatrixMarket coordinate file: ll_mat.export_mtx (pysparseMatrix.py:470-478; 17 digits: the same doubles come back)"""
+        self.matrix.export_mtx(filename, 17)
 
 
 class PysparseIdentityMatrix(PysparseMatrix):

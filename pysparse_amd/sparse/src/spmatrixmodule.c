@@ -297,7 +297,7 @@ static int ll_store(LLMatObject *a, int i, int j, double x, int add) {
     k = a->link[k];
   }
   if (add) {
-    if (x == 0.0) return 0;
+    if (x == 0.0 && a->storeZeros == 0) return 0; /* ll_mat.c:374 */
     if (col == j && k != -1) x += a->val[k];
   }
   if (x != 0.0 || a->storeZeros == 1) {
@@ -794,19 +794,18 @@ done:
   return ret;
 }
 
+/* an (int, int) key with negative indices counting from the end (sss_mat[i, j]) */
 static int parse_int_index(PyObject *key, int dim0, int dim1, int *i, int *j) {
   long a, b;
   if (!PyTuple_Check(key) || PyTuple_GET_SIZE(key) != 2 ||
       !PyIndex_Check(PyTuple_GET_ITEM(key, 0)) || !PyIndex_Check(PyTuple_GET_ITEM(key, 1))) {
-    PyErr_SetString(PyExc_IndexError,
-                    "only integer index pairs [i,j] are supported (sub-matrix slicing is "
-                    "outside the SpMV/Krylov scope of this build)");
+    PyErr_SetString(PyExc_IndexError, "only integer index pairs [i,j] are supported");
     return -1;
   }
   a = PyLong_AsLong(PyTuple_GET_ITEM(key, 0));
   b = PyLong_AsLong(PyTuple_GET_ITEM(key, 1));
   if (PyErr_Occurred()) return -1;
-  if (a < 0) a += dim0; /* negative indices count from the end (test/test_spmatrix.py:17-65) */
+  if (a < 0) a += dim0;
   if (b < 0) b += dim1;
   if (a < 0 || a >= dim0 || b < 0 || b >= dim1) {
     PyErr_SetString(PyExc_IndexError, "indices out of range");
@@ -817,27 +816,8 @@ static int parse_int_index(PyObject *key, int dim0, int dim1, int *i, int *j) {
   return 0;
 }
 
-static PyObject *LLMat_subscript(LLMatObject *self, PyObject *key) {
-  int i, j;
-  double v;
-  if (parse_int_index(key, self->dim[0], self->dim[1], &i, &j)) return NULL;
-  v = SpMatrix_LLMatGetItem(self, i, j);
-  if (PyErr_Occurred()) return NULL;
-  return PyFloat_FromDouble(v);
-}
-
-static int LLMat_ass_subscript(LLMatObject *self, PyObject *key, PyObject *value) {
-  int i, j;
-  double x;
-  if (value == NULL) {
-    PyErr_SetString(PyExc_IndexError, "cannot delete matrix entries");
-    return -1;
-  }
-  if (parse_int_index(key, self->dim[0], self->dim[1], &i, &j)) return -1;
-  x = PyFloat_AsDouble(value);
-  if (PyErr_Occurred()) return -1;
-  return SpMatrix_LLMatSetItem(self, i, j, x);
-}
+/* sub-matrix read / write, copy, shift, scale, norms, deletion, compress, exports, assembly updates, matrix products */
+#include "ll_mat_edit.c"
 
 static void LLMat_dealloc(LLMatObject *a) {
   ll_invalidate(a);
@@ -882,6 +862,27 @@ static PyMethodDef LLMat_methods[] = {
     {"to_sss_arrays", (PyCFunction)LLMat_to_sss_arrays, METH_VARARGS, "(indptr, indices, data, diag) of to_sss(), on the host"},
     {"put", (PyCFunction)LLMat_put, METH_VARARGS, "a.put(b[, id1[, id2]]): a[id1[i], id2[i]] = b[i]"},
     {"update_add_at", (PyCFunction)LLMat_update_add_at, METH_VARARGS, "a.update_add_at(b, id1, id2): a[id1[i], id2[i]] += b[i]"},
+    {"generalize", (PyCFunction)LLMat_generalize, METH_VARARGS, "convert from symmetric to non-symmetric form (in place)"},
+    {"compress", (PyCFunction)LLMat_compress, METH_VARARGS, "A.compress(): reclaim unused space; returns the number of elements freed"},
+    {"export_mtx", (PyCFunction)LLMat_export_mtx, METH_VARARGS, "A.export_mtx(fileName, precision=16): write A in MatrixMarket format"},
+    {"copy", (PyCFunction)LLMat_copy, METH_VARARGS, "A.copy(): a (deep) copy of A"},
+    {"norm", (PyCFunction)LLMat_norm, METH_VARARGS, "A.norm(p): p = '1', 'inf' (general storage) or 'fro'"},
+    {"shift", (PyCFunction)LLMat_shift, METH_VARARGS, "A.shift(sigma, B): A = A + sigma * B"},
+    {"scale", (PyCFunction)LLMat_scale, METH_VARARGS, "A.scale(sigma): every element times sigma"},
+    {"col_scale", (PyCFunction)LLMat_col_scale, METH_VARARGS, "A.col_scale(v): column i times v[i]"},
+    {"row_scale", (PyCFunction)LLMat_row_scale, METH_VARARGS, "A.row_scale(v): row i times v[i]"},
+    {"keys", (PyCFunction)LLMat_keys, METH_VARARGS, "A.keys(): list of the (i, j) of the stored entries"},
+    {"values", (PyCFunction)LLMat_values, METH_VARARGS, "A.values(): list of the stored values"},
+    {"items", (PyCFunction)LLMat_items, METH_VARARGS, "A.items(): list of ((i, j), value)"},
+    {"take", (PyCFunction)LLMat_take, METH_VARARGS, "A.take(b[, id1[, id2]]): b[i] = A[id1[i], id2[i]]"},
+    {"find", (PyCFunction)LLMat_find, METH_VARARGS, "A.find(): (val, irow, jcol) of the stored entries"},
+    {"update_add_mask", (PyCFunction)LLMat_update_add_mask, METH_VARARGS,
+     "A.update_add_mask(b, ind0, ind1, mask0, mask1): a[ind0[i], ind1[j]] += b[i, j] where both masks are set"},
+    {"update_add_mask_sym", (PyCFunction)LLMat_update_add_mask_sym, METH_VARARGS,
+     "A.update_add_mask_sym(b, ind, mask): the symmetric assembly update (pairs j <= i)"},
+    {"delete_rows", (PyCFunction)LLMat_delete_rows, METH_VARARGS, "A.delete_rows(mask): keep the rows whose mask is non-zero"},
+    {"delete_cols", (PyCFunction)LLMat_delete_cols, METH_VARARGS, "A.delete_cols(mask): keep the columns whose mask is non-zero"},
+    {"delete_rowcols", (PyCFunction)LLMat_delete_rowcols, METH_VARARGS, "A.delete_rowcols(mask): both (square matrices)"},
     {NULL, NULL, 0, NULL}};
 
 static PyGetSetDef LLMat_getset[] = {{"shape", (getter)LLMat_get_shape, NULL, "(rows, cols)", NULL},
@@ -1770,6 +1771,9 @@ static PyMethodDef spmatrix_methods[] = {
     {"ll_mat", LLMat_zeros, METH_VARARGS, "ll_mat(n, m, sizeHint=1000, storeZeros=0): empty n x m linked-list matrix"},
     {"ll_mat_sym", LLMat_sym_zeros, METH_VARARGS, "ll_mat_sym(n, sizeHint=1000, storeZeros=0): empty symmetric matrix"},
     {"ll_mat_from_mtx", LLMat_from_mtx, METH_VARARGS, "ll_mat_from_mtx(fileName): read a MatrixMarket coordinate file"},
+    {"matrixmultiply", LLMat_matrixmultiply, METH_VARARGS, "matrixmultiply(A, B): new ll_mat A * B"},
+    {"dot", LLMat_dot, METH_VARARGS, "dot(A, B): new ll_mat transpose(A) * B"},
+    {"symdot", LLMat_symdot, METH_VARARGS, "symdot(A[, d]): new symmetric ll_mat transpose(A) * A or transpose(A) * diag(d) * A"},
     {"coo_sort_unique", Coo_sort_unique, METH_VARARGS,
      "coo_sort_unique(rows, cols, vals, nrows) -> (rows, cols, vals) sorted by (row, col); a repeated (row, col) keeps its last value"},
     {"mtx_read_coordinate", Mtx_read_coordinate, METH_VARARGS,

@@ -49,18 +49,21 @@ def poisson2d_sym(n):
 
 
 def poisson2d_sym_blk(n):
-    """Same matrix as poisson2d_sym.  The reference assembles it from n x n blocks by sub-matrix
-    assignment (poisson.py:50-66), an ll_mat editing feature outside this build's scope; the blocks
-    are written entry by entry here (tridiagonal block on the diagonal, -I below it)."""
+    """Same matrix as poisson2d_sym, assembled from n x n blocks by sub-matrix assignment (poisson.py:50-66)."""
     n2 = n * n
     L = spmatrix.ll_mat_sym(n2, 3 * n2 - 2 * n)
-    for base in range(0, n2, n):
-        for i in range(n):
-            L[base + i, base + i] = 4
-            if i > 0:
-                L[base + i, base + i - 1] = -1
-            if base > 0:
-                L[base + i, base + i - n] = -1
+    minus_identity = spmatrix.ll_mat_sym(n, n)
+    for i in range(n):
+        minus_identity[i, i] = -1
+    P = spmatrix.ll_mat_sym(n, 2 * n - 1)
+    for i in range(n):
+        P[i, i] = 4
+        if i > 0:
+            P[i, i - 1] = -1
+    for i in range(0, n2, n):
+        L[i:i + n, i:i + n] = P
+        if i > 0:
+            L[i:i + n, i - n:i] = minus_identity
     return L
 
 

@@ -13,7 +13,7 @@ PSP_EXT_CFLAGS="$SAN" python pysparse_amd/build_ext.py --force || exit 1
 gcc -O1 -g -fPIC -ffp-contract=off -fvisibility=hidden -std=gnu99 $SAN -shared -o oracle/liboracle.so oracle/pysparse_oracle.c -lm -lpthread || exit 1
 LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=0:halt_on_error=0 \
   UBSAN_OPTIONS=print_stacktrace=1 \
-  timeout 3000 python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@" > gpurun_out/sanitize_host.txt 2>&1
+  timeout 3000 python -m pytest ${@:-tests} -q -m "not gpu" -p no:cacheprovider > gpurun_out/sanitize_host.txt 2>&1
 rc=$?
 python pysparse_amd/build_ext.py --force
 rm -f oracle/liboracle.so && make -s -C oracle liboracle.so
