@@ -1048,3 +1048,80 @@ static PyObject *LLMat_symdot(PyObject *module, PyObject *args) {
   Py_XDECREF(d);
   return (PyObject *)C;
 }
+
+/* ------------------------------------------------------------------ str(A): the text the reference's tp_print writes
+ * (ll_mat.c:3085-3151; PPRINT thresholds :16-17): a dense picture up to 500 x 20, the entry list beyond */
+
+typedef struct {
+  char *p;
+  size_t len, cap;
+} LLText;
+
+static int ll_text_add(LLText *t, const char *fmt, ...) {
+  va_list ap;
+  int n;
+  if (t->cap - t->len < 64) {
+    size_t cap = t->cap ? 2 * t->cap : 1024;
+    char *q = (char *)realloc(t->p, cap);
+    if (q == NULL) return -1;
+    t->p = q;
+    t->cap = cap;
+  }
+  va_start(ap, fmt);
+  n = vsnprintf(t->p + t->len, t->cap - t->len, fmt, ap);
+  va_end(ap);
+  if (n < 0 || (size_t)n >= t->cap - t->len) return -1; /* (every piece is far below 64 characters) */
+  t->len += (size_t)n;
+  return 0;
+}
+
+static PyObject *LLMat_str(LLMatObject *a) {
+  const char *sym = a->issym ? "symmetric" : "general";
+  LLText t = {NULL, 0, 0};
+  PyObject *ret;
+  int i, j, k, bad = 0;
+  if (a->dim[1] <= 20 && a->dim[0] <= 500) {
+    double *row = (double *)malloc(sizeof(double) * (size_t)(a->dim[1] > 0 ? a->dim[1] : 1));
+    if (row == NULL) return PyErr_NoMemory();
+    bad |= ll_text_add(&t, "ll_mat(%s, [%d,%d]):\n", sym, a->dim[0], a->dim[1]);
+    for (i = 0; i < a->dim[0] && !bad; i++) {
+      for (j = 0; j < a->dim[1]; j++) row[j] = 0.0;
+      for (k = a->root[i]; k != -1; k = a->link[k]) row[a->col[k]] = a->val[k];
+      for (j = 0; j < a->dim[1] && !bad; j++) {
+        const double v = row[j];
+        if (v != 0.0) {
+          const int e = (int)log10(fabs(v));
+          if (abs(e) <= 4)
+            bad |= ll_text_add(&t, "%9.*f ", e < 0 ? 6 : 6 - e, v);
+          else
+            bad |= ll_text_add(&t, "%9.1e ", v);
+        } else if (!a->issym || i > j) {
+          bad |= ll_text_add(&t, " -------- ");
+        }
+      }
+      bad |= ll_text_add(&t, "\n");
+    }
+    free(row);
+  } else if (a->nnz == 0) {
+    bad |= ll_text_add(&t, "ll_mat(%s, [%d,%d])", sym, a->dim[0], a->dim[1]);
+  } else {
+    int first = 1;
+    bad |= ll_text_add(&t, "ll_mat(%s, [%d,%d], [", sym, a->dim[0], a->dim[1]);
+    for (i = 0; i < a->dim[0] && !bad; i++)
+      for (k = a->root[i]; k != -1 && !bad; k = a->link[k]) {
+        bad |= ll_text_add(&t, "%s(%d,%d): %g", first ? "" : ", ", i, a->col[k], a->val[k]);
+        first = 0;
+      }
+    bad |= ll_text_add(&t, "])");
+  }
+  if (bad) {
+    free(t.p);
+    return PyErr_NoMemory();
+  }
+  ret = PyUnicode_FromStringAndSize(t.p, (Py_ssize_t)t.len);
+  free(t.p);
+  return ret;
+}
+
+/* ll_mat.c:3193-3197: len(A) = rows * columns */
+static Py_ssize_t LLMat_length(LLMatObject *a) { return (Py_ssize_t)a->dim[0] * (Py_ssize_t)a->dim[1]; }

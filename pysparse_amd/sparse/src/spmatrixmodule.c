@@ -16,6 +16,7 @@
  *   sss_mat.to_arrays().
  */
 #define PY_SSIZE_T_CLEAN
+#include <stdarg.h>
 #include <Python.h>
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
 #include <numpy/arrayobject.h>
@@ -833,6 +834,7 @@ static PyObject *LLMat_get_shape(LLMatObject *a, void *c) {
 }
 static PyObject *LLMat_get_nnz(LLMatObject *a, void *c) { return PyLong_FromLong(a->nnz); }
 static PyObject *LLMat_get_issym(LLMatObject *a, void *c) { return PyLong_FromLong(a->issym); }
+static PyObject *LLMat_get_storezeros(LLMatObject *a, void *c) { return PyLong_FromLong(a->storeZeros); }
 
 static PyObject *LLMat_get_psp_op(LLMatObject *a, void *c) {
   if (a->dim[0] != a->dim[1]) {
@@ -888,10 +890,11 @@ static PyMethodDef LLMat_methods[] = {
 static PyGetSetDef LLMat_getset[] = {{"shape", (getter)LLMat_get_shape, NULL, "(rows, cols)", NULL},
                                      {"nnz", (getter)LLMat_get_nnz, NULL, "stored entries", NULL},
                                      {"issym", (getter)LLMat_get_issym, NULL, "symmetric storage", NULL},
+                                     {"storeZeros", (getter)LLMat_get_storezeros, NULL, "explicit zeros are kept", NULL},
                                      {"_psp_op", (getter)LLMat_get_psp_op, NULL, "device operator", NULL},
                                      {NULL, NULL, NULL, NULL, NULL}};
 
-static PyMappingMethods LLMat_as_mapping = {NULL, (binaryfunc)LLMat_subscript,
+static PyMappingMethods LLMat_as_mapping = {(lenfunc)LLMat_length, (binaryfunc)LLMat_subscript,
                                             (objobjargproc)LLMat_ass_subscript};
 
 /* ------------------------------------------------------------------ csr_mat */
@@ -1819,6 +1822,7 @@ PyMODINIT_FUNC PyInit_spmatrix(void) {
   init_type(&LLMatType, "pysparse_amd.sparse.spmatrix.ll_mat", sizeof(LLMatObject),
             (destructor)LLMat_dealloc, (reprfunc)LLMat_repr, LLMat_methods, LLMat_getset,
             &LLMat_as_mapping);
+  LLMatType.tp_str = (reprfunc)LLMat_str; /* print(A): the reference's tp_print text */
   init_type(&CSRMatType, "pysparse_amd.sparse.spmatrix.csr_mat", sizeof(CSRMatObject),
             (destructor)CSRMat_dealloc, (reprfunc)CSRMat_repr, CSRMat_methods, CSRMat_getset, NULL);
   init_type(&SSSMatType, "pysparse_amd.sparse.spmatrix.sss_mat", sizeof(SSSMatObject),

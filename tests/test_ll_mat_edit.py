@@ -513,6 +513,26 @@ def test_store_zeros_semantics():  # ll_mat.c:250-356, :362-460: explicit zeros 
     assert Z.nnz == 0
 
 
+def test_str_len_and_attributes():  # ll_mat.c:3085-3151 (the text tp_print writes), :3154-3163, :3193-3197
+    A = poisson.poisson1d(4)
+    A[0, 3] = 12345.678
+    A[3, 0] = 1e-7
+    assert str(A) == ("ll_mat(general, [4,4]):\n"
+                      " 2.000000 -1.000000  --------  12345.68 \n"
+                      "-1.000000  2.000000 -1.000000  -------- \n"
+                      " -------- -1.000000  2.000000 -1.000000 \n"
+                      "  1.0e-07  -------- -1.000000  2.000000 \n")
+    assert str(poisson.poisson1d_sym(3)) == ("ll_mat(symmetric, [3,3]):\n 2.000000 \n-1.000000  2.000000 \n"
+                                             " -------- -1.000000  2.000000 \n")
+    B = spmatrix.ll_mat(600, 30)
+    assert str(B) == "ll_mat(general, [600,30])"
+    B[1, 2] = 3.5
+    B[599, 0] = -1
+    assert str(B) == "ll_mat(general, [600,30], [(1,2): 3.5, (599,0): -1])"
+    assert len(A) == 16 and len(B) == 18000 and A.storeZeros == 0 and spmatrix.ll_mat(2, 2, 4, 1).storeZeros == 1
+    assert repr(A).startswith("<ll_mat object")
+
+
 @pytest.mark.gpu
 def test_ref_matrixmultiply_through_matvec():  # test/test_spmatrix.py:204-221
     eps = 2.2204460492503131e-16
