@@ -986,6 +986,53 @@ static PyObject *CSRMat_repr(CSRMatObject *a) {
                               a->dim[1], a->nnz);
 }
 
+/* print(A): the text of the reference's tp_print (csr_mat.c:186-207) -- "csr_mat([m,n], [(i,j): v, ...])" -- for matrices
+ * a person would print; beyond 10 000 stored entries the one-line repr (the arrays live on the device) */
+static PyObject *csr_like_str(const char *name, int rows, int cols, const int *ind, const int *col, const double *val,
+                              const double *diag, long nnz) {
+  LLText t = {NULL, 0, 0};
+  PyObject *ret;
+  int i, k, bad = 0, first = 1;
+  if (nnz == 0) {
+    bad |= ll_text_add(&t, "%s([%d,%d])", name, rows, cols);
+  } else {
+    bad |= ll_text_add(&t, "%s([%d,%d], [", name, rows, cols);
+    for (i = 0; i < rows && !bad; i++) {
+      for (k = ind[i]; k < ind[i + 1] && !bad; k++) {
+        bad |= ll_text_add(&t, "%s(%d,%d): %g", first ? "" : ", ", i, col[k], val[k]);
+        first = 0;
+      }
+      if (diag) { /* sss_mat.c:136-144: the row's lower entries, then its diagonal entry */
+        bad |= ll_text_add(&t, "%s(%d,%d): %g", first ? "" : ", ", i, i, diag[i]);
+        first = 0;
+      }
+    }
+    bad |= ll_text_add(&t, "])");
+  }
+  if (bad) {
+    free(t.p);
+    return PyErr_NoMemory();
+  }
+  ret = PyUnicode_FromStringAndSize(t.p, (Py_ssize_t)t.len);
+  free(t.p);
+  return ret;
+}
+
+static PyObject *CSRMat_repr(CSRMatObject *a);
+static PyObject *CSRMat_str(CSRMatObject *a) {
+  PyObject *empty, *arrs, *ret;
+  if (a->nnz > 10000) return CSRMat_repr(a);
+  if ((empty = PyTuple_New(0)) == NULL) return NULL;
+  arrs = CSRMat_to_arrays(a, empty);
+  Py_DECREF(empty);
+  if (arrs == NULL) return NULL;
+  ret = csr_like_str("csr_mat", a->dim[0], a->dim[1], (const int *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 0)),
+                     (const int *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 1)),
+                     (const double *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 2)), NULL, a->nnz);
+  Py_DECREF(arrs);
+  return ret;
+}
+
 static PyMethodDef CSRMat_methods[] = {
     {"matvec", (PyCFunction)CSRMat_matvec, METH_VARARGS, "a.matvec(x, y): y := a * x"},
     {"matvec_transp", (PyCFunction)CSRMat_matvec_transp, METH_VARARGS, "a.matvec_transp(x, y): y := a^T * x"},
@@ -1096,6 +1143,22 @@ static PyObject *SSSMat_get_psp_op(SSSMatObject *a, void *c) {
 static PyObject *SSSMat_repr(SSSMatObject *a) {
   return PyUnicode_FromFormat("<sss_mat object %s, order %d, %d stored lower entries>", psp_where(),
                               a->n, a->nnz);
+}
+
+static PyObject *SSSMat_repr(SSSMatObject *a);
+static PyObject *SSSMat_str(SSSMatObject *a) {
+  PyObject *empty, *arrs, *ret;
+  if (a->nnz + a->n > 10000) return SSSMat_repr(a);
+  if ((empty = PyTuple_New(0)) == NULL) return NULL;
+  arrs = SSSMat_to_arrays(a, empty);
+  Py_DECREF(empty);
+  if (arrs == NULL) return NULL;
+  ret = csr_like_str("sss_mat", a->n, a->n, (const int *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 0)),
+                     (const int *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 1)),
+                     (const double *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 2)),
+                     (const double *)PyArray_DATA((PyArrayObject *)PyTuple_GET_ITEM(arrs, 3)), (long)a->nnz + a->n);
+  Py_DECREF(arrs);
+  return ret;
 }
 
 static PyMethodDef SSSMat_methods[] = {
@@ -1822,12 +1885,14 @@ PyMODINIT_FUNC PyInit_spmatrix(void) {
   init_type(&LLMatType, "pysparse_amd.sparse.spmatrix.ll_mat", sizeof(LLMatObject),
             (destructor)LLMat_dealloc, (reprfunc)LLMat_repr, LLMat_methods, LLMat_getset,
             &LLMat_as_mapping);
-  LLMatType.tp_str = (reprfunc)LLMat_str; /* print(A): the reference's tp_print text */
   init_type(&CSRMatType, "pysparse_amd.sparse.spmatrix.csr_mat", sizeof(CSRMatObject),
             (destructor)CSRMat_dealloc, (reprfunc)CSRMat_repr, CSRMat_methods, CSRMat_getset, NULL);
   init_type(&SSSMatType, "pysparse_amd.sparse.spmatrix.sss_mat", sizeof(SSSMatObject),
             (destructor)SSSMat_dealloc, (reprfunc)SSSMat_repr, SSSMat_methods, SSSMat_getset,
             &SSSMat_as_mapping);
+  LLMatType.tp_str = (reprfunc)LLMat_str; /* print(A): the text of the reference's tp_print slots */
+  CSRMatType.tp_str = (reprfunc)CSRMat_str;
+  SSSMatType.tp_str = (reprfunc)SSSMat_str;
   if (PyType_Ready(&LLMatType) < 0 || PyType_Ready(&CSRMatType) < 0 || PyType_Ready(&SSSMatType) < 0)
     return NULL;
   m = PyModule_Create(&spmatrix_module);

@@ -55,6 +55,15 @@ O.poisson_csr(30, 20).matvec_transp(x, yto)
 assert np.array_equal(yt, yto)
 assert S[3, 10] == S[10, 3] == -1.0 and S[5, 5] == 4.0 and S[0, 30] == 0.0
 assert "PSP_DEVICE=cpu" in repr(A) and "on the GPU" not in repr(A) and "PSP_DEVICE=cpu" in repr(S)  # host-mode objects say where they live
+# print(A): the text of the reference's tp_print slots (csr_mat.c:186-207, sss_mat.c:127-147)
+T3 = spmatrix.ll_mat_sym(3, 5)
+for i in range(3):
+    T3[i, i] = 2
+    if i:
+        T3[i, i - 1] = -1
+assert str(T3.to_csr()) == "csr_mat([3,3], [(0,0): 2, (0,1): -1, (1,0): -1, (1,1): 2, (1,2): -1, (2,1): -1, (2,2): 2])"
+assert str(T3.to_sss()) == "sss_mat([3,3], [(0,0): 2, (1,0): -1, (1,1): 2, (2,1): -1, (2,2): 2])"
+assert str(spmatrix.poisson_csr(60, 60)).startswith("<csr_mat object")  # beyond 10 000 entries: the one-line repr
 
 # ---- solvers against the goldens of the compiled reference kernels and, bit for bit, the oracle's sequential loops
 with open(os.path.join(ROOT, "tests", "golden", "ref_krylov.json")) as f:

@@ -110,6 +110,28 @@ def test_types_attributes_and_matvec_bit_exact(oracle, L100):
     assert S[5, 5] == 4.0 and S[5, 4] == -1.0 and S[4, 5] == -1.0 and S[5, 7] == 0.0
     with pytest.raises(IndexError, match="slices not supported"):
         S[0:2, 1]
+    # print(A) of device-resident matrices: the text of the reference's tp_print slots (csr_mat.c:186-207, sss_mat.c:127-147)
+    T3 = spmatrix.ll_mat_sym(3, 5)
+    for i in range(3):
+        T3[i, i] = 2
+        if i:
+            T3[i, i - 1] = -1
+    assert str(T3.to_csr()) == "csr_mat([3,3], [(0,0): 2, (0,1): -1, (1,0): -1, (1,1): 2, (1,2): -1, (2,1): -1, (2,2): 2])"
+    assert str(T3.to_sss()) == "sss_mat([3,3], [(0,0): 2, (1,0): -1, (1,1): 2, (2,1): -1, (2,2): 2])"
+    assert str(A).startswith("<csr_mat object")  # beyond 10 000 stored entries: the one-line repr
+    # every editing method of ll_mat drops the device mirror: the next product sees the edit
+    E = poisson2d(6)
+    ye, xe = np.empty(36), np.arange(36.0)
+    E.matvec(xe, ye)
+    E.scale(2.0)
+    E[0:2, 0:2] = 1.0
+    E.delete_rowcols(np.array([1] * 30 + [0] * 6, "l"))
+    Ed = np.zeros(E.shape)
+    v_, r_, c_ = E.find()
+    Ed[r_, c_] = v_
+    y30 = np.empty(30)
+    E.matvec(xe[:30], y30)
+    assert E.shape == (30, 30) and np.allclose(y30, Ed @ xe[:30], rtol=1e-14, atol=1e-12)
     # modifying the ll_mat invalidates its device mirror
     L2 = poisson2d(5)
     y5 = np.empty(25)
