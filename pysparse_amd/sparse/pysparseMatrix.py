@@ -12,7 +12,7 @@ import numpy as np
 
 from . import spmatrix
 
-__all__ = ["PysparseMatrix", "PysparseIdentityMatrix", "PysparseSpDiagsMatrix"]
+__all__ = ["PysparseMatrix", "PysparseIdentityMatrix", "PysparseSpDiagsMatrix", "PysparseMatrix4Scipy"]
 
 
 def _triplets(L):
@@ -26,12 +26,6 @@ def _triplets(L):
                 np.concatenate([val, diag[stored]]))
     ind, col, val = L.to_csr_arrays()
     return np.repeat(np.arange(L.shape[0]), np.diff(ind)), col.astype(np.int64), val
-
-
-def _new_like(L, size_hint=None):
-    n, m = L.shape
-    hint = int(size_hint if size_hint is not None else max(L.nnz, 1))
-    return spmatrix.ll_mat_sym(n, hint) if L.issym else spmatrix.ll_mat(n, m, hint)
 
 
 def _general_triplets(L):
@@ -92,159 +86,195 @@ class PysparseMatrix:
     nnz = property(getNnz)
 
     def copy(self):
-        return PysparseMatrix(matrix=self.matrix.copy())  # pysparseMatrix.py:98-100
+        return PysparseMatrix(matrix=self.matrix.copy())  # pysparseMatrix.py:126-128
 
-    def __getitem__(self, index):
+    def __getitem__(self, index):  # :142-147: a number for [i, j], a (general) sub-matrix otherwise
         m = self.matrix[index]
         return m if isinstance(m, (int, float)) else PysparseMatrix(matrix=m)
 
-    def __setitem__(self, index, value):
+    def __setitem__(self, index, value):  # :149-154
         self.matrix[index] = value.matrix if isinstance(value, PysparseMatrix) else value
 
-    def __repr__(self):
-        return "<PysparseMatrix %dx%d, %d stored entries%s>" % (self.shape + (self.nnz, ", symmetric" if self.isSymmetric() else ""))
+    def __repr__(self):  # sparseMatrix.py:101-102
+        return repr(self.matrix)
 
     def __str__(self):
+        """sparseMatrix.py:78-99: cells of width 11, '---' for zeros; beyond 10 000 cells the one-line repr"""
         n, m = self.shape
-        if n * m > 400:
+        if n * m > 10000:
             return repr(self)
-        a = self.getNumpyArray()
-        return "\n".join(" ".join("   ---    " if x == 0.0 else "%9f " % x for x in row) for row in a)
+        rows = []
+        for row in self.getNumpyArray():
+            cells = []
+            for v in row:
+                if v == 0:
+                    cells.append("---".center(11))
+                elif abs(np.log(abs(v))) <= 4:
+                    cells.append(("%9.6f" % v).ljust(11))
+                else:
+                    cells.append(("%9.2e" % v).ljust(11))
+            rows.append("".join(cells))
+        return "\n".join(rows)
 
-    # ---- arithmetic
-    def _combine(self, other, sign):
-        if not isinstance(other, PysparseMatrix):
-            if other == 0:
-                return self.copy()
-            raise TypeError("a PysparseMatrix can only be added to another PysparseMatrix (or 0)")
-        if self.shape != other.shape:
-            raise TypeError("cannot add matrices of shapes %s and %s" % (self.shape, other.shape))
-        both_sym = self.isSymmetric() and other.isSymmetric()
-        n, m = self.shape
-        L = spmatrix.ll_mat_sym(n, self.nnz + other.nnz) if both_sym else spmatrix.ll_mat(n, m, self.nnz + other.nnz)
-        get = _triplets if both_sym else _general_triplets
-        r, c, v = get(self.matrix)
-        if v.size:
-            L.put(v, r, c)
-        r, c, v = get(other.matrix)
-        if v.size:
-            L.update_add_at(sign * v, r, c)
-        return PysparseMatrix(matrix=L)
+    # ---- arithmetic (pysparseMatrix.py:156-297)
+    def _check_same_shape(self, other, what):
+        if self.getShape() != other.getShape():
+            raise TypeError("Only sparse matrices of the same size may be %s" % what)
+
+    def _shifted(self, sign, other):
+        """self + sign * other as a new ll_mat: copy, generalize when a general matrix joins a symmetric one, shift"""
+        L = self.matrix.copy()
+        if self.isSymmetric() and not other.isSymmetric():
+            L.generalize()
+        L.shift(sign, other.getMatrix())
+        return L
 
     def __add__(self, other):
-        return self._combine(other, 1.0)
+        if isinstance(other, PysparseMatrix):
+            self._check_same_shape(other, "added")
+            return PysparseMatrix(matrix=self._shifted(1, other))
+        if isinstance(other, (int, float, np.integer, np.floating)):
+            if other == 0:
+                return self
+            L = self.copy()  # a number is added to the entries of the nonzero pattern (:183-188)
+            val, irow, jcol = L.find()
+            L.matrix.update_add_at(other * np.ones(val.shape), irow, jcol)
+            return L
+        return NotImplemented
 
     __radd__ = __add__
 
     def __sub__(self, other):
-        return self._combine(other, -1.0)
+        if isinstance(other, PysparseMatrix):
+            self._check_same_shape(other, "subtracted")
+            return PysparseMatrix(matrix=self._shifted(-1, other))
+        if isinstance(other, (int, float, np.integer, np.floating)):
+            return self.__add__(-other)
+        return NotImplemented
 
     def __rsub__(self, other):
-        return (-self)._combine(other, 1.0)
+        return (-self).__add__(other)
+
+    def _iadd(self, other, sign):
+        if not isinstance(other, PysparseMatrix):
+            raise TypeError("in-place addition is with sparse matrices only")
+        self._check_same_shape(other, "added")
+        if self.isSymmetric() and not other.isSymmetric():
+            self.matrix.generalize()
+        self.matrix.shift(sign, other.getMatrix())
+        return self
 
     def __iadd__(self, other):
-        self.matrix = self._combine(other, 1.0).matrix
-        return self
+        return self._iadd(other, 1)
 
     def __isub__(self, other):
-        self.matrix = self._combine(other, -1.0).matrix
-        return self
+        return self._iadd(other, -1)
 
     def __neg__(self):
-        return self * -1.0
+        return self * -1
 
     def __pos__(self):
         return self
 
     def __mul__(self, other):
-        """matrix * scalar, matrix * vector (on the GPU) or matrix * matrix"""
+        """matrix * matrix (spmatrix.matrixmultiply), matrix * scalar, matrix * vector (ll_mat.matvec: on the GPU)"""
+        nrow, ncol = self.getShape()
         if isinstance(other, PysparseMatrix):
-            if self.shape[1] != other.shape[0]:
-                raise TypeError("matrix dimensions do not match for multiplication")
+            if ncol != other.getShape()[0]:
+                raise TypeError("Matrices dimensions do not match for product")
             if not other.isSymmetric():  # what spmatrix.matrixmultiply offers (ll_mat.c:3461-3660), in its summation order
                 return PysparseMatrix(matrix=spmatrix.matrixmultiply(self.matrix, other.matrix))
             import scipy.sparse as sp  # a symmetric right factor: NotImplementedError in the reference
             a = sp.csr_matrix((_general_triplets(self.matrix)[2], _general_triplets(self.matrix)[:2]), shape=self.shape)
             b = sp.csr_matrix((_general_triplets(other.matrix)[2], _general_triplets(other.matrix)[:2]), shape=other.shape)
-            p = (a @ b).tocoo()
-            L = spmatrix.ll_mat(self.shape[0], other.shape[1], max(p.nnz, 1))
-            if p.nnz:
-                L.put(p.data, p.row.astype(np.int64), p.col.astype(np.int64))
+            prod = (a @ b).tocoo()
+            L = spmatrix.ll_mat(nrow, other.shape[1], max(prod.nnz, 1))
+            if prod.nnz:
+                L.put(prod.data, prod.row.astype(np.int64), prod.col.astype(np.int64))
             return PysparseMatrix(matrix=L)
-        if isinstance(other, np.ndarray) or isinstance(other, (list, tuple)):
-            x = np.ascontiguousarray(other, dtype=np.float64)
-            if x.ndim != 1 or x.shape[0] != self.shape[1]:
-                raise TypeError("matrix and vector dimensions do not match")
-            y = np.empty(self.shape[0])
-            self.matrix.matvec(x, y)
+        shape = np.shape(other)
+        if shape == ():
+            L = self.matrix.copy()
+            L.scale(float(other))
+            return PysparseMatrix(matrix=L)
+        if shape == (ncol,):
+            y = np.empty(nrow)
+            self.matrix.matvec(np.ascontiguousarray(other, dtype=np.float64), y)
             return y
-        L = self.matrix.copy()
-        L.scale(float(other))
-        return PysparseMatrix(matrix=L)
+        raise TypeError("Cannot multiply objects")
 
     def __rmul__(self, other):
         """scalar * matrix, or vector * matrix = A^T x"""
-        if isinstance(other, np.ndarray):
-            x = np.ascontiguousarray(other, dtype=np.float64)
-            if x.ndim != 1 or x.shape[0] != self.shape[0]:
-                raise TypeError("vector and matrix dimensions do not match")
+        if isinstance(other, np.ndarray) and other.ndim == 1:
+            if other.shape[0] != self.shape[0]:
+                raise TypeError("Cannot multiply objects")
             y = np.empty(self.shape[1])
-            self.matrix.matvec_transp(x, y)
+            self.matrix.matvec_transp(np.ascontiguousarray(other, dtype=np.float64), y)
             return y
         return self * other
 
     def __imul__(self, other):
-        self.matrix = (self * float(other)).matrix
+        if not isinstance(other, (int, float, np.integer, np.floating)):
+            raise TypeError("In-place multiplication is with scalars only")
+        self.matrix.scale(float(other))
         return self
 
     def matvec(self, x):
         return self * x
 
-    # ---- scaling
+    # ---- scaling (:299-311)
     def col_scale(self, v):
-        """A := A diag(v)"""
+        """A[:, i] *= v[i] (stored entries; a symmetric matrix would lose its symmetry: TypeError here)"""
         if self.isSymmetric():
             raise TypeError("row / column scaling of a symmetric ll_mat is not supported")
         self.matrix.col_scale(np.ascontiguousarray(v, dtype=np.float64))
 
     def row_scale(self, v):
-        """A := diag(v) A"""
+        """A[i, :] *= v[i]"""
         if self.isSymmetric():
             raise TypeError("row / column scaling of a symmetric ll_mat is not supported")
         self.matrix.row_scale(np.ascontiguousarray(v, dtype=np.float64))
 
-    # ---- bulk access
+    # ---- bulk access (:313-478)
     def find(self):
-        """(values, rows, cols) of the stored entries"""
-        r, c, v = _triplets(self.matrix)
-        return v, r, c
+        """(val, irow, jcol) of the stored entries, row by row"""
+        return self.matrix.find()
 
-    @staticmethod
-    def _ids(n, id1, id2):
+    def _ids(self, value, id1, id2):
+        """:358-370: id2 defaults to id1; both default to 0 .. len(value)-1 (0 .. nrow-1 / ncol-1 for a scalar)"""
+        nrow, ncol = self.getShape()
+        scalar = np.ndim(value) == 0
+        if id2 is None and id1 is not None:
+            id2 = id1
         if id1 is None:
-            id1 = np.arange(n)
-        id1 = np.asarray(id1, dtype=np.int64).ravel()
-        id2 = id1 if id2 is None else np.asarray(id2, dtype=np.int64).ravel()
-        return id1, id2
+            id1 = np.arange(nrow if scalar else len(value))
+        if id2 is None:
+            id2 = np.arange(ncol if scalar else len(value))
+        return np.asarray(id1, dtype=np.int64).ravel(), np.asarray(id2, dtype=np.int64).ravel()
 
     def put(self, value, id1=None, id2=None):
-        """A[id1[k], id2[k]] = value[k] (scalars broadcast; id2 defaults to id1)"""
-        id1, id2 = self._ids(min(self.shape), id1, id2)
+        """A[id1[k], id2[k]] = value[k] (a scalar goes to every position)"""
+        id1, id2 = self._ids(value, id1, id2)
         vals = np.broadcast_to(np.asarray(value, dtype=np.float64), id1.shape).copy()
         if vals.size:
             self.matrix.put(vals, id1, id2)
 
     def putDiagonal(self, vector):
-        v = np.atleast_1d(np.asarray(vector, dtype=np.float64))
-        k = np.arange(v.size if v.size > 1 else min(self.shape))
-        self.put(vector, k, k)
+        if np.ndim(vector) == 0:
+            k = np.arange(min(self.shape))
+            self.put(vector, k, k)
+        else:
+            v = np.asarray(vector, dtype=np.float64).ravel()
+            k = np.arange(v.size)
+            self.put(v, k, k)
 
     def take(self, id1=None, id2=None):
-        id1, id2 = self._ids(min(self.shape), id1, id2)
-        sym = self.isSymmetric()
-        out = np.empty(id1.size)
-        for k, (i, j) in enumerate(zip(id1.tolist(), id2.tolist())):
-            out[k] = self.matrix[(j, i) if sym and i < j else (i, j)]
+        """val[k] = A[id1[k], id2[k]]"""
+        if id1 is None and id2 is None:
+            id1 = np.arange(min(self.shape))
+        id1, id2 = self._ids(np.empty(0) if id1 is None else id1, id1, id2)
+        out = np.zeros(id1.size)
+        self.matrix.take(out, id1, id2)
         return out
 
     def takeDiagonal(self):
@@ -253,25 +283,39 @@ class PysparseMatrix:
 
     def addAt(self, vector, id1, id2):
         """A[id1[k], id2[k]] += vector[k]"""
-        id1, id2 = self._ids(min(self.shape), id1, id2)
+        id1 = np.asarray(id1, dtype=np.int64).ravel()
+        id2 = np.asarray(id2, dtype=np.int64).ravel()
         vals = np.broadcast_to(np.asarray(vector, dtype=np.float64), id1.shape).copy()
         if vals.size:
             self.matrix.update_add_at(vals, id1, id2)
 
     def addAtDiagonal(self, vector):
-        v = np.atleast_1d(np.asarray(vector, dtype=np.float64))
-        k = np.arange(v.size if v.size > 1 else min(self.shape))
-        self.addAt(vector, k, k)
+        if np.ndim(vector) == 0:
+            k = np.arange(min(self.shape))
+            self.addAt(np.full(k.size, float(vector)), k, k)
+        else:
+            v = np.asarray(vector, dtype=np.float64).ravel()
+            k = np.arange(v.size)
+            self.addAt(v, k, k)
 
     def getNumpyArray(self):
         a = np.zeros(self.shape)
-        r, c, v = _general_triplets(self.matrix)
-        a[r, c] = v
+        val, irow, jcol = self.matrix.find()
+        a[irow, jcol] = val
+        if self.isSymmetric():
+            a[jcol, irow] = val
         return a
 
     def exportMmf(self, filename):
-        """MatrixMarket coordinate file: ll_mat.export_mtx (pysparseMatrix.py:470-478; 17 digits: the same doubles come back)"""
+        """MatrixMarket coordinate file: ll_mat.export_mtx (:470-478; 17 digits here, so the same doubles come back)"""
         self.matrix.export_mtx(filename, 17)
+
+
+class PysparseMatrix4Scipy(PysparseMatrix):
+    """:545-556: matvec(x, y) with the two-argument signature some SciPy-style callers expect"""
+
+    def matvec(self, x, y):
+        return self.matrix.matvec(x, y)
 
 
 class PysparseIdentityMatrix(PysparseMatrix):

@@ -335,6 +335,94 @@ def test_pysparse_matrix_host_operations(tmp_path):
     assert np.array_equal(PysparseMatrix(matrix=L).getNumpyArray(), dense)
 
 
+def test_pysparse_matrix_reference_doctests():
+    """the doctests of pysparse/sparse/pysparseMatrix.py (:171-186, :228-251, :317-325, :334-344, :372-387, :435-441, :486-489,
+    :506-513), Python 3: same statements, same printed matrices (whitespace normalised as doctest does)"""
+    from pysparse.sparse.pysparseMatrix import (PysparseIdentityMatrix, PysparseMatrix, PysparseMatrix4Scipy,
+                                                PysparseSpDiagsMatrix)
+
+    def shown(M):
+        return [line.split() for line in str(M).splitlines()]
+
+    def expect(text):
+        return [line.split() for line in text.strip().splitlines()]
+
+    L = PysparseMatrix(size=3)
+    L.put([3., 10., np.pi, 2.5], [0, 0, 1, 2], [2, 1, 1, 0])
+    assert shown(L + PysparseIdentityMatrix(size=3)) == expect("""
+         1.000000  10.000000   3.000000
+            ---     4.141593      ---
+         2.500000      ---     1.000000""")
+    assert shown(L + 0) == expect("""
+            ---    10.000000   3.000000
+            ---     3.141593      ---
+         2.500000      ---        ---""")
+    assert shown(L + 3) == expect("""
+            ---    13.000000   6.000000
+            ---     6.141593      ---
+         5.500000      ---        ---""")
+    assert str(L).splitlines()[0] == "---".center(11) + "10.000000".ljust(11) + " 3.000000".ljust(11)  # sparseMatrix.py:78-99
+    L1 = PysparseMatrix(size=3)
+    L1.put([3., 10., np.pi, 2.5], [0, 0, 1, 2], [2, 1, 1, 0])
+    L2 = PysparseMatrix(size=3)
+    L2.put(np.ones(3), np.arange(3), np.arange(3))
+    L2.put([4.38, 12357.2, 1.1], [2, 1, 0], [1, 0, 2])
+    tmp = np.array(((1.23572000e+05, 2.31400000e+01, 3.00000000e+00), (3.88212887e+04, 3.14159265e+00, 0.0),
+                    (2.50000000e+00, 0.0, 2.75000000e+00)))
+    assert np.allclose((L1 * L2).getNumpyArray(), tmp)
+    val, irow, jcol = L.find()
+    assert np.allclose(val, [10., 3., 3.14159265, 2.5]) and irow.tolist() == [0, 0, 1, 2] and jcol.tolist() == [1, 2, 1, 0]
+    L.put(2 * np.pi, range(3), range(3))
+    assert shown(L) == expect("""
+         6.283185  10.000000   3.000000
+            ---     6.283185      ---
+         2.500000      ---     6.283185""")
+    D = PysparseMatrix(size=3)
+    D.putDiagonal([3., 10., np.pi])
+    assert shown(D) == expect("""
+         3.000000      ---        ---
+            ---    10.000000      ---
+            ---        ---     3.141593""")
+    D.putDiagonal([10., 3.])
+    assert shown(D)[0][0] == "10.000000" and shown(D)[1][1] == "3.000000" and shown(D)[2][2] == "3.141593"
+    D.putDiagonal(2.7182)
+    assert [shown(D)[i][i] for i in range(3)] == ["2.718200"] * 3
+    M = PysparseMatrix(size=3)
+    M.put([3., 10., np.pi, 2.5], [0, 0, 1, 2], [2, 1, 1, 0])
+    M.addAt((1.73, 2.2, 8.4, 3.9, 1.23), (1, 2, 0, 0, 1), (2, 2, 0, 0, 2))
+    assert shown(M) == expect("""
+        12.300000  10.000000   3.000000
+            ---     3.141593   2.960000
+         2.500000      ---     2.200000""")
+    assert shown(PysparseIdentityMatrix(size=3)) == expect("""
+         1.000000      ---        ---
+            ---     1.000000      ---
+            ---        ---     1.000000""")
+    e = np.ones(5)
+    assert shown(PysparseSpDiagsMatrix(size=5, vals=(-2 * e, e, 2 * e), pos=(-1, 0, 1)))[:3] == expect("""
+         1.000000   2.000000      ---        ---        ---
+        -2.000000   1.000000   2.000000      ---        ---
+            ---    -2.000000   1.000000   2.000000      ---""")
+    # the behaviours beside the doctests: in-place forms keep the object, a general matrix joining a symmetric one
+    # generalises it, sub-matrices come back wrapped, in-place scaling is for scalars
+    S = PysparseIdentityMatrix(size=3)
+    ident = id(S)
+    S += M
+    assert id(S) == ident and not S.isSymmetric() and np.array_equal(S.getNumpyArray(), np.eye(3) + M.getNumpyArray())
+    S -= M
+    S *= 2
+    assert id(S) == ident and np.array_equal(S.getNumpyArray(), 2 * np.eye(3))
+    with pytest.raises(TypeError):
+        S *= M
+    with pytest.raises(TypeError, match="Cannot multiply objects"):
+        S * np.ones(4)
+    sub = M[0:2, 1:3]
+    assert isinstance(sub, PysparseMatrix) and np.array_equal(sub.getNumpyArray(), M.getNumpyArray()[0:2, 1:3])
+    M[0:2, 0:2] = PysparseIdentityMatrix(size=2)
+    assert np.array_equal(M.getNumpyArray()[0:2, 0:2], np.eye(2))
+    assert repr(M) == repr(M.getMatrix()) and isinstance(PysparseMatrix4Scipy(size=2), PysparseMatrix)
+
+
 def test_mtx_direct_ingest_equals_ll_mat_route(tmp_path):
     """tools.mtx (MatrixMarket -> CSR / SSS arrays without an ll_mat) against ll_mat_from_mtx(...).to_*:
     general and symmetric files, unsorted entries, repeated entries (last one wins), explicit zeros"""
