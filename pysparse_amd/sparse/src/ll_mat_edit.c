@@ -95,7 +95,7 @@ static int ll_compress(LLMatObject *self, int *freed) {
   self->col = col;
   self->link = link;
   self->free = -1;
-  *freed = self->nalloc - nnz;
+  *freed = self->nalloc - cap; /* (one slot stays allocated for an empty matrix) */
   self->nalloc = cap;
   return 0;
 }
