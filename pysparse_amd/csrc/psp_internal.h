@@ -124,7 +124,10 @@ constexpr int kSlots = 4;
 constexpr int kFold = 1024;  // outputs of the first-level folds of psp_csr.hip (grids beyond kMaxParts, parts of a big matrix)
 constexpr int kTailGroup = 256;                      // partials per group
 constexpr int kTailGroups = kMaxParts / kTailGroup;  // 8192
-constexpr int kOneBlockGroups = 256;                 // <= this many groups (65536 partials): one workgroup does it all
+constexpr int kOneBlockGroups = 256;                 // <= this many groups (65536 partials): one workgroup CAN do it all
+constexpr int kFoldAboveGroups = 16;                 // ... and does, up to this many (4096 partials; psp_runtime.hip one_block_groups():
+                                                     // beyond, one workgroup's ~45 GB/s costs more than the second launch --
+                                                     // profiles/r4_fold_threshold_ab.txt: 4096^2 PCG 368 -> 338 us per iteration)
 // streaming vector kernels: one workgroup per contiguous span of kVecSpan elements
 // (non-persistent grids measured faster than grid-stride loops on MI355X, profiles/)
 constexpr int kVecSpan = 512;  // one 16-byte access per lane per array: measured best (profiles/)

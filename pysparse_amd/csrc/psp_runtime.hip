@@ -211,13 +211,26 @@ __global__ __launch_bounds__(kReduceBlock) void finish_kernel(const double *__re
   reduce_block(partials, nparts, nvals, stride, raw != 0, out, sh);
 }
 
+// Up to how many groups of 256 partial sums the finishing block reads the raw partial sums itself.  One workgroup pulls
+// its operands at ~45 GB/s (profiles/r4_c2_kernel_durations.txt: 22 us for 32 768 x 3 partial sums at 4096^2), a group
+// fold over the whole chip + the finishing block cost two launches (~10 us): PSP_FOLD_ONE_BLOCK_GROUPS (tuning switch,
+// read per reduction; tools/fold_threshold_ab.py) moves the boundary; both routes add in the same order (R, psp_internal.h)
+static int one_block_groups() {
+  const char *e = psp::tuning_env("PSP_FOLD_ONE_BLOCK_GROUPS");
+  if (e) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= kOneBlockGroups) return v;
+  }
+  return kFoldAboveGroups;
+}
+
 // first stage of a reduction over more partials than one block takes: the group sums (into slot `fslot` of the
 // workspace's group-sum array); tells the caller what the finishing block has to read (raw: still the per-workgroup
 // partial sums).  fold_stage2: two sets of partial sums, ONE launch when both need the stage.
 static void fold_plan(Workspace *w, const double *partials, int nparts, int fslot, const double **src, int *count,
                       int *stride, bool *raw, bool *need) {
   const int ngroups = (nparts + kTailGroup - 1) / kTailGroup;
-  *need = ngroups > kOneBlockGroups;
+  *need = ngroups > one_block_groups();
   if (*need) {
     *src = w->folded + (size_t)fslot * kTailGroups;
     *count = ngroups;

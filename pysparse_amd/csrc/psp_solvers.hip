@@ -793,11 +793,13 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     }
     // lazy x update: 8 n bytes less per iteration and, since a reduction is one launch (round 4), 5 launches against
     // the eager loop's 6.  In-process A/B on the same buffers (tools/lazy_ab.py, profiles/r4_pcg_lazy_threshold.txt):
-    // +3 ... +10 % from 2^18 to 2^23.5 unknowns, +1 ... +4 % from 2^24.6 on -- and -0.4 / -2.8 % at exactly 2^24 (256^3,
-    // 4096^2 = BASELINE's C2; vectors of exactly 128 MiB), so the band [2^24, 2^25) keeps the eager loop (round 1-3: lazy
-    // from 2^25 only, when either loop was 9-10 launches).  PSP_PCG_LAZYX=2 forces it at any size (tests), 0 disables it
+    // +3 ... +10 % from 2^18 to 2^23.5 unknowns, +1 ... +4 % from 2^24.6 on -- and -0.5 / -2.9 % at exactly 2^24 (256^3,
+    // 4096^2 = BASELINE's C2; vectors of exactly 128 MiB), -0.8 % at 280^3 (2^24.4), +3.6 % at 320^3 (2^24.97;
+    // profiles/r4_pcg_lazy_threshold.txt, second table: after the reductions moved to the group fold), so the band
+    // [2^24, 1.5 * 2^24) keeps the eager loop (round 1-3: lazy from 2^25 only, when either loop was 9-10 launches).
+    // PSP_PCG_LAZYX=2 forces it at any size (tests), 0 disables it
     const int lazy_mode = pcg_lazy_enabled();
-    if ((lazy_mode == 2 || (lazy_mode == 1 && (n < (1 << 24) || n >= (1 << 25)))) && !pcg_graph_enabled())
+    if ((lazy_mode == 2 || (lazy_mode == 1 && (n < (1 << 24) || n >= 3 * (1 << 23)))) && !pcg_graph_enabled())
       return pcg_async_loop_lazy(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                                  relres, hist);
     return pcg_async_loop(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,

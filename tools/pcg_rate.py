@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Jacobi-PCG iterations/s at 512^3 (csr and sss operands) and MINRES, device-resident vectors: three timed solves of 100
-iterations each, best reported (A/B of vector-kernel builds through PSP_LIB_OVERRIDE)."""
+"""Jacobi-PCG iterations/s at 512^3 (or the grid given as "nx,ny,nz": csr and sss operands) and MINRES, device-resident
+vectors: three timed solves of 100 iterations each, best reported (A/B of vector-kernel builds through PSP_LIB_OVERRIDE)."""
 import ctypes as C
 import json
 import os
@@ -15,7 +15,8 @@ from pysparse_amd._capi import check, lib  # noqa: E402
 
 L = lib()
 out = {}
-for form, A in (("csr", dev.DeviceCSR.poisson(512, 512, 512)), ("sss", dev.DeviceSSS.poisson(512, 512, 512))):
+GRID = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "512,512,512").split(","))
+for form, A in (("csr", dev.DeviceCSR.poisson(*GRID)), ("sss", dev.DeviceSSS.poisson(*GRID))):
     n = A.shape[0] if form == "csr" else A.n
     K = dev.DeviceJacobi(A)
     aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
