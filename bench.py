@@ -1694,6 +1694,25 @@ def run_body(a, real_stdout):
                 out["cpu_baseline"]["C1_poisson2d_100"]["gpu_iterations_run"] = its - 1
             except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the bench line
                 out["cpu_baseline"]["C1_poisson2d_100"]["gpu_error"] = str(e)[:200]
+            # configs[1] (4096^2) on the GPU beside the CPU's C2 figure: product and Jacobi-PCG, device-resident vectors
+            try:
+                c2key = [k for k in base if k.startswith("C2_")][0]
+                g2 = int(c2key.rsplit("_", 1)[1])
+                A2 = dev.DeviceCSR.poisson(g2, g2)
+                n2 = A2.shape[0]
+                x2 = dev.DeviceBuffer.from_host(np.random.default_rng(0).standard_normal(n2))
+                y2 = dev.DeviceBuffer(n2)
+                f2 = lambda: A2.matvec_dev(x2.ptr, y2.ptr)  # noqa: E731
+                timed_launches(f2, sync, ev, 5)
+                base[c2key]["gpu_spmv_ms"] = timed_launches(f2, sync, ev, 20)[0]
+                x2.free()
+                y2.free()
+                t2, res2 = pcg_single(L, check, dev, A2, n2, 200, sync)
+                base[c2key]["gpu_pcg_iters_per_s"] = 1.0 / t2
+                base[c2key]["gpu_pcg_check"] = {"info": res2[0], "iter": res2[1]}
+                del A2
+            except Exception as e:  # noqa: BLE001
+                base[[k for k in base if k.startswith("C2_")][0]]["gpu_error"] = str(e)[:200]
             if ref is not None:
                 out["cpu_baseline_reference_pcg"] = ref
             # SURVEY 8d's optional second line, labelled: NOT the reference (which is one thread) -- the headline case's rows
