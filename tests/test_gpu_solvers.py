@@ -423,18 +423,27 @@ def test_minres_loop_variants_agree(oracle):
     """MINRES with device-resident scalars (default: Lanczos / Givens recurrences evaluated by the thread that
     finishes each reduction, 16 iterations enqueued per read of the state) against the host-scalar loop
     (PSP_MINRES_ASYNC=0): the same algorithm -- identical info / iteration counts / residual histories /
-    iterates, on the scaled index-free path (stencil csr and sss), without it (PSP_MINRES_SCALED=0) and on a
-    general CSR matrix (csr_spmv_w2, variant 16578); with and without Jacobi; converged, truncated at every
-    small maxit, and maxit = 0."""
+    iterates, on the scaled paths (stencil csr and sss: index-free kernels; csr_spmv_w3 on a stencil forced to it and on
+    a banded matrix without stencil structure), without them (PSP_MINRES_SCALED=0) and on a general CSR matrix
+    (csr_spmv_w2, variant 16578); with and without Jacobi; converged, truncated at every small maxit, and maxit = 0."""
     import subprocess
     import sys
     code = (
         "import sys, json, numpy as np; sys.path.insert(0, %r);"
         "from pysparse_amd.device import DeviceCSR, DeviceSSS, DeviceJacobi, minres;"
         "out = [];\n"
-        "for M in (DeviceCSR.poisson(60, 50), DeviceSSS.poisson(20, 18, 16), 'w2'):\n"
+        "for M in (DeviceCSR.poisson(60, 50), DeviceSSS.poisson(20, 18, 16), 'w2', 'w3', 'w3band'):\n"
         "    if M == 'w2':\n"
         "        M = DeviceCSR.poisson(60, 50); M.set_variant(16578)\n"
+        "    if M == 'w3':\n"  # csr_spmv_w3 (round 4: it stages x / beta itself when PSP_MINRES_SCALED is on)
+        "        M = DeviceCSR.poisson(60, 50); M.set_variant(1065154); assert M.kernel_info()[0] == 'csr_spmv_w3'\n"
+        "    if M == 'w3band':\n"  # a banded SPD matrix with no stencil structure, a few far couplings (outlier chunks)
+        "        import scipy.sparse as sp; g = np.random.default_rng(5); nn = 6000\n"
+        "        r = np.repeat(np.arange(nn), 6); c = r - g.integers(1, 40, r.size); k = c >= 0; r, c = r[k], c[k]\n"
+        "        far = g.integers(3000, nn, 40); r = np.concatenate([r, far]); c = np.concatenate([c, far - g.integers(2000, 3000, 40)])\n"
+        "        L = sp.coo_matrix((-(0.1 + g.random(r.size)), (r, c)), shape=(nn, nn)).tocsr(); L.sum_duplicates()\n"
+        "        S = (L + L.T).tocsr(); S = (S + sp.diags(1.0 - np.asarray(S.sum(axis=1)).ravel())).tocsr(); S.sort_indices()\n"
+        "        M = DeviceCSR.from_arrays(S.shape, S.indptr, S.indices, S.data); assert M.kernel_info()[0].startswith('csr_spmv_w3')\n"
         "    n = M.shape[0]; b = np.random.default_rng(3).standard_normal(n)\n"
         "    for K in (None, DeviceJacobi(M)):\n"
         "        for tol, mx in [(1e-9, 4000)] + [(0.0, k) for k in range(0, 40, 3)]:\n"
