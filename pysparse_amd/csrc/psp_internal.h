@@ -136,7 +136,9 @@ struct Workspace {
   double *partials = nullptr;   // kSlots * kMaxParts doubles (device)
   double *folded = nullptr;     // kSlots * kTailGroups doubles (device): the group sums
   double *scal_dev = nullptr;   // 16 doubles (device)
-  double *scal_host = nullptr;  // 16 doubles (pinned host)
+  double *scal_host = nullptr;  // 16 doubles + a sequence word (pinned, mapped host memory)
+  double *scal_host_dev = nullptr;      // the device's address of it (fetch_scalars)
+  unsigned long long scal_seq = 0;
   int num_cu = 0;
   int device = -1;
 };

@@ -143,7 +143,14 @@ int workspace(Workspace **out) {
     PSP_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
     PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
     PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
-    PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 16, hipHostMallocDefault));
+    // 16 doubles + a sequence word (fetch_scalars): pinned, mapped, coherent -- the device stores into it directly
+    PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ws.scal_host, 0, sizeof(double) * 24);
+    ws.scal_host_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&ws.scal_host_dev, ws.scal_host, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      ws.scal_host_dev = nullptr;  // fetch_scalars copies then
+    }
     ws.device = d;
   }
   *out = &ws;
@@ -299,9 +306,48 @@ int finish_partials(const double *partials, int nparts, int nvals, double *out_d
   return PSP_OK;
 }
 
+// k <= 16 scalars device -> host.  The host-scalar loops (generic PCG / MINRES, cgs, bicgstab, qmrs, gmres) do this several
+// times per iteration; as a copy + stream synchronisation it left the GPU idle ~18 us each time (trace of the four solvers
+// at 4096^2, profiles/r4_host_scalar_readback.txt).  Instead a one-wave kernel stores the values into mapped host memory,
+// then a sequence number behind a system-scope fence; the host polls the sequence word (a store over the link is visible
+// within a microsecond or two).  Bounded: after 2 s of polling, or where the mapping is not available, or with
+// PSP_FETCH_POLL=0 (tuning switch), the old path runs -- and reports whatever error the stream holds.
+__global__ void publish_scalars_kernel(const double *__restrict__ src, int k, double *dst, unsigned long long *seq_word,
+                                       unsigned long long seq) {
+  if ((int)threadIdx.x < k) __builtin_nontemporal_store(src[threadIdx.x], dst + threadIdx.x);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static bool fetch_poll_enabled() {
+  const char *e = tuning_env("PSP_FETCH_POLL");
+  return !e || atoi(e) != 0;
+}
+
 int fetch_scalars(const double *src_dev, int k, double *dst_host) {
   Workspace *w;
   PSP_TRY(workspace(&w));
+  if (k <= 16 && w->scal_host_dev && fetch_poll_enabled()) {
+    volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(w->scal_host + 16);
+    const unsigned long long seq = ++w->scal_seq;
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, stream(), src_dev, k, w->scal_host_dev,
+                       reinterpret_cast<unsigned long long *>(w->scal_host_dev + 16), seq);
+    if (hipGetLastError() == hipSuccess) {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*word != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+      }
+      if (*word == seq) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        memcpy(dst_host, w->scal_host, sizeof(double) * k);
+        return PSP_OK;
+      }
+    }
+    // fall through: the stream is stuck or faulted -- let the synchronising path say so
+  }
   PSP_HIP(hipMemcpyAsync(w->scal_host, src_dev, sizeof(double) * k, hipMemcpyDeviceToHost,
                          stream()));
   PSP_HIP(hipStreamSynchronize(stream()));
