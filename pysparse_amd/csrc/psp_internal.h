@@ -230,6 +230,8 @@ __device__ __forceinline__ void reduce_block(const double *__restrict__ partials
 #endif
 // copy k scalars device -> host (synchronises the stream)
 int fetch_scalars(const double *src_dev, int k, double *dst_host);
+// finish_partials (below) and fetch_scalars in one launch
+int finish_partials_fetch(const double *partials, int nparts, int nvals, double *out_dev, double *dst_host);
 
 }  // namespace psp
 

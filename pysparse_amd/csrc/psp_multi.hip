@@ -173,6 +173,11 @@ int exchange(psp_mcsr *M, double *const *vext) {
   for (int t = 0; t < M->nranks; ++t) {
     RankOp &T = M->r[t];
     M_HIP(hipSetDevice(T.dev));
+    // the receiver's own stream first: what it enqueued on its ghost zone before this exchange (the clearing of a fresh
+    // vector, the previous product's reads) must be over before a halo lands there -- the copy stream is ordered against
+    // the SENDER by evP below, and nothing else ordered it against the receiver (round 4: a 3-rank product came back
+    // with a ghost zone zeroed after the halo had arrived)
+    if (!T.links.empty()) M_HIP(hipStreamWaitEvent(T.c, T.evP, 0));
     for (Link &L : T.links) {
       RankOp &Q = M->r[L.q];
       M_HIP(hipStreamWaitEvent(T.c, Q.evP, 0));

@@ -212,10 +212,22 @@ __global__ __launch_bounds__(256) void group_fold_kernel(FoldJobs jobs) {
 }
 
 // one block of 1024 threads (reduce_block, psp_internal.h)
+// host_dst != nullptr: the sums also go to mapped host memory, a sequence number behind them (finish_partials_fetch)
 __global__ __launch_bounds__(kReduceBlock) void finish_kernel(const double *__restrict__ partials, int nparts, int nvals,
-                                                              int stride, int raw, double *__restrict__ out) {
+                                                              int stride, int raw, double *out, double *host_dst,
+                                                              unsigned long long *seq_word, unsigned long long seq) {
   __shared__ double sh[kOneBlockGroups];
   reduce_block(partials, nparts, nvals, stride, raw != 0, out, sh);
+  if (host_dst) {
+    __syncthreads();  // out[] was written by whichever lanes finished the sums
+    if (threadIdx.x < 64) {  // ONE wave publishes: a system-scope fence writes the L2 back, sixteen of them do it sixteen times
+      if ((int)threadIdx.x < nvals)
+        __builtin_nontemporal_store(__hip_atomic_load(out + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    host_dst + threadIdx.x);
+      __threadfence_system();  // the wave's stores are complete (and visible to the host) before ...
+      if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // Up to how many groups of 256 partial sums the finishing block reads the raw partial sums itself.  One workgroup pulls
@@ -301,7 +313,7 @@ int finish_partials(const double *partials, int nparts, int nvals, double *out_d
   bool raw;
   PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride, &raw, 0));
   hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kReduceBlock), 0, stream(), src, count, nvals, stride, raw ? 1 : 0,
-                     out_dev);
+                     out_dev, (double *)nullptr, (unsigned long long *)nullptr, 0ull);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
@@ -325,27 +337,50 @@ static bool fetch_poll_enabled() {
   return !e || atoi(e) != 0;
 }
 
+// wait (at most 2 s) until the kernel that carries `seq` has stored its values into the workspace's mapped host words
+static bool poll_scalars(Workspace *w, unsigned long long seq, int k, double *dst_host) {
+  volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(w->scal_host + 16);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*word != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+  }
+  if (*word != seq) return false;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  memcpy(dst_host, w->scal_host, sizeof(double) * k);
+  return true;
+}
+
+// finish_partials + fetch_scalars in one: the finishing block itself stores the sums to the host (one launch and one
+// dependent kernel start less per read-back of the host-scalar loops)
+int finish_partials_fetch(const double *partials, int nparts, int nvals, double *out_dev, double *dst_host) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  if (!(nvals <= 16 && w->scal_host_dev && fetch_poll_enabled())) {
+    PSP_TRY(finish_partials(partials, nparts, nvals, out_dev));
+    return fetch_scalars(out_dev, nvals, dst_host);
+  }
+  const double *src;
+  int count, stride;
+  bool raw;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride, &raw, 0));
+  const unsigned long long seq = ++w->scal_seq;
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kReduceBlock), 0, stream(), src, count, nvals, stride, raw ? 1 : 0,
+                     out_dev, w->scal_host_dev, reinterpret_cast<unsigned long long *>(w->scal_host_dev + 16), seq);
+  PSP_LAUNCH_CHECK();
+  if (poll_scalars(w, seq, nvals, dst_host)) return PSP_OK;
+  return fetch_scalars(out_dev, nvals, dst_host);  // stuck or faulted stream: the synchronising path reports it
+}
+
 int fetch_scalars(const double *src_dev, int k, double *dst_host) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   if (k <= 16 && w->scal_host_dev && fetch_poll_enabled()) {
-    volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(w->scal_host + 16);
     const unsigned long long seq = ++w->scal_seq;
     hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, stream(), src_dev, k, w->scal_host_dev,
                        reinterpret_cast<unsigned long long *>(w->scal_host_dev + 16), seq);
-    if (hipGetLastError() == hipSuccess) {
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (*word != seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-      }
-      if (*word == seq) {
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        memcpy(dst_host, w->scal_host, sizeof(double) * k);
-        return PSP_OK;
-      }
-    }
+    if (hipGetLastError() == hipSuccess && poll_scalars(w, seq, k, dst_host)) return PSP_OK;
     // fall through: the stream is stuck or faulted -- let the synchronising path say so
   }
   PSP_HIP(hipMemcpyAsync(w->scal_host, src_dev, sizeof(double) * k, hipMemcpyDeviceToHost,

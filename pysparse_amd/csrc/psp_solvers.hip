@@ -159,8 +159,7 @@ struct DevVecs {
 
 // reduce `nvals` slots of the workspace partials and bring them to the host
 int reduce_fetch(Workspace *w, int nparts, int nvals, double *host) {
-  PSP_TRY(finish_partials(w->partials, nparts, nvals, w->scal_dev));
-  return fetch_scalars(w->scal_dev, nvals, host);
+  return finish_partials_fetch(w->partials, nparts, nvals, w->scal_dev, host);
 }
 
 // the dinv array when K is a native single-step Jacobi, else nullptr
