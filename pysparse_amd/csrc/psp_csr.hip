@@ -768,10 +768,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip,
     const int *__restrict__ perm, const int *__restrict__ rowperm, const int *__restrict__ colfull = nullptr,
-    int colmod = 0, int use_div = 0, double xdiv = 1.0, const double *__restrict__ xdiv_dev = nullptr) {
-  // use_div (round 4): multiply with x ./ xdiv instead of x -- MINRES' v = y / beta formed while x is staged (the same
-  // correctly rounded division as the separate scale pass, minres.c:123-124), the dot's operand likewise; csr_spmv_w4 has
-  // had this since round 2
+    int colmod = 0) {
   // colmod > 0 (PSP_W3_COLMOD under PSP_TUNING=1; WRONG RESULTS, timing only): chunk c reads the 16-bit columns of chunk
   // c % colmod -- the column stream then comes out of L2 instead of HBM while every other access, the LDS gathers and the
   // arithmetic stay what they are: the time this buys bounds what ANY compression of the columns can buy (round 4)
@@ -785,7 +782,6 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
   constexpr int XL = NB / 8;              // 16-byte x loads per lane
   static_assert(NB == 32 || NB == 64 || NB == 128, "block list is read one or two entries per lane");
   if (skip && *skip) return;  // asynchronous solver loop already finished: no-op launch
-  if (xdiv_dev) xdiv = *xdiv_dev;
   __shared__ double lds_all[WPB * LW];  // 32 KiB at NB <= 64: five workgroups per CU
   double *red = lds_all;
   const int lane = threadIdx.x & 63;
@@ -852,26 +848,18 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
           k1 = (k1 < kmax + 2) ? k1 : kmax + 2;
           const i2v c0 = *reinterpret_cast<const i2v *>(colfull + k0);
           const i2v c1 = *reinterpret_cast<const i2v *>(colfull + k1);
-          double g0 = x[c0.x], g1 = x[c0.y], g2 = x[c1.x], g3 = x[c1.y];
-          if (use_div) {
-            g0 = g0 / xdiv; g1 = g1 / xdiv; g2 = g2 / xdiv; g3 = g3 / xdiv;
-          }
-          p0[st].x = v0[st].x * g0;
-          p0[st].y = v0[st].y * g1;
-          p1[st].x = v1[st].x * g2;
-          p1[st].y = v1[st].y * g3;
+          p0[st].x = v0[st].x * x[c0.x];
+          p0[st].y = v0[st].y * x[c0.y];
+          p1[st].x = v1[st].x * x[c1.x];
+          p1[st].y = v1[st].y * x[c1.y];
         } else {
           int k = kb + (st * 64 + lane) * 4;
           k = (k < kmax) ? k : kmax;
           const i4v cc = *reinterpret_cast<const i4v *>(colfull + k);
-          double g0 = x[cc.x], g1 = x[cc.y], g2 = x[cc.z], g3 = x[cc.w];
-          if (use_div) {
-            g0 = g0 / xdiv; g1 = g1 / xdiv; g2 = g2 / xdiv; g3 = g3 / xdiv;
-          }
-          p0[st].x = v0[st].x * g0;
-          p0[st].y = v0[st].y * g1;
-          p1[st].x = v1[st].x * g2;
-          p1[st].y = v1[st].y * g3;
+          p0[st].x = v0[st].x * x[cc.x];
+          p0[st].y = v0[st].y * x[cc.y];
+          p1[st].x = v1[st].x * x[cc.z];
+          p1[st].y = v1[st].y * x[cc.w];
         }
       }
     } else {
@@ -890,13 +878,6 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
         } else {  // the block that holds the end of x
           xw[j].x = e0 < ncols ? x[e0] : 0.0;
           xw[j].y = 0.0;
-        }
-      }
-      if (use_div) {  // (an unused slot's 0.0 / xdiv is never gathered)
-#pragma unroll
-        for (int j = 0; j < XL; ++j) {
-          xw[j].x = xw[j].x / xdiv;
-          xw[j].y = xw[j].y / xdiv;
         }
       }
 #pragma unroll
@@ -950,7 +931,7 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
           __builtin_nontemporal_store(acc, &y[ro_]);
         else
           y[ro_] = acc;
-        if (dotv) dsum += (use_div ? dotv[ro_] / xdiv : dotv[ro_]) * acc;
+        if (dotv) dsum += dotv[ro_] * acc;
       }
     }
   }
@@ -3199,16 +3180,6 @@ static void launch_variant(int grid, int nchunks, int map_mode, const int2 *tab,
 // Variant bits 25-26 select the other three forms for A/B (stored value XOR 3).
 static int w3_ab(const psp_csr *A) { return (A->variant >= 0 ? (A->variant >> 25) & 3 : 0) ^ 3; }
 
-// the divisor csr_spmv_scaled_launch hands csr_spmv_w3 through the ordinary dispatch (thread-local: every launch of a
-// product happens on the calling thread); `consumed` tells it that the kernel that ran was one that divides
-struct W3Div {
-  int use = 0;
-  double val = 1.0;
-  const double *dev = nullptr;
-  bool consumed = false;
-};
-static thread_local W3Div g_w3div;
-
 // csr_spmv_w3 over chunks [c0, c1) (the whole matrix: 0, nchunks)
 template <int NP, int NB>
 static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int grid, int stripe, int c0,
@@ -3217,17 +3188,15 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
 #define PSP_W3_AB(NTL, PAIRS)                                                                          \
   hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, NTL, PAIRS>), dim3(grid), dim3(256), 0, stream(), c0, c1, \
                      stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,   \
-                     A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod, dv.use, dv.val, dv.dev)
+                     A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod)
   const int ab = w3_ab(A);
   const char *cm = psp::tuning_env("PSP_W3_COLMOD");
   const int colmod = cm ? atoi(cm) : 0;
-  const W3Div dv = g_w3div;
-  if (dv.use) g_w3div.consumed = true;
   if constexpr (NB == 32 || NB == 64) {
     if (t->outliers > 0) {  // one form only: the default stream layout, with the per-chunk fallback compiled in
       hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true, true, true, true>), dim3(grid), dim3(256), 0, stream(), c0, c1,
                          stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                         A->val, x, y, dotv, pbuf, skip, perm, rowperm, A->col, colmod, dv.use, dv.val, dv.dev);
+                         A->val, x, y, dotv, pbuf, skip, perm, rowperm, A->col, colmod);
       return;
     }
   }
@@ -3237,11 +3206,11 @@ static void launch_w3_np_nb(const psp_csr *A, const ChunkTable *t, bool nts, int
   else if (nts)
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, true>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod, dv.use, dv.val, dv.dev);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod);
   else
     hipLaunchKernelGGL((csr_spmv_w3<NP, NB, 4, false>), dim3(grid), dim3(256), 0, stream(), c0, c1, stripe,
                        t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, t->col16, t->blist,
-                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod, dv.use, dv.val, dv.dev);
+                       A->val, x, y, dotv, pbuf, skip, perm, rowperm, nullptr, colmod);
 }
 
 template <int NP>
@@ -3359,46 +3328,7 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
   }();
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
-  if (!on || A->nparts || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
-  bool w4_layout = false;  // does the ordinary dispatch end in csr_spmv_w4 / sss_spmv_w4 for this operator?
-  if (v.w4 && A->sym_owner) {
-    psp_sss *S = const_cast<psp_sss *>(A->sym_owner);
-    PSP_TRY(ensure_sss_w4(S));
-    w4_layout = S->w4_state == 1;
-  }
-  if (v.w4 && !w4_layout) {
-    psp::CsrExtra *exq;
-    PSP_TRY(ensure_w4(A, &exq));
-    w4_layout = exq->dia_state == 1;
-    if (w4_layout && exq->dia_no > 16) return PSP_OK;  // csr_spmv_w4x / w4y have no scaled form
-  }
-  if (!w4_layout) {
-    // banded CSR (round 4): csr_spmv_w3 divides x while it stages it.  Only when the ordinary dispatch ends in plain w3 for
-    // this handle -- the conditions of csr_spmv_launch, in its order; the renumbered copy of a scattered numbering IS such
-    // a handle when the solver runs in the copy's numbering
-    if (A->w4_only || !(v.w1 && v.w2 && v.w3) || A->max_row_nnz > v.tile / 2) return PSP_OK;
-    // one fp64 division per staged entry (~ per nonzero) against 16 bytes per row and a launch: pays up to ~14 entries per
-    // row (7-pt Poisson as csr_spmv_w3: +6.2 % at 512^3, +8.7 % at 2048^2; the FEM stand-in with 44 per row: the product
-    // grows by 9.7 us where the pass saved 5.3 -- profiles/r4_minres_w3_scaled_ab.txt)
-    if ((double)A->nnz > 16.0 * (double)A->nrows) return PSP_OK;
-    ChunkTable *t;
-    PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
-    PSP_TRY(ensure_rowoff(A, t));
-    if (t->np == 0) return PSP_OK;
-    PSP_TRY(ensure_w3(A, t));
-    if (t->nb <= 0) return PSP_OK;
-    g_w3div.use = 1;
-    g_w3div.val = xdiv;
-    g_w3div.dev = xdiv_dev;
-    g_w3div.consumed = false;
-    const int rc = csr_spmv_launch(A, x, y, x, partials, nparts, skip);
-    const bool consumed = g_w3div.consumed;
-    g_w3div = W3Div();
-    if (rc != PSP_OK) return rc;
-    if (!consumed) return fail(PSP_EINVAL, "csr_spmv_scaled_launch: the product did not run through csr_spmv_w3");
-    *available = 1;
-    return PSP_OK;
-  }
+  if (!on || !v.w4 || A->nparts || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
   const int stripe = w4_stripe(A, v);
   const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
   const int grid = w4_grid(nblk, stripe);

@@ -423,8 +423,8 @@ def test_minres_loop_variants_agree(oracle):
     """MINRES with device-resident scalars (default: Lanczos / Givens recurrences evaluated by the thread that
     finishes each reduction, 16 iterations enqueued per read of the state) against the host-scalar loop
     (PSP_MINRES_ASYNC=0): the same algorithm -- identical info / iteration counts / residual histories /
-    iterates, on the scaled paths (stencil csr and sss: index-free kernels; csr_spmv_w3 on a stencil forced to it and on
-    a banded matrix without stencil structure), without them (PSP_MINRES_SCALED=0) and on a general CSR matrix
+    iterates, on the scaled index-free path (stencil csr and sss), without it (PSP_MINRES_SCALED=0), with csr_spmv_w3
+    operators (a stencil forced to it, a banded matrix without stencil structure) and on a general CSR matrix
     (csr_spmv_w2, variant 16578); with and without Jacobi; converged, truncated at every small maxit, and maxit = 0."""
     import subprocess
     import sys
@@ -435,7 +435,7 @@ def test_minres_loop_variants_agree(oracle):
         "for M in (DeviceCSR.poisson(60, 50), DeviceSSS.poisson(20, 18, 16), 'w2', 'w3', 'w3band'):\n"
         "    if M == 'w2':\n"
         "        M = DeviceCSR.poisson(60, 50); M.set_variant(16578)\n"
-        "    if M == 'w3':\n"  # csr_spmv_w3 (round 4: it stages x / beta itself when PSP_MINRES_SCALED is on)
+        "    if M == 'w3':\n"  # csr_spmv_w3 (v = y / beta stays a pass of its own there: profiles/r4_minres_w3_scaled_ab.txt)
         "        M = DeviceCSR.poisson(60, 50); M.set_variant(1065154); assert M.kernel_info()[0] == 'csr_spmv_w3'\n"
         "    if M == 'w3band':\n"  # a banded SPD matrix with no stencil structure, a few far couplings (outlier chunks)
         "        import scipy.sparse as sp; g = np.random.default_rng(5); nn = 6000\n"
