@@ -465,6 +465,35 @@ def test_minres_loop_variants_agree(oracle):
     assert all(o == outs[0] for o in outs)  # bitwise: same products, same reduction order
 
 
+def test_scalar_readback_routes_agree():
+    """the host-scalar loops (cgs, bicgstab, qmrs, gmres, and pcg / minres with PSP_*_ASYNC=0) read their scalars back through
+    mapped host memory that the host polls (round 4, psp_runtime.hip fetch_scalars / finish_partials_fetch); the copy +
+    stream synchronisation of rounds 1-3 (PSP_FETCH_POLL=0) must give the same numbers -- sizes on both sides of the
+    one-block / group-fold boundary of the reductions"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);"
+        "from pysparse_amd import device as dev;"
+        "out = [];\n"
+        "for grid in ((60, 50, 0), (1500, 1500, 0)):\n"
+        "    A = dev.DeviceCSR.poisson(*grid); n = A.shape[0]; K = dev.DeviceJacobi(A)\n"
+        "    b = np.random.default_rng(2).standard_normal(n)\n"
+        "    for f in (dev.pcg, dev.minres, dev.cgs, dev.bicgstab, dev.qmrs, dev.gmres):\n"
+        "        x = np.zeros(n); r = f(A, b, x, 0.0, 12, K)\n"
+        "        out.append([r[0], r[1], r[2], float(x[0]), float(x[n // 2]), float(np.abs(x).sum())])\n"
+        "print(json.dumps(out))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"PSP_FETCH_POLL": "0"}, {"PSP_PCG_ASYNC": "0", "PSP_MINRES_ASYNC": "0"},
+                {"PSP_PCG_ASYNC": "0", "PSP_MINRES_ASYNC": "0", "PSP_FETCH_POLL": "0"}):
+        e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    assert len(outs[0]) == 12 and all(o == outs[0] for o in outs)
+
+
 def test_minres_async_special_exits(oracle):
     """exits of the device-resident MINRES loop: -3 (indefinite preconditioner: beta^2 < 0 inside the loop),
     a zero right-hand side (norm_r0 = 0: NaN relres like the reference), maxit = 0"""
