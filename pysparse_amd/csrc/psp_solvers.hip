@@ -54,7 +54,8 @@ int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double
                 double *w_old, double *x, bool scaled = false, double vdiv = 1.0, const MinresDev *ds = nullptr);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
-int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts);
+int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts,
+               const double *neg_a_dev = nullptr);
 int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double *partials, int *nparts);
 int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc);
 int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts);
@@ -1789,7 +1790,11 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
   for (int i = 0; i <= dim; ++i) PSP_TRY(mem.alloc(n, &V[i]));
   for (int i = 0; i < dim; ++i) PSP_TRY(mem.alloc(n, &W[i]));
   const int m1 = dim + 1;
-  std::vector<double> H((size_t)dim * m1), s(m1), cs(dim), sn(dim);
+  std::vector<double> H((size_t)dim * m1), s(m1), cs(dim), sn(dim), hhost((size_t)dim + 2);
+  double *hdev = nullptr;  // h[0..i] and ||w||^2 of the current column, on the device
+  PSP_TRY(mem.alloc((size_t)dim + 2, &hdev));
+  const char *chain_env = psp::tuning_env("PSP_GMRES_CHAIN");  // 0: one read-back per Gram-Schmidt step (A/B; read per solve)
+  const bool mgs_chain = !chain_env || atoi(chain_env) != 0;
 #define GH(i, j) (H[(size_t)(j) * m1 + (i)])
   int i, j, k, iter = 0;
   double beta, resid0 = 0.0, n2b, rel_resid = 0.0, d;
@@ -1822,7 +1827,21 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
         const char *e = psp::tuning_env("PSP_GMRES_FUSED");  // 0: one dot and one axpy kernel per step (A/B)
         return e ? atoi(e) != 0 : true;
       }();
-      if (mgs_fused) {
+      if (mgs_fused && mgs_chain) {
+        // the whole Gram-Schmidt chain of the column enqueued at once (round 4): step k's axpy takes h[k] from where step
+        // k - 1's reduction left it on the device; the host reads h[0..i] and the norm's square in ONE go at the end
+        // (one scalar read-back per inner iteration instead of i + 2) -- the same operations on the same values
+        int np;
+        PSP_TRY(k_dot(n, V[i + 1], V[0], w->partials, &np));
+        PSP_TRY(finish_partials(w->partials, np, 1, hdev));
+        for (k = 0; k <= i; k++) {
+          PSP_TRY(k_axpy_dot(n, 0.0, V[k], V[i + 1], k < i ? V[k + 1] : nullptr, w->partials, &np, hdev + k));
+          PSP_TRY(finish_partials(w->partials, np, 1, hdev + k + 1));
+        }
+        for (k = 0; k < i + 2; k += 16) PSP_TRY(fetch_scalars(hdev + k, std::min(16, i + 2 - k), hhost.data() + k));
+        for (k = 0; k <= i; k++) GH(k, i) = hhost[k];
+        d = hhost[i + 1];
+      } else if (mgs_fused) {
         PSP_TRY(B.dot(V[i + 1], V[0], &d));
         for (k = 0; k <= i; k++) {
           GH(k, i) = d;

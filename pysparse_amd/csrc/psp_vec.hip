@@ -750,7 +750,11 @@ __global__ __launch_bounds__(kBlock) void qmrs_dx_kernel(long n, const double *_
 template <int V, bool SELF>
 __global__ __launch_bounds__(kBlock) void axpy_dot_kernel(long n, double a, const double *__restrict__ x,
                                                           double *__restrict__ y, const double *__restrict__ z,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials,
+                                                          const double *__restrict__ neg_a_dev) {
+  // neg_a_dev (round 4): the coefficient is minus a value a previous reduction left on the device (the h of the
+  // Gram-Schmidt step before) -- the chain dot -> axpy -> dot then needs no host round trip
+  if (neg_a_dev) a = -*neg_a_dev;
   const bool upd = a != 0.0;
   double acc[1] = {0.0};
   PSP_VEC_LOOP(i, n) {
@@ -1276,13 +1280,14 @@ int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double 
   return PSP_OK;
 }
 
-int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts) {
+int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts,
+               const double *neg_a_dev) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   const bool v2 = z ? can_vec2(n, x, y, z) : can_vec2(n, x, y);
 #define L(V, SELF)                                                                                      \
-  hipLaunchKernelGGL((axpy_dot_kernel<V, SELF>), dim3(grid), dim3(kBlock), 0, stream(), n, a, x, y, z, partials)
+  hipLaunchKernelGGL((axpy_dot_kernel<V, SELF>), dim3(grid), dim3(kBlock), 0, stream(), n, a, x, y, z, partials, neg_a_dev)
   if (z) { if (v2) L(2, false); else L(1, false); }
   else { if (v2) L(2, true); else L(1, true); }
 #undef L
