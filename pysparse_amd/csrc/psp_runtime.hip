@@ -144,10 +144,15 @@ int workspace(Workspace **out) {
     PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
     PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
     // 16 doubles + a sequence word (fetch_scalars): pinned, mapped, coherent -- the device stores into it directly
-    PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent));
+    bool mapped = true;
+    if (hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();  // no mapped coherent host memory here: plain pinned memory, scalars come back by copy
+      mapped = false;
+      PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocDefault));
+    }
     memset(ws.scal_host, 0, sizeof(double) * 24);
     ws.scal_host_dev = nullptr;
-    if (hipHostGetDevicePointer((void **)&ws.scal_host_dev, ws.scal_host, 0) != hipSuccess) {
+    if (!mapped || hipHostGetDevicePointer((void **)&ws.scal_host_dev, ws.scal_host, 0) != hipSuccess) {
       (void)hipGetLastError();
       ws.scal_host_dev = nullptr;  // fetch_scalars copies then
     }
