@@ -513,6 +513,43 @@ def test_store_zeros_semantics():  # ll_mat.c:250-356, :362-460: explicit zeros 
     assert Z.nnz == 0
 
 
+def test_empty_and_degenerate_shapes():
+    """0 x 0 and n x 0 matrices, empty index sets, everything deleted, negative-step slices over a symmetric matrix"""
+    E = spmatrix.ll_mat(0, 0)
+    assert E.shape == (0, 0) and E.nnz == 0 and E.norm("fro") == 0.0 and E.keys() == [] and E.find()[0].size == 0
+    assert str(E) == "ll_mat(general, [0,0]):\n" and E.compress() == 999 and E.compress() == 0
+    Z = spmatrix.ll_mat(3, 0)
+    assert Z[0:3, 0:0].shape == (3, 0) and str(Z) == "ll_mat(general, [3,0]):\n\n\n\n"
+    A = spmatrix.ll_mat(4, 5, 1)
+    A[0:0, :] = 1.0
+    assert A.nnz == 0 and A[[], [0, 1]].shape == (0, 2)
+    A[[], []] = spmatrix.ll_mat(0, 0)
+    A[:, :] = 2.0
+    assert A.nnz == 20 and A.norm("1") == 8.0 and A.norm("inf") == 10.0
+    A.delete_rows(np.zeros(4, "l"))
+    assert A.shape == (0, 5) and A.nnz == 0
+    A.delete_cols(np.zeros(5, "l"))
+    assert A.shape == (0, 0) and A.compress() > 0
+    S = spmatrix.ll_mat_sym(3)
+    S[2, 0] = 1
+    S[1, 1] = 2
+    val, irow, jcol = S[::-1, ::-1].find()  # the full matrix, both axes reversed
+    assert val.tolist() == [1.0, 2.0, 1.0] and irow.tolist() == [0, 1, 2] and jcol.tolist() == [2, 1, 0]
+    S.delete_rowcols(np.array([0, 1, 0]))
+    assert S.shape == (1, 1) and S.items() == [((0, 0), 2.0)]
+    assert spmatrix.matrixmultiply(spmatrix.ll_mat(2, 0), spmatrix.ll_mat(0, 3)).shape == (2, 3)
+    D = spmatrix.symdot(spmatrix.ll_mat(0, 3))
+    assert D.shape == (3, 3) and D.issym and D.nnz == 0
+    big = spmatrix.ll_mat(10, 10)
+    big[2:8:2, 1::3] = 5
+    assert big.nnz == 9 and big[2:8:2, 1::3].nnz == 9 and big[-1:-11:-1, :].shape == (10, 10)
+    big.scale(0.0)  # ll_mat.c:2174-2189 multiplies the stored values; it removes nothing
+    assert big.nnz == 9 and set(big.values()) == {0.0}
+    with pytest.raises(TypeError):
+        spmatrix.matrixmultiply(big, 3)
+    assert len(spmatrix.ll_mat(70000, 70000)) == 4900000000
+
+
 def test_str_len_and_attributes():  # ll_mat.c:3085-3151 (the text tp_print writes), :3154-3163, :3193-3197
     A = poisson.poisson1d(4)
     A[0, 3] = 12345.678
