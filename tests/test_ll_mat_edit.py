@@ -550,6 +550,71 @@ def test_empty_and_degenerate_shapes():
     assert len(spmatrix.ll_mat(70000, 70000)) == 4900000000
 
 
+def test_random_edit_sequences_against_dense():
+    """2000 random edits (element set / update-add, block reads and writes with slices / lists, scaling, shift, row and
+    column deletion, compress, generalize) on general and symmetric matrices, the dense NumPy image checked after each:
+    the free list, the sorted rows and nnz survive any order of operations (run under ASan by tools/sanitize_host.sh)"""
+    rng = np.random.default_rng(17)
+    for sym in (False, True):
+        n = m = 12
+        A = spmatrix.ll_mat_sym(n) if sym else spmatrix.ll_mat(n, m, 3)
+        D = np.zeros((n, m))
+
+        def put_dense(i, j, v, add=False):
+            D[i, j] = D[i, j] + v if add else v
+            if A.issym and i != j:
+                D[j, i] = D[i, j]
+        for step in range(1000):
+            n, m = A.shape
+            if n < 4 or m < 4:  # start again from a fresh matrix once deletions have eaten it
+                n = m = 12
+                A = spmatrix.ll_mat_sym(n) if sym else spmatrix.ll_mat(n, m, 3)
+                D = np.zeros((n, m))
+            op = rng.integers(0, 11)
+            i, j = int(rng.integers(0, n)), int(rng.integers(0, m))
+            if A.issym and i < j:
+                i, j = j, i
+            v = float(rng.choice([0.0, 1.5, -2.25, 3.0]))
+            if op <= 2:
+                A[i, j] = v
+                put_dense(i, j, v)
+            elif op == 3:
+                A.update_add_at(np.array([v]), np.array([i]), np.array([j]))
+                put_dense(i, j, v, add=True)
+            elif op == 4 and not A.issym:
+                r0, c0 = int(rng.integers(0, n - 2)), int(rng.integers(0, m - 2))
+                Bd = rng.integers(-1, 2, (2, 3 if c0 + 3 <= m else 2)).astype(float)
+                A[r0:r0 + 2, c0:c0 + Bd.shape[1]] = from_dense(Bd)
+                D[r0:r0 + 2, c0:c0 + Bd.shape[1]] = Bd
+            elif op == 5:
+                ri = sorted(set(rng.integers(0, n, 3).tolist()))
+                cj = sorted(set(rng.integers(0, m, 3).tolist()))
+                assert np.array_equal(dense(A[ri, cj]), D[np.ix_(ri, cj)])
+                assert np.array_equal(dense(A[1:n:2, ::-1]), D[1:n:2, ::-1])
+            elif op == 6:
+                A.scale(-1.0)
+                D *= -1.0
+            elif op == 7:
+                A.shift(0.5, A.copy())
+                D *= 1.5
+            elif op == 8 and not A.issym and n > 5:
+                mask = (rng.random(n) < 0.85).astype("l")
+                A.delete_rows(mask)
+                D = D[mask != 0]
+            elif op == 9 and n > 5 and n == m:
+                mask = (rng.random(n) < 0.85).astype("l")
+                A.delete_rowcols(mask)
+                D = D[np.ix_(mask != 0, mask != 0)]
+            elif op == 10:
+                if rng.random() < 0.3 and A.issym:
+                    A.generalize()
+                else:
+                    A.compress()
+            assert A.shape == D.shape and np.array_equal(dense(A), D), (sym, step, op)
+            nnz_full = int((D != 0).sum())
+            assert A.nnz == (int((np.tril(D) != 0).sum()) if A.issym else nnz_full), (sym, step, op)
+
+
 def test_str_len_and_attributes():  # ll_mat.c:3085-3151 (the text tp_print writes), :3154-3163, :3193-3197
     A = poisson.poisson1d(4)
     A[0, 3] = 12345.678
