@@ -131,26 +131,44 @@ def _mem_available_gb():
 REF_PCG_TOL = 1e-9  # max-norm relative difference allowed between the reference's and the port's PCG iterates
 
 
-def parity_bound(n, k):
+def parity_bound(n, k, against="oracle"):
     """How far two correct implementations of the same k Krylov iterations may be apart at n unknowns when they differ
     only in the ORDER of their dot-product sums (sequential loop, OpenBLAS kernels, the GPU's fixed tree): every
     reduction of n terms carries ~sqrt(n) eps of order-dependent rounding, each iteration passes it on through alpha /
-    beta, so the iterates drift apart like k sqrt(n) eps; 32 is the head-room over what is measured CPU-against-CPU
-    (the oracle against the compiled reference pcg.c with OpenBLAS: 4.9e-11 at 512^3 / k = 3 where this gives 2.5e-10;
-    1.0e-12 at 4096^2 / k = 10 where it gives 2.9e-10).  north_star's 1e-12 is what the golden-size cases (n <= 3e5)
-    are held to; this is the size-dependent form of the same bar."""
-    return 32.0 * k * float(np.sqrt(n)) * 2.220446049250313e-16  # eps = 2^-52
+    beta, so the iterates drift apart like k sqrt(n) eps.  The head-room over that depends on who is compared:
+      against="oracle"     32 x: the oracle adds its n terms one after the other (the worst order there is); it is itself
+                           4.9e-11 from the compiled reference at 512^3 / k = 3, where this gives 2.5e-10;
+      against="reference"  4 x (round 5): the compiled reference's OpenBLAS sums are blocked like the GPU's tree -- measured
+                           GPU-vs-reference 1.3e-13 at 512^3 / k = 3 and 5.8e-14 at 4096^2 / k = 10 (BENCH_r04), where
+                           this gives 3.1e-11 / 3.6e-11: an error of 1e-10 in a fused update fails it.
+    north_star's 1e-12 is what the golden-size cases (n <= 3e5) are held to; these are the size-dependent forms of the
+    same bar."""
+    factor = {"oracle": 32.0, "reference": 4.0}[against]
+    return factor * k * float(np.sqrt(n)) * 2.220446049250313e-16  # eps = 2^-52
 
 
 def _maxrel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, with_ref=True, x_ref=None, res_ref=None):
+def _ref_solve(O, name, A, b, k, dinv, threads=1):
+    """k iterations (tol = 0) by the reference's own compiled kernel: pysparse/itsolvers/src/{pcg,minres}.c unmodified
+    (oracle/_ref/libref_krylov.so, refk_solve); threads > 1: row-parallel operator callbacks, same bits per row"""
+    x = np.zeros(A.shape[0])
+    info, it, rr, _ = O.ref_krylov(name, A, b, x, 0.0, k, ("jacobi", dinv), threads=threads)
+    return x, (info, it, rr)
+
+
+def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, with_ref=True, x_ref=None, res_ref=None,
+                    with_oracle=True, ref_threads=1):
     """`parity_check` of the bench line and tests/test_gpu_reference_sizes.py: k iterations (tol = 0) of Jacobi-PCG and
-    Jacobi-MINRES on the GPU (through the host-pointer entry points, as the drop-in modules call them) against the
-    oracle's iterates on the same system -- and against the compiled reference PCG when oracle/_ref was built.
-    A / b / x_pcg / res_pcg: what the CPU leg already holds for this grid (else they are made here)."""
+    Jacobi-MINRES on the GPU (through the host-pointer entry points, as the drop-in modules call them) against
+      * the oracle's iterates on the same system (with_oracle; bound 32 k sqrt(n) eps),
+      * the compiled reference where oracle/_ref was built (bound 4 k sqrt(n) eps): PCG by examples/poisson_test/pcg.c
+        (libref_pcg.so) AND by the module's own pcg.c; MINRES by the module's own minres.c (libref_krylov.so, round 5).
+    A / b / x_pcg / res_pcg / x_ref / res_ref: what the CPU leg already holds for this grid (else they are made here).
+    with_oracle=False, ref_threads > 1: the long leg (k = 20 at 512^3) -- the sequential oracle is skipped and the compiled
+    kernels get row-parallel callbacks so that it stays under a minute."""
     if A is None:
         A = O.poisson_csr(*grid)
     n = A.shape[0]
@@ -158,33 +176,53 @@ def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, w
         b = np.empty(n)
         A.matvec(np.ones(n), b)
     dinv = np.full(n, 1.0 / (6.0 if grid[2] else 4.0))
-    if x_pcg is None:
-        x_pcg = np.zeros(n)
-        res_pcg = O.pcg(A, b, x_pcg, 0.0, k, dinv)
-    x_min = np.zeros(n)
-    res_min = O.minres(A, b, x_min, 0.0, k, dinv)
+    x_min = res_min = None
+    if with_oracle:
+        if x_pcg is None:
+            x_pcg = np.zeros(n)
+            res_pcg = O.pcg(A, b, x_pcg, 0.0, k, dinv)
+        x_min = np.zeros(n)
+        res_min = O.minres(A, b, x_min, 0.0, k, dinv)
     G = dev.DeviceCSR.poisson(*grid)
     K = dev.DeviceJacobi(G)
-    bound = parity_bound(n, k)
-    out = {"grid": list(grid), "n": n, "k": k, "bound": bound}
+    bound, bound_ref = parity_bound(n, k), parity_bound(n, k, "reference")
+    out = {"grid": list(grid), "n": n, "k": k, "bound": bound, "bound_vs_reference": bound_ref}
     ok = True
+    have_refk = with_ref and O.have_ref_krylov()
     for name, solver, ref_res, ref_x in (("pcg", dev.pcg, res_pcg, x_pcg), ("minres", dev.minres, res_min, x_min)):
         xg = np.zeros(n)
         rg = solver(G, b, xg, 0.0, k, K)
-        rec = {"info_iter_gpu": [rg[0], rg[1]], "info_iter_oracle": [ref_res[0], ref_res[1]],
-               "relres_rel_diff": rel_diff(rg[2], ref_res[2]), "x_max_rel_diff": _maxrel(xg, ref_x)}
-        rec["ok"] = bool(rec["info_iter_gpu"] == rec["info_iter_oracle"] and rec["relres_rel_diff"] <= bound
-                         and rec["x_max_rel_diff"] <= bound)
-        if name == "pcg" and with_ref and O.have_ref():
+        rec = {"info_iter_gpu": [rg[0], rg[1]], "ok": True}
+        if with_oracle:
+            rec.update({"info_iter_oracle": [ref_res[0], ref_res[1]], "relres_rel_diff": rel_diff(rg[2], ref_res[2]),
+                        "x_max_rel_diff": _maxrel(xg, ref_x)})
+            rec["ok"] = bool(rec["info_iter_gpu"] == rec["info_iter_oracle"] and rec["relres_rel_diff"] <= bound
+                             and rec["x_max_rel_diff"] <= bound)
+        if name == "pcg" and with_ref and O.have_ref() and (x_ref is not None or ref_threads == 1):
             xr, rr = x_ref, res_ref
             if xr is None:
                 xr = np.zeros(n)
                 rr = O.ref_pcg(A, b, xr, 0.0, k, dinv)
-            rec["vs_reference_pcg"] = {"info_iter_reference": [rr[0], rr[1]], "relres_rel_diff": rel_diff(rg[2], rr[2]),
-                                       "x_max_rel_diff": _maxrel(xg, xr),
-                                       "oracle_vs_reference_x_max_rel_diff": _maxrel(ref_x, xr)}
-            rec["ok"] = bool(rec["ok"] and [rr[0], rr[1]] == rec["info_iter_gpu"]
-                             and rec["vs_reference_pcg"]["x_max_rel_diff"] <= bound)
+            v = {"kernel": "examples/poisson_test/pcg.c", "info_iter_reference": [rr[0], rr[1]],
+                 "relres_rel_diff": rel_diff(rg[2], rr[2]), "x_max_rel_diff": _maxrel(xg, xr)}
+            if with_oracle:
+                v["oracle_vs_reference_x_max_rel_diff"] = _maxrel(ref_x, xr)
+            rec["vs_reference_pcg"] = v
+            rec["ok"] = bool(rec["ok"] and [rr[0], rr[1]] == rec["info_iter_gpu"] and v["x_max_rel_diff"] <= bound_ref
+                             and v["relres_rel_diff"] <= bound_ref)
+            del xr
+        if have_refk:
+            t = time.perf_counter()
+            xr, rr = _ref_solve(O, name, A, b, k, dinv, ref_threads)
+            v = {"kernel": "pysparse/itsolvers/src/%s.c" % name, "info_iter_reference": [rr[0], rr[1]],
+                 "relres_rel_diff": rel_diff(rg[2], rr[2]), "x_max_rel_diff": _maxrel(xg, xr),
+                 "callback_threads": ref_threads, "seconds": time.perf_counter() - t}
+            if with_oracle:
+                v["oracle_vs_reference_x_max_rel_diff"] = _maxrel(ref_x, xr)
+            rec["vs_reference_module_kernel"] = v
+            rec["ok"] = bool(rec["ok"] and [rr[0], rr[1]] == rec["info_iter_gpu"] and v["x_max_rel_diff"] <= bound_ref
+                             and v["relres_rel_diff"] <= bound_ref)
+            del xr
         ok = ok and rec["ok"]
         out[name] = rec
         del xg
@@ -330,9 +368,11 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
                                                            (("C3_poisson3d_%d" % c3_grid[0]) if big else
                                                             "poisson3d_%d" % c3_small[0], c3)) if "gpu_parity" in c}
         parity = {"what": "k iterations (tol = 0) of Jacobi-PCG and Jacobi-MINRES on the GPU against the oracle's iterates "
-                          "of the same system (b = A*ones, x0 = 0), and against the compiled reference pcg.c where "
-                          "oracle/_ref exists: equal (info, iter); relres and max-norm of x within `bound`",
-                  "bound": "32 k sqrt(n) eps, eps = 2^-52 (bench.parity_bound; DESIGN.md section 7)",
+                          "of the same system (b = A*ones, x0 = 0), and against the reference's own compiled kernels "
+                          "(examples/poisson_test/pcg.c, pysparse/itsolvers/src/pcg.c and minres.c) where oracle/_ref "
+                          "exists: equal (info, iter); relres and max-norm of x within `bound`",
+                  "bound": "GPU vs oracle: 32 k sqrt(n) eps; GPU vs the compiled reference (pcg.c, minres.c): 4 k sqrt(n) eps; "
+                           "eps = 2^-52 (bench.parity_bound; DESIGN.md section 7)",
                   "cases": cases, "ok": bool(cases) and all(c["ok"] for c in cases.values())}
     return base, ref, parity
 

@@ -71,10 +71,34 @@ int psp_thread_info(int *thread_slot, int *device, void **hip_stream);
 /* test hook of the locking discipline (tests/test_threading_cpu.py): takes the locks of the two handles exactly as an
  * entry point that is handed them does (address order, recursive), holds them for `milliseconds`, releases them */
 int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds);
+/* test hooks of the multi-stream ordering (tests/test_gpu_shake.py; only in a process started with PSP_TUNING=1, else
+ * PSP_EINVAL).  psp_debug_shake arms delay injection: at every cut point of the multi-device driver whose bit is set in
+ * point_mask (psp_internal.h ShakePoint), for every rank whose bit is set in rank_mask, a one-wave spin kernel of
+ * min_us..max_us microseconds (pseudo-random from `seed`; a fixed delay when min_us == max_us) is enqueued on the stream
+ * that cut point names, so that stream's later work moves against every other stream.  revert_mask takes a known fix
+ * out again (bit 0: the copy stream's wait for the receiver's own stream, round 4) -- the test that the facility
+ * finds what it is there to find.  seed < 0 disarms.  psp_debug_shake_count: spin kernels injected since it was armed.
+ * psp_debug_spin: one spin kernel on the calling thread's stream (the torch driver's cut points, distributed.py). */
+int psp_debug_shake(long long seed, int min_us, int max_us, unsigned point_mask, unsigned rank_mask, int revert_mask);
+int psp_debug_shake_count(long long *injected);
+int psp_debug_spin(int microseconds);
 /* *can_access = 1 when `device` can read / write `peer`'s memory directly (xGMI or PCIe peer path; what the
  * halo copies of a multi-device matrix need), 1 for device == peer.  Creates no context: bench.py's pre-flight
  * matrix of an N-GPU run */
 int psp_peer_access(int device, int peer, int *can_access);
+/* Placement of library-owned vectors (round 5; pysparse_amd/csrc/psp_place.hip).  What a
+ * bandwidth-bound product takes depends on which pages of HBM its vector operands occupy (two levels ~8 % apart at
+ * 512^3); for the vectors the LIBRARY allocates -- the solvers' work vectors (the reference's solvers own their work
+ * array too: pysparse/itsolvers/src/itsolversmodule.c:32-118) and the staging pair of the host-pointer products -- it
+ * draws a few candidates once per (device, length), times the handle's own product on each and keeps the best.  Results
+ * do not change by a bit.  psp_set_placement(0) turns the draws off (1: on, the default).  psp_placement_info: draws made
+ * so far and the milliseconds they took.  psp_place_operands hands the same service to a caller that owns its vectors:
+ * *y_dev / *x_dev receive zeroed device vectors (nrows / ncols doubles, release with psp_free) chosen for the output /
+ * input role of y = A x; report6 (may be NULL): candidates drawn (0: plain allocations -- vectors under 64 MiB, or memory
+ * short), best and worst output-role ms, best and worst input-role ms, ms the draw took. */
+int psp_set_placement(int on);
+int psp_placement_info(int *enabled, long long *draws, double *draw_ms_total);
+int psp_place_operands(const psp_csr_t *A, double **y_dev, double **x_dev, double *report6);
 /* the calling thread enqueues on an externally owned hipStream_t (e.g. torch's current stream); NULL = null stream */
 int psp_set_stream(void *hip_stream);
 int psp_synchronize(void);

@@ -439,6 +439,14 @@ class _SssCtx(C.Structure):  # orc_sss_t
     _fields_ = [("n", C.c_int), ("va", C.c_void_p), ("da", C.c_void_p), ("ja", C.c_void_p), ("ia", C.c_void_p)]
 
 
+class _CsrMtCtx(C.Structure):  # orc_csr_mt_t
+    _fields_ = [("A", _CsrCtx), ("nthreads", C.c_int)]
+
+
+class _JacobiMtCtx(C.Structure):  # orc_jacobi_mt_t
+    _fields_ = [("n", C.c_int), ("dinv", C.c_void_p), ("nthreads", C.c_int)]
+
+
 class _JacobiCtx(C.Structure):  # orc_jacobi_t
     _fields_ = [("n", C.c_int), ("dinv", C.c_void_p), ("steps", C.c_int), ("temp", C.c_void_p),
                 ("matvec", C.c_void_p), ("mctx", C.c_void_p)]
@@ -470,17 +478,20 @@ def ref_krylov_lib():
     return _refk
 
 
-def _operator_ctx(A):
-    """(callback address, context struct, keep-alive list) of the oracle's matvec for A."""
+def _operator_ctx(A, threads=1):
+    """(callback address, context struct, keep-alive list) of the oracle's matvec for A.  threads > 1 (CSR only): the
+    row-parallel callback -- the same bits per row; the kernel that calls it stays what it is"""
     L = lib()
     if isinstance(A, CSR):
         ctx = _CsrCtx(A.shape[0], A.shape[1], A.val.ctypes.data, A.col.ctypes.data, A.ind.ctypes.data)
+        if threads > 1:
+            return C.cast(L.orc_csr_matvec_threads_cb, C.c_void_p), _CsrMtCtx(ctx, int(threads))
         return C.cast(L.orc_csr_matvec_cb, C.c_void_p), ctx
     ctx = _SssCtx(A.n, A.val.ctypes.data, A.diag.ctypes.data, A.col.ctypes.data, A.ind.ctypes.data)
     return C.cast(L.orc_sss_matvec_cb, C.c_void_p), ctx
 
 
-def _precon_ctx(A, K, mv, mctx):
+def _precon_ctx(A, K, mv, mctx, threads=1):
     """(callback address, context struct, keep-alive list) for K = None | ("jacobi", dinv[, steps]) |
     ("ssor", omega, steps) -- the oracle's restatements of preconmodule.c"""
     L = lib()
@@ -490,6 +501,8 @@ def _precon_ctx(A, K, mv, mctx):
     if K[0] == "jacobi":
         dinv = np.ascontiguousarray(K[1], dtype=np.float64)
         steps = K[2] if len(K) > 2 else 1
+        if threads > 1 and steps == 1:
+            return C.cast(L.orc_jacobi_threads_cb, C.c_void_p), _JacobiMtCtx(n, dinv.ctypes.data, int(threads)), [dinv]
         temp = np.zeros(max(n, 1))
         ctx = _JacobiCtx(n, dinv.ctypes.data, steps, temp.ctypes.data, mv, C.addressof(mctx))
         return C.cast(L.orc_jacobi_apply, C.c_void_p), ctx, [dinv, temp]
@@ -502,10 +515,10 @@ def _precon_ctx(A, K, mv, mctx):
     raise ValueError(K[0])
 
 
-def _solve_cb(fn, has_fail, solver, A, b, x, tol, maxit, K, dim, fails=()):
+def _solve_cb(fn, has_fail, solver, A, b, x, tol, maxit, K, dim, fails=(), threads=1):
     n = A.shape[0]
-    mv, mctx = _operator_ctx(A)
-    pc, pctx, keep = _precon_ctx(A, K, mv, mctx)
+    mv, mctx = _operator_ctx(A, threads)
+    pc, pctx, keep = _precon_ctx(A, K, mv, mctx, threads)
     it, info, rr = C.c_int(0), C.c_int(0), C.c_double(np.nan)
     work = np.zeros(8 * max(n, 1))
     bb = np.ascontiguousarray(b, dtype=np.float64).copy()  # the reference kernels take a non-const b
@@ -516,14 +529,16 @@ def _solve_cb(fn, has_fail, solver, A, b, x, tol, maxit, K, dim, fails=()):
     return info.value, it.value, rr.value, rc
 
 
-def ref_krylov(solver, A, b, x, tol, maxit, K=None, dim=20, mv_fail_after=-1, pc_fail_after=-1):
+def ref_krylov(solver, A, b, x, tol, maxit, K=None, dim=20, mv_fail_after=-1, pc_fail_after=-1, threads=1):
     """info, iter, relres, rc = the COMPILED REFERENCE kernel `solver` (module sources, unmodified) on
     operator A (CSR or SSS; the matvec is the oracle's restatement -- csr_mat.c / sss_mat.c do not
     compile here) with K = None, ("jacobi", dinv[, steps]) or ("ssor", omega, steps) on an SSS matrix.
     relres comes back NaN when the kernel never wrote it (minres on -3 / -6; minres.c:79-80,158-159).
-    rc is the kernel's own return value (-1 also means "a callback raised", e.g. pcg.c:8-11)."""
+    rc is the kernel's own return value (-1 also means "a callback raised", e.g. pcg.c:8-11).
+    threads > 1 (CSR, K = None or jacobi with one step): the operator / preconditioner callbacks are row-parallel (same
+    bits per row and element); the kernel -- the reference's compiled code -- is unchanged."""
     return _solve_cb(ref_krylov_lib().refk_solve, True, solver, A, b, x, tol, maxit, K, dim,
-                     (mv_fail_after, pc_fail_after))
+                     (mv_fail_after, pc_fail_after), threads)
 
 
 def solve(solver, A, b, x, tol, maxit, K=None, dim=20):

@@ -282,6 +282,68 @@ ORC_API int orc_sss_matvec_cb(void *ctx, int n, const double *x, double *y) {
   return 0;
 }
 
+/* NOT the reference either: the same callback protocol with the rows handed to POSIX threads (orc_csr_matvec_threads:
+ * every y[i] keeps the bits of orc_csr_matvec).  It exists so that the reference's COMPILED kernels (oracle/_ref) can be
+ * driven through 20 iterations at BASELINE's 512^3 inside a test's time budget (tests/test_gpu_reference_sizes.py): the
+ * kernel is the reference's own code, only its operator callback is row-parallel. */
+typedef struct {
+  orc_csr_t A;
+  int nthreads;
+} orc_csr_mt_t;
+
+ORC_API int orc_csr_matvec_threads_cb(void *ctx, int n, const double *x, double *y) {
+  const orc_csr_mt_t *M = (const orc_csr_mt_t *)ctx;
+  (void)n;
+  orc_csr_matvec_threads(M->A.m, x, y, M->A.va, M->A.ja, M->A.ia, M->nthreads);
+  return 0;
+}
+
+/* y = x .* dinv (preconmodule.c:41-42, jacobi with steps == 1) over thread ranges: elementwise, the same bits */
+typedef struct {
+  int n;
+  const double *dinv;
+  int nthreads;
+} orc_jacobi_mt_t;
+
+typedef struct {
+  int r0, r1;
+  const double *x, *dinv;
+  double *y;
+} orc_jac_range;
+
+static void *orc_jacobi_range(void *arg) {
+  const orc_jac_range *q = (const orc_jac_range *)arg;
+  int i;
+  for (i = q->r0; i < q->r1; i++)
+    q->y[i] = q->x[i] * q->dinv[i];
+  return NULL;
+}
+
+ORC_API int orc_jacobi_threads_cb(void *ctx, int n, const double *x, double *y) {
+  enum { MAXT = 256 };
+  const orc_jacobi_mt_t *K = (const orc_jacobi_mt_t *)ctx;
+  pthread_t th[MAXT];
+  orc_jac_range rg[MAXT];
+  int started[MAXT];
+  int t, nt = K->nthreads;
+  if (nt < 1) nt = 1;
+  if (nt > MAXT) nt = MAXT;
+  if (nt > n) nt = n > 0 ? n : 1;
+  for (t = 0; t < nt; t++) {
+    rg[t].r0 = (int)((long)n * t / nt);
+    rg[t].r1 = (int)((long)n * (t + 1) / nt);
+    rg[t].x = x; rg[t].dinv = K->dinv; rg[t].y = y;
+  }
+  for (t = 1; t < nt; t++) {
+    started[t] = pthread_create(&th[t], NULL, orc_jacobi_range, &rg[t]) == 0;
+    if (!started[t]) orc_jacobi_range(&rg[t]);
+  }
+  orc_jacobi_range(&rg[0]);
+  for (t = 1; t < nt; t++)
+    if (started[t]) pthread_join(th[t], NULL);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ Jacobi */
 
 /* pysparse/precon/src/preconmodule.c:389-401: dinv[i] = omega / A[i,i]; a diagonal

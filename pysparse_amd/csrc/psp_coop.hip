@@ -65,10 +65,11 @@ __device__ __forceinline__ double coh_load(const double *p) {
 // Publishing: every wave drains its own vector-memory counter before the workgroup barrier that precedes the arrival.
 // A workgroup-scope release fence does NOT do that on gfx9 (non-tgsplit mode): it emits no s_waitcnt vmcnt, so the sc1
 // stores of the other waves could still be in flight when a remote workgroup passes the barrier and sc1-loads them.
-// Waiting: bounded by the 100 MHz wall clock (kCoopSpinTicks = 20 ms), not by a poll count -- a barrier among
+// Waiting: bounded by the 100 MHz wall clock (kCoopSpinTicks), not by a poll count -- a barrier among
 // co-resident workgroups completes in microseconds; one that cannot complete (a workgroup that is not resident) ends
 // every workgroup through the error word and the host falls back to the launch-per-phase loop from the saved vectors.
-constexpr long long kCoopSpinTicks = 2000000;  // s_memrealtime ticks (100 MHz): 20 ms
+constexpr long long kCoopSpinTicks = 50000000;  // s_memrealtime ticks (100 MHz): 0.5 s (20 ms until round 5: a GPU that is
+                                                // time-sliced between processes can hold a resident workgroup back longer)
 __device__ __forceinline__ bool coop_barrier(CoopCtl *c, int nwg, unsigned &gen) {
   if (nwg == 1) {
     __syncthreads();
@@ -175,9 +176,10 @@ struct OwnedRow {
 __global__ __launch_bounds__(kCoopBlock) void pcg_coop_kernel(int n, int nwg, const int *__restrict__ ind,
                                                               const int *__restrict__ col,
                                                               const double *__restrict__ val,
-                                                              const double *__restrict__ dinv, double *x, double *r,
-                                                              double n2b, double tolb, double normr0, double rho0,
-                                                              int maxit, CoopCtl *ctl, double *part, double *hist) {
+                                                              const double *__restrict__ dinv, const double *x,
+                                                              double *xout, double *r, double n2b, double tolb,
+                                                              double normr0, double rho0, int maxit, CoopCtl *ctl,
+                                                              double *part, double *hist) {
   __shared__ double sh[3 * kCoopMaxWg + 8];
   const int wg = blockIdx.x;
   OwnedRow a;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(kCoopBlock) void pcg_coop_kernel(int n, int nwg, co
       if (k < a.cnt) rc[k] = nwg > 1 ? coh_load(r + a.col[k]) : r[a.col[k]];
     if (nwg == 1) __syncthreads();  // nobody overwrites r before every thread has gathered
   }
-  if (in) x[a.row] = xr;
+  if (in) xout[a.row] = xr;  // a staging vector: the host copies it over x only when NO workgroup gave up at a barrier
   if (wg == 0 && threadIdx.x == 0) {
     ctl->info = flag;
     ctl->iter = it;  // maxit + 1 when the loop ran out (pcg.c:165)
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(kCoopBlock) void pcg_coop_kernel(int n, int nwg, co
 __global__ __launch_bounds__(kCoopBlock) void minres_coop_kernel(int n, int nwg, const int *__restrict__ ind,
                                                                  const int *__restrict__ col,
                                                                  const double *__restrict__ val,
-                                                                 const double *__restrict__ dinv, double *x,
-                                                                 const double *v_hat, double *yv, double norm_r0,
+                                                                 const double *__restrict__ dinv, const double *x,
+                                                                 double *xout, const double *v_hat, double *yv, double norm_r0,
                                                                  double beta0, double errtol, int it_max, CoopCtl *ctl,
                                                                  double *part, double *hist) {
   __shared__ double sh[kCoopMaxWg + 8];
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kCoopBlock) void minres_coop_kernel(int n, int nwg,
     norm_rmr *= fabs(s);  // :192
     if (hist && wg == 0 && threadIdx.x == 0) hist[it] = norm_rmr;
   }
-  if (in) x[a.row] = xr;
+  if (in) xout[a.row] = xr;  // staging, as in pcg_coop_kernel
   if (wg == 0 && threadIdx.x == 0) {
     ctl->iter = it;
     if (info == 1) {
@@ -485,25 +487,28 @@ bool coop_applicable(const psp_csr *A, int n) {
          coop_grid(n) <= std::min(kCoopMaxWg, coop_capacity());
 }
 
-// On kCoopFallback x and r are what they were on entry (x is only written by a kernel that finished; r is restored from
-// the copy kept in q, which the single-kernel loop does not use) and the caller continues with its other loops.
+// On kCoopFallback x and r are what they were on entry and the caller continues with its other loops: the kernel leaves
+// its x in a staging vector (p, which the single-kernel loop does not use otherwise) that is copied over x only after a
+// launch in which no workgroup gave up -- a time-out that strikes in the last iteration lets some workgroups store and
+// others not (round-4 advisor finding) -- and r is restored from the copy kept in q.
 int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                   double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres,
                   double *hist) {
   CoopMem m;
   PSP_TRY(m.init(maxit, hist != nullptr));
   int nwg = coop_grid(n);
-  (void)p;
   PSP_HIP(hipMemcpyAsync(q, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   const int *ind = A->ind, *col = A->col;
   const double *val = A->val;
-  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &x, &r, &n2b, &tolb, &normr0, &rho0, &maxit, &m.ctl, &m.part, &m.hist};
+  const double *xin = x;
+  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &xin, &p, &r, &n2b, &tolb, &normr0, &rho0, &maxit, &m.ctl, &m.part, &m.hist};
   int rc = coop_force_fail() ? kCoopFallback : coop_launch((const void *)pcg_coop_kernel, nwg, args);
   CoopCtl c;
   if (rc == PSP_OK) rc = m.fetch(&c);
   if (rc == kCoopFallback)
     PSP_HIP(hipMemcpyAsync(r, q, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   if (rc != PSP_OK) return rc;
+  PSP_HIP(hipMemcpyAsync(x, p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   *info = c.info;
   *iter = c.iter;
   *relres = c.relres;
@@ -519,7 +524,8 @@ int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double
   return PSP_OK;
 }
 
-// On kCoopFallback x, v_hat and y are what they were on entry (y is restored from the copy kept in av).
+// On kCoopFallback x, v_hat and y are what they were on entry (x: staged in w, as in pcg_coop_loop; y is restored from the
+// copy kept in av).
 int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old,
                      double *y, double *w, double *w_old, double *v, double *av, double norm_r0, double beta0,
                      double errtol, int it_max, int *info, int *iter, double *relres, double *hist) {
@@ -527,7 +533,6 @@ int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, dou
   PSP_TRY(m.init(it_max, hist != nullptr));
   int nwg = coop_grid(n);
   (void)v_hat_old;
-  (void)w;
   (void)w_old;
   double *yv = y;  // the vector that crosses workgroups: K v_hat, or v_hat itself without a preconditioner
   if (!dinv) {
@@ -538,14 +543,17 @@ int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, dou
   }
   const int *ind = A->ind, *col = A->col;
   const double *val = A->val;
-  const double *vh = v_hat;
-  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &x, &vh, &yv, &norm_r0, &beta0, &errtol, &it_max, &m.ctl, &m.part, &m.hist};
+  const double *vh = v_hat, *xin = x;
+  void *args[] = {&n, &nwg, &ind, &col, &val, &dinv, &xin, &w, &vh, &yv, &norm_r0, &beta0, &errtol, &it_max, &m.ctl, &m.part, &m.hist};
   int rc = coop_force_fail() ? kCoopFallback : coop_launch((const void *)minres_coop_kernel, nwg, args);
   CoopCtl c;
   if (rc == PSP_OK) rc = m.fetch(&c);
-  if (rc == kCoopFallback && dinv)
-    PSP_HIP(hipMemcpyAsync(y, av, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  if (rc == kCoopFallback) {
+    if (dinv) PSP_HIP(hipMemcpyAsync(y, av, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+    PSP_HIP(hipMemsetAsync(w, 0, sizeof(double) * (size_t)n, stream()));  // the staging vector is the caller's w = 0 again
+  }
   if (rc != PSP_OK) return rc;
+  PSP_HIP(hipMemcpyAsync(x, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   *info = c.info;
   *iter = c.iter;
   if (c.info == 0 || c.info == -1) *relres = c.relres;

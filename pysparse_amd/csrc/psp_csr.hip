@@ -4084,21 +4084,22 @@ int host_matvec_pipelined(psp_csr *A, const double *xh, double *yh, double *xd, 
 }  // namespace
 
 namespace psp {
-int host_stage(size_t nx, size_t ny, double **x, double **y) {
+int host_stage(const psp_csr *A, size_t nx, size_t ny, double **x, double **y) {
   const int device = current_device();
   if (g_stage.device != device || g_stage.nx < nx || g_stage.ny < ny) {
     host_stage_trim();
-    hipError_t e = hipMalloc((void **)&g_stage.x, sizeof(double) * (nx ? nx : 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&g_stage.y, sizeof(double) * (ny ? ny : 1));
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
+    // the pair is the library's: where the product is HBM-bound its two vectors are drawn for their roles
+    // (psp_place.hip) -- once per thread and size, the pair is kept between calls
+    int rc = place_operands(A, nx, ny, 1, &g_stage.y, &g_stage.x, nullptr);
+    if (rc == PSP_ENOMEM) {
       host_stage_trim();
       (void)psp_trim();
-      PSP_HIP(hipMalloc((void **)&g_stage.x, sizeof(double) * (nx ? nx : 1)));
-      PSP_HIP(hipMalloc((void **)&g_stage.y, sizeof(double) * (ny ? ny : 1)));
+      rc = place_operands(A, nx, ny, 1, &g_stage.y, &g_stage.x, nullptr);
     }
-    g_stage.nx = nx;
-    g_stage.ny = ny;
+    PSP_TRY(rc);
+    // (place_operands sizes both vectors for max(nx, ny))
+    g_stage.nx = std::max(nx, ny);
+    g_stage.ny = std::max(nx, ny);
     g_stage.device = device;
   }
   *x = g_stage.x;
@@ -4537,7 +4538,7 @@ int psp_csr_matvec_stride(psp_csr_t *A, const double *x_host, ptrdiff_t incx, do
   // device staging for the caller's host vectors: kept between calls (hipMalloc + hipFree of two GB-sized vectors cost
   // milliseconds per product); psp_trim() releases it
   double *xd, *yd;
-  PSP_TRY(psp::host_stage(A->ncols, A->nrows, &xd, &yd));
+  PSP_TRY(psp::host_stage(A, A->ncols, A->nrows, &xd, &yd));
   if (incx == 1 && incy == 1) {
     bool done = false;
     PSP_TRY(host_matvec_pipelined(A, x_host, y_host, xd, yd, &done));

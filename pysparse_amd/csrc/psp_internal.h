@@ -33,7 +33,24 @@ const char *tuning_env(const char *name);
 //     while those are held, so callers must not hold the GIL while they wait (ctypes and the extension modules
 //     release it first).
 //   * Entry points without a handle (the psp_k_* vector kernels, memory, events) lock nothing.
-std::recursive_mutex &handle_mutex(const void *handle);
+//   * Device-side order between threads (round 5).  The locks only serialise the HOST side of two calls on one handle;
+//     the asynchronous *_dev entry points return with their kernels still in flight, and the next caller may enqueue on
+//     another stream -- on the same scratch.  So every handle also carries a "last use" event: once a second stream has
+//     been seen anywhere in the process (a second thread, or psp_set_stream to another stream; the one-stream process
+//     pays nothing), an entry point records the event on its stream before it releases the handle, and the next entry
+//     point on that handle makes its stream wait for it when the streams differ.  At the moment the second stream
+//     appears the devices used so far are synchronised once, which covers everything enqueued before events were kept.
+struct HandleEntry {
+  std::recursive_mutex mu;
+  hipEvent_t ev = nullptr;      // recorded behind the last call's work ...
+  hipStream_t last = nullptr;   // ... on this stream
+  int ev_dev = -1;
+  bool has_last = false;
+};
+HandleEntry &handle_entry(const void *handle);
+inline std::recursive_mutex &handle_mutex(const void *handle) { return handle_entry(handle).mu; }
+void handles_enter(HandleEntry *const *e, int n);  // the calling thread's stream waits for the handles' last users
+void handles_leave(HandleEntry *const *e, int n);  // ... and is recorded as their last user
 class HandleLock {
  public:
   HandleLock() {}
@@ -42,7 +59,8 @@ class HandleLock {
     lock();
   }
   ~HandleLock() {
-    for (int i = n_ - 1; i >= 0; --i) mu_[i]->unlock();
+    if (n_ > 0 && locked_) handles_leave(e_, n_);
+    for (int i = (locked_ ? n_ : 0) - 1; i >= 0; --i) e_[i]->mu.unlock();
   }
   HandleLock(const HandleLock &) = delete;
   HandleLock &operator=(const HandleLock &) = delete;
@@ -60,21 +78,49 @@ class HandleLock {
         h_[j - 1] = t;
       }
     for (int i = 0; i < n_; ++i) {
-      mu_[i] = &handle_mutex(h_[i]);
-      mu_[i]->lock();
+      e_[i] = &handle_entry(h_[i]);
+      e_[i]->mu.lock();
     }
+    locked_ = true;
+    if (n_ > 0) handles_enter(e_, n_);
   }
 
  private:
   static constexpr int kMax = 8;
   const void *h_[kMax];
-  std::recursive_mutex *mu_[kMax];
+  HandleEntry *e_[kMax];
   int n_ = 0;
+  bool locked_ = false;
 };
 #define PSP_API_GUARD psp::HandleLock psp_api_guard_
 #define PSP_API_GUARD_H(...) psp::HandleLock psp_api_guard_({__VA_ARGS__})
 hipStream_t stream();
 hipStream_t swap_stream(hipStream_t s);  // returns the previous stream (graph capture needs a non-null one)
+// Delay injection (round 5; psp_runtime.hip "shake").  The multi-device drivers order their streams by events only; an
+// ordering edge that is missing shows as a wrong vector only when the timing happens to open the window (round 4 found
+// one such race once in ~15 suite runs).  Under PSP_TUNING=1 a test arms the facility (psp_debug_shake or
+// PSP_SHAKE="seed,min_us,max_us,points,ranks,revert"); every cut point of psp_multi.hip then enqueues a one-wave spin
+// kernel of a pseudo-random duration on the stream it names, which moves that stream's later work against all others.
+// Not armed (always, without PSP_TUNING=1): shake() is one relaxed load and a return.
+enum ShakePoint {
+  kShakePack = 0,        // sender's compute stream, before "vector final" (evP) is recorded
+  kShakeCopyPre = 1,     // receiver's copy stream, before it waits for anybody
+  kShakeCopyPost = 2,    // receiver's copy stream, after the ghost copies, before evH is recorded
+  kShakePosted = 3,      // compute stream, after the exchange was posted (in front of the interior rows)
+  kShakeBoundary = 4,    // compute stream, in front of the wait for the ghost copies (boundary rows)
+  kShakeReducePre = 5,   // a rank's stream in front of an all-reduce
+  kShakeReduceMid = 6,   // rank 0's stream between the fold kernel and evB
+  kShakeReducePost = 7,  // a rank's stream behind an all-reduce
+  kShakeClear = 8,       // compute stream, in front of the clearing of a fresh vector
+  kShakeOverwrite = 9,   // compute stream, in front of a kernel that overwrites what readers copy from
+  kShakeScatter = 10,    // compute stream, in front of a host -> device slice copy
+  kShakePoints = 11
+};
+// reverting switches (bits of `revert`): test that the facility FINDS a known race when its fix is taken out
+constexpr int kShakeRevertGhostWait = 1;  // round 4: the copy stream's wait for the receiver's own evP (psp_multi.hip exchange)
+int shake(hipStream_t s, int point, int rank);  // the stream's device must be current
+bool shake_armed();
+bool shake_revert(int bit);
 int ensure_device();  // PSP_OK, or PSP_ENODEV (with message) when no GPU is usable
 // PSP_DEVICE=cpu (read once): the opt-in host mode of psp_cpu.hip -- never a fallback, see that file
 bool cpu_mode();
@@ -83,6 +129,13 @@ bool cpu_mode();
 // another.  ws_slot selects the reduction workspace (0 = the thread's ordinary one): ranks of a multi-device matrix that
 // share a device enqueue on different streams and so must not share partial-sum buffers
 int use_device(int device, hipStream_t s, int ws_slot = 0);
+struct ThreadCtxSave {
+  int device, dev_state, ws_slot;
+  hipStream_t stream;
+  bool stream_given;
+};
+ThreadCtxSave save_thread_ctx();
+void restore_thread_ctx(const ThreadCtxSave &c);
 int current_device();
 int current_ws_slot();
 int current_thread_slot();  // 0 for the first thread that used the library, small integers (reused) for the others
@@ -440,8 +493,12 @@ int pcg(const psp_op *A, const psp_op *K, int n, double *x, const double *b, dou
 int minres(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol, int maxit, int *info,
            int *iter, double *relres, double *hist);
 }  // namespace cpu
+// psp_place.hip: placement of the vectors the library owns (solver work vectors, host-pointer staging)
+bool placement_enabled();
+bool placement_applies(const psp_csr *A, size_t n);
+int place_operands(const psp_csr *A, size_t nx, size_t ny, int want_x, double **y_out, double **x_out, double *report);
 // psp_csr.hip: device staging of the host-pointer products (kept between calls, released by psp_trim)
-int host_stage(size_t nx, size_t ny, double **x, double **y);
+int host_stage(const psp_csr *A, size_t nx, size_t ny, double **x, double **y);
 void host_stage_trim();
 // psp_multi.hip: row-partitioned operators on a list of devices, one process
 int multi_destroy(psp_mcsr *M);

@@ -50,7 +50,7 @@ struct Link {              // one neighbour this rank RECEIVES from
 };
 
 struct RankOp {
-  int dev = 0;
+  int dev = 0, rank = 0;
   hipStream_t s = nullptr, c = nullptr;
   hipEvent_t evP = nullptr, evH = nullptr, evA = nullptr;
   psp_csr *A = nullptr;
@@ -140,21 +140,32 @@ namespace {
 int use(const psp_mcsr *M, int r) { return psp::use_device(M->r[r].dev, M->r[r].s, r + 1); }
 
 struct DeviceRestore {  // the caller's device / stream / workspace come back when a multi entry point returns
-  int dev, slot;
-  hipStream_t s;
-  DeviceRestore() : dev(psp::current_device()), slot(psp::current_ws_slot()), s(psp::stream()) {}
-  ~DeviceRestore() { (void)psp::use_device(dev, s, slot); }
+  psp::ThreadCtxSave saved;
+  DeviceRestore() : saved(psp::save_thread_ctx()) {}
+  ~DeviceRestore() { psp::restore_thread_ctx(saved); }
 };
 
 int wait_halo(void *ctx) {  // psp_wait_fn of the overlapped SpMV: the boundary rows wait for the ghost copies in stream order
   RankOp *R = (RankOp *)ctx;
+  if (psp::shake(R->s, psp::kShakeBoundary, R->rank) != PSP_OK) return 1;
   return hipStreamWaitEvent(R->s, R->evH, 0) == hipSuccess ? 0 : 1;
+}
+
+// delay injection on every rank's compute stream (a kernel is launched with its stream's device current)
+int shake_ranks(psp_mcsr *M, int point) {
+  if (!psp::shake_armed()) return PSP_OK;
+  for (int r = 0; r < M->nranks; ++r) {
+    M_HIP(hipSetDevice(M->r[r].dev));
+    PSP_TRY(psp::shake(M->r[r].s, point, r));
+  }
+  return PSP_OK;
 }
 
 // before rank q overwrites a vector its readers copy from (or repacks its send buffers): their last copies must be done
 int guard_overwrite(psp_mcsr *M, int q) {
   RankOp &Q = M->r[q];
   for (int t : Q.readers) M_HIP(hipStreamWaitEvent(Q.s, M->r[t].evH, 0));
+  PSP_TRY(psp::shake(Q.s, psp::kShakeOverwrite, q));
   return PSP_OK;
 }
 
@@ -168,6 +179,7 @@ int exchange(psp_mcsr *M, double *const *vext) {
     for (int t : Q.readers)
       for (Link &L : M->r[t].links)
         if (L.q == q && L.send_idx) PSP_TRY(psp_k_gather(L.count, L.send_idx, vext[q] + Q.ghost_lo, L.send_buf));
+    PSP_TRY(psp::shake(Q.s, psp::kShakePack, q));
     M_HIP(hipEventRecord(Q.evP, Q.s));
   }
   for (int t = 0; t < M->nranks; ++t) {
@@ -177,7 +189,11 @@ int exchange(psp_mcsr *M, double *const *vext) {
     // vector, the previous product's reads) must be over before a halo lands there -- the copy stream is ordered against
     // the SENDER by evP below, and nothing else ordered it against the receiver (round 4: a 3-rank product came back
     // with a ghost zone zeroed after the halo had arrived)
-    if (!T.links.empty()) M_HIP(hipStreamWaitEvent(T.c, T.evP, 0));
+    // (ordering edges of the whole driver: DESIGN.md section 5; psp::shake moves the streams against each other at
+    // every one of them, tests/test_gpu_shake.py; kShakeRevertGhostWait takes this wait out again to show that the
+    // stress finds the race it was added for)
+    PSP_TRY(psp::shake(T.c, psp::kShakeCopyPre, t));
+    if (!T.links.empty() && !psp::shake_revert(psp::kShakeRevertGhostWait)) M_HIP(hipStreamWaitEvent(T.c, T.evP, 0));
     for (Link &L : T.links) {
       RankOp &Q = M->r[L.q];
       M_HIP(hipStreamWaitEvent(T.c, Q.evP, 0));
@@ -189,7 +205,9 @@ int exchange(psp_mcsr *M, double *const *vext) {
       else
         M_HIP(hipMemcpyPeerAsync(dst, T.dev, src, Q.dev, bytes, T.c));
     }
+    PSP_TRY(psp::shake(T.c, psp::kShakeCopyPost, t));
     M_HIP(hipEventRecord(T.evH, T.c));
+    PSP_TRY(psp::shake(T.s, psp::kShakePosted, t));
   }
   return PSP_OK;
 }
@@ -197,6 +215,7 @@ int exchange(psp_mcsr *M, double *const *vext) {
 // sum of scal[off .. off+cnt) over the ranks, left on every rank, in stream order
 int allreduce(psp_mcsr *M, int off, int cnt) {
   if (M->nranks == 1) return PSP_OK;
+  PSP_TRY(shake_ranks(M, psp::kShakeReducePre));
   if (M->use_rccl) {
     Rccl *R = rccl();
     ncclResult_t e = R->GroupStart();
@@ -206,7 +225,7 @@ int allreduce(psp_mcsr *M, int off, int cnt) {
     if (e == ncclSuccess) e = e2;
     if (e != ncclSuccess)
       return fail(PSP_ENODEV, "RCCL all-reduce failed: %s", R->GetErrorString ? R->GetErrorString(e) : "?");
-    return PSP_OK;
+    return shake_ranks(M, psp::kShakeReducePost);
   }
   for (int r = 1; r < M->nranks; ++r) {
     M_HIP(hipSetDevice(M->r[r].dev));
@@ -216,12 +235,13 @@ int allreduce(psp_mcsr *M, int off, int cnt) {
   for (int r = 1; r < M->nranks; ++r) M_HIP(hipStreamWaitEvent(M->r[0].s, M->r[r].evA, 0));
   hipLaunchKernelGGL(multi_fold_kernel, dim3(1), dim3(64), 0, M->r[0].s, M->scal_ptrs, M->nranks, off, cnt);
   PSP_LAUNCH_CHECK();
+  PSP_TRY(psp::shake(M->r[0].s, psp::kShakeReduceMid, 0));  // (rank 0's device is current: use(M, 0) above)
   M_HIP(hipEventRecord(M->evB, M->r[0].s));
   for (int r = 1; r < M->nranks; ++r) {
     M_HIP(hipSetDevice(M->r[r].dev));
     M_HIP(hipStreamWaitEvent(M->r[r].s, M->evB, 0));
   }
-  return PSP_OK;
+  return shake_ranks(M, psp::kShakeReducePost);
 }
 
 int fetch0(psp_mcsr *M, int off, int cnt, double *host) {  // rank 0's copy of reduced scalars (synchronises its stream)
@@ -255,7 +275,10 @@ struct Vecs {
       M_HIP(hipMalloc((void **)&p, sizeof(double) * (n ? n : 1)));
     }
     all.push_back(p);
-    if (zero) M_HIP(hipMemsetAsync(p, 0, sizeof(double) * (n ? n : 1), M->r[r].s));
+    if (zero) {
+      PSP_TRY(psp::shake(M->r[r].s, psp::kShakeClear, r));
+      M_HIP(hipMemsetAsync(p, 0, sizeof(double) * (n ? n : 1), M->r[r].s));
+    }
     *out = p;
     return PSP_OK;
   }
@@ -272,6 +295,7 @@ int scatter_host(psp_mcsr *M, const double *host, ptrdiff_t inc, std::vector<dou
       for (int i = 0; i < R.n; ++i) pack[i] = src[(ptrdiff_t)i * inc];
       src = pack.data();
     }
+    PSP_TRY(psp::shake(R.s, psp::kShakeScatter, r));
     M_HIP(hipMemcpyAsync(dst[r] + (dst_off_is_ghost ? R.ghost_lo : 0), src, sizeof(double) * (size_t)R.n,
                          hipMemcpyHostToDevice, R.s));
     if (inc != 1) M_HIP(hipStreamSynchronize(R.s));  // pack is reused
@@ -375,6 +399,7 @@ int new_ranks(psp_mcsr *M, const int *devices, int ndev) {
     if (devices[r] < 0 || devices[r] >= cnt) return fail(PSP_EINVAL, "device %d out of range (0..%d)", devices[r], cnt - 1);
     RankOp &R = M->r[r];
     R.dev = devices[r];
+    R.rank = r;
     M_HIP(hipSetDevice(R.dev));
     M_HIP(hipStreamCreateWithFlags(&R.s, hipStreamNonBlocking));
     M_HIP(hipStreamCreateWithFlags(&R.c, hipStreamNonBlocking));
@@ -997,6 +1022,50 @@ int psp_csr_create_multi(int nrows, int ncols, int nnz, const int *ind, const in
   return PSP_OK;
 }
 
+namespace {
+// a start / stop event per rank for the timing entry points: destroyed on every way out
+struct RankEvents {
+  std::vector<hipEvent_t> e0, e1;
+  bool started = false;
+  ~RankEvents() {
+    for (hipEvent_t e : e0) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : e1) if (e) (void)hipEventDestroy(e);
+  }
+  int create(psp_mcsr *M) {
+    e0.assign(M->nranks, nullptr);
+    e1.assign(M->nranks, nullptr);
+    for (int r = 0; r < M->nranks; ++r) {
+      M_HIP(hipSetDevice(M->r[r].dev));
+      M_HIP(hipEventCreate(&e0[r]));
+      M_HIP(hipEventCreate(&e1[r]));
+    }
+    return PSP_OK;
+  }
+  int start(psp_mcsr *M) {  // everything before is over; the clocks of all ranks start together
+    PSP_TRY(sync_all(M));
+    for (int r = 0; r < M->nranks; ++r) {
+      M_HIP(hipSetDevice(M->r[r].dev));
+      M_HIP(hipEventRecord(e0[r], M->r[r].s));
+    }
+    started = true;
+    return PSP_OK;
+  }
+  int stop(psp_mcsr *M, double *worst_ms) {  // the slowest rank's stream time
+    if (!started) return fail(PSP_EINVAL, "timing: no repetition was started");
+    *worst_ms = 0.0;
+    for (int r = 0; r < M->nranks; ++r) {
+      float ms = 0.f;
+      M_HIP(hipSetDevice(M->r[r].dev));
+      M_HIP(hipEventRecord(e1[r], M->r[r].s));
+      M_HIP(hipEventSynchronize(e1[r]));
+      M_HIP(hipEventElapsedTime(&ms, e0[r], e1[r]));
+      *worst_ms = std::max(*worst_ms, (double)ms);
+    }
+    return PSP_OK;
+  }
+};
+}  // namespace
+
 int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_product) {
   PSP_API_GUARD_H(A);
   if (!A || !A->multi || reps < 1 || warmup < 0 || !ms_per_product)
@@ -1011,48 +1080,28 @@ int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_p
     PSP_TRY(use(M, r));
     if (M->r[r].n) PSP_TRY(psp_k_jacobi(M->r[r].n, y[r], y[r], y[r]));  // touch
   }
-  std::vector<hipEvent_t> e0(M->nranks), e1(M->nranks);
-  for (int r = 0; r < M->nranks; ++r) {
-    M_HIP(hipSetDevice(M->r[r].dev));
-    M_HIP(hipEventCreate(&e0[r]));
-    M_HIP(hipEventCreate(&e1[r]));
-  }
-  int rc = PSP_OK;
-  for (int k = -warmup; k < reps && rc == PSP_OK; ++k) {
-    if (k == 0) {
-      rc = sync_all(M);
-      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r)
-        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e0[r], M->r[r].s) != hipSuccess) rc = PSP_ENODEV;
-    }
+  RankEvents ev;
+  PSP_TRY(ev.create(M));
+  for (int k = -warmup; k < reps; ++k) {
+    if (k == 0) PSP_TRY(ev.start(M));
     // one product the way a solver iteration does it: exchange on the copy streams, interior rows meanwhile
-    for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
-      rc = use(M, r);
-      if (rc == PSP_OK) rc = guard_overwrite(M, r);
+    for (int r = 0; r < M->nranks; ++r) {
+      PSP_TRY(use(M, r));
+      PSP_TRY(guard_overwrite(M, r));
     }
-    if (rc == PSP_OK) rc = exchange(M, vext.data());
-    for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+    PSP_TRY(exchange(M, vext.data()));
+    for (int r = 0; r < M->nranks; ++r) {
       RankOp &R = M->r[r];
-      rc = use(M, r);
-      if (rc != PSP_OK || !R.n) continue;
+      PSP_TRY(use(M, r));
+      if (!R.n) continue;
       if (M->nranks == 1)
-        rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr);
+        PSP_TRY(psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr));
       else
-        rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], R.ia, R.ib, wait_halo, &R, nullptr);
+        PSP_TRY(psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], R.ia, R.ib, wait_halo, &R, nullptr));
     }
   }
   double worst = 0.0;
-  for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
-    float ms = 0.f;
-    if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e1[r], M->r[r].s) != hipSuccess ||
-        hipEventSynchronize(e1[r]) != hipSuccess || hipEventElapsedTime(&ms, e0[r], e1[r]) != hipSuccess)
-      rc = fail(PSP_ENODEV, "psp_csr_multi_spmv_time: %s", hipGetErrorString(hipGetLastError()));
-    worst = std::max(worst, (double)ms);
-  }
-  for (int r = 0; r < M->nranks; ++r) {
-    (void)hipEventDestroy(e0[r]);
-    (void)hipEventDestroy(e1[r]);
-  }
-  if (rc != PSP_OK) return rc;
+  PSP_TRY(ev.stop(M, &worst));
   PSP_TRY(sync_all(M));
   *ms_per_product = worst / reps;  // the slowest rank's stream time: what an iteration waits for
   return PSP_OK;
@@ -1061,7 +1110,7 @@ int psp_csr_multi_spmv_time(psp_csr_t *A, int warmup, int reps, double *ms_per_p
 // The pieces of one iteration on their own (bench.py: `phases` of the single-process line): the slowest rank's stream
 // time per repetition of
 //   what 0  the ghost exchange alone (packing, peer copies on the copy streams, the compute streams wait for evH)
-//   what 1  the local product alone (all owned rows, ghost entries as they are: no exchange, no wait)
+//   what 1  the local product alone (all owned rows, ghost entries as they are -- zeros: no exchange, no wait)
 //   what 2  one packed reduction of two doubles (RCCL all-reduce or the fold kernel), in stream order
 // psp_csr_multi_spmv_time is the product as a solver does it (0 overlapped with 1); overlap = (t0 + t1 - t_spmv) / t0.
 int psp_csr_multi_phase_time(psp_csr_t *A, int what, int warmup, int reps, double *ms_per_rep) {
@@ -1073,55 +1122,35 @@ int psp_csr_multi_phase_time(psp_csr_t *A, int what, int warmup, int reps, doubl
   Vecs mem;
   std::vector<double *> vext(M->nranks), y(M->nranks);
   for (int r = 0; r < M->nranks; ++r) {
-    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n_ext, &vext[r]));
+    PSP_TRY(mem.get(M, r, (size_t)M->r[r].n_ext, &vext[r]));  // cleared (Vecs::get)
     PSP_TRY(mem.get(M, r, (size_t)M->r[r].n, &y[r]));
   }
-  std::vector<hipEvent_t> e0(M->nranks), e1(M->nranks);
-  for (int r = 0; r < M->nranks; ++r) {
-    M_HIP(hipSetDevice(M->r[r].dev));
-    M_HIP(hipEventCreate(&e0[r]));
-    M_HIP(hipEventCreate(&e1[r]));
-  }
-  int rc = PSP_OK;
-  for (int k = -warmup; k < reps && rc == PSP_OK; ++k) {
-    if (k == 0) {
-      rc = sync_all(M);
-      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r)
-        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e0[r], M->r[r].s) != hipSuccess) rc = PSP_ENODEV;
-    }
+  RankEvents ev;
+  PSP_TRY(ev.create(M));
+  for (int k = -warmup; k < reps; ++k) {
+    if (k == 0) PSP_TRY(ev.start(M));
     if (what == 0) {
-      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
-        rc = use(M, r);
-        if (rc == PSP_OK) rc = guard_overwrite(M, r);
+      for (int r = 0; r < M->nranks; ++r) {
+        PSP_TRY(use(M, r));
+        PSP_TRY(guard_overwrite(M, r));
       }
-      if (rc == PSP_OK) rc = exchange(M, vext.data());
-      for (int r = 0; r < M->nranks && rc == PSP_OK && M->nranks > 1; ++r)
-        if (hipSetDevice(M->r[r].dev) != hipSuccess || hipStreamWaitEvent(M->r[r].s, M->r[r].evH, 0) != hipSuccess)
-          rc = PSP_ENODEV;
+      PSP_TRY(exchange(M, vext.data()));
+      for (int r = 0; r < M->nranks && M->nranks > 1; ++r) {
+        M_HIP(hipSetDevice(M->r[r].dev));
+        M_HIP(hipStreamWaitEvent(M->r[r].s, M->r[r].evH, 0));
+      }
     } else if (what == 1) {
-      for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
+      for (int r = 0; r < M->nranks; ++r) {
         RankOp &R = M->r[r];
-        rc = use(M, r);
-        if (rc == PSP_OK && R.n)
-          rc = psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr);
+        PSP_TRY(use(M, r));
+        if (R.n) PSP_TRY(psp_k_csr_matvec_overlap(R.A, vext[r], R.ghost_lo, y[r], 0, R.n, nullptr, nullptr, nullptr));
       }
     } else {
-      rc = allreduce(M, 0, 2);
+      PSP_TRY(allreduce(M, 0, 2));
     }
   }
   double worst = 0.0;
-  for (int r = 0; r < M->nranks && rc == PSP_OK; ++r) {
-    float ms = 0.f;
-    if (hipSetDevice(M->r[r].dev) != hipSuccess || hipEventRecord(e1[r], M->r[r].s) != hipSuccess ||
-        hipEventSynchronize(e1[r]) != hipSuccess || hipEventElapsedTime(&ms, e0[r], e1[r]) != hipSuccess)
-      rc = fail(PSP_ENODEV, "psp_csr_multi_phase_time: %s", hipGetErrorString(hipGetLastError()));
-    worst = std::max(worst, (double)ms);
-  }
-  for (int r = 0; r < M->nranks; ++r) {
-    (void)hipEventDestroy(e0[r]);
-    (void)hipEventDestroy(e1[r]);
-  }
-  if (rc != PSP_OK) return rc;
+  PSP_TRY(ev.stop(M, &worst));
   PSP_TRY(sync_all(M));
   *ms_per_rep = worst / reps;
   return PSP_OK;

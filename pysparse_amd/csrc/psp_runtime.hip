@@ -46,7 +46,12 @@ struct ThreadCtx {
     return device;
   }
   ~ThreadCtx() {
-    for (auto &kv : own) (void)hipStreamDestroy(kv.second);  // (best effort: the runtime may already be shutting down)
+    // the slot (and the reduction workspaces cached under it) goes to the next thread that asks: nothing of this thread
+    // may still be in flight on them (best effort: the runtime may already be shutting down)
+    for (auto &kv : own) {
+      if (hipStreamSynchronize(kv.second) != hipSuccess) (void)hipGetLastError();
+      (void)hipStreamDestroy(kv.second);
+    }
     if (thread_slot > 0) {
       std::lock_guard<std::mutex> lk(g_mu);
       g_free_slots.push_back(thread_slot);  // its workspaces stay cached for the next thread that gets the slot
@@ -78,13 +83,78 @@ const char *tuning_env(const char *name) {
   return on ? getenv(name) : nullptr;
 }
 
-std::recursive_mutex &handle_mutex(const void *handle) {
+HandleEntry &handle_entry(const void *handle) {
   static std::mutex mu;
-  static std::unordered_map<const void *, std::unique_ptr<std::recursive_mutex>> tab;  // entries live as long as the process
+  static std::unordered_map<const void *, std::unique_ptr<HandleEntry>> tab;  // entries live as long as the process
   std::lock_guard<std::mutex> lk(mu);
   auto &e = tab[handle];
-  if (!e) e.reset(new std::recursive_mutex());
+  if (!e) e.reset(new HandleEntry());
   return *e;
+}
+
+// ---- device-side order between the streams that use one handle (psp_internal.h "Device-side order between threads")
+static std::atomic<int> g_track{0};                        // a second stream has been seen: keep last-use events
+static std::atomic<unsigned long long> g_devices_used{0};  // devices some thread of the library has made current
+static std::mutex g_first_mu;
+static bool g_first_set = false;
+static hipStream_t g_first_stream = nullptr;  // the one stream everything ran on so far
+
+void handles_enter(HandleEntry *const *e, int n) {
+  if (cpu_mode()) return;
+  if (tl.dev_state == 0) (void)ensure_device();  // a thread's first call: its stream must exist before it can wait
+  if (tl.dev_state != 1) return;                 // no device: nothing was, or can be, enqueued
+  const hipStream_t cur = stream();
+  if (!g_track.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_first_mu);
+    if (!g_first_set) {
+      g_first_set = true;
+      g_first_stream = cur;
+    } else if (cur != g_first_stream && !g_track.load(std::memory_order_relaxed)) {
+      // the second stream of the process: whatever was enqueued so far carries no event -- wait for it once
+      const unsigned long long used = g_devices_used.load();
+      for (int d = 0; d < 64; ++d)
+        if (used >> d & 1ull) {
+          if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+          (void)hipGetLastError();
+        }
+      (void)hipSetDevice(tl.dev());
+      g_track.store(1, std::memory_order_release);
+    }
+  }
+  if (!g_track.load(std::memory_order_acquire)) return;
+  for (int i = 0; i < n; ++i)
+    if (e[i]->has_last && e[i]->last != cur) {
+      if (hipStreamWaitEvent(cur, e[i]->ev, 0) != hipSuccess) (void)hipGetLastError();
+    }
+}
+
+void handles_leave(HandleEntry *const *e, int n) {
+  if (!g_track.load(std::memory_order_acquire) || cpu_mode() || tl.dev_state != 1) return;
+  const hipStream_t cur = tl.stream;  // what the call enqueued on (stream() ran in handles_enter)
+  const int d = tl.dev();
+  for (int i = 0; i < n; ++i) {
+    HandleEntry &h = *e[i];
+    if (h.ev && h.ev_dev != d) {  // the handle moved to a stream of another device: events belong to a device
+      (void)hipEventDestroy(h.ev);
+      h.ev = nullptr;
+    }
+    if (!h.ev) {
+      if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        h.ev = nullptr;
+        h.has_last = false;
+        continue;
+      }
+      h.ev_dev = d;
+    }
+    if (hipEventRecord(h.ev, cur) == hipSuccess) {
+      h.last = cur;
+      h.has_last = true;
+    } else {
+      (void)hipGetLastError();
+      h.has_last = false;
+    }
+  }
 }
 
 hipStream_t stream() {
@@ -128,6 +198,7 @@ int ensure_device() {
     return fail(PSP_ENODEV, "device %d requested but only %d visible", tl.dev(), cnt);
   PSP_HIP(hipSetDevice(tl.dev()));  // the HIP runtime's current device is per host thread too
   tl.dev_state = 1;
+  g_devices_used.fetch_or(1ull << (tl.dev() & 63));
   return PSP_OK;
 }
 
@@ -170,12 +241,113 @@ int use_device(int device, hipStream_t s, int ws_slot) {
   tl.stream = s;
   tl.stream_given = true;
   tl.ws_slot = ws_slot;
+  g_devices_used.fetch_or(1ull << (device & 63));
   return PSP_OK;
+}
+
+// what a multi-device entry point puts back when it returns (psp_multi.hip DeviceRestore): the thread's context as it was,
+// including WHETHER its stream had been chosen by the caller -- going through use_device would pin a secondary thread's
+// automatic per-device stream as if the user had supplied it, and a later psp_set_device would keep enqueueing on a
+// stream of the old device
+ThreadCtxSave save_thread_ctx() { return {tl.device, tl.dev_state, tl.ws_slot, tl.stream, tl.stream_given}; }
+void restore_thread_ctx(const ThreadCtxSave &c) {
+  if (c.device >= 0) {
+    if (hipSetDevice(c.device) != hipSuccess) (void)hipGetLastError();
+  }
+  tl.device = c.device;
+  tl.dev_state = c.dev_state;
+  tl.ws_slot = c.ws_slot;
+  tl.stream = c.stream;
+  tl.stream_given = c.stream_given;
 }
 
 int current_device() { return tl.dev(); }
 int current_ws_slot() { return tl.ws_slot; }
 int current_thread_slot() { return tl.slot(); }
+
+// ---- delay injection (psp_internal.h "shake")
+// one wave that does nothing until `ticks` of the 100 MHz wall clock have passed; the poll count is bounded too, so the
+// kernel ends even where the clock does not advance
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
+namespace {
+struct ShakeState {
+  std::atomic<int> armed{0};
+  std::mutex mu;
+  unsigned long long rng = 0;
+  int min_us = 0, max_us = 0;
+  unsigned points = 0, ranks = 0;
+  int revert = 0;
+  long long injected = 0;
+  bool env_read = false;
+};
+ShakeState g_shake;
+
+void shake_configure(long long seed, int min_us, int max_us, unsigned points, unsigned ranks, int revert) {
+  std::lock_guard<std::mutex> lk(g_shake.mu);
+  g_shake.rng = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed * 0xD1B54A32D192ED03ull + 1ull);
+  g_shake.min_us = std::max(0, min_us);
+  g_shake.max_us = std::min(100000, std::max(g_shake.min_us, max_us));  // <= 100 ms per injection
+  g_shake.points = points;
+  g_shake.ranks = ranks;
+  g_shake.revert = revert;
+  g_shake.injected = 0;
+  g_shake.armed.store(seed >= 0 && (points || revert) ? 1 : 0, std::memory_order_release);
+}
+
+void shake_read_env() {  // PSP_SHAKE="seed,min_us,max_us,points,ranks,revert" (tuning switch), once
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *e = tuning_env("PSP_SHAKE");
+    if (!e) return;
+    long long seed = 0;
+    int mn = 0, mx = 200, rv = 0;
+    unsigned pts = 0xffffffffu, rks = 0xffffffffu;
+    (void)sscanf(e, "%lld,%d,%d,%i,%i,%d", &seed, &mn, &mx, (int *)&pts, (int *)&rks, &rv);
+    shake_configure(seed, mn, mx, pts, rks, rv);
+  });
+}
+}  // namespace
+
+int shake(hipStream_t s, int point, int rank) {
+  shake_read_env();
+  if (!g_shake.armed.load(std::memory_order_acquire)) return PSP_OK;
+  long long us;
+  {
+    std::lock_guard<std::mutex> lk(g_shake.mu);
+    if (!(g_shake.points >> point & 1u) || !(g_shake.ranks >> (rank & 31) & 1u)) return PSP_OK;
+    unsigned long long x = g_shake.rng;  // xorshift64*: the same seed draws the same delays
+    x ^= x >> 12;
+    x ^= x << 25;
+    x ^= x >> 27;
+    g_shake.rng = x;
+    const unsigned long long r = x * 0x2545F4914F6CDD1Dull;
+    if (g_shake.min_us == g_shake.max_us) {
+      us = g_shake.max_us;
+    } else {
+      if (r >> 63) return PSP_OK;  // half of the visits inject nothing: a delayed stream next to an undelayed one
+      us = g_shake.min_us + (long long)((r >> 20) % (unsigned long long)(g_shake.max_us - g_shake.min_us + 1));
+    }
+    if (us <= 0) return PSP_OK;
+    g_shake.injected += 1;
+  }
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, us * 100);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+bool shake_armed() {
+  shake_read_env();
+  return g_shake.armed.load(std::memory_order_acquire) != 0;
+}
+
+bool shake_revert(int bit) {
+  shake_read_env();
+  return g_shake.armed.load(std::memory_order_acquire) && (g_shake.revert & bit) != 0;
+}
 
 // psp_stream_probe: R read streams (the first with ordinary loads, the others non-temporal, like the value streams
 // of csr_spmv_w4) and optionally one non-temporal write stream; one 16-byte element per thread and stream, full grid
@@ -349,9 +521,17 @@ static bool poll_scalars(Workspace *w, unsigned long long seq, int k, double *ds
   unsigned spins = 0;
   while (*word != seq) {
     __builtin_ia32_pause();
-    if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    if ((++spins & 0xfff) == 0) {  // a value is normally there within microseconds; beyond ~4000 polls give the core away
+      std::this_thread::yield();
+      if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
   }
-  if (*word != seq) return false;
+  if (*word != seq) {
+    // stuck, faulted or starved stream: the synchronising copy reports it, and this workspace does not poll again (a
+    // second publish kernel + another 2 s of spinning per read-back would be the price on a GPU shared with other jobs)
+    w->scal_host_dev = nullptr;
+    return false;
+  }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   memcpy(dst_host, w->scal_host, sizeof(double) * k);
   return true;
@@ -375,7 +555,7 @@ int finish_partials_fetch(const double *partials, int nparts, int nvals, double 
                      out_dev, w->scal_host_dev, reinterpret_cast<unsigned long long *>(w->scal_host_dev + 16), seq);
   PSP_LAUNCH_CHECK();
   if (poll_scalars(w, seq, nvals, dst_host)) return PSP_OK;
-  return fetch_scalars(out_dev, nvals, dst_host);  // stuck or faulted stream: the synchronising path reports it
+  return fetch_scalars(out_dev, nvals, dst_host);  // timed out (polling is off for this workspace now): copy + synchronise
 }
 
 int fetch_scalars(const double *src_dev, int k, double *dst_host) {
@@ -438,6 +618,7 @@ int psp_set_device(int device) {
   if (tl.device != device && !tl.stream_given) tl.stream = nullptr;  // a secondary thread's own stream is per device
   tl.device = device;
   tl.dev_state = 1;
+  g_devices_used.fetch_or(1ull << (device & 63));
   g_default_device.store(device);  // threads that start later begin here
   return PSP_OK;
 }
@@ -452,6 +633,31 @@ int psp_set_stream(void *hip_stream) {
 int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds) {
   PSP_API_GUARD_H(h1, h2);
   if (milliseconds > 0) std::this_thread::sleep_for(std::chrono::milliseconds(milliseconds));
+  return PSP_OK;
+}
+
+int psp_debug_shake(long long seed, int min_us, int max_us, unsigned point_mask, unsigned rank_mask, int revert_mask) {
+  if (!psp::tuning_env("PSP_TUNING"))  // (PSP_TUNING itself is set whenever the tuning switches are honoured)
+    return fail(PSP_EINVAL, "psp_debug_shake: delay injection needs a process started with PSP_TUNING=1");
+  psp::shake_read_env();  // an environment setting is consumed first, so that it cannot overwrite this call later
+  psp::shake_configure(seed, min_us, max_us, point_mask, rank_mask, revert_mask);
+  return PSP_OK;
+}
+
+int psp_debug_shake_count(long long *injected) {
+  if (!injected) return fail(PSP_EINVAL, "psp_debug_shake_count: NULL argument");
+  std::lock_guard<std::mutex> lk(psp::g_shake.mu);
+  *injected = psp::g_shake.injected;
+  return PSP_OK;
+}
+
+int psp_debug_spin(int microseconds) {
+  if (!psp::tuning_env("PSP_TUNING"))
+    return fail(PSP_EINVAL, "psp_debug_spin: needs a process started with PSP_TUNING=1");
+  PSP_TRY(ensure_device());
+  if (microseconds <= 0) return PSP_OK;
+  hipLaunchKernelGGL(psp::spin_kernel, dim3(1), dim3(64), 0, stream(), (long long)std::min(microseconds, 100000) * 100);
+  PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
 

@@ -84,7 +84,9 @@ struct ScratchPool {
   struct Item {
     double *p;
     size_t cap;
-    int dev;  // the device the vector lives on (threads may be on different devices)
+    int dev;   // the device the vector lives on (threads may be on different devices)
+    int role;  // 0 ordinary; 1 / 2: drawn for the output / input role of a product (psp_place.hip) -- handed out only
+               // for that role and that exact length, so that a draw is paid once per (device, length) and process
   };
   std::vector<Item> free_;
   std::mutex mu;
@@ -100,20 +102,23 @@ struct ScratchPool {
     }();
     return cap;
   }
+  // a cached vector of this role (role != 0: of exactly this length), or nullptr
+  double *take(size_t n, int role) {
+    std::lock_guard<std::mutex> lk(mu);
+    int best = -1;
+    const int dev = current_device();
+    for (int i = 0; i < (int)free_.size(); ++i)
+      if (free_[i].dev == dev && free_[i].role == role && (role ? free_[i].cap == n : free_[i].cap >= n) &&
+          (best < 0 || free_[i].cap < free_[best].cap))
+        best = i;
+    if (best < 0 || (!role && free_[best].cap > 2 * n + 1024)) return nullptr;
+    double *p = free_[best].p;
+    cached_bytes -= free_[best].cap * sizeof(double);
+    free_.erase(free_.begin() + best);
+    return p;
+  }
   int get(size_t n, double **out) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      int best = -1;
-      const int dev = current_device();
-      for (int i = 0; i < (int)free_.size(); ++i)
-        if (free_[i].dev == dev && free_[i].cap >= n && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
-      if (best >= 0 && free_[best].cap <= 2 * n + 1024) {
-        *out = free_[best].p;
-        cached_bytes -= free_[best].cap * sizeof(double);
-        free_.erase(free_.begin() + best);
-        return PSP_OK;
-      }
-    }
+    if ((*out = take(n, 0))) return PSP_OK;
     double *p = nullptr;
     hipError_t e = hipMalloc((void **)&p, sizeof(double) * (n ? n : 1));
     if (e != hipSuccess) {
@@ -125,13 +130,13 @@ struct ScratchPool {
     *out = p;
     return PSP_OK;
   }
-  void put(double *p, size_t cap) {
+  void put(double *p, size_t cap, int role = 0) {
     std::lock_guard<std::mutex> lk(mu);
     if (free_.size() >= kMaxCached || cached_bytes + cap * sizeof(double) > cap_bytes()) {
       (void)hipFree(p);
       return;
     }
-    free_.push_back({p, cap, current_device()});
+    free_.push_back({p, cap, current_device(), role});
     cached_bytes += cap * sizeof(double);
   }
   void trim() {
@@ -144,16 +149,52 @@ struct ScratchPool {
 ScratchPool g_pool;
 
 struct DevVecs {
-  std::vector<std::pair<double *, size_t>> ptrs;
+  struct Held {
+    double *p;
+    size_t cap;
+    int role;
+  };
+  std::vector<Held> ptrs;
   ~DevVecs() {
-    for (auto &p : ptrs)
-      if (p.first) g_pool.put(p.first, p.second);
+    for (auto &h : ptrs)
+      if (h.p) g_pool.put(h.p, h.cap, h.role);
   }
   int alloc(size_t n, double **out) {
     double *p = nullptr;
     PSP_TRY(g_pool.get(n, &p));
-    ptrs.push_back({p, n ? n : 1});
+    ptrs.push_back({p, n ? n : 1, 0});
     *out = p;
+    return PSP_OK;
+  }
+  // the operands of the solve's products y = A x (psp_place.hip): *y for the output role, *x0 / *x1 for the input role.
+  // Where placement does not apply they are ordinary pool vectors.  The first solve of a (device, length) draws them;
+  // later solves find them in the pool under their roles.
+  int alloc_operands(const psp_csr *A, size_t n, double **y, double **x0, double **x1) {
+    if (!placement_applies(A, n)) {
+      PSP_TRY(alloc(n, y));
+      PSP_TRY(alloc(n, x0));
+      return alloc(n, x1);
+    }
+    double *py = g_pool.take(n, 1), *pa = g_pool.take(n, 2), *pb = g_pool.take(n, 2);
+    if (!(py && pa && pb)) {  // an incomplete set (the pool let part of it go): draw afresh
+      for (double *p : {py, pa, pb})
+        if (p) (void)hipFree(p);
+      double *xs[2] = {nullptr, nullptr};
+      int rc = place_operands(A, n, n, 2, &py, xs, nullptr);
+      if (rc == PSP_ENOMEM) {  // the draw holds several vectors at once: without the cached ones it may fit
+        g_pool.trim();
+        rc = place_operands(A, n, n, 2, &py, xs, nullptr);
+      }
+      PSP_TRY(rc);
+      pa = xs[0];
+      pb = xs[1];
+    }
+    ptrs.push_back({py, n, 1});
+    ptrs.push_back({pa, n, 2});
+    ptrs.push_back({pb, n, 2});
+    *y = py;
+    *x0 = pa;
+    *x1 = pb;
     return PSP_OK;
   }
 };
@@ -730,16 +771,19 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
   PSP_TRY(workspace(&w));
   DevVecs mem;
   double *r, *p, *q, *z = nullptr;
-  PSP_TRY(mem.alloc(n, &r));
-  PSP_TRY(mem.alloc(n, &p));
-  PSP_TRY(mem.alloc(n, &q));
-
   psp_csr *Acsr = Acsr_forced ? Acsr_forced : op_native_csr(A);
   const double *dinv = Acsr_forced ? dinv_forced : fused_dinv(K);
   const bool fused = Acsr != nullptr && (Acsr_forced || K == nullptr || dinv != nullptr);
-  if (!fused && K) PSP_TRY(mem.alloc(n, &z));
   double *p2 = nullptr;  // second direction buffer of the p-update-in-SpMV path (csr_spmv_w4_pf)
-  if (fused) PSP_TRY(mem.alloc(n, &p2));
+  PSP_TRY(mem.alloc(n, &r));
+  if (fused) {
+    // q = A p is THE product of an iteration: q takes the output role, p (and its twin p2) the input role (psp_place.hip)
+    PSP_TRY(mem.alloc_operands(Acsr, n, &q, &p, &p2));
+  } else {
+    PSP_TRY(mem.alloc(n, &p));
+    PSP_TRY(mem.alloc(n, &q));
+    if (K) PSP_TRY(mem.alloc(n, &z));
+  }
 
   double s[4];
   int np;
@@ -1169,23 +1213,35 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   Workspace *w;
   PSP_TRY(workspace(&w));
   DevVecs mem;
-  double *v_hat_old, *v_hat, *y = nullptr, *wv, *w_old, *v, *av;
-  PSP_TRY(mem.alloc(n, &v_hat_old));
-  PSP_TRY(mem.alloc(n, &v_hat));
-  PSP_TRY(mem.alloc(n, &wv));
-  PSP_TRY(mem.alloc(n, &w_old));
-  PSP_TRY(mem.alloc(n, &v));
-  PSP_TRY(mem.alloc(n, &av));
+  double *v_hat_old = nullptr, *v_hat = nullptr, *y = nullptr, *wv, *w_old, *v, *av = nullptr;
   const bool hasK = Acsr_forced ? dinv_forced != nullptr : K != nullptr;
-  if (hasK) PSP_TRY(mem.alloc(n, &y));
-
   psp_csr *Acsr = Acsr_forced ? Acsr_forced : op_native_csr(A);
   const double *dinv = Acsr_forced ? dinv_forced : fused_dinv(K);
   const bool kfused = Acsr_forced || (K == nullptr) || dinv != nullptr;  // y = K v_hat can ride in the update
   // scaled mode (index-free SpMV layouts): v = y / beta is never stored; the unnormalised vector of
   // the iteration must then survive the Lanczos update, so y ping-pongs between two buffers
   double *y2 = nullptr;
-  if (hasK && kfused && Acsr) PSP_TRY(mem.alloc(n, &y2));
+  if (Acsr && kfused && placement_applies(Acsr, n)) {
+    // Av = A (y / beta) is THE product of an iteration: av takes the output role; the vector it reads -- y and its twin
+    // y2 with a preconditioner, v_hat and v_hat_old (they change places every iteration) without -- the input role
+    double *xa, *xb;
+    PSP_TRY(mem.alloc_operands(Acsr, n, &av, &xa, &xb));
+    if (hasK) {
+      y = xa;
+      y2 = xb;
+    } else {
+      v_hat = xa;
+      v_hat_old = xb;
+    }
+  }
+  if (!v_hat_old) PSP_TRY(mem.alloc(n, &v_hat_old));
+  if (!v_hat) PSP_TRY(mem.alloc(n, &v_hat));
+  PSP_TRY(mem.alloc(n, &wv));
+  PSP_TRY(mem.alloc(n, &w_old));
+  PSP_TRY(mem.alloc(n, &v));
+  if (!av) PSP_TRY(mem.alloc(n, &av));
+  if (hasK && !y) PSP_TRY(mem.alloc(n, &y));
+  if (hasK && kfused && Acsr && !y2) PSP_TRY(mem.alloc(n, &y2));
   const size_t bytes = sizeof(double) * (size_t)n;
   double s[4];
   int np;

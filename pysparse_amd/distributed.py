@@ -865,7 +865,7 @@ class PhaseTimer:
         return out
 
 
-def _matvec_state(A, kd, st, v_ext, y, timer=None):
+def _matvec_state(A, kd, st, v_ext, y, timer=None, shake=None):
     """y = A v for the owned rows through a state-driven kernel (kd = be.kd_matvec_overlap or
     be.kd_minres_matvec): the ghost exchange is started first and overlapped with the interior rows;
     the local v_owned . y lands in be.scal[0]"""
@@ -874,15 +874,25 @@ def _matvec_state(A, kd, st, v_ext, y, timer=None):
         if timer is not None:
             timer.mark("spmv_interior")
         return
+    if shake is not None:
+        shake()  # the vector the sends read is late
     sends, recvs = A._halo_ops(v_ext)
     wait = A.comm.exchange_start(sends, recvs)
-    if timer is not None:
+    if shake is not None:
+        shake()  # the interior rows are late against the transfers
+    if timer is not None or shake is not None:
         inner = wait
 
         def wait():  # called by the kernel driver between the interior and the boundary rows
-            timer.mark("spmv_interior")
+            if timer is not None:
+                timer.mark("spmv_interior")
+            if shake is not None:
+                shake()
             inner()
-            timer.mark("halo_exposed")
+            if shake is not None:
+                shake()  # the boundary rows are late against the next iteration's traffic
+            if timer is not None:
+                timer.mark("halo_exposed")
     kd(st, A.A, v_ext, A.plan.p_offset, y, A.plan.interior, wait)
     if timer is not None:
         timer.mark("spmv_boundary")
@@ -891,6 +901,40 @@ def _matvec_state(A, kd, st, v_ext, y, timer=None):
 def _tuning(name, default):
     """A/B switches are read only when the process was started with PSP_TUNING=1"""
     return os.environ.get(name, default) if os.environ.get("PSP_TUNING") == "1" else default
+
+
+SHAKE_INJECTED = 0  # spin kernels enqueued by _Shaker in this process (tests)
+
+
+class _Shaker:
+    """Delay injection at the cut points of the rank-per-process loops (the twin of psp::shake in psp_multi.hip): under
+    PSP_TUNING=1 PSP_DIST_SHAKE="seed,max_us" every cut point enqueues, with probability 1/2, a spin kernel of up to
+    max_us microseconds (psp_debug_spin) on the stream the library's kernels run on -- torch's current stream, the one
+    RCCL's collectives and send / recv batches order themselves against.  Each rank draws its own sequence (seed +
+    rank), so the ranks drift against each other as well.  The ordering edges this moves, per iteration:
+      px / scale kernel -> [send reads p | recv writes the ghost zone]  RCCL waits for the current stream at post time
+      recv -> boundary rows                                             wait() makes the current stream wait for RCCL
+      send -> next px / scale kernel (overwrites p)                     the same wait(), before the boundary rows
+      local sums -> all-reduce -> scalar step                           stream order (RCCL) / _dev_sync (gloo)
+    Results must not depend on it: tests/test_gpu_shake.py, bench.py's `shake_check` of an N-rank run."""
+
+    def __init__(self, be, rank):
+        spec = _tuning("PSP_DIST_SHAKE", "")
+        self.on = bool(spec) and hasattr(be, "L") and hasattr(be.L, "psp_debug_spin")
+        self.count = 0
+        if self.on:
+            parts = [int(t) for t in spec.split(",") if t.strip()]
+            self.rng = np.random.default_rng((parts[0] if parts else 0) + 7919 * rank)
+            self.max_us = parts[1] if len(parts) > 1 else 200
+            self.be = be
+
+    def __call__(self):
+        if self.on and self.rng.integers(0, 2):
+            us = int(self.rng.integers(1, self.max_us + 1))
+            self.be._capi.check(self.be.L.psp_debug_spin(us))
+            self.count += 1
+            global SHAKE_INJECTED
+            SHAKE_INJECTED += 1
 
 
 def dist_pcg_mode():
@@ -1110,6 +1154,9 @@ def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None, timer=None):
     if s[1] == 0.0:  # pcg.c:101-104 in iteration 1
         return -2, 1, normr / n2b
     st = be.pcg_state(n2b, tolb, normr, s[1], maxit, hist is not None)
+    shake = _Shaker(be, comm.rank)
+    if not shake.on:
+        shake = None
     try:
         enq = 0
         while True:
@@ -1117,19 +1164,27 @@ def _dist_pcg_dev(A, b, x, tol, maxit, dinv=None, hist=None, timer=None):
             for _ in range(batch):
                 if timer is not None:
                     timer.begin()
+                if shake is not None:
+                    shake()
                 be.kd_px_update(st, r, dinv, p, x)                      # -> scal[1]
                 if timer is not None:
                     timer.mark("px_update")
-                _matvec_state(A, be.kd_matvec_overlap, st, p_ext, q, timer)  # -> scal[0]
+                _matvec_state(A, be.kd_matvec_overlap, st, p_ext, q, timer, shake)  # -> scal[0]
+                if shake is not None:
+                    shake()
                 comm.allreduce_sum(be.scal[0:2])                        # all-reduce #1
                 if timer is not None:
                     timer.mark("allreduce_1")
+                if shake is not None:
+                    shake()
                 be.kd_pcg_scalar_xpq(st)
                 if timer is not None:
                     timer.mark("scalar_1")
                 be.kd_r_update(st, q, dinv, r)                          # -> scal[2:4]
                 if timer is not None:
                     timer.mark("r_update")
+                if shake is not None:
+                    shake()
                 comm.allreduce_sum(be.scal[2:4])                        # all-reduce #2
                 if timer is not None:
                     timer.mark("allreduce_2")
@@ -1196,16 +1251,27 @@ def dist_minres(A, b, x, tol, maxit, dinv=None, hist=None):
         if maxit < 1 or conv0:  # minres.c:114 before the first iteration
             return (0 if conv0 else -1), 0, float(np.float64(norm_r0) / np.float64(norm_r0))
         st = be.minres_state(norm_r0, beta, tol, maxit, hist is not None)
+        shake = _Shaker(be, comm.rank)
+        if not shake.on:
+            shake = None
         enq = 0
         while True:
             batch = max(1, min(PCG_BATCH, maxit - enq))
             for _ in range(batch):
+                if shake is not None:
+                    shake()
                 be.kd_minres_scale(st, y if dinv is not None else v_hat, v)   # v = y / beta
-                _matvec_state(A, be.kd_minres_matvec, st, v_ext, av)          # -> scal[0]
+                _matvec_state(A, be.kd_minres_matvec, st, v_ext, av, None, shake)  # -> scal[0]
+                if shake is not None:
+                    shake()
                 comm.allreduce_sum(be.scal[0:1])                              # all-reduce #1: alpha
+                if shake is not None:
+                    shake()
                 be.kd_minres_scalar(st, 0)
                 be.kd_minres_lanczos(st, av, v_hat, v_hat_old, dinv, y)       # -> scal[4]
                 v_hat, v_hat_old = v_hat_old, v_hat
+                if shake is not None:
+                    shake()
                 comm.allreduce_sum(be.scal[4:5])                              # all-reduce #2: beta^2
                 be.kd_minres_scalar(st, 1)
                 be.kd_minres_wx(st, v, wv, w_old, x)

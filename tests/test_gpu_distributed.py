@@ -161,6 +161,7 @@ def _worker(rank, world, port, q, transport="host_staged"):
         xb = be.zeros(hi - lo)
         gb = D.dist_pcg(B, be.from_numpy(bg[lo:hi]), xb, 1e-9, 1000, be.from_numpy(dinv_g[lo:hi]))
         out["big_slab"] = bool(torch.equal(yb, y) and tuple(gb) == tuple(got) and torch.equal(xb, x))
+        out["shake_injected"] = int(getattr(D, "SHAKE_INJECTED", 0))  # > 0 only under PSP_DIST_SHAKE (test_gpu_shake.py)
         q.put((rank, out))
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001

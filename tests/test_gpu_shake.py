@@ -1,0 +1,109 @@
+"""Delay injection into the multi-stream event graph of the multi-GPU drivers (round 5, VERDICT r4 "Next" #1).
+
+The N > 1 path orders its streams by events only.  A missing ordering edge shows as a wrong vector only when the timing
+opens the window: round 4 found one such race (a ghost zone cleared after the halo had arrived) once in ~15 suite runs, by
+luck.  psp_debug_shake (include/pysparse_hip.h; PSP_TUNING=1 processes only) enqueues spin kernels of pseudo-random length
+at every cut point of psp_multi.hip, on the stream that cut point names; PSP_DIST_SHAKE does the same at the cut points of
+the rank-per-process loops (pysparse_amd/distributed.py).  Tested here, on ONE GPU (ranks share it; every stream, event,
+copy and fold of the N > 1 path runs -- only the transport between two different devices does not):
+
+  * the facility finds what it is there to find: with the round-4 fix taken out again (revert bit 0) and ONE directed
+    delay, the product is wrong 5 times out of 5; on HEAD the same delay changes nothing;
+  * 200 shaken repetitions of products, PCG and MINRES on 2-5 ranks are bit-identical to the unshaken calls;
+  * three torch ranks (gloo transport, device tensors) under PSP_DIST_SHAKE: the device-scalar loop still equals the
+    host-scalar loop bit for bit.
+
+Reference loops being sharded: pcg.c:91-163, minres.c:96-193."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "shake_child.py")
+
+
+def test_shake_is_refused_outside_tuning_processes():
+    """not a GPU test: the hook must be inert in a user's process (no PSP_TUNING=1 at start-up)"""
+    if os.environ.get("PSP_TUNING") == "1":
+        pytest.skip("this process was started with PSP_TUNING=1")
+    from pysparse_amd import _capi
+    L = _capi.lib()
+    assert L.psp_debug_shake(1, 0, 100, 0xFFFFFFFF, 0xFFFFFFFF, 0) == -1  # PSP_EINVAL
+    assert b"PSP_TUNING" in L.psp_last_error()
+    assert L.psp_debug_spin(10) == -1
+
+
+def _child(*args, timeout=900):
+    env = dict(os.environ, PSP_TUNING="1")
+    env.pop("PSP_SHAKE", None)
+    p = subprocess.run([sys.executable, CHILD] + [str(a) for a in args], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_directed_delay_reproduces_the_round4_race_and_head_is_clean():
+    out = _child("race")
+    assert out["reverted_injected"] >= 1 and out["head_injected"] >= 1, out
+    assert out["reverted_wrong_of_5"] == 5, ("the delay no longer opens the window the round-4 fix closed", out)
+    assert out["head_wrong_of_5"] == 0 and out["disarmed_ok"], out
+
+
+@pytest.mark.gpu
+def test_shaken_products_and_solves_are_bit_identical():
+    out = _child("stress", 40, 120)
+    assert out["configs"] == 5 and out["runs_per_config"] * out["configs"] >= 200
+    assert out["injected"] > 10000, out  # the cut points were reached and delays were drawn
+    assert out["mismatches"] == [], out
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_torch_ranks_under_delay_injection():
+    """the rank-per-process driver with its cut points shaken (PSP_DIST_SHAKE): three ranks sharing the GPU over gloo with
+    the product's own Comm class; dist_pcg's device-scalar loop (shaken) == the host-scalar lazy loop (not shaken), bit for
+    bit, and both match the oracle"""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from test_gpu_distributed import _worker
+    world = 3
+    keep = {k: os.environ.get(k) for k in ("PSP_TUNING", "PSP_DIST_SHAKE")}
+    os.environ["PSP_TUNING"] = "1"      # read by the children (fresh interpreters: spawn), not by this process' library
+    os.environ["PSP_DIST_SHAKE"] = "5,150"
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, "gloo_device")) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = dict(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for rank, out in results.items():
+        assert "error" not in out, out.get("error")
+        assert out["spmv_ok"] and out["dev_equals_lazy"] and out["big_slab"]
+        ref, got, err = out["pcg"]
+        assert tuple(got[:2]) == tuple(ref[:2]) and err < 1e-12
+        ref, got, err = out["minres"]
+        assert tuple(got[:2]) == tuple(ref[:2]) and err < 1e-12
+        assert out.get("shake_injected", 0) > 0, out

@@ -119,3 +119,68 @@ def test_two_threads_sharing_one_handle_take_turns_and_stay_correct(oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_two_threads_async_dev_entry_points_on_one_handle(oracle):
+    """Round-4 advisor finding: the handle locks serialise only the HOST side of two calls; the asynchronous *_dev entry
+    points return with their kernels in flight, and the second thread enqueues on ANOTHER stream -- on the same scratch
+    (the renumbered copy's xp / yp, SSOR's sweep vectors and brick flags).  Every handle now carries a "last use" event
+    that the next caller's stream waits for (psp_internal.h).  Two threads fire unsynchronised *_dev calls at one irregular
+    csr handle and one ssor handle, each into its own output vectors; every output must be the oracle's bits."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import lib, check
+    L = lib()
+    rng = np.random.default_rng(11)
+    S = oracle.tendigit_sss(20000)  # large enough that a product + permutation passes outlast the next enqueue
+    S.diag[:] = 60.0 + rng.random(S.n)
+    S.val[:] = rng.standard_normal(S.val.size)
+    O = oracle.sss_to_csr(S)
+    n = O.shape[0]
+    A = dev.DeviceCSR.from_arrays(O.shape, O.ind, O.col, O.val)
+    D = dev.DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
+    K = dev.DeviceSSOR(D, 1.0, 1)
+    reps = 24
+    xs = [rng.standard_normal(n) for _ in range(2)]
+    want = []
+    for x in xs:
+        y = np.empty(n)
+        O.matvec(x, y)
+        z = np.empty(n)
+        oracle.ssor_apply(S, x, z, 1.0, 1)
+        want.append((y, z))
+    # warm the lazily built tables from the main thread (their construction synchronises; the race is in steady state)
+    y0 = np.empty(n)
+    A.matvec(xs[0], y0)
+    z0 = np.zeros(n)
+    K.precon(xs[0], z0)
+    bufs = []
+    for k in range(2):
+        xd = dev.DeviceBuffer.from_host(xs[k])
+        ys = [dev.DeviceBuffer(n) for _ in range(reps)]
+        zs = [dev.DeviceBuffer(n) for _ in range(reps)]
+        bufs.append((xd, ys, zs))
+    errs, streams = [], [None, None]
+    go = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            xd, ys, zs = bufs[k]
+            go.wait()
+            for i in range(reps):      # nothing here waits for the GPU: the calls of the two threads interleave
+                A.matvec_dev(xd.ptr, ys[i].ptr)
+                K.precon_dev(xd.ptr, zs[i].ptr)
+            streams[k] = _thread_info(L)[2]
+            check(L.psp_synchronize())  # this thread's stream
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert streams[0] and streams[1] and streams[0] != streams[1]
+    for k in range(2):
+        _, ys, zs = bufs[k]
+        for i in range(reps):
+            assert np.array_equal(ys[i].download(), want[k][0]), ("matvec_dev", k, i)
+            assert np.array_equal(zs[i].download(), want[k][1]), ("ssor precon_dev", k, i)
