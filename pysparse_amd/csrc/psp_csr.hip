@@ -712,11 +712,20 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
     count += __popcll(bal);
   }
   __syncthreads();
+  int nrun = 0;  // runs of consecutive ids in the sorted list (csr_spmv_w6 keeps up to kW6Runs of them in registers)
+  if constexpr (SHIFT == 4) {
+    for (int base = 0; base < count; base += 64) {
+      const int i = base + lane;
+      const bool flag = i < count && (i == 0 || ulist[i] != ulist[i - 1] + 1);
+      nrun += __popcll(__ballot(flag));
+    }
+  }
   if (lane == 0) {
     atomicMax(maxblocks, count);
     if constexpr (SHIFT == 4) {  // (the w5 builder passes a single counter)
       if (count > 64) atomicAdd(maxblocks + 1, 1);  // chunks that do not fit csr_spmv_w3's 64-block list
       if (count > 32) atomicAdd(maxblocks + 2, 1);  // ... its 32-block list
+      if (count > 64 || nrun > 8) atomicAdd(maxblocks + 3, 1);  // chunks csr_spmv_w6 serves through memory
     }
   }
   if (!write) return;
@@ -724,13 +733,15 @@ __global__ __launch_bounds__(64) void build_w3_kernel(int nchunks, int target, i
     // an OUTLIER chunk of a matrix that otherwise qualifies (ensure_w3): no list -- the kernel sees the -1 and
     // gathers this chunk's x entries from memory through the int32 columns
     for (int i = lane; i < NB; i += 64) blist[(size_t)chunk * NB + i] = -1;
-    for (int i = lane; i < WT; i += 64) col16[(size_t)chunk * WT + i] = 0;
+    if (col16)
+      for (int i = lane; i < WT; i += 64) col16[(size_t)chunk * WT + i] = 0;
     return;
   }
   if (count > NB) return;
   // unused list slots hold -2: the kernel issues no load for them (SHIFT 0, csr_spmv_w5: padded with the last column)
   for (int i = lane; i < NB; i += 64)
     blist[(size_t)chunk * NB + i] = i < count ? ulist[i] : (SHIFT == 4 ? -2 : (count ? ulist[count - 1] : 0));
+  if (!col16) return;  // csr_spmv_w6: the list alone (the columns stay the csr_mat's own)
   for (int i = lane; i < WT; i += 64) {
     const long k = kb + i;
     unsigned short v = 0;
@@ -932,6 +943,184 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
         else
           y[ro_] = acc;
         if (dotv) dsum += dotv[ro_] * acc;
+      }
+    }
+  }
+  if (partials) {
+    dsum = wave_sum(dsum);
+    __syncthreads();  // red[] lives in wave 0's slice: every wave must be done with its rows
+    if (lane == 0) red[wid] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < WPB; ++i) t += red[i];
+      partials[blockIdx.x] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ w6: the CSR arrays as stored + x staged in LDS
+//
+// Round 5 (VERDICT r4 "Next" #6).  csr_spmv_w2 is the one kernel that streams a csr_mat the way north_star words it --
+// int32 col_ind + fp64 val, 12 bytes per nonzero, nothing re-encoded -- and it is bound by the L1, not by HBM: every x
+// gather instruction touches ~20 cache lines (1.14e9 L1 accesses per launch at 512^3 against csr_spmv_w4's 2.7e8, 1.15x
+// fabric traffic; profiles/r4_spmv_w2_pmc_summary.txt).  w3 takes the gathers off the L1 but pays for it with a second
+// copy of the columns (16-bit, chunk-local).  w6 keeps w3's staging and w2's streams: the chunk's x blocks come from the
+// same block list (64 ids per chunk, 0.25 bytes per nonzero -- the only side table besides w2's row offsets), and a
+// nonzero's LDS slot is computed from its int32 column on the fly.  That works because the list of a banded matrix is a
+// handful of RUNS of consecutive blocks (seven for the 7-point operator: one per offset): the wave finds the runs with one
+// ballot over the sorted list, keeps (first block, first slot) of up to kW6Runs of them in scalar registers, and a
+// column's slot is ((c >> 4) + base_r) * 16 + (c & 15) with base_r picked by at most kW6Runs compares.  A chunk with
+// more runs, or more than 64 blocks, gathers through memory like w2 (wave-uniform branch).  Same products, same order
+// (csr_mat.c:49-54): the same bits as every other kernel.
+constexpr int kW6Runs = 8;
+
+template <int NP, int WPB, bool NTS>
+__global__ __launch_bounds__(64 * WPB) void csr_spmv_w6(
+    int chunk0, int nchunks, int stripe, int target, int kmax, int ncols, const int2 *__restrict__ tab,
+    const unsigned short *__restrict__ rowoff, const int *__restrict__ col, const int *__restrict__ blist,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ dotv, double *__restrict__ partials, const int *__restrict__ skip) {
+  constexpr int WT = 1024;
+  constexpr int STEPS = WT / 256;
+  constexpr int E = 64 * NP;
+  constexpr int NB = 64;
+  constexpr int XL = NB / 8;  // 16-byte x loads per lane
+  if (skip && *skip) return;
+  __shared__ double lds_all[WPB * WT];  // the x window (64 blocks x 16 doubles), then the products in its place
+  double *red = lds_all;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *buf = lds_all + wid * WT;
+  int vb = (int)blockIdx.x;  // XCD-aware placement, see csr_spmv_w1
+  if (stripe > 0) {
+    const int k = vb >> 3;
+    vb = ((k / stripe) * 8 + (vb & 7)) * stripe + k % stripe;
+  }
+  const int chunk = chunk0 + vb * WPB + wid;
+  double dsum = 0.0;
+  if (chunk < nchunks) {
+    const int kb = chunk * target;
+    // --- independent loads: values and columns exactly as the csr_mat stores them, row offsets, block list, table entry
+    d2v v0[STEPS], v1[STEPS];
+    i4v c[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      int k = kb + (st * 64 + lane) * 4;
+      k = (k < kmax) ? k : kmax;
+      c[st] = *reinterpret_cast<const i4v *>(col + k);
+      v0[st] = *reinterpret_cast<const d2v *>(val + k);
+      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
+    }
+    const int blk0 = blist[(size_t)chunk * NB + lane];
+    const unsigned short *ro = rowoff + (size_t)chunk * E;
+    int lo[NP], hi[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      lo[m] = ro[i];
+      hi[m] = ro[i + 1 < E ? i + 1 : E - 1];
+    }
+    const int r0 = tab[chunk].x;
+    const int nr = tab[chunk + 1].x - r0;
+    // --- the runs of the sorted list (unused slots hold -2, an over-full chunk's list -1 everywhere)
+    const int prev = __shfl_up(blk0, 1, 64);
+    const bool starts = blk0 >= 0 && (lane == 0 || blk0 != prev + 1);
+    unsigned long long runs = __ballot(starts);
+    const int nruns = __popcll(runs);
+    const bool direct = __builtin_amdgcn_readfirstlane(blk0) == -1 || nruns > kW6Runs;  // wave-uniform
+    d2v p0[STEPS], p1[STEPS];
+    if (direct) {
+      // --- x straight from memory through the columns (padding holds valid columns), like csr_spmv_w2
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        p0[st].x = v0[st].x * x[c[st].x];
+        p0[st].y = v0[st].y * x[c[st].y];
+        p1[st].x = v1[st].x * x[c[st].z];
+        p1[st].y = v1[st].y * x[c[st].w];
+      }
+    } else {
+      // (first block, slot - first block) of every run, wave-uniform; unused runs can never be chosen
+      int rs[kW6Runs], rb[kW6Runs];
+#pragma unroll
+      for (int r = 0; r < kW6Runs; ++r) {
+        const int i = runs ? __builtin_ctzll(runs) : 0;
+        const int b = __builtin_amdgcn_readlane(blk0, i);
+        rs[r] = (r < nruns) ? b : 0x7fffffff;
+        rb[r] = i - b;
+        runs &= runs - 1;
+      }
+      // --- the chunk's x blocks: 8 lanes per 128-byte block, 8 blocks per load instruction
+      d2v xw[XL];
+#pragma unroll
+      for (int j = 0; j < XL; ++j) {
+        const int b = __shfl(blk0, j * 8 + (lane >> 3), 64);
+        const long e0 = (long)b * 16 + (lane & 7) * 2;
+        if (b < 0) {  // unused slot: nothing to fetch
+          xw[j].x = 0.0;
+          xw[j].y = 0.0;
+        } else if (e0 + 1 < ncols) {
+          xw[j] = *reinterpret_cast<const d2v *>(x + e0);
+        } else {  // the block that holds the end of x
+          xw[j].x = e0 < ncols ? x[e0] : 0.0;
+          xw[j].y = 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < XL; ++j) *reinterpret_cast<d2v *>(&buf[(j * 64 + lane) * 2]) = xw[j];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // --- slot of a column: its block's rank in the list (from the runs) * 16 + its place in the block.  Entries of the
+      // window that belong to the next chunk may name blocks outside this list: their slot is meaningless, masked into the
+      // slice, and their product is never added
+      auto slot = [&](int cc) {
+        const int b = cc >> 4;
+        int base = rb[0];
+#pragma unroll
+        for (int r = 1; r < kW6Runs; ++r) base = (b >= rs[r]) ? rb[r] : base;
+        return (((b + base) << 4) + (cc & 15)) & (WT - 1);
+      };
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        p0[st].x = v0[st].x * buf[slot(c[st].x)];
+        p0[st].y = v0[st].y * buf[slot(c[st].y)];
+        p1[st].x = v1[st].x * buf[slot(c[st].z)];
+        p1[st].y = v1[st].y * buf[slot(c[st].w)];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int off = (st * 64 + lane) * 4;
+      *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
+      *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // --- one lane per row, products added left to right (reference order, csr_mat.c:49-54)
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int i = 64 * m + lane;
+      if (i < nr) {
+        double acc = 0.0;
+        for (int k = lo[m]; k < hi[m]; k += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int idx = k + u;
+            idx = idx < WT ? idx : WT - 1;
+            t[u] = buf[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += (k + u < hi[m]) ? t[u] : 0.0;
+        }
+        if constexpr (NTS)
+          __builtin_nontemporal_store(acc, &y[r0 + i]);
+        else
+          y[r0 + i] = acc;
+        if (dotv) dsum += dotv[r0 + i] * acc;
       }
     }
   }
@@ -1745,18 +1934,32 @@ __global__ __launch_bounds__(256) void csr_spmv_w4y(
 //   the lane's own rows; p_old and p_new are different buffers.  Saves the separate pass that
 //   writes p and the SpMV's read of it (8 bytes per row).  Square operators only (x = p has nrows
 //   entries).
-template <int NO, int PRE>
+// XU (round 5, the lazy loop's variant): the pending x update of the PREVIOUS iteration and its stagnation scan
+// (pcg.c:127-141: x += alpha_x p_old, the scan reads x before the update) ride along for the lane's own rows -- p_old[own] is
+// in registers already -- so the separate px pass disappears: 130 n instead of 138 n bytes per iteration.  The same
+// expressions as px_update_kernel (psp_vec.hip), hence the same bits; scan_partials[blockIdx.x] = number of the
+// workgroup's waves whose rows did not stagnate (only its being zero or not is ever used).
+template <int NO, int PRE, bool XU = false>
 __global__ __launch_bounds__(256) void csr_spmv_w4_pf(
     int nrows, int stripe, DiaOffs offs, const double *__restrict__ valT,
     const unsigned short *__restrict__ mask, const double *__restrict__ r, const double *__restrict__ dinv,
     double dc, const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ q,
-    double beta, int first, double *__restrict__ partials, const psp::PcgDev *__restrict__ dstate) {
+    double beta, int first, double *__restrict__ partials, const psp::PcgDev *__restrict__ dstate,
+    double *__restrict__ x = nullptr, double *__restrict__ scan_partials = nullptr) {
+  double alpha_x = 0.0;
+  bool xp = false;
   if (dstate) {  // asynchronous loop: scalars live on the device
     if (dstate->status) return;
     beta = dstate->beta;
     first = dstate->it == 1;
+    if constexpr (XU) {
+      alpha_x = dstate->alpha_x;
+      xp = dstate->xpend != 0;
+    }
   }
   __shared__ double red[4];
+  __shared__ double red2[4];
+  double dmax = 0.0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int vb = (int)blockIdx.x;
@@ -1850,12 +2053,53 @@ __global__ __launch_bounds__(256) void csr_spmv_w4_pf(
       p_new[row] = pn[NO].x;
       dsum += pn[NO].x * a0;
     }
+    if constexpr (XU) {
+      if (xp) {  // px_update_kernel's scan and update, on the own pair of p_old (never in iteration 1: nothing is pending)
+        const bool upd = alpha_x != 0.0;
+        const bool two = row + 1 < nrows;
+        d2u xx;
+        if (two) {
+          xx = *reinterpret_cast<const d2u *>(x + row);
+        } else {
+          xx.x = x[row];
+          xx.y = 0.0;
+        }
+        const double po[2] = {pp[NO].x, pp[NO].y};
+        double xv[2] = {xx.x, xx.y};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+          const double quot = fabs(alpha_x * po[u] / xv[u]);
+          const double ddum = (xv[u] != 0.0) ? quot : ((po[u] != 0.0) ? 1.0 : 0.0);
+          dmax = (ddum > dmax) ? ddum : dmax;
+          if (upd) xv[u] = xv[u] + alpha_x * po[u];
+        }
+        if (two) {
+          xx.x = xv[0];
+          xx.y = xv[1];
+          *reinterpret_cast<d2u *>(x + row) = xx;
+        } else {
+          x[row] = xv[0];
+        }
+      }
+    }
   }
   if (partials) {
     dsum = wave_sum(dsum);
     if (lane == 0) red[wid] = dsum;
+    if constexpr (XU) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(dmax, off, 64);
+        if (o > dmax) dmax = o;
+      }
+      if (lane == 0) red2[wid] = (1.0 + dmax != 1.0) ? 1.0 : 0.0;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+      partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+      if constexpr (XU) scan_partials[blockIdx.x] = red2[0] + red2[1] + red2[2] + red2[3];
+    }
   }
 }
 
@@ -2076,7 +2320,10 @@ __global__ void poisson_sss_kernel(int nx, int ny, int nz, long n, int *__restri
 constexpr int kW3Bit = 1 << 20;
 // bit 22: csr_spmv_w4 (masked offset-major layout, no column indices) where the matrix qualifies
 constexpr int kW4Bit = 1 << 22;
-constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8) + kW3Bit + kW4Bit;
+// bit 23: csr_spmv_w6 (the CSR arrays as stored, x staged in LDS through the block list alone) in front of csr_spmv_w2
+// where the matrix qualifies
+constexpr int kW6Bit = 1 << 23;
+constexpr int kDefaultVariant = 128 + 2 + 64 + (64 << 8) + kW3Bit + kW4Bit + kW6Bit;
 
 struct Variant {
   int tile, vec;
@@ -2090,6 +2337,7 @@ struct Variant {
   bool w3;
   bool sched;
   bool w4;
+  bool w6;
 };
 
 Variant decode_variant(int v) {
@@ -2102,6 +2350,7 @@ Variant decode_variant(int v) {
   const bool w3bit = (v & kW3Bit) != 0;
   const bool nosched = (v & (1 << 21)) != 0;
   r.w4 = (v & kW4Bit) != 0;
+  const bool w6bit = (v & kW6Bit) != 0;
   v &= 0xff;
   static const int vecs[4] = {4, 2, 1, 4};
   r.vec = vecs[v & 3];
@@ -2130,6 +2379,7 @@ Variant decode_variant(int v) {
   // w3 rides on the w2 tables (tile 1024, 4 waves per workgroup)
   r.w3 = w3bit && r.w2 && r.tile == 1024 && r.layout == 0;
   r.sched = r.w3 && !nosched;  // bit 21: keep the natural order + XCD stripes
+  r.w6 = w6bit && r.w2 && r.tile == 1024 && r.layout == 0 && !r.nt;
   return r;
 }
 
@@ -2193,6 +2443,10 @@ struct ChunkTable {
   int outliers = 0;   // chunks with more than 64 blocks that csr_spmv_w3<OUTL> serves through the int32 columns
   int *blist = nullptr;
   unsigned short *col16 = nullptr;
+  // csr_spmv_w6: the 64-slot block list alone (the columns stay the csr_mat's int32 array)
+  int nb6 = -1;       // -1: not examined yet, 0: too many chunks would gather through memory, 64: built
+  int direct6 = 0;    // chunks with more than 64 blocks or more than kW6Runs runs
+  int *blist6 = nullptr;
   // csr_spmv_w5: per chunk its distinct columns (fixed stride nu, a multiple of 64) and the chunk's columns
   // as 16-bit ranks in that list (fixed stride 1024)
   int nu = -1;        // -1: not examined yet, 0: not worth it (some chunk has too many distinct columns)
@@ -2419,6 +2673,43 @@ static int ensure_w3(const psp_csr *A, ChunkTable *t) {
   return PSP_OK;
 }
 
+
+// block lists of csr_spmv_w6 (built on first use; needs the w2 tables).  The kernel is chosen when at most 2 % of the
+// chunks would gather through memory (more than 64 blocks, or more than kW6Runs runs of consecutive blocks).
+static int ensure_w6(const psp_csr *A, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  if (t->nb6 >= 0) return PSP_OK;
+  t->nb6 = 0;
+  static const bool off = [] {
+    const char *e = psp::tuning_env("PSP_SPMV_W6");
+    return e && atoi(e) == 0;
+  }();
+  if (off || t->tile != 1024 || t->np == 0 || A->nnz == 0) return PSP_OK;
+  ScratchDev cnt;
+  PSP_HIP(hipMalloc(&cnt.p, 4 * sizeof(int)));
+  int *d_max = (int *)cnt.p;
+  PSP_HIP(hipMemsetAsync(d_max, 0, 4 * sizeof(int), stream()));
+  hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target, 0, t->tab,
+                     A->col, (int *)nullptr, (unsigned short *)nullptr, d_max);
+  PSP_LAUNCH_CHECK();
+  int st[4] = {0, 0, 0, 0};
+  PSP_HIP(hipMemcpyAsync(st, d_max, sizeof(st), hipMemcpyDeviceToHost, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  t->direct6 = st[3];
+  if (t->max_blocks == 0) t->max_blocks = st[0];
+  if ((long)st[3] * 50 > (long)t->nchunks) return PSP_OK;
+  if (hipMalloc((void **)&t->blist6, sizeof(int) * (size_t)t->nchunks * 64) != hipSuccess) {  // no room: stay on w2
+    (void)hipGetLastError();
+    t->blist6 = nullptr;
+    return PSP_OK;
+  }
+  hipLaunchKernelGGL(build_w3_kernel<64>, dim3(t->nchunks), dim3(64), 0, stream(), t->nchunks, t->target, 1, t->tab,
+                     A->col, t->blist6, (unsigned short *)nullptr, d_max);
+  PSP_LAUNCH_CHECK();
+  PSP_HIP(hipStreamSynchronize(stream()));
+  t->nb6 = 64;
+  return PSP_OK;
+}
 
 // column lists + 16-bit ranks of csr_spmv_w5 (built on first use; needs the w2 tables)
 static int ensure_w5(const psp_csr *A, ChunkTable *t) {
@@ -3367,6 +3658,46 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
   return PSP_OK;
 }
 
+// the lazy loop's product (csr_spmv_w4_pf<.., XU = true>): pending x update + scan, p_new, q = A p_new, p_new.q in one
+// pass; device-resident scalars only.  partials: slot 0 = p.q, slot 2 (partials + 2 kMaxParts) = the scan.
+// *available = 0 when the operator has no index-free layout of <= 8 offsets or the grid exceeds the partial-sum slots.
+int csr_spmv_pfx_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old, double *p_new,
+                        double *q, double *x, double *partials, int *nparts, const PcgDev *dstate, int *available) {
+  *available = 0;
+  Variant v = decode_variant(A->variant);
+  if (!v.w4 || A->nparts || A->sym_owner || A->nrows != A->ncols || A->nrows < 2 || !dstate || !partials) return PSP_OK;
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1 || ex->dia_no > 8) return PSP_OK;  // register budget: up to 8 offsets
+  const int stripe = w4_stripe(A, v);
+  const int nblk = (A->nrows + kDiaRows - 1) / kDiaRows;
+  const int grid = w4_grid(nblk, stripe);
+  if (grid > kMaxParts) return PSP_OK;
+  double dc = 0.0;
+  const int pre = !dinv ? 0 : (dinv_constant(dinv, A->nrows, &dc) ? 2 : 1);
+  double *scan = partials + 2 * (size_t)kMaxParts;
+#define PSP_PFX(NO, PRE)                                                                                    \
+  hipLaunchKernelGGL((csr_spmv_w4_pf<NO, PRE, true>), dim3(grid), dim3(256), 0, stream(), A->nrows, stripe, \
+                     ex->dia_offs, ex->dia_val, ex->dia_mask, r, dinv, dc, p_old, p_new, q, 0.0, 0, partials, dstate, x, scan)
+#define PSP_PFX_NO(NO)                \
+  case NO:                            \
+    if (pre == 0) PSP_PFX(NO, 0);     \
+    else if (pre == 1) PSP_PFX(NO, 1); \
+    else PSP_PFX(NO, 2);              \
+    break
+  switch (ex->dia_no) {
+    PSP_PFX_NO(1); PSP_PFX_NO(2); PSP_PFX_NO(3); PSP_PFX_NO(4); PSP_PFX_NO(5); PSP_PFX_NO(6); PSP_PFX_NO(7); PSP_PFX_NO(8);
+    default:
+      return PSP_OK;
+  }
+#undef PSP_PFX_NO
+#undef PSP_PFX
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  *available = 1;
+  return PSP_OK;
+}
+
 // q = A (z + beta p_old) with p_new written on the way (csr_spmv_w4_pf); *available = 0 when the
 // operator has no w4 layout (the caller then runs pupdate + csr_spmv_launch)
 int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old,
@@ -3655,6 +3986,37 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
       }
       if (nparts) *nparts = np;
       return PSP_OK;
+    }
+    if (v.w2 && v.w6) {
+      PSP_TRY(ensure_w6(A, t));
+      if (t->nb6 > 0) {
+        const int g6 = stripe > 0 ? ((t->nchunks + 3) / 4 + 8 * stripe - 1) / (8 * stripe) * (8 * stripe) : (t->nchunks + 3) / 4;
+        double *pb6 = partials;
+        if (partials && g6 > kMaxParts) {
+          psp::CsrExtra *ex6;
+          {
+            std::lock_guard<std::mutex> lk(g_extra_mu);
+            ex6 = &g_extra[A];
+          }
+          PSP_TRY(ensure_big_partials(ex6, g6));
+          pb6 = ex6->big_partials;
+        }
+#define PSP_W6(NP)                                                                                          \
+  hipLaunchKernelGGL((csr_spmv_w6<NP, 4, true>), dim3(g6), dim3(256), 0, stream(), 0, t->nchunks, stripe,    \
+                     t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, A->col, t->blist6, A->val, x, y, \
+                     dotv, pb6, skip)
+        if (t->np == 2) PSP_W6(2); else if (t->np == 3) PSP_W6(3); else PSP_W6(4);
+#undef PSP_W6
+        PSP_LAUNCH_CHECK();
+        int np6 = g6;
+        if (pb6 != partials) {
+          np6 = kFold;
+          hipLaunchKernelGGL(fold_partials_kernel, dim3(np6 / 16), dim3(256), 0, stream(), pb6, g6, partials, np6);
+          PSP_LAUNCH_CHECK();
+        }
+        if (nparts) *nparts = np6;
+        return PSP_OK;
+      }
     }
     char *packed = nullptr;
     if (v.w2 && v.layout == 1) PSP_TRY(ensure_packed(A, &packed));
@@ -4425,6 +4787,7 @@ int psp_csr_destroy(psp_csr_t *A) {
         if (t.second.tab) (void)hipFree(t.second.tab);
         if (t.second.rowoff) (void)hipFree(t.second.rowoff);
         if (t.second.blist) (void)hipFree(t.second.blist);
+        if (t.second.blist6) (void)hipFree(t.second.blist6);
         if (t.second.col16) (void)hipFree(t.second.col16);
         if (t.second.ulist) (void)hipFree(t.second.ulist);
         if (t.second.colu) (void)hipFree(t.second.colu);
@@ -4705,6 +5068,15 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
               vals[2] = t->sched_state == 1;
               vals[3] = t->half_band;
             }
+          }
+        }
+        if (v.w6 && !strcmp(k, "csr_spmv_w2")) {  // what csr_spmv_launch tries in front of w2
+          PSP_TRY(ensure_w6(A, t));
+          if (t->nb6 > 0) {
+            k = "csr_spmv_w6";
+            vals[0] = t->nb6;
+            vals[1] = t->max_blocks;
+            vals[2] = t->direct6;
           }
         }
       }

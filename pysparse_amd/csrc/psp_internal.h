@@ -442,6 +442,10 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
 int csr_spmv_pfused_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old,
                            double *p_new, double *q, double beta, bool first, double *partials, int *nparts,
                            const PcgDev *dstate, int *available);
+// the lazy PCG loop's product on a w4 operator: the pending x update + stagnation scan of the previous iteration, p_new,
+// q = A p_new and the p_new.q partials in one pass (psp_csr.hip csr_spmv_w4_pf<.., XU>); *available = 0 otherwise
+int csr_spmv_pfx_launch(const psp_csr *A, const double *r, const double *dinv, const double *p_old, double *p_new,
+                        double *q, double *x, double *partials, int *nparts, const PcgDev *dstate, int *available);
 // MINRES: y = A (x ./ xdiv) + partials of (x ./ xdiv) . y on the index-free layouts; *available = 0 otherwise
 // xdiv_dev != nullptr: the divisor is read from the device (asynchronous MINRES loop)
 int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, double *y, double *partials,

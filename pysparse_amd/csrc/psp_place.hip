@@ -81,8 +81,8 @@ int place_operands(const psp_csr *A, size_t nx, size_t ny, int want_x, double **
     fr = 0;
   }
   // candidates spread over the address space: pads of twice the vector in between (released at the end) -- neighbouring
-  // allocations share a level (runs of 3-5 in profiles/r4_modes.txt), the pads make four draws reach as far as twelve
-  int m = 5;
+  // allocations share a level (runs of 3-5 in profiles/r4_modes.txt), the pads make eight draws reach as far as twenty
+  int m = 7;
   size_t pad = 2 * bytes;
   if (fr < 2 * ((size_t)(m + 1) * bytes + (size_t)m * pad)) pad = 0;
   if (fr < 2 * (size_t)(m + 1) * bytes) m = 3;

@@ -629,10 +629,24 @@ static int pcg_lazy_enabled() {  // read per solve (tools/reduce_ab.py alternate
   return e ? atoi(e) : 1;
 }
 
-static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p,
+// PSP_PCG_LAZYPF (tuning switch, read per solve: tools/lazypf_ab.py alternates it inside one process): the lazy loop with
+// the p update AND the pending x update folded into the product on index-free operators (csr_spmv_pfx_launch): 4 launches
+// and 130 n bytes per iteration instead of 5 and 138 n.  Same expressions on the same operands: the same bits.
+// Measured in one process on the same buffers (tools/lazypf_ab.py, profiles/r5_pcg_lazypf_ab.txt), same bits everywhere:
+// 2048^2 +5.2 %, 4096^2 +2.9 %, 512^3 +0.8 %, 256^3 +0.8 %, 1024^2 -0.4 % -- the saved 8 n bytes and the saved launch
+// are partly paid back by reading r AND p_old at every neighbour position (twice the L1 traffic of the plain product):
+// on from 2^21 unknowns.
+static int pcg_lazypf_mode(int n) {
+  const char *e = psp::tuning_env("PSP_PCG_LAZYPF");
+  return e ? atoi(e) : (n >= (1 << 21) ? 1 : 0);
+}
+
+static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double *x, double *r, double *p, double *p2,
                                double *q, double n2b, double tolb, double normr0, double rho0, int maxit,
                                int *info, int *iter, double *relres, double *hist) {
   constexpr int kBatch = 16;
+  double *const P[2] = {p, p2};  // folded form: iteration e reads p_{e-1} from P[(e-1) & 1] and writes p_e to P[e & 1]
+  int usepf = (p2 && pcg_lazypf_mode(n)) ? 1 : 0;
   Workspace *w;
   PSP_TRY(workspace(&w));
   PcgDev *st = nullptr, *hst = nullptr;
@@ -684,6 +698,18 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
       // not used.  Same scalar steps in the same order on the same reduced values: the same bits
       // (PSP_PCG_MERGE_XPQ=0 keeps the scan's reduction in front of the product: A/B and test_pcg_loop_variants_agree).
       int np_x = 0;
+      if (usepf) {
+        const int e = enqueued + i + 1;
+        int av = 0;
+        PCG_TRY(csr_spmv_pfx_launch(Acsr, r, dinv, P[(e - 1) & 1], P[e & 1], q, x, w->partials, &np, st, &av));
+        if (av) {
+          PCG_TRY(pcg_reduce_xpq(w, stag_parts, np, w->partials, np, w->scal_dev + 8, w->scal_dev, st));
+          PCG_TRY(k_r_update(n, 0.0, q, dinv, r, w->partials, &np, st));
+          PCG_TRY(pcg_reduce_then<kOpLazyR>(w->partials, np, 2, w->scal_dev + 4, st, hist_dev));
+          continue;
+        }
+        usepf = 0;  // no index-free layout (decided by the operator: this is iteration 1, p = P[0] is untouched)
+      }
       PCG_TRY(k_px_update(n, r, dinv, p, x, w->partials, &np_x, st));
       if (!merge_xpq) PCG_TRY(pcg_reduce_then<kOpLazyX>(stag_parts, np_x, 1, w->scal_dev + 8, st, nullptr));
       PCG_TRY(csr_spmv_launch(Acsr, p, q, p, w->partials, &np, &st->status));
@@ -699,6 +725,7 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
     PCG_HIP(hipMemcpyAsync(hst, st, sizeof(PcgDev), hipMemcpyDeviceToHost, stream()));
     PCG_HIP(hipStreamSynchronize(stream()));
   } while (!hst->status);
+  if (usepf) p = P[hst->it & 1];  // the direction of the iteration the loop ended in
   if (hst->xpend) {  // the x update (and scan) of the last iteration
     double s[1];
     PCG_TRY(k_x_update(n, hst->alpha_x, p, x, w->partials, &np, nullptr));
@@ -844,7 +871,7 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     // PSP_PCG_LAZYX=2 forces it at any size (tests), 0 disables it
     const int lazy_mode = pcg_lazy_enabled();
     if ((lazy_mode == 2 || (lazy_mode == 1 && (n < (1 << 24) || n >= 3 * (1 << 23)))) && !pcg_graph_enabled())
-      return pcg_async_loop_lazy(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter,
+      return pcg_async_loop_lazy(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                                  relres, hist);
     return pcg_async_loop(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                           relres, hist);

@@ -406,7 +406,10 @@ def test_pcg_loop_variants_agree(golden, p2d, monkeypatch):
     for env in ({"PSP_PCG_ASYNC": "0"}, {}, {"PSP_PCG_GRAPH": "1"}, {"PSP_PCG_PFUSED": "1"},
                 {"PSP_PCG_PFUSED": "1", "PSP_PCG_ASYNC": "0"}, {"PSP_DINV_CONST": "0"},
                 {"PSP_DINV_CONST": "0", "PSP_PCG_PFUSED": "1"}, {"PSP_PCG_LAZYX": "2"},
-                {"PSP_PCG_LAZYX": "2", "PSP_DINV_CONST": "0"}):
+                {"PSP_PCG_LAZYX": "2", "PSP_DINV_CONST": "0"},
+                # round 5: the lazy loop with p update AND pending x update folded into the product (csr_spmv_w4_pf<XU>)
+                {"PSP_PCG_LAZYX": "2", "PSP_PCG_LAZYPF": "1"}, {"PSP_PCG_LAZYX": "2", "PSP_PCG_LAZYPF": "0"},
+                {"PSP_PCG_LAZYX": "2", "PSP_PCG_LAZYPF": "1", "PSP_DINV_CONST": "0"}):
         # PSP_TUNING: the master switch that makes the library read its A/B variables; PSP_COOP=0: these tests compare
         # the launch-per-phase loops with each other (at this size the default is the single-kernel loop, psp_coop.hip)
         e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
@@ -604,14 +607,17 @@ def test_pcg_lazy_x_update_exit_semantics_match_eager_loop():
         "print(json.dumps(out))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "2"}, {"PSP_PCG_ASYNC": "0"}):
+    # the last one (round 5): lazy loop with the p update and the pending x update folded into the product -- the
+    # direction vector ping-pongs between two buffers there, so every truncation point (both parities) matters
+    for env in ({"PSP_PCG_LAZYX": "0"}, {"PSP_PCG_LAZYX": "2", "PSP_PCG_LAZYPF": "0"}, {"PSP_PCG_ASYNC": "0"},
+                {"PSP_PCG_LAZYX": "2", "PSP_PCG_LAZYPF": "1"}):
         # PSP_TUNING: the master switch that makes the library read its A/B variables; PSP_COOP=0: these tests compare
         # the launch-per-phase loops with each other (at this size the default is the single-kernel loop, psp_coop.hip)
         e = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
         outs.append(json.loads(out.strip().splitlines()[-1]))
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     infos = {o[0] for o in outs[1][:-1]}
     assert -5 in infos and -1 in infos  # the sweep really crosses the stagnation point
     k5 = min(o[1] for o in outs[1][:-1] if o[0] == -5)

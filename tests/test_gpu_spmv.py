@@ -252,11 +252,11 @@ def test_csr_matvec_w3_banded_bit_exact(oracle, shape):
         if info["max_blocks"] <= 64:
             assert name == "csr_spmv_w3" and info["nb"] in (32, 64)
         else:
-            assert name == "csr_spmv_w2"
+            assert name in ("csr_spmv_w2", "csr_spmv_w6")
     y = np.full(m, np.nan)
     D.matvec(x, y)
     assert np.array_equal(y, y_ref)
-    for v in (16578, 1065154, 34619586, 68174018, 101728450):  # w2; w3 4-wide; w3 NT / pairs / both
+    for v in (16578, 16578 + (1 << 23), 1065154, 34619586, 68174018, 101728450):  # w2; w6; w3 4-wide; w3 NT / pairs / both
         D.set_variant(v)
         if v == 16578:
             assert D.kernel_info()[0] in ("csr_spmv_w2", "csr_spmv_w1")
@@ -711,3 +711,84 @@ def test_csr_matvec_w5_ragged_and_empty_rows(oracle):
     D.matvec(x, y)
     A.matvec(x, yo)
     assert np.array_equal(y, yo, equal_nan=True)
+
+
+W6_VARIANT = 16578 + (1 << 23)  # csr_spmv_w2's variant + bit 23: the CSR arrays as stored, x staged in LDS (psp_csr.hip)
+
+
+def _many_runs_csr(O, n, seed):
+    """every row couples to 12 columns spread 40 apart: a chunk's x blocks fall into more than 8 runs (csr_spmv_w6's
+    register budget) -- the kernel must take its memory-gather branch for such chunks, or leave the matrix to w2"""
+    rng = np.random.default_rng(seed)
+    ind = np.arange(0, 12 * n + 1, 12, dtype=np.int32)
+    col = np.empty(12 * n, dtype=np.int32)
+    for i in range(n):
+        col[12 * i:12 * i + 12] = np.sort((i + 40 * np.arange(-6, 6)) % n)
+    return O.CSR((n, n), rng.standard_normal(12 * n), col, ind)
+
+
+@pytest.mark.parametrize("case", ["poisson2d", "poisson3d", "banded", "banded_odd", "ragged_wide_x", "many_runs",
+                                  "few_wild_rows", "tiny"])
+def test_csr_matvec_w6_streams_the_stored_arrays_bit_exact(oracle, case):
+    """csr_spmv_w6 (round 5): int32 col + fp64 val exactly as the csr_mat stores them (csr_mat.h:6-13), x staged in LDS
+    through the chunk's block list, a nonzero's LDS slot computed from its column via the list's runs of consecutive
+    blocks; chunks with more than 8 runs / 64 blocks gather through memory.  Reference order csr_mat.c:49-54: bit-equal
+    to the oracle and to w2 / w3 on stencils, banded, ragged / empty rows, odd and short x, NaN / Inf operands."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    L = lib()
+    expect_w6 = True
+    if case == "poisson2d":
+        A = oracle.poisson_csr(300, 257)
+    elif case == "poisson3d":
+        A = oracle.poisson_csr(40, 37, 33)
+    elif case == "banded":
+        A = banded_csr(oracle, 5000, 4999, 21, 150, 12)
+    elif case == "banded_odd":
+        A = banded_csr(oracle, 3001, 3001, 5, 40, 9, empty_frac=0.2)
+    elif case == "ragged_wide_x":
+        A = banded_csr(oracle, 800, 100000, 7, 20, 7)
+        expect_w6 = False  # every row looks at its own window of x: far more than 64 blocks per chunk
+    elif case == "many_runs":
+        A = _many_runs_csr(oracle, 6000, 3)
+        expect_w6 = False  # every chunk would gather through memory: stays on w2
+    elif case == "few_wild_rows":
+        A = banded_csr(oracle, 60000, 60000, 9, 30, 8)
+        rng = np.random.default_rng(1)
+        for r in rng.choice(60000, 4, replace=False):  # four rows point anywhere: > 8 runs in their chunks (1.5 % of all)
+            a, b = A.ind[r], A.ind[r + 1]
+            if b - a >= 4:
+                A.col[a:b] = np.sort(rng.choice(60000, b - a, replace=False)).astype(np.int32)
+    else:
+        A = oracle.poisson_csr(3, 2)
+    m, n = A.shape
+    D = dev.DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    D.set_variant(W6_VARIANT)
+    name, info = D.kernel_info()
+    if case == "tiny":
+        assert name in ("csr_spmv_w6", "csr_spmv_w2", "csr_spmv_w1")
+    elif name != "csr_spmv_w1":
+        assert name == ("csr_spmv_w6" if expect_w6 else "csr_spmv_w2"), (name, info)
+    x = rng_vec(n, 11)
+    y, yo = np.full(m, np.nan), np.empty(m)
+    A.matvec(x, yo)
+    D.matvec(x, y)
+    assert np.array_equal(y, yo)
+    # the fused dot epilogue (PCG's p.q) through the same kernel
+    if m == n:
+        xd, yd, out = dev.DeviceBuffer.from_host(x), dev.DeviceBuffer(m), dev.DeviceBuffer(1)
+        check(L.psp_k_csr_matvec_dot(D._h, xd.ptr, 0, yd.ptr, out.ptr))
+        assert np.array_equal(yd.download(), yo)
+        d = float(out.download()[0])
+        assert abs(d - float(np.dot(x, yo))) <= 1e-11 * max(abs(d), 1.0)
+    # NaN / Inf reach exactly the rows they reach on the CPU
+    x[::97] = np.inf
+    x[5::131] = np.nan
+    A.matvec(x, yo)
+    D.matvec(x, y)
+    assert np.array_equal(y, yo, equal_nan=True)
+    for v in (16578, -1):  # w2 and the default choice: the same bits
+        D.set_variant(v)
+        y2 = np.full(m, np.nan)
+        D.matvec(x, y2)
+        assert np.array_equal(y2, yo, equal_nan=True), v
