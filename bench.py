@@ -37,73 +37,24 @@ import time  # noqa: E402
 
 import numpy as np  # noqa: E402
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3-6.8 achievable)
-W3_VARIANT = (1 << 20) + 128 + 64 + 2 + (64 << 8)  # csr_spmv_w3 (general banded CSR), see psp_csr.hip
-W2_VARIANT = 128 + 64 + 2 + (64 << 8)              # csr_spmv_w2 (int32 col + fp64 val streamed as stored)
-PMC_FILES = {"csr_spmv_w4": "r3_spmv_pmc.json", "csr_spmv_w3": "r3_spmv_w3_pmc.json",
-             "csr_spmv_w2": "r3_spmv_w2_pmc.json"}
-
-
-def csr_model_bytes(n, nnz):
-    """val 8 + col 4 per nonzero; ind 4 + y 8 + x 8 per row."""
-    return 12 * nnz + 20 * n + 4
+from bench_common import (HBM_PEAK_GBPS, METRIC, PARITY_ITERS, PARITY_TOL, PMC_FILES, ROOT, W2_VARIANT, W3_VARIANT,  # noqa: E402,F401
+                          Events, _maxrel, csr_model_bytes, kernel_bytes, parity_object, pcg_vector_bytes, provenance,
+                          rel_diff, timed_launches)
+from bench_launch import LADDER, guarded_rank, orchestrate  # noqa: E402
+from bench_legs import (dry_strong_n1, gpu_clocks, link_topology, live_traffic, pcg_single, peer_matrix,  # noqa: E402
+                        placement_sweep_leg, same_operator_kernels_leg, single_process_main, sss_leg, stream_ceiling_leg,
+                        strong_n1_leg)
 
 
-def kernel_bytes(kernel, info, n, nnz, nnz_lower=None):
-    """Bytes one launch of `kernel` has to move from/to DRAM: x and y once + the matrix in the
-    format that kernel streams.  Never more than the CSR model."""
-    if kernel == "csr_spmv_w4":   # values in padded offset-major blocks of 128 rows + 16-bit row masks
-        rows = (n + 127) // 128 * 128
-        return 8 * rows * info["nb"] + 2 * n + 16 * n
-    if kernel == "sss_spmv_w4":   # strict lower triangle (offset-major), diagonal, 16-bit masks
-        rows = (n + 127) // 128 * 128
-        return 8 * rows * info["nb"] + 8 * n + 2 * n + 16 * n
-    if kernel == "csr_spmv_w3":   # val 8 + col16 2 per nonzero; per chunk of ~1016 nonzeros: block list + row offsets
-        chunks = nnz / 1016.0
-        return int(10 * nnz * (1024 / 1016.0) + chunks * (4 * info["nb"] + 2 * 256 + 16) + 16 * n)
-    return csr_model_bytes(n, nnz)
 
 
-def pcg_vector_bytes(n, lazy, const_dinv=True):
-    """vector traffic of one fused Jacobi-PCG iteration beside the SpMV:
-    lazy: px_update (r, p, x read; p, x written) + r_update (q, r read; r written) = 64 n;
-    eager: pupdate 24 n + x_update 24 n + r_update 24 n; + 16 n when dinv is streamed (twice)."""
-    return (64 if lazy else 72) * n + (0 if const_dinv else 16 * n)
 
 
-class Events:
-    """HIP events on the library's stream (the stream the kernels are launched on)."""
-
-    def __init__(self, L, check, count=2):
-        self.L, self.check = L, check
-        self.ev = []
-        for _ in range(count):
-            e = C.c_void_p()
-            check(L.psp_event_create(C.byref(e)))
-            self.ev.append(e)
-
-    def record(self, i):
-        self.check(self.L.psp_event_record(self.ev[i]))
-
-    def ms(self, i, j):
-        ms = C.c_float()
-        self.check(self.L.psp_event_elapsed_ms(self.ev[i], self.ev[j], C.byref(ms)))
-        return float(ms.value)
 
 
-def timed_launches(step, sync, ev, count):
-    """count launches, one event between each: (average ms, median ms) per launch"""
-    sync()
-    for i in range(count):
-        ev.record(i)
-        step()
-    ev.record(count)
-    sync()
-    per = [ev.ms(i, i + 1) for i in range(count)]
-    return ev.ms(0, count) / count, float(np.median(per))
+
+
+
 
 
 # ------------------------------------------------------------------------------------ CPU legs
@@ -147,8 +98,6 @@ def parity_bound(n, k, against="oracle"):
     return factor * k * float(np.sqrt(n)) * 2.220446049250313e-16  # eps = 2^-52
 
 
-def _maxrel(a, b):
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
 def _ref_solve(O, name, A, b, k, dinv, threads=1):
@@ -377,384 +326,36 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
     return base, ref, parity
 
 
-def live_traffic(grid, variant):
-    """HBM-side bytes per launch of the SpMV kernel(s) of this operator, measured in THIS job: two child processes
-    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, HBM section: on
-    gfx950 FETCH_SIZE reports half the bytes of a wide streaming read -> doubled; both in KB) run the same operator
-    through tools/prof_spmv.py.  Called BEFORE this process touches the GPU: with a second process holding a context
-    on the device a counter pass takes minutes instead of seconds.  Returns ({kernel name: {...}}, None) or
-    (None, reason): no profiler, a profiler already attached to this process, a time-out -- the caller then falls
-    back to the committed passes."""
-    import csv
-    import glob
-    import shutil
-    import tempfile
-    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
-        return None, "rocprofv3 not found"
-    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or \
-            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None, "this process runs under a profiler"
-    tmp = tempfile.mkdtemp(prefix="psp_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    vals = {}
-    try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "tools", "prof_spmv.py"), "--reps", "3", "--grid", "%d,%d,%d" % grid,
-                   "--variant", str(variant)]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=90)
-            if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s exited with %d" % (ctr, r.returncode)
-            acc = {}
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    name = row.get("Kernel_Name", "")
-                    if "_spmv_" in name and row.get("Counter_Name") == ctr:
-                        acc.setdefault(name, []).append(float(row["Counter_Value"]))
-            if not acc:
-                return None, "no %s samples of an SpMV kernel" % ctr
-            for name, v in acc.items():
-                vals.setdefault(name, {})[ctr] = sum(v) / len(v)
-        # third pass (round 3, profiles/r3_modes.txt): what differs between a fast and a slow process of the same launch
-        # is not bytes, clocks or the latency of a memory request but HOW MANY read requests the L2s keep in flight:
-        # TCC_EA0_RDREQ_LEVEL / TCC_CYCLE (reads in flight, summed over the channels) and RDREQ_LEVEL / RDREQ (cycles per
-        # request), with the kernel's duration in that process.  Best effort: a failure only drops the field.
-        try:
-            grp = ["TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_sum", "TCC_CYCLE_sum", "GRBM_GUI_ACTIVE"]
-            outd = os.path.join(tmp, "mode")
-            cmd = [prof, "--pmc"] + grp + ["--output-format", "csv", "-d", outd, "--", sys.executable,
-                                           os.path.join(ROOT, "tools", "prof_spmv.py"), "--reps", "5", "--grid",
-                                           "%d,%d,%d" % grid, "--variant", str(variant)]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
-            if r.returncode == 0:
-                acc, dur = {}, {}
-                for f in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
-                    for row in csv.DictReader(open(f)):
-                        name = row.get("Kernel_Name", "")
-                        if "_spmv_" in name:
-                            acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                            dur.setdefault(name, {})[row.get("Dispatch_Id")] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
-                for name, c in acc.items():
-                    m = {k: sum(v) / len(v) for k, v in c.items()}
-                    d = sorted(dur[name].values())
-                    if m.get("TCC_EA0_RDREQ_sum") and m.get("TCC_CYCLE_sum"):
-                        vals.setdefault(name, {})["mode"] = {
-                            "kernel_ms_in_that_process": d[len(d) // 2],
-                            # both are sums over the 128 channel instances: their ratio is the average per channel
-                            "ea_reads_in_flight_per_channel": m["TCC_EA0_RDREQ_LEVEL_sum"] / m["TCC_CYCLE_sum"],
-                            "ea_read_latency_tcc_cycles": m["TCC_EA0_RDREQ_LEVEL_sum"] / m["TCC_EA0_RDREQ_sum"],
-                            "gpu_cycles": m.get("GRBM_GUI_ACTIVE"),
-                        }
-        except (OSError, subprocess.SubprocessError, ValueError, KeyError):
-            pass
-    except (OSError, subprocess.SubprocessError, ValueError) as e:
-        return None, "%s: %s" % (type(e).__name__, e)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    out = {}
-    for name, v in vals.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            out[name] = {"bytes": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KB": v["FETCH_SIZE"],
-                         "WRITE_SIZE_KB": v["WRITE_SIZE"], "fetch_correction": 2.0}
-            if "mode" in v:
-                out[name]["mode_counters"] = v["mode"]
-    return (out, None) if out else (None, "counters incomplete")
 
 
-def gpu_clocks():
-    """rocm-smi, called while ~1 s of SpMV launches is in flight: which clock / power state the numbers
-    of this run come from (runs land in a faster and a slower mode per box)."""
-    try:
-        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp",
-                            "--json"],
-                           capture_output=True, text=True, timeout=20)
-        txt = p.stdout.strip()
-        try:
-            d = json.loads(txt)
-            card = d.get("card0", d)
-            keep = {}
-            for k, v in card.items():
-                kl = k.lower()
-                if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "temperature")):
-                    keep[k] = v
-            return keep or {"raw": txt[:400]}
-        except ValueError:
-            return {"raw": txt[:400] or p.stderr.strip()[:400]}
-    except (OSError, subprocess.SubprocessError) as e:
-        return {"error": str(e)[:200]}
 
 
 # ------------------------------------------------------------------------------------ launcher
 
-METRIC = "CSR SpMV GB/s (7-pt Poisson, % of 8 TB/s HBM peak) + PCG iters/s"
-PARITY_ITERS = 20      # iterations of the in-job parity solves (tol = 0)
-PARITY_TOL = 1e-9      # N-rank solve against the one-GPU solve of the same problem: relres and x checksums
-# The ladder of an N > 1 run started as a plain script: every stage is a FRESH child process (this process never
-# touches the GPU, and a process that has is never re-executed); the first stage that prints a valid line wins.
-#   torch_rccl_ranks     one torch.distributed rank per GPU; halos = RCCL send/recv, reductions = RCCL all-reduce
-#   single_process_rccl  ONE process, device list (psp_csr_poisson_multi); halos = peer copies, reductions = RCCL
-#                        inside the library (ncclCommInitAll)
-#   single_process_fold  the same with the reductions through the fold kernel over peer pointers (no RCCL at all)
-LADDER = ("torch_rccl_ranks", "single_process_rccl", "single_process_fold")
-STAGE_CAP_S = {"torch_rccl_ranks": 300.0, "single_process_rccl": 200.0, "single_process_fold": 200.0}
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
-def _stage_cmd(stage, argv, n):
-    """(command, extra environment) of one ladder stage"""
-    me = os.path.abspath(__file__)
-    if stage == "torch_rccl_ranks":
-        return ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), me] + argv + ["--stage", stage], {})
-    env = {}
-    if stage == "single_process_fold":
-        env = {"PSP_TUNING": "1", "PSP_MULTI_REDUCE": "local"}
-    return [sys.executable, me] + argv + ["--single-process", "--stage", stage], env
 
 
-def _run_stage(cmd, env, timeout_s, log):
-    """run one stage in its own process group; (rc, stdout, stderr tail, wall seconds, timed_out).  On a time-out
-    the whole group is ended -- SIGTERM, then SIGKILL -- by its group id: the ranks are grandchildren."""
-    import signal
-    import tempfile
-    t0 = time.time()
-    with tempfile.TemporaryFile() as fo, tempfile.TemporaryFile() as fe:
-        p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True)
-        timed_out = False
-        last = t0
-        while True:
-            try:
-                p.wait(timeout=5.0)
-                break
-            except subprocess.TimeoutExpired:
-                now = time.time()
-                if now - last >= 30.0:  # a line now and then: a silent job looks hung to whoever runs it
-                    log("... %.0f s" % (now - t0))
-                    last = now
-                if now - t0 > timeout_s:
-                    timed_out = True
-                    for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
-                        try:
-                            os.killpg(p.pid, sig)
-                        except ProcessLookupError:
-                            pass
-                        try:
-                            p.wait(timeout=grace)
-                            break
-                        except subprocess.TimeoutExpired:
-                            continue
-                    break
-        fo.seek(0)
-        fe.seek(0)
-        out = fo.read().decode("utf-8", "replace")
-        err = fe.read().decode("utf-8", "replace")
-    return (p.returncode if p.returncode is not None else -9), out, err[-200000:], time.time() - t0, timed_out  # (_err_tail condenses it)
 
 
-def _err_tail(err, keep=14):
-    """the lines of a failed stage's stderr worth keeping: the exception lines of the ranks (`SomeError: message`, the
-    first few -- the root cause comes first -- and the last), injected-failure notes, then the end of the stream"""
-    import re
-    lines = [l for l in err.strip().splitlines() if l.strip()]
-    pat = re.compile(r"\b\w*(Error|Exception)\b: \S")
-    hits = [l.strip()[:300] for k, l in enumerate(lines)
-            if (pat.search(l) or "injected failure" in l or (k and lines[k - 1].strip() == "Last error:"))  # (RCCL's own reason)
-            and "ChildFailedError" not in l and "error_file" not in l]
-    seen, uniq = set(), []
-    for l in hits:
-        if l not in seen:
-            seen.add(l)
-            uniq.append(l)
-    head = uniq[:4] + [l for l in uniq[-2:] if l not in uniq[:4]]
-    return (head + lines[-max(2, keep - len(head)):])[:keep + 2]
 
 
-def orchestrate(a, argv):
-    """`python bench.py --gpus N` (N > 1) called as a plain script.  Runs the ladder inside `--deadline` seconds, prints
-    ONE JSON line -- the winning stage's, with `launcher` saying which stage produced it and what the earlier ones
-    died of -- or, when every stage failed, an error line (value null) and a non-zero exit code."""
-    t_start = time.time()
-    stages = [st for st in (a.ladder.split(",") if a.ladder else LADDER)]
-    for st in stages:
-        if st not in LADDER:
-            raise SystemExit("unknown ladder stage %r (known: %s)" % (st, ", ".join(LADDER)))
-
-    def log(msg):
-        print("[bench ladder] " + msg, file=sys.stderr, flush=True)
-
-    failed = []
-    for k, stage in enumerate(stages):
-        remaining = a.deadline - (time.time() - t_start) - 5.0
-        cap = a.stage_timeout if a.stage_timeout > 0 else STAGE_CAP_S[stage]
-        # the last stage may use whatever is left; earlier ones leave room for those behind them
-        budget = remaining if k == len(stages) - 1 else min(cap, remaining - 45.0 * (len(stages) - 1 - k))
-        if a.stage_timeout > 0:
-            budget = min(a.stage_timeout, remaining)
-        if budget < 15.0:
-            failed.append({"stage": stage, "rc": None, "reason": "skipped: %.0f s left of the %.0f s deadline"
-                           % (max(remaining, 0.0), a.deadline)})
-            continue
-        cmd, extra = _stage_cmd(stage, argv, a.gpus)
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.update(extra)
-        log("stage %s (time-out %.0f s)" % (stage, budget))
-        rc, out, err, wall, timed_out = _run_stage(cmd, env, budget, log)
-        lines = [l for l in out.strip().splitlines() if l.startswith("{")]
-        rec = None
-        if lines:
-            try:
-                rec = json.loads(lines[-1])
-            except ValueError:
-                rec = None
-        if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
-            rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": stages,
-                               "deadline_s": a.deadline, "total_wall_s": time.time() - t_start}
-            print(json.dumps(rec), flush=True)
-            return 0
-        reason = ("timed out after %.0f s" % wall) if timed_out else (
-            (rec or {}).get("error") or "exit code %d" % rc)
-        tail = _err_tail(err)
-        failed.append({"stage": stage, "rc": rc, "reason": reason, "wall_s": wall, "stderr_tail": tail})
-        log("stage %s failed: %s" % (stage, reason))
-        for l in tail:
-            log("    " + l[:300])
-    print(json.dumps({"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": a.gpus, "steps": a.steps,
-                      "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
-                      "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "error": "every stage of the launch ladder failed",
-                      "launcher": {"stage": None, "fallback_from": failed, "ladder": stages, "deadline_s": a.deadline,
-                                   "total_wall_s": time.time() - t_start}}), flush=True)
-    return 1
 
 
-def peer_matrix(L, ndev):
-    """pre-flight: can device i reach device j's memory directly (psp_peer_access; no context is created)"""
-    m = []
-    for i in range(ndev):
-        row = []
-        for j in range(ndev):
-            c = C.c_int(-1)
-            row.append(c.value if L.psp_peer_access(i, j, C.byref(c)) == 0 else -1)
-        m.append(row)
-    return m
 
 
-def link_topology():
-    """pre-flight: how the GPUs are wired (rocm-smi --showtopotype: XGMI / PCIE per pair), best effort"""
-    try:
-        p = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=20)
-        return json.loads(p.stdout)
-    except (OSError, subprocess.SubprocessError, ValueError) as e:
-        return {"error": str(e)[:200]}
 
 
-def provenance(L):
-    """which sources the library that ran was built from (tests/test_capi_symbols.py holds the two equal)"""
-    out = {"build_id": L.psp_build_id().decode()}
-    try:
-        import __graft_entry__ as G
-        out["source_hash"] = G.source_hash()
-        out["match"] = out["build_id"] == out["source_hash"]
-    except Exception as e:  # noqa: BLE001 - the sources may not lie next to an installed library
-        out["source_hash"] = None
-        out["match"] = None
-        out["note"] = str(e)[:120]
-    return out
 
 
-def rel_diff(a, b):
-    return abs(a - b) / max(abs(a), abs(b), 1e-300)
 
 
-def parity_object(n1, nr, what):
-    """`parity_vs_n1`: the N-rank Jacobi-PCG against the one-GPU solve of the same system after PARITY_ITERS
-    iterations (tol = 0): the recurred residual and two checksums of x.  The two differ by the order of the
-    reductions only (<= 1e-13 on the probes)."""
-    d = {k: rel_diff(n1[k], nr[k]) for k in ("relres", "x_dot_b", "x_dot_x")}
-    worst = max(d.values())
-    return {"iters": PARITY_ITERS, "n1": n1, what: nr, "rel_diff": d, "max_rel_diff": worst, "tol": PARITY_TOL,
-            "same_info_iter": n1["info_iter"] == nr["info_iter"], "ok": bool(worst <= PARITY_TOL and
-                                                                               n1["info_iter"] == nr["info_iter"])}
 
 
-def pcg_single(L, check, dev, A, n, iters, sync, parity=False):
-    """Jacobi-PCG through the library's device-resident loop: b = A*ones, x0 = 0, tol = 0 (exactly
-    `iters` iterations; ||b|| and r = b - A x0 are inside the timed region).  parity: the warm-up solve runs
-    PARITY_ITERS iterations and leaves (relres, x.b, x.x) as the third result."""
-    K = dev.DeviceJacobi(A)
-    aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
-    bb, xb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
-    ones = np.ones(1 << 24)
-    for k in range(0, n, ones.size):  # chunked: n may be 2^30
-        check(L.psp_memcpy_h2d(xb.ptr + 8 * k, ones.ctypes.data, 8 * min(ones.size, n - k)))
-    A.matvec_dev(xb.ptr, bb.ptr)
-    sync()
-    par = None
-    for kk in ((PARITY_ITERS if parity else 2), iters):  # first call = warm-up
-        xb.zero()
-        info, it, rr = C.c_int(), C.c_int(), C.c_double()
-        sync()
-        t = time.perf_counter()
-        check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it),
-                            C.byref(rr), None))
-        sync()
-        dt = time.perf_counter() - t
-        if parity and par is None:
-            ob = dev.DeviceBuffer(2)
-            check(L.psp_k_dot(n, xb.ptr, bb.ptr, ob.ptr))
-            check(L.psp_k_dot(n, xb.ptr, xb.ptr, ob.ptr + 8))
-            sync()
-            v = ob.download()
-            ob.free()
-            par = {"relres": rr.value, "x_dot_b": float(v[0]), "x_dot_x": float(v[1]),
-                   "info_iter": [info.value, it.value]}
-    del aop, kop, K
-    bb.free()
-    xb.free()
-    if parity:
-        return dt / iters, (info.value, it.value, rr.value), par
-    return dt / iters, (info.value, it.value, rr.value)
 
 
-def strong_n1_leg(L, check, dev, grid, iters):
-    """the whole strong-scaling problem on ONE GPU (index-free operator, psp_csr_poisson_big): SpMV
-    time and Jacobi-PCG iterations/s -- the denominator of `vs_n1`"""
-    def sync():
-        check(L.psp_synchronize())
-    nx, ny, nz = grid
-    A = dev.DeviceCSR.poisson_big(nx, ny, nz)
-    n, nnz = A.shape[0], A.nnz
-    x, y = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
-    chunk = np.random.default_rng(0).standard_normal(1 << 24)
-    for k in range(0, n, chunk.size):
-        check(L.psp_memcpy_h2d(x.ptr + 8 * k, chunk.ctypes.data, 8 * min(chunk.size, n - k)))
-    ev = Events(L, check, 12)
-    timed_launches(lambda: A.matvec_dev(x.ptr, y.ptr), sync, ev, 3)
-    avg, med = timed_launches(lambda: A.matvec_dev(x.ptr, y.ptr), sync, ev, 10)
-    kern, info = A.kernel_info()
-    x.free()
-    y.free()
-    s_per_it, chk, par = pcg_single(L, check, dev, A, n, iters, sync, parity=True)
-    kb = kernel_bytes(kern, info, n, nnz)
-    out = {"grid": [nx, ny, nz], "n": n, "nnz": nnz, "kernel": kern, "spmv_ms": med,
-           "spmv_GBps": kb / (med * 1e-3) / 1e9, "spmv_frac_of_peak": kb / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "pcg_iters_per_s": 1.0 / s_per_it, "pcg_check": {"info": chk[0], "iter": chk[1], "relres": chk[2]},
-           "parity_solve": par,  # after PARITY_ITERS iterations: what an N-rank solve of the same system is held to
-           "path": "psp_pcg_dev (single-GPU device-resident loop)"}
-    A.close()
-    check(L.psp_trim())
-    return out
 
 
 def mtx_leg(spec, steps=50, minres_iters=200):
@@ -880,141 +481,8 @@ def mtx_main(a):
     return 1 if "error" in out else 0
 
 
-def dry_strong_n1(test_backend, grid):
-    """CPU dry run of the launcher (tests): the parity reference = the same system solved by the test backend without
-    a partition (SingleComm), PARITY_ITERS iterations"""
-    import importlib
-    from pysparse_amd import distributed as D
-    mod, fn = test_backend.split(":")
-    be, make_local = getattr(importlib.import_module(mod), fn)()
-    nx, ny, nz = grid
-    A = D.DistCSR.poisson(nx, ny, nz, D.SingleComm(), be, make_local)
-    n = A.n_local
-    ones = A.new_ext()
-    ones.fill_(1.0)
-    b = be.zeros(n)
-    A.matvec(ones, b)
-    dinv = be.zeros(n)
-    dinv.fill_(1.0 / (6.0 if nz > 0 else 4.0))
-    x = be.zeros(n)
-    res = D.dist_pcg(A, b, x, 0.0, PARITY_ITERS, dinv)
-    return {"grid": [nx, ny, nz], "n": n, "path": "test backend, world size 1",
-            "parity_solve": {"relres": res[2], "x_dot_b": float(be.dot(x, b)[0]), "x_dot_x": float(be.dot(x, x)[0]),
-                             "info_iter": [res[0], res[1]]}}
 
 
-def single_process_main(a):
-    """--single-process: the N-GPU job as ONE process through the C ABI's device-list variant
-    (psp_csr_poisson_multi: one rank per entry of the list, peer copies for the ghost planes, RCCL for the two
-    packed reductions of an iteration) -- what `krylov.pcg(A, ...)` of a drop-in script runs when A was made with
-    devices=[...].  Same workload and the same JSON line as the torch.distributed launch (strong scaling at 1024^3
-    for N > 1).  --share-gpu lists device 0 N times: a rehearsal on a one-GPU box, not a measurement."""
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-    from pysparse_amd import _capi, device as dev
-    L, check = _capi.lib(), _capi.check
-    N = a.gpus
-    devices = [0] * N if a.share_gpu else list(range(N))
-    if a.grid:
-        nx, ny, nz = (int(t) for t in a.grid.split(","))
-    else:
-        nx = ny = nz = 1024 if N > 1 else 512
-    preflight = {"device_count": L.psp_device_count(), "peer_access": peer_matrix(L, 1 if a.share_gpu else N)}
-    if N > 1 and not a.share_gpu:
-        preflight["link_topology"] = link_topology()
-    # the 1-GPU end of the strong-scaling ratio and of the parity check: the whole problem on device 0, first
-    strong_n1 = None
-    if N > 1 and not a.no_strong_n1:
-        check(L.psp_set_device(0))
-        strong_n1 = strong_n1_leg(L, check, dev, (nx, ny, nz), min(a.pcg_iters, 24))
-    A = dev.DeviceCSR.poisson_multi(nx, ny, nz, devices=devices)
-    n, nnz = A.shape[0], A.nnz
-    ranks, distinct, rccl_used = A.multi_info()
-    ms = C.c_double()
-    t0 = time.perf_counter()
-    check(L.psp_csr_multi_spmv_time(A._h, a.warmup, a.steps, C.byref(ms)))
-    wall = time.perf_counter() - t0
-    kbytes = 8 * 7 * n + 2 * n + 16 * n  # csr_spmv_w4 on the 7-point operator (kernel_bytes)
-    if nz == 0:
-        kbytes = 8 * 5 * n + 2 * n + 16 * n
-    # the pieces of that product and of an iteration on their own (psp_csr_multi_phase_time)
-    phases = {}
-    for what, name in ((0, "halo_ms"), (1, "spmv_local_ms"), (2, "allreduce_ms")):
-        v = C.c_double()
-        check(L.psp_csr_multi_phase_time(A._h, what, 2, max(5, min(a.steps, 20)), C.byref(v)))
-        phases[name] = v.value
-    phases["spmv_with_halo_ms"] = ms.value
-    phases["allreduce_us"] = phases["allreduce_ms"] * 1e3
-    if phases["halo_ms"] > 0:
-        phases["overlap_frac"] = max(0.0, min(1.0, (phases["halo_ms"] + phases["spmv_local_ms"] - ms.value)
-                                              / phases["halo_ms"]))
-    # Jacobi-PCG iterations/s: tol = 0 runs exactly k iterations; two runs, the difference cancels the host
-    # transfers of b and x and the set-up products (the vectors cross PCIe once per solve)
-    K = dev.DeviceJacobi(A)
-    ones = np.ones(n)
-    b = np.empty(n)
-    A.matvec(ones, b)
-    del ones
-    # in-job parity: PARITY_ITERS iterations against the one-GPU solve of the same system (strong_n1)
-    parity = None
-    x = np.zeros(n)
-    rp = dev.pcg(A, b, x, 0.0, PARITY_ITERS, K)
-    mine = {"relres": rp[2], "x_dot_b": float(np.dot(x, b)), "x_dot_x": float(np.dot(x, x)), "info_iter": [rp[0], rp[1]]}
-    if strong_n1 is not None:
-        parity = parity_object(strong_n1["parity_solve"], mine, "n_ranks")
-    k1, k2 = 4, 4 + max(8, min(a.pcg_iters, 64))
-    # the difference of two solves of k1 and k2 iterations (best of three each, after a warm-up solve): on a problem
-    # of a few hundred thousand rows the host-side noise of a single pair can exceed the k2 - k1 iterations themselves
-    times = {}
-    for k in (k1, k1, k2, k1, k2, k1, k2):
-        x = np.zeros(n)
-        t = time.perf_counter()
-        res = dev.pcg(A, b, x, 0.0, k, K)
-        dt = time.perf_counter() - t
-        times[k] = min(times.get(k, dt), dt) if k in times or k != k1 else dt
-    if times[k2] > times[k1]:
-        s_per_iter = (times[k2] - times[k1]) / (k2 - k1)
-    else:  # still inside the noise: price the whole longer solve (an upper bound of the iteration time)
-        s_per_iter = times[k2] / k2
-    reductions = "rccl" if rccl_used else ("none" if ranks == 1 else "fold kernel over peer pointers")
-    out = {
-        "metric": METRIC,
-        "value": kbytes / (ms.value * 1e-3) / 1e9, "unit": "GB/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms.value, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "3D Poisson 7-pt %dx%dx%d fp64 csr_mat, y = A x; z-slab row partition over a device list, "
-                               "ONE process (psp_csr_poisson_multi)" % (nx, ny, nz),
-                   "n": n, "nnz": nnz, "rows_per_gpu": n // N, "parallelism": "row-range x%d, single process" % N,
-                   "scaling_mode": "strong", "devices": devices},
-        "launcher_kind": "single process, C ABI device list",
-        "stage": a.stage or None,
-        "transport": {"halo": "hipMemcpyPeerAsync on a copy stream per rank" if distinct > 1 else
-                              "device-to-device copies (ranks share a GPU)",
-                      "reductions": reductions},
-        "ranks": ranks, "distinct_devices": distinct, "rccl_ranks": ranks if rccl_used else 0,
-        "reductions": reductions,
-        "pct_hbm_peak": 100.0 * kbytes / (ms.value * 1e-3) / 1e9 / (HBM_PEAK_GBPS * max(distinct, 1)),
-        "pcg_iters_per_s": 1.0 / s_per_iter,
-        "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k2 - k1,
-                      "path": "psp_pcg on a multi-device matrix (psp_multi.hip)", "solve_s": times},
-        "phases": phases,
-        "preflight": preflight,
-        "parity_solve": mine,
-        "provenance": provenance(L),
-        "wall_s_spmv_leg": wall,
-    }
-    if strong_n1 is not None:
-        out["strong_n1"] = strong_n1
-        out["vs_n1"] = (1.0 / s_per_iter) / strong_n1["pcg_iters_per_s"]
-    if parity is not None:
-        out["parity_vs_n1"] = parity
-        if not parity["ok"]:
-            out["error"] = "parity_vs_n1 failed: max relative difference %.3e > %.1e" % (parity["max_rel_diff"], PARITY_TOL)
-    if a.share_gpu:
-        out["dry_run"] = "%d ranks sharing device 0 in one process: a rehearsal of the N > 1 path, NOT a measurement" % N
-    print(json.dumps(out), file=real_stdout, flush=True)
-    return 1 if "error" in out else 0
 
 
 def main():
@@ -1089,142 +557,43 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not a.stage:
         # started as one rank of N by somebody else's `torch.distributed.run` (the driver's scaling run), not by the
         # ladder above: this rank guards itself
-        return guarded_rank(a, real_stdout)
+        return guarded_rank(a, real_stdout, run_body)
     return run_body(a, real_stdout)
 
 
-class RankGuard:
-    """One rank of an N-rank job that was NOT started by this file's ladder (the driver launches `python -m
-    torch.distributed.run ... bench.py --gpus N` itself): a hang in communicator set-up or a failing rank must still end
-    in ONE JSON line.  A watchdog thread per rank:
-      * `--rank-deadline` seconds without the job finishing, or an exception in the rank, or another rank's failure note
-        (a file keyed by the rendezvous port) -> ranks other than 0 leave QUIETLY with code 0 (a non-zero code would make
-        the launcher tear rank 0 down before it can answer); rank 0 waits a moment for their GPUs to be released, then
-        runs the rest of the ladder -- `single_process_rccl`, `single_process_fold` -- as FRESH child processes (this
-        process has touched the GPU and is never re-executed) and prints the winner's line with `launcher.fallback_from`
-        saying what the torch ranks died of, or the error line;
-      * SIGTERM from the launcher (some rank crashed hard): rank 0 prints the error line at once."""
-
-    def __init__(self, a, real_stdout):
-        import threading
-        self.a, self.out = a, real_stdout
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.flag = "/tmp/psp_bench_fail_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
-        self.t0 = time.time()
-        self.done = threading.Event()
-        self.lock = threading.Lock()
-        self.fired = False
-        self.thread = threading.Thread(target=self._watch, daemon=True)
-
-    def start(self):
-        import signal
-        try:
-            if self.rank == 0 and os.path.exists(self.flag):
-                os.remove(self.flag)
-        except OSError:
-            pass
-        if self.rank == 0:
-            # SIGTERM is BLOCKED in this thread (and in every thread started from now on) and picked up by the watchdog with
-            # sigtimedwait: a Python-level handler would never run while the main thread sits inside a collective
-            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
-        self.thread.start()
-
-    def _watch(self):
-        import signal
-        while not self.done.is_set():
-            if self.rank == 0:
-                if signal.sigtimedwait({signal.SIGTERM}, 2.0) is not None:
-                    self._terminated()
-            elif self.done.wait(2.0):
-                break
-            if time.time() - self.t0 > self.a.rank_deadline:
-                self.fail("no result after %.0f s (--rank-deadline): a rank hangs" % self.a.rank_deadline)
-            if os.path.exists(self.flag):
-                try:
-                    why = open(self.flag).read()[:300]
-                except OSError:
-                    why = "another rank failed"
-                self.fail(why)
-
-    def _error_line(self, failed, msg):
-        a = self.a
-        return {"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic", "error": msg,
-                "launcher": {"stage": None, "fallback_from": failed, "ladder": list(LADDER), "started_by": "external launcher"}}
-
-    def _terminated(self):
-        with self.lock:
-            if self.fired:
-                return
-            self.fired = True
-        print(json.dumps(self._error_line([{"stage": "torch_rccl_ranks", "rc": None, "reason": "SIGTERM from the launcher "
-                                             "(another rank ended abnormally) after %.0f s" % (time.time() - self.t0)}],
-                                           "the launcher ended the job")), file=self.out, flush=True)
-        os._exit(1)
-
-    def fail(self, reason):
-        """called from the watchdog thread or from the rank's own exception handler; never returns"""
-        with self.lock:
-            if self.fired:
-                time.sleep(1e6)
-            self.fired = True
-        print("[bench rank %d] %s" % (self.rank, reason), file=sys.stderr, flush=True)
-        if self.rank != 0:
-            try:
-                with open(self.flag, "w") as f:
-                    f.write("rank %d: %s" % (self.rank, reason))
-            except OSError:
-                pass
-            os._exit(0)
-        failed = [{"stage": "torch_rccl_ranks", "rc": None, "reason": reason, "wall_s": time.time() - self.t0}]
-        time.sleep(6.0)  # the other ranks see the note / their own deadline and release their GPUs
-        argv = [t for t in sys.argv[1:]]
-        for stage in LADDER[1:]:
-            cmd, extra = _stage_cmd(stage, argv, self.world)
-            env = {k: v for k, v in os.environ.items()
-                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
-            env.update(extra)
-            budget = self.a.stage_timeout if self.a.stage_timeout > 0 else min(150.0, STAGE_CAP_S[stage])
-            rc, out, err, wall, timed_out = _run_stage(cmd, env, budget, lambda m: print("[bench rank 0] " + m, file=sys.stderr, flush=True))
-            lines = [l for l in out.strip().splitlines() if l.startswith("{")]
-            rec = None
-            if lines:
-                try:
-                    rec = json.loads(lines[-1])
-                except ValueError:
-                    rec = None
-            if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
-                rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": list(LADDER),
-                                   "started_by": "external launcher (torch.distributed.run); rank 0 ran the fall-back "
-                                                 "stages as fresh child processes"}
-                print(json.dumps(rec), file=self.out, flush=True)
-                os._exit(0)
-            failed.append({"stage": stage, "rc": rc, "reason": ("timed out after %.0f s" % wall) if timed_out else
-                           ((rec or {}).get("error") or "exit code %d" % rc), "wall_s": wall, "stderr_tail": _err_tail(err)})
-        print(json.dumps(self._error_line(failed, "every stage of the launch ladder failed")), file=self.out, flush=True)
-        os._exit(1)
-
-    def finish(self):
-        import signal
-        self.done.set()
-        if self.rank == 0:
-            self.thread.join(timeout=5.0)
-            signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})
 
 
-def guarded_rank(a, real_stdout):
-    g = RankGuard(a, real_stdout)
-    g.start()
-    try:
-        rc = run_body(a, real_stdout)
-    except BaseException as e:  # noqa: BLE001 - whatever the rank died of becomes the reason
-        import traceback
-        traceback.print_exc()
-        g.fail("%s: %s" % (type(e).__name__, str(e)[:300]))
-    g.finish()
-    return rc
+
+
+def timed_region(step, sync, ev, warmup, steps):
+    """THE timed region of the contract.  `warmup` untimed steps, then exactly `steps` steps bracketed by sync() on both
+    sides (N = 1: psp_synchronize; N > 1: device synchronise + barrier + device synchronise).  Returns (wall seconds of the
+    K steps, milliseconds between two HIP events recorded around the same K launches on the stream the library launches
+    on -- the wall time in ms when there is no device, i.e. in the gloo dry runs).  Nothing else happens in here: no
+    allocation, no side leg, no oracle (tests/test_bench_region.py)."""
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    if ev:
+        ev.record(0)
+    for _ in range(steps):
+        step()
+    if ev:
+        ev.record(1)
+    sync()
+    wall = time.perf_counter() - t0
+    return wall, (ev.ms(0, 1) if ev else wall * 1e3)
+
+
+def headline(kbytes_job, kbytes_launch, wall, ev_ms, steps):
+    """`value` / `ms_per_step` / `roofline.achieved` from what timed_region measured: value = bytes the kernels of the
+    WHOLE JOB have to move per step / wall time per step (max over ranks); achieved = one GPU's bytes per launch / that
+    kernel's average launch over the same K launches (HIP events)"""
+    kern_ms = ev_ms / steps
+    achieved = kbytes_launch / (kern_ms * 1e-3) / 1e9
+    return {"value": kbytes_job / (wall / steps) / 1e9, "ms_per_step": wall * 1e3 / steps, "avg_launch_ms": kern_ms,
+            "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS}
 
 
 def run_body(a, real_stdout):
@@ -1350,106 +719,29 @@ def run_body(a, real_stdout):
         def sync():
             check(L.psp_synchronize())
 
-    # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize
+    # ---- the timed region (timed_region above): W warm-up steps, then exactly K steps between barrier + synchronize
     ev = None if dry else Events(L, check, a.steps + 1)
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    if ev:
-        ev.record(0)
-    for _ in range(a.steps):
-        step()
-    if ev:
-        ev.record(1)
-    sync()
-    wall = time.perf_counter() - t0
+    wall, ev_ms = timed_region(step, sync, ev, a.warmup, a.steps)
     if dry:
-        ev_ms = med_ms = wall * 1e3
+        med_ms = ev_ms
         kernel, kinfo = "test-backend", {}
     else:
-        ev_ms = ev.ms(0, 1)
         # per-launch median of the same K launches (SURVEY 8d protocol), outside the timed region
         _, med_ms = timed_launches(step, sync, ev, a.steps)
         kernel, kinfo = Aloc.kernel_info()
     kbytes_loc = kernel_bytes(kernel, kinfo, n_loc, nnz_loc)
 
-    # ---- beside it (N = 1): the other SpMV kernels on the SAME operator.  csr_spmv_w4 (default for a
-    # stencil operator) reads no column indices; csr_spmv_w3 is what an arbitrary banded csr_mat gets
-    # (16-bit chunk-local columns); csr_spmv_w2 streams int32 col + fp64 val exactly as stored.
-    kernels = None
-    if not use_dist and a.variant < 0 and not a.no_kernels:
-        kernels = []
-        for var in (W3_VARIANT, W2_VARIANT):
-            A.set_variant(var)
-            kn, ki = A.kernel_info()
-            timed_launches(step, sync, ev, 3)
-            avg, med = timed_launches(step, sync, ev, a.steps)
-            own = kernel_bytes(kn, ki, n_loc, nnz_loc)
-            kernels.append({"kernel": kn, "avg_launch_ms": avg, "median_launch_ms": med,
-                            "bytes_per_launch": own, "GBps": own / (avg * 1e-3) / 1e9,
-                            "frac": own / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                            "csr_model_GBps": csr_model_bytes(n_loc, nnz_loc) / (avg * 1e-3) / 1e9,
-                            "csr_model_frac": csr_model_bytes(n_loc, nnz_loc) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS})
-        A.set_variant(-1)
-
-    # ---- beside it (N = 1): the placement levels (profiles/r4_modes.txt).  What a launch takes depends
-    # on where in device memory its operands lie; `value` above is THIS job's first allocation, as any job's would be.  Here y
-    # is re-allocated six times (pads of odd sizes in between, everything stays alive until the end) and the same launch is
-    # timed on each: the spread a user sees, in every bench line.  Reported only -- never used for `value` / `roofline`.
-    placement = None
-    if not use_dist and not dry and not a.no_kernels:
-        keep, ms_list = [], []
-        try:
-            for j in range(6):
-                keep.append(dev.DeviceBuffer((37 + 101 * j) * (1 << 17) + 512 * j))  # (37 + 101 j) MiB + 4 j KiB
-                yj = dev.DeviceBuffer(n_loc)
-                keep.append(yj)
-                fj = lambda yj=yj: A.matvec_dev(xb.ptr, yj.ptr)  # noqa: E731
-                timed_launches(fj, sync, ev, 3)
-                ms_list.append(timed_launches(fj, sync, ev, min(a.steps, 20))[0])
-            placement = {"what": "the same launch with y re-allocated six times (x and the operator stay): where the operands lie "
-                                 "decides up to 8 % (profiles/r4_modes.txt); `value` is the job's FIRST allocation",
-                         "y_realloc_avg_launch_ms": ms_list, "first_allocation_ms": None,
-                         "best_ms": min(ms_list), "worst_ms": max(ms_list),
-                         "best_frac_of_peak": kbytes_loc / (min(ms_list) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "worst_frac_of_peak": kbytes_loc / (max(ms_list) * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        except Exception as e:  # noqa: BLE001 - a reported extra (e.g. out of memory on a small device), never fatal
-            placement = {"error": str(e)[:200]}
-        for bfr in keep:
-            bfr.free()
-        del keep
-
-    # ---- beside it (N = 1): what this GPU's memory system gives the library's own streaming kernels in
-    # the same run ("a measured device ceiling from the same run") -- a read-only pass (the dot
-    # product kernel: 16 n bytes) and a read-read-write pass (y = x o dinv: 24 n bytes) over the same vectors
-    ceiling = None
-    if not use_dist and not dry and not a.no_kernels:
-        zb = dev.DeviceBuffer(n_loc)
-        ob = dev.DeviceBuffer(1)
-        check(L.psp_k_jacobi(n_loc, xb.ptr, xb.ptr, zb.ptr))  # fill zb
-
-        def dot_step():
-            check(L.psp_k_dot(n_loc, xb.ptr, zb.ptr, ob.ptr))
-
-        def triad_step():
-            check(L.psp_k_jacobi(n_loc, xb.ptr, zb.ptr, yb.ptr))
-        ceiling = {"what": "library streaming kernels on vectors of n = %d fp64, same process" % n_loc}
-        for name, fn, nbytes in (("read_only_dot", dot_step, 16 * n_loc), ("read2_write1", triad_step, 24 * n_loc)):
-            timed_launches(fn, sync, ev, 3)
-            avg, med = timed_launches(fn, sync, ev, min(a.steps, 50))
-            ceiling[name] = {"bytes": nbytes, "avg_launch_ms": avg, "GBps": nbytes / (avg * 1e-3) / 1e9}
-        zb.free()
-        ob.free()
-        # the access shape of the dominant kernel as a plain streaming kernel, in this process: 7 read streams + 1
-        # write stream of 1 GiB each (psp_stream_probe; csr_spmv_w4 on the 7-point operator reads 7 value streams
-        # and writes y).  Round 3: processes / boxes differ by up to 8 % on every store-carrying kernel (DESIGN.md
-        # section 6, profiles/r3_modes.txt); this probe moves with them, so it names the mode a number comes from.
-        import ctypes as _C
-        pa, pm = _C.c_float(), _C.c_float()
-        check(L.psp_stream_probe(7, 1, 1 << 30, 10, _C.byref(pa), _C.byref(pm)))
-        ceiling["read7_write1_probe"] = {"bytes": 8 << 30, "avg_launch_ms": pa.value, "min_launch_ms": pm.value,
-                                         "GBps": (8 << 30) / (pa.value * 1e-3) / 1e9}
+    # ---- beside it (N = 1; bench_legs.py): the other SpMV kernels on the SAME operator, the placement sweep, the
+    # streaming ceilings of this job.  Reported only -- none of them feeds `value` / `roofline.achieved`.
+    kernels = placement = ceiling = None
+    if not use_dist and not a.no_kernels:
+        ctx = {"L": L, "check": check, "dev": dev, "A": A, "xb": xb, "yb": yb, "n": n_loc, "nnz": nnz_loc, "step": step,
+               "sync": sync, "ev": ev, "steps": a.steps, "kbytes": kbytes_loc}
+        if a.variant < 0:
+            kernels = same_operator_kernels_leg(ctx)
+        if not dry:
+            placement = placement_sweep_leg(ctx)
+            ceiling = stream_ceiling_leg(ctx)
 
     clocks = None
     if not a.no_clocks and not dry:
@@ -1515,29 +807,12 @@ def run_body(a, real_stdout):
         pcg_path = "psp_pcg_dev (single-GPU device-resident loop)"
         parity_mine, phases, preflight = None, None, None
 
-    # ---- beside it (N = 1): the same operator as an sss_mat (examples/poisson_test.py solves with
+    # ---- beside it (N = 1; bench_legs.py): the same operator as an sss_mat (examples/poisson_test.py solves with
     # S = L.to_sss()): y = S x from the strict lower triangle only, and Jacobi-PCG on it
     sss = None
     if not use_dist and not a.no_sss:
-        S = dev.DeviceSSS.poisson(nx, ny, nz)
-
-        def sstep():
-            S.matvec_dev(xb.ptr, yb.ptr)
-        timed_launches(sstep, sync, ev, 3)
-        s_avg, s_med = timed_launches(sstep, sync, ev, a.steps)
-        nnz_lower = S.nnz - n_loc
-        s_per_it, s_chk = pcg_single(L, check, dev, S, n_loc, k, sync)
-        skern, sinfo = S.kernel_info()
-        sown = kernel_bytes(skern, sinfo, n_loc, 2 * nnz_lower + n_loc, nnz_lower)
-        sss = {"kernel": skern, "spmv_ms": s_avg, "median_launch_ms": s_med,
-               # B_sss = 12 nnz_lower + 28 n + 4; the kernel's own format moves `bytes_per_launch`
-               "bytes_per_launch": sown, "spmv_GBps": sown / (s_avg * 1e-3) / 1e9,
-               "frac": sown / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-               "sss_model_GBps": (12 * nnz_lower + 28 * n_loc + 4) / (s_avg * 1e-3) / 1e9,
-               "pcg_iters_per_s": 1.0 / s_per_it,
-               "pcg_check": {"info": s_chk[0], "iter": s_chk[1], "relres": s_chk[2]}}
-        S.close()
-        del S
+        sss = sss_leg({"L": L, "check": check, "dev": dev, "xb": xb, "yb": yb, "n": n_loc, "sync": sync, "ev": ev,
+                       "steps": a.steps, "grid": (nx, ny, nz), "pcg_iters": k})
 
     # ---- N = 1 default run: the 1-GPU end of the strong-scaling target (1024^3 on this GPU)
     if not use_dist and not a.grid and not a.no_strong_n1:
@@ -1560,10 +835,8 @@ def run_body(a, real_stdout):
         n_tot, nnz_tot, kbytes_tot = n_loc, nnz_loc, kbytes_loc
 
     if rank == 0:
-        ms_step = wall * 1e3 / a.steps
-        value = kbytes_tot / (wall / a.steps) / 1e9
-        kern_ms = ev_ms / a.steps
-        achieved = kbytes_loc / (kern_ms * 1e-3) / 1e9  # one GPU, one launch
+        hl = headline(kbytes_tot, kbytes_loc, wall, ev_ms, a.steps)
+        ms_step, value, kern_ms, achieved = hl["ms_per_step"], hl["value"], hl["avg_launch_ms"], hl["achieved"]
         lazy = n_loc >= (1 << 25) or use_dist
         pcg_moved = kbytes_tot + pcg_vector_bytes(n_tot, lazy)
         traffic, traffic_source, traffic_detail = None, None, None
@@ -1656,6 +929,13 @@ def run_body(a, real_stdout):
                 world, a.backend)
         if kernels is not None:
             out["kernels_same_operator"] = kernels
+            # the other reading of "CSR SpMV % of HBM peak" (VERDICT r4 #5 / #8): the kernels that stream the csr_mat's own
+            # col_ind + val arrays (csr_spmv_w6, csr_spmv_w2), priced in SURVEY 8d's bytes -- which is what they move
+            lit = [kk for kk in kernels if kk["kernel"] in ("csr_spmv_w6", "csr_spmv_w2")]
+            if lit:
+                best = max(lit, key=lambda kk: kk["csr_model_frac"])
+                out["roofline"]["csr_model_frac_of_streaming_kernel"] = best["csr_model_frac"]
+                out["roofline"]["streaming_kernel"] = best["kernel"]
         if sss is not None:
             out["sss_mat"] = sss
         if strong_n1 is not None:

@@ -79,6 +79,9 @@ int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds);
  * out again (bit 0: the copy stream's wait for the receiver's own stream, round 4) -- the test that the facility
  * finds what it is there to find.  seed < 0 disarms.  psp_debug_shake_count: spin kernels injected since it was armed.
  * psp_debug_spin: one spin kernel on the calling thread's stream (the torch driver's cut points, distributed.py). */
+/* how many solves the single-kernel loop for mid-size offset-structured systems (psp_mid.hip) has run in this process,
+ * and how many times it handed a solve back to the launch-per-phase loops (tests) */
+int psp_debug_mid_count(long long *solves, long long *fallbacks);
 int psp_debug_shake(long long seed, int min_us, int max_us, unsigned point_mask, unsigned rank_mask, int revert_mask);
 int psp_debug_shake_count(long long *injected);
 int psp_debug_spin(int microseconds);
@@ -90,9 +93,10 @@ int psp_peer_access(int device, int peer, int *can_access);
  * bandwidth-bound product takes depends on which pages of HBM its vector operands occupy (two levels ~8 % apart at
  * 512^3); for the vectors the LIBRARY allocates -- the solvers' work vectors (the reference's solvers own their work
  * array too: pysparse/itsolvers/src/itsolversmodule.c:32-118) and the staging pair of the host-pointer products -- it
- * draws a few candidates once per (device, length), times the handle's own product on each and keeps the best.  Results
- * do not change by a bit.  psp_set_placement(0) turns the draws off (1: on, the default).  psp_placement_info: draws made
- * so far and the milliseconds they took.  psp_place_operands hands the same service to a caller that owns its vectors:
+ * can draw a few candidates once per (device, length), time the handle's own product on each and keep the best.  Results
+ * do not change by a bit.  psp_set_placement(1) turns the draws on; the default is OFF: measured over 11 processes the
+ * product on a drawn pair is 0 ... 4.6 % faster (mean 1.8 %), Jacobi-PCG +0.5 ... +1.7 %, for 60-80 ms per draw
+ * (profiles/r5_placement_ab_*.jsonl).  psp_placement_info: draws made so far and the milliseconds they took.  psp_place_operands hands the same service to a caller that owns its vectors:
  * *y_dev / *x_dev receive zeroed device vectors (nrows / ncols doubles, release with psp_free) chosen for the output /
  * input role of y = A x; report6 (may be NULL): candidates drawn (0: plain allocations -- vectors under 64 MiB, or memory
  * short), best and worst output-role ms, best and worst input-role ms, ms the draw took. */

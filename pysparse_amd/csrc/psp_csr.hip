@@ -976,7 +976,9 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w3(
 // (csr_mat.c:49-54): the same bits as every other kernel.
 constexpr int kW6Runs = 8;
 
-template <int NP, int WPB, bool NTS>
+// PAIRS (as in csr_spmv_w3): a lane takes 2 consecutive nonzeros per load (8 col + 16 val bytes) instead of 4: every load
+// instruction then covers one contiguous run of cache lines; with NTL the value / column streams are non-temporal
+template <int NP, int WPB, bool NTS, bool NTL = false, bool PAIRS = false>
 __global__ __launch_bounds__(64 * WPB) void csr_spmv_w6(
     int chunk0, int nchunks, int stripe, int target, int kmax, int ncols, const int2 *__restrict__ tab,
     const unsigned short *__restrict__ rowoff, const int *__restrict__ col, const int *__restrict__ blist,
@@ -1007,11 +1009,22 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w6(
     i4v c[STEPS];
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      int k = kb + (st * 64 + lane) * 4;
-      k = (k < kmax) ? k : kmax;
-      c[st] = *reinterpret_cast<const i4v *>(col + k);
-      v0[st] = *reinterpret_cast<const d2v *>(val + k);
-      v1[st] = *reinterpret_cast<const d2v *>(val + k + 2);
+      if constexpr (PAIRS) {  // v0 = nonzeros (2 st) * 128 + 2 lane .. + 1, v1 = the same in the next 128
+        int k0 = kb + (2 * st) * 128 + 2 * lane, k1 = k0 + 128;
+        k0 = (k0 < kmax + 2) ? k0 : kmax + 2;
+        k1 = (k1 < kmax + 2) ? k1 : kmax + 2;
+        v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k0));
+        v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k1));
+        const i2v c0 = ldg<NTL>(reinterpret_cast<const i2v *>(col + k0));
+        const i2v c1 = ldg<NTL>(reinterpret_cast<const i2v *>(col + k1));
+        c[st].x = c0.x; c[st].y = c0.y; c[st].z = c1.x; c[st].w = c1.y;
+      } else {
+        int k = kb + (st * 64 + lane) * 4;
+        k = (k < kmax) ? k : kmax;
+        c[st] = ldg<NTL>(reinterpret_cast<const i4v *>(col + k));
+        v0[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k));
+        v1[st] = ldg<NTL>(reinterpret_cast<const d2v *>(val + k + 2));
+      }
     }
     const int blk0 = blist[(size_t)chunk * NB + lane];
     const unsigned short *ro = rowoff + (size_t)chunk * E;
@@ -1041,16 +1054,18 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w6(
         p1[st].y = v1[st].y * x[c[st].w];
       }
     } else {
-      // (first block, slot - first block) of every run, wave-uniform; unused runs can never be chosen
-      int rs[kW6Runs], rb[kW6Runs];
-#pragma unroll
-      for (int r = 0; r < kW6Runs; ++r) {
-        const int i = runs ? __builtin_ctzll(runs) : 0;
-        const int b = __builtin_amdgcn_readlane(blk0, i);
-        rs[r] = (r < nruns) ? b : 0x7fffffff;
-        rb[r] = i - b;
-        runs &= runs - 1;
-      }
+      // (first block, slot - first block) of every run, wave-uniform scalars (named one by one: an array that a lambda
+      // captures by reference ends up in scratch memory -- 48 bytes per lane, 2.8 GB of extra writes per launch at 512^3,
+      // measured); unused runs can never be chosen
+#define PSP_W6_RUN(R)                                                          \
+  const int i##R = runs ? __builtin_ctzll(runs) : 0;                           \
+  const int f##R = __builtin_amdgcn_readlane(blk0, i##R);                      \
+  const int rs##R = (R < nruns) ? f##R : 0x7fffffff;                           \
+  const int rb##R = i##R - f##R;                                               \
+  runs &= runs - 1;
+      PSP_W6_RUN(0) PSP_W6_RUN(1) PSP_W6_RUN(2) PSP_W6_RUN(3) PSP_W6_RUN(4) PSP_W6_RUN(5) PSP_W6_RUN(6) PSP_W6_RUN(7)
+#undef PSP_W6_RUN
+      (void)rs0;
       // --- the chunk's x blocks: 8 lanes per 128-byte block, 8 blocks per load instruction
       d2v xw[XL];
 #pragma unroll
@@ -1074,28 +1089,45 @@ __global__ __launch_bounds__(64 * WPB) void csr_spmv_w6(
       // --- slot of a column: its block's rank in the list (from the runs) * 16 + its place in the block.  Entries of the
       // window that belong to the next chunk may name blocks outside this list: their slot is meaningless, masked into the
       // slice, and their product is never added
-      auto slot = [&](int cc) {
-        const int b = cc >> 4;
-        int base = rb[0];
-#pragma unroll
-        for (int r = 1; r < kW6Runs; ++r) base = (b >= rs[r]) ? rb[r] : base;
-        return (((b + base) << 4) + (cc & 15)) & (WT - 1);
-      };
+#define PSP_W6_SLOT(OUT, CC)                                                   \
+  {                                                                            \
+    const int b_ = (CC) >> 4;                                                  \
+    int base_ = rb0;                                                           \
+    base_ = (b_ >= rs1) ? rb1 : base_;                                         \
+    base_ = (b_ >= rs2) ? rb2 : base_;                                         \
+    base_ = (b_ >= rs3) ? rb3 : base_;                                         \
+    base_ = (b_ >= rs4) ? rb4 : base_;                                         \
+    base_ = (b_ >= rs5) ? rb5 : base_;                                         \
+    base_ = (b_ >= rs6) ? rb6 : base_;                                         \
+    base_ = (b_ >= rs7) ? rb7 : base_;                                         \
+    OUT = (((b_ + base_) << 4) + ((CC) & 15)) & (WT - 1);                      \
+  }
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
-        p0[st].x = v0[st].x * buf[slot(c[st].x)];
-        p0[st].y = v0[st].y * buf[slot(c[st].y)];
-        p1[st].x = v1[st].x * buf[slot(c[st].z)];
-        p1[st].y = v1[st].y * buf[slot(c[st].w)];
+        int s0, s1, s2, s3;
+        PSP_W6_SLOT(s0, c[st].x)
+        PSP_W6_SLOT(s1, c[st].y)
+        PSP_W6_SLOT(s2, c[st].z)
+        PSP_W6_SLOT(s3, c[st].w)
+        p0[st].x = v0[st].x * buf[s0];
+        p0[st].y = v0[st].y * buf[s1];
+        p1[st].x = v1[st].x * buf[s2];
+        p1[st].y = v1[st].y * buf[s3];
       }
+#undef PSP_W6_SLOT
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      const int off = (st * 64 + lane) * 4;
-      *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
-      *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+      if constexpr (PAIRS) {
+        *reinterpret_cast<d2v *>(&buf[(2 * st) * 128 + 2 * lane]) = p0[st];
+        *reinterpret_cast<d2v *>(&buf[(2 * st + 1) * 128 + 2 * lane]) = p1[st];
+      } else {
+        const int off = (st * 64 + lane) * 4;
+        *reinterpret_cast<d2v *>(&buf[off]) = p0[st];
+        *reinterpret_cast<d2v *>(&buf[off + 2]) = p1[st];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -3658,6 +3690,28 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
   return PSP_OK;
 }
 
+// What the single-kernel loops for mid-size systems (psp_mid.hip) need to know about an operator's index-free layout:
+// the offsets, the value / mask tables, and the grid and XCD stripe the launch-per-phase product would use (its dot
+// partials are indexed by workgroup, and the mid-size loops add theirs in exactly that order).  *available = 0 when the
+// product of this handle is not csr_spmv_w4 with at most 8 offsets.
+int csr_w4_view(const psp_csr *A, W4View *out, int *available) {
+  *available = 0;
+  Variant v = decode_variant(A->variant);
+  if (A->w4_only) v.w4 = true;
+  if (!v.w4 || A->nparts || A->sym_owner || A->multi || A->host || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1 || ex->dia_no > 8 || !ex->dia_mask) return PSP_OK;
+  out->no = ex->dia_no;
+  for (int i = 0; i < 8; ++i) out->offs[i] = i < ex->dia_no ? ex->dia_offs.o[i] : 0;
+  out->valT = ex->dia_val;
+  out->mask = ex->dia_mask;
+  out->stripe = w4_stripe(A, v);
+  out->grid = w4_grid((A->nrows + kDiaRows - 1) / kDiaRows, out->stripe);
+  *available = 1;
+  return PSP_OK;
+}
+
 // the lazy loop's product (csr_spmv_w4_pf<.., XU = true>): pending x update + scan, p_new, q = A p_new, p_new.q in one
 // pass; device-resident scalars only.  partials: slot 0 = p.q, slot 2 (partials + 2 kMaxParts) = the scan.
 // *available = 0 when the operator has no index-free layout of <= 8 offsets or the grid exceeds the partial-sum slots.
@@ -4001,12 +4055,22 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
           PSP_TRY(ensure_big_partials(ex6, g6));
           pb6 = ex6->big_partials;
         }
-#define PSP_W6(NP)                                                                                          \
-  hipLaunchKernelGGL((csr_spmv_w6<NP, 4, true>), dim3(g6), dim3(256), 0, stream(), 0, t->nchunks, stripe,    \
-                     t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, A->col, t->blist6, A->val, x, y, \
-                     dotv, pb6, skip)
+#define PSP_W6_F(NP, NTL, PAIRS)                                                                             \
+  hipLaunchKernelGGL((csr_spmv_w6<NP, 4, true, NTL, PAIRS>), dim3(g6), dim3(256), 0, stream(), 0, t->nchunks, \
+                     stripe, t->target, (int)A->padded - 4, A->ncols, t->tab, t->rowoff, A->col, t->blist6, A->val, \
+                     x, y, dotv, pb6, skip)
+        // load form as for csr_spmv_w3 (variant bits 25-26 XOR 3; default: non-temporal pair loads)
+#define PSP_W6(NP)                                                                                           \
+  do {                                                                                                       \
+    const int ab6 = w3_ab(A);                                                                                \
+    if (ab6 == 3) PSP_W6_F(NP, true, true);                                                                  \
+    else if (ab6 == 2) PSP_W6_F(NP, false, true);                                                            \
+    else if (ab6 == 1) PSP_W6_F(NP, true, false);                                                            \
+    else PSP_W6_F(NP, false, false);                                                                         \
+  } while (0)
         if (t->np == 2) PSP_W6(2); else if (t->np == 3) PSP_W6(3); else PSP_W6(4);
 #undef PSP_W6
+#undef PSP_W6_F
         PSP_LAUNCH_CHECK();
         int np6 = g6;
         if (pb6 != partials) {

@@ -464,6 +464,20 @@ int dinv_register(const double *v, long n);
 void dinv_unregister(const double *v);
 bool dinv_constant(const double *v, long n, double *c);
 int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
+// psp_csr.hip -> psp_mid.hip: an operator's index-free (csr_spmv_w4) layout
+struct W4View {
+  int no;       // offsets (<= 8)
+  int offs[8];  // col - row, ascending
+  const double *valT;          // blocks of 128 rows, offset-major inside a block
+  const unsigned short *mask;  // bit o of mask[r]: row r stores an entry at offset o
+  int stripe, grid;            // XCD stripe and grid of the launch-per-phase product (order of its dot partials)
+};
+int csr_w4_view(const psp_csr *A, W4View *out, int *available);
+// psp_mid.hip: the whole PCG loop as one cooperative kernel for mid-size offset-structured systems (vectors in
+// registers, the direction vector exchanged through LDS); kCoopFallback as for the small-system loops
+bool mid_applicable(const psp_csr *A, int n, const double *dinv);
+int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
+                 double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist);
 // psp_coop.hip: the whole loop as one kernel for small systems (grid barriers instead of dependent launches).
 // The two loops return kCoopFallback (not an error; nothing was changed) when the cooperative launch is refused or a
 // grid barrier gives up: the caller then runs its launch-per-phase loop from the same vectors.

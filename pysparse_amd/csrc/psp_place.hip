@@ -10,7 +10,8 @@
 // candidate buffers spread over the address space, time the handle's own product on each, keep the best for the role it
 // was best in (y: the product's output, x: its input), release the rest.  Once per (device, vector length) in a process:
 // the winners stay in the solvers' scratch pool (psp_solvers.hip) / the thread's staging pair (psp_csr.hip).
-// Same kernels on other addresses: no bit of any result changes.  psp_set_placement(0) / PSP_PLACE=0 turns it off.
+// Same kernels on other addresses: no bit of any result changes.  Opt-in: psp_set_placement(1) (see placement_enabled
+// for what it measured to be worth).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -21,7 +22,7 @@
 namespace psp {
 
 namespace {
-std::atomic<int> g_place{-1};  // -1: not decided yet (PSP_PLACE under PSP_TUNING=1, else on)
+std::atomic<int> g_place{-1};  // -1: not decided yet (PSP_PLACE under PSP_TUNING=1, else off)
 std::atomic<long long> g_draws{0};
 std::atomic<long long> g_draw_us{0};
 }  // namespace
@@ -29,8 +30,13 @@ std::atomic<long long> g_draw_us{0};
 bool placement_enabled() {
   int v = g_place.load(std::memory_order_relaxed);
   if (v < 0) {
+    // OFF unless asked for (psp_set_placement(1); PSP_PLACE=1 under PSP_TUNING=1).  Measured over 11 fresh processes at
+    // 512^3 (profiles/r5_placement_ab_*.jsonl): the product on the drawn pair 0 ... 4.6 % faster than on the process'
+    // first allocations (mean 1.8 %: in most processes NONE of 8 candidates spread over 22 GB lies on the fast level),
+    // Jacobi-PCG +0.5 ... +1.7 % in the mean, MINRES 0 %; a draw costs 57-79 ms, and twice it took 3-4 s (the
+    // allocator).  Not enough to pay a draw for in everybody's first solve.
     const char *e = tuning_env("PSP_PLACE");
-    v = (e && atoi(e) == 0) ? 0 : 1;
+    v = (e && atoi(e) == 1) ? 1 : 0;
     g_place.store(v);
   }
   return v != 0;

@@ -851,6 +851,12 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     return PSP_OK;
   }
 
+  if (fused && maxit >= 1 && rho_next != 0.0 && mid_applicable(Acsr, n, dinv)) {
+    // mid-size offset-structured system: the whole loop is one cooperative kernel, vectors in registers, p through LDS
+    // (psp_mid.hip) -- the launch-per-phase loops' bits
+    const int rc = pcg_mid_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
+  }
   if (fused && maxit >= 1 && coop_applicable(Acsr, n)) {  // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
     if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over

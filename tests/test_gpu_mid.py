@@ -1,0 +1,109 @@
+"""GPU: the single-kernel PCG loop for mid-size offset-structured systems (pysparse_amd/csrc/psp_mid.hip; VERDICT r4
+"Next" #2): between 2^18 and 2^20 unknowns the whole loop of pysparse/itsolvers/src/pcg.c:91-166 runs in one cooperative
+kernel -- vectors in registers, the direction vector exchanged through LDS, two grid barriers per iteration.
+
+It must give the launch-per-phase loops' bits (same per-thread sums, same wave trees, same order of the partial sums --
+for p.q the order of csr_spmv_w4's workgroups, XCD-stripe remap included): every case below runs in this process (single
+kernel) and in a child with PSP_MID=0 (launch per phase) and compares info / iter / relres / x / history for EQUALITY:
+2-D and 3-D grids, one and two row pairs per thread, sizes that end in the middle of a span, no preconditioner / Jacobi
+with a constant diagonal / Jacobi with a varying diagonal (a 5-offset operator with random coefficients), converged runs
+and every small truncation point.  Refusals (PSP_COOP_FAIL, a capacity of 4 workgroups) fall back and give the same."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, json, ctypes as C, numpy as np
+sys.path.insert(0, %r)
+from pysparse_amd import device as dev, _capi
+L = _capi.lib()
+spec = json.loads(sys.argv[1])
+out = []
+for case in spec:
+    kind, grid = case["kind"], tuple(case["grid"])
+    if kind == "poisson":
+        A = dev.DeviceCSR.poisson(*grid)
+    else:  # 5-offset operator with random coefficients and a varying, dominant diagonal (symmetric)
+        nx, ny = grid[0], grid[1]
+        n = nx * ny
+        g = np.random.default_rng(case["seed"])
+        import scipy.sparse as sp
+        e1 = -(0.2 + g.random(n - 1)); e1[np.arange(1, n) %% nx == 0] = 0.0
+        e2 = -(0.2 + g.random(n - nx))
+        S = sp.diags([e2, e1, e1, e2], [-nx, -1, 1, nx], shape=(n, n), format="csr")
+        S = (S + sp.diags(-np.asarray(S.sum(axis=1)).ravel() + 0.5 + g.random(n))).tocsr()
+        S.sort_indices()
+        A = dev.DeviceCSR.from_arrays(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    n = A.shape[0]
+    assert A.kernel_info()[0] == "csr_spmv_w4", A.kernel_info()
+    b = np.random.default_rng(case.get("bseed", 1)).standard_normal(n)
+    s0 = C.c_longlong(); f0 = C.c_longlong()
+    L.psp_debug_mid_count(C.byref(s0), C.byref(f0))
+    for Kname in case["K"]:
+        K = None if Kname == "none" else dev.DeviceJacobi(A)
+        for tol, maxit in case["runs"]:
+            x = np.zeros(n)
+            r = dev.pcg(A, b, x, tol, maxit, K, hist=True)
+            h = np.asarray(r[3], dtype=np.float64)
+            out.append([r[0], r[1], float(r[2]).hex(), x.tobytes().hex()[:256], float(np.abs(x).sum()).hex(),
+                        float(np.nansum(h)).hex(), int(np.isnan(h).sum())])
+    s1 = C.c_longlong(); f1 = C.c_longlong()
+    L.psp_debug_mid_count(C.byref(s1), C.byref(f1))
+    out.append(["mid_solves", s1.value - s0.value, f1.value - f0.value])
+print(json.dumps(out))
+""" % ROOT
+
+RUNS = [[0.0, k] for k in (1, 2, 3, 7, 16, 17, 40)] + [[1e-9, 5000]]
+
+
+def _run(spec, env=None):
+    e = dict(os.environ)
+    e.pop("PSP_TUNING", None)
+    if env:
+        e.update(env, PSP_TUNING="1")
+    p = subprocess.run([sys.executable, "-c", CHILD, json.dumps(spec)], env=e, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def _counts(out, ncases):
+    return [row for row in out if row and row[0] == "mid_solves"]
+
+
+@pytest.mark.parametrize("spec", [
+    [{"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS}],           # one layer, 176 workgroups
+    [{"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS}],         # two layers, 256 workgroups
+    [{"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS}],                   # ends inside a span and a row pair
+    [{"kind": "poisson", "grid": [70, 70, 70], "K": ["none", "jacobi"], "runs": RUNS}],            # 7 offsets, halo of 4900 rows
+    [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS}],  # varying diagonal: dinv array
+    [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:]}],
+], ids=["600sq", "1024sq", "601x733", "70cube", "random5_640x700", "random5_1000sq"])
+def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0"})
+    nsolves = sum(len(c["K"]) * len(c["runs"]) for c in spec)
+    assert [r for r in mid if r[0] == "mid_solves"] == [["mid_solves", nsolves, 0]], mid[-1]
+    assert [r for r in ref if r[0] == "mid_solves"] == [["mid_solves", 0, 0]]
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert len(a) == len(b) == nsolves
+    for k, (ra, rb) in enumerate(zip(a, b)):
+        assert ra == rb, (k, ra[:3], rb[:3])
+    assert a[-1][0] == 0  # the last run of every spec converges
+
+
+def test_refused_or_failed_launch_falls_back_with_the_same_result():
+    spec = [{"kind": "poisson", "grid": [600, 600, 0], "K": ["jacobi"], "runs": [[0.0, 9], [1e-9, 5000]]}]
+    want = [r for r in _run(spec, {"PSP_MID": "0"}) if r[0] != "mid_solves"]
+    for env, fb in (({"PSP_COOP_FAIL": "1"}, 2), ({"PSP_COOP_CAPACITY": "4"}, 0)):
+        got = _run(spec, env)
+        assert [r for r in got if r[0] != "mid_solves"] == want, env
+        assert [r for r in got if r[0] == "mid_solves"] == [["mid_solves", 0, fb]], (env, got[-1])

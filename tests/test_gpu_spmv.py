@@ -716,19 +716,21 @@ def test_csr_matvec_w5_ragged_and_empty_rows(oracle):
 W6_VARIANT = 16578 + (1 << 23)  # csr_spmv_w2's variant + bit 23: the CSR arrays as stored, x staged in LDS (psp_csr.hip)
 
 
-def _many_runs_csr(O, n, seed):
-    """every row couples to 12 columns spread 40 apart: a chunk's x blocks fall into more than 8 runs (csr_spmv_w6's
-    register budget) -- the kernel must take its memory-gather branch for such chunks, or leave the matrix to w2"""
+def _many_runs_csr(O, n, seed, clusters):
+    """every row couples to `clusters` groups of 6 adjacent columns, the groups 3000 apart: a chunk of 1000 nonzeros is
+    ~18 rows, so its x blocks fall into `clusters` runs of 2-3 blocks each -- few blocks (<= 64), many runs"""
     rng = np.random.default_rng(seed)
-    ind = np.arange(0, 12 * n + 1, 12, dtype=np.int32)
-    col = np.empty(12 * n, dtype=np.int32)
+    w = 6 * clusters
+    ind = np.arange(0, w * n + 1, w, dtype=np.int32)
+    col = np.empty(w * n, dtype=np.int32)
+    base = np.concatenate([3000 * k + np.arange(6) for k in range(clusters)])
     for i in range(n):
-        col[12 * i:12 * i + 12] = np.sort((i + 40 * np.arange(-6, 6)) % n)
-    return O.CSR((n, n), rng.standard_normal(12 * n), col, ind)
+        col[w * i:w * i + w] = np.sort((i + base) % n)
+    return O.CSR((n, n), rng.standard_normal(w * n), col, ind)
 
 
 @pytest.mark.parametrize("case", ["poisson2d", "poisson3d", "banded", "banded_odd", "ragged_wide_x", "many_runs",
-                                  "few_wild_rows", "tiny"])
+                                  "eight_runs", "few_wild_rows", "tiny"])
 def test_csr_matvec_w6_streams_the_stored_arrays_bit_exact(oracle, case):
     """csr_spmv_w6 (round 5): int32 col + fp64 val exactly as the csr_mat stores them (csr_mat.h:6-13), x staged in LDS
     through the chunk's block list, a nonzero's LDS slot computed from its column via the list's runs of consecutive
@@ -750,8 +752,10 @@ def test_csr_matvec_w6_streams_the_stored_arrays_bit_exact(oracle, case):
         A = banded_csr(oracle, 800, 100000, 7, 20, 7)
         expect_w6 = False  # every row looks at its own window of x: far more than 64 blocks per chunk
     elif case == "many_runs":
-        A = _many_runs_csr(oracle, 6000, 3)
-        expect_w6 = False  # every chunk would gather through memory: stays on w2
+        A = _many_runs_csr(oracle, 40000, 3, 9)
+        expect_w6 = False  # nine runs per chunk, one more than the kernel keeps: every chunk would gather through memory
+    elif case == "eight_runs":
+        A = _many_runs_csr(oracle, 40000, 4, 8)  # exactly the register budget: every compare of the slot search is used
     elif case == "few_wild_rows":
         A = banded_csr(oracle, 60000, 60000, 9, 30, 8)
         rng = np.random.default_rng(1)
@@ -787,7 +791,8 @@ def test_csr_matvec_w6_streams_the_stored_arrays_bit_exact(oracle, case):
     A.matvec(x, yo)
     D.matvec(x, y)
     assert np.array_equal(y, yo, equal_nan=True)
-    for v in (16578, -1):  # w2 and the default choice: the same bits
+    # w2, the default choice, and w6's other three load forms (variant bits 25-26, as for w3): the same bits
+    for v in (16578, -1, W6_VARIANT + (1 << 25), W6_VARIANT + (2 << 25), W6_VARIANT + (3 << 25)):
         D.set_variant(v)
         y2 = np.full(m, np.nan)
         D.matvec(x, y2)

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Single-kernel PCG loop for mid-size systems (psp_mid.hip) against the launch-per-phase loop, in ONE process on the same
+operator and vectors, alternated (PSP_MID_MIN is read per solve): microseconds per iteration and the bits of x.
+Start with PSP_TUNING=1.  Usage: mid_ab.py [nx,ny,nz ...]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+assert os.environ.get("PSP_TUNING") == "1", "start with PSP_TUNING=1"
+from pysparse_amd import _capi, device as dev  # noqa: E402
+
+L = _capi.lib()
+check = _capi.check
+
+
+def main():
+    grids = sys.argv[1:] or ["1024,1024,0", "724,724,0", "600,600,0", "512,512,0", "80,80,80", "64,64,64"]
+    for g in grids:
+        grid = tuple(int(t) for t in g.split(","))
+        A = dev.DeviceCSR.poisson(*grid)
+        n = A.shape[0]
+        K = dev.DeviceJacobi(A)
+        aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
+        bb, xb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+        xb.upload(np.ones(n))
+        A.matvec_dev(xb.ptr, bb.ptr)
+        check(L.psp_synchronize())
+        iters = 2000
+        rec = {"mid": [], "phase": []}
+        xs = {}
+        for rnd in range(3):
+            for mode in ("phase", "mid"):
+                os.environ["PSP_MID_MIN"] = "1" if mode == "mid" else str(1 << 30)
+                os.environ["PSP_COOP"] = "1" if mode == "mid" else "0"  # (PSP_COOP is read once; kept for the record)
+                for kk in (5, iters):
+                    xb.zero()
+                    info, it, rr = C.c_int(), C.c_int(), C.c_double()
+                    check(L.psp_synchronize())
+                    t = time.perf_counter()
+                    check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
+                    check(L.psp_synchronize())
+                    dt = time.perf_counter() - t
+                rec[mode].append(dt / iters * 1e6)
+                xs[mode] = ((info.value, it.value, rr.value), xb.download())
+        s, f = C.c_longlong(), C.c_longlong()
+        L.psp_debug_mid_count(C.byref(s), C.byref(f))
+        out = {"n": n, "us_per_iter_single_kernel": min(rec["mid"]), "us_per_iter_launch_per_phase": min(rec["phase"]),
+               "speedup": min(rec["phase"]) / min(rec["mid"]),
+               "same_bits": bool(xs["mid"][0] == xs["phase"][0] and np.array_equal(xs["mid"][1], xs["phase"][1])),
+               "result": list(xs["mid"][0]), "mid_solves_so_far": s.value, "fallbacks": f.value, "all_us": rec}
+        print("x".join(str(v) for v in grid if v), "pcg", json.dumps(out), flush=True)
+        del aop, kop, K
+        A.close()
+        bb.free()
+        xb.free()
+
+
+if __name__ == "__main__":
+    main()
