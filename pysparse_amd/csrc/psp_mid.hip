@@ -47,11 +47,18 @@ constexpr int kMidMaxSpans = kMidMaxRows / kMidSpan;
 constexpr int kMidMaxLds = 150 * 1024;       // bytes of dynamic LDS the kernel may ask for (160 KB per CU)
 static_assert(kMidSpan == kVecSpan, "partial sums must match the vector kernels' spans");
 
+constexpr int kMidCounters = 16;  // arrival counters, one 128-byte line each
 struct MidCtl {
-  unsigned count;
+  // Arrivals, monotone over the whole solve, spread over kMidCounters words in lines of their own: workgroup w adds to
+  // word w % 16, and the polling wave reads all of them with one load per lane.  With ONE word the 256 arrivals of a barrier
+  // queued up behind each other (and behind 256 polls of the same word) at one memory channel: 4 us per barrier
+  // (in-kernel stamps, profiles/r5_mid_stamps.txt).
+  unsigned count[kMidCounters * 32];
   int error;
   int info, iter;
   double relres;
+  double nonstag;    // running count of (workgroup, wave) pairs whose rows did not stagnate: the scan's reduction needs no
+                     // order (small integers), so it is an atomic counter and every iteration looks at its increase
 };
 
 struct MidArgs {
@@ -72,6 +79,7 @@ struct MidArgs {
   double *hist;
   int np_w4, stripe;  // grid and XCD stripe of the launch-per-phase product: the order its p.q partials are added in
   int nspans;         // ceil(n / 512): grid of the vector kernels
+  long long *stamps;  // PSP_MID_STAMPS (tuning): 8 wall-clock stamps (100 MHz) per iteration of workgroup 0, iterations 1..16
 };
 
 __device__ __forceinline__ void mcoh_store(double *p, double v) {
@@ -89,16 +97,24 @@ __device__ __forceinline__ bool mid_barrier(MidCtl *c, int nwg, unsigned &gen) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   gen += 1;
-  if (nwg > 1 && threadIdx.x == 0) {
-    (void)__hip_atomic_fetch_add(&c->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = gen * (unsigned)nwg;
+  if (nwg > 1 && threadIdx.x < 64) {  // wave 0: lane 0 announces the workgroup, lanes 0 .. 15 poll one counter each
+    const int lane = threadIdx.x;
+    if (lane == 0)
+      (void)__hip_atomic_fetch_add(&c->count[((int)blockIdx.x % kMidCounters) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // counter k is complete at gen x (workgroups w with w % 16 == k)
+    const unsigned mine = lane < kMidCounters ? (unsigned)((nwg - lane + kMidCounters - 1) / kMidCounters) : 0u;
+    const unsigned target = gen * mine;
     const long long t0 = wall_clock64();
     unsigned spins = 0;
-    while ((int)(__hip_atomic_load(&c->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
+    for (;;) {
+      bool ok = true;
+      if (lane < kMidCounters && mine)
+        ok = (int)(__hip_atomic_load(&c->count[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
       if ((++spins & 15u) == 0 &&
           (wall_clock64() - t0 > kMidSpinTicks || __hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&c->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
@@ -115,50 +131,58 @@ __device__ __forceinline__ int w4_remap(int b, int stripe) {
   return ((k / stripe) * 8 + (b & 7)) * stripe + k % stripe;
 }
 
-// R(v[0 .. count)) by one wave (psp_internal.h): lane l adds v[l], v[l + 64], ... in order, then the shuffle-down tree;
-// lane 0 holds the sum.  Entry i of the sequence is src[map(i)] (device-coherent load), or 0.0 where map(i) >= limit:
-//   stripe < 0   map(i) = first + i                      (r.r, r.z, flags: span order)
-//   stripe >= 0  map(i) = w4_remap(first + i, stripe)    (p.q: the order of csr_spmv_w4's workgroups; those of its padded
-//                                                         grid that multiply nothing add 0.0)
-// (No callable parameter: a lambda that captures by reference puts its captures into scratch memory.)
-__device__ __forceinline__ double mid_wave_reduce(const double *src, int first, int count, int stripe, int limit) {
+// reduce(parts, np) of psp_internal.h for NV value arrays (value j at src + j * kMidMaxSpans), by every workgroup for
+// itself (all of them get the same bits):
+//   np <= 256: R(parts); else R([R(group g of 256)]),   R(v) = wave_sum_l(v[l] + v[l + 64] + ...)
+// The span-ordered partial sums are first copied into LDS by LDS-DMA (global_load_lds_dwordx4, device-coherent: sc1) --
+// ONE round trip for all of them and no registers, while the whole solver state is live; with ordinary loads (sequential,
+// for want of registers) the kernel spent most of its iteration waiting for them (profiles/r5_mid_ab_*.txt).  Entry i of
+// the sequence that is added is stage[map(i)], or 0.0 where map(i) >= limit:
+//   stripe < 0   map(i) = i                      (r.r, r.z: span order)
+//   stripe >= 0  map(i) = w4_remap(i, stripe)    (p.q: the order of csr_spmv_w4's workgroups; those of its padded grid
+//                                                 that multiply nothing add 0.0)
+// stage: NV * pitch doubles (pitch = limit rounded up to 128); grp_lds: NV * 16 + NV doubles.
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
+
+__device__ __forceinline__ double mid_wave_reduce_lds(const double *v, int first, int count, int stripe, int limit) {
   const int lane = threadIdx.x & 63;
   double s = 0.0;
   for (int i = lane; i < count; i += 64) {
     const int b = stripe >= 0 ? w4_remap(first + i, stripe) : first + i;
-    s += b < limit ? mcoh_load(src + b) : 0.0;
+    s += b < limit ? v[b] : 0.0;
   }
   return psp_wave_sum(s);
 }
-__device__ __forceinline__ double mid_wave_reduce_lds(const double *v, int count) {
-  const int lane = threadIdx.x & 63;
-  double s = 0.0;
-  for (int i = lane; i < count; i += 64) s += v[i];
-  return psp_wave_sum(s);
-}
 
-// reduce(parts, np) of psp_internal.h for NV value arrays (value j at src + j * kMidMaxSpans) at once, by every workgroup
-// for itself (all of them get the same bits): np <= 256: R(parts); else R([R(group g of 256)]).  grp_lds: NV * 16 + NV.
 template <int NV>
 __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src, int np, int stripe, int limit,
-                                           double *grp_lds) {
+                                           double *stage, double *grp_lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pitch = (limit + 127) & ~127;  // the partial-sum arrays are kMidMaxSpans long (a multiple of 128) and zero-filled
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    for (int base = wave * 128; base < pitch; base += (kMidBlock / 64) * 128)  // one wave-instruction: 64 lanes x 16 bytes
+      __builtin_amdgcn_global_load_lds((global_void_ptr)(src + (size_t)j * kMidMaxSpans + base + 2 * lane),
+                                       (lds_void_ptr)(stage + j * pitch + base), 16, 0, 16 /* sc1: device scope */);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   const int ngroups = (np + kTailGroup - 1) / kTailGroup;  // <= 16 (np <= 4096)
   if (ngroups <= 1) {
     if (wave < NV) {
-      const double s = mid_wave_reduce(src + (size_t)wave * kMidMaxSpans, 0, np, stripe, limit);
+      const double s = mid_wave_reduce_lds(stage + wave * pitch, 0, np, stripe, limit);
       if (lane == 0) grp_lds[NV * 16 + wave] = s;
     }
   } else {
     for (int task = wave; task < NV * ngroups; task += kMidBlock / 64) {
       const int j = task / ngroups, g = task % ngroups;
       const int cnt = min(kTailGroup, np - g * kTailGroup);
-      const double s = mid_wave_reduce(src + (size_t)j * kMidMaxSpans, g * kTailGroup, cnt, stripe, limit);
+      const double s = mid_wave_reduce_lds(stage + j * pitch, g * kTailGroup, cnt, stripe, limit);
       if (lane == 0) grp_lds[j * 16 + g] = s;
     }
     __syncthreads();
     if (wave < NV) {
-      const double s = mid_wave_reduce_lds(grp_lds + wave * 16, ngroups);
+      const double s = mid_wave_reduce_lds(grp_lds + wave * 16, 0, ngroups, -1, ngroups);
       if (lane == 0) grp_lds[NV * 16 + wave] = s;
     }
   }
@@ -166,6 +190,36 @@ __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src,
 #pragma unroll
   for (int j = 0; j < NV; ++j) out[j] = grp_lds[NV * 16 + j];
   __syncthreads();
+}
+
+// The residual of the rows on either side of the block -- [base - H, base) and [base + B, base + B + H), what the
+// neighbours published at the last barrier -- copied into LDS (hst[0, H) and hst[H, 2H)) by LDS-DMA, a pair of rows per
+// lane (rows outside the matrix skipped).  Asynchronous: the caller waits (s_waitcnt vmcnt(0)) before it reads.
+// Issued together with the partial sums' copies, the halo costs no round trip of its own; read with ordinary loads in a
+// loop it cost three (no registers to keep them in flight).
+__device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, int H, int n, double *hst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int zone = 0; zone < 2; ++zone) {
+    const long row0 = zone == 0 ? base - H : base + B;  // even (base is a multiple of 2048, H is even): 16-byte aligned pairs
+    for (int e0 = wave * 128; e0 < H; e0 += (kMidBlock / 64) * 128) {  // one wave-instruction: 64 lanes x one pair of rows
+      const int e = e0 + 2 * lane;
+      const long g = row0 + e;
+      if (e < H && g >= 0 && g + 1 < n)
+        __builtin_amdgcn_global_load_lds((global_void_ptr)(r + g), (lds_void_ptr)(hst + zone * H + e0), 16, 0, 16);
+      else if (e < H && g >= 0 && g < n)  // the matrix' last row when n is odd: one lane in the whole grid
+        hst[zone * H + e] = mcoh_load(r + g);
+    }
+  }
+}
+
+// grid barrier, then the reduction by every workgroup for itself; false: some workgroup gave up -- everybody leaves
+template <int NV>
+__device__ __forceinline__ bool mid_barrier_reduce(MidCtl *c, int nwg, unsigned &gen, double (&out)[NV], const double *src,
+                                                   int np, int stripe, int limit, double *stage, double *grp_lds) {
+  if (!mid_barrier(c, nwg, gen)) return false;
+  mid_reduce<NV>(out, src, np, stripe, limit, stage, grp_lds);
+  return true;
 }
 
 // pcg.c:91-166 from the head of iteration 1 (r = b - A x, rho = r.z, ||r|| > tolb are the caller's)
@@ -183,6 +237,10 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
   double *ql = xl + (XQ_LDS ? B : 0);
   double *red = ql + (XQ_LDS ? B : 0);  // 3 x (LAYERS * NW) wave sums
   double *grp = red + 3 * LAYERS * NW;  // mid_reduce's scratch: 3 * 16 + 3
+  double *stage = grp + 3 * 16 + 4;  // the partial sums, staged for the reduction: two arrays of nspans (rounded up to 128)
+  // the neighbours' residual, staged for the p update of the halo: q's place (dead between the r update and the next
+  // product) with two layers, a region of its own with one
+  double *hst = XQ_LDS ? ql : stage + 2 * ((a.nspans + 127) & ~127);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wg = blockIdx.x, nwg = a.nwg, n = a.n;
   const long base = (long)wg * B;
@@ -224,11 +282,19 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
     }
   }
   for (int i = t; i < 2 * H + B; i += kMidBlock) win[i] = 0.0;
+  for (int i = t; i < 2 * H; i += kMidBlock) hst[i] = 0.0;  // (rows outside the matrix are never copied)
+  __syncthreads();
+  mid_halo_dma(a.r, base, B, H, n, hst);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   unsigned gen = 0;
+  double nonstag_seen = 0.0;
   double rho = a.rho0, rho1 = 1.0, normr = a.normr0, alpha = 0.0, beta = 0.0;
   int flag = -1, it;
+#define PSP_MID_STAMP(K)                                                                     \
+  if (a.stamps && wg == (int)(a.stamps[0]) && t == 0 && it <= 16) a.stamps[8 + (it - 1) * 8 + (K)] = wall_clock64()
   for (it = 1; it <= a.maxit; ++it) {
+    PSP_MID_STAMP(0);
     if (rho == 0.0) {  // pcg.c:101-104
       flag = -2;
       break;
@@ -262,7 +328,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       const int wi = h < H ? h : B + h;
       const long g = base - H + wi;
       if (g >= 0 && g < n) {
-        double z = mcoh_load(a.r + g);
+        double z = hst[h];
         if (pre == 1) z = z * a.dinv[g];
         if (pre == 2) z = z * dc;
         if (it > 1) z = z + beta * win[wi];
@@ -270,6 +336,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       }
     }
     __syncthreads();
+    PSP_MID_STAMP(1);
     // ---- q = A p for the own rows (csr_spmv_w4: products added in offset order where the row stores an entry), p.q
 #pragma unroll
     for (int L = 0; L < LAYERS; ++L) {
@@ -303,9 +370,12 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       const int gs = wg * (B / kMidSpan) + t;
       if (gs < a.nspans) mcoh_store(a.part + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
     }
-    if (!mid_barrier(a.ctl, nwg, gen)) return;
     double s1[1];
-    mid_reduce<1>(s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, grp);
+    PSP_MID_STAMP(2);
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+    PSP_MID_STAMP(3);
+    mid_reduce<1>(s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp);
+    PSP_MID_STAMP(4);
     const double pq = s1[0];
     if (pq == 0.0) {  // pcg.c:118-120
       flag = -6;
@@ -363,16 +433,33 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       }
     }
     __syncthreads();
-    if (t < 3 * LAYERS * 4) {
+    if (t < 2 * LAYERS * 4) {
       const int j = t / (LAYERS * 4), s = t % (LAYERS * 4);
       const int gs = wg * (B / kMidSpan) + s;
       const double *rj = red + j * LAYERS * NW;
       if (gs < a.nspans)
         mcoh_store(a.part + (size_t)(1 + j) * kMidMaxSpans + gs, rj[4 * s] + rj[4 * s + 1] + rj[4 * s + 2] + rj[4 * s + 3]);
     }
-    if (!mid_barrier(a.ctl, nwg, gen)) return;
+    if (t == 64) {  // the workgroup's non-stagnated waves (exact small integers: any order)
+      double f = 0.0;
+      for (int w = 0; w < LAYERS * NW; ++w) f += red[2 * LAYERS * NW + w];
+      if (f != 0.0) (void)__hip_atomic_fetch_add(&a.ctl->nonstag, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     double s3[3];
-    mid_reduce<3>(s3, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, grp);
+    {
+      double s2[2];
+      PSP_MID_STAMP(5);
+      if (!mid_barrier(a.ctl, nwg, gen)) return;
+      PSP_MID_STAMP(6);
+      mid_halo_dma(a.r, base, B, H, n, hst);  // the next iteration's halo rides with the partial sums: one round trip
+      mid_reduce<2>(s2, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
+      PSP_MID_STAMP(7);
+      s3[0] = s2[0];
+      s3[1] = s2[1];
+      const double seen = mcoh_load(&a.ctl->nonstag);  // complete: every workgroup added its share before it arrived
+      s3[2] = seen - nonstag_seen;
+      nonstag_seen = seen;
+    }
     normr = sqrt(s3[0]);  // the recurred residual (pcg.c:146-153)
     if (a.hist && wg == 0 && t == 0) a.hist[it] = normr;
     if (normr <= a.tolb) {  // pcg.c:154-157
@@ -447,11 +534,14 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P) {
   int omax = 1;
   for (int i = 0; i < P->w4.no; ++i) omax = std::max(omax, std::abs(P->w4.offs[i]));
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)
+  if (P->H > 2048) return false;  // the halo is staged in LDS and updated in <= 4 passes: 2-D grids up to 2046 wide, slim 3-D ones
   P->layers = n > kMidMaxWg * kMidLayer ? 2 : 1;
   if (P->layers == 2 && P->w4.no > 5) return false;  // register budget of two row pairs per thread: up to 5 offsets
   const int B = P->layers * kMidLayer;
   P->nwg = (n + B - 1) / B;
-  P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 2 * B : 0) + 3 * P->layers * 16 + 3 * 16 + 3);
+  const int nspans = (n + kMidSpan - 1) / kMidSpan;
+  P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 2 * B : 0) + 3 * P->layers * 16 + 3 * 16 + 4 +
+                                     2 * ((nspans + 127) & ~127) + (P->layers == 2 ? 0 : 2 * P->H));
   if (P->nwg > kMidMaxWg || P->lds > (size_t)kMidMaxLds) return false;
   if (P->w4.grid > 4096 || (n + kMidSpan - 1) / kMidSpan > kMidMaxSpans) return false;
   P->kernel = mid_kernel(P->w4.no, P->layers);
@@ -534,6 +624,16 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   a.np_w4 = P.w4.grid;
   a.stripe = P.w4.stripe;
   a.nspans = (n + kMidSpan - 1) / kMidSpan;
+  a.stamps = nullptr;
+  long long *stamps_dev = nullptr;
+  const char *se = tuning_env("PSP_MID_STAMPS");  // workgroup to stamp
+  if (se) {
+    PSP_HIP(hipMalloc((void **)&stamps_dev, sizeof(long long) * (8 + 16 * 8)));
+    PSP_HIP(hipMemsetAsync(stamps_dev, 0, sizeof(long long) * (8 + 16 * 8), stream()));
+    const long long which = atoll(se);
+    PSP_HIP(hipMemcpyAsync(stamps_dev, &which, sizeof(long long), hipMemcpyHostToDevice, stream()));
+    a.stamps = stamps_dev;
+  }
   void *args[] = {&a};
   int rc = PSP_OK;
   const char *ff = tuning_env("PSP_COOP_FAIL");
@@ -548,6 +648,19 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
     PSP_HIP(hipMemcpyAsync(&c, m.ctl, sizeof(MidCtl), hipMemcpyDeviceToHost, stream()));
     PSP_HIP(hipStreamSynchronize(stream()));
     if (c.error) rc = kCoopFallback;
+  }
+  if (stamps_dev) {
+    long long st[8 + 16 * 8];
+    (void)hipMemcpy(st, stamps_dev, sizeof(st), hipMemcpyDeviceToHost);
+    (void)hipFree(stamps_dev);
+    fprintf(stderr, "[psp_mid] n %d nwg %d layers %d H %d: 10 ns ticks per phase (p update | product | barrier 1 | reduce 1 | updates | barrier 2 | reduce 2 + halo | loop end)\n",
+            n, P.nwg, P.layers, P.H);
+    for (int it = 2; it < 12 && it < maxit; ++it) {
+      const long long *q0 = st + 8 + it * 8, *q1 = st + 8 + (it + 1) * 8;
+      fprintf(stderr, "[psp_mid]   it %2d:", it + 1);
+      for (int k = 0; k < 7; ++k) fprintf(stderr, " %5lld", q0[k + 1] - q0[k]);
+      fprintf(stderr, " %5lld | total %lld\n", q1[0] - q0[7], q1[0] - q0[0]);
+    }
   }
   if (rc == kCoopFallback) {
     g_mid_fallbacks.fetch_add(1);

@@ -82,10 +82,10 @@ def _counts(out, ncases):
     [{"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS}],           # one layer, 176 workgroups
     [{"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS}],         # two layers, 256 workgroups
     [{"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS}],                   # ends inside a span and a row pair
-    [{"kind": "poisson", "grid": [70, 70, 70], "K": ["none", "jacobi"], "runs": RUNS}],            # 7 offsets, halo of 4900 rows
+    [{"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS}],           # 7 offsets, halo of 1602 rows
     [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS}],  # varying diagonal: dinv array
     [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:]}],
-], ids=["600sq", "1024sq", "601x733", "70cube", "random5_640x700", "random5_1000sq"])
+], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq"])
 def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
     mid = _run(spec)
     ref = _run(spec, {"PSP_MID": "0"})

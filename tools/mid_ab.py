@@ -30,22 +30,25 @@ def main():
         xb.upload(np.ones(n))
         A.matvec_dev(xb.ptr, bb.ptr)
         check(L.psp_synchronize())
-        iters = 2000
+        # two truncated solves per measurement: the difference cancels the set-up (||b||, r = b - A x, allocations, the
+        # cooperative launch itself); both counts lie well before these systems stagnate
+        k1, k2 = (50, 250) if grid[2] else (100, 1100)
         rec = {"mid": [], "phase": []}
         xs = {}
         for rnd in range(3):
             for mode in ("phase", "mid"):
                 os.environ["PSP_MID_MIN"] = "1" if mode == "mid" else str(1 << 30)
-                os.environ["PSP_COOP"] = "1" if mode == "mid" else "0"  # (PSP_COOP is read once; kept for the record)
-                for kk in (5, iters):
+                ts = {}
+                for kk in (k1, k1, k2):
                     xb.zero()
                     info, it, rr = C.c_int(), C.c_int(), C.c_double()
                     check(L.psp_synchronize())
                     t = time.perf_counter()
                     check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
                     check(L.psp_synchronize())
-                    dt = time.perf_counter() - t
-                rec[mode].append(dt / iters * 1e6)
+                    ts[kk] = time.perf_counter() - t
+                    assert it.value == kk + 1, (it.value, info.value)
+                rec[mode].append((ts[k2] - ts[k1]) / (k2 - k1) * 1e6)
                 xs[mode] = ((info.value, it.value, rr.value), xb.download())
         s, f = C.c_longlong(), C.c_longlong()
         L.psp_debug_mid_count(C.byref(s), C.byref(f))
