@@ -426,6 +426,22 @@ struct MinresDev {
   int skip;    // status | stop -- what the SpMV / scale / Lanczos kernels look at
   int info, iter, it_max;
 };
+// Device-resident scalars of the cgs / bicgstab / qmrs loops (round 5; psp_solvers.hip): the recurrences of
+// cgs.c / bicgstab.c / qmrs.c are evaluated by the thread that finishes each reduction, the fused vector kernels read their
+// coefficients from here, the host enqueues a batch of iterations and reads the state once -- no host round trip per
+// reduction (they cost 12 us each at 1024^2: profiles/r4_extra_solvers_1024sq.txt).
+struct KryDev {
+  double r[32];
+  int status;  // 1: the loop is over -- every later kernel is a no-op
+  int code;    // which way it ended (per solver)
+  int iter, maxit;
+};
+// scalar operands of a fused vector kernel: S == nullptr: the by-value arguments; else S->r[i0 / i1 / i2] (and the
+// kernel does nothing once S->status is set)
+struct KryArg {
+  const KryDev *S = nullptr;
+  int i0 = 0, i1 = 0, i2 = 0;
+};
 // y = op(x) on device vectors; y must not alias x
 int op_apply(const psp_op *op, const double *x_dev, double *y_dev);
 // the csr that a native operator multiplies with (csr, or sss->full); nullptr otherwise

@@ -411,22 +411,25 @@ __global__ __launch_bounds__(kReduceBlock) void finish_kernel(const double *__re
 // its operands at ~45 GB/s (profiles/r4_c2_kernel_durations.txt: 22 us for 32 768 x 3 partial sums at 4096^2), a group
 // fold over the whole chip + the finishing block cost two launches (~10 us): PSP_FOLD_ONE_BLOCK_GROUPS (tuning switch,
 // read per reduction; tools/fold_threshold_ab.py) moves the boundary; both routes add in the same order (R, psp_internal.h)
-static int one_block_groups() {
-  const char *e = psp::tuning_env("PSP_FOLD_ONE_BLOCK_GROUPS");
+// A reduction of ONE value reads a third of what the PCG reductions read (two or three values): its boundary lies at
+// three times as many groups (PSP_FOLD_ONE_BLOCK_GROUPS1; MINRES' alpha over the ~10 000 workgroup sums of csr_spmv_w3 at
+// n = 9.3e5 is one launch instead of two: profiles/r5_fem_minres.txt).
+static int one_block_groups(int nvals) {
+  const char *e = psp::tuning_env(nvals == 1 ? "PSP_FOLD_ONE_BLOCK_GROUPS1" : "PSP_FOLD_ONE_BLOCK_GROUPS");
   if (e) {
     const int v = atoi(e);
     if (v >= 1 && v <= kOneBlockGroups) return v;
   }
-  return kFoldAboveGroups;
+  return nvals == 1 ? 3 * kFoldAboveGroups : kFoldAboveGroups;
 }
 
 // first stage of a reduction over more partials than one block takes: the group sums (into slot `fslot` of the
 // workspace's group-sum array); tells the caller what the finishing block has to read (raw: still the per-workgroup
 // partial sums).  fold_stage2: two sets of partial sums, ONE launch when both need the stage.
-static void fold_plan(Workspace *w, const double *partials, int nparts, int fslot, const double **src, int *count,
+static void fold_plan(Workspace *w, const double *partials, int nparts, int nvals, int fslot, const double **src, int *count,
                       int *stride, bool *raw, bool *need) {
   const int ngroups = (nparts + kTailGroup - 1) / kTailGroup;
-  *need = ngroups > one_block_groups();
+  *need = ngroups > one_block_groups(nvals);
   if (*need) {
     *src = w->folded + (size_t)fslot * kTailGroups;
     *count = ngroups;
@@ -445,7 +448,7 @@ int fold_stage(const double *partials, int nparts, int nvals, const double **src
   Workspace *w;
   PSP_TRY(workspace(&w));
   bool need;
-  fold_plan(w, partials, nparts, fslot, src, count, stride, raw, &need);
+  fold_plan(w, partials, nparts, nvals, fslot, src, count, stride, raw, &need);
   if (need) {
     FoldJobs jobs;
     jobs.in[0] = partials;
@@ -464,7 +467,7 @@ int fold_stage2(const double *const partials[2], const int nparts[2], const int 
   PSP_TRY(workspace(&w));
   bool need[2];
   for (int k = 0; k < 2; ++k)
-    fold_plan(w, partials[k], nparts[k], fslot[k], &src[k], &count[k], &stride[k], &raw[k], &need[k]);
+    fold_plan(w, partials[k], nparts[k], 2, fslot[k], &src[k], &count[k], &stride[k], &raw[k], &need[k]);
   if (need[0] || need[1]) {
     FoldJobs jobs;
     int nj = 0, maxg = 0;

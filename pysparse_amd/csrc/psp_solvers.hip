@@ -52,25 +52,29 @@ int k_lanczos(long n, const double *av, double c1, double c2, const double *v_ha
 int k_lanczos_plain(long n, const double *av, double c1, double c2, const double *v_hat, double *v_hat_old);
 int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double c_eta, const double *w,
                 double *w_old, double *x, bool scaled = false, double vdiv = 1.0, const MinresDev *ds = nullptr);
+int k_minres_wx_vnext(long n, double *v, const double *ynext, const double *w, double *w_old, double *x,
+                      const MinresDev *ds);
 int k_lin2(long n, double a, const double *x, double b, const double *y, double *z);
 int k_scal(long n, double a, double *x);
 int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts,
                const double *neg_a_dev = nullptr);
 int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double *partials, int *nparts);
-int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc);
-int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts);
+int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc, KryArg ka = KryArg());
+int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts, KryArg ka = KryArg());
 int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double *wrk1, const double *dinv, double eta,
-              double cc, double rho1inv, double *partials, int *nparts);
+              double cc, double rho1inv, double *partials, int *nparts, KryArg ka = KryArg());
 int k_cgs_q(long n, const double *u, const double *v, double *x, double *q, double *tmp2, const double *dinv,
-            double alpha);
-int k_cgs_r(long n, double *r, const double *t, const double *r0, double alpha, double *partials, int *nparts);
+            double alpha, KryArg ka = KryArg());
+int k_cgs_r(long n, double *r, const double *t, const double *r0, double alpha, double *partials, int *nparts,
+            KryArg ka = KryArg());
 int k_cgs_p(long n, const double *r, const double *q, double *p, double *u, double *kp, const double *dinv,
-            double beta);
+            double beta, KryArg ka = KryArg());
 int k_bicg_p(long n, const double *r, const double *v, double *p, double *phat, const double *dinv, double beta,
-             double omega, bool first);
-int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, const double *dinv, double alpha);
+             double omega, bool first, KryArg ka = KryArg());
+int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, const double *dinv, double alpha,
+             KryArg ka = KryArg());
 int k_bicg_xr(long n, double *x, const double *phat, const double *shat, const double *s, const double *t, double *r,
-              const double *rhat, double alpha, double omega, double *partials, int *nparts);
+              const double *rhat, double alpha, double omega, double *partials, int *nparts, KryArg ka = KryArg());
 }  // namespace psp
 
 extern "C" int psp_csr_diagonal_dev(const psp_csr_t *A, double *diag_dev);
@@ -1179,6 +1183,11 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
       goto done;                                                     \
     }                                                                \
   } while (0)
+  bool v_ready = false;
+  const bool wx_vnext = [] {  // PSP_MINRES_WXV (tuning switch, read per solve): 0 keeps v = y / beta a pass of its own
+    const char *e = psp::tuning_env("PSP_MINRES_WXV");
+    return e ? atoi(e) != 0 : true;
+  }();
   memset(hst, 0, sizeof(MinresDev));
   hst->beta = beta0;
   hst->beta_old = 1.0;
@@ -1203,7 +1212,9 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
       if (!hasK || y2)
         MR_TRY(csr_spmv_scaled_launch(Acsr, vsrc, 1.0, av, w->partials, &np, &scaled, &st->skip, &st->beta));
       if (!scaled) {
-        MR_TRY(k_scale_div(n, vsrc, 1.0, v, st));
+        // v = y / beta: a pass of its own in the first iteration only -- afterwards the previous iteration's w / x update
+        // has written it (k_minres_wx_vnext below)
+        if (!v_ready) MR_TRY(k_scale_div(n, vsrc, 1.0, v, st));
         MR_TRY(csr_spmv_launch(Acsr, v, av, v, w->partials, &np, &st->skip));
       }
       MR_TRY(minres_reduce_then<kMrAlpha>(w->partials, np, w->scal_dev, st, nullptr));
@@ -1214,7 +1225,14 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
       if (scaled && hasK) std::swap(y, y2);
       MR_TRY(minres_reduce_then<kMrBeta>(w->partials, np, w->scal_dev + 4, st, hist_dev));
       // w, x update (:172-180); the new w lands in w_old's buffer
-      MR_TRY(k_minres_wx(n, scaled ? vsrc : v, 0.0, 0.0, 0.0, 0.0, wv, w_old, x, scaled != 0, 1.0, st));
+      if (!scaled && wx_vnext) {
+        // the unnormalised vector of the NEXT iteration: y (with a preconditioner: the Lanczos pass just wrote it) or the
+        // new v_hat (the names were swapped above)
+        MR_TRY(k_minres_wx_vnext(n, v, hasK ? y : v_hat, wv, w_old, x, st));
+        v_ready = true;
+      } else {
+        MR_TRY(k_minres_wx(n, scaled ? vsrc : v, 0.0, 0.0, 0.0, 0.0, wv, w_old, x, scaled != 0, 1.0, st));
+      }
       std::swap(wv, w_old);
     }
     MR_HIP(hipGetLastError());
@@ -1521,6 +1539,196 @@ int apply_or_copy(const psp_op *K, long n, const double *x, double *y) {
 
 }  // namespace
 
+// ---------------------------------------------------------------- cgs / bicgstab / qmrs with device-resident scalars
+//
+// Round 5 (VERDICT r4 "Next" #5).  The fused loops below (native matrix + None / jacobi(1)) used to read every reduced
+// value back to the host -- through mapped memory and polling since round 4, but still one GPU-idle round trip per
+// reduction: 2 (cgs), 4 (bicgstab), 4 (qmrs) per iteration, ~12 us each at 1024^2.  Now the recurrences of cgs.c /
+// bicgstab.c / qmrs.c are evaluated by the thread that finishes each reduction (kry_finish_kernel<OP>: reduce_block's
+// canonical order, so the reduced values are the ones the host used to get; then the same expressions in the same order,
+// IEEE double, -ffp-contract=off on both sides), the vector kernels take their coefficients from the KryDev state
+// (KryArg) and do nothing once its status is set, and the host enqueues kKryBatch iterations between two reads of the
+// state.  Same bits as the host-scalar loops (tests/test_gpu_krylov_golden.py, test_krylov_more.py; PSP_KRY_DEVSCAL=0
+// keeps the host-scalar loops for A/B).
+namespace {
+
+constexpr int kKryBatch = 8;
+
+enum KryOp {
+  kCgsD, kCgsR,
+  kBicgD1, kBicgTs, kBicgTt, kBicgXr,
+  kQmrsDelta0, kQmrsEps, kQmrsRho, kQmrsDelta,
+};
+// cgs registers
+enum { CG_RHO = 0, CG_ALPHA, CG_BETA, CG_D, CG_RES, CG_RHONEW, CG_THR };
+// bicgstab registers
+enum { BI_RHO1 = 0, BI_RHO2, BI_ALPHA, BI_OMEGA, BI_BETA, BI_D1, BI_D2, BI_RR, BI_RHONEXT, BI_RES0, BI_TOL, BI_RES };
+// qmrs registers
+enum { QM_RHO0 = 0, QM_RHO1, QM_TAU, QM_C0, QM_C1, QM_EPS0, QM_XI1, QM_THETA0, QM_THETA, QM_ETA0, QM_DELTA, QM_CC, QM_BETA,
+       QM_CC2, QM_RHO1INV, QM_ERR, QM_RESINIT, QM_TOL, QM_OUT };
+
+__device__ __forceinline__ void kry_end(KryDev *S, int code) {
+  S->status = 1;
+  S->code = code;
+}
+
+// bicgstab.c: head of an iteration (the do-loop's first statements), after the previous one decided to go on
+__device__ __forceinline__ void bicg_head(KryDev *S) {
+  S->iter += 1;
+  if (S->r[BI_RHO1] == 0.0) {
+    kry_end(S, 3);  // "return" with info as initialised (-6)
+    return;
+  }
+  S->r[BI_BETA] = (S->r[BI_RHO1] / S->r[BI_RHO2]) * (S->r[BI_ALPHA] / S->r[BI_OMEGA]);
+}
+
+// qmrs.c: head of an iteration (while test, ++iter, eps0 / delta tests, cc)
+__device__ __forceinline__ void qmrs_head(KryDev *S) {
+  if (!(S->r[QM_ERR] > S->r[QM_TOL] && S->iter < S->maxit)) {
+    kry_end(S, 1);  // the loop test failed: normal end
+    return;
+  }
+  S->iter += 1;
+  if (S->r[QM_EPS0] == 0.0) {
+    kry_end(S, 6);
+    return;
+  }
+  if (S->r[QM_DELTA] == 0.0) {
+    kry_end(S, 2);
+    return;
+  }
+  S->r[QM_CC] = S->r[QM_XI1] * (S->r[QM_DELTA] / S->r[QM_EPS0]);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kReduceBlock) void kry_finish_kernel(const double *__restrict__ src, int count, int nvals,
+                                                                  int stride, int raw, KryDev *S, int out_base) {
+  if (S->status) return;
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(src, count, nvals, stride, raw != 0, S->r + out_base, sh);
+  if (threadIdx.x != 0) return;
+  double *r = S->r;
+  if constexpr (OP == kCgsD) {  // cgs.c: alpha = rho / (v . r0)
+    r[CG_ALPHA] = r[CG_RHO] / r[CG_D];
+  }
+  if constexpr (OP == kCgsR) {  // cgs.c: convergence test on r.r, beta, the for-loop's increment and test
+    if (r[CG_RES] < r[CG_THR]) {
+      kry_end(S, 1);
+    } else {
+      r[CG_BETA] = r[CG_RHONEW] / r[CG_RHO];
+      r[CG_RHO] = r[CG_RHONEW];
+      S->iter += 1;
+      if (!(S->iter < S->maxit)) kry_end(S, 2);
+    }
+  }
+  if constexpr (OP == kBicgD1) r[BI_ALPHA] = r[BI_RHO1] / r[BI_D1];  // alpha = rho / (rhat . v)
+  if constexpr (OP == kBicgTs) {}                                    // t . s lands in r[BI_D1]
+  if constexpr (OP == kBicgTt) r[BI_OMEGA] = r[BI_D1] / r[BI_D2];    // omega = (t . s) / (t . t)
+  if constexpr (OP == kBicgXr) {  // res, the omega == 0 return, the loop test, then the next iteration's head
+    const double res = sqrt(r[BI_RR]);
+    r[BI_RES] = res;
+    if (r[BI_OMEGA] == 0.0) {
+      kry_end(S, 4);
+    } else {
+      r[BI_RHO2] = r[BI_RHO1];
+      r[BI_RHO1] = r[BI_RHONEXT];
+      if (!((res / r[BI_RES0] > r[BI_TOL]) && (S->iter < S->maxit))) kry_end(S, 1);
+      else bicg_head(S);
+    }
+  }
+  if constexpr (OP == kQmrsDelta0) {  // first iteration: delta = K v1 . v1, then the head
+    r[QM_DELTA] = r[QM_OUT];
+    qmrs_head(S);
+  }
+  if constexpr (OP == kQmrsEps) {  // eps0 = g . t; beta = eps0 / delta
+    r[QM_EPS0] = r[QM_OUT];
+    r[QM_BETA] = r[QM_EPS0] / r[QM_DELTA];
+  }
+  if constexpr (OP == kQmrsRho) {  // qmrs.c: rho1 = ||v1||, theta, c1, eta0, tau, the coefficients of the d / x update
+    const double rho1 = sqrt(r[QM_OUT]);
+    const double beta = r[QM_BETA], c0 = r[QM_C0];
+    r[QM_RHO1] = rho1;
+    r[QM_XI1] = rho1;
+    if (c0 * fabs(beta) == 0.0) {
+      kry_end(S, 6);
+      return;
+    }
+    const double theta = rho1 / (c0 * fabs(beta));
+    const double c1 = 1.0 / sqrt(theta * theta + 1.0);
+    r[QM_THETA] = theta;
+    r[QM_C1] = c1;
+    if (beta * (c0 * c0) == 0.0) {
+      kry_end(S, 6);
+      return;
+    }
+    r[QM_ETA0] = -r[QM_ETA0] * r[QM_RHO0] * (c1 * c1) / (beta * (c0 * c0));
+    r[QM_TAU] = r[QM_TAU] * theta * c1;
+    if (rho1 == 0.0) {
+      kry_end(S, 6);
+      return;
+    }
+    const double d1 = r[QM_THETA0] * c1;
+    r[QM_CC2] = d1 * d1;
+    r[QM_RHO1INV] = 1.0 / rho1;
+  }
+  if constexpr (OP == kQmrsDelta) {  // delta of the next iteration; the tail of this one; the next one's head
+    r[QM_DELTA] = r[QM_OUT];
+    if (r[QM_XI1] == 0.0) {
+      kry_end(S, 6);
+      return;
+    }
+    r[QM_RHO0] = r[QM_RHO1];
+    r[QM_ERR] = r[QM_TAU] / r[QM_RESINIT];
+    r[QM_C0] = r[QM_C1];
+    r[QM_THETA0] = r[QM_THETA];
+    qmrs_head(S);
+  }
+}
+
+template <int OP>
+int kry_reduce_then(const double *partials, int nparts, int nvals, KryDev *S, int out_base, int fslot = 0) {
+  const double *src;
+  int count, stride;
+  bool raw;
+  PSP_TRY(fold_stage(partials, nparts, nvals, &src, &count, &stride, &raw, fslot));
+  hipLaunchKernelGGL((kry_finish_kernel<OP>), dim3(1), dim3(kReduceBlock), 0, stream(), src, count, nvals, stride,
+                     raw ? 1 : 0, S, out_base);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+// the state on the device + its pinned host mirror
+struct KryState {
+  KryDev *dev = nullptr, *host = nullptr;
+  ~KryState() {
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+  }
+  int init() {
+    PSP_HIP(hipMalloc((void **)&dev, sizeof(KryDev)));
+    PSP_HIP(hipHostMalloc((void **)&host, sizeof(KryDev), hipHostMallocDefault));
+    memset(host, 0, sizeof(KryDev));
+    return PSP_OK;
+  }
+  int upload() {
+    PSP_HIP(hipMemcpyAsync(dev, host, sizeof(KryDev), hipMemcpyHostToDevice, stream()));
+    return PSP_OK;
+  }
+  int fetch() {
+    PSP_HIP(hipGetLastError());
+    PSP_HIP(hipMemcpyAsync(host, dev, sizeof(KryDev), hipMemcpyDeviceToHost, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    return PSP_OK;
+  }
+};
+
+bool kry_devscal_enabled() {  // read per solve (A/B inside one process)
+  const char *e = psp::tuning_env("PSP_KRY_DEVSCAL");
+  return e ? atoi(e) != 0 : true;
+}
+
+}  // namespace
+
 // pysparse/itsolvers/src/cgs.c:14-110
 static int cgs_device(const psp_op *A, const psp_op *K, int n, double *x, const double *b, double tol,
                       int maxit, int *info, int *iter, double *res) {
@@ -1563,6 +1771,31 @@ static int cgs_device(const psp_op *A, const psp_op *K, int n, double *x, const 
     }
     double sc[2];
     int np;
+    if (kry_devscal_enabled() && maxit >= 1 && csr_spmv_has_skip(Acsr)) {
+      KryState st;
+      PSP_TRY(st.init());
+      st.host->r[CG_RHO] = rho;
+      st.host->r[CG_THR] = bnrm_sq * tol_sq;
+      st.host->maxit = maxit;
+      PSP_TRY(st.upload());
+      KryDev *S = st.dev;
+      do {
+        for (int k = 0; k < kKryBatch; ++k) {
+          PSP_TRY(csr_spmv_launch(Acsr, kp, v, r0, w->partials, &np, &S->status));
+          PSP_TRY(kry_reduce_then<kCgsD>(w->partials, np, 1, S, CG_D));
+          PSP_TRY(k_cgs_q(n, u, v, x, q, tmp2, dinv, 0.0, KryArg{S, CG_ALPHA}));
+          PSP_TRY(csr_spmv_launch(Acsr, tmp2, tmp, nullptr, nullptr, nullptr, &S->status));
+          PSP_TRY(k_cgs_r(n, r, tmp, r0, 0.0, w->partials, &np, KryArg{S, CG_ALPHA}));
+          PSP_TRY(kry_reduce_then<kCgsR>(w->partials, np, 2, S, CG_RES));
+          PSP_TRY(k_cgs_p(n, r, q, p, u, kp, dinv, 0.0, KryArg{S, CG_BETA}));
+        }
+        PSP_TRY(st.fetch());
+      } while (!st.host->status);
+      *iter = st.host->iter;
+      *res = sqrt(st.host->r[CG_RES] / bnrm_sq);
+      *info = st.host->code == 1 ? 0 : -1;
+      return PSP_OK;
+    }
     for (; *iter < maxit; (*iter)++) {
       PSP_TRY(csr_spmv_launch(Acsr, kp, v, r0, w->partials, &np, nullptr));
       PSP_TRY(reduce_fetch(w, np, 1, &d));
@@ -1664,6 +1897,41 @@ static int bicgstab_device(const psp_op *A, const psp_op *K, int n, double *x, c
     double sc[2];
     int np;
     PSP_TRY(B.dot(rhat, r, &rho_im1));
+    if (kry_devscal_enabled() && maxit >= 1 && csr_spmv_has_skip(Acsr)) {
+      *iter = 1;
+      if (rho_im1 == 0.0) return PSP_OK;  // the first iteration's head, on the host
+      KryState st;
+      PSP_TRY(st.init());
+      st.host->r[BI_RHO1] = rho_im1;
+      st.host->r[BI_RES0] = res0;
+      st.host->r[BI_TOL] = tol;
+      st.host->iter = 1;
+      st.host->maxit = maxit;
+      PSP_TRY(st.upload());
+      KryDev *S = st.dev;
+      int np2;
+      do {
+        for (int k = 0; k < kKryBatch; ++k) {
+          PSP_TRY(k_bicg_p(n, r, v, p, ph, dinv, 0.0, 0.0, false, KryArg{S, BI_BETA, BI_OMEGA}));  // first: S->iter == 1
+          PSP_TRY(csr_spmv_launch(Acsr, ph, v, rhat, w->partials, &np, &S->status));
+          PSP_TRY(kry_reduce_then<kBicgD1>(w->partials, np, 1, S, BI_D1));
+          PSP_TRY(k_bicg_s(n, r, v, s, sh, dinv, 0.0, KryArg{S, BI_ALPHA}));
+          PSP_TRY(csr_spmv_launch(Acsr, sh, t, s, w->partials, &np, &S->status));
+          PSP_TRY(kry_reduce_then<kBicgTs>(w->partials, np, 1, S, BI_D1));
+          PSP_TRY(k_dot(n, t, t, w->partials, &np2));  // (runs once more after the loop has ended: its result is ignored)
+          PSP_TRY(kry_reduce_then<kBicgTt>(w->partials, np2, 1, S, BI_D2));
+          PSP_TRY(k_bicg_xr(n, x, ph, sh, s, t, r, rhat, 0.0, 0.0, w->partials, &np, KryArg{S, BI_ALPHA, BI_OMEGA}));
+          PSP_TRY(kry_reduce_then<kBicgXr>(w->partials, np, 2, S, BI_RR));
+        }
+        PSP_TRY(st.fetch());
+      } while (!st.host->status);
+      *iter = st.host->iter;
+      if (st.host->code == 1) {
+        *relres = st.host->r[BI_RES] / res0;
+        *info = (*relres >= tol) ? -1 : 0;
+      }
+      return PSP_OK;  // codes 3 / 4: rho == 0 / omega == 0 -- info stays -6, relres untouched, like the returns below
+    }
     do {
       (*iter)++;
       if (rho_im1 == 0.0) return PSP_OK;
@@ -1761,6 +2029,48 @@ static int qmrs_device(const psp_op *A, const psp_op *K, int n, double *x, const
     double *kv = K ? wrk1 : v1;  // no preconditioner: K v1 is v1
     int np;
     bool have_delta = false;
+    if (kry_devscal_enabled() && csr_spmv_has_skip(Acsr)) {
+      KryState st;
+      PSP_TRY(st.init());
+      double *R = st.host->r;
+      R[QM_RHO0] = rho0;
+      R[QM_TAU] = tau;
+      R[QM_C0] = c0;
+      R[QM_EPS0] = eps0;
+      R[QM_XI1] = xi1;
+      R[QM_THETA0] = theta0;
+      R[QM_ETA0] = eta0;
+      R[QM_ERR] = *err;
+      R[QM_RESINIT] = res_init;
+      R[QM_TOL] = tol;
+      st.host->maxit = maxit;
+      PSP_TRY(st.upload());
+      KryDev *S = st.dev;
+      // K v1 . v1 of the first iteration, then its head (the later ones get theirs from the d / x pass)
+      PSP_TRY(k_qmrs_kv(n, v1, kv, dinv, w->partials, &np));
+      PSP_TRY(kry_reduce_then<kQmrsDelta0>(w->partials, np, 1, S, QM_OUT));
+      do {
+        for (int k = 0; k < kKryBatch; ++k) {
+          PSP_TRY(k_qmrs_pg(n, v1, kv, p, g, 0.0, KryArg{S, QM_CC}));
+          PSP_TRY(csr_spmv_launch(Acsr, g, t, g, w->partials, &np, &S->status));
+          PSP_TRY(kry_reduce_then<kQmrsEps>(w->partials, np, 1, S, QM_OUT));
+          PSP_TRY(k_qmrs_v(n, t, v1, 0.0, w->partials, &np, KryArg{S, QM_BETA}));
+          PSP_TRY(kry_reduce_then<kQmrsRho>(w->partials, np, 1, S, QM_OUT));
+          PSP_TRY(k_qmrs_dx(n, p, d, x, v1, kv, dinv, 0.0, 0.0, 0.0, w->partials, &np, KryArg{S, QM_ETA0, QM_CC2, QM_RHO1INV}));
+          PSP_TRY(kry_reduce_then<kQmrsDelta>(w->partials, np, 1, S, QM_OUT));
+        }
+        PSP_TRY(st.fetch());
+      } while (!st.host->status);
+      *iter = st.host->iter;
+      *err = st.host->r[QM_ERR];
+      if (st.host->code != 1) QMRS_RET(-st.host->code);  // 6 -> -6, 2 -> -2: left by a breakdown test
+      if (K) {
+        PSP_TRY(op_apply(K, x, wrk1));
+        PSP_TRY(B.copy(wrk1, x));
+      }
+      *info = (*err < tol) ? 0 : -1;
+      return PSP_OK;
+    }
     while (*err > tol && *iter < maxit) {
       ++(*iter);
       if (eps0 == 0.0) QMRS_RET(-6);

@@ -435,13 +435,18 @@ __global__ __launch_bounds__(kBlock) void lanczos_plain_kernel(long n, const dou
 
 // ---- MINRES update (minres.c:172-180): tmp = w; w = (v - r3*w_old - r2*tmp)/r1;
 //      w_old = tmp; x += c_eta*w.  The new w is written over w_old and the caller swaps the names.
-template <int V, bool SCALED>
-__global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double *__restrict__ v,
+// VNEXT (round 5; unscaled products only -- csr_spmv_w3 / w2 operators): the NEXT iteration's v = y / beta (minres.c:123-124,
+// scale_div_kernel's division; y and beta are final by now) is written over v in the same pass: one launch less per
+// iteration where every launch sits on the ~5 us floor (FEM stand-in, n = 9.3e5: profiles/r5_fem_minres.txt).
+template <int V, bool SCALED, bool VNEXT = false>
+__global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, double *__restrict__ v,
                                                            double vdiv, double r1, double r2, double r3,
                                                            double c_eta, const double *__restrict__ w,
                                                            double *__restrict__ w_old,
                                                            double *__restrict__ x,
-                                                           const MinresDev *__restrict__ ds) {
+                                                           const MinresDev *__restrict__ ds,
+                                                           const double *__restrict__ ynext = nullptr) {
+  double beta_next = 1.0;
   if (ds) {  // the update of the running iteration is still due when only `stop` is set
     if (ds->status) return;
     vdiv = ds->beta_old;  // beta at the start of this iteration (the scalar step has moved on)
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double 
     r2 = ds->r2;
     r3 = ds->r3;
     c_eta = ds->c_eta;
+    beta_next = ds->beta;
   }
   // SCALED: v holds the unnormalised Lanczos vector and v / vdiv is formed here (minres.c:123-124)
   PSP_VEC_LOOP(i, n) {
@@ -464,6 +470,12 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(long n, const double 
     }
     st<V>(w_old, i, wo);
     st<V>(x, i, xx);
+    if constexpr (VNEXT) {
+      Pack<V> yn = ld<V>(ynext, i);
+#pragma unroll
+      for (int u = 0; u < V; ++u) yn.v[u] = yn.v[u] / beta_next;
+      st<V>(v, i, yn);
+    }
   }
 }
 
@@ -488,7 +500,13 @@ template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void bicg_p_kernel(long n, const double *__restrict__ r,
                                                         const double *__restrict__ v, double *__restrict__ p,
                                                         double *__restrict__ phat, const double *__restrict__ dinv,
-                                                        double dc, double beta, double omega, int first) {
+                                                        double dc, double beta, double omega, int first, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    beta = ka.S->r[ka.i0];
+    omega = ka.S->r[ka.i1];
+    first = ka.S->iter == 1;
+  }
   PSP_VEC_LOOP(i, n) {
     Pack<V> pp = ld<V>(r, i);
     if (!first) {
@@ -520,7 +538,11 @@ template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void bicg_s_kernel(long n, const double *__restrict__ r,
                                                         const double *__restrict__ v, double *__restrict__ sv,
                                                         double *__restrict__ shat, const double *__restrict__ dinv,
-                                                        double dc, double alpha) {
+                                                        double dc, double alpha, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    alpha = ka.S->r[ka.i0];
+  }
   PSP_VEC_LOOP(i, n) {
     const Pack<V> rr = ld<V>(r, i), vv = ld<V>(v, i);
     Pack<V> ss;
@@ -549,7 +571,12 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_kernel(long n, double *__restr
                                                          const double *__restrict__ shat,
                                                          const double *__restrict__ sv, const double *__restrict__ t,
                                                          double *__restrict__ r, const double *__restrict__ rhat,
-                                                         double alpha, double omega, double *__restrict__ partials) {
+                                                         double alpha, double omega, double *__restrict__ partials, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    alpha = ka.S->r[ka.i0];
+    omega = ka.S->r[ka.i1];
+  }
   double acc[2] = {0.0, 0.0};
   PSP_VEC_LOOP(i, n) {
     Pack<V> xx = ld<V>(x, i);
@@ -578,7 +605,11 @@ template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void cgs_q_kernel(long n, const double *__restrict__ u,
                                                        const double *__restrict__ v, double *__restrict__ x,
                                                        double *__restrict__ q, double *__restrict__ tmp2,
-                                                       const double *__restrict__ dinv, double dc, double alpha) {
+                                                       const double *__restrict__ dinv, double dc, double alpha, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    alpha = ka.S->r[ka.i0];
+  }
   const bool upd = alpha != 0.0;
   PSP_VEC_LOOP(i, n) {
     const Pack<V> uu = ld<V>(u, i), vv = ld<V>(v, i);
@@ -602,7 +633,11 @@ __global__ __launch_bounds__(kBlock) void cgs_q_kernel(long n, const double *__r
 template <int V>
 __global__ __launch_bounds__(kBlock) void cgs_r_kernel(long n, double *__restrict__ r, const double *__restrict__ t,
                                                        const double *__restrict__ r0, double alpha,
-                                                       double *__restrict__ partials) {
+                                                       double *__restrict__ partials, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    alpha = ka.S->r[ka.i0];
+  }
   const bool upd = alpha != 0.0;
   double acc[2] = {0.0, 0.0};
   PSP_VEC_LOOP(i, n) {
@@ -624,7 +659,11 @@ template <int V, int PRE>
 __global__ __launch_bounds__(kBlock) void cgs_p_kernel(long n, const double *__restrict__ r,
                                                        const double *__restrict__ q, double *__restrict__ p,
                                                        double *__restrict__ u, double *__restrict__ kp,
-                                                       const double *__restrict__ dinv, double dc, double beta) {
+                                                       const double *__restrict__ dinv, double dc, double beta, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    beta = ka.S->r[ka.i0];
+  }
   const bool upd = beta != 0.0;
   PSP_VEC_LOOP(i, n) {
     const Pack<V> rr = ld<V>(r, i), qq = ld<V>(q, i), po = ld<V>(p, i);
@@ -683,7 +722,11 @@ __global__ __launch_bounds__(kBlock) void qmrs_kv_kernel(long n, const double *_
 template <int V>
 __global__ __launch_bounds__(kBlock) void qmrs_pg_kernel(long n, const double *__restrict__ v1,
                                                          const double *__restrict__ wrk1, double *__restrict__ p,
-                                                         double *__restrict__ g, double cc) {
+                                                         double *__restrict__ g, double cc, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    cc = ka.S->r[ka.i0];
+  }
   PSP_VEC_LOOP(i, n) {
     const Pack<V> vv = ld<V>(v1, i), ww = ld<V>(wrk1, i);
     Pack<V> pp = ld<V>(p, i), gg = ld<V>(g, i);
@@ -700,7 +743,11 @@ __global__ __launch_bounds__(kBlock) void qmrs_pg_kernel(long n, const double *_
 //   v1 = t - beta*v1;  partial v1.v1
 template <int V>
 __global__ __launch_bounds__(kBlock) void qmrs_v_kernel(long n, const double *__restrict__ t, double *__restrict__ v1,
-                                                        double beta, double *__restrict__ partials) {
+                                                        double beta, double *__restrict__ partials, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    beta = ka.S->r[ka.i0];
+  }
   double acc[1] = {0.0};
   PSP_VEC_LOOP(i, n) {
     const Pack<V> tt = ld<V>(t, i);
@@ -721,7 +768,13 @@ __global__ __launch_bounds__(kBlock) void qmrs_dx_kernel(long n, const double *_
                                                          double *__restrict__ x, double *__restrict__ v1,
                                                          double *__restrict__ wrk1, const double *__restrict__ dinv,
                                                          double dc, double eta, double cc, double rho1inv,
-                                                         double *__restrict__ partials) {
+                                                         double *__restrict__ partials, KryArg ka) {
+  if (ka.S) {
+    if (ka.S->status) return;
+    eta = ka.S->r[ka.i0];
+    cc = ka.S->r[ka.i1];
+    rho1inv = ka.S->r[ka.i2];
+  }
   double acc[1] = {0.0};
   PSP_VEC_LOOP(i, n) {
     const Pack<V> pp = ld<V>(p, i);
@@ -1112,7 +1165,7 @@ int k_lin2(long n, double a, const double *x, double b, const double *y, double 
 }
 
 int k_bicg_p(long n, const double *r, const double *v, double *p, double *phat, const double *dinv, double beta,
-             double omega, bool first) {
+             double omega, bool first, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -1121,7 +1174,7 @@ int k_bicg_p(long n, const double *r, const double *v, double *p, double *phat, 
   const bool v2 = dinv ? (cst ? can_vec2(n, r, v, p, phat) : can_vec2(n, r, v, p, phat, dinv)) : can_vec2(n, r, v, p);
 #define L(V, PRE)                                                                                       \
   hipLaunchKernelGGL((bicg_p_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, v, p, phat, \
-                     dinv, dc, beta, omega, first ? 1 : 0)
+                     dinv, dc, beta, omega, first ? 1 : 0, ka)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -1130,7 +1183,7 @@ int k_bicg_p(long n, const double *r, const double *v, double *p, double *phat, 
   return PSP_OK;
 }
 
-int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, const double *dinv, double alpha) {
+int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, const double *dinv, double alpha, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -1139,7 +1192,7 @@ int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, 
   const bool v2 = dinv ? (cst ? can_vec2(n, r, v, s, shat) : can_vec2(n, r, v, s, shat, dinv)) : can_vec2(n, r, v, s);
 #define L(V, PRE)                                                                                    \
   hipLaunchKernelGGL((bicg_s_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, v, s, shat, \
-                     dinv, dc, alpha)
+                     dinv, dc, alpha, ka)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -1149,23 +1202,23 @@ int k_bicg_s(long n, const double *r, const double *v, double *s, double *shat, 
 }
 
 int k_bicg_xr(long n, double *x, const double *phat, const double *shat, const double *s, const double *t, double *r,
-              const double *rhat, double alpha, double omega, double *partials, int *nparts) {
+              const double *rhat, double alpha, double omega, double *partials, int *nparts, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   if (can_vec2(n, x, phat, shat, s, t, r, rhat))
     hipLaunchKernelGGL(bicg_xr_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, x, phat, shat, s, t, r, rhat,
-                       alpha, omega, partials);
+                       alpha, omega, partials, ka);
   else
     hipLaunchKernelGGL(bicg_xr_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, x, phat, shat, s, t, r, rhat,
-                       alpha, omega, partials);
+                       alpha, omega, partials, ka);
   PSP_LAUNCH_CHECK();
   *nparts = grid;
   return PSP_OK;
 }
 
 int k_cgs_q(long n, const double *u, const double *v, double *x, double *q, double *tmp2, const double *dinv,
-            double alpha) {
+            double alpha, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -1174,7 +1227,7 @@ int k_cgs_q(long n, const double *u, const double *v, double *x, double *q, doub
   const bool v2 = dinv && !cst ? can_vec2(n, u, v, x, q, tmp2, dinv) : can_vec2(n, u, v, x, q, tmp2);
 #define L(V, PRE)                                                                                       \
   hipLaunchKernelGGL((cgs_q_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, u, v, x, q, tmp2, \
-                     dinv, dc, alpha)
+                     dinv, dc, alpha, ka)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -1183,21 +1236,21 @@ int k_cgs_q(long n, const double *u, const double *v, double *x, double *q, doub
   return PSP_OK;
 }
 
-int k_cgs_r(long n, double *r, const double *t, const double *r0, double alpha, double *partials, int *nparts) {
+int k_cgs_r(long n, double *r, const double *t, const double *r0, double alpha, double *partials, int *nparts, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   if (can_vec2(n, r, t, r0))
-    hipLaunchKernelGGL(cgs_r_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials);
+    hipLaunchKernelGGL(cgs_r_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials, ka);
   else
-    hipLaunchKernelGGL(cgs_r_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials);
+    hipLaunchKernelGGL(cgs_r_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, r, t, r0, alpha, partials, ka);
   PSP_LAUNCH_CHECK();
   *nparts = grid;
   return PSP_OK;
 }
 
 int k_cgs_p(long n, const double *r, const double *q, double *p, double *u, double *kp, const double *dinv,
-            double beta) {
+            double beta, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -1206,7 +1259,7 @@ int k_cgs_p(long n, const double *r, const double *q, double *p, double *u, doub
   const bool v2 = dinv ? (cst ? can_vec2(n, r, q, p, u, kp) : can_vec2(n, r, q, p, u, kp, dinv)) : can_vec2(n, r, q, p, u);
 #define L(V, PRE)                                                                                    \
   hipLaunchKernelGGL((cgs_p_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, r, q, p, u, kp, \
-                     dinv, dc, beta)
+                     dinv, dc, beta, ka)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -1234,33 +1287,33 @@ int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double
   return PSP_OK;
 }
 
-int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc) {
+int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   if (can_vec2(n, v1, wrk1, p, g))
-    hipLaunchKernelGGL(qmrs_pg_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc);
+    hipLaunchKernelGGL(qmrs_pg_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc, ka);
   else
-    hipLaunchKernelGGL(qmrs_pg_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc);
+    hipLaunchKernelGGL(qmrs_pg_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, v1, wrk1, p, g, cc, ka);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }
 
-int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts) {
+int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   if (can_vec2(n, t, v1))
-    hipLaunchKernelGGL(qmrs_v_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials);
+    hipLaunchKernelGGL(qmrs_v_kernel<2>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials, ka);
   else
-    hipLaunchKernelGGL(qmrs_v_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials);
+    hipLaunchKernelGGL(qmrs_v_kernel<1>, dim3(grid), dim3(kBlock), 0, stream(), n, t, v1, beta, partials, ka);
   PSP_LAUNCH_CHECK();
   *nparts = grid;
   return PSP_OK;
 }
 
 int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double *wrk1, const double *dinv, double eta,
-              double cc, double rho1inv, double *partials, int *nparts) {
+              double cc, double rho1inv, double *partials, int *nparts, KryArg ka) {
   Workspace *w;
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
@@ -1270,7 +1323,7 @@ int k_qmrs_dx(long n, const double *p, double *d, double *x, double *v1, double 
                        : can_vec2(n, p, d, x, v1);
 #define L(V, PRE)                                                                                          \
   hipLaunchKernelGGL((qmrs_dx_kernel<V, PRE>), dim3(grid), dim3(kBlock), 0, stream(), n, p, d, x, v1, wrk1, \
-                     dinv, dc, eta, cc, rho1inv, partials)
+                     dinv, dc, eta, cc, rho1inv, partials, ka)
   if (cst) { if (v2) L(2, 2); else L(1, 2); }
   else if (dinv) { if (v2) L(2, 1); else L(1, 1); }
   else { if (v2) L(2, 0); else L(1, 0); }
@@ -1314,12 +1367,29 @@ int k_minres_wx(long n, const double *v, double r1, double r2, double r3, double
   PSP_TRY(workspace(&w));
   const int grid = vec_grid(*w, n);
   const bool v2 = can_vec2(n, v, w_, w_old, x);
+  double *vm = const_cast<double *>(v);  // (only the VNEXT form writes v)
 #define L(V, S)                                                                                   \
-  hipLaunchKernelGGL((minres_wx_kernel<V, S>), dim3(grid), dim3(kBlock), 0, stream(), n, v, vdiv, r1, \
-                     r2, r3, c_eta, w_, w_old, x, ds)
+  hipLaunchKernelGGL((minres_wx_kernel<V, S>), dim3(grid), dim3(kBlock), 0, stream(), n, vm, vdiv, r1, \
+                     r2, r3, c_eta, w_, w_old, x, ds, (const double *)nullptr)
   if (scaled) { if (v2) L(2, true); else L(1, true); }
   else { if (v2) L(2, false); else L(1, false); }
 #undef L
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
+// the w / x update of the running iteration AND v = ynext / beta of the next one (device-resident scalars, unscaled products)
+int k_minres_wx_vnext(long n, double *v, const double *ynext, const double *w_, double *w_old, double *x,
+                      const MinresDev *ds) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  const int grid = vec_grid(*w, n);
+  if (can_vec2(n, v, w_, w_old, x) && can_vec2(n, ynext, v))
+    hipLaunchKernelGGL((minres_wx_kernel<2, false, true>), dim3(grid), dim3(kBlock), 0, stream(), n, v, 1.0, 0.0, 0.0, 0.0,
+                       0.0, w_, w_old, x, ds, ynext);
+  else
+    hipLaunchKernelGGL((minres_wx_kernel<1, false, true>), dim3(grid), dim3(kBlock), 0, stream(), n, v, 1.0, 0.0, 0.0, 0.0,
+                       0.0, w_, w_old, x, ds, ynext);
   PSP_LAUNCH_CHECK();
   return PSP_OK;
 }

@@ -149,3 +149,48 @@ def test_gpu_more_solvers_unfused_paths_still_match_oracle():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "4 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_scalars_give_the_host_scalar_loops_bits():
+    """cgs / bicgstab / qmrs (round 5): the recurrences of cgs.c / bicgstab.c / qmrs.c run in the thread that finishes each
+    reduction and the host reads the state once per batch of iterations; PSP_KRY_DEVSCAL=0 keeps the loops that read
+    every reduced value back.  The same expressions on the same reduced values: info, iteration count, residual and x
+    must agree BIT FOR BIT -- converged runs, every small truncation point (the batch boundary at 8 included), with and
+    without Jacobi, on a stencil operator (csr_spmv_w4), a general banded one (csr_spmv_w3) and an sss_mat, and for the
+    breakdown exits (zero right-hand side / exact start)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);\n"
+        "from pysparse_amd import device as dev\n"
+        "out = []\n"
+        "ops = [dev.DeviceCSR.poisson(60, 50), dev.DeviceSSS.poisson(20, 18, 16)]\n"
+        "W = dev.DeviceCSR.poisson(70, 40); W.set_variant(1065154); assert W.kernel_info()[0] == 'csr_spmv_w3'; ops.append(W)\n"
+        "for M in ops:\n"
+        "    n = M.shape[0] if hasattr(M, 'shape') else M.n\n"
+        "    b = np.random.default_rng(3).standard_normal(n)\n"
+        "    for K in (None, dev.DeviceJacobi(M)):\n"
+        "        for name in ('cgs', 'bicgstab', 'qmrs'):\n"
+        "            for tol, mx in [(1e-10, 3000)] + [(0.0, k) for k in (0, 1, 2, 3, 7, 8, 9, 16, 17, 40)]:\n"
+        "                x = np.zeros(n); r = getattr(dev, name)(M, b, x, tol, mx, K)\n"
+        "                out.append([name, r[0], r[1], float(r[2]).hex(), float(np.abs(x).sum()).hex(), x.tobytes().hex()[:128]])\n"
+        "    for name in ('cgs', 'bicgstab', 'qmrs'):\n"  # zero right-hand side; a start that already solves the system
+        "        x = np.ones(n); r = getattr(dev, name)(M, np.zeros(n), x, 1e-8, 50, None); out.append([name, 'b=0', r[0], r[1], float(np.abs(x).sum()).hex()])\n"
+        "        y = np.empty(n); M.matvec(np.ones(n), y); x = np.ones(n); r = getattr(dev, name)(M, y, x, 1e-8, 50, None); out.append([name, 'exact', r[0], r[1], float(np.abs(x).sum()).hex()])\n"
+        "print(json.dumps(out))"
+    ) % root
+    outs = []
+    for env in ({}, {"PSP_KRY_DEVSCAL": "0"}):
+        e = dict(os.environ, PSP_TUNING="1")
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert len(outs[0]) == len(outs[1]) > 200
+    for a, b in zip(outs[0], outs[1]):
+        assert a == b, (a[:4], b[:4])
+    assert any(r[1] == 0 for r in outs[0] if isinstance(r[1], int))  # the converged runs converged
