@@ -494,6 +494,10 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available);
 bool mid_applicable(const psp_csr *A, int n, const double *dinv);
 int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                  double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist);
+bool mid_minres_applicable(const psp_csr *A, int n);
+int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
+                    double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,
+                    int *info, int *iter, double *relres, double *hist);
 // psp_coop.hip: the whole loop as one kernel for small systems (grid barriers instead of dependent launches).
 // The two loops return kCoopFallback (not an error; nothing was changed) when the cooperative launch is refused or a
 // grid barrier gives up: the caller then runs its launch-per-phase loop from the same vectors.

@@ -197,7 +197,9 @@ __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src,
 // lane (rows outside the matrix skipped).  Asynchronous: the caller waits (s_waitcnt vmcnt(0)) before it reads.
 // Issued together with the partial sums' copies, the halo costs no round trip of its own; read with ordinary loads in a
 // loop it cost three (no registers to keep them in flight).
-__device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, int H, int n, double *hst) {
+__device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, int H, int n, double *hst, int zone1 = -1) {
+  // zone1 < 0: the second zone follows the first (hst[H ..)); else it starts at hst[zone1] (the window's upper halo)
+  const int z1 = zone1 < 0 ? H : zone1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int zone = 0; zone < 2; ++zone) {
@@ -206,9 +208,9 @@ __device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, 
       const int e = e0 + 2 * lane;
       const long g = row0 + e;
       if (e < H && g >= 0 && g + 1 < n)
-        __builtin_amdgcn_global_load_lds((global_void_ptr)(r + g), (lds_void_ptr)(hst + zone * H + e0), 16, 0, 16);
+        __builtin_amdgcn_global_load_lds((global_void_ptr)(r + g), (lds_void_ptr)(hst + zone * z1 + e0), 16, 0, 16);
       else if (e < H && g >= 0 && g < n)  // the matrix' last row when n is odd: one lane in the whole grid
-        hst[zone * H + e] = mcoh_load(r + g);
+        hst[zone * z1 + e] = mcoh_load(r + g);
     }
   }
 }
@@ -486,6 +488,261 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
   }
 }
 
+// minres.c:96-193 from the head of iteration 1 (v_hat = b - A x, y = K v_hat, beta = sqrt(v_hat . y), the first loop test and
+// w = w_old = v_hat_old = 0 are the caller's) -- the same structure as pcg_mid_kernel.  What crosses workgroups is the
+// unnormalised Lanczos vector y (= K v_hat), published at the barrier of the v_hat . y reduction; every reader divides the
+// entries it gathers by beta itself (the owner's own correctly rounded division), so v = y / beta is never exchanged.  The
+// window holds nothing between iterations here, so the partial sums are staged in its own part and the neighbours' y is
+// copied straight into its halo zones.  Expressions: csr_spmv_w4's scaled product, lanczos_kernel, minres_wx_kernel
+// (psp_vec.hip), minres_scalar_alpha / minres_scalar_beta (psp_solvers.hip) -- the launch-per-phase loop's bits.
+struct MidMinresArgs {
+  int n, nwg, H;
+  int offs[8];
+  const double *valT;
+  const unsigned short *mask;
+  const double *dinv;
+  double dc;
+  int pre;
+  const double *x;
+  double *xout;
+  const double *v_hat;
+  double *yv;  // in: K v_hat (v_hat itself without a preconditioner); the kernel publishes its block-boundary rows here
+  double norm_r0, beta0, errtol;
+  int it_max;
+  MidCtl *ctl;
+  double *part;  // 2 x kMidMaxSpans: v . Av | v_hat . y, by span
+  double *hist;
+  int np_w4, stripe, nspans;
+};
+
+template <int NO, int LAYERS>
+__global__ __launch_bounds__(kMidBlock) void minres_mid_kernel(MidMinresArgs a) {
+  extern __shared__ double lds[];
+  constexpr int B = LAYERS * kMidLayer;
+  constexpr int NW = kMidBlock / 64;
+  constexpr bool X_LDS = LAYERS == 2;  // two layers: x, w, w_old of the own rows live in LDS
+  const int H = a.H;
+  double *win = lds;                   // v = y / beta at rows [base - H, base + B + H); between iterations: staging
+  double *xl = lds + (2 * H + B);
+  double *wl = xl + (X_LDS ? B : 0);
+  double *wol = wl + (X_LDS ? B : 0);
+  double *red = wol + (X_LDS ? B : 0);  // LAYERS * NW wave sums
+  double *grp = red + LAYERS * NW;      // mid_reduce's scratch: 16 + 1
+  double *stage = win + H;              // the partial sums, staged in the window's own part (dead at both barriers)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wg = blockIdx.x, nwg = a.nwg, n = a.n;
+  const long base = (long)wg * B;
+  const int pre = a.pre;
+  const double dc = a.dc;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v[LAYERS][NO];
+  unsigned m0[LAYERS], m1[LAYERS];
+  double xr[LAYERS][2], wr[LAYERS][2], wo[LAYERS][2], vh[LAYERS][2], vho[LAYERS][2], yr[LAYERS][2], avr[LAYERS][2];
+  bool in0[LAYERS], in1[LAYERS];
+#pragma unroll
+  for (int L = 0; L < LAYERS; ++L) {
+    const long row = base + (long)L * kMidLayer + 2 * t;
+    in0[L] = row < n;
+    in1[L] = row + 1 < n;
+    m0[L] = m1[L] = 0;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) v[L][o] = d2{0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) xr[L][u] = wr[L][u] = wo[L][u] = vh[L][u] = vho[L][u] = yr[L][u] = avr[L][u] = 0.0;
+    if (in0[L]) {
+      const unsigned mm = *reinterpret_cast<const unsigned *>(a.mask + row);
+      m0[L] = mm & 0xffffu;
+      m1[L] = mm >> 16;
+      const double *vp = a.valT + (size_t)(row / 128) * NO * 128 + (size_t)(row % 128);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) v[L][o] = *reinterpret_cast<const d2 *>(vp + o * 128);
+      xr[L][0] = a.x[row];
+      vh[L][0] = a.v_hat[row];
+      yr[L][0] = a.yv[row];
+      if (in1[L]) {
+        xr[L][1] = a.x[row + 1];
+        vh[L][1] = a.v_hat[row + 1];
+        yr[L][1] = a.yv[row + 1];
+      }
+    }
+    if constexpr (X_LDS) {
+      const int li = L * kMidLayer + 2 * t;
+      xl[li] = xr[L][0];
+      xl[li + 1] = xr[L][1];
+      wl[li] = wl[li + 1] = 0.0;
+      wol[li] = wol[li + 1] = 0.0;
+    }
+  }
+  for (int i = t; i < 2 * H + B; i += kMidBlock) win[i] = 0.0;
+  __syncthreads();
+  // the neighbours' y into the window's halo zones (rows outside the matrix stay 0)
+  mid_halo_dma(a.yv, base, B, H, n, win, H + B);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned gen = 0;
+  double beta = a.beta0, beta_old = 1.0, c = 1.0, c_old = 1.0, sn = 0.0, s_old = 0.0, eta = a.beta0, norm_rmr = a.norm_r0;
+  int it = 1, info = 1;  // 1: left by the loop test (0 / -1 decided there)
+  double relres = 0.0;
+  for (;;) {
+    // ---- v = y / beta (minres.c:123-124): own rows and halo, into the window
+#pragma unroll
+    for (int L = 0; L < LAYERS; ++L)
+      if (in0[L]) {
+        win[H + L * kMidLayer + 2 * t] = yr[L][0] / beta;
+        win[H + L * kMidLayer + 2 * t + 1] = in1[L] ? yr[L][1] / beta : 0.0;
+      }
+    for (int h = t; h < 2 * H; h += kMidBlock) {
+      const int wi = h < H ? h : B + h;
+      const long g = base - H + wi;
+      if (g >= 0 && g < n) win[wi] = win[wi] / beta;
+    }
+    __syncthreads();
+    // ---- Av = A v (:127-129; csr_spmv_w4's order), alpha = v . Av
+#pragma unroll
+    for (int L = 0; L < LAYERS; ++L) {
+      double a0 = 0.0, a1 = 0.0;
+      const int c0 = H + L * kMidLayer + 2 * t;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const double p0 = win[c0 + a.offs[o]], p1 = win[c0 + a.offs[o] + 1];
+        const double t0 = a0 + v[L][o].x * p0;
+        const double t1 = a1 + v[L][o].y * p1;
+        a0 = ((m0[L] >> o) & 1u) ? t0 : a0;
+        a1 = ((m1[L] >> o) & 1u) ? t1 : a1;
+      }
+      avr[L][0] = a0;
+      avr[L][1] = a1;
+      double dsum = 0.0;
+      if (in0[L]) {
+        dsum += win[c0] * a0;
+        if (in1[L]) dsum += win[c0 + 1] * a1;
+      }
+      dsum = psp_wave_sum(dsum);
+      if (lane == 0) red[L * NW + wave] = dsum;
+    }
+    __syncthreads();
+    if (t < LAYERS * 4) {
+      const int gs = wg * (B / kMidSpan) + t;
+      if (gs < a.nspans) mcoh_store(a.part + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
+    }
+    double s1[1];
+    if (!mid_barrier_reduce<1>(a.ctl, nwg, gen, s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp)) return;
+    const double alpha = s1[0];
+    const double c1 = alpha / beta, c2 = beta / beta_old;  // :131
+    // ---- Lanczos update (:131-143; lanczos_kernel's expressions), beta^2 = v_hat . y; y published for the neighbours
+    double yold[LAYERS][2];
+#pragma unroll
+    for (int L = 0; L < LAYERS; ++L) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        yold[L][u] = yr[L][u];
+        if (u == 0 ? in0[L] : in1[L]) {
+          const double nv = avr[L][u] - c1 * vh[L][u] - c2 * vho[L][u];
+          vho[L][u] = vh[L][u];
+          vh[L][u] = nv;
+          if (pre != 0) {
+            const double yy = nv * (pre == 1 ? a.dinv[base + L * kMidLayer + 2 * t + u] : dc);
+            yr[L][u] = yy;
+            acc += nv * yy;
+          } else {
+            yr[L][u] = nv;
+            acc += nv * nv;
+          }
+        }
+      }
+      acc = psp_wave_sum(acc);
+      if (lane == 0) red[L * NW + wave] = acc;
+      const int lr = L * kMidLayer + 2 * t;
+      if (in0[L] && (lr < H || lr + 2 > B - H)) {
+        const long row = base + lr;
+        mcoh_store(a.yv + row, yr[L][0]);
+        if (in1[L]) mcoh_store(a.yv + row + 1, yr[L][1]);
+      }
+    }
+    __syncthreads();
+    if (t < LAYERS * 4) {
+      const int gs = wg * (B / kMidSpan) + t;
+      if (gs < a.nspans)
+        mcoh_store(a.part + kMidMaxSpans + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
+    }
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+    mid_halo_dma(a.yv, base, B, H, n, win, H + B);  // the next iteration's halo rides with the partial sums
+    mid_reduce<1>(s1, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
+    // ---- minres_scalar_beta: :143-164, :180, :192
+    const double beta_start = beta;  // beta at the start of this iteration
+    beta_old = beta;
+    double b2 = s1[0];
+    if (b2 < 0.0) {  // :144-146
+      info = -3;
+      break;
+    }
+    beta = sqrt(b2);
+    const double c_oold = c_old, s_oold = s_old;
+    c_old = c;
+    s_old = sn;
+    const double r1_hat = c_old * alpha - c_oold * s_old * beta_old;
+    const double r1 = sqrt(r1_hat * r1_hat + beta * beta);
+    const double r2 = s_old * alpha + c_oold * c_old * beta_old;
+    const double r3 = s_oold * beta_old;
+    if (r1 == 0.0) {  // :160-162
+      info = -6;
+      break;
+    }
+    c = r1_hat / r1;
+    sn = beta / r1;
+    const double c_eta = c * eta;
+    eta = -sn * eta;
+    norm_rmr = norm_rmr * fabs(sn);
+    if (a.hist && wg == 0 && t == 0) a.hist[it] = norm_rmr;
+    // ---- w / x update (:172-180; minres_wx_kernel's expressions, v = y_old / beta formed again)
+#pragma unroll
+    for (int L = 0; L < LAYERS; ++L) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0 ? in0[L] : in1[L]) {
+          const int li = L * kMidLayer + 2 * t + u;
+          const double vv = yold[L][u] / beta_start;
+          const double ww = X_LDS ? wl[li] : wr[L][u];
+          const double wov = X_LDS ? wol[li] : wo[L][u];
+          double xv = X_LDS ? xl[li] : xr[L][u];
+          const double nw = (vv - r3 * wov - r2 * ww) / r1;
+          xv += c_eta * nw;
+          if constexpr (X_LDS) {
+            wol[li] = ww;
+            wl[li] = nw;
+            xl[li] = xv;
+          } else {
+            wo[L][u] = ww;
+            wr[L][u] = nw;
+            xr[L][u] = xv;
+          }
+        }
+      }
+    }
+    // ---- the loop test at the head of the next iteration (:114, strict <)
+    const bool conv = norm_rmr < a.errtol * a.norm_r0;
+    if (it >= a.it_max || conv) {
+      info = conv ? 0 : -1;
+      relres = norm_rmr / a.norm_r0;
+      break;
+    }
+    it += 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a halo copy may still be in flight)
+#pragma unroll
+  for (int L = 0; L < LAYERS; ++L) {
+    const long row = base + (long)L * kMidLayer + 2 * t;
+    if (in0[L]) a.xout[row] = X_LDS ? xl[L * kMidLayer + 2 * t] : xr[L][0];
+    if (in1[L]) a.xout[row + 1] = X_LDS ? xl[L * kMidLayer + 2 * t + 1] : xr[L][1];
+  }
+  if (wg == 0 && t == 0) {
+    a.ctl->info = info;
+    a.ctl->iter = it;
+    a.ctl->relres = relres;
+  }
+}
+
 std::atomic<long long> g_mid_solves{0}, g_mid_fallbacks{0};
 
 bool mid_enabled() {
@@ -518,6 +775,23 @@ const void *mid_kernel(int no, int layers) {
 #undef PSP_MID_K
 }
 
+template <int NO, int LAYERS>
+const void *mid_minres_kernel_ptr() {
+  return (const void *)minres_mid_kernel<NO, LAYERS>;
+}
+
+const void *mid_minres_kernel(int no, int layers) {
+#define PSP_MID_K(NO)                                              \
+  case NO:                                                          \
+    return layers == 1 ? mid_minres_kernel_ptr<NO, 1>() : mid_minres_kernel_ptr<NO, 2>()
+  switch (no) {
+    PSP_MID_K(1); PSP_MID_K(2); PSP_MID_K(3); PSP_MID_K(4); PSP_MID_K(5); PSP_MID_K(6); PSP_MID_K(7);
+    default:
+      return nullptr;
+  }
+#undef PSP_MID_K
+}
+
 struct MidPlan {
   W4View w4;
   int layers, nwg, H;
@@ -527,7 +801,7 @@ struct MidPlan {
 
 // the plan for this operator, or false: no index-free layout of <= 7 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
-bool mid_plan(const psp_csr *A, int n, MidPlan *P) {
+bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
   if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < mid_min_rows() || n > kMidMaxRows) return false;
   int av = 0;
   if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no > 7) return false;
@@ -540,11 +814,14 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P) {
   const int B = P->layers * kMidLayer;
   P->nwg = (n + B - 1) / B;
   const int nspans = (n + kMidSpan - 1) / kMidSpan;
-  P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 2 * B : 0) + 3 * P->layers * 16 + 3 * 16 + 4 +
-                                     2 * ((nspans + 127) & ~127) + (P->layers == 2 ? 0 : 2 * P->H));
+  if (minres)  // window (also the staging area) + x, w, w_old with two layers + the wave sums and mid_reduce's scratch
+    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 3 * B : 0) + P->layers * 16 + 18);
+  else
+    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 2 * B : 0) + 3 * P->layers * 16 + 3 * 16 + 4 +
+                                       2 * ((nspans + 127) & ~127) + (P->layers == 2 ? 0 : 2 * P->H));
   if (P->nwg > kMidMaxWg || P->lds > (size_t)kMidMaxLds) return false;
   if (P->w4.grid > 4096 || (n + kMidSpan - 1) / kMidSpan > kMidMaxSpans) return false;
-  P->kernel = mid_kernel(P->w4.no, P->layers);
+  P->kernel = minres ? mid_minres_kernel(P->w4.no, P->layers) : mid_kernel(P->w4.no, P->layers);
   if (!P->kernel) return false;
   // the grid must be resident at once: one workgroup per CU with this much LDS
   static std::mutex mu;
@@ -573,6 +850,106 @@ bool mid_applicable(const psp_csr *A, int n, const double *dinv) {
   (void)dinv;
   MidPlan P;
   return mid_plan(A, n, &P);
+}
+
+bool mid_minres_applicable(const psp_csr *A, int n) {
+  MidPlan P;
+  return mid_plan(A, n, &P, true);
+}
+
+// On kCoopFallback x, v_hat and y are what they were on entry (x: staged in w, which is zeroed again; y -- whose
+// block-boundary rows the kernel overwrites -- restored from the copy kept in av); as minres_coop_loop (psp_coop.hip).
+int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
+                    double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,
+                    int *info, int *iter, double *relres, double *hist) {
+  MidPlan P;
+  if (!mid_plan(A, n, &P, true)) return kCoopFallback;
+  (void)v_hat_old;
+  (void)w_old;
+  struct Mem {
+    MidCtl *ctl = nullptr;
+    double *part = nullptr, *hist = nullptr;
+    ~Mem() {
+      if (ctl) (void)hipFree(ctl);
+      if (part) (void)hipFree(part);
+      if (hist) (void)hipFree(hist);
+    }
+  } m;
+  PSP_HIP(hipMalloc((void **)&m.ctl, sizeof(MidCtl)));
+  PSP_HIP(hipMalloc((void **)&m.part, sizeof(double) * 2 * kMidMaxSpans));
+  PSP_HIP(hipMemsetAsync(m.ctl, 0, sizeof(MidCtl), stream()));
+  PSP_HIP(hipMemsetAsync(m.part, 0, sizeof(double) * 2 * kMidMaxSpans, stream()));
+  if (hist) {
+    PSP_HIP(hipMalloc((void **)&m.hist, sizeof(double) * ((size_t)it_max + 2)));
+    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * ((size_t)it_max + 2), stream()));
+  }
+  double *yv = y;  // the vector that crosses workgroups: K v_hat, or v_hat itself without a preconditioner
+  if (!dinv) {
+    yv = v;
+    PSP_HIP(hipMemcpyAsync(yv, v_hat, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  } else {
+    PSP_HIP(hipMemcpyAsync(av, y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  }
+  MidMinresArgs a;
+  a.n = n;
+  a.nwg = P.nwg;
+  a.H = P.H;
+  for (int i = 0; i < 8; ++i) a.offs[i] = P.w4.offs[i];
+  a.valT = P.w4.valT;
+  a.mask = P.w4.mask;
+  a.dinv = dinv;
+  a.dc = 0.0;
+  a.pre = !dinv ? 0 : (dinv_constant(dinv, n, &a.dc) ? 2 : 1);
+  a.x = x;
+  a.xout = w;
+  a.v_hat = v_hat;
+  a.yv = yv;
+  a.norm_r0 = norm_r0;
+  a.beta0 = beta0;
+  a.errtol = errtol;
+  a.it_max = it_max;
+  a.ctl = m.ctl;
+  a.part = m.part;
+  a.hist = m.hist;
+  a.np_w4 = P.w4.grid;
+  a.stripe = P.w4.stripe;
+  a.nspans = (n + kMidSpan - 1) / kMidSpan;
+  void *args[] = {&a};
+  int rc = PSP_OK;
+  const char *ff = tuning_env("PSP_COOP_FAIL");
+  if (ff && atoi(ff) == 1) {
+    rc = kCoopFallback;
+  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(kMidBlock), args, (unsigned)P.lds, stream()) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = kCoopFallback;
+  }
+  MidCtl c;
+  if (rc == PSP_OK) {
+    PSP_HIP(hipMemcpyAsync(&c, m.ctl, sizeof(MidCtl), hipMemcpyDeviceToHost, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    if (c.error) rc = kCoopFallback;
+  }
+  if (rc == kCoopFallback) {
+    g_mid_fallbacks.fetch_add(1);
+    if (dinv) PSP_HIP(hipMemcpyAsync(y, av, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+    PSP_HIP(hipMemsetAsync(w, 0, sizeof(double) * (size_t)n, stream()));
+  }
+  if (rc != PSP_OK) return rc;
+  g_mid_solves.fetch_add(1);
+  PSP_HIP(hipMemcpyAsync(x, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  *info = c.info;
+  *iter = c.iter;
+  if (c.info == 0 || c.info == -1) *relres = c.relres;
+  if (hist) {
+    const int cnt = std::min(c.iter, it_max);
+    if (cnt >= 1) {
+      std::vector<double> h((size_t)cnt);
+      PSP_HIP(hipMemcpy(h.data(), m.hist + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; ++i)
+        if (h[i] == h[i]) hist[1 + i] = h[i];
+    }
+  }
+  return PSP_OK;
 }
 
 // On kCoopFallback x and r are what they were on entry: the kernel leaves its x in a staging vector (p) that is copied

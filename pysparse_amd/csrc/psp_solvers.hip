@@ -1335,6 +1335,12 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   double norm_rmr = norm_r0;
   if (hist) hist[0] = norm_rmr;
 
+  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && mid_minres_applicable(Acsr, n)) {
+    // mid-size offset-structured system: the whole loop is one cooperative kernel (psp_mid.hip), the launch-per-phase bits
+    const int rc = minres_mid_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
+                                   beta, errtol, it_max, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;
+  }
   if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n)) {
     // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,

@@ -48,10 +48,11 @@ for case in spec:
     s0 = C.c_longlong(); f0 = C.c_longlong()
     L.psp_debug_mid_count(C.byref(s0), C.byref(f0))
     for Kname in case["K"]:
-        K = None if Kname == "none" else dev.DeviceJacobi(A)
+      K = None if Kname == "none" else dev.DeviceJacobi(A)
+      for solver in case.get("solvers", ["pcg"]):
         for tol, maxit in case["runs"]:
             x = np.zeros(n)
-            r = dev.pcg(A, b, x, tol, maxit, K, hist=True)
+            r = getattr(dev, solver)(A, b, x, tol, maxit, K, hist=True)
             h = np.asarray(r[3], dtype=np.float64)
             out.append([r[0], r[1], float(r[2]).hex(), x.tobytes().hex()[:256], float(np.abs(x).sum()).hex(),
                         float(np.nansum(h)).hex(), int(np.isnan(h).sum())])
@@ -100,10 +101,35 @@ def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
     assert a[-1][0] == 0  # the last run of every spec converges
 
 
+@pytest.mark.parametrize("spec", [
+    [{"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+    [{"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+    [{"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+    [{"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+    [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+    [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:],
+      "solvers": ["minres"]}],
+], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq"])
+def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
+    """minres.c:96-193 in one kernel (minres_mid_kernel): the same comparison, every field for equality"""
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0"})
+    nsolves = sum(len(c["K"]) * len(c["runs"]) for c in spec)
+    assert [r for r in mid if r[0] == "mid_solves"] == [["mid_solves", nsolves, 0]], mid[-1]
+    assert [r for r in ref if r[0] == "mid_solves"] == [["mid_solves", 0, 0]]
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert len(a) == len(b) == nsolves
+    for k, (ra, rb) in enumerate(zip(a, b)):
+        assert ra == rb, (k, ra[:3], rb[:3])
+    assert a[-1][0] == 0
+
+
 def test_refused_or_failed_launch_falls_back_with_the_same_result():
-    spec = [{"kind": "poisson", "grid": [600, 600, 0], "K": ["jacobi"], "runs": [[0.0, 9], [1e-9, 5000]]}]
+    spec = [{"kind": "poisson", "grid": [600, 600, 0], "K": ["jacobi"], "runs": [[0.0, 9], [1e-9, 5000]],
+             "solvers": ["pcg", "minres"]}]
     want = [r for r in _run(spec, {"PSP_MID": "0"}) if r[0] != "mid_solves"]
-    for env, fb in (({"PSP_COOP_FAIL": "1"}, 2), ({"PSP_COOP_CAPACITY": "4"}, 0)):
+    for env, fb in (({"PSP_COOP_FAIL": "1"}, 4), ({"PSP_COOP_CAPACITY": "4"}, 0)):
         got = _run(spec, env)
         assert [r for r in got if r[0] != "mid_solves"] == want, env
         assert [r for r in got if r[0] == "mid_solves"] == [["mid_solves", 0, fb]], (env, got[-1])

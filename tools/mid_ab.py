@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-kernel PCG loop for mid-size systems (psp_mid.hip) against the launch-per-phase loop, in ONE process on the same
 operator and vectors, alternated (PSP_MID_MIN is read per solve): microseconds per iteration and the bits of x.
-Start with PSP_TUNING=1.  Usage: mid_ab.py [nx,ny,nz ...]"""
+Start with PSP_TUNING=1.  Usage: mid_ab.py [pcg|minres] [nx,ny,nz ...]"""
 import ctypes as C
 import json
 import os
@@ -19,7 +19,10 @@ check = _capi.check
 
 
 def main():
-    grids = sys.argv[1:] or ["1024,1024,0", "724,724,0", "600,600,0", "512,512,0", "80,80,80", "64,64,64"]
+    argv = sys.argv[1:]
+    solver = argv.pop(0) if argv and argv[0] in ("pcg", "minres") else "pcg"
+    fn = L.psp_pcg_dev if solver == "pcg" else L.psp_minres_dev
+    grids = argv or ["1024,1024,0", "724,724,0", "600,600,0", "512,512,0", "80,80,80", "64,64,64"]
     for g in grids:
         grid = tuple(int(t) for t in g.split(","))
         A = dev.DeviceCSR.poisson(*grid)
@@ -44,10 +47,10 @@ def main():
                     info, it, rr = C.c_int(), C.c_int(), C.c_double()
                     check(L.psp_synchronize())
                     t = time.perf_counter()
-                    check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
+                    check(fn(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
                     check(L.psp_synchronize())
                     ts[kk] = time.perf_counter() - t
-                    assert it.value == kk + 1, (it.value, info.value)
+                    assert it.value == (kk + 1 if solver == "pcg" else kk), (it.value, info.value)
                 rec[mode].append((ts[k2] - ts[k1]) / (k2 - k1) * 1e6)
                 xs[mode] = ((info.value, it.value, rr.value), xb.download())
         s, f = C.c_longlong(), C.c_longlong()
@@ -56,7 +59,7 @@ def main():
                "speedup": min(rec["phase"]) / min(rec["mid"]),
                "same_bits": bool(xs["mid"][0] == xs["phase"][0] and np.array_equal(xs["mid"][1], xs["phase"][1])),
                "result": list(xs["mid"][0]), "mid_solves_so_far": s.value, "fallbacks": f.value, "all_us": rec}
-        print("x".join(str(v) for v in grid if v), "pcg", json.dumps(out), flush=True)
+        print("x".join(str(v) for v in grid if v), solver, json.dumps(out), flush=True)
         del aop, kop, K
         A.close()
         bb.free()
