@@ -42,7 +42,7 @@ from bench_common import (HBM_PEAK_GBPS, METRIC, PARITY_ITERS, PARITY_TOL, PMC_F
                           rel_diff, timed_launches)
 from bench_launch import LADDER, guarded_rank, orchestrate  # noqa: E402
 from bench_legs import (dry_strong_n1, gpu_clocks, link_topology, live_traffic, pcg_single, peer_matrix,  # noqa: E402
-                        placement_sweep_leg, same_operator_kernels_leg, single_process_main, sss_leg, stream_ceiling_leg,
+                        placement_sweep_leg, same_operator_kernels_leg, single_process_main, solvers_leg, sss_leg, stream_ceiling_leg,
                         strong_n1_leg)
 
 
@@ -498,6 +498,7 @@ def main():
     ap.add_argument("--grid", default="", help="override the grid, e.g. 256,256,256 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sss", action="store_true", help="skip the sss_mat leg (N = 1)")
+    ap.add_argument("--no-solvers", action="store_true", help="skip the cgs / bicgstab / qmrs / gmres(20) leg (N = 1)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the w3 / w2 legs on the same operator (N = 1)")
     ap.add_argument("--no-strong-n1", action="store_true", help="skip the one-GPU 1024^3 leg")
     ap.add_argument("--no-clocks", action="store_true")
@@ -814,6 +815,14 @@ def run_body(a, real_stdout):
         sss = sss_leg({"L": L, "check": check, "dev": dev, "xb": xb, "yb": yb, "n": n_loc, "sync": sync, "ev": ev,
                        "steps": a.steps, "grid": (nx, ny, nz), "pcg_iters": k})
 
+    # ---- beside it (N = 1; bench_legs.py): the reference's other Krylov solvers on the same operator
+    solvers = None
+    if not use_dist and not dry and not a.no_solvers:
+        try:
+            solvers = solvers_leg({"dev": dev, "A": A, "n": n_loc, "kbytes": kbytes_loc})
+        except Exception as e:  # noqa: BLE001 - a reported extra, never fatal
+            solvers = {"error": str(e)[:200]}
+
     # ---- N = 1 default run: the 1-GPU end of the strong-scaling target (1024^3 on this GPU)
     if not use_dist and not a.grid and not a.no_strong_n1:
         A.close()
@@ -938,6 +947,8 @@ def run_body(a, real_stdout):
                 out["roofline"]["streaming_kernel"] = best["kernel"]
         if sss is not None:
             out["sss_mat"] = sss
+        if solvers is not None:
+            out["solvers"] = solvers
         if strong_n1 is not None:
             out["strong_n1"] = strong_n1
             if use_dist and scaling == "strong" and strong_n1["grid"] == [nx, ny, nz]:

@@ -457,3 +457,55 @@ def sss_leg(ctx):
     S.close()
     return out
 
+
+
+# vector streams (8 n bytes each) of one iteration of the fused loops (psp_solvers.hip: cgs_device / bicgstab_device /
+# qmrs_device, native operator + jacobi(1) with a constant diagonal: dinv is a scalar, not a stream) and the products in it:
+#   cgs       v = A K p (+ v.r0): 3 | q, tmp2, x: 6 | t = A tmp2: 2 | r, {r.r, r.r0}: 4 | u, p, K p: 6
+#   bicgstab  p, K p: 5 | v = A phat (+ rhat.v): 3 | s, K s: 4 | t = A shat (+ t.s): 3 | t.t: 1 | x, r, {r.r, rhat.r}: 8
+#   qmrs      p, g: 6 | t = A g (+ g.t): 2 | v1, v1.v1: 3 | d, x, v1, K v1: 8
+#   gmres(m)  per inner iteration i: W_i = K V_i: 2 | V_{i+1} = A W_i: 2 | V_{i+1}.V_0: 2 | i + 1 modified Gram-Schmidt steps of
+#             4 streams (the last: 3) | scaling: 2   = 4 i + 11; per restart: r = b - A x: 2 + 3, its norm and scaling: 1 + 2,
+#             x += s_j W_j: 3 m
+SOLVER_STREAMS = {"cgs": (2, 21), "bicgstab": (2, 24), "qmrs": (1, 19)}
+
+
+def gmres_streams(m):
+    """(products, vector streams) per inner iteration of gmres(m), averaged over whole restart cycles"""
+    inner = sum(4 * i + 11 for i in range(m))
+    restart = 2 + 3 + 1 + 2 + 3 * m
+    return 1.0 + 1.0 / m, (inner + restart) / m
+
+
+def solvers_leg(ctx):
+    """`solvers` (VERDICT r4 'Next' #5): the reference's other Krylov solvers (pysparse/itsolvers/src/{cgs,bicgstab,qmrs,
+    gmres}.c) on the same operator with Jacobi, through the host-pointer entry points the extension module binds; two
+    truncated solves of different length (tol = 0) per solver, so that the copies of b and x and the set-up drop out.
+    Priced in the bytes their kernels have to move: the operator once per product + the vector streams above."""
+    dev, A, n, kbytes = (ctx[k] for k in ("dev", "A", "n", "kbytes"))
+    K = dev.DeviceJacobi(A)
+    b = np.empty(n)
+    A.matvec(np.ones(n), b)
+    m = 20
+    op_bytes = kbytes - 16 * n  # the operator's own bytes of one product (kbytes counts x and y once)
+    out = {"what": "Jacobi-preconditioned, b = A*ones, x0 = 0, tol = 0; per-iteration time from two truncated solves; "
+                   "bytes = products x operator bytes + vector streams x 8 n (bench_legs.SOLVER_STREAMS)",
+           "operator_bytes_per_product": op_bytes}
+    for name, fn, short, long_ in (("cgs", dev.cgs, 5, 25), ("bicgstab", dev.bicgstab, 5, 25), ("qmrs", dev.qmrs, 5, 25),
+                                   ("gmres20", dev.gmres, m, 3 * m)):
+        ts, res = {}, None
+        for kk in (short, long_, short, long_):
+            x = np.zeros(n)
+            t = time.perf_counter()
+            res = fn(A, b, x, 0.0, kk, K)
+            ts.setdefault(kk, []).append(time.perf_counter() - t)
+        dt = (min(ts[long_]) - min(ts[short])) / (long_ - short)
+        prods, streams = gmres_streams(m) if name == "gmres20" else SOLVER_STREAMS[name]
+        nbytes = prods * op_bytes + streams * 8 * n
+        out[name] = {"ms_per_iter": dt * 1e3, "iters_per_s": 1.0 / dt if dt > 0 else None,
+                     "products_per_iter": prods, "vector_streams_per_iter": streams, "bytes_per_iter": nbytes,
+                     "GBps": nbytes / dt / 1e9 if dt > 0 else None,
+                     "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS if dt > 0 else None,
+                     "last": [int(res[0]), int(res[1]), float(res[2])]}
+    del K
+    return out

@@ -55,6 +55,14 @@ def test_bench_json_contract_small_grid():
     assert r["csr_model_frac_of_streaming_kernel"] == max(ks["csr_spmv_w6"]["csr_model_frac"], ks["csr_spmv_w2"]["csr_model_frac"])
     assert all(k["frac"] <= 1.0 for k in ks.values())
     assert d["sss_mat"]["kernel"] == "sss_spmv_w4" and d["sss_mat"]["frac"] <= 1.0
+    # the reference's other Krylov solvers on the same operator, priced in the bytes their kernels move
+    sv = d["solvers"]
+    op_bytes = r["algorithmic_bytes_per_launch"] - 16 * n
+    for name, prods, streams in (("cgs", 2, 21), ("bicgstab", 2, 24), ("qmrs", 1, 19)):
+        assert sv[name]["bytes_per_iter"] == prods * op_bytes + streams * 8 * n and sv[name]["ms_per_iter"] > 0
+        assert 0 < sv[name]["frac"] <= 1.0
+    assert sv["gmres20"]["last"][1] == 60 and 0 < sv["gmres20"]["frac"] <= 1.0
+    assert sv["cgs"]["last"][1] == 25 and sv["qmrs"]["last"][1] == 25
     assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 9  # tol = 0: exactly 8 iterations
     assert d["pcg_iters_per_s"] > 0 and d["value"] > 0
     # the placement sweep rides along and never feeds `value`: the first allocation's launch time is roofline's
