@@ -82,11 +82,7 @@ __device__ __forceinline__ T ldg(const T *p) {
     return *p;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return psp::psp_wave_sum(v); }
 
 // block-wide sum of v; result valid in thread 0.  sh: 4 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *sh) {

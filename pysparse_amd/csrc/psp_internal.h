@@ -223,9 +223,52 @@ struct FoldJobs {  // kernel argument of group_fold_kernel
 };
 
 #ifdef __HIPCC__
+// The fixed tree of a wave's 64 values: v[l] + v[l + 32], then + 16, 8, 4, 2, 1 -- lane 0 holds the sum (the other lanes
+// hold nothing a caller may use).  Round 5: the operands come through v_permlane32_swap / v_permlane16_swap (gfx950) and
+// DPP row shifts instead of ds_bpermute (__shfl_down): the same additions on the same values -- the same bits
+// (tools/wave_sum_check.hip) -- without six dependent trips through the LDS crossbar (the single-kernel loops of
+// psp_mid.hip add a dozen waves' worth per iteration on their critical path).
+template <int CTRL>
+__device__ __forceinline__ double psp_dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double psp_lane_plus_32(double v) {  // lanes 0 .. 31 receive lanes 32 .. 63
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double psp_lane_plus_16(double v) {  // lanes 0 .. 15 receive lanes 16 .. 31 (32 .. 47: 48 .. 63)
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[1], a[1]);
+}
 __device__ __forceinline__ double psp_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  v = v + psp_lane_plus_32(v);
+  v = v + psp_lane_plus_16(v);
+  v = v + psp_dpp_mov<0x108>(v);  // row_shl:8 -- lane l receives lane l + 8 of its row of 16
+  v = v + psp_dpp_mov<0x104>(v);
+  v = v + psp_dpp_mov<0x102>(v);
+  v = v + psp_dpp_mov<0x101>(v);
+  return v;
+}
+__device__ __forceinline__ double psp_wave_max(double v) {  // lane 0: the largest of the wave's values (v >= 0 or any: plain >)
+  double o = psp_lane_plus_32(v);
+  v = o > v ? o : v;
+  o = psp_lane_plus_16(v);
+  v = o > v ? o : v;
+  o = psp_dpp_mov<0x108>(v);
+  v = o > v ? o : v;
+  o = psp_dpp_mov<0x104>(v);
+  v = o > v ? o : v;
+  o = psp_dpp_mov<0x102>(v);
+  v = o > v ? o : v;
+  o = psp_dpp_mov<0x101>(v);
+  v = o > v ? o : v;
   return v;
 }
 // R(v[0..count)) by one wave: lane l adds v[l], v[l+64], ... in order, then the shuffle tree; lane 0 holds the result.

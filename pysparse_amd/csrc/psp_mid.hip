@@ -6,10 +6,11 @@
 // psp_coop.hip stop at 2^18 rows because every gathered entry is a device-coherent load that bypasses the caches
 // (84 MB of 64-byte sectors per iteration at 512^2: 21.8 us).  Here:
 //
-//   * one workgroup of 1024 threads per CU owns a CONTIGUOUS block of B = 2048 or 4096 rows for the whole solve; a thread
-//     owns one or two pairs of adjacent rows: x, r, p, q of its rows, the rows' matrix entries (index-free layout of
-//     csr_spmv_w4: up to 7 offsets) and their masks stay in registers -- NOTHING of the matrix or of x, r, q is read
-//     again after the first iteration;
+//   * one workgroup of 1024 or 512 threads per CU owns a CONTIGUOUS block of B = 2048 or 4096 rows for the whole solve; a
+//     thread owns one to four pairs of adjacent rows: x, r, p, q of its rows, the rows' matrix entries (index-free layout
+//     of csr_spmv_w4: up to 7 offsets) and their masks stay in registers -- NOTHING of the matrix or of x, r, q is read
+//     again after the first iteration.  512 threads may keep 256 registers each: the 4096-row blocks and the 7-offset
+//     operators run (nearly) without scratch memory that way (mid_block_threads);
 //   * the direction vector p is exchanged through LDS: a window of H + B + H entries (H = largest |offset|); a row reads
 //     the p entries it multiplies with from the window;
 //   * what crosses workgroups is the residual r of the H rows at either end of a block, published with device-coherent
@@ -38,8 +39,6 @@ namespace psp {
 
 namespace {
 
-constexpr int kMidBlock = 1024;
-constexpr int kMidLayer = 2 * kMidBlock;     // rows one layer of a workgroup covers: a pair of rows per thread
 constexpr int kMidMaxWg = 256;
 constexpr int kMidMaxRows = 1 << 20;         // two layers x 256 workgroups
 constexpr int kMidSpan = 512;                // rows per partial sum (kVecSpan; csr_spmv_w4: 4 waves x 128 rows)
@@ -155,14 +154,14 @@ __device__ __forceinline__ double mid_wave_reduce_lds(const double *v, int first
   return psp_wave_sum(s);
 }
 
-template <int NV>
+template <int NV, int BLK>
 __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src, int np, int stripe, int limit,
                                            double *stage, double *grp_lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pitch = (limit + 127) & ~127;  // the partial-sum arrays are kMidMaxSpans long (a multiple of 128) and zero-filled
 #pragma unroll
   for (int j = 0; j < NV; ++j)
-    for (int base = wave * 128; base < pitch; base += (kMidBlock / 64) * 128)  // one wave-instruction: 64 lanes x 16 bytes
+    for (int base = wave * 128; base < pitch; base += (BLK / 64) * 128)  // one wave-instruction: 64 lanes x 16 bytes
       __builtin_amdgcn_global_load_lds((global_void_ptr)(src + (size_t)j * kMidMaxSpans + base + 2 * lane),
                                        (lds_void_ptr)(stage + j * pitch + base), 16, 0, 16 /* sc1: device scope */);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,7 +173,7 @@ __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src,
       if (lane == 0) grp_lds[NV * 16 + wave] = s;
     }
   } else {
-    for (int task = wave; task < NV * ngroups; task += kMidBlock / 64) {
+    for (int task = wave; task < NV * ngroups; task += BLK / 64) {
       const int j = task / ngroups, g = task % ngroups;
       const int cnt = min(kTailGroup, np - g * kTailGroup);
       const double s = mid_wave_reduce_lds(stage + j * pitch, g * kTailGroup, cnt, stripe, limit);
@@ -197,6 +196,7 @@ __device__ __forceinline__ void mid_reduce(double (&out)[NV], const double *src,
 // lane (rows outside the matrix skipped).  Asynchronous: the caller waits (s_waitcnt vmcnt(0)) before it reads.
 // Issued together with the partial sums' copies, the halo costs no round trip of its own; read with ordinary loads in a
 // loop it cost three (no registers to keep them in flight).
+template <int BLK>
 __device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, int H, int n, double *hst, int zone1 = -1) {
   // zone1 < 0: the second zone follows the first (hst[H ..)); else it starts at hst[zone1] (the window's upper halo)
   const int z1 = zone1 < 0 ? H : zone1;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, 
 #pragma unroll
   for (int zone = 0; zone < 2; ++zone) {
     const long row0 = zone == 0 ? base - H : base + B;  // even (base is a multiple of 2048, H is even): 16-byte aligned pairs
-    for (int e0 = wave * 128; e0 < H; e0 += (kMidBlock / 64) * 128) {  // one wave-instruction: 64 lanes x one pair of rows
+    for (int e0 = wave * 128; e0 < H; e0 += (BLK / 64) * 128) {  // one wave-instruction: 64 lanes x one pair of rows
       const int e = e0 + 2 * lane;
       const long g = row0 + e;
       if (e < H && g >= 0 && g + 1 < n)
@@ -216,24 +216,26 @@ __device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, 
 }
 
 // grid barrier, then the reduction by every workgroup for itself; false: some workgroup gave up -- everybody leaves
-template <int NV>
+template <int NV, int BLK>
 __device__ __forceinline__ bool mid_barrier_reduce(MidCtl *c, int nwg, unsigned &gen, double (&out)[NV], const double *src,
                                                    int np, int stripe, int limit, double *stage, double *grp_lds) {
   if (!mid_barrier(c, nwg, gen)) return false;
-  mid_reduce<NV>(out, src, np, stripe, limit, stage, grp_lds);
+  mid_reduce<NV, BLK>(out, src, np, stripe, limit, stage, grp_lds);
   return true;
 }
 
 // pcg.c:91-166 from the head of iteration 1 (r = b - A x, rho = r.z, ||r|| > tolb are the caller's)
-template <int NO, int LAYERS>
-__global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
+template <int NO, int LAYERS, int BLK>
+__global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
   extern __shared__ double lds[];
+  constexpr int kMidLayer = 2 * BLK;  // rows one layer of a workgroup covers: a pair of rows per thread
+  constexpr int kMidBlock = BLK;
   constexpr int B = LAYERS * kMidLayer;
-  constexpr int NW = kMidBlock / 64;  // 16 waves
+  constexpr int NW = kMidBlock / 64;  // 16 waves (8 with 512 threads)
   const int H = a.H;
   // Two layers: x and q of the own rows live in LDS as well (each is touched once per iteration; 16 registers less --
   // with them the kernel spilled 24 registers per lane for the 5-point operator).  One layer: registers.
-  constexpr bool XQ_LDS = LAYERS == 2;
+  constexpr bool XQ_LDS = B == 4096;
   double *win = lds;                  // p at rows [base - H, base + B + H)
   double *xl = lds + (2 * H + B);     // XQ_LDS: x of the own rows, then q
   double *ql = xl + (XQ_LDS ? B : 0);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
   for (int i = t; i < 2 * H + B; i += kMidBlock) win[i] = 0.0;
   for (int i = t; i < 2 * H; i += kMidBlock) hst[i] = 0.0;  // (rows outside the matrix are never copied)
   __syncthreads();
-  mid_halo_dma(a.r, base, B, H, n, hst);
+  mid_halo_dma<BLK>(a.r, base, B, H, n, hst);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   unsigned gen = 0;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       if (lane == 0) red[L * NW + wave] = dsum;
     }
     __syncthreads();
-    if (t < LAYERS * 4) {  // span t of this workgroup: its four waves in order
+    if (t < B / kMidSpan) {  // span t of this workgroup: its four waves in order
       const int gs = wg * (B / kMidSpan) + t;
       if (gs < a.nspans) mcoh_store(a.part + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
     PSP_MID_STAMP(2);
     if (!mid_barrier(a.ctl, nwg, gen)) return;
     PSP_MID_STAMP(3);
-    mid_reduce<1>(s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp);
+    mid_reduce<1, BLK>(s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp);
     PSP_MID_STAMP(4);
     const double pq = s1[0];
     if (pq == 0.0) {  // pcg.c:118-120
@@ -414,11 +416,7 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
         }
       }
       if (pre == 0) acc1 = acc0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_down(dmax, off, 64);
-        if (o > dmax) dmax = o;
-      }
+      dmax = psp_wave_max(dmax);
       acc0 = psp_wave_sum(acc0);
       acc1 = psp_wave_sum(acc1);
       if (lane == 0) {
@@ -435,8 +433,8 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       }
     }
     __syncthreads();
-    if (t < 2 * LAYERS * 4) {
-      const int j = t / (LAYERS * 4), s = t % (LAYERS * 4);
+    if (t < 2 * (B / kMidSpan)) {
+      const int j = t / (B / kMidSpan), s = t % (B / kMidSpan);
       const int gs = wg * (B / kMidSpan) + s;
       const double *rj = red + j * LAYERS * NW;
       if (gs < a.nspans)
@@ -453,8 +451,8 @@ __global__ __launch_bounds__(kMidBlock) void pcg_mid_kernel(MidArgs a) {
       PSP_MID_STAMP(5);
       if (!mid_barrier(a.ctl, nwg, gen)) return;
       PSP_MID_STAMP(6);
-      mid_halo_dma(a.r, base, B, H, n, hst);  // the next iteration's halo rides with the partial sums: one round trip
-      mid_reduce<2>(s2, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
+      mid_halo_dma<BLK>(a.r, base, B, H, n, hst);  // the next iteration's halo rides with the partial sums: one round trip
+      mid_reduce<2, BLK>(s2, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
       PSP_MID_STAMP(7);
       s3[0] = s2[0];
       s3[1] = s2[1];
@@ -515,12 +513,14 @@ struct MidMinresArgs {
   int np_w4, stripe, nspans;
 };
 
-template <int NO, int LAYERS>
-__global__ __launch_bounds__(kMidBlock) void minres_mid_kernel(MidMinresArgs a) {
+template <int NO, int LAYERS, int BLK>
+__global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
   extern __shared__ double lds[];
+  constexpr int kMidLayer = 2 * BLK;
+  constexpr int kMidBlock = BLK;
   constexpr int B = LAYERS * kMidLayer;
   constexpr int NW = kMidBlock / 64;
-  constexpr bool X_LDS = LAYERS == 2;  // two layers: x, w, w_old of the own rows live in LDS
+  constexpr bool X_LDS = B == 4096;  // blocks of 4096 rows: x, w, w_old of the own rows live in LDS
   const int H = a.H;
   double *win = lds;                   // v = y / beta at rows [base - H, base + B + H); between iterations: staging
   double *xl = lds + (2 * H + B);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kMidBlock) void minres_mid_kernel(MidMinresArgs a) 
   for (int i = t; i < 2 * H + B; i += kMidBlock) win[i] = 0.0;
   __syncthreads();
   // the neighbours' y into the window's halo zones (rows outside the matrix stay 0)
-  mid_halo_dma(a.yv, base, B, H, n, win, H + B);
+  mid_halo_dma<BLK>(a.yv, base, B, H, n, win, H + B);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   unsigned gen = 0;
@@ -621,12 +621,12 @@ __global__ __launch_bounds__(kMidBlock) void minres_mid_kernel(MidMinresArgs a) 
       if (lane == 0) red[L * NW + wave] = dsum;
     }
     __syncthreads();
-    if (t < LAYERS * 4) {
+    if (t < B / kMidSpan) {
       const int gs = wg * (B / kMidSpan) + t;
       if (gs < a.nspans) mcoh_store(a.part + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
     }
     double s1[1];
-    if (!mid_barrier_reduce<1>(a.ctl, nwg, gen, s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp)) return;
+    if (!mid_barrier_reduce<1, BLK>(a.ctl, nwg, gen, s1, a.part, a.np_w4, a.stripe > 0 ? a.stripe : 0, a.nspans, stage, grp)) return;
     const double alpha = s1[0];
     const double c1 = alpha / beta, c2 = beta / beta_old;  // :131
     // ---- Lanczos update (:131-143; lanczos_kernel's expressions), beta^2 = v_hat . y; y published for the neighbours
@@ -661,14 +661,14 @@ __global__ __launch_bounds__(kMidBlock) void minres_mid_kernel(MidMinresArgs a) 
       }
     }
     __syncthreads();
-    if (t < LAYERS * 4) {
+    if (t < B / kMidSpan) {
       const int gs = wg * (B / kMidSpan) + t;
       if (gs < a.nspans)
         mcoh_store(a.part + kMidMaxSpans + gs, red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
     }
     if (!mid_barrier(a.ctl, nwg, gen)) return;
-    mid_halo_dma(a.yv, base, B, H, n, win, H + B);  // the next iteration's halo rides with the partial sums
-    mid_reduce<1>(s1, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
+    mid_halo_dma<BLK>(a.yv, base, B, H, n, win, H + B);  // the next iteration's halo rides with the partial sums
+    mid_reduce<1, BLK>(s1, a.part + kMidMaxSpans, a.nspans, -1, a.nspans, stage, grp);
     // ---- minres_scalar_beta: :143-164, :180, :192
     const double beta_start = beta;  // beta at the start of this iteration
     beta_old = beta;
@@ -753,51 +753,59 @@ bool mid_enabled() {
   return on;
 }
 
-int mid_min_rows() {  // PSP_MID_MIN (tuning switch): from how many rows on (default: where psp_coop.hip's range ends)
+// PSP_MID_MIN (tuning switch): from how many rows on.  Default 2^16: against psp_coop.hip's one-row-per-thread loops (which
+// remain for general matrices of <= 8 entries per row and for everything smaller) the kernels here take 9.7 / 11.7 us per
+// PCG iteration at 256^2, 9.9 / 13.1 at 300^2, 12.5 / 21.4 at 512^2; MINRES 9.2 / 10.4 at 300^2, 10.9 / 18.8 at 512^2;
+// below ~200^2 the order flips (100^2: 10.1 / 9.2) (profiles/r5_mid_vs_coop.txt)
+int mid_min_rows() {
   const char *e = tuning_env("PSP_MID_MIN");
-  return e ? atoi(e) : (1 << 18) + 1;
+  return e ? atoi(e) : 1 << 16;
 }
 
-template <int NO, int LAYERS>
-const void *mid_kernel_ptr() {
-  return (const void *)pcg_mid_kernel<NO, LAYERS>;
-}
-
-const void *mid_kernel(int no, int layers) {
-#define PSP_MID_K(NO)                                              \
-  case NO:                                                          \
-    return layers == 1 ? mid_kernel_ptr<NO, 1>() : mid_kernel_ptr<NO, 2>()
-  switch (no) {
-    PSP_MID_K(1); PSP_MID_K(2); PSP_MID_K(3); PSP_MID_K(4); PSP_MID_K(5); PSP_MID_K(6); PSP_MID_K(7);
-    default:
-      return nullptr;
+// kernel of (offsets, rows per workgroup, threads per workgroup); nullptr: not built
+#define PSP_MID_TABLE(FN, KERNEL)                                                      \
+  const void *FN(int no, int rows, int blk) {                                          \
+    const int key = rows == 2048 ? (blk == 1024 ? 0 : 1) : (blk == 1024 ? 2 : 3);      \
+    switch (no * 4 + key) {                                                            \
+      PSP_MID_ROW(KERNEL, 1) PSP_MID_ROW(KERNEL, 2) PSP_MID_ROW(KERNEL, 3) PSP_MID_ROW(KERNEL, 4) \
+      PSP_MID_ROW(KERNEL, 5) PSP_MID_ROW(KERNEL, 6) PSP_MID_ROW(KERNEL, 7)             \
+      default:                                                                         \
+        return nullptr;                                                                \
+    }                                                                                  \
   }
-#undef PSP_MID_K
-}
-
-template <int NO, int LAYERS>
-const void *mid_minres_kernel_ptr() {
-  return (const void *)minres_mid_kernel<NO, LAYERS>;
-}
-
-const void *mid_minres_kernel(int no, int layers) {
-#define PSP_MID_K(NO)                                              \
-  case NO:                                                          \
-    return layers == 1 ? mid_minres_kernel_ptr<NO, 1>() : mid_minres_kernel_ptr<NO, 2>()
-  switch (no) {
-    PSP_MID_K(1); PSP_MID_K(2); PSP_MID_K(3); PSP_MID_K(4); PSP_MID_K(5); PSP_MID_K(6); PSP_MID_K(7);
-    default:
-      return nullptr;
-  }
-#undef PSP_MID_K
-}
+#define PSP_MID_ROW(KERNEL, NO)                             \
+  case NO * 4 + 0:                                          \
+    return (const void *)KERNEL<NO, 1, 1024>;               \
+  case NO * 4 + 1:                                          \
+    return (const void *)KERNEL<NO, 2, 512>;                \
+  case NO * 4 + 2:                                          \
+    return (const void *)KERNEL<NO, 2, 1024>;               \
+  case NO * 4 + 3:                                          \
+    return (const void *)KERNEL<NO, 4, 512>;
+PSP_MID_TABLE(mid_kernel, pcg_mid_kernel)
+PSP_MID_TABLE(mid_minres_kernel, minres_mid_kernel)
+#undef PSP_MID_ROW
+#undef PSP_MID_TABLE
 
 struct MidPlan {
   W4View w4;
-  int layers, nwg, H;
+  int rows, blk, nwg, H;  // rows per workgroup (2048 / 4096), threads per workgroup (1024 / 512)
   size_t lds;
   const void *kernel;
 };
+
+// threads per workgroup: 512 threads may keep 256 registers each -- the blocks of 4096 rows, whose 1024-thread kernels
+// spill (132 .. 250 bytes per lane with 5 offsets), run without scratch memory.  PSP_MID_BLK (tuning switch, read per solve)
+int mid_block_threads(int rows, int no) {
+  if (const char *e = tuning_env("PSP_MID_BLK")) {
+    const int v = atoi(e);
+    if (v == 512 || v == 1024) return v;
+  }
+  // measured (profiles/r5_mid_blk_ab.txt): blocks of 4096 rows 24.0 -> 21.7 us (PCG), 29.3 -> 19.0 us (MINRES) per iteration at
+  // 1024^2 with 512 threads; blocks of 2048 rows the same either way with 5 offsets, 512 ahead with 7 (40 x 40 x 300:
+  // MINRES 19.5 -> 15.9 us), whose 1024-thread kernels spill
+  return (rows == 4096 || no >= 6) ? 512 : 1024;
+}
 
 // the plan for this operator, or false: no index-free layout of <= 7 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
@@ -809,19 +817,20 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
   for (int i = 0; i < P->w4.no; ++i) omax = std::max(omax, std::abs(P->w4.offs[i]));
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)
   if (P->H > 2048) return false;  // the halo is staged in LDS and updated in <= 4 passes: 2-D grids up to 2046 wide, slim 3-D ones
-  P->layers = n > kMidMaxWg * kMidLayer ? 2 : 1;
-  if (P->layers == 2 && P->w4.no > 5) return false;  // register budget of two row pairs per thread: up to 5 offsets
-  const int B = P->layers * kMidLayer;
+  P->rows = n > kMidMaxWg * 2048 ? 4096 : 2048;
+  P->blk = mid_block_threads(P->rows, P->w4.no);
+  if (P->rows == 4096 && P->blk == 1024 && P->w4.no > 5) return false;  // register budget of two row pairs per thread
+  const int B = P->rows;
   P->nwg = (n + B - 1) / B;
   const int nspans = (n + kMidSpan - 1) / kMidSpan;
-  if (minres)  // window (also the staging area) + x, w, w_old with two layers + the wave sums and mid_reduce's scratch
-    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 3 * B : 0) + P->layers * 16 + 18);
+  if (minres)  // window (also the staging area) + x, w, w_old for blocks of 4096 rows + the wave sums and mid_reduce's scratch
+    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (B == 4096 ? 3 * B : 0) + B / 128 + 18);
   else
-    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (P->layers == 2 ? 2 * B : 0) + 3 * P->layers * 16 + 3 * 16 + 4 +
-                                       2 * ((nspans + 127) & ~127) + (P->layers == 2 ? 0 : 2 * P->H));
+    P->lds = sizeof(double) * (size_t)(2 * P->H + B + (B == 4096 ? 2 * B : 0) + 3 * (B / 128) + 3 * 16 + 4 +
+                                       2 * ((nspans + 127) & ~127) + (B == 4096 ? 0 : 2 * P->H));
   if (P->nwg > kMidMaxWg || P->lds > (size_t)kMidMaxLds) return false;
   if (P->w4.grid > 4096 || (n + kMidSpan - 1) / kMidSpan > kMidMaxSpans) return false;
-  P->kernel = minres ? mid_minres_kernel(P->w4.no, P->layers) : mid_kernel(P->w4.no, P->layers);
+  P->kernel = minres ? mid_minres_kernel(P->w4.no, P->rows, P->blk) : mid_kernel(P->w4.no, P->rows, P->blk);
   if (!P->kernel) return false;
   // the grid must be resident at once: one workgroup per CU with this much LDS
   static std::mutex mu;
@@ -835,7 +844,7 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
     Workspace *w = nullptr;
     if (hipFuncSetAttribute(P->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) == hipSuccess &&
         workspace(&w) == PSP_OK && w->num_cu > 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, P->kernel, kMidBlock, kMidMaxLds) == hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, P->kernel, P->blk, kMidMaxLds) == hipSuccess)
       c = per * w->num_cu;
     else
       (void)hipGetLastError();
@@ -919,7 +928,7 @@ int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, doub
   const char *ff = tuning_env("PSP_COOP_FAIL");
   if (ff && atoi(ff) == 1) {
     rc = kCoopFallback;
-  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(kMidBlock), args, (unsigned)P.lds, stream()) != hipSuccess) {
+  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(P.blk), args, (unsigned)P.lds, stream()) != hipSuccess) {
     (void)hipGetLastError();
     rc = kCoopFallback;
   }
@@ -1016,7 +1025,7 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   const char *ff = tuning_env("PSP_COOP_FAIL");
   if (ff && atoi(ff) == 1) {
     rc = kCoopFallback;
-  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(kMidBlock), args, (unsigned)P.lds, stream()) != hipSuccess) {
+  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(P.blk), args, (unsigned)P.lds, stream()) != hipSuccess) {
     (void)hipGetLastError();
     rc = kCoopFallback;
   }
@@ -1030,8 +1039,8 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
     long long st[8 + 16 * 8];
     (void)hipMemcpy(st, stamps_dev, sizeof(st), hipMemcpyDeviceToHost);
     (void)hipFree(stamps_dev);
-    fprintf(stderr, "[psp_mid] n %d nwg %d layers %d H %d: 10 ns ticks per phase (p update | product | barrier 1 | reduce 1 | updates | barrier 2 | reduce 2 + halo | loop end)\n",
-            n, P.nwg, P.layers, P.H);
+    fprintf(stderr, "[psp_mid] n %d nwg %d rows %d threads %d H %d: 10 ns ticks per phase (p update | product | barrier 1 | reduce 1 | updates | barrier 2 | reduce 2 + halo | loop end)\n",
+            n, P.nwg, P.rows, P.blk, P.H);
     for (int it = 2; it < 12 && it < maxit; ++it) {
       const long long *q0 = st + 8 + it * 8, *q1 = st + 8 + (it + 1) * 8;
       fprintf(stderr, "[psp_mid]   it %2d:", it + 1);

@@ -50,11 +50,7 @@ __device__ __forceinline__ void st(double *p, long i, const Pack<V> &x) {
 #endif
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return psp::psp_wave_sum(v); }
 
 // sums NV per-thread values over the block; thread 0 stores them to partials[j*kMaxParts + block]
 template <int NV>

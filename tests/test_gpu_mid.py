@@ -86,7 +86,8 @@ def _counts(out, ncases):
     [{"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS}],           # 7 offsets, halo of 1602 rows
     [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS}],  # varying diagonal: dinv array
     [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:]}],
-], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq"])
+    [{"kind": "poisson", "grid": [20, 20, 2500], "K": ["none", "jacobi"], "runs": RUNS}],  # 7 offsets, 4096 rows per workgroup (512 threads)
+], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq", "20x20x2500"])
 def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
     mid = _run(spec)
     ref = _run(spec, {"PSP_MID": "0"})
@@ -109,7 +110,8 @@ def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
     [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
     [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:],
       "solvers": ["minres"]}],
-], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq"])
+    [{"kind": "poisson", "grid": [20, 20, 2500], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
+], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq", "20x20x2500"])
 def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
     """minres.c:96-193 in one kernel (minres_mid_kernel): the same comparison, every field for equality"""
     mid = _run(spec)
@@ -123,6 +125,18 @@ def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
     for k, (ra, rb) in enumerate(zip(a, b)):
         assert ra == rb, (k, ra[:3], rb[:3])
     assert a[-1][0] == 0
+
+
+@pytest.mark.parametrize("blk", ["512", "1024"])
+def test_both_workgroup_sizes_give_the_same_bits(blk):
+    """PSP_MID_BLK: 512 or 1024 threads per workgroup (the default picks per shape) -- the same sums in the same order"""
+    spec = [{"kind": "poisson", "grid": [600, 600, 0], "K": ["jacobi"], "runs": RUNS[:5] + RUNS[-1:], "solvers": ["pcg", "minres"]},
+            {"kind": "poisson", "grid": [1024, 1000, 0], "K": ["jacobi"], "runs": RUNS[:5], "solvers": ["pcg", "minres"]},
+            {"kind": "poisson", "grid": [40, 40, 300], "K": ["none"], "runs": RUNS[:5], "solvers": ["pcg", "minres"]}]
+    got = _run(spec, {"PSP_MID_BLK": blk})
+    ref = _run(spec, {"PSP_MID": "0"})
+    assert [r for r in got if r[0] != "mid_solves"] == [r for r in ref if r[0] != "mid_solves"]
+    assert all(r[1] > 0 and r[2] == 0 for r in got if r[0] == "mid_solves")
 
 
 def test_refused_or_failed_launch_falls_back_with_the_same_result():

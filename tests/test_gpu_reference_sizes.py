@@ -102,3 +102,22 @@ def test_gpu_against_compiled_reference_20_iterations_at_512_cubed(oracle):
         assert out[name]["vs_reference_module_kernel"]["callback_threads"] == threads
     print("C3 k=20 vs compiled reference:", {nm: (out[nm]["vs_reference_module_kernel"]["x_max_rel_diff"],
                                                    out[nm]["vs_reference_module_kernel"]["seconds"]) for nm in ("pcg", "minres")})
+
+
+@pytest.mark.parametrize("grid,k", [((1024, 1024, 0), 200), ((600, 600, 0), 150), ((40, 40, 300), 120)])
+def test_single_kernel_range_against_oracle_and_reference(oracle, grid, k):
+    """2^18 < n <= 2^20: the product path is ONE cooperative kernel per solve (psp_mid.hip; tests/test_gpu_mid.py pins it
+    bit for bit to the launch-per-phase loops) -- here the same solves against the oracle and the reference's compiled
+    pcg.c / minres.c, hundreds of iterations deep"""
+    import ctypes as C
+
+    import bench
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import lib
+    s0, f0, s1, f1 = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+    lib().psp_debug_mid_count(C.byref(s0), C.byref(f0))
+    out = bench.gpu_parity_case(dev, oracle, grid, k)
+    lib().psp_debug_mid_count(C.byref(s1), C.byref(f1))
+    assert s1.value - s0.value >= 2 and f1.value == f0.value  # PCG and MINRES both ran as single kernels
+    assert (1 << 18) < out["n"] <= (1 << 20)
+    _check(out, k, True, oracle.have_ref() and oracle.have_ref_krylov())

@@ -34,9 +34,10 @@ def test_two_threads_two_handles_same_bits_different_streams_and_overlap(oracle)
     from pysparse_amd import device as dev
     from pysparse_amd._capi import lib
     L = lib()
-    # launch-latency-bound sizes (the GPU is far from full: side by side must beat one after the other), beyond the
-    # single-kernel loops' range so that every iteration is a handful of launches on the thread's stream
-    grids = [(600, 600, 0), (80, 80, 80)]
+    # launch-latency-bound sizes (the GPU is far from full: side by side must beat one after the other), outside the
+    # single-kernel loops' range (3-D grids whose halo of one plane does not fit the LDS: psp_mid.hip refuses them) so
+    # that every iteration is a handful of launches on the thread's stream
+    grids = [(72, 72, 100), (80, 80, 80)]
     ops = []
     for g in grids:
         A = dev.DeviceCSR.poisson(*g)
@@ -77,6 +78,38 @@ def test_two_threads_two_handles_same_bits_different_streams_and_overlap(oracle)
             assert ra[:2] in ((-1, maxit + 1), (-1, maxit))
     # overlap: side by side clearly faster than one after the other (both are latency-bound: ideally the longer of the two)
     assert t_threads < 0.85 * t_serial, (t_threads, t_serial)
+
+
+def test_two_threads_in_the_single_kernel_range_same_bits(oracle):
+    """two threads whose solves are cooperative single-kernel loops (psp_mid.hip / psp_coop.hip) at the same time: each
+    launch needs the whole grid resident, the runtime runs them one after the other -- no deadlock, the bits of a solve alone"""
+    from pysparse_amd import device as dev
+    ops = []
+    for g in [(600, 600, 0), (724, 724, 0), (200, 200, 0)]:
+        A = dev.DeviceCSR.poisson(*g)
+        b = np.random.default_rng(11).standard_normal(A.shape[0])
+        ops.append((A, dev.DeviceJacobi(A), b))
+    reps, maxit = 2, 300
+    alone = [_solve_many(dev, A, K, b, reps, dev.pcg, 0.0, maxit) + _solve_many(dev, A, K, b, reps, dev.minres, 0.0, maxit)
+             for A, K, b in ops]
+    res, errs = [None] * len(ops), []
+    start = threading.Barrier(len(ops))
+
+    def worker(k):
+        try:
+            A, K, b = ops[k]
+            start.wait()
+            res[k] = _solve_many(dev, A, K, b, reps, dev.pcg, 0.0, maxit) + _solve_many(dev, A, K, b, reps, dev.minres, 0.0, maxit)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(ops))]
+    [x.start() for x in ts]
+    [x.join(timeout=300) for x in ts]
+    assert not errs and not any(x.is_alive() for x in ts), errs
+    for k in range(len(ops)):
+        for (ra, xa), (rt, xt) in zip(alone[k], res[k]):
+            assert ra == rt and np.array_equal(xa, xt)
 
 
 def test_two_threads_sharing_one_handle_take_turns_and_stay_correct(oracle):

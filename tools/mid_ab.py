@@ -35,7 +35,7 @@ def main():
         check(L.psp_synchronize())
         # two truncated solves per measurement: the difference cancels the set-up (||b||, r = b - A x, allocations, the
         # cooperative launch itself); both counts lie well before these systems stagnate
-        k1, k2 = (50, 250) if grid[2] else (100, 1100)
+        k1, k2 = (50, 250) if grid[2] else ((100, 1100) if n > (1 << 18) else (40, 240))
         rec = {"mid": [], "phase": []}
         xs = {}
         for rnd in range(3):
