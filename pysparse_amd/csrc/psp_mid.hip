@@ -215,6 +215,21 @@ __device__ __forceinline__ void mid_halo_dma(const double *r, long base, int B, 
   }
 }
 
+// pcg.c:128-139's stagnation test for one row WITHOUT its division.  The reference forms d = |alpha p / x| (1.0 if x == 0 != p),
+// takes the maximum over the rows and asks whether 1 + dmax == 1; a row contributes to "not stagnated" iff its own
+// 1 + d != 1, i.e. (round to nearest even) iff d > 2^-53.  With a = |fl(alpha p)|, b = |x| and t = 2^-53 b (exact for
+// b >= 2^-960): fl(a / b) > 2^-53  <=>  a / b > 2^-53 (1 + 2^-53)  <=>  a >= the double after t  <=>  a > t.  NaNs compare false on
+// both sides as the reference's "ddum > dmax" does, an infinite quotient is "moves" on both; tiny |x| takes the division.
+__device__ __forceinline__ bool mid_row_moves(double ap, double pv, double xv) {
+  if (xv == 0.0) return pv != 0.0;
+  const double a = fabs(ap), b = fabs(xv);
+  if (b < 0x1p-960) {
+    const double q = a / b;
+    return q == q && 1.0 + q != 1.0;
+  }
+  return a > 0x1p-53 * b;
+}
+
 // grid barrier, then the reduction by every workgroup for itself; false: some workgroup gave up -- everybody leaves
 template <int NV, int BLK>
 __device__ __forceinline__ bool mid_barrier_reduce(MidCtl *c, int nwg, unsigned &gen, double (&out)[NV], const double *src,
@@ -392,7 +407,8 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
     const double malpha = -alpha;
 #pragma unroll
     for (int L = 0; L < LAYERS; ++L) {
-      double dmax = 0.0, acc0 = 0.0, acc1 = 0.0;
+      double acc0 = 0.0, acc1 = 0.0;
+      bool moves = false;  // some row of this lane has 1 + |alpha p / x| != 1 (pcg.c:128-139)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 0 ? in0[L] : in1[L]) {
@@ -400,10 +416,9 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
           double xv = XQ_LDS ? xl[li] : xr[L][u];
           const double qv = XQ_LDS ? ql[li] : qr[L][u];
           const double pv = XQ_LDS ? win[H + li] : pr[L][u];
-          const double quot = fabs(alpha * pv / xv);
-          const double ddum = (xv != 0.0) ? quot : ((pv != 0.0) ? 1.0 : 0.0);
-          dmax = (ddum > dmax) ? ddum : dmax;
-          if (upd) xv = xv + alpha * pv;
+          const double ap = alpha * pv;
+          moves = moves || mid_row_moves(ap, pv, xv);
+          if (upd) xv = xv + ap;
           if constexpr (XQ_LDS) xl[li] = xv;
           else xr[L][u] = xv;
           const double tt = upd ? rr[L][u] + malpha * qv : rr[L][u];
@@ -415,14 +430,13 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
           }
         }
       }
-      if (pre == 0) acc1 = acc0;
-      dmax = psp_wave_max(dmax);
+      const bool wave_moves = __ballot(moves) != 0ull;  // (the launch-per-phase loops: 1 + max over the wave != 1 -- the same)
       acc0 = psp_wave_sum(acc0);
-      acc1 = psp_wave_sum(acc1);
+      acc1 = pre == 0 ? acc0 : psp_wave_sum(acc1);  // no preconditioner: z is r, the same sum
       if (lane == 0) {
         red[L * NW + wave] = acc0;
         red[LAYERS * NW + L * NW + wave] = acc1;
-        red[2 * LAYERS * NW + L * NW + wave] = (1.0 + dmax != 1.0) ? 1.0 : 0.0;
+        red[2 * LAYERS * NW + L * NW + wave] = wave_moves ? 1.0 : 0.0;
       }
       // the rows the neighbours' halos cover: published for the next iteration's p
       const int lr = L * kMidLayer + 2 * t;  // row inside the block

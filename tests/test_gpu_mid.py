@@ -45,6 +45,8 @@ for case in spec:
     n = A.shape[0]
     assert A.kernel_info()[0] == "csr_spmv_w4", A.kernel_info()
     b = np.random.default_rng(case.get("bseed", 1)).standard_normal(n)
+    if case.get("b") == "A*ones":  # the exact solution is representable: PCG ends by stagnation (pcg.c:159-162)
+        b = np.empty(n); A.matvec(np.ones(n), b)
     s0 = C.c_longlong(); f0 = C.c_longlong()
     L.psp_debug_mid_count(C.byref(s0), C.byref(f0))
     for Kname in case["K"]:
@@ -125,6 +127,21 @@ def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
     for k, (ra, rb) in enumerate(zip(a, b)):
         assert ra == rb, (k, ra[:3], rb[:3])
     assert a[-1][0] == 0
+
+
+def test_stagnation_exit_at_the_same_iteration():
+    """pcg.c:124-139, :159-162: the kernel decides "1 + max |alpha p / x| == 1" row by row without the division
+    (mid_row_moves) -- the exit must come at the launch-per-phase loops' iteration, with their bits"""
+    spec = [{"kind": "poisson", "grid": [400, 400, 0], "K": ["jacobi", "none"], "runs": [[0.0, 5000]], "b": "A*ones"},
+            {"kind": "poisson", "grid": [1024, 1024, 0], "K": ["jacobi"], "runs": [[0.0, 9000]], "b": "A*ones"},
+            {"kind": "random5", "grid": [300, 300, 0], "seed": 9, "K": ["jacobi"], "runs": [[0.0, 5000]], "b": "A*ones"}]
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0", "PSP_COOP": "0"})
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert a == b
+    assert [r[0] for r in a] == [-5] * len(a), [r[:2] for r in a]
+    assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
 
 
 @pytest.mark.parametrize("blk", ["512", "1024"])
