@@ -3694,7 +3694,11 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available) {
   *available = 0;
   Variant v = decode_variant(A->variant);
   if (A->w4_only) v.w4 = true;
-  if (!v.w4 || A->nparts || A->sym_owner || A->multi || A->host || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  if (!v.w4 || A->nparts || A->multi || A->host || A->nrows != A->ncols || A->nrows < 2) return PSP_OK;
+  // The full mirror of an sss_mat (sym_owner): its product is sss_spmv_w4 -- per row the lower entries in ascending column,
+  // the diagonal, the mirrored entries in ascending row (sss_mat.c:45-55) -- which IS the mirror's row in ascending column
+  // order, added left to right: the offset table of the mirror gives the same bits, and the workgroup order of the dot
+  // partials (stripe, grid) is computed from the same handle.  The table is built here, on the first single-kernel solve.
   psp::CsrExtra *ex;
   PSP_TRY(ensure_w4(A, &ex));
   if (ex->dia_state != 1 || ex->dia_no > 8 || !ex->dia_mask) return PSP_OK;

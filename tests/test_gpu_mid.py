@@ -31,6 +31,8 @@ for case in spec:
     kind, grid = case["kind"], tuple(case["grid"])
     if kind == "poisson":
         A = dev.DeviceCSR.poisson(*grid)
+    elif kind == "poisson_sss":  # the same operator as an sss_mat (examples/poisson_test.py: S = L.to_sss())
+        A = dev.DeviceSSS.poisson(*grid)
     else:  # 5-offset operator with random coefficients and a varying, dominant diagonal (symmetric)
         nx, ny = grid[0], grid[1]
         n = nx * ny
@@ -43,7 +45,7 @@ for case in spec:
         S.sort_indices()
         A = dev.DeviceCSR.from_arrays(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
     n = A.shape[0]
-    assert A.kernel_info()[0] == "csr_spmv_w4", A.kernel_info()
+    assert A.kernel_info()[0] == ("sss_spmv_w4" if kind == "poisson_sss" else "csr_spmv_w4"), A.kernel_info()
     b = np.random.default_rng(case.get("bseed", 1)).standard_normal(n)
     if case.get("b") == "A*ones":  # the exact solution is representable: PCG ends by stagnation (pcg.c:159-162)
         b = np.empty(n); A.matvec(np.ones(n), b)
@@ -127,6 +129,23 @@ def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
     for k, (ra, rb) in enumerate(zip(a, b)):
         assert ra == rb, (k, ra[:3], rb[:3])
     assert a[-1][0] == 0
+
+
+def test_sss_operands_take_the_single_kernel_loops_with_their_own_bits():
+    """an sss_mat's product adds a row's lower entries, its diagonal and its mirrored entries in ascending column order
+    (sss_mat.c:45-55): the offset table of the handle's full mirror is the same sum -- PCG and MINRES on the sss form run
+    as single kernels and give the bits of the launch-per-phase loops around sss_spmv_w4"""
+    spec = [{"kind": "poisson_sss", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["pcg", "minres"]},
+            {"kind": "poisson_sss", "grid": [1024, 1000, 0], "K": ["jacobi"], "runs": RUNS[:5], "solvers": ["pcg", "minres"]},
+            {"kind": "poisson_sss", "grid": [40, 40, 300], "K": ["jacobi"], "runs": RUNS[:5] + RUNS[-1:], "solvers": ["pcg", "minres"]},
+            {"kind": "poisson_sss", "grid": [300, 300, 0], "K": ["jacobi"], "runs": RUNS[:5] + RUNS[-1:], "solvers": ["pcg", "minres"]}]
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0", "PSP_COOP": "0"})
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert a == b and len(a) > 0
+    assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
+    assert all(r[1] == 0 for r in ref if r[0] == "mid_solves")
 
 
 def test_stagnation_exit_at_the_same_iteration():

@@ -41,16 +41,16 @@ if __name__ == "__main__":
         print(json.dumps(run()))
     else:
         res = {"device_scalars": run()}
-        env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0")  # round 3: without the single-kernel loops of psp_coop.hip
+        env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0", PSP_MID="0")  # without the single-kernel loops (psp_coop.hip, psp_mid.hip)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
         res["launch_per_phase_loops"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else p.stderr[-500:]
         if isinstance(res["launch_per_phase_loops"], dict):
             for size, row in res["device_scalars"].items():
                 a = res["launch_per_phase_loops"][size]
-                print("%s: single-kernel loop (default up to 2^18 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
+                print("%s: single-kernel loops (default up to 2^20 rows) pcg %.1f / minres %.1f us/it; launch-per-phase loops "
                       "pcg %.1f / minres %.1f" % (size, row["pcg"]["us_per_iter"], row["minres"]["us_per_iter"],
                                                    a["pcg"]["us_per_iter"], a["minres"]["us_per_iter"]), flush=True)
-        env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0", PSP_MINRES_ASYNC="0")
+        env = dict(os.environ, PSP_TUNING="1", PSP_COOP="0", PSP_MID="0", PSP_MINRES_ASYNC="0")
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
         res["minres_host_scalars"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else p.stderr[-500:]
         for size, row in res["device_scalars"].items():
