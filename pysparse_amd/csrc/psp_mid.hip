@@ -402,25 +402,19 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
     }
     alpha = rho / pq;
     const int stag0 = alpha == 0.0;  // pcg.c:124-125
-    // ---- stagnation scan, x += alpha p, r -= alpha q; r.r, r.z (x_update_kernel / r_update_kernel's expressions)
+    // ---- r -= alpha q; r.r, r.z -- then the stagnation scan and x += alpha p (x_update_kernel / r_update_kernel's
+    // expressions).  The residual comes first: what the neighbours and the reduction need -- the block-boundary rows of r and
+    // the spans' partial sums -- is on its way to memory while the scan and the x update, which nobody else reads, still run.
     const bool upd = alpha != 0.0;
     const double malpha = -alpha;
 #pragma unroll
     for (int L = 0; L < LAYERS; ++L) {
       double acc0 = 0.0, acc1 = 0.0;
-      bool moves = false;  // some row of this lane has 1 + |alpha p / x| != 1 (pcg.c:128-139)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 0 ? in0[L] : in1[L]) {
           const int li = L * kMidLayer + 2 * t + u;
-          double xv = XQ_LDS ? xl[li] : xr[L][u];
           const double qv = XQ_LDS ? ql[li] : qr[L][u];
-          const double pv = XQ_LDS ? win[H + li] : pr[L][u];
-          const double ap = alpha * pv;
-          moves = moves || mid_row_moves(ap, pv, xv);
-          if (upd) xv = xv + ap;
-          if constexpr (XQ_LDS) xl[li] = xv;
-          else xr[L][u] = xv;
           const double tt = upd ? rr[L][u] + malpha * qv : rr[L][u];
           rr[L][u] = tt;
           acc0 += tt * tt;
@@ -430,20 +424,18 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
           }
         }
       }
-      const bool wave_moves = __ballot(moves) != 0ull;  // (the launch-per-phase loops: 1 + max over the wave != 1 -- the same)
-      acc0 = psp_wave_sum(acc0);
-      acc1 = pre == 0 ? acc0 : psp_wave_sum(acc1);  // no preconditioner: z is r, the same sum
-      if (lane == 0) {
-        red[L * NW + wave] = acc0;
-        red[LAYERS * NW + L * NW + wave] = acc1;
-        red[2 * LAYERS * NW + L * NW + wave] = wave_moves ? 1.0 : 0.0;
-      }
       // the rows the neighbours' halos cover: published for the next iteration's p
       const int lr = L * kMidLayer + 2 * t;  // row inside the block
       if (in0[L] && (lr < H || lr + 2 > B - H)) {
         const long row = base + lr;
         mcoh_store(a.r + row, rr[L][0]);
         if (in1[L]) mcoh_store(a.r + row + 1, rr[L][1]);
+      }
+      acc0 = psp_wave_sum(acc0);
+      acc1 = pre == 0 ? acc0 : psp_wave_sum(acc1);  // no preconditioner: z is r, the same sum
+      if (lane == 0) {
+        red[L * NW + wave] = acc0;
+        red[LAYERS * NW + L * NW + wave] = acc1;
       }
     }
     __syncthreads();
@@ -454,6 +446,26 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
       if (gs < a.nspans)
         mcoh_store(a.part + (size_t)(1 + j) * kMidMaxSpans + gs, rj[4 * s] + rj[4 * s + 1] + rj[4 * s + 2] + rj[4 * s + 3]);
     }
+#pragma unroll
+    for (int L = 0; L < LAYERS; ++L) {
+      bool moves = false;  // some row of this lane has 1 + |alpha p / x| != 1 (pcg.c:128-139)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0 ? in0[L] : in1[L]) {
+          const int li = L * kMidLayer + 2 * t + u;
+          double xv = XQ_LDS ? xl[li] : xr[L][u];
+          const double pv = XQ_LDS ? win[H + li] : pr[L][u];
+          const double ap = alpha * pv;
+          moves = moves || mid_row_moves(ap, pv, xv);
+          if (upd) xv = xv + ap;
+          if constexpr (XQ_LDS) xl[li] = xv;
+          else xr[L][u] = xv;
+        }
+      }
+      const bool wave_moves = __ballot(moves) != 0ull;  // (the launch-per-phase loops: 1 + max over the wave != 1 -- the same)
+      if (lane == 0) red[2 * LAYERS * NW + L * NW + wave] = wave_moves ? 1.0 : 0.0;
+    }
+    __syncthreads();
     if (t == 64) {  // the workgroup's non-stagnated waves (exact small integers: any order)
       double f = 0.0;
       for (int w = 0; w < LAYERS * NW; ++w) f += red[2 * LAYERS * NW + w];
