@@ -395,21 +395,24 @@ __global__ __launch_bounds__(kCoopBlock) void minres_coop_kernel(int n, int nwg,
 }
 
 struct CoopMem {
+  // control block and partial sums: the thread's slab (psp_internal.h: no allocation per solve); the history: the
+  // solvers' vector pool
   CoopCtl *ctl = nullptr;
   double *part = nullptr, *hist = nullptr;
-  ~CoopMem() {
-    if (ctl) (void)hipFree(ctl);
-    if (part) (void)hipFree(part);
-    if (hist) (void)hipFree(hist);
-  }
+  size_t nhist = 0;
+  ~CoopMem() { scratch_put(hist, nhist); }
   int init(int maxit, bool want_hist) {
-    PSP_HIP(hipMalloc((void **)&ctl, sizeof(CoopCtl)));
-    PSP_HIP(hipMalloc((void **)&part, sizeof(double) * 4 * kCoopMaxWg));
+    static_assert(sizeof(CoopCtl) <= kStateBytes && 4 * (size_t)kCoopMaxWg <= kCtlPartDoubles, "state slab");
+    Workspace *ws;
+    PSP_TRY(workspace(&ws));
+    ctl = static_cast<CoopCtl *>(ws->state_dev);
+    part = ws->ctl_part;
     PSP_HIP(hipMemsetAsync(ctl, 0, sizeof(CoopCtl), stream()));
     PSP_HIP(hipMemsetAsync(part, 0, sizeof(double) * 4 * kCoopMaxWg, stream()));
     if (want_hist) {
-      PSP_HIP(hipMalloc((void **)&hist, sizeof(double) * ((size_t)maxit + 2)));
-      PSP_HIP(hipMemsetAsync(hist, 0xff, sizeof(double) * ((size_t)maxit + 2), stream()));
+      nhist = (size_t)maxit + 2;
+      PSP_TRY(scratch_get(nhist, &hist));
+      PSP_HIP(hipMemsetAsync(hist, 0xff, sizeof(double) * nhist, stream()));
     }
     return PSP_OK;
   }
@@ -509,6 +512,7 @@ int pcg_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, double
     PSP_HIP(hipMemcpyAsync(r, q, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   if (rc != PSP_OK) return rc;
   PSP_HIP(hipMemcpyAsync(x, p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));  // x is final when the call returns
   *info = c.info;
   *iter = c.iter;
   *relres = c.relres;
@@ -554,6 +558,7 @@ int minres_coop_loop(const psp_csr *A, const double *dinv, int n, double *x, dou
   }
   if (rc != PSP_OK) return rc;
   PSP_HIP(hipMemcpyAsync(x, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));  // x is final when the call returns
   *info = c.info;
   *iter = c.iter;
   if (c.info == 0 || c.info == -1) *relres = c.relres;

@@ -192,10 +192,24 @@ struct Workspace {
   double *scal_host = nullptr;  // 16 doubles + a sequence word (pinned, mapped host memory)
   double *scal_host_dev = nullptr;      // the device's address of it (fetch_scalars)
   unsigned long long scal_seq = 0;
+  // Round 5: what a solve needs besides its vectors -- the device-resident state of its loop and the pinned mirror the
+  // host reads it into (PcgDev / MinresDev / KryDev; the control block of the single-kernel loops) and the partial sums of
+  // the single-kernel loops -- lives here for the life of the thread instead of a hipMalloc / hipHostMalloc / hipFree per
+  // solve (a solve of ONE iteration took 430 us at 2048^2, 110-150 us in the single-kernel range: tools/solve_overhead.py).
+  // One solve at a time per thread uses them (the loops that do never run a caller's callback).
+  void *state_dev = nullptr;    // kStateBytes (device)
+  void *state_host = nullptr;   // kStateBytes (pinned)
+  double *ctl_part = nullptr;   // kCtlPartDoubles (device)
   int num_cu = 0;
   int device = -1;
 };
+constexpr size_t kStateBytes = 8192;
+constexpr size_t kCtlPartDoubles = 4 * 2048;
 int workspace(Workspace **out);
+// the solvers' pool of device work vectors (psp_solvers.hip) for the other translation units: at least n doubles,
+// contents undefined; give back with the n asked for
+int scratch_get(size_t n, double **out);
+void scratch_put(double *p, size_t n);
 
 // grid for streaming n-element vector kernels: one workgroup per span (capped; the kernels
 // loop over spans beyond the cap)

@@ -901,22 +901,24 @@ int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, doub
   if (!mid_plan(A, n, &P, true)) return kCoopFallback;
   (void)v_hat_old;
   (void)w_old;
+  // control block and partial sums: the thread's slab (psp_internal.h); the history: the solvers' vector pool
+  static_assert(sizeof(MidCtl) <= kStateBytes && 4 * (size_t)kMidMaxSpans <= kCtlPartDoubles, "state slab");
+  Workspace *ws;
+  PSP_TRY(workspace(&ws));
   struct Mem {
     MidCtl *ctl = nullptr;
     double *part = nullptr, *hist = nullptr;
-    ~Mem() {
-      if (ctl) (void)hipFree(ctl);
-      if (part) (void)hipFree(part);
-      if (hist) (void)hipFree(hist);
-    }
+    size_t nhist = 0;
+    ~Mem() { scratch_put(hist, nhist); }
   } m;
-  PSP_HIP(hipMalloc((void **)&m.ctl, sizeof(MidCtl)));
-  PSP_HIP(hipMalloc((void **)&m.part, sizeof(double) * 2 * kMidMaxSpans));
+  m.ctl = static_cast<MidCtl *>(ws->state_dev);
+  m.part = ws->ctl_part;
   PSP_HIP(hipMemsetAsync(m.ctl, 0, sizeof(MidCtl), stream()));
   PSP_HIP(hipMemsetAsync(m.part, 0, sizeof(double) * 2 * kMidMaxSpans, stream()));
   if (hist) {
-    PSP_HIP(hipMalloc((void **)&m.hist, sizeof(double) * ((size_t)it_max + 2)));
-    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * ((size_t)it_max + 2), stream()));
+    m.nhist = (size_t)it_max + 2;
+    PSP_TRY(scratch_get(m.nhist, &m.hist));
+    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * m.nhist, stream()));
   }
   double *yv = y;  // the vector that crosses workgroups: K v_hat, or v_hat itself without a preconditioner
   if (!dinv) {
@@ -972,6 +974,7 @@ int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, doub
   if (rc != PSP_OK) return rc;
   g_mid_solves.fetch_add(1);
   PSP_HIP(hipMemcpyAsync(x, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
   *info = c.info;
   *iter = c.iter;
   if (c.info == 0 || c.info == -1) *relres = c.relres;
@@ -994,22 +997,24 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
                  double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist) {
   MidPlan P;
   if (!mid_plan(A, n, &P)) return kCoopFallback;
+  // control block and partial sums: the thread's slab (psp_internal.h); the history: the solvers' vector pool
+  static_assert(sizeof(MidCtl) <= kStateBytes && 4 * (size_t)kMidMaxSpans <= kCtlPartDoubles, "state slab");
+  Workspace *ws;
+  PSP_TRY(workspace(&ws));
   struct Mem {
     MidCtl *ctl = nullptr;
     double *part = nullptr, *hist = nullptr;
-    ~Mem() {
-      if (ctl) (void)hipFree(ctl);
-      if (part) (void)hipFree(part);
-      if (hist) (void)hipFree(hist);
-    }
+    size_t nhist = 0;
+    ~Mem() { scratch_put(hist, nhist); }
   } m;
-  PSP_HIP(hipMalloc((void **)&m.ctl, sizeof(MidCtl)));
-  PSP_HIP(hipMalloc((void **)&m.part, sizeof(double) * 4 * kMidMaxSpans));
+  m.ctl = static_cast<MidCtl *>(ws->state_dev);
+  m.part = ws->ctl_part;
   PSP_HIP(hipMemsetAsync(m.ctl, 0, sizeof(MidCtl), stream()));
   PSP_HIP(hipMemsetAsync(m.part, 0, sizeof(double) * 4 * kMidMaxSpans, stream()));
   if (hist) {
-    PSP_HIP(hipMalloc((void **)&m.hist, sizeof(double) * ((size_t)maxit + 2)));
-    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * ((size_t)maxit + 2), stream()));
+    m.nhist = (size_t)maxit + 2;
+    PSP_TRY(scratch_get(m.nhist, &m.hist));
+    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * m.nhist, stream()));
   }
   PSP_HIP(hipMemcpyAsync(q, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
   MidArgs a;
@@ -1081,6 +1086,7 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   if (rc != PSP_OK) return rc;
   g_mid_solves.fetch_add(1);
   PSP_HIP(hipMemcpyAsync(x, p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));  // x is final when the call returns, as after the other loops
   *info = c.info;
   *iter = c.iter;
   *relres = c.relres;

@@ -227,6 +227,9 @@ int workspace(Workspace **out) {
       (void)hipGetLastError();
       ws.scal_host_dev = nullptr;  // fetch_scalars copies then
     }
+    PSP_HIP(hipMalloc(&ws.state_dev, kStateBytes));
+    PSP_HIP(hipHostMalloc(&ws.state_host, kStateBytes, hipHostMallocDefault));
+    PSP_HIP(hipMalloc((void **)&ws.ctl_part, sizeof(double) * kCtlPartDoubles));
     ws.device = d;
   }
   *out = &ws;

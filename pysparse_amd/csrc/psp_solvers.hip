@@ -151,6 +151,14 @@ struct ScratchPool {
   }
 };
 ScratchPool g_pool;
+}  // namespace
+namespace psp {
+int scratch_get(size_t n, double **out) { return g_pool.get(n, out); }
+void scratch_put(double *p, size_t n) {
+  if (p) g_pool.put(p, n ? n : 1, 0);
+}
+}  // namespace psp
+namespace {
 
 struct DevVecs {
   struct Held {
@@ -395,12 +403,14 @@ static int pcg_async_loop(psp_csr *Acsr, const double *dinv, int n, double *x, d
   hipGraphExec_t exec = nullptr;
   int enqueued = 0;  // iterations launched so far (never more than maxit: a no-op launch of a
                      // 512^3 grid still costs ~55 us)
-  PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
-  hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
-  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
+  static_assert(sizeof(PcgDev) <= kStateBytes, "state slab");
+  Workspace *wst;
+  PSP_TRY(workspace(&wst));
+  st = static_cast<PcgDev *>(wst->state_dev);  // the thread's state slab (psp_internal.h): nothing to allocate or free
+  hst = static_cast<PcgDev *>(wst->state_host);
+  hipError_t e = hipSuccess;
+  if (hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
   if (e != hipSuccess) {
-    (void)hipFree(st);
-    if (hst) (void)hipHostFree(hst);
     return fail(PSP_ENOMEM, "pcg: state allocation failed: %s", hipGetErrorString(e));
   }
   int rc = PSP_OK;
@@ -484,8 +494,6 @@ done:
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
   if (own) (void)hipStreamDestroy(own);
-  (void)hipFree(st);
-  (void)hipHostFree(hst);
   if (hist_dev) (void)hipFree(hist_dev);
   return rc;
 }
@@ -655,12 +663,14 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
   PSP_TRY(workspace(&w));
   PcgDev *st = nullptr, *hst = nullptr;
   double *hist_dev = nullptr;
-  PSP_HIP(hipMalloc((void **)&st, sizeof(PcgDev)));
-  hipError_t e = hipHostMalloc((void **)&hst, sizeof(PcgDev), hipHostMallocDefault);
-  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
+  static_assert(sizeof(PcgDev) <= kStateBytes, "state slab");
+  Workspace *wst;
+  PSP_TRY(workspace(&wst));
+  st = static_cast<PcgDev *>(wst->state_dev);  // the thread's state slab (psp_internal.h): nothing to allocate or free
+  hst = static_cast<PcgDev *>(wst->state_host);
+  hipError_t e = hipSuccess;
+  if (hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)maxit + 1));
   if (e != hipSuccess) {
-    (void)hipFree(st);
-    if (hst) (void)hipHostFree(hst);
     return fail(PSP_ENOMEM, "pcg: state allocation failed: %s", hipGetErrorString(e));
   }
   int rc = PSP_OK;
@@ -753,8 +763,6 @@ static int pcg_async_loop_lazy(psp_csr *Acsr, const double *dinv, int n, double 
 done:
 #undef PCG_TRY
 #undef PCG_HIP
-  (void)hipFree(st);
-  (void)hipHostFree(hst);
   if (hist_dev) (void)hipFree(hist_dev);
   return rc;
 }
@@ -1159,12 +1167,12 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
   PSP_TRY(workspace(&w));
   MinresDev *st = nullptr, *hst = nullptr;
   double *hist_dev = nullptr;
-  PSP_HIP(hipMalloc((void **)&st, sizeof(MinresDev)));
-  hipError_t e = hipHostMalloc((void **)&hst, sizeof(MinresDev), hipHostMallocDefault);
-  if (e == hipSuccess && hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)it_max + 1));
+  static_assert(sizeof(MinresDev) <= kStateBytes, "state slab");
+  st = static_cast<MinresDev *>(w->state_dev);  // the thread's state slab (psp_internal.h)
+  hst = static_cast<MinresDev *>(w->state_host);
+  hipError_t e = hipSuccess;
+  if (hist) e = hipMalloc((void **)&hist_dev, sizeof(double) * ((size_t)it_max + 1));
   if (e != hipSuccess) {
-    (void)hipFree(st);
-    if (hst) (void)hipHostFree(hst);
     return fail(PSP_ENOMEM, "minres: state allocation failed: %s", hipGetErrorString(e));
   }
   if (hist_dev) (void)hipMemsetAsync(hist_dev, 0xff, sizeof(double) * ((size_t)it_max + 1), stream());  // NaN, like the PCG loops
@@ -1252,8 +1260,6 @@ static int minres_async_loop(psp_csr *Acsr, const double *dinv, bool hasK, int n
 done:
 #undef MR_TRY
 #undef MR_HIP
-  (void)hipFree(st);
-  (void)hipHostFree(hst);
   if (hist_dev) (void)hipFree(hist_dev);
   return rc;
 }
@@ -1705,14 +1711,13 @@ int kry_reduce_then(const double *partials, int nparts, int nvals, KryDev *S, in
 
 // the state on the device + its pinned host mirror
 struct KryState {
-  KryDev *dev = nullptr, *host = nullptr;
-  ~KryState() {
-    if (dev) (void)hipFree(dev);
-    if (host) (void)hipHostFree(host);
-  }
+  KryDev *dev = nullptr, *host = nullptr;  // in the thread's state slab (psp_internal.h)
   int init() {
-    PSP_HIP(hipMalloc((void **)&dev, sizeof(KryDev)));
-    PSP_HIP(hipHostMalloc((void **)&host, sizeof(KryDev), hipHostMallocDefault));
+    static_assert(sizeof(KryDev) <= kStateBytes, "state slab");
+    Workspace *w;
+    PSP_TRY(workspace(&w));
+    dev = static_cast<KryDev *>(w->state_dev);
+    host = static_cast<KryDev *>(w->state_host);
     memset(host, 0, sizeof(KryDev));
     return PSP_OK;
   }
