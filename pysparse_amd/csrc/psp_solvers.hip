@@ -58,6 +58,8 @@ int k_lin2(long n, double a, const double *x, double b, const double *y, double 
 int k_scal(long n, double a, double *x);
 int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, double *partials, int *nparts,
                const double *neg_a_dev = nullptr);
+int k_axpy_dot_chain(long n, const double *prev, int np_prev, double *h_out, const double *x, double *y, const double *z,
+                     double *partials, int *nparts);
 int k_qmrs_kv(long n, const double *v1, double *wrk1, const double *dinv, double *partials, int *nparts);
 int k_qmrs_pg(long n, const double *v1, const double *wrk1, double *p, double *g, double cc, KryArg ka = KryArg());
 int k_qmrs_v(long n, const double *t, double *v1, double beta, double *partials, int *nparts, KryArg ka = KryArg());
@@ -2203,8 +2205,11 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
   std::vector<double> H((size_t)dim * m1), s(m1), cs(dim), sn(dim), hhost((size_t)dim + 2);
   double *hdev = nullptr;  // h[0..i] and ||w||^2 of the current column, on the device
   PSP_TRY(mem.alloc((size_t)dim + 2, &hdev));
-  const char *chain_env = psp::tuning_env("PSP_GMRES_CHAIN");  // 0: one read-back per Gram-Schmidt step (A/B; read per solve)
+  // PSP_GMRES_CHAIN (A/B; read per solve): 0 one read-back per Gram-Schmidt step, 1 the chain with a finishing launch per
+  // step (round 4), 2 (default) the finishing reduction folded into the next step's kernel where a step is launch-bound
+  const char *chain_env = psp::tuning_env("PSP_GMRES_CHAIN");
   const bool mgs_chain = !chain_env || atoi(chain_env) != 0;
+  const bool mgs_fold = (!chain_env || atoi(chain_env) == 2) && vec_grid(*w, n) <= 2048;  // n <= 2^20
 #define GH(i, j) (H[(size_t)(j) * m1 + (i)])
   int i, j, k, iter = 0;
   double beta, resid0 = 0.0, n2b, rel_resid = 0.0, d;
@@ -2243,10 +2248,19 @@ static int gmres_device(const psp_op *A, const psp_op *K, int n, double *x, cons
         // (one scalar read-back per inner iteration instead of i + 2) -- the same operations on the same values
         int np;
         PSP_TRY(k_dot(n, V[i + 1], V[0], w->partials, &np));
-        PSP_TRY(finish_partials(w->partials, np, 1, hdev));
-        for (k = 0; k <= i; k++) {
-          PSP_TRY(k_axpy_dot(n, 0.0, V[k], V[i + 1], k < i ? V[k + 1] : nullptr, w->partials, &np, hdev + k));
-          PSP_TRY(finish_partials(w->partials, np, 1, hdev + k + 1));
+        if (mgs_fold) {
+          // round 5: step k adds the partial sums of step k - 1 itself (every workgroup, reduce_block: the finishing block's
+          // bits) -- i + 3 launches for the column instead of 2 i + 4
+          double *P[2] = {w->partials, w->partials + kMaxParts};
+          for (k = 0; k <= i; k++)
+            PSP_TRY(k_axpy_dot_chain(n, P[k & 1], np, hdev + k, V[k], V[i + 1], k < i ? V[k + 1] : nullptr, P[(k + 1) & 1], &np));
+          PSP_TRY(finish_partials(P[(i + 1) & 1], np, 1, hdev + i + 1));
+        } else {
+          PSP_TRY(finish_partials(w->partials, np, 1, hdev));
+          for (k = 0; k <= i; k++) {
+            PSP_TRY(k_axpy_dot(n, 0.0, V[k], V[i + 1], k < i ? V[k + 1] : nullptr, w->partials, &np, hdev + k));
+            PSP_TRY(finish_partials(w->partials, np, 1, hdev + k + 1));
+          }
         }
         for (k = 0; k < i + 2; k += 16) PSP_TRY(fetch_scalars(hdev + k, std::min(16, i + 2 - k), hhost.data() + k));
         for (k = 0; k <= i; k++) GH(k, i) = hhost[k];

@@ -826,6 +826,45 @@ __global__ __launch_bounds__(kBlock) void axpy_dot_kernel(long n, double a, cons
   block_reduce_store<1>(acc, partials);
 }
 
+// ---- the same step with the reduction that yields its coefficient folded in (round 5; gmres.c:110-116, modified
+// Gram-Schmidt): every workgroup first adds the partial sums the step BEFORE left (prev[0 .. np_prev): reduce_block, the
+// finishing block's own routine -- its result does not depend on how many waves run it, so these are the bits a finishing
+// launch would have stored), takes a = -h, and workgroup 0 stores h where the host will read the column's coefficients.
+// One launch per Gram-Schmidt step instead of two; the partial sums ping-pong between two arrays (a workgroup may still be
+// adding the previous ones while another already stores its own).  np_prev <= 4096 (16 groups of 256).
+template <int V, bool SELF>
+__global__ __launch_bounds__(kBlock) void axpy_dot_chain_kernel(long n, const double *__restrict__ prev, int np_prev,
+                                                                double *__restrict__ h_out, const double *__restrict__ x,
+                                                                double *__restrict__ y, const double *__restrict__ z,
+                                                                double *__restrict__ partials) {
+  __shared__ double gsum[16];
+  __shared__ double hsh;
+  reduce_block(prev, np_prev, 1, 0, true, &hsh, gsum);  // (ends with a workgroup barrier)
+  const double h = hsh;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *h_out = h;
+  const double a = -h;
+  const bool upd = a != 0.0;
+  double acc[1] = {0.0};
+  PSP_VEC_LOOP(i, n) {
+    Pack<V> yy = ld<V>(y, i);
+    if (upd) {
+      const Pack<V> xx = ld<V>(x, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) yy.v[k] = 1.0 * yy.v[k] + a * xx.v[k];
+      st<V>(y, i, yy);
+    }
+    if constexpr (SELF) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[0] += yy.v[k] * yy.v[k];
+    } else {
+      const Pack<V> zz = ld<V>(z, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[0] += yy.v[k] * zz.v[k];
+    }
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
 // ---- x = a*x (dscal)
 template <int V>
 __global__ __launch_bounds__(kBlock) void scal_kernel(long n, double a, double *x) {
@@ -1337,6 +1376,24 @@ int k_axpy_dot(long n, double a, const double *x, double *y, const double *z, do
   const bool v2 = z ? can_vec2(n, x, y, z) : can_vec2(n, x, y);
 #define L(V, SELF)                                                                                      \
   hipLaunchKernelGGL((axpy_dot_kernel<V, SELF>), dim3(grid), dim3(kBlock), 0, stream(), n, a, x, y, z, partials, neg_a_dev)
+  if (z) { if (v2) L(2, false); else L(1, false); }
+  else { if (v2) L(2, true); else L(1, true); }
+#undef L
+  PSP_LAUNCH_CHECK();
+  *nparts = grid;
+  return PSP_OK;
+}
+
+int k_axpy_dot_chain(long n, const double *prev, int np_prev, double *h_out, const double *x, double *y, const double *z,
+                     double *partials, int *nparts) {
+  Workspace *w;
+  PSP_TRY(workspace(&w));
+  if (np_prev < 1 || np_prev > 4096) return fail(PSP_EINVAL, "k_axpy_dot_chain: %d partial sums", np_prev);
+  const int grid = vec_grid(*w, n);
+  const bool v2 = z ? can_vec2(n, x, y, z) : can_vec2(n, x, y);
+#define L(V, SELF)                                                                                                 \
+  hipLaunchKernelGGL((axpy_dot_chain_kernel<V, SELF>), dim3(grid), dim3(kBlock), 0, stream(), n, prev, np_prev, h_out, x, y, \
+                     z, partials)
   if (z) { if (v2) L(2, false); else L(1, false); }
   else { if (v2) L(2, true); else L(1, true); }
 #undef L

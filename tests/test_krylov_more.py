@@ -194,3 +194,40 @@ def test_gpu_device_resident_scalars_give_the_host_scalar_loops_bits():
     for a, b in zip(outs[0], outs[1]):
         assert a == b, (a[:4], b[:4])
     assert any(r[1] == 0 for r in outs[0] if isinstance(r[1], int))  # the converged runs converged
+
+
+@pytest.mark.gpu
+def test_gpu_gmres_gram_schmidt_chain_variants_give_the_same_bits():
+    """gmres.c:110-116 (modified Gram-Schmidt) three ways: one read-back per step (PSP_GMRES_CHAIN=0), the chain with a
+    finishing launch per step (1), the finishing reduction folded into the next step's kernel (2, the default up to 2^20
+    rows; round 5).  The same sums in the same order: info, iteration count, residual and x agree BIT FOR BIT -- restarts,
+    truncated runs, with and without Jacobi, odd sizes (the V = 1 mapping), a size with several groups of partial sums."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);\n"
+        "from pysparse_amd import device as dev\n"
+        "out = []\n"
+        "for grid in ((60, 50, 0), (37, 31, 0), (20, 18, 17), (640, 401, 0)):\n"
+        "    M = dev.DeviceCSR.poisson(*grid); n = M.shape[0]\n"
+        "    b = np.random.default_rng(3).standard_normal(n)\n"
+        "    for K in (None, dev.DeviceJacobi(M)):\n"
+        "        for dim in (5, 20):\n"
+        "            for tol, mx in [(1e-9, 400)] + [(0.0, k) for k in (1, 2, dim - 1, dim, dim + 1, 2 * dim + 3)]:\n"
+        "                x = np.zeros(n); r = dev.gmres(M, b, x, tol, mx, K, dim)\n"
+        "                out.append([grid[0], dim, r[0], r[1], float(r[2]).hex(), float(np.abs(x).sum()).hex(), x.tobytes().hex()[:128]])\n"
+        "print(json.dumps(out))"
+    ) % root
+    outs = []
+    for env in ({}, {"PSP_GMRES_CHAIN": "1"}, {"PSP_GMRES_CHAIN": "0"}):
+        e = dict(os.environ, PSP_TUNING="1")
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert len(outs[0]) == len(outs[1]) == len(outs[2]) > 100
+    for a, b, c in zip(*outs):
+        assert a == b == c, (a[:5], b[:5], c[:5])
