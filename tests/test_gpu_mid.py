@@ -33,6 +33,10 @@ for case in spec:
         A = dev.DeviceCSR.poisson(*grid)
     elif kind == "poisson_sss":  # the same operator as an sss_mat (examples/poisson_test.py: S = L.to_sss())
         A = dev.DeviceSSS.poisson(*grid)
+    elif kind == "signs":  # diag(+1, -1, +1, ...): one offset; with b = ones p.Ap = 0 in the first iteration (pcg.c:118-120)
+        n = grid[0]
+        d = np.where(np.arange(n) %% 2 == 0, 1.0, -1.0)
+        A = dev.DeviceCSR.from_arrays((n, n), np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), d)
     else:  # 5-offset operator with random coefficients and a varying, dominant diagonal (symmetric)
         nx, ny = grid[0], grid[1]
         n = nx * ny
@@ -47,6 +51,8 @@ for case in spec:
     n = A.shape[0]
     assert A.kernel_info()[0] == ("sss_spmv_w4" if kind == "poisson_sss" else "csr_spmv_w4"), A.kernel_info()
     b = np.random.default_rng(case.get("bseed", 1)).standard_normal(n)
+    if case.get("b") == "ones":
+        b = np.ones(n)
     if case.get("b") == "A*ones":  # the exact solution is representable: PCG ends by stagnation (pcg.c:159-162)
         b = np.empty(n); A.matvec(np.ones(n), b)
     s0 = C.c_longlong(); f0 = C.c_longlong()
@@ -160,6 +166,20 @@ def test_stagnation_exit_at_the_same_iteration():
     b = [r for r in ref if r[0] != "mid_solves"]
     assert a == b
     assert [r[0] for r in a] == [-5] * len(a), [r[:2] for r in a]
+    assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
+
+
+def test_breakdown_exit_inside_the_kernel():
+    """p.Ap == 0 (pcg.c:118-120: flag -6, x untouched by that iteration) decided inside the single kernel, at the
+    launch-per-phase loops' iteration and with their x; MINRES on the same indefinite operator runs to its own end"""
+    spec = [{"kind": "signs", "grid": [65536, 1, 0], "K": ["none"], "runs": [[1e-8, 50]], "b": "ones", "solvers": ["pcg", "minres"]},
+            {"kind": "signs", "grid": [300000, 1, 0], "K": ["none"], "runs": [[1e-8, 50]], "b": "ones", "solvers": ["pcg"]}]
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0", "PSP_COOP": "0"})
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert a == b
+    assert a[0][:2] == [-6, 1] and a[2][:2] == [-6, 1], [r[:2] for r in a]
     assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
 
 

@@ -25,6 +25,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--count", type=int, default=200)
 ap.add_argument("--seconds", type=float, default=420.0)
+ap.add_argument("--indefinite", action="store_true",
+                help="flip the sign of some diagonal entries (and with them of Jacobi's): the breakdown exits -- "
+                     "pcg -2 / -6 / -5, minres -3 / -6 -- inside the kernels; compared: single kernel vs launch per phase "
+                     "bit for bit, and (info, iter) with the oracle")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 L = _capi.lib()
@@ -57,6 +61,9 @@ def build():
         dg = np.full(n, rowsum.max() * (1.0 + dom) + 0.01)  # a constant diagonal: jacobi's dinv is a scalar
     else:
         dg = rowsum * (1.0 + dom) + 0.01 + rng.random(n) * float(rng.choice([1.0, 0.0]))
+    if a.indefinite:
+        flips = rng.random(n) < float(rng.choice([0.5, 0.1, 1e-3, 2.0 / n]))
+        dg = np.where(flips, -dg, dg)
     rows = np.concatenate([r, np.arange(n), c])
     cols = np.concatenate([c, np.arange(n), r])
     vals = np.concatenate([v, dg, v])
@@ -75,6 +82,7 @@ def build():
 t0 = time.time()
 done = 0
 refused = set()
+soft, exits = [], {}
 for it in range(a.count):
     if time.time() - t0 > a.seconds:
         break
@@ -116,6 +124,15 @@ for it in range(a.count):
                 if rm != rp or not np.array_equal(xm, xp):
                     print("MISMATCH single kernel vs launch per phase", name, pre, desc, opk, rm, rp, flush=True)
                     sys.exit(1)
+                if a.indefinite:  # iterates of a breaking-down recurrence are not comparable digit by digit: the exit is
+                    if rm[0] != ref[0] or abs(rm[1] - ref[1]) > (8 if rm[0] == 0 else 1):
+                        # (an exit decided by a sign or an exact zero may fall one iteration apart between summation orders;
+                        # on an indefinite system the residual of CG / MINRES does not fall monotonically: runs that
+                        # converge cross the tolerance a few iterations apart -- 2 .. 5 seen -- in either implementation)
+                        print("EXIT DIFFERS FROM THE ORACLE'S", name, pre, desc, opk, rm, ref[:3], flush=True)
+                        soft.append((it, name, pre, rm, ref[:3]))
+                    exits[(name, rm[0])] = exits.get((name, rm[0]), 0) + 1
+                    continue
                 err = np.abs(xm - xo).max() / max(np.abs(xo).max(), 1e-300)
                 # 32 k sqrt(n) eps (bench.parity_bound) times the conditioning: 1 / dominance, and without the
                 # preconditioner also the spread of the diagonal (rows that lost all their neighbours keep 0.01 + random)
@@ -124,10 +141,12 @@ for it in range(a.count):
                         abs(rm[2] - ref[2]) > 1e-9 * abs(ref[2]) + bound + (tol if rm[1] != ref[1] else 0.0):
                     print("MISMATCH vs oracle", name, pre, desc, opk, rm, ref[:3], err, flush=True)
                     sys.exit(1)
-            msg += " %s%s %d %.1e" % (name, "+jac" if pre else "", ref[1], err)
+            msg += " %s%s %d %s" % (name, "+jac" if pre else "", ref[1], ("info %d" % ref[0]) if a.indefinite else "%.1e" % err)
     D.close()
     Sd.close()
     done += 1
     print(it, desc, skern, msg, "(plan declined)" if it in refused else "", flush=True)
 print("matrices: %d (plan declined for %d), seconds %.0f, single-kernel solves %d, fallbacks %d" % (
     (done, len(refused), time.time() - t0) + mid_count()))
+if a.indefinite:
+    print("exits seen (solver, info): count", sorted(exits.items()), "; exits that differ from the oracle's:", len(soft))
