@@ -103,6 +103,9 @@ def stress(runs, max_us):
                 if ra != rb or not np.array_equal(va, vb):
                     out["mismatches"].append({"ranks": ranks, "grid": grid, "call": nm, "seed": seed - 1, "base": ra, "got": rb})
             out["injected"] += injected()
+            if k % 10 == 9:  # a long campaign must show that it lives (the box ends a silent command)
+                print("[shake] ranks %d grid %s: %d / %d runs, %d delays injected, %d mismatches" % (
+                    ranks, grid, k + 1, runs, out["injected"], len(out["mismatches"])), file=sys.stderr, flush=True)
         out["configs"] += 1
     disarm()
     out["mismatches"] = out["mismatches"][:10]
