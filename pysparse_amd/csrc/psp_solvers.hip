@@ -1711,6 +1711,35 @@ int kry_reduce_then(const double *partials, int nparts, int nvals, KryDev *S, in
   return PSP_OK;
 }
 
+// two single-value reductions (their partial sums in different arrays, of different length) and the step that needs both,
+// in ONE finishing launch -- bicgstab: t . s (the product's epilogue) and t . t (a pass of its own), then omega
+template <int OP>
+__global__ __launch_bounds__(kReduceBlock) void kry_finish2_kernel(const double *__restrict__ src0, int count0, int stride0,
+                                                                   int raw0, int out0, const double *__restrict__ src1,
+                                                                   int count1, int stride1, int raw1, int out1, KryDev *S) {
+  if (S->status) return;
+  __shared__ double sh[kOneBlockGroups];
+  reduce_block(src0, count0, 1, stride0, raw0 != 0, S->r + out0, sh);
+  reduce_block(src1, count1, 1, stride1, raw1 != 0, S->r + out1, sh);
+  if (threadIdx.x != 0) return;
+  double *r = S->r;
+  if constexpr (OP == kBicgTt) r[BI_OMEGA] = r[BI_D1] / r[BI_D2];  // omega = (t . s) / (t . t)
+}
+
+template <int OP>
+int kry_reduce2_then(const double *p0, int n0, int out0, const double *p1, int n1, int out1, KryDev *S) {
+  const double *parts[2] = {p0, p1};
+  const int np[2] = {n0, n1}, fslot[2] = {0, 1};
+  const double *src[2];
+  int count[2], stride[2];
+  bool raw[2];
+  PSP_TRY(fold_stage2(parts, np, fslot, src, count, stride, raw));
+  hipLaunchKernelGGL((kry_finish2_kernel<OP>), dim3(1), dim3(kReduceBlock), 0, stream(), src[0], count[0], stride[0],
+                     raw[0] ? 1 : 0, out0, src[1], count[1], stride[1], raw[1] ? 1 : 0, out1, S);
+  PSP_LAUNCH_CHECK();
+  return PSP_OK;
+}
+
 // the state on the device + its pinned host mirror
 struct KryState {
   KryDev *dev = nullptr, *host = nullptr;  // in the thread's state slab (psp_internal.h)
@@ -1930,9 +1959,10 @@ static int bicgstab_device(const psp_op *A, const psp_op *K, int n, double *x, c
           PSP_TRY(kry_reduce_then<kBicgD1>(w->partials, np, 1, S, BI_D1));
           PSP_TRY(k_bicg_s(n, r, v, s, sh, dinv, 0.0, KryArg{S, BI_ALPHA}));
           PSP_TRY(csr_spmv_launch(Acsr, sh, t, s, w->partials, &np, &S->status));
-          PSP_TRY(kry_reduce_then<kBicgTs>(w->partials, np, 1, S, BI_D1));
-          PSP_TRY(k_dot(n, t, t, w->partials, &np2));  // (runs once more after the loop has ended: its result is ignored)
-          PSP_TRY(kry_reduce_then<kBicgTt>(w->partials, np2, 1, S, BI_D2));
+          // t . t into the second array of partial sums (runs once more after the loop has ended: its result is ignored);
+          // ONE finishing launch for t . s, t . t and omega
+          PSP_TRY(k_dot(n, t, t, w->partials + kMaxParts, &np2));
+          PSP_TRY(kry_reduce2_then<kBicgTt>(w->partials, np, BI_D1, w->partials + kMaxParts, np2, BI_D2, S));
           PSP_TRY(k_bicg_xr(n, x, ph, sh, s, t, r, rhat, 0.0, 0.0, w->partials, &np, KryArg{S, BI_ALPHA, BI_OMEGA}));
           PSP_TRY(kry_reduce_then<kBicgXr>(w->partials, np, 2, S, BI_RR));
         }
