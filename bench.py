@@ -109,7 +109,7 @@ def _ref_solve(O, name, A, b, k, dinv, threads=1):
 
 
 def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, with_ref=True, x_ref=None, res_ref=None,
-                    with_oracle=True, ref_threads=1):
+                    with_oracle=True, ref_threads=1, form="csr"):
     """`parity_check` of the bench line and tests/test_gpu_reference_sizes.py: k iterations (tol = 0) of Jacobi-PCG and
     Jacobi-MINRES on the GPU (through the host-pointer entry points, as the drop-in modules call them) against
       * the oracle's iterates on the same system (with_oracle; bound 32 k sqrt(n) eps),
@@ -132,10 +132,12 @@ def gpu_parity_case(dev, O, grid, k, A=None, b=None, x_pcg=None, res_pcg=None, w
             res_pcg = O.pcg(A, b, x_pcg, 0.0, k, dinv)
         x_min = np.zeros(n)
         res_min = O.minres(A, b, x_min, 0.0, k, dinv)
-    G = dev.DeviceCSR.poisson(*grid)
+    # form "sss": the GPU side holds the operator as an sss_mat (examples/poisson_test.py: S = L.to_sss()) -- its product adds
+    # a row in the csr_mat's order (sss_mat.c:45-55), so the CPU legs stay the same; its dot partials are ordered differently
+    G = dev.DeviceSSS.poisson(*grid) if form == "sss" else dev.DeviceCSR.poisson(*grid)
     K = dev.DeviceJacobi(G)
     bound, bound_ref = parity_bound(n, k), parity_bound(n, k, "reference")
-    out = {"grid": list(grid), "n": n, "k": k, "bound": bound, "bound_vs_reference": bound_ref}
+    out = {"grid": list(grid), "n": n, "k": k, "form": form, "bound": bound, "bound_vs_reference": bound_ref}
     ok = True
     have_refk = with_ref and O.have_ref_krylov()
     for name, solver, ref_res, ref_x in (("pcg", dev.pcg, res_pcg, x_pcg), ("minres", dev.minres, res_min, x_min)):

@@ -121,3 +121,14 @@ def test_single_kernel_range_against_oracle_and_reference(oracle, grid, k):
     assert s1.value - s0.value >= 2 and f1.value == f0.value  # PCG and MINRES both ran as single kernels
     assert (1 << 18) < out["n"] <= (1 << 20)
     _check(out, k, True, oracle.have_ref() and oracle.have_ref_krylov())
+
+
+@pytest.mark.parametrize("grid,k", [((4096, 4096, 0), 10), ((1024, 1024, 0), 150), ((96, 96, 96), 60)])
+def test_sss_form_against_oracle_and_reference(oracle, grid, k):
+    """the same comparison with the operator held as an sss_mat on the GPU (sss_spmv_w4; in the single-kernel range the
+    offset table of its mirror): SURVEY 8a row B2 at configs[1]'s size, in the single-kernel range and on a 3-D grid"""
+    import bench
+    from pysparse_amd import device as dev
+    out = bench.gpu_parity_case(dev, oracle, grid, k, form="sss")
+    assert out["form"] == "sss" and out["n"] == grid[0] * grid[1] * max(grid[2], 1)
+    _check(out, k, True, oracle.have_ref() and oracle.have_ref_krylov())
