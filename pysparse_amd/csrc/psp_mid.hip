@@ -779,13 +779,14 @@ bool mid_enabled() {
   return on;
 }
 
-// PSP_MID_MIN (tuning switch): from how many rows on.  Default 2^16: against psp_coop.hip's one-row-per-thread loops (which
+// PSP_MID_MIN (tuning switch): from how many rows on.  Default 2^16 (MINRES), 2^15 (PCG): against psp_coop.hip's one-row-per-thread loops (which
 // remain for general matrices of <= 8 entries per row and for everything smaller) the kernels here take 9.7 / 11.7 us per
 // PCG iteration at 256^2, 9.9 / 13.1 at 300^2, 12.5 / 21.4 at 512^2; MINRES 9.2 / 10.4 at 300^2, 10.9 / 18.8 at 512^2;
 // below ~200^2 the order flips (100^2: 10.1 / 9.2) (profiles/r5_mid_vs_coop.txt)
-int mid_min_rows() {
+// (PCG from 2^15: 200^2 9.8 / 10.6; MINRES's one-row-per-thread loop holds out longer: 200^2 9.2 / 8.6)
+int mid_min_rows(bool minres) {
   const char *e = tuning_env("PSP_MID_MIN");
-  return e ? atoi(e) : 1 << 16;
+  return e ? atoi(e) : (minres ? 1 << 16 : 1 << 15);
 }
 
 // kernel of (offsets, rows per workgroup, threads per workgroup); nullptr: not built
@@ -836,7 +837,7 @@ int mid_block_threads(int rows, int no) {
 // the plan for this operator, or false: no index-free layout of <= 7 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
 bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
-  if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < mid_min_rows() || n > kMidMaxRows) return false;
+  if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < mid_min_rows(minres) || n > kMidMaxRows) return false;
   int av = 0;
   if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no > 7) return false;
   int omax = 1;
