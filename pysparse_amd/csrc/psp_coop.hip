@@ -103,9 +103,9 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *sh /* >= 16 *
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    double s = v[j];
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    // lane 0 of the xor tree this loop used to be IS the shuffle-down tree's lane 0 (v[l] + v[l + 32], then 16, 8, ...):
+    // psp_wave_sum's permlane / DPP form of it (psp_internal.h), the same bits
+    const double s = psp_wave_sum(v[j]);
     if (lane == 0) sh[j * 16 + wid] = s;
   }
   __syncthreads();
