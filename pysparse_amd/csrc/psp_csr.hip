@@ -3701,9 +3701,9 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available) {
   // partials (stripe, grid) is computed from the same handle.  The table is built here, on the first single-kernel solve.
   psp::CsrExtra *ex;
   PSP_TRY(ensure_w4(A, &ex));
-  if (ex->dia_state != 1 || ex->dia_no > 8 || !ex->dia_mask) return PSP_OK;
+  if (ex->dia_state != 1 || ex->dia_no > 9 || !ex->dia_mask) return PSP_OK;  // (9: the nine-point stencils of 2-D grids)
   out->no = ex->dia_no;
-  for (int i = 0; i < 8; ++i) out->offs[i] = i < ex->dia_no ? ex->dia_offs.o[i] : 0;
+  for (int i = 0; i < 12; ++i) out->offs[i] = i < ex->dia_no ? ex->dia_offs.o[i] : 0;
   out->valT = ex->dia_val;
   out->mask = ex->dia_mask;
   out->stripe = w4_stripe(A, v);

@@ -540,7 +540,7 @@ int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
 // psp_csr.hip -> psp_mid.hip: an operator's index-free (csr_spmv_w4) layout
 struct W4View {
   int no;       // offsets (<= 8)
-  int offs[8];  // col - row, ascending
+  int offs[12];  // col - row, ascending (the first `no`)
   const double *valT;          // blocks of 128 rows, offset-major inside a block
   const unsigned short *mask;  // bit o of mask[r]: row r stores an entry at offset o
   int stripe, grid;            // XCD stripe and grid of the launch-per-phase product (order of its dot partials)

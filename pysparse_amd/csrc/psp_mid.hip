@@ -8,7 +8,7 @@
 //
 //   * one workgroup of 1024 or 512 threads per CU owns a CONTIGUOUS block of B = 2048 or 4096 rows for the whole solve; a
 //     thread owns one to four pairs of adjacent rows: x, r, p, q of its rows, the rows' matrix entries (index-free layout
-//     of csr_spmv_w4: up to 7 offsets) and their masks stay in registers -- NOTHING of the matrix or of x, r, q is read
+//     of csr_spmv_w4: up to 9 offsets) and their masks stay in registers -- NOTHING of the matrix or of x, r, q is read
 //     again after the first iteration.  512 threads may keep 256 registers each: the 4096-row blocks and the 7-offset
 //     operators run (nearly) without scratch memory that way (mid_block_threads);
 //   * the direction vector p is exchanged through LDS: a window of H + B + H entries (H = largest |offset|); a row reads
@@ -62,7 +62,7 @@ struct MidCtl {
 
 struct MidArgs {
   int n, nwg, H;  // H: halo entries on either side of a block (even, >= the largest |offset|)
-  int offs[8];
+  int offs[12];
   const double *valT;
   const unsigned short *mask;
   const double *dinv;  // pre == 1
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
 // (psp_vec.hip), minres_scalar_alpha / minres_scalar_beta (psp_solvers.hip) -- the launch-per-phase loop's bits.
 struct MidMinresArgs {
   int n, nwg, H;
-  int offs[8];
+  int offs[12];
   const double *valT;
   const unsigned short *mask;
   const double *dinv;
@@ -796,6 +796,7 @@ int mid_min_rows(bool minres) {
     switch (no * 4 + key) {                                                            \
       PSP_MID_ROW(KERNEL, 1) PSP_MID_ROW(KERNEL, 2) PSP_MID_ROW(KERNEL, 3) PSP_MID_ROW(KERNEL, 4) \
       PSP_MID_ROW(KERNEL, 5) PSP_MID_ROW(KERNEL, 6) PSP_MID_ROW(KERNEL, 7)             \
+      PSP_MID_ROW(KERNEL, 8) PSP_MID_ROW(KERNEL, 9)                                    \
       default:                                                                         \
         return nullptr;                                                                \
     }                                                                                  \
@@ -834,12 +835,12 @@ int mid_block_threads(int rows, int no) {
   return (rows == 4096 || no >= 6) ? 512 : 1024;
 }
 
-// the plan for this operator, or false: no index-free layout of <= 7 offsets, too many rows, a halo that does not fit
+// the plan for this operator, or false: no index-free layout of <= 9 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
 bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
   if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < mid_min_rows(minres) || n > kMidMaxRows) return false;
   int av = 0;
-  if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no > 7) return false;
+  if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no > 9) return false;
   int omax = 1;
   for (int i = 0; i < P->w4.no; ++i) omax = std::max(omax, std::abs(P->w4.offs[i]));
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)
@@ -932,7 +933,7 @@ int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, doub
   a.n = n;
   a.nwg = P.nwg;
   a.H = P.H;
-  for (int i = 0; i < 8; ++i) a.offs[i] = P.w4.offs[i];
+  for (int i = 0; i < 12; ++i) a.offs[i] = P.w4.offs[i];
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;
@@ -1022,7 +1023,7 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   a.n = n;
   a.nwg = P.nwg;
   a.H = P.H;
-  for (int i = 0; i < 8; ++i) a.offs[i] = P.w4.offs[i];
+  for (int i = 0; i < 12; ++i) a.offs[i] = P.w4.offs[i];
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;

@@ -33,6 +33,20 @@ for case in spec:
         A = dev.DeviceCSR.poisson(*grid)
     elif kind == "poisson_sss":  # the same operator as an sss_mat (examples/poisson_test.py: S = L.to_sss())
         A = dev.DeviceSSS.poisson(*grid)
+    elif kind == "nine":  # 9-point operator (bilinear elements on a grid): random symmetric couplings, dominant diagonal
+        nx, ny = grid[0], grid[1]
+        n = nx * ny
+        g = np.random.default_rng(case["seed"])
+        import scipy.sparse as sp
+        ix = np.arange(n) %% nx
+        diags, offs = [], []
+        for o, ok in ((1, ix[:-1] < nx - 1), (nx - 1, ix[:n - nx + 1] > 0), (nx, np.ones(n - nx, bool)), (nx + 1, ix[:n - nx - 1] < nx - 1)):
+            e = -(0.1 + g.random(n - o)) * ok
+            diags += [e, e]; offs += [o, -o]
+        S = sp.diags(diags, offs, shape=(n, n), format="csr")
+        S = (S + sp.diags(-np.asarray(S.sum(axis=1)).ravel() + 0.3 + g.random(n))).tocsr()
+        S.eliminate_zeros(); S.sort_indices()
+        A = dev.DeviceCSR.from_arrays(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
     elif kind == "signs":  # diag(+1, -1, +1, ...): one offset; with b = ones p.Ap = 0 in the first iteration (pcg.c:118-120)
         n = grid[0]
         d = np.where(np.arange(n) %% 2 == 0, 1.0, -1.0)
@@ -152,6 +166,20 @@ def test_sss_operands_take_the_single_kernel_loops_with_their_own_bits():
     assert a == b and len(a) > 0
     assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
     assert all(r[1] == 0 for r in ref if r[0] == "mid_solves")
+
+
+def test_nine_point_operators():
+    """9 offsets (round 5, late): blocks of 2048 rows keep them in registers without scratch memory (512 threads), blocks of
+    4096 rows with some"""
+    spec = [{"kind": "nine", "grid": [400, 300, 0], "seed": 1, "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["pcg", "minres"]},
+            {"kind": "nine", "grid": [1000, 900, 0], "seed": 2, "K": ["jacobi"], "runs": RUNS[:5] + RUNS[-1:], "solvers": ["pcg", "minres"]}]
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0", "PSP_COOP": "0"})
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert a == b and len(a) > 0
+    assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
+    assert a[-1][0] == 0
 
 
 def test_stagnation_exit_at_the_same_iteration():

@@ -24,8 +24,26 @@ def main():
     fn = L.psp_pcg_dev if solver == "pcg" else L.psp_minres_dev
     grids = argv or ["1024,1024,0", "724,724,0", "600,600,0", "512,512,0", "80,80,80", "64,64,64"]
     for g in grids:
-        grid = tuple(int(t) for t in g.split(","))
-        A = dev.DeviceCSR.poisson(*grid)
+        nine = g.startswith("9:")  # "9:nx,ny,0": a 9-point operator with random symmetric couplings instead of the 5-point one
+        grid = tuple(int(t) for t in g[2 if nine else 0:].split(","))
+        if nine:
+            import scipy.sparse as sp
+            nx, ny = grid[0], grid[1]
+            nn = nx * ny
+            rg = np.random.default_rng(1)
+            ix = np.arange(nn) % nx
+            diags, offs = [], []
+            for o, ok in ((1, ix[:-1] < nx - 1), (nx - 1, ix[:nn - nx + 1] > 0), (nx, np.ones(nn - nx, bool)), (nx + 1, ix[:nn - nx - 1] < nx - 1)):
+                e = -(0.1 + rg.random(nn - o)) * ok
+                diags += [e, e]
+                offs += [o, -o]
+            S = sp.diags(diags, offs, shape=(nn, nn), format="csr")
+            S = (S + sp.diags(-np.asarray(S.sum(axis=1)).ravel() + 1e-5)).tocsr()  # nearly singular: thousands of iterations
+            S.eliminate_zeros()
+            S.sort_indices()
+            A = dev.DeviceCSR.from_arrays(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+        else:
+            A = dev.DeviceCSR.poisson(*grid)
         n = A.shape[0]
         K = dev.DeviceJacobi(A)
         aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
