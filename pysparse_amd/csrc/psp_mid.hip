@@ -838,9 +838,12 @@ int mid_block_threads(int rows, int no) {
 // the plan for this operator, or false: no index-free layout of <= 9 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
 bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
-  if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < mid_min_rows(minres) || n > kMidMaxRows) return false;
+  if (!mid_enabled() || !A || A->nrows != n || A->ncols != n || n < 1024 || n > kMidMaxRows) return false;
   int av = 0;
   if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no > 9) return false;
+  // below mid_min_rows psp_coop.hip's one-row-per-thread loops are faster -- where they apply: rows of 9 entries are
+  // beyond them at every size (launch-per-phase loops: 22-25 us per iteration at 400^2 against 11-13 here)
+  if (n < mid_min_rows(minres) && !(P->w4.no > 8 && !tuning_env("PSP_MID_MIN"))) return false;
   int omax = 1;
   for (int i = 0; i < P->w4.no; ++i) omax = std::max(omax, std::abs(P->w4.offs[i]));
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)

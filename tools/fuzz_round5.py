@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off differential campaign for round 5's single-kernel loops (psp_mid.hip; not part of the test suite): random
-symmetric positive definite OFFSET-STRUCTURED matrices in their range -- 2^16 .. 2^20 rows, 1 .. 3 lower offsets up to 2046
-(3 / 5 / 7 offsets in all), dropped entries (row masks), weak to strong diagonal dominance, constant or varying diagonals,
+symmetric positive definite OFFSET-STRUCTURED matrices in their range -- 2^16 .. 2^20 rows, 1 .. 4 lower offsets up to 2046
+(3 / 5 / 7 / 9 offsets in all), dropped entries (row masks), weak to strong diagonal dominance, constant or varying diagonals,
 extents that are no multiple of a span -- as csr_mat and as sss_mat, Jacobi-PCG and Jacobi-MINRES and both without a
 preconditioner:
   * against the oracle: equal (info, iter), iterates within max(1e-12, 32 k sqrt(n) eps / dominance);
@@ -42,7 +42,7 @@ def mid_count():
 
 def build():
     n = int(rng.choice([65536, 65537, 70001, 131071, 200003, 262144, 300007, 524288, 524800, 777777, 1048575, 1048576]))
-    nlo = int(rng.integers(1, 4))
+    nlo = int(rng.integers(1, 5))  # 3 .. 9 offsets in all
     hb = int(rng.choice([1, 3, 40, 700, 2044]))
     lo = np.unique(-rng.integers(1, hb + 1, size=nlo))
     keep = float(rng.choice([1.0, 1.0, 0.9, 0.5]))
