@@ -82,6 +82,8 @@ int psp_debug_hold_handles(const void *h1, const void *h2, int milliseconds);
 /* how many solves the single-kernel loop for mid-size offset-structured systems (psp_mid.hip) has run in this process,
  * and how many times it handed a solve back to the launch-per-phase loops (tests) */
 int psp_debug_mid_count(long long *solves, long long *fallbacks);
+/* the same counters for the brick form of those loops (7-offset operators of 3-D grids; psp_mid.hip) */
+int psp_debug_brick_count(long long *solves, long long *fallbacks);
 int psp_debug_shake(long long seed, int min_us, int max_us, unsigned point_mask, unsigned rank_mask, int revert_mask);
 int psp_debug_shake_count(long long *injected);
 int psp_debug_spin(int microseconds);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PSP_LIB_OVERRIDE") or os.path.join(HERE, "libpysparse
 
 # every symbol include/pysparse_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = """
-psp_last_error psp_version psp_device_count psp_set_device psp_thread_info psp_debug_hold_handles psp_debug_mid_count psp_debug_shake psp_debug_shake_count psp_debug_spin psp_peer_access psp_set_stream psp_synchronize
+psp_last_error psp_version psp_device_count psp_set_device psp_thread_info psp_debug_hold_handles psp_debug_mid_count psp_debug_brick_count psp_debug_shake psp_debug_shake_count psp_debug_spin psp_peer_access psp_set_stream psp_synchronize
 psp_set_placement psp_placement_info psp_place_operands psp_device_info psp_mem_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset psp_trim
 psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_stream_probe psp_build_id
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
@@ -97,7 +97,7 @@ def _declare(L):
     L.psp_device_count.restype = i
     L.psp_device_count.argtypes = []
     sig = {
-        "psp_set_device": [i], "psp_thread_info": [pi, pi, pvp], "psp_debug_hold_handles": [vp, vp, i], "psp_debug_shake": [C.c_longlong, i, i, C.c_uint, C.c_uint, i], "psp_debug_shake_count": [C.POINTER(C.c_longlong)], "psp_debug_spin": [i], "psp_debug_mid_count": [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "psp_peer_access": [i, i, pi], "psp_set_stream": [vp], "psp_synchronize": [], "psp_trim": [],
+        "psp_set_device": [i], "psp_thread_info": [pi, pi, pvp], "psp_debug_hold_handles": [vp, vp, i], "psp_debug_shake": [C.c_longlong, i, i, C.c_uint, C.c_uint, i], "psp_debug_shake_count": [C.POINTER(C.c_longlong)], "psp_debug_spin": [i], "psp_debug_mid_count": [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "psp_debug_brick_count": [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], "psp_peer_access": [i, i, pi], "psp_set_stream": [vp], "psp_synchronize": [], "psp_trim": [],
         "psp_set_placement": [i], "psp_placement_info": [pi, C.POINTER(C.c_longlong), pd], "psp_place_operands": [vp, pvp, pvp, pd],
         "psp_device_info": [C.c_char_p, i, pi, C.POINTER(i64)],
         "psp_mem_info": [C.POINTER(i64), C.POINTER(i64)],

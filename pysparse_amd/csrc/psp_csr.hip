@@ -2519,6 +2519,10 @@ struct CsrExtra {
   double *xp = nullptr;    // x, then y, in the new numbering (scratch, 2 * nrows doubles)
   int orig_max_blocks = 0;
   bool reorder_on_device = false;  // the numbering was computed by reorder_rcm_device
+  // csr_w4_view: is the operator a 7-offset one of a 3-D grid WITHOUT couplings across the ends of a grid line (entries
+  // at offset +-1 / +-nx only between cells that are neighbours on the grid)?  -1 not examined, 0 no, 1 yes
+  int grid_state = -1;
+  int grid_nx = 0, grid_ny = 0;
 };
 
 }  // namespace psp
@@ -3686,6 +3690,22 @@ int csr_spmv_scaled_launch(const psp_csr *A, const double *x, double xdiv, doubl
   return PSP_OK;
 }
 
+// rows whose stored entries at offset -1 / +1 / -nx / +nx would couple cells that are NOT neighbours on an nx x ny x nz
+// grid (k = i + nx j + nx ny l): counted into *bad
+__global__ __launch_bounds__(256) void grid_wrap_check_kernel(int n, int nx, int ny, const unsigned short *__restrict__ mask,
+                                                              int *__restrict__ bad) {
+  int found = 0;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+    const unsigned m = mask[r];  // bits 0 .. 6: offsets -nx ny, -nx, -1, 0, +1, +nx, +nx ny
+    const int i = (int)(r % nx), j = (int)((r / nx) % ny);
+    if (((m >> 2) & 1u) && i == 0) found = 1;
+    if (((m >> 4) & 1u) && i == nx - 1) found = 1;
+    if (((m >> 1) & 1u) && j == 0) found = 1;
+    if (((m >> 5) & 1u) && j == ny - 1) found = 1;
+  }
+  if (found) atomicAdd(bad, 1);
+}
+
 // What the single-kernel loops for mid-size systems (psp_mid.hip) need to know about an operator's index-free layout:
 // the offsets, the value / mask tables, and the grid and XCD stripe the launch-per-phase product would use (its dot
 // partials are indexed by workgroup, and the mid-size loops add theirs in exactly that order).  *available = 0 when the
@@ -3708,6 +3728,39 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available) {
   out->mask = ex->dia_mask;
   out->stripe = w4_stripe(A, v);
   out->grid = w4_grid((A->nrows + kDiaRows - 1) / kDiaRows, out->stripe);
+  // 3-D grid operator?  offsets {-s2, -s1, -1, 0, 1, s1, s2} with nx = s1, ny = s2 / s1, nz = n / s2 whole numbers, and no
+  // entry that couples across the end of a grid line (one pass over the row masks, once per handle)
+  out->grid3[0] = out->grid3[1] = out->grid3[2] = 0;
+  if (ex->dia_no == 7) {
+    const int *o = out->offs;
+    const int s1 = o[5], s2 = o[6];
+    if (ex->grid_state < 0) {
+      ex->grid_state = 0;
+      if (o[3] == 0 && o[4] == 1 && o[2] == -1 && o[1] == -s1 && o[0] == -s2 && s1 >= 2 && s2 % s1 == 0 && s2 / s1 >= 2 &&
+          A->nrows % s2 == 0 && A->nrows / s2 >= 2) {
+        int *bad = nullptr;
+        PSP_HIP(hipMalloc((void **)&bad, sizeof(int)));
+        PSP_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream()));
+        hipLaunchKernelGGL(grid_wrap_check_kernel, dim3(std::min((A->nrows + 255) / 256, 4096)), dim3(256), 0, stream(),
+                           A->nrows, s1, s2 / s1, ex->dia_mask, bad);
+        int hbad = 1;
+        const hipError_t e1 = hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, stream());
+        const hipError_t e2 = hipStreamSynchronize(stream());
+        (void)hipFree(bad);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(PSP_ENODEV, "csr_w4_view: grid check failed");
+        if (hbad == 0) {
+          ex->grid_state = 1;
+          ex->grid_nx = s1;
+          ex->grid_ny = s2 / s1;
+        }
+      }
+    }
+    if (ex->grid_state == 1) {
+      out->grid3[0] = ex->grid_nx;
+      out->grid3[1] = ex->grid_ny;
+      out->grid3[2] = A->nrows / (ex->grid_nx * ex->grid_ny);
+    }
+  }
   *available = 1;
   return PSP_OK;
 }

@@ -541,6 +541,7 @@ int jacobi_apply_dev(psp_jacobi *K, const double *x, double *y);
 struct W4View {
   int no;       // offsets (<= 8)
   int offs[12];  // col - row, ascending (the first `no`)
+  int grid3[3];  // nx, ny, nz when the operator is a 7-offset one of a 3-D grid without couplings across line ends, else 0
   const double *valT;          // blocks of 128 rows, offset-major inside a block
   const unsigned short *mask;  // bit o of mask[r]: row r stores an entry at offset o
   int stripe, grid;            // XCD stripe and grid of the launch-per-phase product (order of its dot partials)
@@ -551,6 +552,11 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available);
 bool mid_applicable(const psp_csr *A, int n, const double *dinv);
 int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                  double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist);
+// psp_mid.hip: the same for the 7-offset operators of 3-D grids, the points dealt out in bricks (iterates agree with the
+// launch-per-phase loops' to rounding)
+bool brick_applicable(const psp_csr *A, int n);
+int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
+                   double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist);
 bool mid_minres_applicable(const psp_csr *A, int n);
 int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
                     double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,

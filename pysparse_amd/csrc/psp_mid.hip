@@ -769,7 +769,314 @@ __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
   }
 }
 
-std::atomic<long long> g_mid_solves{0}, g_mid_fallbacks{0};
+// ---------------------------------------------------------------------------------------------------------------------
+// 3-D grid operators (7 offsets: -nx ny, -nx, -1, 0, 1, nx, nx ny) -- the same loop with the rows dealt out in BRICKS.
+// A contiguous block of rows of a 3-D grid is a slab whose halo is a whole grid plane on either side (80^3: 6400 rows for a
+// block of 2048): the window does not fit the LDS and forming p there costs six times the block's own work -- the kernels
+// above refuse such operators (80^3 ran 33.5 us per iteration against 29.9 launch-per-phase).  Here a workgroup owns a
+// brick of bx x by x bz <= 4096 grid points (eight per thread, 512 threads): its halo is the brick's surface (16^3: 1536
+// cells), p of the brick and its halo lives in one LDS array addressed by (a + 1) + (bx + 2)((b + 1) + (by + 2)(c + 1)),
+// x and q of the own points in LDS, r and the points' seven matrix entries in registers.  What crosses workgroups is r
+// of a brick's surface points (published with device-coherent stores at the barrier of the r.r / r.z reduction; the
+// neighbours form their halo entries of p from it, as above) and one partial sum per workgroup and reduction.
+// Arithmetic: per element the reference's operations (pcg.c:91-166), a row's products added in ascending column order
+// (csr_mat.c:49-54); a reduction adds a thread's points in a fixed order, the wave tree, the workgroup's waves in order,
+// the workgroups' sums by R -- fixed for a given grid, so runs are bitwise reproducible; the order differs from the
+// launch-per-phase loops' (rows of a span lie in several bricks), so iterates agree with theirs to rounding, not bit for
+// bit -- as psp_coop.hip's do (tests/test_gpu_brick.py: the oracle's counts and iterates within 1e-12).
+constexpr int kBrickBlock = 512;
+constexpr int kBrickPPT = 8;   // points per thread: bricks of <= 4096 points
+constexpr int kBrickHPT = 5;   // halo cells per thread: <= 2560 (a brick of 4096 points has at most 2 (bx by + by bz + bx bz) of them)
+
+struct BrickArgs {
+  int n, nwg;
+  int nx, ny, nz;  // the grid
+  int bx, by, bz;  // points of a brick along each axis
+  int cx, cy;      // bricks along x and y (workgroup w owns brick (w % cx, (w / cx) % cy, w / (cx cy)))
+  const double *valT;
+  const unsigned short *mask;
+  const double *dinv;
+  double dc;
+  int pre;
+  const double *x;
+  double *xout;
+  double *r;
+  double n2b, tolb, normr0, rho0;
+  int maxit;
+  MidCtl *ctl;
+  double *part;  // 3 x kMidMaxWg: p.q | r.r | r.z by workgroup
+  double *hist;
+};
+
+// R over the workgroups' partial sums of NV values (value j at part + j * kMidMaxWg), by every workgroup for itself
+template <int NV>
+__device__ __forceinline__ void brick_reduce(double (&out)[NV], const double *part, int nwg, double *sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < NV) {
+    double t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = lane + 64 * k < nwg ? mcoh_load(part + wave * kMidMaxWg + lane + 64 * k) : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += t[k];
+    s = psp_wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) out[j] = sh[j];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
+  extern __shared__ double lds[];
+  constexpr int NW = kBrickBlock / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wg = blockIdx.x, nwg = a.nwg;
+  const int bx = a.bx, by = a.by, bz = a.bz, nx = a.nx, ny = a.ny, nz = a.nz;
+  const int x0 = (wg % a.cx) * bx, y0 = ((wg / a.cx) % a.cy) * by, z0 = (wg / (a.cx * a.cy)) * bz;
+  const int ex = min(bx, nx - x0), ey = min(by, ny - y0), ez = min(bz, nz - z0);  // (the last bricks may be cut)
+  const int sx = bx + 2, sxy = sx * (by + 2);
+  const int vol = bx * by * bz, npad = sxy * (bz + 2);
+  double *P = lds;                         // p of the brick and its halo
+  double *xl = P + ((npad + 1) & ~1);      // x of the own points, by point number t + 512 m
+  double *ql = xl + kBrickBlock * kBrickPPT;  // q
+  double *rl = ql + kBrickBlock * kBrickPPT;  // r (in LDS like x and q: with it in registers the kernel spilled)
+  double *red = rl + kBrickBlock * kBrickPPT;  // 3 x NW wave sums, then 4 for brick_reduce
+  const int pre = a.pre;
+  const double dc = a.dc;
+  const int loff[7] = {-sxy, -sx, -1, 0, 1, sx, sxy};
+  // ---- the thread's points
+  double v[kBrickPPT][7];
+  unsigned long long mk = 0;  // 7 mask bits per point
+  int li[kBrickPPT], row[kBrickPPT];
+  unsigned inmask = 0, surf = 0;
+#pragma unroll
+  for (int m = 0; m < kBrickPPT; ++m) {
+    const int l = t + kBrickBlock * m;
+    const int pa = l % bx, pb = (l / bx) % by, pc = l / (bx * by);
+    const bool in = l < vol && pa < ex && pb < ey && pc < ez;
+    li[m] = (pa + 1) + sx * (pb + 1) + sxy * (pc + 1);
+    row[m] = in ? (x0 + pa) + nx * ((y0 + pb) + ny * (z0 + pc)) : 0;
+    double xv = 0.0, rv = 0.0;
+#pragma unroll
+    for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+    if (in) {
+      inmask |= 1u << m;
+      if (pa == 0 || pa == ex - 1 || pb == 0 || pb == ey - 1 || pc == 0 || pc == ez - 1) surf |= 1u << m;
+      const int rw = row[m];
+      mk |= (unsigned long long)(a.mask[rw] & 0x7fu) << (7 * m);
+      const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
+#pragma unroll
+      for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+      xv = a.x[rw];
+      rv = a.r[rw];
+    }
+    xl[l] = xv;
+    rl[l] = rv;
+  }
+  // ---- the thread's halo cells: LDS index and grid row (-1: outside the grid, or beyond a cut brick's faces)
+  int hidx[kBrickHPT], hrow[kBrickHPT];
+  {
+    const int f0 = bx * by, f1 = bx * bz, f2 = by * bz;
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j) {
+      int h = t + kBrickBlock * j;
+      int pa = 0, pb = 0, pc = 0;
+      bool ok = true;
+      if (h < 2 * f0) {
+        pc = h < f0 ? -1 : ez;
+        h = h < f0 ? h : h - f0;
+        pa = h % bx;
+        pb = h / bx;
+        ok = pa < ex && pb < ey;
+      } else if (h < 2 * f0 + 2 * f1) {
+        h -= 2 * f0;
+        pb = h < f1 ? -1 : ey;
+        h = h < f1 ? h : h - f1;
+        pa = h % bx;
+        pc = h / bx;
+        ok = pa < ex && pc < ez;
+      } else if (h < 2 * f0 + 2 * f1 + 2 * f2) {
+        h -= 2 * f0 + 2 * f1;
+        pa = h < f2 ? -1 : ex;
+        h = h < f2 ? h : h - f2;
+        pb = h % by;
+        pc = h / by;
+        ok = pb < ey && pc < ez;
+      } else {
+        ok = false;
+      }
+      const int gx = x0 + pa, gy = y0 + pb, gz = z0 + pc;
+      ok = ok && gx >= 0 && gx < nx && gy >= 0 && gy < ny && gz >= 0 && gz < nz;
+      hidx[j] = ok ? (pa + 1) + sx * (pb + 1) + sxy * (pc + 1) : -1;
+      hrow[j] = ok ? gx + nx * (gy + ny * gz) : 0;
+    }
+  }
+  for (int i = t; i < npad; i += kBrickBlock) P[i] = 0.0;
+  double rh[kBrickHPT];  // r of the halo cells, fetched after the barrier that published it
+#pragma unroll
+  for (int j = 0; j < kBrickHPT; ++j) rh[j] = hidx[j] >= 0 ? a.r[hrow[j]] : 0.0;
+  __syncthreads();
+  unsigned gen = 0;
+  double nonstag_seen = 0.0;
+  double rho = a.rho0, rho1 = 1.0, normr = a.normr0, alpha = 0.0, beta = 0.0;
+  int flag = -1, it;
+  for (it = 1; it <= a.maxit; ++it) {
+    if (rho == 0.0) {  // pcg.c:101-104
+      flag = -2;
+      break;
+    }
+    if (it > 1) {
+      beta = rho / rho1;
+      if (beta == 0.0) {  // pcg.c:109-112
+        flag = -6;
+        break;
+      }
+    }
+    // ---- p = z (+ beta p): the own points and the halo cells (pcg.c:93-97, :106, :113-114)
+#pragma unroll
+    for (int m = 0; m < kBrickPPT; ++m)
+      if ((inmask >> m) & 1u) {
+        double z = rl[t + kBrickBlock * m];
+        if (pre == 1) z = z * a.dinv[row[m]];
+        if (pre == 2) z = z * dc;
+        if (it > 1) z = z + beta * P[li[m]];
+        P[li[m]] = z;
+      }
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j)
+      if (hidx[j] >= 0) {
+        double z = rh[j];
+        if (pre == 1) z = z * a.dinv[hrow[j]];
+        if (pre == 2) z = z * dc;
+        if (it > 1) z = z + beta * P[hidx[j]];
+        P[hidx[j]] = z;
+      }
+    __syncthreads();
+    // ---- q = A p for the own points (ascending column order), p.q
+    {
+      double dsum = 0.0;
+#pragma unroll
+      for (int m = 0; m < kBrickPPT; ++m) {
+        double acc = 0.0;
+        if ((inmask >> m) & 1u) {
+#pragma unroll
+          for (int o = 0; o < 7; ++o) {
+            const double tt = acc + v[m][o] * P[li[m] + loff[o]];
+            acc = ((mk >> (7 * m + o)) & 1ull) ? tt : acc;
+          }
+          dsum += P[li[m]] * acc;
+        }
+        ql[t + kBrickBlock * m] = acc;
+      }
+      dsum = psp_wave_sum(dsum);
+      if (lane == 0) red[wave] = dsum;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double s = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += red[w];
+      mcoh_store(a.part + wg, s);
+    }
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+    double s1[1];
+    brick_reduce<1>(s1, a.part, nwg, red + 3 * NW);
+    const double pq = s1[0];
+    if (pq == 0.0) {  // pcg.c:118-120
+      flag = -6;
+      break;
+    }
+    alpha = rho / pq;
+    const int stag0 = alpha == 0.0;  // pcg.c:124-125
+    const bool upd = alpha != 0.0;
+    const double malpha = -alpha;
+    // ---- r -= alpha q; r.r, r.z; the surface points' r published; then the stagnation scan and x += alpha p
+    {
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < kBrickPPT; ++m)
+        if ((inmask >> m) & 1u) {
+          const double qv = ql[t + kBrickBlock * m];
+          const double ro = rl[t + kBrickBlock * m];
+          const double tt = upd ? ro + malpha * qv : ro;
+          rl[t + kBrickBlock * m] = tt;
+          acc0 += tt * tt;
+          if (pre != 0) {
+            const double z = tt * (pre == 1 ? a.dinv[row[m]] : dc);
+            acc1 += tt * z;
+          }
+          if ((surf >> m) & 1u) mcoh_store(a.r + row[m], tt);
+        }
+      acc0 = psp_wave_sum(acc0);
+      acc1 = pre == 0 ? acc0 : psp_wave_sum(acc1);
+      if (lane == 0) {
+        red[wave] = acc0;
+        red[NW + wave] = acc1;
+      }
+    }
+    __syncthreads();
+    if (t < 2) {
+      const double *rj = red + t * NW;
+      double s = rj[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += rj[w];
+      mcoh_store(a.part + (size_t)(1 + t) * kMidMaxWg + wg, s);
+    }
+    {
+      bool moves = false;
+#pragma unroll
+      for (int m = 0; m < kBrickPPT; ++m)
+        if ((inmask >> m) & 1u) {
+          double xv = xl[t + kBrickBlock * m];
+          const double pv = P[li[m]];
+          const double ap = alpha * pv;
+          moves = moves || mid_row_moves(ap, pv, xv);
+          if (upd) xv = xv + ap;
+          xl[t + kBrickBlock * m] = xv;
+        }
+      const bool wave_moves = __ballot(moves) != 0ull;
+      if (lane == 0) red[2 * NW + wave] = wave_moves ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (t == 64) {
+      double f = 0.0;
+      for (int w = 0; w < NW; ++w) f += red[2 * NW + w];
+      if (f != 0.0) (void)__hip_atomic_fetch_add(&a.ctl->nonstag, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j) rh[j] = hidx[j] >= 0 ? mcoh_load(a.r + hrow[j]) : 0.0;  // the next iteration's halo
+    double s2[2];
+    brick_reduce<2>(s2, a.part + kMidMaxWg, nwg, red + 3 * NW);
+    const double seen = mcoh_load(&a.ctl->nonstag);
+    const double nonstag = seen - nonstag_seen;
+    nonstag_seen = seen;
+    normr = sqrt(s2[0]);  // the recurred residual (pcg.c:146-153)
+    if (a.hist && wg == 0 && t == 0) a.hist[it] = normr;
+    if (normr <= a.tolb) {  // pcg.c:154-157
+      flag = 0;
+      break;
+    }
+    if (stag0 || nonstag == 0.0) {  // pcg.c:159-162
+      flag = -5;
+      break;
+    }
+    rho1 = rho;
+    rho = s2[1];
+  }
+#pragma unroll
+  for (int m = 0; m < kBrickPPT; ++m)
+    if ((inmask >> m) & 1u) a.xout[row[m]] = xl[t + kBrickBlock * m];
+  if (wg == 0 && t == 0) {
+    a.ctl->info = flag;
+    a.ctl->iter = it;
+    a.ctl->relres = normr / a.n2b;
+  }
+}
+
+std::atomic<long long> g_mid_solves{0}, g_mid_fallbacks{0}, g_brick_solves{0}, g_brick_fallbacks{0};
 
 bool mid_enabled() {
   static const bool on = [] {
@@ -1107,10 +1414,195 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   return PSP_OK;
 }
 
+// ---- 3-D grid operators in bricks (pcg_brick_kernel)
+namespace {
+
+struct BrickPlan {
+  W4View w4;
+  int nx, ny, nz, bx, by, bz, cx, cy, cz, nwg;
+  size_t lds;
+};
+
+bool brick_enabled() {
+  static const bool on = [] {
+    const char *e = tuning_env("PSP_BRICK");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
+// PSP_BRICK_MIN (tuning switch, read per solve): from how many rows on.  Measured against psp_coop.hip's one-row-per-thread
+// loop (up to 2^18 rows) and the launch-per-phase loops (tools/brick_ab.py, profiles/r5_brick_ab.txt), microseconds per PCG
+// iteration: 48^3 15.1 / 12.2, 56^3 15.0 / 16.1, 64^3 15.2 / 20.5, 80^3 18.2 / 28.0, 96^3 22.7 / 36.6, 100^3 24.4 / 38.0
+int brick_min_rows() {
+  const char *e = tuning_env("PSP_BRICK_MIN");
+  return e ? atoi(e) : 150000;
+}
+
+size_t brick_lds(int bx, int by, int bz) {
+  const int npad = (bx + 2) * (by + 2) * (bz + 2);
+  return sizeof(double) * (size_t)(((npad + 1) & ~1) + 3 * kBrickBlock * kBrickPPT + 3 * (kBrickBlock / 64) + 8);
+}
+
+// the bricks for this operator, or false: not a 3-D grid operator, or no decomposition into <= capacity bricks of <= 4096
+// points whose surfaces fit
+bool brick_plan(const psp_csr *A, int n, BrickPlan *P) {
+  if (!brick_enabled() || !mid_enabled() || !A || A->nrows != n || A->ncols != n || n < brick_min_rows() ||
+      n > kMidMaxWg * kBrickBlock * kBrickPPT)
+    return false;
+  int av = 0;
+  if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no != 7 || P->w4.grid3[0] == 0) return false;
+  const int nx = P->w4.grid3[0], ny = P->w4.grid3[1], nz = P->w4.grid3[2];
+  if ((long)nx * ny * nz != n) return false;
+  static std::mutex mu;
+  static std::map<int, int> cap;  // device -> workgroups the device holds at once
+  int capacity;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (const char *e = tuning_env("PSP_COOP_CAPACITY")) {
+      capacity = atoi(e);
+    } else {
+      auto it = cap.find(current_device());
+      if (it == cap.end()) {
+        int c = 0, per = 0;
+        Workspace *w = nullptr;
+        if (hipFuncSetAttribute((const void *)pcg_brick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) ==
+                hipSuccess &&
+            workspace(&w) == PSP_OK && w->num_cu > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void *)pcg_brick_kernel, kBrickBlock, kMidMaxLds) ==
+                hipSuccess)
+          c = per * w->num_cu;
+        else
+          (void)hipGetLastError();
+        it = cap.emplace(current_device(), c).first;
+      }
+      capacity = it->second;
+    }
+  }
+  capacity = std::min(capacity, kMidMaxWg);
+  // bricks: as many as the device holds, as close to cubes as the grid allows -- least work (points + halo cells) per
+  // workgroup among the decompositions that fit
+  long best = -1;
+  for (int cz = 1; cz <= std::min(nz, capacity); ++cz)
+    for (int cy = 1; cy <= std::min(ny, capacity / cz); ++cy)
+      for (int cx = 1; cx <= std::min(nx, capacity / (cz * cy)); ++cx) {
+        const int bx = (nx + cx - 1) / cx, by = (ny + cy - 1) / cy, bz = (nz + cz - 1) / cz;
+        if ((long)(cx - 1) * bx >= nx || (long)(cy - 1) * by >= ny || (long)(cz - 1) * bz >= nz) continue;  // an empty last brick
+        const long vol = (long)bx * by * bz, halo = 2L * (bx * by + by * bz + bx * bz);
+        if (vol > kBrickBlock * kBrickPPT || halo > kBrickBlock * kBrickHPT || brick_lds(bx, by, bz) > (size_t)kMidMaxLds) continue;
+        const long work = vol + halo;
+        if (best < 0 || work < best) {
+          best = work;
+          P->bx = bx; P->by = by; P->bz = bz;
+          P->cx = cx; P->cy = cy; P->cz = cz;
+        }
+      }
+  if (best < 0) return false;
+  P->nx = nx; P->ny = ny; P->nz = nz;
+  P->nwg = P->cx * P->cy * P->cz;
+  P->lds = brick_lds(P->bx, P->by, P->bz);
+  return true;
+}
+
+}  // namespace
+
+bool brick_applicable(const psp_csr *A, int n) {
+  BrickPlan P;
+  return brick_plan(A, n, &P);
+}
+
+int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
+                   double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist) {
+  BrickPlan P;
+  if (!brick_plan(A, n, &P)) return kCoopFallback;
+  static_assert(3 * (size_t)kMidMaxWg <= kCtlPartDoubles, "state slab");
+  Workspace *ws;
+  PSP_TRY(workspace(&ws));
+  struct Mem {
+    double *hist = nullptr;
+    size_t nhist = 0;
+    ~Mem() { scratch_put(hist, nhist); }
+  } m;
+  MidCtl *ctl = static_cast<MidCtl *>(ws->state_dev);
+  PSP_HIP(hipMemsetAsync(ctl, 0, sizeof(MidCtl), stream()));
+  PSP_HIP(hipMemsetAsync(ws->ctl_part, 0, sizeof(double) * 3 * kMidMaxWg, stream()));
+  if (hist) {
+    m.nhist = (size_t)maxit + 2;
+    PSP_TRY(scratch_get(m.nhist, &m.hist));
+    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * m.nhist, stream()));
+  }
+  PSP_HIP(hipMemcpyAsync(q, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));  // r as it is, for a fall-back
+  BrickArgs a;
+  a.n = n;
+  a.nwg = P.nwg;
+  a.nx = P.nx; a.ny = P.ny; a.nz = P.nz;
+  a.bx = P.bx; a.by = P.by; a.bz = P.bz;
+  a.cx = P.cx; a.cy = P.cy;
+  a.valT = P.w4.valT;
+  a.mask = P.w4.mask;
+  a.dinv = dinv;
+  a.dc = 0.0;
+  a.pre = !dinv ? 0 : (dinv_constant(dinv, n, &a.dc) ? 2 : 1);
+  a.x = x;
+  a.xout = p;
+  a.r = r;
+  a.n2b = n2b;
+  a.tolb = tolb;
+  a.normr0 = normr0;
+  a.rho0 = rho0;
+  a.maxit = maxit;
+  a.ctl = ctl;
+  a.part = ws->ctl_part;
+  a.hist = m.hist;
+  void *args[] = {&a};
+  int rc = PSP_OK;
+  const char *ff = tuning_env("PSP_COOP_FAIL");
+  if (ff && atoi(ff) == 1) {
+    rc = kCoopFallback;
+  } else if (hipLaunchCooperativeKernel((const void *)pcg_brick_kernel, dim3(P.nwg), dim3(kBrickBlock), args, (unsigned)P.lds,
+                                        stream()) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = kCoopFallback;
+  }
+  MidCtl c;
+  if (rc == PSP_OK) {
+    PSP_HIP(hipMemcpyAsync(&c, ctl, sizeof(MidCtl), hipMemcpyDeviceToHost, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    if (c.error) rc = kCoopFallback;
+  }
+  if (rc == kCoopFallback) {
+    g_brick_fallbacks.fetch_add(1);
+    PSP_HIP(hipMemcpyAsync(r, q, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  }
+  if (rc != PSP_OK) return rc;
+  g_brick_solves.fetch_add(1);
+  PSP_HIP(hipMemcpyAsync(x, p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  *info = c.info;
+  *iter = c.iter;
+  *relres = c.relres;
+  if (hist) {
+    const int cnt = std::min(c.iter, maxit);
+    if (cnt >= 1) {
+      std::vector<double> h((size_t)cnt);
+      PSP_HIP(hipMemcpy(h.data(), m.hist + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; ++i)
+        if (h[i] == h[i]) hist[1 + i] = h[i];
+    }
+  }
+  return PSP_OK;
+}
+
 }  // namespace psp
 
 extern "C" int psp_debug_mid_count(long long *solves, long long *fallbacks) {
   if (solves) *solves = psp::g_mid_solves.load();
   if (fallbacks) *fallbacks = psp::g_mid_fallbacks.load();
+  return PSP_OK;
+}
+
+extern "C" int psp_debug_brick_count(long long *solves, long long *fallbacks) {
+  if (solves) *solves = psp::g_brick_solves.load();
+  if (fallbacks) *fallbacks = psp::g_brick_fallbacks.load();
   return PSP_OK;
 }

@@ -871,6 +871,11 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     const int rc = pcg_mid_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
     if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
   }
+  if (fused && maxit >= 1 && rho_next != 0.0 && brick_applicable(Acsr, n)) {
+    // 3-D grid operator whose slabs the loop above declines: the same loop with the points dealt out in bricks (psp_mid.hip)
+    const int rc = pcg_brick_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;
+  }
   if (fused && maxit >= 1 && coop_applicable(Acsr, n)) {  // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
     if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
