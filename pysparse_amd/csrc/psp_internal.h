@@ -557,6 +557,10 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
 bool brick_applicable(const psp_csr *A, int n);
 int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,
                    double tolb, double normr0, double rho0, int maxit, int *info, int *iter, double *relres, double *hist);
+bool brick_minres_applicable(const psp_csr *A, int n);
+int minres_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
+                      double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,
+                      int *info, int *iter, double *relres, double *hist);
 bool mid_minres_applicable(const psp_csr *A, int n);
 int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
                     double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,

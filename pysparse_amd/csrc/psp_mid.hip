@@ -1076,6 +1076,257 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
   }
 }
 
+// minres.c:96-193 in bricks (as minres_mid_kernel is to pcg_mid_kernel): what crosses workgroups is the unnormalised
+// Lanczos vector y = K v_hat of the bricks' surface points; every reader divides what it gathers by beta itself.
+// P holds v = y / beta of the brick and its halo; x, w, w_old of the own points live in LDS, v_hat, v_hat_old and y in
+// registers.
+struct BrickMinresArgs {
+  int n, nwg;
+  int nx, ny, nz, bx, by, bz, cx, cy;
+  const double *valT;
+  const unsigned short *mask;
+  const double *dinv;
+  double dc;
+  int pre;
+  const double *x;
+  double *xout;
+  const double *v_hat;
+  double *yv;  // in: K v_hat (v_hat itself without a preconditioner); the kernel publishes the surface points' rows here
+  double norm_r0, beta0, errtol;
+  int it_max;
+  MidCtl *ctl;
+  double *part;  // 2 x kMidMaxWg: v . Av | v_hat . y by workgroup
+  double *hist;
+};
+
+__global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresArgs a) {
+  extern __shared__ double lds[];
+  constexpr int NW = kBrickBlock / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wg = blockIdx.x, nwg = a.nwg;
+  const int bx = a.bx, by = a.by, bz = a.bz, nx = a.nx, ny = a.ny, nz = a.nz;
+  const int x0 = (wg % a.cx) * bx, y0 = ((wg / a.cx) % a.cy) * by, z0 = (wg / (a.cx * a.cy)) * bz;
+  const int ex = min(bx, nx - x0), ey = min(by, ny - y0), ez = min(bz, nz - z0);
+  const int sx = bx + 2, sxy = sx * (by + 2);
+  const int vol = bx * by * bz, npad = sxy * (bz + 2);
+  double *P = lds;
+  double *vol_ = P + ((npad + 1) & ~1);           // v_hat_old of the own points, by point number t + 512 m
+  double *wl = vol_ + kBrickBlock * kBrickPPT;    // w
+  double *wol = wl + kBrickBlock * kBrickPPT;     // w_old
+  double *red = wol + kBrickBlock * kBrickPPT;    // NW wave sums, then 4 for brick_reduce
+  // x of the own points stays in memory (xout: touched once per iteration, by the thread that owns the point); y = K v_hat
+  // is formed again from v_hat where it is needed (the same rounded product) -- with v_hat_old, y and x in registers too
+  // the kernel spilled 330 bytes per lane
+  const int pre = a.pre;
+  const double dc = a.dc;
+  const int loff[7] = {-sxy, -sx, -1, 0, 1, sx, sxy};
+  double v[kBrickPPT][7], vh[kBrickPPT];
+  unsigned long long mk = 0;
+  int li[kBrickPPT], row[kBrickPPT];
+  unsigned inmask = 0, surf = 0;
+#pragma unroll
+  for (int m = 0; m < kBrickPPT; ++m) {
+    const int l = t + kBrickBlock * m;
+    const int pa = l % bx, pb = (l / bx) % by, pc = l / (bx * by);
+    const bool in = l < vol && pa < ex && pb < ey && pc < ez;
+    li[m] = (pa + 1) + sx * (pb + 1) + sxy * (pc + 1);
+    row[m] = in ? (x0 + pa) + nx * ((y0 + pb) + ny * (z0 + pc)) : 0;
+    vh[m] = 0.0;
+#pragma unroll
+    for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+    if (in) {
+      inmask |= 1u << m;
+      if (pa == 0 || pa == ex - 1 || pb == 0 || pb == ey - 1 || pc == 0 || pc == ez - 1) surf |= 1u << m;
+      const int rw = row[m];
+      mk |= (unsigned long long)(a.mask[rw] & 0x7fu) << (7 * m);
+      const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
+#pragma unroll
+      for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+      a.xout[rw] = a.x[rw];
+      vh[m] = a.v_hat[rw];
+    }
+    vol_[l] = 0.0;
+    wl[l] = 0.0;
+    wol[l] = 0.0;
+  }
+  int hidx[kBrickHPT], hrow[kBrickHPT];
+  {
+    const int f0 = bx * by, f1 = bx * bz, f2 = by * bz;
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j) {
+      int h = t + kBrickBlock * j;
+      int pa = 0, pb = 0, pc = 0;
+      bool ok = true;
+      if (h < 2 * f0) {
+        pc = h < f0 ? -1 : ez;
+        h = h < f0 ? h : h - f0;
+        pa = h % bx;
+        pb = h / bx;
+        ok = pa < ex && pb < ey;
+      } else if (h < 2 * f0 + 2 * f1) {
+        h -= 2 * f0;
+        pb = h < f1 ? -1 : ey;
+        h = h < f1 ? h : h - f1;
+        pa = h % bx;
+        pc = h / bx;
+        ok = pa < ex && pc < ez;
+      } else if (h < 2 * f0 + 2 * f1 + 2 * f2) {
+        h -= 2 * f0 + 2 * f1;
+        pa = h < f2 ? -1 : ex;
+        h = h < f2 ? h : h - f2;
+        pb = h % by;
+        pc = h / by;
+        ok = pb < ey && pc < ez;
+      } else {
+        ok = false;
+      }
+      const int gx = x0 + pa, gy = y0 + pb, gz = z0 + pc;
+      ok = ok && gx >= 0 && gx < nx && gy >= 0 && gy < ny && gz >= 0 && gz < nz;
+      hidx[j] = ok ? (pa + 1) + sx * (pb + 1) + sxy * (pc + 1) : -1;
+      hrow[j] = ok ? gx + nx * (gy + ny * gz) : 0;
+    }
+  }
+  for (int i = t; i < npad; i += kBrickBlock) P[i] = 0.0;
+  double yh[kBrickHPT];  // y of the halo cells
+#pragma unroll
+  for (int j = 0; j < kBrickHPT; ++j) yh[j] = hidx[j] >= 0 ? a.yv[hrow[j]] : 0.0;
+  __syncthreads();
+  unsigned gen = 0;
+  double beta = a.beta0, beta_old = 1.0, c = 1.0, c_old = 1.0, sn = 0.0, s_old = 0.0, eta = a.beta0, norm_rmr = a.norm_r0;
+  int it = 1, info = 1;
+  double relres = 0.0;
+  for (;;) {
+    // ---- v = y / beta (minres.c:123-124): the own points and the halo cells
+#pragma unroll
+    for (int m = 0; m < kBrickPPT; ++m)
+      if ((inmask >> m) & 1u) {
+        double yy = vh[m];  // y = K v_hat (lanczos_kernel's expression)
+        if (pre == 1) yy = yy * a.dinv[row[m]];
+        if (pre == 2) yy = yy * dc;
+        P[li[m]] = yy / beta;
+      }
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j)
+      if (hidx[j] >= 0) P[hidx[j]] = yh[j] / beta;
+    __syncthreads();
+    // ---- Av = A v (:127-129), alpha = v . Av
+    double avr[kBrickPPT];
+    {
+      double dsum = 0.0;
+#pragma unroll
+      for (int m = 0; m < kBrickPPT; ++m) {
+        double acc = 0.0;
+        if ((inmask >> m) & 1u) {
+#pragma unroll
+          for (int o = 0; o < 7; ++o) {
+            const double tt = acc + v[m][o] * P[li[m] + loff[o]];
+            acc = ((mk >> (7 * m + o)) & 1ull) ? tt : acc;
+          }
+          dsum += P[li[m]] * acc;
+        }
+        avr[m] = acc;
+      }
+      dsum = psp_wave_sum(dsum);
+      if (lane == 0) red[wave] = dsum;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double s = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += red[w];
+      mcoh_store(a.part + wg, s);
+    }
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+    double s1[1];
+    brick_reduce<1>(s1, a.part, nwg, red + NW);
+    const double alpha = s1[0];
+    const double c1 = alpha / beta, c2 = beta / beta_old;  // :131
+    // ---- Lanczos update (:131-143), beta^2 = v_hat . y; the surface points' y published
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < kBrickPPT; ++m)
+        if ((inmask >> m) & 1u) {
+          const double nv = avr[m] - c1 * vh[m] - c2 * vol_[t + kBrickBlock * m];
+          vol_[t + kBrickBlock * m] = vh[m];
+          vh[m] = nv;
+          double yy = nv;
+          if (pre != 0) {
+            yy = nv * (pre == 1 ? a.dinv[row[m]] : dc);
+            acc += nv * yy;
+          } else {
+            acc += nv * nv;
+          }
+          if ((surf >> m) & 1u) mcoh_store(a.yv + row[m], yy);
+        }
+      acc = psp_wave_sum(acc);
+      if (lane == 0) red[wave] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double s = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += red[w];
+      mcoh_store(a.part + kMidMaxWg + wg, s);
+    }
+    if (!mid_barrier(a.ctl, nwg, gen)) return;
+#pragma unroll
+    for (int j = 0; j < kBrickHPT; ++j) yh[j] = hidx[j] >= 0 ? mcoh_load(a.yv + hrow[j]) : 0.0;  // the next iteration's halo
+    brick_reduce<1>(s1, a.part + kMidMaxWg, nwg, red + NW);
+    // ---- minres_scalar_beta: :143-164, :180, :192
+    const double beta_start = beta;
+    beta_old = beta;
+    const double b2 = s1[0];
+    if (b2 < 0.0) {  // :144-146
+      info = -3;
+      break;
+    }
+    beta = sqrt(b2);
+    const double c_oold = c_old, s_oold = s_old;
+    c_old = c;
+    s_old = sn;
+    const double r1_hat = c_old * alpha - c_oold * s_old * beta_old;
+    const double r1 = sqrt(r1_hat * r1_hat + beta * beta);
+    const double r2 = s_old * alpha + c_oold * c_old * beta_old;
+    const double r3 = s_oold * beta_old;
+    if (r1 == 0.0) {  // :160-162
+      info = -6;
+      break;
+    }
+    c = r1_hat / r1;
+    sn = beta / r1;
+    const double c_eta = c * eta;
+    eta = -sn * eta;
+    norm_rmr = norm_rmr * fabs(sn);
+    if (a.hist && wg == 0 && t == 0) a.hist[it] = norm_rmr;
+    (void)beta_start;
+    // ---- w / x update (:172-180); v of this iteration is still in P
+#pragma unroll
+    for (int m = 0; m < kBrickPPT; ++m)
+      if ((inmask >> m) & 1u) {
+        const int l = t + kBrickBlock * m;
+        const double vv = P[li[m]];
+        const double ww = wl[l], wov = wol[l];
+        const double nw = (vv - r3 * wov - r2 * ww) / r1;
+        wol[l] = ww;
+        wl[l] = nw;
+        a.xout[row[m]] = a.xout[row[m]] + c_eta * nw;
+      }
+    const bool conv = norm_rmr < a.errtol * a.norm_r0;
+    if (it >= a.it_max || conv) {
+      info = conv ? 0 : -1;
+      relres = norm_rmr / a.norm_r0;
+      break;
+    }
+    it += 1;
+  }
+  if (wg == 0 && t == 0) {
+    a.ctl->info = info;
+    a.ctl->iter = it;
+    a.ctl->relres = relres;
+  }
+}
+
 std::atomic<long long> g_mid_solves{0}, g_mid_fallbacks{0}, g_brick_solves{0}, g_brick_fallbacks{0};
 
 bool mid_enabled() {
@@ -1446,7 +1697,8 @@ size_t brick_lds(int bx, int by, int bz) {
 
 // the bricks for this operator, or false: not a 3-D grid operator, or no decomposition into <= capacity bricks of <= 4096
 // points whose surfaces fit
-bool brick_plan(const psp_csr *A, int n, BrickPlan *P) {
+bool brick_plan(const psp_csr *A, int n, BrickPlan *P, bool minres = false) {
+  const void *kernel = minres ? (const void *)minres_brick_kernel : (const void *)pcg_brick_kernel;
   if (!brick_enabled() || !mid_enabled() || !A || A->nrows != n || A->ncols != n || n < brick_min_rows() ||
       n > kMidMaxWg * kBrickBlock * kBrickPPT)
     return false;
@@ -1455,26 +1707,25 @@ bool brick_plan(const psp_csr *A, int n, BrickPlan *P) {
   const int nx = P->w4.grid3[0], ny = P->w4.grid3[1], nz = P->w4.grid3[2];
   if ((long)nx * ny * nz != n) return false;
   static std::mutex mu;
-  static std::map<int, int> cap;  // device -> workgroups the device holds at once
+  static std::map<std::pair<int, const void *>, int> cap;  // (device, kernel) -> workgroups the device holds at once
   int capacity;
   {
     std::lock_guard<std::mutex> lk(mu);
     if (const char *e = tuning_env("PSP_COOP_CAPACITY")) {
       capacity = atoi(e);
     } else {
-      auto it = cap.find(current_device());
+      const auto key = std::make_pair(current_device(), kernel);
+      auto it = cap.find(key);
       if (it == cap.end()) {
         int c = 0, per = 0;
         Workspace *w = nullptr;
-        if (hipFuncSetAttribute((const void *)pcg_brick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) ==
-                hipSuccess &&
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) == hipSuccess &&
             workspace(&w) == PSP_OK && w->num_cu > 0 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void *)pcg_brick_kernel, kBrickBlock, kMidMaxLds) ==
-                hipSuccess)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, kBrickBlock, kMidMaxLds) == hipSuccess)
           c = per * w->num_cu;
         else
           (void)hipGetLastError();
-        it = cap.emplace(current_device(), c).first;
+        it = cap.emplace(key, c).first;
       }
       capacity = it->second;
     }
@@ -1509,6 +1760,103 @@ bool brick_plan(const psp_csr *A, int n, BrickPlan *P) {
 bool brick_applicable(const psp_csr *A, int n) {
   BrickPlan P;
   return brick_plan(A, n, &P);
+}
+
+bool brick_minres_applicable(const psp_csr *A, int n) {
+  BrickPlan P;
+  return brick_plan(A, n, &P, true);
+}
+
+// as minres_mid_loop: on kCoopFallback x, v_hat and y are what they were on entry
+int minres_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *v_hat, double *v_hat_old, double *y,
+                      double *w, double *w_old, double *v, double *av, double norm_r0, double beta0, double errtol, int it_max,
+                      int *info, int *iter, double *relres, double *hist) {
+  BrickPlan P;
+  if (!brick_plan(A, n, &P, true)) return kCoopFallback;
+  (void)v_hat_old;
+  (void)w_old;
+  Workspace *ws;
+  PSP_TRY(workspace(&ws));
+  struct Mem {
+    double *hist = nullptr;
+    size_t nhist = 0;
+    ~Mem() { scratch_put(hist, nhist); }
+  } m;
+  MidCtl *ctl = static_cast<MidCtl *>(ws->state_dev);
+  PSP_HIP(hipMemsetAsync(ctl, 0, sizeof(MidCtl), stream()));
+  PSP_HIP(hipMemsetAsync(ws->ctl_part, 0, sizeof(double) * 2 * kMidMaxWg, stream()));
+  if (hist) {
+    m.nhist = (size_t)it_max + 2;
+    PSP_TRY(scratch_get(m.nhist, &m.hist));
+    PSP_HIP(hipMemsetAsync(m.hist, 0xff, sizeof(double) * m.nhist, stream()));
+  }
+  double *yv = y;
+  if (!dinv) {
+    yv = v;
+    PSP_HIP(hipMemcpyAsync(yv, v_hat, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  } else {
+    PSP_HIP(hipMemcpyAsync(av, y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  }
+  BrickMinresArgs a;
+  a.n = n;
+  a.nwg = P.nwg;
+  a.nx = P.nx; a.ny = P.ny; a.nz = P.nz;
+  a.bx = P.bx; a.by = P.by; a.bz = P.bz;
+  a.cx = P.cx; a.cy = P.cy;
+  a.valT = P.w4.valT;
+  a.mask = P.w4.mask;
+  a.dinv = dinv;
+  a.dc = 0.0;
+  a.pre = !dinv ? 0 : (dinv_constant(dinv, n, &a.dc) ? 2 : 1);
+  a.x = x;
+  a.xout = w;
+  a.v_hat = v_hat;
+  a.yv = yv;
+  a.norm_r0 = norm_r0;
+  a.beta0 = beta0;
+  a.errtol = errtol;
+  a.it_max = it_max;
+  a.ctl = ctl;
+  a.part = ws->ctl_part;
+  a.hist = m.hist;
+  void *args[] = {&a};
+  int rc = PSP_OK;
+  const char *ff = tuning_env("PSP_COOP_FAIL");
+  if (ff && atoi(ff) == 1) {
+    rc = kCoopFallback;
+  } else if (hipLaunchCooperativeKernel((const void *)minres_brick_kernel, dim3(P.nwg), dim3(kBrickBlock), args,
+                                        (unsigned)P.lds, stream()) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = kCoopFallback;
+  }
+  MidCtl c;
+  if (rc == PSP_OK) {
+    PSP_HIP(hipMemcpyAsync(&c, ctl, sizeof(MidCtl), hipMemcpyDeviceToHost, stream()));
+    PSP_HIP(hipStreamSynchronize(stream()));
+    if (c.error) rc = kCoopFallback;
+  }
+  if (rc == kCoopFallback) {
+    g_brick_fallbacks.fetch_add(1);
+    if (dinv) PSP_HIP(hipMemcpyAsync(y, av, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+    PSP_HIP(hipMemsetAsync(w, 0, sizeof(double) * (size_t)n, stream()));
+  }
+  if (rc != PSP_OK) return rc;
+  g_brick_solves.fetch_add(1);
+  PSP_HIP(hipMemcpyAsync(x, w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream()));
+  PSP_HIP(hipStreamSynchronize(stream()));
+  *info = c.info;
+  *iter = c.iter;
+  if (c.info == 0 || c.info == -1) *relres = c.relres;
+  if (hist) {
+    const int cnt = std::min(c.iter, it_max);
+    if (cnt >= 1) {
+      std::vector<double> h((size_t)cnt);
+      PSP_HIP(hipMemcpy(h.data(), m.hist + 1, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; ++i)
+        if (h[i] == h[i]) hist[1 + i] = h[i];
+    }
+  }
+  return PSP_OK;
 }
 
 int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, double *r, double *p, double *q, double n2b,

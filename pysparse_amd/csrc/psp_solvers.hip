@@ -1354,6 +1354,12 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
                                    beta, errtol, it_max, info, iter, relres, hist);
     if (rc != kCoopFallback) return rc;
   }
+  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && brick_minres_applicable(Acsr, n)) {
+    // 3-D grid operator: the same with the points dealt out in bricks
+    const int rc = minres_brick_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
+                                     beta, errtol, it_max, info, iter, relres, hist);
+    if (rc != kCoopFallback) return rc;
+  }
   if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n)) {
     // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,

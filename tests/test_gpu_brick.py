@@ -1,5 +1,5 @@
-"""GPU: the single-kernel PCG loop for 3-D grid operators, the points dealt out in bricks (pysparse_amd/csrc/psp_mid.hip,
-pcg_brick_kernel; pcg.c:91-166).  A contiguous block of rows of a 3-D grid has a whole grid plane as its halo, so the
+"""GPU: the single-kernel PCG and MINRES loops for 3-D grid operators, the points dealt out in bricks
+(pysparse_amd/csrc/psp_mid.hip, pcg_brick_kernel / minres_brick_kernel; pcg.c:91-166, minres.c:96-193).  A contiguous block of rows of a 3-D grid has a whole grid plane as its halo, so the
 row-block kernels decline such operators; here a workgroup owns a brick of <= 4096 grid points and exchanges its surface.
 
 Its reductions add in another order than the launch-per-phase loops' (the rows of a span lie in several bricks), so -- as for
@@ -48,7 +48,7 @@ def _varying(oracle, grid, seed):
 
 
 CASES = [("poisson", (64, 64, 64)), ("poisson", (80, 80, 80)), ("poisson", (50, 60, 70)), ("poisson", (47, 101, 33)),
-         ("varying", (48, 48, 48)), ("varying", (70, 64, 55))]
+         ("varying", (56, 56, 56)), ("varying", (70, 64, 55))]
 
 
 @pytest.mark.parametrize("kind,grid", CASES)
@@ -66,20 +66,21 @@ def test_brick_loop_matches_the_oracle(oracle, kind, grid):
     runs = 0
     for K, dg in ((None, None), (dev.DeviceJacobi(D), dinv)):
         for tol, maxit in ((1e-10, 3000), (0.0, 9), (0.0, 1)):
-            xo, xg = np.full(n, 0.5), np.full(n, 0.5)
-            ro = oracle.pcg(O, b, xo, tol, maxit, dg, hist=True)
-            rg = dev.pcg(D, b, xg, tol, maxit, K, hist=True)
-            runs += 1
-            assert rg[:2] == ro[:2], (tol, rg[:3], ro[:3])
-            assert abs(rg[2] - ro[2]) <= 1e-6 * ro[2]
-            assert relerr(xg, xo) < 1e-12
-            m = np.isfinite(ro[3])
-            assert np.array_equal(m, np.isfinite(rg[3]))
-            assert np.allclose(rg[3][m], ro[3][m], rtol=1e-5, atol=0)
-            xg2 = np.full(n, 0.5)
-            rg2 = dev.pcg(D, b, xg2, tol, maxit, K, hist=True)
-            runs += 1
-            assert rg2[:3] == rg[:3] and np.array_equal(xg, xg2)  # fixed reduction order: the same bits every run
+            for solver, osolver in ((dev.pcg, oracle.pcg), (dev.minres, oracle.minres)):
+                xo, xg = np.full(n, 0.5), np.full(n, 0.5)
+                ro = osolver(O, b, xo, tol, maxit, dg, hist=True)
+                rg = solver(D, b, xg, tol, maxit, K, hist=True)
+                runs += 1
+                assert rg[:2] == ro[:2], (solver.__name__, tol, rg[:3], ro[:3])
+                assert abs(rg[2] - ro[2]) <= 1e-6 * ro[2]
+                assert relerr(xg, xo) < 1e-12
+                m = np.isfinite(ro[3])
+                assert np.array_equal(m, np.isfinite(rg[3]))
+                assert np.allclose(rg[3][m], ro[3][m], rtol=1e-5, atol=0)
+                xg2 = np.full(n, 0.5)
+                rg2 = solver(D, b, xg2, tol, maxit, K, hist=True)
+                runs += 1
+                assert rg2[:3] == rg[:3] and np.array_equal(xg, xg2)  # fixed reduction order: the same bits every run
     s1 = _counts(L)
     assert s1[0] - s0[0] == runs and s1[1] == s0[1]  # every solve ran as one kernel, none was handed back
 
@@ -92,11 +93,12 @@ def test_sss_form_and_the_launch_per_phase_loops(oracle):
         "from pysparse_amd import device as dev, _capi\n"
         "L = _capi.lib(); out = []\n"
         "for form in ('csr', 'sss'):\n"
-        "    A = (dev.DeviceCSR if form == 'csr' else dev.DeviceSSS).poisson(48, 52, 60); n = A.shape[0]\n"
+        "    A = (dev.DeviceCSR if form == 'csr' else dev.DeviceSSS).poisson(50, 54, 60); n = A.shape[0]\n"
         "    b = np.random.default_rng(5).standard_normal(n)\n"
         "    for K in (None, dev.DeviceJacobi(A)):\n"
         "        for tol, mx in ((1e-9, 4000), (0.0, 11)):\n"
-        "            x = np.zeros(n); r = dev.pcg(A, b, x, tol, mx, K)\n"
+        "          for s in (dev.pcg, dev.minres):\n"
+        "            x = np.zeros(n); r = s(A, b, x, tol, mx, K)\n"
         "            out.append([r[0], r[1], r[2], float(np.abs(x).max()), x[::max(1, n // 97)].tolist()])\n"
         "s, f = C.c_longlong(), C.c_longlong(); L.psp_debug_brick_count(C.byref(s), C.byref(f)); out.append([s.value, f.value])\n"
         "print(json.dumps(out))"
@@ -109,7 +111,7 @@ def test_sss_form_and_the_launch_per_phase_loops(oracle):
         p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
         res.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert res[0][-1] == [8, 0] and res[1][-1] == [0, 0] and res[2][-1] == [0, 8]
+    assert res[0][-1] == [16, 0] and res[1][-1] == [0, 0] and res[2][-1] == [0, 16]
     for a, b in zip(res[0][:-1], res[1][:-1]):
         assert a[:2] == b[:2], (a[:3], b[:3])
         assert abs(a[2] - b[2]) <= 1e-6 * b[2]

@@ -2,7 +2,7 @@
 """The brick form of the single-kernel PCG loop (3-D grid operators; psp_mid.hip) against what runs without it -- psp_coop.hip's
 one-row-per-thread loop up to 2^18 rows, the launch-per-phase loops beyond -- in ONE process on the same operator and vectors
 (PSP_BRICK_MIN is read per solve): microseconds per iteration from two truncated solves.  Start with PSP_TUNING=1.
-Usage: brick_ab.py [nx,ny,nz ...]"""
+Usage: brick_ab.py [pcg|minres] [nx,ny,nz ...]"""
 import ctypes as C
 import json
 import os
@@ -17,7 +17,10 @@ from pysparse_amd import _capi, device as dev  # noqa: E402
 
 L = _capi.lib()
 check = _capi.check
-for g in sys.argv[1:] or ["32,32,32", "48,48,48", "64,64,64", "80,80,80", "96,96,96", "100,100,100", "128,64,64"]:
+argv = sys.argv[1:]
+solver = argv.pop(0) if argv and argv[0] in ("pcg", "minres") else "pcg"
+fn = L.psp_pcg_dev if solver == "pcg" else L.psp_minres_dev
+for g in argv or ["32,32,32", "48,48,48", "64,64,64", "80,80,80", "96,96,96", "100,100,100", "128,64,64"]:
     grid = tuple(int(t) for t in g.split(","))
     A = dev.DeviceCSR.poisson(*grid)
     n = A.shape[0]
@@ -39,15 +42,15 @@ for g in sys.argv[1:] or ["32,32,32", "48,48,48", "64,64,64", "80,80,80", "96,96
                 info, it, rr = C.c_int(), C.c_int(), C.c_double()
                 check(L.psp_synchronize())
                 t = time.perf_counter()
-                check(L.psp_pcg_dev(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
+                check(fn(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
                 check(L.psp_synchronize())
                 ts[kk] = time.perf_counter() - t
-                assert it.value == kk + 1, (it.value, info.value)
+                assert it.value == (kk + 1 if solver == "pcg" else kk), (it.value, info.value)
             rec[mode].append((ts[k2] - ts[k1]) / (k2 - k1) * 1e6)
             res[mode] = (rr.value, float(np.abs(xb.download()).max()))
     s, f = C.c_longlong(), C.c_longlong()
     L.psp_debug_brick_count(C.byref(s), C.byref(f))
-    print("x".join(str(v) for v in grid), json.dumps({
+    print("x".join(str(v) for v in grid), solver, json.dumps({
         "n": n, "us_per_iter_bricks": min(rec["brick"]), "us_per_iter_without": min(rec["other"]),
         "speedup": min(rec["other"]) / min(rec["brick"]), "relres_rel_diff": abs(res["brick"][0] - res["other"][0]) / res["other"][0],
         "brick_solves_so_far": s.value, "fallbacks": f.value}), flush=True)
