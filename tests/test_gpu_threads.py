@@ -35,13 +35,19 @@ def test_two_threads_two_handles_same_bits_different_streams_and_overlap(oracle)
     from pysparse_amd._capi import lib
     L = lib()
     # launch-latency-bound sizes (the GPU is far from full: side by side must beat one after the other), outside the
-    # single-kernel loops' range (3-D grids whose halo of one plane does not fit the LDS: psp_mid.hip refuses them) so
-    # that every iteration is a handful of launches on the thread's stream
-    grids = [(72, 72, 100), (80, 80, 80)]
+    # single-kernel loops' range so that every iteration is a handful of launches on the thread's stream
+    # (7-offset BANDED matrices: entries at +-1 / +-s1 also across what would be the ends of grid lines, so they are no grid
+    # operators -- the brick kernels decline them as the row-block kernels decline their wide halo)
+    import scipy.sparse as sp
     ops = []
-    for g in grids:
-        A = dev.DeviceCSR.poisson(*g)
-        n = A.shape[0]
+    for n, s1, s2 in ((518400, 72, 5184), (512000, 80, 6400)):
+        g = np.random.default_rng(n)
+        es = [-(0.1 + g.random(n - o)) for o in (s2, s1, 1)]
+        S = sp.diags([es[0], es[1], es[2], es[2], es[1], es[0]], [-s2, -s1, -1, 1, s1, s2], shape=(n, n), format="csr")
+        S = (S + sp.diags(-np.asarray(S.sum(axis=1)).ravel() + 1e-5)).tocsr()
+        S.sort_indices()
+        A = dev.DeviceCSR.from_arrays(S.shape, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+        assert A.kernel_info()[0] == "csr_spmv_w4"
         b = np.random.default_rng(7).standard_normal(n)
         ops.append((A, dev.DeviceJacobi(A), b))
     reps, maxit = 3, 600
@@ -75,7 +81,7 @@ def test_two_threads_two_handles_same_bits_different_streams_and_overlap(oracle)
     for k in range(2):
         for (ra, xa), (rt, xt) in zip(alone[k], res[k]):
             assert ra == rt and np.array_equal(xa, xt)  # the same bits as alone
-            assert ra[:2] in ((-1, maxit + 1), (-1, maxit))
+            assert ra[1] >= 200  # (long enough runs: the nearly singular shift below keeps PCG from converging early)
     # overlap: side by side clearly faster than one after the other (both are latency-bound: ideally the longer of the two)
     assert t_threads < 0.85 * t_serial, (t_threads, t_serial)
 
