@@ -31,6 +31,7 @@
 #include <map>
 #include <new>
 #include <thread>
+#include <cmath>
 #include <vector>
 
 #include "psp_internal.h"
@@ -2523,6 +2524,9 @@ struct CsrExtra {
   // at offset +-1 / +-nx only between cells that are neighbours on the grid)?  -1 not examined, 0 no, 1 yes
   int grid_state = -1;
   int grid_nx = 0, grid_ny = 0;
+  // csr_w4_view: does every offset carry ONE value (constant-coefficient stencils)?  -1 not examined, 0 no, 1 yes
+  int constv_state = -1;
+  double constv[16] = {0};
 };
 
 }  // namespace psp
@@ -3706,6 +3710,53 @@ __global__ __launch_bounds__(256) void grid_wrap_check_kernel(int n, int nx, int
   if (found) atomicAdd(bad, 1);
 }
 
+// per offset the smallest and the largest stored value (rows whose mask has the offset's bit), one pair per workgroup:
+// out[(block * no + o) * 2 + {0, 1}]; +inf / -inf where a workgroup saw no entry at the offset
+__global__ __launch_bounds__(256) void w4_value_range_kernel(int n, int no, const double *__restrict__ valT,
+                                                             const unsigned short *__restrict__ mask, double *__restrict__ out) {
+  __shared__ double smin[4][16], smax[4][16];
+  double lo[16], hi[16];
+  for (int o = 0; o < 16; ++o) {
+    lo[o] = INFINITY;
+    hi[o] = -INFINITY;
+  }
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+    const unsigned m = mask[r];
+    const double *vp = valT + (size_t)(r / kDiaRows) * no * kDiaRows + (size_t)(r % kDiaRows);
+    for (int o = 0; o < no; ++o)
+      if ((m >> o) & 1u) {
+        const double v = vp[(size_t)o * kDiaRows];
+        lo[o] = v < lo[o] ? v : lo[o];
+        hi[o] = v > hi[o] ? v : hi[o];
+        if (!(v == v)) hi[o] = INFINITY, lo[o] = -INFINITY;  // a NaN entry: never "constant"
+      }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int o = 0; o < no; ++o) {
+    double a = lo[o], b = hi[o];
+    for (int off = 32; off > 0; off >>= 1) {
+      const double a2 = __shfl_down(a, off, 64), b2 = __shfl_down(b, off, 64);
+      a = a2 < a ? a2 : a;
+      b = b2 > b ? b2 : b;
+    }
+    if (lane == 0) {
+      smin[wid][o] = a;
+      smax[wid][o] = b;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < no) {
+    const int o = threadIdx.x;
+    double a = smin[0][o], b = smax[0][o];
+    for (int w = 1; w < 4; ++w) {
+      a = smin[w][o] < a ? smin[w][o] : a;
+      b = smax[w][o] > b ? smax[w][o] : b;
+    }
+    out[((size_t)blockIdx.x * no + o) * 2] = a;
+    out[((size_t)blockIdx.x * no + o) * 2 + 1] = b;
+  }
+}
+
 // What the single-kernel loops for mid-size systems (psp_mid.hip) need to know about an operator's index-free layout:
 // the offsets, the value / mask tables, and the grid and XCD stripe the launch-per-phase product would use (its dot
 // partials are indexed by workgroup, and the mid-size loops add theirs in exactly that order).  *available = 0 when the
@@ -3759,6 +3810,39 @@ int csr_w4_view(const psp_csr *A, W4View *out, int *available) {
       out->grid3[0] = ex->grid_nx;
       out->grid3[1] = ex->grid_ny;
       out->grid3[2] = A->nrows / (ex->grid_nx * ex->grid_ny);
+    }
+  }
+  // constant coefficients?  (one value per offset: the kernels of psp_mid.hip then keep 7 scalars instead of 7 registers
+  // per grid point)  One pass over the table, once per handle.
+  out->constv = 0;
+  if (ex->dia_no <= 12) {
+    if (ex->constv_state < 0) {
+      ex->constv_state = 0;
+      const int no = ex->dia_no, blocks = std::min((A->nrows + 255) / 256, 512);
+      double *d = nullptr;
+      PSP_HIP(hipMalloc((void **)&d, sizeof(double) * 2 * no * blocks));
+      hipLaunchKernelGGL(w4_value_range_kernel, dim3(blocks), dim3(256), 0, stream(), A->nrows, no, ex->dia_val, ex->dia_mask, d);
+      std::vector<double> h((size_t)2 * no * blocks);
+      const hipError_t e1 = hipMemcpyAsync(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream());
+      const hipError_t e2 = hipStreamSynchronize(stream());
+      (void)hipFree(d);
+      if (e1 != hipSuccess || e2 != hipSuccess) return fail(PSP_ENODEV, "csr_w4_view: value range pass failed");
+      bool all = true;
+      for (int o = 0; o < no && all; ++o) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int b = 0; b < blocks; ++b) {
+          lo = std::min(lo, h[((size_t)b * no + o) * 2]);
+          hi = std::max(hi, h[((size_t)b * no + o) * 2 + 1]);
+        }
+        // (bitwise: +0.0 and -0.0 compare equal but multiply differently)
+        if (!(lo == hi) || std::signbit(lo) != std::signbit(hi)) all = false;
+        ex->constv[o] = lo;
+      }
+      if (all) ex->constv_state = 1;
+    }
+    if (ex->constv_state == 1) {
+      out->constv = 1;
+      for (int o = 0; o < 12; ++o) out->cval[o] = o < ex->dia_no ? ex->constv[o] : 0.0;
     }
   }
   *available = 1;

@@ -542,6 +542,8 @@ struct W4View {
   int no;       // offsets (<= 8)
   int offs[12];  // col - row, ascending (the first `no`)
   int grid3[3];  // nx, ny, nz when the operator is a 7-offset one of a 3-D grid without couplings across line ends, else 0
+  int constv;    // 1: every stored entry at offset o has the value cval[o] (constant-coefficient stencil)
+  double cval[12];
   const double *valT;          // blocks of 128 rows, offset-major inside a block
   const unsigned short *mask;  // bit o of mask[r]: row r stores an entry at offset o
   int stripe, grid;            // XCD stripe and grid of the launch-per-phase product (order of its dot partials)

@@ -793,6 +793,7 @@ struct BrickArgs {
   int nx, ny, nz;  // the grid
   int bx, by, bz;  // points of a brick along each axis
   int cx, cy;      // bricks along x and y (workgroup w owns brick (w % cx, (w / cx) % cy, w / (cx cy)))
+  double cval[7];  // CV kernels: the one value of every offset
   const double *valT;
   const unsigned short *mask;
   const double *dinv;
@@ -828,6 +829,8 @@ __device__ __forceinline__ void brick_reduce(double (&out)[NV], const double *pa
   __syncthreads();
 }
 
+// CV: constant coefficients -- seven scalars instead of seven registers per grid point (56 of 256): no scratch memory
+template <bool CV>
 __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
   extern __shared__ double lds[];
   constexpr int NW = kBrickBlock / 64;
@@ -847,7 +850,10 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
   const double dc = a.dc;
   const int loff[7] = {-sxy, -sx, -1, 0, 1, sx, sxy};
   // ---- the thread's points
-  double v[kBrickPPT][7];
+  double v[CV ? 1 : kBrickPPT][7];
+  double cv[7];
+#pragma unroll
+  for (int o = 0; o < 7; ++o) cv[o] = a.cval[o];
   unsigned long long mk = 0;  // 7 mask bits per point
   int li[kBrickPPT], row[kBrickPPT];
   unsigned inmask = 0, surf = 0;
@@ -859,16 +865,20 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
     li[m] = (pa + 1) + sx * (pb + 1) + sxy * (pc + 1);
     row[m] = in ? (x0 + pa) + nx * ((y0 + pb) + ny * (z0 + pc)) : 0;
     double xv = 0.0, rv = 0.0;
+    if constexpr (!CV) {
 #pragma unroll
-    for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+      for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+    }
     if (in) {
       inmask |= 1u << m;
       if (pa == 0 || pa == ex - 1 || pb == 0 || pb == ey - 1 || pc == 0 || pc == ez - 1) surf |= 1u << m;
       const int rw = row[m];
       mk |= (unsigned long long)(a.mask[rw] & 0x7fu) << (7 * m);
-      const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
+      if constexpr (!CV) {
+        const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
 #pragma unroll
-      for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+        for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+      }
       xv = a.x[rw];
       rv = a.r[rw];
     }
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
         if ((inmask >> m) & 1u) {
 #pragma unroll
           for (int o = 0; o < 7; ++o) {
-            const double tt = acc + v[m][o] * P[li[m] + loff[o]];
+            const double tt = acc + (CV ? cv[o] : v[CV ? 0 : m][o]) * P[li[m] + loff[o]];
             acc = ((mk >> (7 * m + o)) & 1ull) ? tt : acc;
           }
           dsum += P[li[m]] * acc;
@@ -1083,6 +1093,7 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
 struct BrickMinresArgs {
   int n, nwg;
   int nx, ny, nz, bx, by, bz, cx, cy;
+  double cval[7];  // CV kernels: the one value of every offset
   const double *valT;
   const unsigned short *mask;
   const double *dinv;
@@ -1099,6 +1110,7 @@ struct BrickMinresArgs {
   double *hist;
 };
 
+template <bool CV>
 __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresArgs a) {
   extern __shared__ double lds[];
   constexpr int NW = kBrickBlock / 64;
@@ -1120,7 +1132,10 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
   const int pre = a.pre;
   const double dc = a.dc;
   const int loff[7] = {-sxy, -sx, -1, 0, 1, sx, sxy};
-  double v[kBrickPPT][7], vh[kBrickPPT];
+  double v[CV ? 1 : kBrickPPT][7], vh[kBrickPPT];
+  double cv[7];
+#pragma unroll
+  for (int o = 0; o < 7; ++o) cv[o] = a.cval[o];
   unsigned long long mk = 0;
   int li[kBrickPPT], row[kBrickPPT];
   unsigned inmask = 0, surf = 0;
@@ -1132,16 +1147,20 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
     li[m] = (pa + 1) + sx * (pb + 1) + sxy * (pc + 1);
     row[m] = in ? (x0 + pa) + nx * ((y0 + pb) + ny * (z0 + pc)) : 0;
     vh[m] = 0.0;
+    if constexpr (!CV) {
 #pragma unroll
-    for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+      for (int o = 0; o < 7; ++o) v[m][o] = 0.0;
+    }
     if (in) {
       inmask |= 1u << m;
       if (pa == 0 || pa == ex - 1 || pb == 0 || pb == ey - 1 || pc == 0 || pc == ez - 1) surf |= 1u << m;
       const int rw = row[m];
       mk |= (unsigned long long)(a.mask[rw] & 0x7fu) << (7 * m);
-      const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
+      if constexpr (!CV) {
+        const double *vp = a.valT + (size_t)(rw / 128) * 7 * 128 + (size_t)(rw % 128);
 #pragma unroll
-      for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+        for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
+      }
       a.xout[rw] = a.x[rw];
       vh[m] = a.v_hat[rw];
     }
@@ -1219,7 +1238,7 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
         if ((inmask >> m) & 1u) {
 #pragma unroll
           for (int o = 0; o < 7; ++o) {
-            const double tt = acc + v[m][o] * P[li[m] + loff[o]];
+            const double tt = acc + (CV ? cv[o] : v[CV ? 0 : m][o]) * P[li[m] + loff[o]];
             acc = ((mk >> (7 * m + o)) & 1ull) ? tt : acc;
           }
           dsum += P[li[m]] * acc;
@@ -1672,6 +1691,7 @@ struct BrickPlan {
   W4View w4;
   int nx, ny, nz, bx, by, bz, cx, cy, cz, nwg;
   size_t lds;
+  const void *kernel;
 };
 
 bool brick_enabled() {
@@ -1698,7 +1718,7 @@ size_t brick_lds(int bx, int by, int bz) {
 // the bricks for this operator, or false: not a 3-D grid operator, or no decomposition into <= capacity bricks of <= 4096
 // points whose surfaces fit
 bool brick_plan(const psp_csr *A, int n, BrickPlan *P, bool minres = false) {
-  const void *kernel = minres ? (const void *)minres_brick_kernel : (const void *)pcg_brick_kernel;
+  const void *kernel = nullptr;  // (set below, once the view says whether the coefficients are constant)
   if (!brick_enabled() || !mid_enabled() || !A || A->nrows != n || A->ncols != n || n < brick_min_rows() ||
       n > kMidMaxWg * kBrickBlock * kBrickPPT)
     return false;
@@ -1706,6 +1726,8 @@ bool brick_plan(const psp_csr *A, int n, BrickPlan *P, bool minres = false) {
   if (csr_w4_view(A, &P->w4, &av) != PSP_OK || !av || P->w4.no != 7 || P->w4.grid3[0] == 0) return false;
   const int nx = P->w4.grid3[0], ny = P->w4.grid3[1], nz = P->w4.grid3[2];
   if ((long)nx * ny * nz != n) return false;
+  P->kernel = kernel = minres ? (P->w4.constv ? (const void *)minres_brick_kernel<true> : (const void *)minres_brick_kernel<false>)
+                              : (P->w4.constv ? (const void *)pcg_brick_kernel<true> : (const void *)pcg_brick_kernel<false>);
   static std::mutex mu;
   static std::map<std::pair<int, const void *>, int> cap;  // (device, kernel) -> workgroups the device holds at once
   int capacity;
@@ -1803,6 +1825,7 @@ int minres_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, do
   a.nx = P.nx; a.ny = P.ny; a.nz = P.nz;
   a.bx = P.bx; a.by = P.by; a.bz = P.bz;
   a.cx = P.cx; a.cy = P.cy;
+  for (int o = 0; o < 7; ++o) a.cval[o] = P.w4.cval[o];
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;
@@ -1824,7 +1847,7 @@ int minres_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, do
   const char *ff = tuning_env("PSP_COOP_FAIL");
   if (ff && atoi(ff) == 1) {
     rc = kCoopFallback;
-  } else if (hipLaunchCooperativeKernel((const void *)minres_brick_kernel, dim3(P.nwg), dim3(kBrickBlock), args,
+  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(kBrickBlock), args,
                                         (unsigned)P.lds, stream()) != hipSuccess) {
     (void)hipGetLastError();
     rc = kCoopFallback;
@@ -1886,6 +1909,7 @@ int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, doubl
   a.nx = P.nx; a.ny = P.ny; a.nz = P.nz;
   a.bx = P.bx; a.by = P.by; a.bz = P.bz;
   a.cx = P.cx; a.cy = P.cy;
+  for (int o = 0; o < 7; ++o) a.cval[o] = P.w4.cval[o];
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;
@@ -1907,7 +1931,7 @@ int pcg_brick_loop(const psp_csr *A, const double *dinv, int n, double *x, doubl
   const char *ff = tuning_env("PSP_COOP_FAIL");
   if (ff && atoi(ff) == 1) {
     rc = kCoopFallback;
-  } else if (hipLaunchCooperativeKernel((const void *)pcg_brick_kernel, dim3(P.nwg), dim3(kBrickBlock), args, (unsigned)P.lds,
+  } else if (hipLaunchCooperativeKernel(P.kernel, dim3(P.nwg), dim3(kBrickBlock), args, (unsigned)P.lds,
                                         stream()) != hipSuccess) {
     (void)hipGetLastError();
     rc = kCoopFallback;
