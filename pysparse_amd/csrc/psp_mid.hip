@@ -63,6 +63,7 @@ struct MidCtl {
 struct MidArgs {
   int n, nwg, H;  // H: halo entries on either side of a block (even, >= the largest |offset|)
   int offs[12];
+  double cval[12];  // CV kernels: the one value of every offset (constant-coefficient operators)
   const double *valT;
   const unsigned short *mask;
   const double *dinv;  // pre == 1
@@ -240,7 +241,8 @@ __device__ __forceinline__ bool mid_barrier_reduce(MidCtl *c, int nwg, unsigned 
 }
 
 // pcg.c:91-166 from the head of iteration 1 (r = b - A x, rho = r.z, ||r|| > tolb are the caller's)
-template <int NO, int LAYERS, int BLK>
+// CV: constant coefficients (one value per offset) -- NO scalars instead of NO registers per row
+template <int NO, int LAYERS, int BLK, bool CV = false>
 __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
   extern __shared__ double lds[];
   constexpr int kMidLayer = 2 * BLK;  // rows one layer of a workgroup covers: a pair of rows per thread
@@ -267,7 +269,10 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
   const double dc = a.dc;
   // ---- the thread's rows: everything that does not change stays in registers for the whole solve
   typedef double d2 __attribute__((ext_vector_type(2)));
-  d2 v[LAYERS][NO];
+  d2 v[CV ? 1 : LAYERS][NO];
+  double cv[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) cv[o] = a.cval[o];
   unsigned m0[LAYERS], m1[LAYERS];
   double xr[LAYERS][2], rr[LAYERS][2], pr[LAYERS][2], qr[LAYERS][2];
   bool in0[LAYERS], in1[LAYERS];
@@ -278,7 +283,8 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
     in1[L] = row + 1 < n;
     m0[L] = m1[L] = 0;
 #pragma unroll
-    for (int o = 0; o < NO; ++o) v[L][o] = d2{0.0, 0.0};
+    for (int o = 0; o < NO; ++o)
+      if constexpr (!CV) v[L][o] = d2{0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) xr[L][u] = rr[L][u] = pr[L][u] = qr[L][u] = 0.0;
     if (in0[L]) {
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
       m1[L] = mm >> 16;
       const double *vp = a.valT + (size_t)(row / 128) * NO * 128 + (size_t)(row % 128);
 #pragma unroll
-      for (int o = 0; o < NO; ++o) v[L][o] = *reinterpret_cast<const d2 *>(vp + o * 128);
+      for (int o = 0; o < NO; ++o)
+        if constexpr (!CV) v[L][o] = *reinterpret_cast<const d2 *>(vp + o * 128);
       xr[L][0] = a.x[row];
       rr[L][0] = a.r[row];
       if (in1[L]) {
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         const double p0 = win[c0 + a.offs[o]], p1 = win[c0 + a.offs[o] + 1];
-        const double t0 = a0 + v[L][o].x * p0;
-        const double t1 = a1 + v[L][o].y * p1;
+        const double t0 = a0 + (CV ? cv[o] : v[CV ? 0 : L][o].x) * p0;
+        const double t1 = a1 + (CV ? cv[o] : v[CV ? 0 : L][o].y) * p1;
         a0 = ((m0[L] >> o) & 1u) ? t0 : a0;
         a1 = ((m1[L] >> o) & 1u) ? t1 : a1;
       }
@@ -522,6 +529,7 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
 struct MidMinresArgs {
   int n, nwg, H;
   int offs[12];
+  double cval[12];
   const double *valT;
   const unsigned short *mask;
   const double *dinv;
@@ -539,7 +547,7 @@ struct MidMinresArgs {
   int np_w4, stripe, nspans;
 };
 
-template <int NO, int LAYERS, int BLK>
+template <int NO, int LAYERS, int BLK, bool CV = false>
 __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
   extern __shared__ double lds[];
   constexpr int kMidLayer = 2 * BLK;
@@ -561,7 +569,10 @@ __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
   const int pre = a.pre;
   const double dc = a.dc;
   typedef double d2 __attribute__((ext_vector_type(2)));
-  d2 v[LAYERS][NO];
+  d2 v[CV ? 1 : LAYERS][NO];
+  double cv[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) cv[o] = a.cval[o];
   unsigned m0[LAYERS], m1[LAYERS];
   double xr[LAYERS][2], wr[LAYERS][2], wo[LAYERS][2], vh[LAYERS][2], vho[LAYERS][2], yr[LAYERS][2], avr[LAYERS][2];
   bool in0[LAYERS], in1[LAYERS];
@@ -572,7 +583,8 @@ __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
     in1[L] = row + 1 < n;
     m0[L] = m1[L] = 0;
 #pragma unroll
-    for (int o = 0; o < NO; ++o) v[L][o] = d2{0.0, 0.0};
+    for (int o = 0; o < NO; ++o)
+      if constexpr (!CV) v[L][o] = d2{0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) xr[L][u] = wr[L][u] = wo[L][u] = vh[L][u] = vho[L][u] = yr[L][u] = avr[L][u] = 0.0;
     if (in0[L]) {
@@ -581,7 +593,8 @@ __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
       m1[L] = mm >> 16;
       const double *vp = a.valT + (size_t)(row / 128) * NO * 128 + (size_t)(row % 128);
 #pragma unroll
-      for (int o = 0; o < NO; ++o) v[L][o] = *reinterpret_cast<const d2 *>(vp + o * 128);
+      for (int o = 0; o < NO; ++o)
+        if constexpr (!CV) v[L][o] = *reinterpret_cast<const d2 *>(vp + o * 128);
       xr[L][0] = a.x[row];
       vh[L][0] = a.v_hat[row];
       yr[L][0] = a.yv[row];
@@ -631,8 +644,8 @@ __global__ __launch_bounds__(BLK) void minres_mid_kernel(MidMinresArgs a) {
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         const double p0 = win[c0 + a.offs[o]], p1 = win[c0 + a.offs[o] + 1];
-        const double t0 = a0 + v[L][o].x * p0;
-        const double t1 = a1 + v[L][o].y * p1;
+        const double t0 = a0 + (CV ? cv[o] : v[CV ? 0 : L][o].x) * p0;
+        const double t1 = a1 + (CV ? cv[o] : v[CV ? 0 : L][o].y) * p1;
         a0 = ((m0[L] >> o) & 1u) ? t0 : a0;
         a1 = ((m1[L] >> o) & 1u) ? t1 : a1;
       }
@@ -1391,6 +1404,29 @@ PSP_MID_TABLE(mid_kernel, pcg_mid_kernel)
 PSP_MID_TABLE(mid_minres_kernel, minres_mid_kernel)
 #undef PSP_MID_ROW
 #undef PSP_MID_TABLE
+// the constant-coefficient forms: 3 / 5 / 7 / 9 offsets (the Poisson-like operators)
+#define PSP_MID_CV_ROW(KERNEL, NO)                          \
+  case NO * 4 + 0:                                          \
+    return (const void *)KERNEL<NO, 1, 1024, true>;         \
+  case NO * 4 + 1:                                          \
+    return (const void *)KERNEL<NO, 2, 512, true>;          \
+  case NO * 4 + 2:                                          \
+    return (const void *)KERNEL<NO, 2, 1024, true>;         \
+  case NO * 4 + 3:                                          \
+    return (const void *)KERNEL<NO, 4, 512, true>;
+#define PSP_MID_CV_TABLE(FN, KERNEL)                                                   \
+  const void *FN(int no, int rows, int blk) {                                          \
+    const int key = rows == 2048 ? (blk == 1024 ? 0 : 1) : (blk == 1024 ? 2 : 3);      \
+    switch (no * 4 + key) {                                                            \
+      PSP_MID_CV_ROW(KERNEL, 3) PSP_MID_CV_ROW(KERNEL, 5) PSP_MID_CV_ROW(KERNEL, 7) PSP_MID_CV_ROW(KERNEL, 9) \
+      default:                                                                         \
+        return nullptr;                                                                \
+    }                                                                                  \
+  }
+PSP_MID_CV_TABLE(mid_kernel_cv, pcg_mid_kernel)
+PSP_MID_CV_TABLE(mid_minres_kernel_cv, minres_mid_kernel)
+#undef PSP_MID_CV_ROW
+#undef PSP_MID_CV_TABLE
 
 struct MidPlan {
   W4View w4;
@@ -1401,7 +1437,7 @@ struct MidPlan {
 
 // threads per workgroup: 512 threads may keep 256 registers each -- the blocks of 4096 rows, whose 1024-thread kernels
 // spill (132 .. 250 bytes per lane with 5 offsets), run without scratch memory.  PSP_MID_BLK (tuning switch, read per solve)
-int mid_block_threads(int rows, int no) {
+int mid_block_threads(int rows, int no, bool cv) {
   if (const char *e = tuning_env("PSP_MID_BLK")) {
     const int v = atoi(e);
     if (v == 512 || v == 1024) return v;
@@ -1409,6 +1445,9 @@ int mid_block_threads(int rows, int no) {
   // measured (profiles/r5_mid_blk_ab.txt): blocks of 4096 rows 24.0 -> 21.7 us (PCG), 29.3 -> 19.0 us (MINRES) per iteration at
   // 1024^2 with 512 threads; blocks of 2048 rows the same either way with 5 offsets, 512 ahead with 7 (40 x 40 x 300:
   // MINRES 19.5 -> 15.9 us), whose 1024-thread kernels spill
+  // constant-coefficient forms (no matrix registers, no scratch either way): 1024 threads -- 1024^2 PCG 21.7 -> 19.6 us,
+  // MINRES 18.7 -> 18.1, 40 x 40 x 300 PCG 18.6 -> 17.6 (profiles/r5_mid_cv_ab.txt)
+  if (cv) return 1024;
   return (rows == 4096 || no >= 6) ? 512 : 1024;
 }
 
@@ -1426,8 +1465,10 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)
   if (P->H > 2048) return false;  // the halo is staged in LDS and updated in <= 4 passes: 2-D grids up to 2046 wide, slim 3-D ones
   P->rows = n > kMidMaxWg * 2048 ? 4096 : 2048;
-  P->blk = mid_block_threads(P->rows, P->w4.no);
-  if (P->rows == 4096 && P->blk == 1024 && P->w4.no > 5) return false;  // register budget of two row pairs per thread
+  const bool cv = P->w4.constv && !tuning_env("PSP_MID_NOCV") &&
+                  (minres ? mid_minres_kernel_cv(P->w4.no, P->rows, 1024) : mid_kernel_cv(P->w4.no, P->rows, 1024)) != nullptr;
+  P->blk = mid_block_threads(P->rows, P->w4.no, cv);
+  if (P->rows == 4096 && P->blk == 1024 && P->w4.no > 5 && !cv) return false;  // register budget of two row pairs per thread
   const int B = P->rows;
   P->nwg = (n + B - 1) / B;
   const int nspans = (n + kMidSpan - 1) / kMidSpan;
@@ -1438,7 +1479,10 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
                                        2 * ((nspans + 127) & ~127) + (B == 4096 ? 0 : 2 * P->H));
   if (P->nwg > kMidMaxWg || P->lds > (size_t)kMidMaxLds) return false;
   if (P->w4.grid > 4096 || (n + kMidSpan - 1) / kMidSpan > kMidMaxSpans) return false;
-  P->kernel = minres ? mid_minres_kernel(P->w4.no, P->rows, P->blk) : mid_kernel(P->w4.no, P->rows, P->blk);
+  P->kernel = nullptr;
+  if (P->w4.constv && !tuning_env("PSP_MID_NOCV"))  // (PSP_MID_NOCV: tuning switch, A/B of the constant-coefficient forms)
+    P->kernel = minres ? mid_minres_kernel_cv(P->w4.no, P->rows, P->blk) : mid_kernel_cv(P->w4.no, P->rows, P->blk);
+  if (!P->kernel) P->kernel = minres ? mid_minres_kernel(P->w4.no, P->rows, P->blk) : mid_kernel(P->w4.no, P->rows, P->blk);
   if (!P->kernel) return false;
   // the grid must be resident at once: one workgroup per CU with this much LDS
   static std::mutex mu;
@@ -1514,6 +1558,7 @@ int minres_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, doub
   a.nwg = P.nwg;
   a.H = P.H;
   for (int i = 0; i < 12; ++i) a.offs[i] = P.w4.offs[i];
+  for (int i = 0; i < 12; ++i) a.cval[i] = P.w4.constv ? P.w4.cval[i] : 0.0;
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;
@@ -1604,6 +1649,7 @@ int pcg_mid_loop(const psp_csr *A, const double *dinv, int n, double *x, double 
   a.nwg = P.nwg;
   a.H = P.H;
   for (int i = 0; i < 12; ++i) a.offs[i] = P.w4.offs[i];
+  for (int i = 0; i < 12; ++i) a.cval[i] = P.w4.constv ? P.w4.cval[i] : 0.0;
   a.valT = P.w4.valT;
   a.mask = P.w4.mask;
   a.dinv = dinv;
