@@ -46,6 +46,7 @@ def build():
     hb = int(rng.choice([1, 3, 40, 700, 2044]))
     lo = np.unique(-rng.integers(1, hb + 1, size=nlo))
     keep = float(rng.choice([1.0, 1.0, 0.9, 0.5]))
+    allconst = rng.random() < 0.25  # one value per offset and a constant diagonal: the constant-coefficient kernel forms
     rr, cc, vv = [], [], []
     for o in lo:
         r = np.arange(-o, n)
@@ -53,11 +54,11 @@ def build():
         r = r[sel]
         rr.append(r)
         cc.append(r + o)
-        vv.append(-(0.1 + 0.9 * rng.random(r.size)) if rng.random() < 0.7 else -np.ones(r.size))
+        vv.append(-(0.1 + 0.9 * rng.random(r.size)) if (rng.random() < 0.7 and not allconst) else -np.full(r.size, float(rng.integers(1, 4))))
     r, c, v = np.concatenate(rr), np.concatenate(cc), np.concatenate(vv)
     rowsum = np.bincount(np.concatenate([r, c]), weights=np.concatenate([-v, -v]), minlength=n)
     dom = float(rng.choice([1.0, 0.05, 0.002]))
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 or allconst:
         dg = np.full(n, rowsum.max() * (1.0 + dom) + 0.01)  # a constant diagonal: jacobi's dinv is a scalar
     else:
         dg = rowsum * (1.0 + dom) + 0.01 + rng.random(n) * float(rng.choice([1.0, 0.0]))
@@ -75,7 +76,7 @@ def build():
     lind = np.zeros(n + 1, dtype=np.int32)
     np.cumsum(np.bincount(r, minlength=n), out=lind[1:])
     S = O.SSS(n, np.ascontiguousarray(v[lorder]), dg, np.ascontiguousarray(c[lorder].astype(np.int32)), lind)
-    return dict(n=n, offsets=2 * int(lo.size) + 1, far=int(-lo.min()), keep=keep, dom=dom,
+    return dict(n=n, offsets=2 * int(lo.size) + 1, far=int(-lo.min()), keep=keep, dom=dom, const=bool(allconst),
                 spread=float(dg.max() / dg.min())), A, S
 
 
