@@ -1146,6 +1146,7 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
   const double dc = a.dc;
   const int loff[7] = {-sxy, -sx, -1, 0, 1, sx, sxy};
   double v[CV ? 1 : kBrickPPT][7], vh[kBrickPPT];
+  double xr[CV ? kBrickPPT : 1];  // constant coefficients: the registers the matrix left hold x (else it stays in memory)
   double cv[7];
 #pragma unroll
   for (int o = 0; o < 7; ++o) cv[o] = a.cval[o];
@@ -1174,7 +1175,8 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
 #pragma unroll
         for (int o = 0; o < 7; ++o) v[m][o] = vp[o * 128];
       }
-      a.xout[rw] = a.x[rw];
+      if constexpr (CV) xr[m] = a.x[rw];
+      else a.xout[rw] = a.x[rw];
       vh[m] = a.v_hat[rw];
     }
     vol_[l] = 0.0;
@@ -1342,7 +1344,8 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
         const double nw = (vv - r3 * wov - r2 * ww) / r1;
         wol[l] = ww;
         wl[l] = nw;
-        a.xout[row[m]] = a.xout[row[m]] + c_eta * nw;
+        if constexpr (CV) xr[m] = xr[m] + c_eta * nw;
+        else a.xout[row[m]] = a.xout[row[m]] + c_eta * nw;
       }
     const bool conv = norm_rmr < a.errtol * a.norm_r0;
     if (it >= a.it_max || conv) {
@@ -1351,6 +1354,11 @@ __global__ __launch_bounds__(kBrickBlock) void minres_brick_kernel(BrickMinresAr
       break;
     }
     it += 1;
+  }
+  if constexpr (CV) {
+#pragma unroll
+    for (int m = 0; m < kBrickPPT; ++m)
+      if ((inmask >> m) & 1u) a.xout[row[m]] = xr[m];
   }
   if (wg == 0 && t == 0) {
     a.ctl->info = info;
