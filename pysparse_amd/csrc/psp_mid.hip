@@ -868,6 +868,7 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
 #pragma unroll
   for (int o = 0; o < 7; ++o) cv[o] = a.cval[o];
   unsigned long long mk = 0;  // 7 mask bits per point
+  double rg[CV ? kBrickPPT : 1], qg[CV ? kBrickPPT : 1];  // constant coefficients: r and q in the registers the matrix left
   int li[kBrickPPT], row[kBrickPPT];
   unsigned inmask = 0, surf = 0;
 #pragma unroll
@@ -896,7 +897,8 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
       rv = a.r[rw];
     }
     xl[l] = xv;
-    rl[l] = rv;
+    if constexpr (CV) rg[m] = rv;
+    else rl[l] = rv;
   }
   // ---- the thread's halo cells: LDS index and grid row (-1: outside the grid, or beyond a cut brick's faces)
   int hidx[kBrickHPT], hrow[kBrickHPT];
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
 #pragma unroll
     for (int m = 0; m < kBrickPPT; ++m)
       if ((inmask >> m) & 1u) {
-        double z = rl[t + kBrickBlock * m];
+        double z = CV ? rg[CV ? m : 0] : rl[t + kBrickBlock * m];
         if (pre == 1) z = z * a.dinv[row[m]];
         if (pre == 2) z = z * dc;
         if (it > 1) z = z + beta * P[li[m]];
@@ -991,7 +993,8 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
           }
           dsum += P[li[m]] * acc;
         }
-        ql[t + kBrickBlock * m] = acc;
+        if constexpr (CV) qg[m] = acc;
+        else ql[t + kBrickBlock * m] = acc;
       }
       dsum = psp_wave_sum(dsum);
       if (lane == 0) red[wave] = dsum;
@@ -1021,10 +1024,11 @@ __global__ __launch_bounds__(kBrickBlock) void pcg_brick_kernel(BrickArgs a) {
 #pragma unroll
       for (int m = 0; m < kBrickPPT; ++m)
         if ((inmask >> m) & 1u) {
-          const double qv = ql[t + kBrickBlock * m];
-          const double ro = rl[t + kBrickBlock * m];
+          const double qv = CV ? qg[CV ? m : 0] : ql[t + kBrickBlock * m];
+          const double ro = CV ? rg[CV ? m : 0] : rl[t + kBrickBlock * m];
           const double tt = upd ? ro + malpha * qv : ro;
-          rl[t + kBrickBlock * m] = tt;
+          if constexpr (CV) rg[m] = tt;
+          else rl[t + kBrickBlock * m] = tt;
           acc0 += tt * tt;
           if (pre != 0) {
             const double z = tt * (pre == 1 ? a.dinv[row[m]] : dc);
