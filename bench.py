@@ -42,7 +42,7 @@ from bench_common import (HBM_PEAK_GBPS, METRIC, PARITY_ITERS, PARITY_TOL, PMC_F
                           rel_diff, timed_launches)
 from bench_launch import LADDER, guarded_rank, orchestrate  # noqa: E402
 from bench_legs import (dry_strong_n1, gpu_clocks, link_topology, live_traffic, pcg_single, peer_matrix,  # noqa: E402
-                        placement_sweep_leg, same_operator_kernels_leg, single_process_main, solvers_leg, sss_leg, stream_ceiling_leg,
+                        placement_sweep_leg, same_operator_kernels_leg, single_kernel_leg, single_process_main, solvers_leg, sss_leg, stream_ceiling_leg,
                         strong_n1_leg)
 
 
@@ -825,6 +825,14 @@ def run_body(a, real_stdout):
         except Exception as e:  # noqa: BLE001 - a reported extra, never fatal
             solvers = {"error": str(e)[:200]}
 
+    # ---- beside it (N = 1 default run; bench_legs.py): the single-kernel loops at configs[0]'s size and at 10^6 points
+    single_kernel = None
+    if not use_dist and not dry and not a.grid and not a.no_solvers:
+        try:
+            single_kernel = single_kernel_leg(L, check, dev)
+        except Exception as e:  # noqa: BLE001 - a reported extra, never fatal
+            single_kernel = {"error": str(e)[:200]}
+
     # ---- N = 1 default run: the 1-GPU end of the strong-scaling target (1024^3 on this GPU)
     if not use_dist and not a.grid and not a.no_strong_n1:
         A.close()
@@ -951,6 +959,8 @@ def run_body(a, real_stdout):
             out["sss_mat"] = sss
         if solvers is not None:
             out["solvers"] = solvers
+        if single_kernel is not None:
+            out["single_kernel_loops"] = single_kernel
         if strong_n1 is not None:
             out["strong_n1"] = strong_n1
             if use_dist and scaling == "strong" and strong_n1["grid"] == [nx, ny, nz]:

@@ -511,3 +511,48 @@ def solvers_leg(ctx):
                      "last": [int(res[0]), int(res[1]), float(res[2])]}
     del K
     return out
+
+
+def single_kernel_leg(L, check, dev):
+    """`single_kernel_loops`: Jacobi-PCG and Jacobi-MINRES per iteration where the whole loop runs as ONE cooperative kernel
+    (pysparse_amd/csrc/psp_coop.hip, psp_mid.hip: row blocks for 2-D grids, bricks for 3-D ones) -- configs[0]'s size, a 2-D
+    and a 3-D grid of 10^6 points; two truncated solves each (tol = 0), device-resident vectors.  Reported only."""
+    out = {"what": "microseconds per iteration, Jacobi, b = A x_random, x0 = 0, tol = 0 (two truncated solves); which loop ran: "
+                   "counters of the library"}
+    for grid, (k1, k2) in (((100, 100, 0), (40, 140)), ((1024, 1024, 0), (100, 600)), ((100, 100, 100), (15, 75))):
+        A = dev.DeviceCSR.poisson(*grid)
+        n = A.shape[0]
+        K = dev.DeviceJacobi(A)
+        aop, kop = dev._Op(A, "matvec"), dev._Op(K, "precon")
+        bb, xb = dev.DeviceBuffer(n), dev.DeviceBuffer(n)
+        xb.upload(np.random.default_rng(1).standard_normal(n))
+        A.matvec_dev(xb.ptr, bb.ptr)
+        check(L.psp_synchronize())
+        rec = {"n": n}
+        m0, b0 = (C.c_longlong(), C.c_longlong()), (C.c_longlong(), C.c_longlong())
+        L.psp_debug_mid_count(C.byref(m0[0]), C.byref(m0[1]))
+        L.psp_debug_brick_count(C.byref(b0[0]), C.byref(b0[1]))
+        for name, fn in (("pcg", L.psp_pcg_dev), ("minres", L.psp_minres_dev)):
+            ts = {}
+            for kk in (k1, k1, k2, k1, k2):
+                xb.zero()
+                info, it, rr = C.c_int(), C.c_int(), C.c_double()
+                check(L.psp_synchronize())
+                t = time.perf_counter()
+                check(fn(aop._h, kop._h, n, xb.ptr, bb.ptr, 0.0, kk, C.byref(info), C.byref(it), C.byref(rr), None))
+                check(L.psp_synchronize())
+                ts.setdefault(kk, []).append(time.perf_counter() - t)
+            rec[name + "_us_per_iter"] = (min(ts[k2]) - min(ts[k1])) / (k2 - k1) * 1e6
+            rec[name + "_last"] = [info.value, it.value]
+        m1, b1 = (C.c_longlong(), C.c_longlong()), (C.c_longlong(), C.c_longlong())
+        L.psp_debug_mid_count(C.byref(m1[0]), C.byref(m1[1]))
+        L.psp_debug_brick_count(C.byref(b1[0]), C.byref(b1[1]))
+        rec["loop"] = ("row blocks (psp_mid.hip)" if m1[0].value > m0[0].value else
+                       "bricks (psp_mid.hip)" if b1[0].value > b0[0].value else "one row per thread (psp_coop.hip) or launch per phase")
+        rec["handed_back"] = int(m1[1].value - m0[1].value + b1[1].value - b0[1].value)
+        out["x".join(str(v) for v in grid if v)] = rec
+        del aop, kop, K
+        A.close()
+        bb.free()
+        xb.free()
+    return out
