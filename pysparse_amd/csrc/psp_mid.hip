@@ -1,4 +1,9 @@
-// psp_mid.hip -- mid-size offset-structured systems: the whole PCG loop as ONE cooperative kernel (round 5).
+// psp_mid.hip -- mid-size offset-structured systems: the whole PCG / MINRES loop as ONE cooperative kernel (round 5).
+//
+// Contents: pcg_mid_kernel / minres_mid_kernel (contiguous row blocks: 2-D grids and slim 3-D ones, up to 9 offsets, bit-exact
+// with the launch-per-phase loops; CV = constant-coefficient forms), pcg_brick_kernel / minres_brick_kernel (the 7-offset
+// operators of 3-D grids, the points dealt out in bricks; oracle parity), their plans and host loops.  What follows describes
+// the row-block PCG kernel; the others say where they differ.
 //
 // Between 2^18 and 2^20 unknowns an iteration of the launch-per-phase loops (psp_solvers.hip) is five kernels that each
 // sit on the ~5 us floor of a dependent launch: 47 us per PCG iteration at 1024^2 for 128 MB of traffic that the memory
