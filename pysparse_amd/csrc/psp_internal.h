@@ -204,7 +204,7 @@ struct Workspace {
   int device = -1;
 };
 constexpr size_t kStateBytes = 8192;
-constexpr size_t kCtlPartDoubles = 4 * 2048;
+constexpr size_t kCtlPartDoubles = 4 * 4096;
 int workspace(Workspace **out);
 // the solvers' pool of device work vectors (psp_solvers.hip) for the other translation units: at least n doubles,
 // contents undefined; give back with the n asked for

@@ -45,7 +45,7 @@ namespace psp {
 namespace {
 
 constexpr int kMidMaxWg = 256;
-constexpr int kMidMaxRows = 1 << 20;         // two layers x 256 workgroups
+constexpr int kMidMaxRows = 1 << 21;         // 256 workgroups x 8192 rows (constant-coefficient PCG; everything else: 4096)
 constexpr int kMidSpan = 512;                // rows per partial sum (kVecSpan; csr_spmv_w4: 4 waves x 128 rows)
 constexpr int kMidMaxSpans = kMidMaxRows / kMidSpan;
 constexpr int kMidMaxLds = 150 * 1024;       // bytes of dynamic LDS the kernel may ask for (160 KB per CU)
@@ -263,10 +263,15 @@ __global__ __launch_bounds__(BLK) void pcg_mid_kernel(MidArgs a) {
   double *ql = xl + (XQ_LDS ? B : 0);
   double *red = ql + (XQ_LDS ? B : 0);  // 3 x (LAYERS * NW) wave sums
   double *grp = red + 3 * LAYERS * NW;  // mid_reduce's scratch: 3 * 16 + 3
-  double *stage = grp + 3 * 16 + 4;  // the partial sums, staged for the reduction: two arrays of nspans (rounded up to 128)
+  // the partial sums, staged for the reduction: two arrays of nspans (rounded up to 128) -- behind the scratch, or, for
+  // blocks of 8192 rows (up to 4096 spans: 64 KB), in the window's own part, which is dead at both barriers when the own p
+  // lives in registers (the halo zones, which carry p_old of the neighbours' rows across iterations, are not touched)
+  constexpr bool STAGE_IN_WIN = B > 4096;
+  static_assert(!STAGE_IN_WIN || !XQ_LDS, "staging in the window needs the own p in registers");
+  double *stage = STAGE_IN_WIN ? win + H : grp + 3 * 16 + 4;
   // the neighbours' residual, staged for the p update of the halo: q's place (dead between the r update and the next
   // product) with two layers, a region of its own with one
-  double *hst = XQ_LDS ? ql : stage + 2 * ((a.nspans + 127) & ~127);
+  double *hst = XQ_LDS ? ql : (STAGE_IN_WIN ? grp + 3 * 16 + 4 : stage + 2 * ((a.nspans + 127) & ~127));
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wg = blockIdx.x, nwg = a.nwg, n = a.n;
   const long base = (long)wg * B;
@@ -1441,6 +1446,16 @@ PSP_MID_TABLE(mid_minres_kernel, minres_mid_kernel)
     }                                                                                  \
   }
 PSP_MID_CV_TABLE(mid_kernel_cv, pcg_mid_kernel)
+// blocks of 8192 rows (2^20 < n <= 2^21): PCG, constant coefficients, 512 threads with eight row pairs each
+const void *mid_kernel_cv8(int no) {
+  switch (no) {
+    case 3: return (const void *)pcg_mid_kernel<3, 8, 512, true>;
+    case 5: return (const void *)pcg_mid_kernel<5, 8, 512, true>;
+    case 7: return (const void *)pcg_mid_kernel<7, 8, 512, true>;
+    case 9: return (const void *)pcg_mid_kernel<9, 8, 512, true>;
+    default: return nullptr;
+  }
+}
 PSP_MID_CV_TABLE(mid_minres_kernel_cv, minres_mid_kernel)
 #undef PSP_MID_CV_ROW
 #undef PSP_MID_CV_TABLE
@@ -1468,6 +1483,28 @@ int mid_block_threads(int rows, int no, bool cv) {
   return (rows == 4096 || no >= 6) ? 512 : 1024;
 }
 
+// the grid must be resident at once: one workgroup per CU with this much LDS
+bool mid_capacity_ok(const MidPlan *P) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> cap;  // (device, kernel) -> workgroups the device holds at once
+  std::lock_guard<std::mutex> lk(mu);
+  if (const char *e = tuning_env("PSP_COOP_CAPACITY")) return P->nwg <= atoi(e);
+  const auto key = std::make_pair(current_device(), P->kernel);
+  auto it = cap.find(key);
+  if (it == cap.end()) {
+    int c = 0, per = 0;
+    Workspace *w = nullptr;
+    if (hipFuncSetAttribute(P->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) == hipSuccess &&
+        workspace(&w) == PSP_OK && w->num_cu > 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, P->kernel, P->blk, kMidMaxLds) == hipSuccess)
+      c = per * w->num_cu;
+    else
+      (void)hipGetLastError();
+    it = cap.emplace(key, c).first;
+  }
+  return P->nwg <= it->second;
+}
+
 // the plan for this operator, or false: no index-free layout of <= 9 offsets, too many rows, a halo that does not fit
 // the LDS, or a grid the device cannot hold at once
 bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
@@ -1481,7 +1518,19 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
   for (int i = 0; i < P->w4.no; ++i) omax = std::max(omax, std::abs(P->w4.offs[i]));
   P->H = (omax + 2) & ~1;  // even, and one pair beyond the farthest entry (a row pair reads offset + 1)
   if (P->H > 2048) return false;  // the halo is staged in LDS and updated in <= 4 passes: 2-D grids up to 2046 wide, slim 3-D ones
-  P->rows = n > kMidMaxWg * 2048 ? 4096 : 2048;
+  P->rows = n > kMidMaxWg * 4096 ? 8192 : (n > kMidMaxWg * 2048 ? 4096 : 2048);
+  if (P->rows == 8192) {
+    // 2^20 < n <= 2^21: constant-coefficient PCG only (no matrix registers: eight row pairs per thread fit 512 threads; the
+    // partial sums are staged in the window) -- measured against the launch-per-phase loops in profiles/r5_mid_8192_ab.txt
+    if (minres || !P->w4.constv || tuning_env("PSP_MID_NOCV") || !mid_kernel_cv8(P->w4.no)) return false;
+    P->blk = 512;
+    P->nwg = (n + 8191) / 8192;
+    P->lds = sizeof(double) * (size_t)(4 * P->H + 8192 + 3 * (8192 / 128) + 3 * 16 + 8);
+    if (P->nwg > kMidMaxWg || P->lds > (size_t)kMidMaxLds) return false;
+    if (P->w4.grid > 4096 || (n + kMidSpan - 1) / kMidSpan > kMidMaxSpans) return false;
+    P->kernel = mid_kernel_cv8(P->w4.no);
+    return mid_capacity_ok(P);
+  }
   const bool cv = P->w4.constv && !tuning_env("PSP_MID_NOCV") &&
                   (minres ? mid_minres_kernel_cv(P->w4.no, P->rows, 1024) : mid_kernel_cv(P->w4.no, P->rows, 1024)) != nullptr;
   P->blk = mid_block_threads(P->rows, P->w4.no, cv);
@@ -1501,25 +1550,7 @@ bool mid_plan(const psp_csr *A, int n, MidPlan *P, bool minres = false) {
     P->kernel = minres ? mid_minres_kernel_cv(P->w4.no, P->rows, P->blk) : mid_kernel_cv(P->w4.no, P->rows, P->blk);
   if (!P->kernel) P->kernel = minres ? mid_minres_kernel(P->w4.no, P->rows, P->blk) : mid_kernel(P->w4.no, P->rows, P->blk);
   if (!P->kernel) return false;
-  // the grid must be resident at once: one workgroup per CU with this much LDS
-  static std::mutex mu;
-  static std::map<std::pair<int, const void *>, int> cap;  // (device, kernel) -> workgroups the device holds at once
-  std::lock_guard<std::mutex> lk(mu);
-  if (const char *e = tuning_env("PSP_COOP_CAPACITY")) return P->nwg <= atoi(e);
-  const auto key = std::make_pair(current_device(), P->kernel);
-  auto it = cap.find(key);
-  if (it == cap.end()) {
-    int c = 0, per = 0;
-    Workspace *w = nullptr;
-    if (hipFuncSetAttribute(P->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMidMaxLds) == hipSuccess &&
-        workspace(&w) == PSP_OK && w->num_cu > 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, P->kernel, P->blk, kMidMaxLds) == hipSuccess)
-      c = per * w->num_cu;
-    else
-      (void)hipGetLastError();
-    it = cap.emplace(key, c).first;
-  }
-  return P->nwg <= it->second;
+  return mid_capacity_ok(P);
 }
 
 }  // namespace

@@ -183,6 +183,24 @@ def test_nine_point_operators():
     assert a[-1][0] == 0
 
 
+def test_blocks_of_8192_rows_for_constant_coefficient_pcg():
+    """2^20 < n <= 2^21 (round 5, late): constant-coefficient operators run PCG in blocks of 8192 rows (no matrix registers,
+    the partial sums staged in the window) -- the launch-per-phase loops' bits; MINRES and varying coefficients keep those loops"""
+    spec = [{"kind": "poisson", "grid": [1200, 1200, 0], "K": ["none", "jacobi"], "runs": RUNS[:6], "solvers": ["pcg"]},
+            {"kind": "poisson", "grid": [1448, 1447, 0], "K": ["jacobi"], "runs": RUNS[:5], "solvers": ["pcg"]},
+            {"kind": "poisson_sss", "grid": [1100, 1300, 0], "K": ["jacobi"], "runs": RUNS[:5], "solvers": ["pcg"]},
+            {"kind": "poisson", "grid": [30, 30, 1500], "K": ["jacobi"], "runs": RUNS[:5], "solvers": ["pcg"]}]
+    mid = _run(spec)
+    ref = _run(spec, {"PSP_MID": "0"})
+    a = [r for r in mid if r[0] != "mid_solves"]
+    b = [r for r in ref if r[0] != "mid_solves"]
+    assert a == b and len(a) > 0
+    assert all(r[1] > 0 and r[2] == 0 for r in mid if r[0] == "mid_solves")
+    other = [{"kind": "poisson", "grid": [1200, 1200, 0], "K": ["jacobi"], "runs": RUNS[:2], "solvers": ["minres"]},
+             {"kind": "random5", "grid": [1200, 1100, 0], "seed": 2, "K": ["jacobi"], "runs": RUNS[:2], "solvers": ["pcg"]}]
+    assert all(r[1] == 0 for r in _run(other) if r[0] == "mid_solves")
+
+
 def test_stagnation_exit_at_the_same_iteration():
     """pcg.c:124-139, :159-162: the kernel decides "1 + max |alpha p / x| == 1" row by row without the division
     (mid_row_moves) -- the exit must come at the launch-per-phase loops' iteration, with their bits"""

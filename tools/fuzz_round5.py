@@ -41,7 +41,8 @@ def mid_count():
 
 
 def build():
-    n = int(rng.choice([65536, 65537, 70001, 131071, 200003, 262144, 300007, 524288, 524800, 777777, 1048575, 1048576]))
+    n = int(rng.choice([65536, 65537, 70001, 131071, 200003, 262144, 300007, 524288, 524800, 777777, 1048575, 1048576,
+                        1048577, 1500001, 2097152]))  # (beyond 2^20: blocks of 8192 rows for constant-coefficient PCG, else declined)
     nlo = int(rng.integers(1, 5))  # 3 .. 9 offsets in all
     hb = int(rng.choice([1, 3, 40, 700, 2044]))
     lo = np.unique(-rng.integers(1, hb + 1, size=nlo))
