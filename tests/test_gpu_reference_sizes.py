@@ -132,3 +132,20 @@ def test_sss_form_against_oracle_and_reference(oracle, grid, k):
     out = bench.gpu_parity_case(dev, oracle, grid, k, form="sss")
     assert out["form"] == "sss" and out["n"] == grid[0] * grid[1] * max(grid[2], 1)
     _check(out, k, True, oracle.have_ref() and oracle.have_ref_krylov())
+
+
+def test_brick_range_against_oracle_and_reference(oracle):
+    """3-D grids of 1.5e5 .. 2^20 points: the product path is ONE cooperative kernel with the points dealt out in bricks
+    (psp_mid.hip; its sums are ordered differently from every other loop's) -- 100 iterations against the oracle and the
+    reference's compiled pcg.c / minres.c"""
+    import ctypes as C
+
+    import bench
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import lib
+    s0, f0, s1, f1 = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+    lib().psp_debug_brick_count(C.byref(s0), C.byref(f0))
+    out = bench.gpu_parity_case(dev, oracle, (80, 80, 80), 100)
+    lib().psp_debug_brick_count(C.byref(s1), C.byref(f1))
+    assert s1.value - s0.value >= 2 and f1.value == f0.value  # PCG and MINRES both ran in bricks
+    _check(out, 100, True, oracle.have_ref() and oracle.have_ref_krylov())
