@@ -103,52 +103,46 @@ def _counts(out, ncases):
     return [row for row in out if row and row[0] == "mid_solves"]
 
 
-@pytest.mark.parametrize("spec", [
-    [{"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS}],           # one layer, 176 workgroups
-    [{"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS}],         # two layers, 256 workgroups
-    [{"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS}],                   # ends inside a span and a row pair
-    [{"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS}],           # 7 offsets, halo of 1602 rows
-    [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS}],  # varying diagonal: dinv array
-    [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:]}],
-    [{"kind": "poisson", "grid": [20, 20, 2500], "K": ["none", "jacobi"], "runs": RUNS}],  # 7 offsets, 4096 rows per workgroup (512 threads)
-], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq", "20x20x2500"])
-def test_single_kernel_loop_has_the_launch_per_phase_bits(spec):
+PCG_CASES = [
+    {"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS},           # one layer, 176 workgroups
+    {"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS},         # 4096 rows per workgroup
+    {"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS},                   # ends inside a span and a row pair
+    {"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS},           # 7 offsets, halo of 1602 rows
+    {"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS},  # varying diagonal: dinv array
+    {"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:]},
+    {"kind": "poisson", "grid": [20, 20, 2500], "K": ["none", "jacobi"], "runs": RUNS},          # 7 offsets, 4096 rows per workgroup
+]
+
+
+def _compare_with_launch_per_phase(spec):
+    """every case of the spec in one child with the single-kernel loops and in one without: all fields for equality, every
+    solve of the first child one kernel, the last run of every case converged"""
     mid = _run(spec)
     ref = _run(spec, {"PSP_MID": "0"})
-    nsolves = sum(len(c["K"]) * len(c["runs"]) for c in spec)
-    assert [r for r in mid if r[0] == "mid_solves"] == [["mid_solves", nsolves, 0]], mid[-1]
-    assert [r for r in ref if r[0] == "mid_solves"] == [["mid_solves", 0, 0]]
+    want = [["mid_solves", len(c["K"]) * len(c["runs"]) * len(c.get("solvers", ["pcg"])), 0] for c in spec]
+    assert [r for r in mid if r[0] == "mid_solves"] == want, [r for r in mid if r[0] == "mid_solves"]
+    assert [r for r in ref if r[0] == "mid_solves"] == [["mid_solves", 0, 0]] * len(spec)
     a = [r for r in mid if r[0] != "mid_solves"]
     b = [r for r in ref if r[0] != "mid_solves"]
-    assert len(a) == len(b) == nsolves
+    assert len(a) == len(b) == sum(w[1] for w in want)
     for k, (ra, rb) in enumerate(zip(a, b)):
         assert ra == rb, (k, ra[:3], rb[:3])
-    assert a[-1][0] == 0  # the last run of every spec converges
+    pos = 0
+    for w in want:
+        pos += w[1]
+        assert a[pos - 1][0] == 0  # the last run of every case converges
 
 
-@pytest.mark.parametrize("spec", [
-    [{"kind": "poisson", "grid": [600, 600, 0], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-    [{"kind": "poisson", "grid": [1024, 1024, 0], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-    [{"kind": "poisson", "grid": [601, 733, 0], "K": ["jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-    [{"kind": "poisson", "grid": [40, 40, 300], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-    [{"kind": "random5", "grid": [640, 700, 0], "seed": 4, "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-    [{"kind": "random5", "grid": [1000, 1000, 0], "seed": 5, "K": ["jacobi"], "runs": RUNS[:4] + RUNS[-1:],
-      "solvers": ["minres"]}],
-    [{"kind": "poisson", "grid": [20, 20, 2500], "K": ["none", "jacobi"], "runs": RUNS, "solvers": ["minres"]}],
-], ids=["600sq", "1024sq", "601x733", "40x40x300", "random5_640x700", "random5_1000sq", "20x20x2500"])
-def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(spec):
+@pytest.mark.parametrize("part", [0, 1], ids=["2d", "3d_and_varying"])
+def test_single_kernel_loop_has_the_launch_per_phase_bits(part):
+    _compare_with_launch_per_phase(PCG_CASES[:3] if part == 0 else PCG_CASES[3:])
+
+
+@pytest.mark.parametrize("part", [0, 1], ids=["2d", "3d_and_varying"])
+def test_single_kernel_minres_loop_has_the_launch_per_phase_bits(part):
     """minres.c:96-193 in one kernel (minres_mid_kernel): the same comparison, every field for equality"""
-    mid = _run(spec)
-    ref = _run(spec, {"PSP_MID": "0"})
-    nsolves = sum(len(c["K"]) * len(c["runs"]) for c in spec)
-    assert [r for r in mid if r[0] == "mid_solves"] == [["mid_solves", nsolves, 0]], mid[-1]
-    assert [r for r in ref if r[0] == "mid_solves"] == [["mid_solves", 0, 0]]
-    a = [r for r in mid if r[0] != "mid_solves"]
-    b = [r for r in ref if r[0] != "mid_solves"]
-    assert len(a) == len(b) == nsolves
-    for k, (ra, rb) in enumerate(zip(a, b)):
-        assert ra == rb, (k, ra[:3], rb[:3])
-    assert a[-1][0] == 0
+    cases = [dict(c, solvers=["minres"]) for c in (PCG_CASES[:3] if part == 0 else PCG_CASES[3:])]
+    _compare_with_launch_per_phase(cases)
 
 
 def test_sss_operands_take_the_single_kernel_loops_with_their_own_bits():

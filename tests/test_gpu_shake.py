@@ -56,7 +56,7 @@ def test_directed_delay_reproduces_the_round4_race_and_head_is_clean():
 
 @pytest.mark.gpu
 def test_shaken_products_and_solves_are_bit_identical():
-    out = _child("stress", 40, 120)
+    out = _child("stress", 40, 80)
     assert out["configs"] == 5 and out["runs_per_config"] * out["configs"] >= 200
     assert out["injected"] > 10000, out  # the cut points were reached and delays were drawn
     assert out["mismatches"] == [], out
