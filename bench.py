@@ -30,6 +30,7 @@ os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # cpu_baseline legs: ONE cor
 import argparse  # noqa: E402
 import ctypes as C  # noqa: E402
 import json  # noqa: E402
+import re  # noqa: E402
 import socket  # noqa: E402
 import subprocess  # noqa: E402
 import sys  # noqa: E402
@@ -41,6 +42,7 @@ from bench_common import (HBM_PEAK_GBPS, METRIC, PARITY_ITERS, PARITY_TOL, PMC_F
                           Events, _maxrel, csr_model_bytes, kernel_bytes, parity_object, pcg_vector_bytes, provenance,
                           rel_diff, timed_launches)
 from bench_launch import LADDER, guarded_rank, orchestrate  # noqa: E402
+from bench_line import emit, judge_phases, predicted_iteration  # noqa: E402
 from bench_legs import (dry_strong_n1, gpu_clocks, link_topology, live_traffic, pcg_single, peer_matrix,  # noqa: E402
                         placement_sweep_leg, same_operator_kernels_leg, single_kernel_leg, single_process_main, solvers_leg, sss_leg, stream_ceiling_leg,
                         strong_n1_leg)
@@ -246,6 +248,88 @@ def _cpu_case(O, grid, spmv_reps, pcg_iters, with_ref, dev=None, threads=1):
     return out
 
 
+def published_table_leg(O, sizes=(100, 300, 500)):
+    """The reference's ONLY published benchmark for this path -- doc/pysparse/source/itsolvers.rst:120-130 (script), :189-199
+    (table): L x = 1 on the 2-D Poisson matrix, n = 100 / 300 / 500, `krylov.pcg(L.to_sss(), b, x, 1e-12, 2000)`, no
+    preconditioner, seconds for assembly and solve -- reproduced end to end through the drop-in modules (ll_mat assembly on
+    the host as the script does it, to_sss(), upload, the solve, x back in the caller's NumPy array), beside the reference's own
+    native twin (examples/poisson_test/poisson_test.c:110-125, compiled unmodified: oracle/_ref/poisson_test) on ONE host
+    core of the same box, reading the same matrix from a file as the doc's "Native C" rows do.  Pinned by
+    tests/golden/ref_published_table.json (that program's iteration counts and x; oracle/make_golden.py).
+    Part of the cpu_baseline leg: the compiled reference is the thing timed beside, never the thing shipped."""
+    import shutil
+    import tempfile
+    from pysparse_amd.itsolvers import krylov
+    from pysparse_amd.tools import poisson
+    gold = None
+    try:
+        gold = {r["n"]: r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "ref_published_table.json")))["rows"]}
+        gx = np.load(os.path.join(ROOT, "tests", "golden", "ref_published_table.npz"))
+    except (OSError, ValueError):
+        gx = None
+    rows, ok = [], True
+    for nn in sizes:
+        n = nn * nn
+        t0 = time.perf_counter()
+        L = poisson.poisson2d_sym_blk(nn)
+        S = L.to_sss()
+        t_asm = time.perf_counter() - t0
+        b, x = np.ones(n), np.zeros(n)
+        t0 = time.perf_counter()
+        info, it, relres = krylov.pcg(S, b, x, 1e-12, 2000)
+        t_first = time.perf_counter() - t0  # includes whatever the handle builds on its first solve
+        x2 = np.zeros(n)
+        t0 = time.perf_counter()
+        info2, it2, _ = krylov.pcg(S, b, x2, 1e-12, 2000)
+        t_solve = time.perf_counter() - t0
+        row = {"n": nn, "rows": n, "info": info, "iter": it, "relres": relres, "gpu_assembly_s": t_asm,
+               "gpu_first_solve_s": t_first, "gpu_solve_s": t_solve, "gpu_total_s": t_asm + t_first,
+               "same_bits_second_solve": bool((info, it) == (info2, it2) and np.array_equal(x, x2))}
+        if gold and nn in gold:
+            g = gold[nn]["compiled_pcg_with_sss_product"]
+            row["iter_reference_openblas"] = g["iter"]
+            row["x_max_rel_diff_vs_reference"] = float(np.abs(x[::97] - gx["x_%d" % nn]).max() / np.abs(gx["x_%d" % nn]).max())
+            row["ok"] = bool(info == 0 and relres <= 1e-12 and row["x_max_rel_diff_vs_reference"] <= 1e-12)
+            ok = ok and row["ok"]
+        if O.have_ref():
+            # the unmodified native program, one core: it reads matrices/poi2d_100.mtx (name fixed in its source), converts
+            # COO -> SSS and solves; wall time of the whole process = the doc's "Native C" Total
+            So = O.poisson_sss(nn, nn)
+            td = tempfile.mkdtemp()
+            try:
+                os.makedirs(os.path.join(td, "matrices"))
+                with open(os.path.join(td, "matrices", "poi2d_100.mtx"), "w") as f:
+                    f.write("%%%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (n, n, So.nnz_lower + n))
+                    rr = np.repeat(np.arange(n), np.diff(So.ind))
+                    ii = np.concatenate([rr, np.arange(n)]) + 1
+                    jj = np.concatenate([So.col, np.arange(n)]) + 1
+                    vv = np.concatenate([So.val, So.diag])
+                    np.savetxt(f, np.column_stack([ii, jj, vv]), fmt="%d %d %.17g")
+                t0 = time.perf_counter()
+                out = subprocess.run([O.REF_BIN_PATH], cwd=td, capture_output=True, text=True,
+                                     env=dict(os.environ, OPENBLAS_NUM_THREADS="1")).stdout
+                wall = time.perf_counter() - t0
+                row["ref_stdout_tail"] = out.strip().splitlines()[-1] if out.strip() else ""
+                m = re.search(r"converged at iteration (\d+)", row["ref_stdout_tail"])
+                if m:  # (a run that did not get there is no timing)
+                    row["ref_total_s"] = wall
+                    row["ref_iter_this_box"] = int(m.group(1))
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
+        rows.append(row)
+        del L, S
+    return {"what": "L x = 1, L = poisson2d_sym_blk(n).to_sss(), x0 = 0, krylov.pcg(S, b, x, 1e-12, 2000), no preconditioner: "
+                    "doc/pysparse/source/itsolvers.rst:120-130,189-199; native twin examples/poisson_test/poisson_test.c",
+            "rows": rows, "ok": ok if gold else None,
+            "published_seconds_total": {"Python": {"100": 1.15, "300": 49.86, "500": 300.01},
+                                        "Native C": {"100": 1.26, "300": 51.52, "500": 299.53},
+                                        "note": "the doc's own numbers, machine unknown: context only"},
+            "iteration_counts": "at tol 1e-12 the recurred residual stagnates near its floor and the count depends on the "
+                                "ORDER of the BLAS-1 sums: the reference's own program gives 225 / 677 / 1132 linked with "
+                                "OpenBLAS and 225 / 735 / 1297 with a sequential BLAS-1 (DESIGN.md section 7); x agrees to "
+                                "1e-13 either way, which is what `ok` checks"}
+
+
 def _usable_cores():
     """threads the "all host cores" line may use: the affinity mask, cut to the cgroup's CPU quota where one is set (a GPU
     box shows all 256 hardware threads to a job that owns 16 of them) and to 64 (one thread's ranges stay >= 2 MB at C2)"""
@@ -271,7 +355,8 @@ def _usable_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256), dev=None):
+def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512), c3_small=(256, 256, 256), dev=None,
+                 published=False):
     """`cpu_baseline` (kind "port": the oracle's SpMV -- the reference's csr_mat.c needs the Python-2
     C API and cannot be compiled) and `cpu_baseline_reference_pcg` (kind "reference": the reference's
     own pcg.c, compiled unmodified, driven by the oracle's CSR matvec callback).  Sizes: C2 (4096^2)
@@ -325,6 +410,11 @@ def cpu_baseline(budget_s=75.0, c2_grid=(4096, 4096, 0), c3_grid=(512, 512, 512)
                   "bound": "GPU vs oracle: 32 k sqrt(n) eps; GPU vs the compiled reference (pcg.c, minres.c): 4 k sqrt(n) eps; "
                            "eps = 2^-52 (bench.parity_bound; DESIGN.md section 7)",
                   "cases": cases, "ok": bool(cases) and all(c["ok"] for c in cases.values())}
+    if published and dev is not None:
+        try:
+            base["published_table"] = published_table_leg(O)
+        except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the bench line
+            base["published_table"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return base, ref, parity
 
 
@@ -536,6 +626,9 @@ def main():
                     help="failure injection for the launcher tests: exit:RANK (that rank leaves with code 3 after the "
                          "process group formed) or hang:RANK (that rank sleeps instead of taking part)")
     ap.add_argument("--no-phases", action="store_true", help="skip the per-phase timing of an N > 1 iteration")
+    ap.add_argument("--side-file", default="",
+                    help="where the full record goes (default gpurun_out/bench_side_n<N>.json under the repo); the "
+                         "printed line stays <= 6 KB and names it as `side_file`")
     ap.add_argument("--mtx", default="",
                     help="configs[4] on its own: a symmetric MatrixMarket file (e.g. SuiteSparse Emilia_923.mtx) or "
                          "standin:fem32 | standin:fem512 | standin:logspaced -- sss_mat product + Jacobi-MINRES on one "
@@ -783,6 +876,9 @@ def run_body(a, real_stdout):
                 parity_mine = {"relres": res[2], "x_dot_b": cs[0], "x_dot_x": cs[1], "info_iter": [res[0], res[1]]}
         pcg_s_per_iter = pcg_t / k
         pcg_path = "pysparse_amd.distributed.dist_pcg (row-range driver, %s)" % D.dist_pcg_mode()
+        # the row-range driver's loop is the lazy one cut at its two reductions (distributed.py): 64 n beside the product
+        pcg_loop, pcg_loop_info = "dist_pcg_lazy", {"launches": 7, "vec_bytes_per_row": 64, "dinv_streamed": False,
+                                                    "single_kernel_fallbacks": 0}
         # where the time of an iteration goes: marks between the phases of the same loop (events on the stream the
         # kernels and the collectives are ordered on), + the ghost exchange on its own
         phases = None
@@ -807,7 +903,8 @@ def run_body(a, real_stdout):
                               "rows still wait for after the interior rows; halo_ms = one ghost exchange on its own")
     else:
         pcg_s_per_iter, res = pcg_single(L, check, dev, A, n_loc, k, sync)
-        pcg_path = "psp_pcg_dev (single-GPU device-resident loop)"
+        pcg_loop, pcg_loop_info = dev.last_solve_info()  # which of the library's loops ran: the byte model follows it
+        pcg_path = "psp_pcg_dev (single-GPU device-resident loop: %s)" % pcg_loop
         parity_mine, phases, preflight = None, None, None
 
     # ---- beside it (N = 1; bench_legs.py): the same operator as an sss_mat (examples/poisson_test.py solves with
@@ -856,8 +953,11 @@ def run_body(a, real_stdout):
     if rank == 0:
         hl = headline(kbytes_tot, kbytes_loc, wall, ev_ms, a.steps)
         ms_step, value, kern_ms, achieved = hl["ms_per_step"], hl["value"], hl["avg_launch_ms"], hl["achieved"]
-        lazy = n_loc >= (1 << 25) or use_dist
-        pcg_moved = kbytes_tot + pcg_vector_bytes(n_tot, lazy)
+        # bytes one PCG iteration has to move: the product in the format of the kernel that ran + what the loop THAT RAN
+        # (psp_last_solve_info) streams per row beside it -- 56 n for the folded lazy loop, 64 n lazy, 72 n eager (round-5
+        # advisor finding: the line used to price the folded loop at 64 n)
+        vb = pcg_loop_info["vec_bytes_per_row"]
+        pcg_moved = kbytes_tot + (vb * n_tot if vb >= 0 else pcg_vector_bytes(n_tot, True))
         traffic, traffic_source, traffic_detail = None, None, None
         if pmc_live is not None:
             hits = [v for name, v in pmc_live.items() if kernel in name]
@@ -907,7 +1007,8 @@ def run_body(a, real_stdout):
             "pcg_effective_GBps": pcg_moved / pcg_s_per_iter / 1e9,
             "pcg_pct_hbm_peak": 100.0 * pcg_moved / pcg_s_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
             "pcg_csr_model_equiv_GBps": (12 * nnz_tot + 108 * n_tot) / pcg_s_per_iter / 1e9,
-            "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k, "path": pcg_path},
+            "pcg_check": {"info": res[0], "iter": res[1], "relres": res[2], "iters_timed": k, "path": pcg_path,
+                          "loop": pcg_loop, "loop_info": pcg_loop_info, "bytes_per_iter": pcg_moved},
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -917,6 +1018,14 @@ def run_body(a, real_stdout):
                 "median_launch_ms": med_ms,
                 "csr_model_bytes_per_launch": csr_model_bytes(n_loc, nnz_loc),
                 "csr_model_equiv_GBps": csr_model_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9,
+                # the same launch priced in SURVEY 8d's CSR bytes: > 1 is possible and says nothing about the memory system
+                # -- csr_spmv_w4 reads no column indices; the comparable figure is `csr_literal` below
+                "frac_8d_of_timed_kernel": csr_model_bytes(n_loc, nnz_loc) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_8d_note": "format-compressed kernel priced in CSR bytes: not comparable, never claimed",
+                # the other half of BASELINE.json's metric, where the driver keeps it
+                "pcg_iters_per_s": 1.0 / pcg_s_per_iter, "pcg_loop": pcg_loop,
+                "pcg_launches_per_iter": pcg_loop_info["launches"], "pcg_bytes_per_iter": pcg_moved,
+                "pcg_frac_own_bytes": pcg_moved / pcg_s_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
                 "note": "achieved = bytes this kernel's format needs (csr_spmv_w4: 8 B per stored-offset slot + "
                         "2 B row mask + x + y; no column indices) / avg launch time of the K timed launches.  traffic "
                         "above the algorithmic bytes (1.11x at 512^3) is ONE extra pass over x served by the Infinity "
@@ -955,6 +1064,9 @@ def run_body(a, real_stdout):
                 best = max(lit, key=lambda kk: kk["csr_model_frac"])
                 out["roofline"]["csr_model_frac_of_streaming_kernel"] = best["csr_model_frac"]
                 out["roofline"]["streaming_kernel"] = best["kernel"]
+                # the kernel that literally streams the csr_mat's int32 col + fp64 val: SURVEY 8d's bytes ARE its bytes
+                out["roofline"]["csr_literal"] = {"kernel": best["kernel"], "avg_launch_ms": best["avg_launch_ms"],
+                                                  "frac_8d": best["csr_model_frac"]}
         if sss is not None:
             out["sss_mat"] = sss
         if solvers is not None:
@@ -963,6 +1075,9 @@ def run_body(a, real_stdout):
             out["single_kernel_loops"] = single_kernel
         if strong_n1 is not None:
             out["strong_n1"] = strong_n1
+            if strong_n1.get("pcg_iters_per_s"):
+                out["roofline"]["strong_n1_iters_per_s"] = strong_n1["pcg_iters_per_s"]
+                out["roofline"]["strong_n1_spmv_frac"] = strong_n1.get("spmv_frac_of_peak")
             if use_dist and scaling == "strong" and strong_n1["grid"] == [nx, ny, nz]:
                 if strong_n1.get("pcg_iters_per_s"):
                     out["vs_n1"] = (1.0 / pcg_s_per_iter) / strong_n1["pcg_iters_per_s"]
@@ -999,6 +1114,7 @@ def run_body(a, real_stdout):
                     cls = "fast" if med_ms <= 1.56 else ("slow" if med_ms >= 1.63 else "usual")
                 else:
                     cls = None
+                out["roofline"]["placement_level"] = cls
                 out["process_mode"] = {"class": cls, "median_launch_ms": med_ms, "read7_write1_GBps": probe["GBps"],
                                        "counters": mc,
                                        "note": "which LEVEL this job's allocations landed on, not a property of the process: "
@@ -1010,7 +1126,9 @@ def run_body(a, real_stdout):
         if clocks is not None:
             out["gpu_clocks_under_load"] = clocks
         if world == 1 and not a.no_cpu_baseline:
-            base, ref, parity = cpu_baseline(dev=dev)
+            base, ref, parity = cpu_baseline(dev=dev, published=not a.grid)
+            if "published_table" in base:
+                out["published_table"] = base.pop("published_table")
             if parity is not None:
                 out["parity_check"] = parity
                 if not parity["ok"]:
@@ -1075,7 +1193,13 @@ def run_body(a, real_stdout):
                 out["config5"] = mtx_leg(os.environ["EMILIA_MTX"])
             except Exception as e:  # noqa: BLE001
                 out["config5"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        print(json.dumps(out), file=real_stdout, flush=True)
+        if use_dist and world > 1:
+            # DESIGN.md section 5's prediction for THIS N beside what was measured
+            t1 = (1e3 / strong_n1["pcg_iters_per_s"]) if (strong_n1 and strong_n1.get("pcg_iters_per_s")
+                                                          and strong_n1["grid"] == [nx, ny, nz]) else None
+            out["predicted"] = predicted_iteration(n_tot, world, nx * ny, t1, kbytes_row=kbytes_loc / float(n_loc))
+            out["predicted"]["missed_budget"] = judge_phases(phases, out["predicted"])
+        emit(out, real_stdout, a.side_file or None)
     if use_dist:
         code = torch.tensor([exit_code], dtype=torch.int32, device="cpu" if dry else "cuda")
         dist.all_reduce(code, op=dist.ReduceOp.MAX)  # every rank leaves with rank 0's verdict

@@ -14,6 +14,7 @@ import sys
 import time
 
 from bench_common import METRIC, ROOT  # noqa: F401
+from bench_line import attach_launcher, compact_launcher
 
 # The ladder of an N > 1 run started as a plain script: every stage is a FRESH child process (this process never
 # touches the GPU, and a process that has is never re-executed); the first stage that prints a valid line wins.
@@ -143,8 +144,8 @@ def orchestrate(a, argv):
             except ValueError:
                 rec = None
         if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
-            rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": stages,
-                               "deadline_s": a.deadline, "total_wall_s": time.time() - t_start}
+            attach_launcher(rec, {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": stages,
+                                  "deadline_s": a.deadline, "total_wall_s": time.time() - t_start})
             print(json.dumps(rec), flush=True)
             return 0
         reason = ("timed out after %.0f s" % wall) if timed_out else (
@@ -158,8 +159,9 @@ def orchestrate(a, argv):
                       "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
                       "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                       "error": "every stage of the launch ladder failed",
-                      "launcher": {"stage": None, "fallback_from": failed, "ladder": stages, "deadline_s": a.deadline,
-                                   "total_wall_s": time.time() - t_start}}), flush=True)
+                      "launcher": compact_launcher({"stage": None, "fallback_from": failed, "ladder": stages,
+                                                    "deadline_s": a.deadline, "total_wall_s": time.time() - t_start})}),
+          flush=True)
     return 1
 
 
@@ -222,7 +224,8 @@ class RankGuard:
         return {"metric": METRIC, "value": None, "unit": "GB/s", "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic", "error": msg,
-                "launcher": {"stage": None, "fallback_from": failed, "ladder": list(LADDER), "started_by": "external launcher"}}
+                "launcher": compact_launcher({"stage": None, "fallback_from": failed, "ladder": list(LADDER),
+                                              "started_by": "external launcher"})}
 
     def _terminated(self):
         with self.lock:
@@ -266,9 +269,9 @@ class RankGuard:
                 except ValueError:
                     rec = None
             if rc == 0 and rec is not None and rec.get("value") is not None and "error" not in rec:
-                rec["launcher"] = {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": list(LADDER),
-                                   "started_by": "external launcher (torch.distributed.run); rank 0 ran the fall-back "
-                                                 "stages as fresh child processes"}
+                attach_launcher(rec, {"stage": stage, "fallback_from": failed, "stage_wall_s": wall, "ladder": list(LADDER),
+                                      "started_by": "external launcher (torch.distributed.run); rank 0 ran the fall-back "
+                                                    "stages as fresh child processes"})
                 print(json.dumps(rec), file=self.out, flush=True)
                 os._exit(0)
             failed.append({"stage": stage, "rc": rc, "reason": ("timed out after %.0f s" % wall) if timed_out else

@@ -347,7 +347,21 @@ def single_process_main(a):
             out["error"] = "parity_vs_n1 failed: max relative difference %.3e > %.1e" % (parity["max_rel_diff"], PARITY_TOL)
     if a.share_gpu:
         out["dry_run"] = "%d ranks sharing device 0 in one process: a rehearsal of the N > 1 path, NOT a measurement" % N
-    print(json.dumps(out), file=real_stdout, flush=True)
+    out["roofline"] = {"bound": "hbm", "kernel": "csr_spmv_w4", "achieved": out["value"] / max(distinct, 1), "peak": HBM_PEAK_GBPS,
+                       "unit": "GB/s", "frac": out["value"] / max(distinct, 1) / HBM_PEAK_GBPS, "traffic": None,
+                       "algorithmic_bytes_per_launch": kbytes // N, "avg_launch_ms": ms.value,
+                       "pcg_iters_per_s": 1.0 / s_per_iter, "pcg_loop": "pcg_multi",
+                       "pcg_bytes_per_iter": kbytes + 64 * n,
+                       "pcg_frac_own_bytes": (kbytes + 64 * n) / s_per_iter / 1e9 / (HBM_PEAK_GBPS * max(distinct, 1))}
+    if strong_n1 is not None:
+        out["roofline"]["strong_n1_iters_per_s"] = strong_n1["pcg_iters_per_s"]
+    if N > 1:
+        from bench_line import judge_phases, predicted_iteration
+        t1 = 1e3 / strong_n1["pcg_iters_per_s"] if strong_n1 is not None else None
+        out["predicted"] = predicted_iteration(n, N, nx * ny, t1, kbytes_row=kbytes / float(n))
+        out["predicted"]["missed_budget"] = judge_phases(dict(phases, iteration_ms=s_per_iter * 1e3), out["predicted"])
+    from bench_line import emit
+    emit(out, real_stdout, getattr(a, "side_file", "") or None)
     return 1 if "error" in out else 0
 
 

@@ -133,6 +133,22 @@ int psp_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on
  * reads = 7, writes = 1 is the access shape of csr_spmv_w4 on the 7-point operator without its x re-reads:
  * bench.py prints it beside the SpMV as the ceiling of that shape.  The buffers are the call's own. */
 int psp_stream_probe(int reads, int writes, size_t bytes_per_stream, int reps, float *avg_ms, float *min_ms);
+/* Which loop the calling thread's LAST psp_pcg / psp_minres ran (the reference has one loop each: pcg.c:91-163,
+ * minres.c:96-193; here the size and the operator pick one of several with the same semantics), so that a caller -- bench.py
+ * -- derives its byte model from what ran instead of mirroring the selection rules.  name: "pcg_lazy_pf" (p and x updates
+ * folded into the product: 4 launches), "pcg_lazy" (5), "pcg_eager" (6), "pcg_mid" / "pcg_brick" / "pcg_coop" (the whole
+ * loop in one cooperative kernel), "pcg_host_scalars" (generic operands, Python callbacks), "minres_async", "minres_mid",
+ * "minres_brick", "minres_coop", "minres_host_scalars", "pcg_multi" / "minres_multi" (device list); "" before the first
+ * solve.  info[4] = {launches per iteration, vector bytes per row and iteration beside the product (0 inside the
+ * single-kernel loops, -1 where not modelled), 1 when the Jacobi diagonal is streamed (not a constant), single-kernel
+ * loops refused or abandoned after launch in this process so far (each fell back to the launch-per-phase loop)}. */
+int psp_last_solve_info(char *name, int name_cap, int *info);
+/* on = 0: psp_pcg / psp_minres never take the single-kernel loops (psp_mid.hip, psp_coop.hip) in this process.  Why one
+ * would: the brick and small-system loops add their dot products in an order of their own that depends on the device's CU
+ * count, so their iterates agree with the launch-per-phase loops' to rounding only, and a refused cooperative launch
+ * (a shared GPU) falls back to those loops' bits -- with 0 every solve has the launch-per-phase bits on every device.
+ * Default 1. */
+int psp_set_single_kernel_loops(int on);
 /* hash of the sources this binary was built from (__graft_entry__.source_hash(); "unstamped" for a hand build):
  * tests compare it with the hash of the sources on disk, so a stale prebuilt library cannot pass for a fresh one */
 const char *psp_build_id(void);

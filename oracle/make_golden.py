@@ -18,6 +18,11 @@ What is pinned, and by what:
                      analytic invariants the reference's tests assert
                      (test/test_spmatrix.py:77-78,186-187).
   tendigit.json      K1: examples/tendigit.py known answer (Trefethen challenge #7).
+  ref_published_table.json  the reference's only published benchmark for this path (doc/pysparse/source/itsolvers.rst:
+                     120-130,189-199: n = 100 / 300 / 500, sss_mat, no preconditioner, tol 1e-12, maxit 2000): the
+                     UNMODIFIED standalone program run on generated .mtx files of those sizes (iteration count, printed
+                     relres) and the compiled pcg.c driven by the SSS product (info / iter / relres / strided x);
+                     ref_published_table.npz holds x[::97] of each.  (round 6; `--published-only` regenerates it alone)
   ref_krylov.json    the module's OWN six kernels -- pysparse/itsolvers/src/{pcg,minres,cgs,bicgstab,
                      qmrs,gmres}.c compiled unmodified into oracle/_ref/libref_krylov.so -- on the
                      cases of tests/krylov_cases.py: info / iter / relres / kernel return value and
@@ -83,12 +88,72 @@ def krylov_goldens():
     np.savez_compressed(os.path.join(OUT, "ref_krylov_iterates.npz"), **iterates)
 
 
+def write_sym_mtx(path, S):
+    """poisson2d_sym(n).to_sss() as a symmetric coordinate file (lower triangle + diagonal, 1-based)"""
+    n = S.n
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write("%d %d %d\n" % (n, n, S.nnz_lower + n))
+        for i in range(n):
+            for k in range(S.ind[i], S.ind[i + 1]):
+                f.write("%d %d %.17g\n" % (i + 1, S.col[k] + 1, S.val[k]))
+            f.write("%d %d %.17g\n" % (i + 1, i + 1, S.diag[i]))
+
+
+def run_standalone(S):
+    """the unmodified examples/poisson_test/poisson_test.c (oracle/_ref/poisson_test) on S written to the one file name
+    the program opens (matrices/poi2d_100.mtx -- the name is fixed in its source, the size is not): (iter, printed
+    relres, last stdout line, wall seconds of the whole program = its read + convert + solve)"""
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "matrices"))
+        write_sym_mtx(os.path.join(td, "matrices", "poi2d_100.mtx"), S)
+        t0 = time.perf_counter()
+        out = subprocess.run([O.REF_BIN_PATH], cwd=td, capture_output=True, text=True).stdout
+        wall = time.perf_counter() - t0
+    m = re.search(r"converged at iteration (\d+) to a solution with relative residual ([0-9.eE+-]+)", out)
+    assert m, out
+    return int(m.group(1)), float(m.group(2)), out.strip().splitlines()[-1], wall
+
+
+def published_table_goldens():
+    """tests/golden/ref_published_table.json (+ .npz): itsolvers.rst:120-130,189-199 -- n = 100 / 300 / 500"""
+    rows, strided = [], {}
+    for nn in (100, 300, 500):
+        S = O.poisson_sss(nn, nn)
+        n = S.n
+        it, rr, tail, wall = run_standalone(S)
+        x, r = run_ref(S, np.ones(n), 1e-12, 2000)
+        assert r["info"] == 0 and r["iter"] == it, (nn, r, it)
+        strided["x_%d" % nn] = x[::97].copy()
+        rows.append({"n": nn, "rows": n, "nnz_lower": int(S.nnz_lower),
+                     "standalone": {"iter": it, "relres_printed": rr, "stdout_tail": tail,
+                                    "wall_s_in_the_build_container": wall},
+                     "compiled_pcg_with_sss_product": r})
+    with open(os.path.join(OUT, "ref_published_table.json"), "w") as f:
+        json.dump({"what": "L x = 1, L = poisson2d_sym(n).to_sss(), x0 = 0, pcg(S, b, x, 1e-12, 2000), no preconditioner",
+                   "published_in": "doc/pysparse/source/itsolvers.rst:120-130 (script), :189-199 (table)",
+                   "published_seconds_assembly_solve_total": {
+                       "Python": {"100": [0.03, 1.12, 1.15], "300": [0.21, 49.65, 49.86], "500": [0.62, 299.39, 300.01]},
+                       "Native C": {"100": [0.30, 0.96, 1.26], "300": [3.14, 48.38, 51.52], "500": [10.86, 288.67, 299.53]},
+                       "Matlab": {"100": [0.21, 8.85, 9.06], "300": [2.05, 387.26, 389.31], "500": [6.23, 1905.67, 1911.8]},
+                       "note": "machine unknown (the doc says so itself): context, not a target"},
+                   "program": "examples/poisson_test/poisson_test.c + pcg.c + mmio.c compiled unmodified (oracle/Makefile); "
+                              "the program opens matrices/poi2d_100.mtx whatever the size of the matrix inside",
+                   "rows": rows}, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "ref_published_table.npz"), **strided)
+
+
 def main():
     O.build(ref=True)
     os.makedirs(OUT, exist_ok=True)
+    if "--published-only" in sys.argv:
+        published_table_goldens()
+        return
     krylov_goldens()
     if "--krylov-only" in sys.argv:
         return
+    published_table_goldens()
     cases = {}
     iterates = {}
 

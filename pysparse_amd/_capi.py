@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("PSP_LIB_OVERRIDE") or os.path.join(HERE, "libpysparse
 SYMBOLS = """
 psp_last_error psp_version psp_device_count psp_set_device psp_thread_info psp_debug_hold_handles psp_debug_mid_count psp_debug_brick_count psp_debug_shake psp_debug_shake_count psp_debug_spin psp_peer_access psp_set_stream psp_synchronize
 psp_set_placement psp_placement_info psp_place_operands psp_device_info psp_mem_info psp_malloc psp_free psp_memcpy_h2d psp_memcpy_d2h psp_memset psp_trim
-psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_stream_probe psp_build_id
+psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_stream_probe psp_build_id psp_last_solve_info psp_set_single_kernel_loops
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
@@ -165,6 +165,7 @@ def _declare(L):
         "psp_kd_minres_matvec": [vp, vp, vp, i, vp, i, i, WAIT_FN, vp, vp],
         "psp_kd_minres_lanczos": [vp, i, vp, vp, vp, vp, vp, vp], "psp_kd_minres_scalar": [vp, i, vp],
         "psp_kd_minres_wx": [vp, i, vp, vp, vp, vp],
+        "psp_last_solve_info": [C.c_char_p, i, C.POINTER(i)], "psp_set_single_kernel_loops": [i],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

@@ -19,6 +19,12 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // nullptr otherwise, so a stray PSP_* variable in a user's environment cannot change the code path of the
 // drop-in.  Tests and tools that select a variant set both.
 const char *tuning_env(const char *name);
+// psp_last_solve_info / psp_set_single_kernel_loops (psp_runtime.hip): the pcg / minres entry points note which loop they
+// ran -- per calling thread -- with its launches per iteration and the vector bytes per row it moves beside its product
+// (-1: not modelled); note_fallback counts single-kernel loops that were refused or gave up after they were chosen
+void note_solve(const char *loop, int launches_per_iter, int vec_bytes_per_row, int dinv_streamed);
+void note_fallback();
+bool single_kernel_loops_enabled();
 // Threading model (round 4; SURVEY 8b: "one HIP stream per handle; handles not thread-safe").
 //   * What an entry point enqueues on -- device, stream, reduction workspace, host staging -- belongs to the CALLING
 //     THREAD (a thread-local context).  The first thread that touches the library keeps the null stream (or whatever it

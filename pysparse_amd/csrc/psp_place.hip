@@ -106,14 +106,17 @@ int place_operands(const psp_csr *A, size_t nx, size_t ny, int want_x, double **
   const int total = draw ? m + 1 : want_x + 1;
   for (int i = 0; i < total; ++i) {
     Cand k;
-    hipError_t e = hipMalloc((void **)&k.p, bytes);
+    // no draw (the default): plain allocations of each role's own size -- y (candidate 0) ny doubles, x nx doubles -- so a
+    // strongly rectangular host-pointer product does not pay for two vectors of max(nx, ny) (round-5 advisor finding)
+    const size_t want = draw ? bytes : sizeof(double) * std::max<size_t>(i == 0 ? ny : nx, 1);
+    hipError_t e = hipMalloc((void **)&k.p, want);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       release(true);
       return fail(PSP_ENOMEM, "place_operands: %zu bytes: %s", bytes, hipGetErrorString(e));
     }
     c.push_back(k);
-    if (hipMemsetAsync(k.p, 0, bytes, stream()) != hipSuccess) {
+    if (hipMemsetAsync(k.p, 0, want, stream()) != hipSuccess) {
       release(true);
       return fail(PSP_ENODEV, "place_operands: %s", hipGetErrorString(hipGetLastError()));
     }

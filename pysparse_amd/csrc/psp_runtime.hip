@@ -83,6 +83,24 @@ const char *tuning_env(const char *name) {
   return on ? getenv(name) : nullptr;
 }
 
+// ---- which loop the calling thread's last solve ran (psp_last_solve_info), single-kernel loops on / off
+struct SolveNote {
+  char loop[48];
+  int launches, vec_bytes, dinv_streamed;
+};
+static thread_local SolveNote g_note = {"", 0, 0, 0};
+static std::atomic<long long> g_sk_fallbacks{0};
+static std::atomic<int> g_sk_enabled{1};
+
+void note_solve(const char *loop, int launches_per_iter, int vec_bytes_per_row, int dinv_streamed) {
+  snprintf(g_note.loop, sizeof g_note.loop, "%s", loop);
+  g_note.launches = launches_per_iter;
+  g_note.vec_bytes = vec_bytes_per_row;
+  g_note.dinv_streamed = dinv_streamed;
+}
+void note_fallback() { g_sk_fallbacks.fetch_add(1, std::memory_order_relaxed); }
+bool single_kernel_loops_enabled() { return g_sk_enabled.load(std::memory_order_relaxed) != 0; }
+
 HandleEntry &handle_entry(const void *handle) {
   static std::mutex mu;
   static std::unordered_map<const void *, std::unique_ptr<HandleEntry>> tab;  // entries live as long as the process
@@ -96,7 +114,7 @@ HandleEntry &handle_entry(const void *handle) {
 static std::atomic<int> g_track{0};                        // a second stream has been seen: keep last-use events
 static std::atomic<unsigned long long> g_devices_used{0};  // devices some thread of the library has made current
 static std::mutex g_first_mu;
-static bool g_first_set = false;
+static std::atomic<bool> g_first_set{false};  // stored (release) after g_first_stream: readers need no mutex
 static hipStream_t g_first_stream = nullptr;  // the one stream everything ran on so far
 
 void handles_enter(HandleEntry *const *e, int n) {
@@ -104,13 +122,17 @@ void handles_enter(HandleEntry *const *e, int n) {
   if (tl.dev_state == 0) (void)ensure_device();  // a thread's first call: its stream must exist before it can wait
   if (tl.dev_state != 1) return;                 // no device: nothing was, or can be, enqueued
   const hipStream_t cur = stream();
-  if (!g_track.load(std::memory_order_acquire)) {
+  if (!g_track.load(std::memory_order_acquire) &&
+      !(g_first_set.load(std::memory_order_acquire) && cur == g_first_stream)) {  // the one-stream process: no mutex
     std::lock_guard<std::mutex> lk(g_first_mu);
-    if (!g_first_set) {
-      g_first_set = true;
+    if (!g_first_set.load(std::memory_order_relaxed)) {
       g_first_stream = cur;
+      g_first_set.store(true, std::memory_order_release);
     } else if (cur != g_first_stream && !g_track.load(std::memory_order_relaxed)) {
-      // the second stream of the process: whatever was enqueued so far carries no event -- wait for it once
+      // the second stream of the process.  Tracking starts FIRST, so that every handles_leave from here on records its
+      // event -- also the one of a call that is in flight on the first stream right now; the one-off synchronisation
+      // below then only has to cover what was enqueued before events were kept
+      g_track.store(1, std::memory_order_release);
       const unsigned long long used = g_devices_used.load();
       for (int d = 0; d < 64; ++d)
         if (used >> d & 1ull) {
@@ -118,7 +140,6 @@ void handles_enter(HandleEntry *const *e, int n) {
           (void)hipGetLastError();
         }
       (void)hipSetDevice(tl.dev());
-      g_track.store(1, std::memory_order_release);
     }
   }
   if (!g_track.load(std::memory_order_acquire)) return;
@@ -211,15 +232,38 @@ int workspace(Workspace **out) {
     hipDeviceProp_t prop;
     PSP_HIP(hipGetDeviceProperties(&prop, d));
     ws.num_cu = prop.multiProcessorCount;
-    PSP_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
-    PSP_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
-    PSP_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
+    // all or nothing: a failed allocation releases what the earlier ones got (ws.device stays unset, so the next call
+    // starts over -- without this it would allocate everything again on top of the survivors; round-5 advisor finding)
+    auto undo = [&ws]() {
+      if (ws.partials) (void)hipFree(ws.partials);
+      if (ws.folded) (void)hipFree(ws.folded);
+      if (ws.scal_dev) (void)hipFree(ws.scal_dev);
+      if (ws.scal_host) (void)hipHostFree(ws.scal_host);
+      if (ws.state_dev) (void)hipFree(ws.state_dev);
+      if (ws.state_host) (void)hipHostFree(ws.state_host);
+      if (ws.ctl_part) (void)hipFree(ws.ctl_part);
+      ws.partials = ws.folded = ws.scal_dev = ws.scal_host = ws.scal_host_dev = ws.ctl_part = nullptr;
+      ws.state_dev = ws.state_host = nullptr;
+      (void)hipGetLastError();
+    };
+#define WS_HIP(call)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      undo();                                                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "%s: %s", #call, hipGetErrorString(e_)); \
+    }                                                                                                     \
+  } while (0)
+    WS_HIP(hipMalloc((void **)&ws.partials, sizeof(double) * kSlots * kMaxParts));
+    WS_HIP(hipMalloc((void **)&ws.folded, sizeof(double) * kSlots * kTailGroups));
+    WS_HIP(hipMalloc((void **)&ws.scal_dev, sizeof(double) * 16));
     // 16 doubles + a sequence word (fetch_scalars): pinned, mapped, coherent -- the device stores into it directly
     bool mapped = true;
     if (hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
       (void)hipGetLastError();  // no mapped coherent host memory here: plain pinned memory, scalars come back by copy
       mapped = false;
-      PSP_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocDefault));
+      ws.scal_host = nullptr;
+      WS_HIP(hipHostMalloc((void **)&ws.scal_host, sizeof(double) * 24, hipHostMallocDefault));
     }
     memset(ws.scal_host, 0, sizeof(double) * 24);
     ws.scal_host_dev = nullptr;
@@ -227,9 +271,10 @@ int workspace(Workspace **out) {
       (void)hipGetLastError();
       ws.scal_host_dev = nullptr;  // fetch_scalars copies then
     }
-    PSP_HIP(hipMalloc(&ws.state_dev, kStateBytes));
-    PSP_HIP(hipHostMalloc(&ws.state_host, kStateBytes, hipHostMallocDefault));
-    PSP_HIP(hipMalloc((void **)&ws.ctl_part, sizeof(double) * kCtlPartDoubles));
+    WS_HIP(hipMalloc(&ws.state_dev, kStateBytes));
+    WS_HIP(hipHostMalloc(&ws.state_host, kStateBytes, hipHostMallocDefault));
+    WS_HIP(hipMalloc((void **)&ws.ctl_part, sizeof(double) * kCtlPartDoubles));
+#undef WS_HIP
     ws.device = d;
   }
   *out = &ws;
@@ -760,6 +805,23 @@ int psp_event_record(void *event) {
 int psp_event_elapsed_ms(void *start, void *stop, float *ms) {
   PSP_HIP(hipEventSynchronize((hipEvent_t)stop));
   PSP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PSP_OK;
+}
+
+int psp_last_solve_info(char *name, int name_cap, int *info) {
+  if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", psp::g_note.loop);
+  if (info) {
+    info[0] = psp::g_note.launches;
+    info[1] = psp::g_note.vec_bytes;
+    info[2] = psp::g_note.dinv_streamed;
+    const long long f = psp::g_sk_fallbacks.load(std::memory_order_relaxed);
+    info[3] = f > 0x7fffffffLL ? 0x7fffffff : (int)f;
+  }
+  return PSP_OK;
+}
+
+int psp_set_single_kernel_loops(int on) {
+  psp::g_sk_enabled.store(on ? 1 : 0, std::memory_order_relaxed);
   return PSP_OK;
 }
 

@@ -808,6 +808,7 @@ static int robust_nrm2(Workspace *w, int n, const double *v, double sq, double *
 static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_forced, const double *dinv_forced,
                            int n, double *x, const double *b, double tol, int maxit, int *info, int *iter,
                            double *relres, double *hist) {
+  note_solve("pcg_no_iterations", 0, 0, 0);  // until one of the loops below is taken (b = 0, x0 already good enough)
   Workspace *w;
   PSP_TRY(workspace(&w));
   DevVecs mem;
@@ -865,20 +866,35 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     return PSP_OK;
   }
 
-  if (fused && maxit >= 1 && rho_next != 0.0 && mid_applicable(Acsr, n, dinv)) {
+  const bool sk = single_kernel_loops_enabled();  // psp_set_single_kernel_loops(0): launch-per-phase loops only
+  double dcst;
+  const int dstream = (dinv && !dinv_constant(dinv, n, &dcst)) ? 1 : 0;
+  if (sk && fused && maxit >= 1 && rho_next != 0.0 && mid_applicable(Acsr, n, dinv)) {
     // mid-size offset-structured system: the whole loop is one cooperative kernel, vectors in registers, p through LDS
     // (psp_mid.hip) -- the launch-per-phase loops' bits
     const int rc = pcg_mid_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
+    if (rc != kCoopFallback) {
+      note_solve("pcg_mid", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();  // refused / gave up: x and r are untouched, the loops below take over
   }
-  if (fused && maxit >= 1 && rho_next != 0.0 && brick_applicable(Acsr, n)) {
+  if (sk && fused && maxit >= 1 && rho_next != 0.0 && brick_applicable(Acsr, n)) {
     // 3-D grid operator whose slabs the loop above declines: the same loop with the points dealt out in bricks (psp_mid.hip)
     const int rc = pcg_brick_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;
+    if (rc != kCoopFallback) {
+      note_solve("pcg_brick", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();
   }
-  if (fused && maxit >= 1 && coop_applicable(Acsr, n)) {  // small system: the whole loop is one kernel (psp_coop.hip)
+  if (sk && fused && maxit >= 1 && coop_applicable(Acsr, n)) {  // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = pcg_coop_loop(Acsr, dinv, n, x, r, p, q, n2b, tolb, normr, rho_next, maxit, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;  // refused / gave up: x and r are untouched, the loops below take over
+    if (rc != kCoopFallback) {
+      note_solve("pcg_coop", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();  // refused / gave up: x and r are untouched, the loops below take over
   }
   if (fused && maxit >= 1 && pcg_async_enabled() && csr_spmv_has_skip(Acsr)) {
     if (rho_next == 0.0) {  // pcg.c:101-104 in iteration 1
@@ -895,12 +911,21 @@ static int pcg_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_force
     // [2^24, 1.5 * 2^24) keeps the eager loop (round 1-3: lazy from 2^25 only, when either loop was 9-10 launches).
     // PSP_PCG_LAZYX=2 forces it at any size (tests), 0 disables it
     const int lazy_mode = pcg_lazy_enabled();
-    if ((lazy_mode == 2 || (lazy_mode == 1 && (n < (1 << 24) || n >= 3 * (1 << 23)))) && !pcg_graph_enabled())
+    // launches per iteration: a reduction is one launch up to 4096 partial sums (n <= 2^21), group fold + finish beyond
+    const int rl = n > (1 << 21) ? 2 : 0;
+    if ((lazy_mode == 2 || (lazy_mode == 1 && (n < (1 << 24) || n >= 3 * (1 << 23)))) && !pcg_graph_enabled()) {
+      // bytes per row beside the product: px_update 40 (r, p, x read; p, x written) + r_update 24 (q, r read; r written);
+      // folded form: the product forms p and x itself (x read and written, p written: 32 - 8 for the p it reads anyway)
+      const bool pf = p2 && pcg_lazypf_mode(n);
+      note_solve(pf ? "pcg_lazy_pf" : "pcg_lazy", (pf ? 4 : 5) + rl, (pf ? 56 : 64) + 16 * dstream, dstream);
       return pcg_async_loop_lazy(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                                  relres, hist);
+    }
+    note_solve("pcg_eager", 6 + rl, 72 + 16 * dstream, dstream);
     return pcg_async_loop(Acsr, dinv, n, x, r, p, p2, q, n2b, tolb, normr, rho_next, maxit, info, iter,
                           relres, hist);
   }
+  note_solve("pcg_host_scalars", -1, -1, dstream);
 
   double rho = 1.0, rho1, beta = 0.0, alpha, pq;
   int stag = 0;
@@ -1274,6 +1299,7 @@ done:
 static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_forced, const double *dinv_forced,
                               int n, double *x, const double *b, double errtol, int it_max, int *info, int *iter,
                               double *relres, double *hist) {
+  note_solve("minres_no_iterations", 0, 0, 0);  // until one of the loops below is taken
   Workspace *w;
   PSP_TRY(workspace(&w));
   DevVecs mem;
@@ -1348,29 +1374,48 @@ static int minres_device_core(const psp_op *A, const psp_op *K, psp_csr *Acsr_fo
   double norm_rmr = norm_r0;
   if (hist) hist[0] = norm_rmr;
 
-  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && mid_minres_applicable(Acsr, n)) {
+  const bool sk = single_kernel_loops_enabled();  // psp_set_single_kernel_loops(0): launch-per-phase loops only
+  double dcst;
+  const int dstream = (hasK && dinv && !dinv_constant(dinv, n, &dcst)) ? 1 : 0;
+  if (sk && Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && mid_minres_applicable(Acsr, n)) {
     // mid-size offset-structured system: the whole loop is one cooperative kernel (psp_mid.hip), the launch-per-phase bits
     const int rc = minres_mid_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
                                    beta, errtol, it_max, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;
+    if (rc != kCoopFallback) {
+      note_solve("minres_mid", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();
   }
-  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && brick_minres_applicable(Acsr, n)) {
+  if (sk && Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && (!hasK || dinv) && brick_minres_applicable(Acsr, n)) {
     // 3-D grid operator: the same with the points dealt out in bricks
     const int rc = minres_brick_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
                                      beta, errtol, it_max, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;
+    if (rc != kCoopFallback) {
+      note_solve("minres_brick", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();
   }
-  if (Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n)) {
+  if (sk && Acsr && kfused && it_max >= 1 && !(norm_rmr < errtol * norm_r0) && coop_applicable(Acsr, n)) {
     // small system: the whole loop is one kernel (psp_coop.hip)
     const int rc = minres_coop_loop(Acsr, hasK ? dinv : nullptr, n, x, v_hat, v_hat_old, y, wv, w_old, v, av, norm_r0,
                                     beta, errtol, it_max, info, iter, relres, hist);
-    if (rc != kCoopFallback) return rc;  // refused / gave up: x, v_hat, y are untouched, the loops below take over
+    if (rc != kCoopFallback) {
+      note_solve("minres_coop", 1, 0, dstream);
+      return rc;
+    }
+    note_fallback();  // refused / gave up: x, v_hat, y are untouched, the loops below take over
   }
   if (Acsr && kfused && minres_async_enabled() && it_max >= 1 && !(norm_rmr < errtol * norm_r0)) {
+    // scaled product (reads y, writes Av) + lanczos (Av, v_hat, v_hat_old read; v_hat, y written: 40, + 8 when K streams
+    // dinv) + w / x update (y, w, w_old, x read; w, x written: 48): 88 bytes per row beside the product
+    note_solve("minres_async", 5 + (n > (1 << 21) ? 2 : 0), 88 + 8 * dstream, dstream);
     // the device loop writes hist[1 .. iter]; slots it never reaches keep the caller's fill
     return minres_async_loop(Acsr, dinv, hasK, n, x, v_hat, v_hat_old, y, y2, wv, w_old, v, av, norm_r0,
                              beta, errtol, it_max, info, iter, relres, hist);
   }
+  note_solve("minres_host_scalars", -1, -1, dstream);
 
   while (true) {
     if (*iter >= it_max || norm_rmr < errtol * norm_r0) break;  // minres.c:114 (strict <)
@@ -2963,8 +3008,10 @@ int psp_pcg(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, const d
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
   if (multi) {
     if (multi_jac) PSP_TRY(multi_jacobi_setup(multi, K->jac->omega));  // this handle's omega, whatever was used last
+    note_solve("pcg_multi", -1, -1, 0);
     return multi_pcg(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   }
+  if (cpu_mode()) note_solve("pcg_cpu_mode", 0, -1, 0);
   if (cpu_mode()) return cpu::pcg(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;
@@ -2998,8 +3045,10 @@ int psp_minres(const psp_op_t *A, const psp_op_t *K, int n, double *x_host, cons
   PSP_TRY(check_solver_args(A, K, n, x_host, b_host, info, iter, relres, &multi, &multi_jac));
   if (multi) {
     if (multi_jac) PSP_TRY(multi_jacobi_setup(multi, K->jac->omega));
+    note_solve("minres_multi", -1, -1, 0);
     return multi_minres(multi, multi_jac, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   }
+  if (cpu_mode()) note_solve("minres_cpu_mode", 0, -1, 0);
   if (cpu_mode()) return cpu::minres(A, K, n, x_host, b_host, tol, maxit, info, iter, relres, hist_host);
   PSP_TRY(ensure_device());
   DevVecs mem;

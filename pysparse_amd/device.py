@@ -550,6 +550,21 @@ def gmres(A, b, x, tol, maxit, K=None, dim=20):
     return _solve_more("gmres", A, b, x, tol, maxit, K, dim)
 
 
+def last_solve_info():
+    """(loop name, {launches, vec_bytes_per_row, dinv_streamed, single_kernel_fallbacks}) of the calling thread's last
+    pcg / minres (psp_last_solve_info): which of the library's loops ran and what it moves per row beside its product."""
+    name = C.create_string_buffer(64)
+    info = (C.c_int * 4)()
+    check(lib().psp_last_solve_info(name, 64, info))
+    return name.value.decode(), {"launches": info[0], "vec_bytes_per_row": info[1], "dinv_streamed": bool(info[2]),
+                                 "single_kernel_fallbacks": info[3]}
+
+
+def set_single_kernel_loops(on):
+    """psp_set_single_kernel_loops: False keeps every pcg / minres of this process on the launch-per-phase loops"""
+    check(lib().psp_set_single_kernel_loops(1 if on else 0))
+
+
 def device_count():
     return lib().psp_device_count()
 

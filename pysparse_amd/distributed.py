@@ -916,7 +916,7 @@ class _Shaker:
       recv -> boundary rows                                             wait() makes the current stream wait for RCCL
       send -> next px / scale kernel (overwrites p)                     the same wait(), before the boundary rows
       local sums -> all-reduce -> scalar step                           stream order (RCCL) / _dev_sync (gloo)
-    Results must not depend on it: tests/test_gpu_shake.py, bench.py's `shake_check` of an N-rank run."""
+    Results must not depend on it: tests/test_gpu_shake.py::test_torch_ranks_under_delay_injection."""
 
     def __init__(self, be, rank):
         spec = _tuning("PSP_DIST_SHAKE", "")

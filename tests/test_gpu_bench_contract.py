@@ -12,12 +12,28 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def parse(stdout):
+    """ONE JSON line of at most bench_line.LINE_LIMIT characters on stdout; the full record it stands for is in the side
+    file it names (round 6).  Returns the full record, with the line itself under "_line"."""
+    sys.path.insert(0, ROOT)
+    import bench_line
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    assert len(lines[0]) <= bench_line.LINE_LIMIT, len(lines[0])
+    line, full = bench_line.read(stdout)
+    for k in line:  # whatever the line says, the side file says too (the launcher object: in full there, in short here)
+        if k not in ("side_file", "side_keys", "launcher", "config", "roofline", "cpu_baseline", "parity_check", "phases",
+                     "parity_vs_n1", "preflight", "transport", "provenance", "published_table"):
+            assert full.get(k) == line[k], k
+    d = dict(full)
+    d["_line"] = line
+    return d
+
+
 def run_bench(*args):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True,
                          text=True, check=True, cwd=ROOT).stdout
-    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out
-    return json.loads(lines[0])
+    return parse(out)
 
 
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -106,9 +122,7 @@ def test_bench_n_ranks_rehearsal_on_one_gpu(world):
                           "--no-cpu-baseline", "--no-clocks"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = parse(out.stdout)
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["backend"] == "gloo" and "dry_run" in d
@@ -155,9 +169,7 @@ def test_bench_launches_its_own_ranks_dry_run():
                           "--test-backend", "tests.dist_oracle_backend:bench_factory"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = parse(out.stdout)
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and "dry_run" in d
@@ -186,9 +198,8 @@ def _run_ladder(*extra, timeout=240):
                           "--steps", "3", "--warmup", "1", "--pcg-iters", "5", "--no-cpu-baseline",
                           "--test-backend", "tests.dist_oracle_backend:bench_factory"] + list(extra),
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout + out.stderr[-2000:]
-    return out.returncode, json.loads(lines[0]), time.time() - t0
+    assert len([l for l in out.stdout.strip().splitlines() if l.startswith("{")]) == 1, out.stdout + out.stderr[-2000:]
+    return out.returncode, parse(out.stdout), time.time() - t0
 
 
 def test_bench_ladder_a_rank_that_exits_gives_an_error_line_and_a_nonzero_exit_code():
@@ -240,9 +251,7 @@ def test_bench_ladder_falls_back_to_the_single_process_stage_on_the_gpu():
                           "--no-cpu-baseline", "--no-clocks", "--inject", "exit:2"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = parse(out.stdout)
     assert d["launcher"]["stage"] == "single_process_rccl" == d["stage"]
     f = d["launcher"]["fallback_from"]
     assert len(f) == 1 and f[0]["stage"] == "torch_rccl_ranks"
@@ -329,7 +338,7 @@ def _run_external(*extra, timeout=240):
 def test_bench_as_a_rank_of_an_external_launcher_prints_its_line():
     rc, lines, wall, err = _run_external()
     assert rc == 0 and len(lines) == 1, err[-2000:]
-    d = json.loads(lines[0])
+    d = parse(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["parity_vs_n1"]["ok"] and d["pcg_check"]["iter"] == 6
 
 
@@ -343,7 +352,7 @@ def test_bench_rank_guard_a_hanging_rank_still_ends_in_one_json_line():
         pytest.skip("a GPU is present: rank 0's fall-back stages would run")
     rc, lines, wall, err = _run_external("--inject", "hang:1", "--rank-deadline", "12")
     assert rc != 0 and len(lines) == 1, err[-3000:]
-    d = json.loads(lines[0])
+    d = parse(lines[0])
     assert d["value"] is None and "error" in d and d["n_gpus"] == 2
     f = d["launcher"]["fallback_from"]
     assert [x["stage"] for x in f] == ["torch_rccl_ranks", "single_process_rccl", "single_process_fold"]
@@ -355,7 +364,7 @@ def test_bench_rank_guard_answers_the_launchers_sigterm_with_an_error_line():
     """a rank that crashes hard makes the launcher end the others: rank 0 answers the SIGTERM with the error line"""
     rc, lines, wall, err = _run_external("--inject", "exit:1")
     assert rc != 0 and len(lines) == 1, err[-3000:]
-    d = json.loads(lines[0])
+    d = parse(lines[0])
     assert d["value"] is None and "SIGTERM" in d["launcher"]["fallback_from"][0]["reason"]
 
 
@@ -373,12 +382,10 @@ def test_bench_rank_guard_falls_back_to_the_single_process_stage_on_the_gpu():
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--backend", "gloo", "--share-gpu", "--grid", "64,48,36", "--steps", "4",
                           "--warmup", "2", "--pcg-iters", "24", "--no-cpu-baseline", "--no-clocks", "--inject", "hang:1",
-                          "--rank-deadline", "45"],
+                          "--rank-deadline", "20"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = parse(out.stdout)
     assert d["launcher"]["stage"] == "single_process_rccl" and "external launcher" in d["launcher"]["started_by"]
     assert d["launcher"]["fallback_from"][0]["stage"] == "torch_rccl_ranks" and "hangs" in d["launcher"]["fallback_from"][0]["reason"]
     assert d["ranks"] == 2 and d["parity_vs_n1"]["ok"] and d["value"] > 0
@@ -393,9 +400,7 @@ def test_bench_ladder_survives_a_real_rccl_failure():
                           "--steps", "4", "--warmup", "2", "--pcg-iters", "24", "--no-cpu-baseline", "--no-clocks",
                           "--stage-timeout", "150"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = parse(out.stdout)
     assert d["launcher"]["stage"] == "single_process_rccl"
     f = d["launcher"]["fallback_from"]
     assert len(f) == 1 and f[0]["stage"] == "torch_rccl_ranks" and f[0]["rc"] != 0

@@ -93,14 +93,18 @@ def test_types_attributes_and_matvec_bit_exact(oracle, L100):
     x = np.random.default_rng(0).standard_normal(10000)
     y_ref = np.empty(10000)
     O.matvec(x, y_ref)
+    yt_ref = np.full(10000, np.nan)
+    O.matvec_transp(x, yt_ref)  # orc_csr_matvec_transp: zero y, then the row-wise scatter of csr_mat.c:74-88
     for M in (A, S, L, spmatrix.poisson_csr(100, 100), spmatrix.poisson_sss(100, 100),
               spmatrix.csr_from_arrays(O.ind, O.col, O.val, (10000, 10000))):
         y = np.full(10000, np.nan)
         M.matvec(x, y)
         assert np.array_equal(y, y_ref)
         y2 = np.full(10000, np.nan)
-        M.matvec_transp(x, y2)  # symmetric operator
-        assert np.allclose(y2, y_ref, rtol=1e-12, atol=1e-12)
+        M.matvec_transp(x, y2)
+        # bit for bit (round 6; was allclose): csr_mat / ll_mat add every y[c] by ascending row like the reference's scatter
+        # (a gather in the scatter's order, no atomics); sss_mat.matvec_transp IS sss_mat.matvec (sss_mat.c:108)
+        assert np.array_equal(y2, y_ref if isinstance(M, spmatrix.SSSMatType) else yt_ref), type(M).__name__
     # strided NumPy views (spmatrix.h:38-54)
     xb, yb = np.zeros(20000), np.zeros(30000)
     xb[::2] = x
@@ -337,3 +341,56 @@ def test_callback_solves_from_two_threads_do_not_deadlock(oracle):
         assert not any(t.is_alive() for t in ts), "deadlock between callback solves"
         for k in ("ext", "ctypes"):
             assert got[k][0] == alone[k][0] and np.array_equal(got[k][1], alone[k][1])
+
+
+@pytest.mark.parametrize("nn", [100, 300, 500])
+def test_published_table_flow_against_the_unmodified_reference_program(golden_dir, nn):
+    """The reference's only published benchmark for this path (doc/pysparse/source/itsolvers.rst:120-130 script, :189-199
+    table; native twin examples/poisson_test/poisson_test.c:110-125): L x = 1, L = poisson2d_sym_blk(n).to_sss(), x0 = 0,
+    pcg(S, b, x, 1e-12, 2000), no preconditioner, n = 100 / 300 / 500 -- through the drop-in modules, against
+    tests/golden/ref_published_table.json (the UNMODIFIED program's counts and x; oracle/make_golden.py --published-only).
+
+    What is pinned how: x within 1e-12 of the reference's at every size; the iteration count bit for bit at n = 100 (225).
+    At n = 300 / 500 the recurred residual creeps along its floor just above 1e-12 and the count depends on the ORDER in
+    which the BLAS-1 sums are added -- the reference's own program stops at 677 / 1132 linked with OpenBLAS and at 735 /
+    1297 linked with a sequential BLAS-1 (measured) while its x moves by 2e-14 / 6e-14 -- so there the
+    count is held to the band those two builds span (-10 % / +10 %), the residual to the tolerance, and the run to
+    reproducing itself bit for bit."""
+    from pysparse.itsolvers import krylov
+    from pysparse.tools import poisson
+    from pysparse_amd import device as dev
+    with open(os.path.join(golden_dir, "ref_published_table.json")) as f:
+        g = {r["n"]: r for r in json.load(f)["rows"]}[nn]
+    gx = np.load(os.path.join(golden_dir, "ref_published_table.npz"))["x_%d" % nn]
+    sequential_blas = {100: 225, 300: 735, 500: 1297}[nn]
+    assert g["standalone"]["iter"] == g["compiled_pcg_with_sss_product"]["iter"] == {100: 225, 300: 677, 500: 1132}[nn]
+    n = nn * nn
+    L = poisson.poisson2d_sym_blk(nn)
+    S = L.to_sss()
+    assert S.nnz == g["nnz_lower"] + n
+    b, x = np.ones(n), np.zeros(n)
+    info, it, relres = krylov.pcg(S, b, x, 1e-12, 2000)
+    loop = dev.last_solve_info()[0]
+    assert info == 0 and relres <= 1e-12, (info, it, relres)
+    assert np.abs(x[::97] - gx).max() <= 1e-12 * np.abs(gx).max(), (it, np.abs(x[::97] - gx).max() / np.abs(gx).max())
+    if nn == 100:
+        assert it == 225 and abs(relres - g["compiled_pcg_with_sss_product"]["relres"]) <= 1e-2 * relres
+    assert 0.9 * g["standalone"]["iter"] <= it <= 1.1 * sequential_blas, (it, loop)
+    r = np.empty(n)
+    S.matvec(x, r)
+    assert np.linalg.norm(b - r) <= 1e-9 * np.linalg.norm(b)  # the true residual (the recurred one drifts: 2e-11 / 7e-11 on the CPU)
+    x2 = np.zeros(n)
+    assert krylov.pcg(S, b, x2, 1e-12, 2000) == (info, it, relres) and np.array_equal(x, x2)
+    # the same system on the launch-per-phase loops only (psp_set_single_kernel_loops(0)): in the single-kernel range the
+    # two have the same bits (psp_mid.hip); below it (n = 100: psp_coop.hip) they agree to rounding
+    dev.set_single_kernel_loops(False)
+    try:
+        x3 = np.zeros(n)
+        res3 = krylov.pcg(S, b, x3, 1e-12, 2000)
+        assert dev.last_solve_info()[0] in ("pcg_lazy", "pcg_eager", "pcg_lazy_pf")
+    finally:
+        dev.set_single_kernel_loops(True)
+    if loop == "pcg_mid":
+        assert res3 == (info, it, relres) and np.array_equal(x, x3)
+    else:
+        assert res3[0] == 0 and np.abs(x3 - x).max() <= 1e-12 * np.abs(x).max()

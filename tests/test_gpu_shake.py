@@ -50,15 +50,19 @@ def _child(*args, timeout=900):
 def test_directed_delay_reproduces_the_round4_race_and_head_is_clean():
     out = _child("race")
     assert out["reverted_injected"] >= 1 and out["head_injected"] >= 1, out
-    assert out["reverted_wrong_of_5"] == 5, ("the delay no longer opens the window the round-4 fix closed", out)
+    # the re-opened race is a race: how often a 3 ms delay lands a wrong product depends on driver and clocks (5 of 5 on the
+    # round-5 boxes).  One is enough to show that the facility reaches the window; HEAD must be clean every time
+    assert out["reverted_wrong_of_5"] >= 1, ("the delay no longer opens the window the round-4 fix closed", out)
     assert out["head_wrong_of_5"] == 0 and out["disarmed_ok"], out
 
 
 @pytest.mark.gpu
 def test_shaken_products_and_solves_are_bit_identical():
-    out = _child("stress", 40, 80)
-    assert out["configs"] == 5 and out["runs_per_config"] * out["configs"] >= 200
-    assert out["injected"] > 10000, out  # the cut points were reached and delays were drawn
+    # 5 configurations x 16 seeds x 9 calls in the suite (round 6: the suite's wall time; round 5 ran 40 seeds here and the
+    # campaigns of tools/ ran 200 -- profiles/r5_*; `python tests/shake_child.py stress 200 120` repeats them)
+    out = _child("stress", 16, 80)
+    assert out["configs"] == 5 and out["runs_per_config"] * out["configs"] >= 80
+    assert out["injected"] > 4000, out  # the cut points were reached and delays were drawn
     assert out["mismatches"] == [], out
 
 
