@@ -484,62 +484,107 @@ def mtx_leg(spec, steps=50, minres_iters=200):
         source = "MatrixMarket file " + os.path.basename(spec)
     ingest_s = time.perf_counter() - t0
     nnz_lower = int(val.shape[0])
+    rng = np.random.default_rng(7)
+    xh = rng.standard_normal(n)
+    b = np.zeros(n)
+    b[0] = 1.0
+    b += 1e-3 * rng.standard_normal(n)
+    # a process pays for its first large host-to-device copy (~160 ms) and for the first launch from each translation unit
+    # (~15 ms each) whatever the matrix: out of the way before anything is timed, on a 3 000-row stand-in of the same kind
+    from pysparse_amd.tools import standins as _st
+    wn, wi, wc, wv, wd = _st.fem_sss_arrays(10, 10, 10, 64)
+    Sw = dev.DeviceSSS.from_arrays(wn, wi, wc, wv, wd)
+    Sw.prepare(1 << 30)
+    Kw = dev.DeviceJacobi(Sw)
+    dev.minres(Sw, np.ones(wn), np.zeros(wn), 1e-10, 50, Kw)
+    Kw.close()
+    Sw.close()
+    dev.DeviceBuffer.from_host(np.ones(1 << 22)).free()
+    sync()
+    # ---- time to solution, as a script that solves ONCE sees it (examples/demo_pcg.py:47-98): arrays up, Jacobi, converged
+    # MINRES with x back in the caller's array.  The handle decides by its cost rule what to build (psp_csr.hip
+    # pick_scattered: an irregular numbering multiplies with csr_spmv_w5 and gets its renumbered copy after 4096 products)
+    t_all = time.perf_counter()
     t0 = time.perf_counter()
     S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
     sync()
     upload_s = time.perf_counter() - t0
-    rng = np.random.default_rng(7)
-    xh = rng.standard_normal(n)
-    xb, yb = dev.DeviceBuffer.from_host(xh), dev.DeviceBuffer(n)
+    K = dev.DeviceJacobi(S)
+    xg, xo = np.zeros(n), np.zeros(n)
     t0 = time.perf_counter()
-    S.matvec_dev(xb.ptr, yb.ptr)  # builds the product's tables (mirror, renumbered copy, ...)
+    got = dev.minres(S, b, xg, 1e-10, 500, K)
+    first_solve_s = time.perf_counter() - t0
+    end_to_end_s = time.perf_counter() - t_all
+    kern0, kinfo0 = S.kernel_info()
+    So = O.SSS(n, val, diag, col, ind)
+    ref = O.minres(So, b, xo, 1e-10, 500, O.jacobi_dinv(diag))
+    x_diff = _maxrel(xg, xo)
+    t0 = time.perf_counter()
+    dev.minres(S, b, np.zeros(n), 1e-10, 500, K)
+    second_solve_s = time.perf_counter() - t0
+
+    def us_per_iteration():
+        times = {}
+        for k in (20, 20 + minres_iters):  # the difference cancels the transfers of b and x and the set-up product
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dev.minres(S, b, np.zeros(n), 0.0, k, K)
+                best = min(best, time.perf_counter() - t0)
+            times[k] = best
+        return (times[20 + minres_iters] - times[20]) / minres_iters * 1e6
+    xb, yb = dev.DeviceBuffer.from_host(xh), dev.DeviceBuffer(n)
+    ev = Events(L, check, steps + 1)
+    cold = {"kernel": kern0, "kernel_info": kinfo0}
+    timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, 5)
+    cold["spmv_ms"], _ = timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, steps)
+    cold["minres_us_per_iteration"] = us_per_iteration()
+    cold["products_counted"] = S.setup_info()["products_counted"]
+    # ---- steady state: the caller announces many products (psp_sss_prepare), the handle builds what pays for itself
+    S.prepare(1 << 30)
+    t0 = time.perf_counter()
+    S.matvec_dev(xb.ptr, yb.ptr)  # builds the renumbered copy and its tables where the numbering is irregular
     sync()
     first_product_s = time.perf_counter() - t0
     kern, kinfo = S.kernel_info()
-    ev = Events(L, check, steps + 1)
+    setup = S.setup_info()
     timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, 5)
     avg, med = timed_launches(lambda: S.matvec_dev(xb.ptr, yb.ptr), sync, ev, steps)
     sss_bytes = 12 * nnz_lower + 28 * n + 4
     csr_bytes = csr_model_bytes(n, 2 * nnz_lower + n)
     # parity: the product against the oracle's sss_matvec loop (sss_mat.c:40-56), bit for bit
-    So = O.SSS(n, val, diag, col, ind)
     yo = np.empty(n)
     So.matvec(xh, yo)
     yg = yb.download()
     spmv_bits = bool(np.array_equal(yg, yo))
-    # Jacobi-MINRES (minres.c:43-200): to 1e-10 against the oracle, then a fixed iteration count for the rate
-    b = np.zeros(n)
-    b[0] = 1.0
-    b += 1e-3 * rng.standard_normal(n)
-    K = dev.DeviceJacobi(S)
-    xg, xo = np.zeros(n), np.zeros(n)
-    t0 = time.perf_counter()
-    got = dev.minres(S, b, xg, 1e-10, 500, K)
-    solve_s = time.perf_counter() - t0
-    ref = O.minres(So, b, xo, 1e-10, 500, O.jacobi_dinv(diag))
-    x_diff = _maxrel(xg, xo)
-    times = {}
-    for k in (20, 20 + minres_iters):  # the difference cancels the transfers of b and x and the set-up product
-        best = 1e9
-        for _ in range(3):
-            xg2 = np.zeros(n)
-            t0 = time.perf_counter()
-            dev.minres(S, b, xg2, 0.0, k, K)
-            best = min(best, time.perf_counter() - t0)
-        times[k] = best
-    us_iter = (times[20 + minres_iters] - times[20]) / minres_iters * 1e6
+    xg2 = np.zeros(n)
+    got2 = dev.minres(S, b, xg2, 1e-10, 500, K)  # in the copy's numbering now
+    x_diff2 = _maxrel(xg2, xo)
+    us_iter = us_per_iteration()
     out = {"source": source, "n": n, "nnz_lower": nnz_lower, "nnz_full": 2 * nnz_lower + n,
-           "ingest_s": ingest_s, "upload_s": upload_s, "first_product_s": first_product_s,
-           "kernel": kern, "kernel_info": kinfo, "spmv_ms": avg, "spmv_median_ms": med,
+           "ingest_s": ingest_s, "upload_s": upload_s, "first_solve_s": first_solve_s, "end_to_end_s": end_to_end_s,
+           "second_solve_s": second_solve_s, "first_product_s": first_product_s,
+           "time_to_solution": {"what": "arrays up + Jacobi + converged MINRES (tol 1e-10) + x on the host, warm process, the "
+                                        "handle's own cost rule", "end_to_end_ms": end_to_end_s * 1e3,
+                                "upload_ms": upload_s * 1e3, "first_solve_ms": first_solve_s * 1e3,
+                                "second_solve_ms": second_solve_s * 1e3, "kernel": kern0,
+                                "round5_same_flow_ms": "upload 116-120 + first product 47-57 + solve 5-6 "
+                                                       "(profiles/r5_mtx_leg_standins.jsonl; first large copy of the process "
+                                                       "included there)"},
+           "cold": cold, "setup_ms": setup["reorder_ms"], "setup": setup,
+           "kernel": kern, "kernel_info": dict(kinfo, setup_ms=setup["reorder_ms"]), "spmv_ms": avg, "spmv_median_ms": med,
            "sss_model_bytes": sss_bytes, "sss_model_GBps": sss_bytes / (avg * 1e-3) / 1e9,
            "sss_model_frac_of_peak": sss_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "csr_model_bytes": csr_bytes, "csr_model_GBps": csr_bytes / (avg * 1e-3) / 1e9,
            "csr_model_frac_of_peak": csr_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-           "minres": {"info": got[0], "iter": got[1], "relres": got[2], "solve_s_with_transfers": solve_s,
+           "minres": {"info": got[0], "iter": got[1], "relres": got[2], "solve_s_with_transfers": first_solve_s,
                       "us_per_iteration": us_iter, "iters_timed": minres_iters},
            "parity": {"spmv_bit_exact_vs_oracle": spmv_bits, "minres_info_iter_oracle": [ref[0], ref[1]],
-                      "minres_info_iter_gpu": [got[0], got[1]], "x_max_rel_diff": x_diff, "x_tol": 1e-12,
-                      "ok": bool(spmv_bits and (got[0], got[1]) == (ref[0], ref[1]) and x_diff <= 1e-12)}}
+                      "minres_info_iter_gpu": [got[0], got[1]], "x_max_rel_diff": x_diff,
+                      "minres_info_iter_gpu_renumbered": [got2[0], got2[1]], "x_max_rel_diff_renumbered": x_diff2,
+                      "x_tol": 1e-12,
+                      "ok": bool(spmv_bits and (got[0], got[1]) == (ref[0], ref[1]) == (got2[0], got2[1])
+                                 and x_diff <= 1e-12 and x_diff2 <= 1e-12)}}
     K.close()
     S.close()
     xb.free()
@@ -569,7 +614,8 @@ def mtx_main(a):
            "config5": leg, "provenance": provenance(_capi.lib())}
     if not leg["parity"]["ok"]:
         out["error"] = "parity against the oracle failed"
-    print(json.dumps(out), file=real_stdout, flush=True)
+    out["stage"] = "mtx"
+    emit(out, real_stdout, a.side_file or None)
     return 1 if "error" in out else 0
 
 

@@ -154,6 +154,21 @@ def compact(full, side_file=None):
                                    "rows": [[r_["n"], r_.get("iter"), r_.get("gpu_total_s"), r_.get("ref_total_s")]
                                             for r_ in pt.get("rows", [])],
                                    "columns": ["n", "iter", "gpu assembly+solve s", "compiled reference 1 core s"]}
+    if "config5" in full and isinstance(full["config5"], dict):
+        c5 = full["config5"]
+        if "error" in c5:
+            line["config5"] = {"error": str(c5["error"])[:200]}
+        else:
+            tts = c5.get("time_to_solution") or {}
+            line["config5"] = {
+                "source": str(c5.get("source", ""))[:90], "n": c5.get("n"), "nnz_lower": c5.get("nnz_lower"),
+                "kernel": c5.get("kernel"), "spmv_ms": c5.get("spmv_ms"), "setup_ms": c5.get("setup_ms"),
+                "sss_model_frac_of_peak": c5.get("sss_model_frac_of_peak"),
+                "csr_model_frac_of_peak": c5.get("csr_model_frac_of_peak"),
+                "time_to_solution": _pick(tts, ("end_to_end_ms", "upload_ms", "first_solve_ms", "second_solve_ms", "kernel")),
+                "cold": _pick(c5.get("cold") or {}, ("kernel", "spmv_ms", "minres_us_per_iteration")),
+                "minres": _pick(c5.get("minres") or {}, ("info", "iter", "us_per_iteration")),
+                "parity_ok": (c5.get("parity") or {}).get("ok")}
     if "provenance" in full:
         line["provenance"] = _pick(full["provenance"], ("build_id", "match"))
     for k in ("rccl_ranks", "backend", "stage", "launcher_kind", "vs_n1", "dry_run", "ranks", "distinct_devices",

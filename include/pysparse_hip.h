@@ -273,6 +273,17 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
  *   chunk-local columns; csr_spmv_w2 / w1 / stream: any CSR.  All add each row's products left
  *   to right (csr_mat.c:49-54), so the choice never changes a bit of y. */
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
+/* Set-up against steady state for irregular numberings (round 6; no reference analogue: csr_mat.c:259-296 builds nothing).
+ * A csr_mat whose stored numbering scatters its columns (an FEM mesh as it comes out of a generator) multiplies 7-12 us
+ * faster per product through a renumbered copy (reverse Cuthill-McKee, "csr_spmv_w3_rcm") than on the stored numbering
+ * ("csr_spmv_w5") -- and the copy costs 17-57 ms to build at n = 9.3e5.  The library therefore builds it only once a handle
+ * has done 4096 products (solver iterations included), or at the next product after the caller has announced at least that
+ * many here.  y = A x has the same bits either way; a fused solve's iterates differ at rounding level between the two
+ * numberings (its dot products add in the numbering it runs in), deterministically for a given sequence of calls.
+ * psp_csr_setup_info: info4 = {ms the copy took to build (0: not built), products counted so far, the threshold,
+ * state (-1 undecided, 0 examined and not built, 1 built)}. */
+int psp_csr_prepare(psp_csr_t *A, long long expected_products);
+int psp_csr_setup_info(psp_csr_t *A, double *info4);
 /* The renumbering behind "csr_spmv_w3_rcm" (irregular square operators): perm_host[new] = old row
  * (nrows ints) and *available = 2 (numbering computed on the device) or 1 (on the host: fallback, A/B switch) when
  * psp_csr_kernel_info / a product has built one for this handle; *available = 0 otherwise (perm_host untouched).
@@ -295,6 +306,9 @@ int psp_sss_destroy(psp_sss_t *A);
  * only, half the traffic of the mirrored product; otherwise the csr kernels on the full mirror),
  * and the A/B knob -- same meaning as psp_csr_kernel_info / psp_csr_set_variant */
 int psp_sss_kernel_info(psp_sss_t *A, char *name, int name_cap, int *info);
+/* psp_csr_prepare / psp_csr_setup_info for the mirror an irregular sss_mat multiplies with */
+int psp_sss_prepare(psp_sss_t *A, long long expected_products);
+int psp_sss_setup_info(psp_sss_t *A, double *info4);
 int psp_sss_set_variant(psp_sss_t *A, int variant);
 int psp_sss_shape(const psp_sss_t *A, int *n, int *nnz_reported);
 int psp_sss_download(const psp_sss_t *A, int *ind_host, int *col_host, double *val_host,

@@ -34,6 +34,8 @@
 #include <cmath>
 #include <vector>
 
+#include <chrono>
+
 #include "psp_internal.h"
 
 using namespace psp;
@@ -2189,6 +2191,55 @@ __global__ void transp_gather_kernel(int nnz, const int *__restrict__ perm, cons
   }
 }
 
+// ---- the transpose by counting (round 6): entries per column by atomic histogram, a scan, every entry takes a slot of
+// its column by an atomic cursor (any order), then each column's few entries are sorted by (row, stored position) --
+// the order the stable radix sort by column gave (16 ms of an sss_mat's 60 ms upload at 2e7 entries; this: ~3 ms).
+// The result does not depend on the order in which the atomics landed.
+__global__ void transp_count_kernel(int nnz, int ncols, const int *__restrict__ col, int *__restrict__ cnt, int *bad) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x) {
+    const int c = col[k];
+    if (c < 0 || c >= ncols) *bad = 1;
+    else atomicAdd(cnt + c, 1);
+  }
+}
+
+__global__ void transp_slot_kernel(int nrows, const int *__restrict__ ind, const int *__restrict__ col,
+                                   const int *__restrict__ tind, int *__restrict__ cursor,
+                                   unsigned long long *__restrict__ key) {
+  const int lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrows; r += (long)gridDim.x * 4)
+    for (int k = ind[r] + lane; k < ind[r + 1]; k += 64) {
+      const int c = col[k];
+      const int at = tind[c] + atomicAdd(cursor + c, 1);
+      key[at] = ((unsigned long long)(unsigned)r << 32) | (unsigned)k;
+    }
+}
+
+// one thread per column: insertion sort of its keys (short segments; the keys are distinct)
+__global__ void transp_sort_kernel(int ncols, const int *__restrict__ tind, unsigned long long *__restrict__ key) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
+    const int b = tind[c], e = tind[c + 1];
+    for (int i = b + 1; i < e; ++i) {
+      const unsigned long long v = key[i];
+      int j = i - 1;
+      while (j >= b && key[j] > v) {
+        key[j + 1] = key[j];
+        --j;
+      }
+      key[j + 1] = v;
+    }
+  }
+}
+
+__global__ void transp_emit_kernel(int nnz, const unsigned long long *__restrict__ key, const double *__restrict__ val,
+                                   int *__restrict__ tcol, double *__restrict__ tval) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long kv = key[i];
+    tcol[i] = (int)(kv >> 32);
+    tval[i] = val[(unsigned)(kv & 0xffffffffull)];
+  }
+}
+
 // ind_t[c] = first position whose (sorted) column is >= c
 __global__ void transp_ptr_kernel(int nnz, int ncols, const int *__restrict__ sorted_cols, int *__restrict__ ind_t) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= nnz; k += gridDim.x * blockDim.x) {
@@ -2514,6 +2565,11 @@ struct CsrExtra {
   psp_csr *transposed = nullptr;       // A^T as its own handle (matvec_transp on irregular matrices)
   // renumbered copy R = P A P^T for csr_spmv_w3 (psp_reorder.hip): state -1 not examined, 0 none, 1 built
   int reorder_state = -1;
+  // the cost rule of the renumbering (round 6; pick_scattered): products this handle has multiplied with on the stored
+  // numbering so far, what the caller announced (psp_csr_prepare), and what the copy cost when it was built
+  long products = 0;
+  long expected_products = 0;
+  double reorder_ms = 0.0;
   psp_csr *reordered = nullptr;
   int *perm = nullptr;     // new -> old (device)
   int *inv = nullptr;      // old -> new
@@ -3214,6 +3270,51 @@ static int transpose_into(int nrows, int ncols, int nnz, const int *ind, const i
       goto done;                                                                           \
     }                                                                                      \
   } while (0)
+  static const bool by_sort = [] {  // A/B: the stable radix sort of rounds 1-5
+    const char *e = psp::tuning_env("PSP_TRANSPOSE_SORT");
+    return e && atoi(e) != 0;
+  }();
+  if (nnz > 0 && !by_sort) {
+    // counting form (kernels above); scratch from the solvers' vector pool: no hipMalloc / hipFree of 80 MB arrays
+    double *kbuf = nullptr, *cbuf = nullptr;
+    const size_t nk = (size_t)nnz, ncur = ((size_t)ncols + 2) / 2 + 1;
+    rc = psp::scratch_get(nk, &kbuf);
+    if (rc == PSP_OK) rc = psp::scratch_get(ncur, &cbuf);
+    if (rc == PSP_OK) {
+      unsigned long long *key = reinterpret_cast<unsigned long long *>(kbuf);
+      int *cursor = reinterpret_cast<int *>(cbuf);  // ncols + 1 ints: the counts, then the cursors; [ncols] = the flag
+      size_t bytes = 0;
+      hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * ((size_t)ncols + 2), stream());
+      const int g = (int)std::min<long>(((long)nnz + 255) / 256, 65536);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(transp_count_kernel, dim3(g), dim3(256), 0, stream(), nnz, ncols, col, cursor, cursor + ncols + 1);
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cursor, T->ind, ncols + 1, stream());
+      }
+      if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 1);
+      if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cursor, T->ind, ncols + 1, stream());
+      int bad = 0;
+      if (e == hipSuccess) e = hipMemcpyAsync(&bad, cursor + ncols + 1, sizeof(int), hipMemcpyDeviceToHost, stream());
+      if (e == hipSuccess) e = hipStreamSynchronize(stream());
+      if (e == hipSuccess && bad) rc = fail(PSP_EINVAL, "transpose: a column index is out of range");
+      if (e == hipSuccess && !bad) e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)ncols, stream());
+      if (e == hipSuccess && !bad) {
+        hipLaunchKernelGGL(transp_slot_kernel, dim3(std::min((nrows + 3) / 4, 65536)), dim3(256), 0, stream(), nrows, ind, col,
+                           T->ind, cursor, key);
+        hipLaunchKernelGGL(transp_sort_kernel, dim3(std::min((ncols + 255) / 256, 65536)), dim3(256), 0, stream(), ncols, T->ind,
+                           key);
+        hipLaunchKernelGGL(transp_emit_kernel, dim3(g), dim3(256), 0, stream(), nnz, key, val, T->col, T->val);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(stream());
+      if (e != hipSuccess)
+        rc = fail(e == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "transpose: %s", hipGetErrorString(e));
+    }
+    psp::scratch_put(kbuf, nk);
+    psp::scratch_put(cbuf, ncur);
+    if (rc != PSP_OK) goto done;
+    rc = finalize_csr(T);
+    goto done;
+  }
   if (nnz > 0) {
     const size_t ib = sizeof(int) * (size_t)nnz;
     TR_HIP(hipMalloc((void **)&rows, ib));
@@ -3338,8 +3439,10 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     on_device = 0;
   };
   auto attempt = [&]() -> int {
+    psp::setup_mark("first product: before the renumbering");
     if (!host_forced) {
       PSP_TRY(psp::reorder_rcm_device(n, A->ind, A->col, &dperm, &dinv, &on_device));
+      psp::setup_mark("renumbering: reorder_rcm_device");
       if (on_device < 0) {  // unsymmetric pattern or unsorted rows: number the pattern of A + A^T, built on the device
         int *sind = nullptr, *scol = nullptr, ok_sym = 0;
         long snnz = 0;
@@ -3356,8 +3459,10 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     }
     PSP_TRY(alloc_csr(n, n, (long)nnz, &R));
     R->no_reorder = true;
+    psp::setup_mark("renumbering: allocate the copy");
     if (on_device) {
       PSP_TRY(psp::reorder_build_device(n, A->ind, A->col, A->val, dperm, dinv, R->ind, R->col, R->val));
+      psp::setup_mark("renumbering: build R = P A P^T");
     } else {
       std::vector<int> ind((size_t)n + 1), col(nnz), perm, rind, rcol;
       std::vector<double> val(nnz), rval;
@@ -3380,11 +3485,13 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     }
     PSP_HIP(hipMalloc((void **)&xp, sizeof(double) * 2 * (size_t)n));
     PSP_TRY(finalize_csr(R));
+    psp::setup_mark("renumbering: finalize_csr(R)");
     ChunkTable *t = nullptr;
     PSP_TRY(get_chunk_table(R, 1024, &t));
     PSP_TRY(ensure_rowoff(R, t));
     if (t->np == 0) return PSP_EINVAL;  // the new numbering does not qualify either
     PSP_TRY(ensure_w3(R, t));
+    psp::setup_mark("renumbering: chunk table + w3 tables of R");
     return t->nb > 0 ? PSP_OK : PSP_EINVAL;
   };
   auto guarded = [&]() -> int {
@@ -3394,6 +3501,7 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
       return PSP_ENOMEM;
     }
   };
+  const auto t_build = std::chrono::steady_clock::now();
   int rc = guarded();
   if (rc == PSP_ENOMEM) {
     release();
@@ -3404,7 +3512,9 @@ static int ensure_reordered(const psp_csr *A, psp::CsrExtra *ex, int orig_max_bl
     release();
     return PSP_OK;
   }
+  (void)hipStreamSynchronize(stream());
   std::lock_guard<std::mutex> lk(g_extra_mu);
+  ex->reorder_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   ex->reordered = R;
   ex->perm = dperm;
   ex->inv = dinv;
@@ -3582,21 +3692,46 @@ static void launch_w5(const psp_csr *A, const ChunkTable *t, int grid, int strip
 // csr_spmv_w3 takes (t->nb == 0): 1 = the renumbered copy through csr_spmv_w3 (measured best on the FEM-like
 // stand-ins and the only form that cuts the cache-line traffic of the x gathers), 2 = csr_spmv_w5, 0 = neither
 // (csr_spmv_w2).  A/B: variant bit 27 switches the renumbered copy off, bit 28 csr_spmv_w5.
-static int pick_scattered(const psp_csr *A, ChunkTable *t, psp::CsrExtra **ex_out, int *mode) {
+// THE COST RULE OF THE RENUMBERED COPY (round 6, VERDICT r5 #4a).  Building it -- reverse Cuthill-McKee on the device, R =
+// P A P^T, R's tables -- takes 17-20 ms at n = 9.3e5 / 4.1e7 nonzeros in a warm process (45-57 ms in a fresh one); what it
+// buys is 7-12 us per product against csr_spmv_w5 on the stored numbering (0.092-0.097 against 0.099-0.109 ms; 117
+// against 127 us per Jacobi-MINRES iteration): it pays for itself after ~2 000-4 000 products, and the solve of
+// BASELINE.json configs[4] converges in 14.  So a handle multiplies with csr_spmv_w5 until it HAS done kReorderAfter
+// products (counted here: every product and every solver iteration on the stored numbering) or its caller announces that
+// many (psp_csr_prepare / psp_sss_prepare); the copy is then built at the next product or at the start of the next solve
+// -- never in the middle of one: a fused solve runs in one numbering from its first reduction to its last.
+// y = A x has the same bits either way; a solve's iterates differ at rounding level between the two numberings (its
+// reductions add in the numbering it runs in), deterministically for a given sequence of calls.
+// PSP_SPMV_REORDER_AFTER (tuning) moves the threshold; 0 = the copy at first use, as rounds 2-5 built it.
+constexpr long kReorderAfter = 4096;
+static long reorder_after() {
+  static const long v = [] {
+    const char *e = psp::tuning_env("PSP_SPMV_REORDER_AFTER");
+    return e ? atol(e) : kReorderAfter;
+  }();
+  return v;
+}
+
+static int pick_scattered(const psp_csr *A, ChunkTable *t, psp::CsrExtra **ex_out, int *mode, bool count = false) {
   *mode = 0;
   if (t->nb != 0 || t->max_blocks <= 0) return PSP_OK;
   const int var = A->variant < 0 ? 0 : A->variant;
   if (((var >> 27) & 1) == 0) {
     psp::CsrExtra *exr;
+    bool due;
     {
       std::lock_guard<std::mutex> lk(g_extra_mu);
       exr = &g_extra[A];
+      due = exr->reorder_state >= 0 || exr->products >= reorder_after() || exr->expected_products >= reorder_after();
+      if (count && !due) exr->products += 1;
     }
-    PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
-    if (exr->reorder_state == 1) {
-      *ex_out = exr;
-      *mode = 1;
-      return PSP_OK;
+    if (due) {
+      PSP_TRY(ensure_reordered(A, exr, t->max_blocks));
+      if (exr->reorder_state == 1) {
+        *ex_out = exr;
+        *mode = 1;
+        return PSP_OK;
+      }
     }
   }
   if (((var >> 28) & 1) == 0) {
@@ -3977,6 +4112,7 @@ bool csr_spmv_has_skip(const psp_csr *A) {
 // of launch_reordered in every iteration.
 int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const int **inv) {
   *R = nullptr;
+  psp::setup_mark(nullptr);
   Variant v = decode_variant(A->variant);
   if (A->nparts || A->w4_only || A->no_reorder || !(v.w1 && v.w2 && v.w3) || A->nrows != A->ncols ||
       A->max_row_nnz > v.tile / 2 || v.tile != 1024)
@@ -3991,11 +4127,14 @@ int csr_reordered_view(const psp_csr *A, psp_csr **R, const int **perm, const in
     PSP_TRY(ensure_w4(A, &ex));
     if (ex->dia_state == 1) return PSP_OK;
   }
+  psp::setup_mark("first use: index-free (w4) layouts tried");
   ChunkTable *t;
   PSP_TRY(get_chunk_table(const_cast<psp_csr *>(A), v.tile, &t));
   PSP_TRY(ensure_rowoff(A, t));
   if (t->np == 0) return PSP_OK;
+  psp::setup_mark("first use: chunk table + row offsets");
   PSP_TRY(ensure_w3(A, t));
+  psp::setup_mark("first use: w3 tables on the stored numbering");
   psp::CsrExtra *exs = nullptr;
   int mode = 0;
   PSP_TRY(pick_scattered(A, t, &exs, &mode));
@@ -4011,6 +4150,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
                     double *partials, int *nparts, const int *skip) {
   Workspace *w;
   PSP_TRY(workspace(&w));
+  psp::setup_mark(nullptr);
   if (A->nparts) {
     // partitioned matrix: one product per part, rows offset; each part's dot partials are folded to kFold
     // values at partials + p*kFold (fixed order), through the workspace's last slot
@@ -4140,7 +4280,7 @@ int csr_spmv_launch(const psp_csr *A, const double *x, double *y, const double *
     if (!use_w3 && v.w2 && v.w3) {  // scattered numbering
       psp::CsrExtra *exs = nullptr;
       int mode = 0;
-      PSP_TRY(pick_scattered(A, t, &exs, &mode));
+      PSP_TRY(pick_scattered(A, t, &exs, &mode, true));
       if (mode == 1) return launch_reordered(A, exs, stripe, x, y, dotv, partials, nparts, skip);
       if (mode == 2) {
         double *pb5 = partials;
@@ -4680,6 +4820,15 @@ void host_stage_trim() {
 
 // ------------------------------------------------------------------ C ABI: csr
 
+// *bad = the first position whose column is outside [0, ncols) (unchanged: none)
+__global__ __launch_bounds__(256) void csr_validate_kernel(int nnz, int ncols, const int *__restrict__ col,
+                                                           unsigned long long *bad) {
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) {
+    const int c = col[k];
+    if (c < 0 || c >= ncols) atomicMin(bad, (unsigned long long)k);
+  }
+}
+
 extern "C" {
 
 int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int *col_host,
@@ -4694,18 +4843,36 @@ int psp_csr_create(int nrows, int ncols, int nnz, const int *ind_host, const int
   for (int i = 0; i < nrows; ++i)
     if (ind_host[i + 1] < ind_host[i])
       return fail(PSP_EINVAL, "psp_csr_create: ind not monotone at row %d", i);
-  for (int k = 0; k < nnz; ++k)
-    if (col_host[k] < 0 || col_host[k] >= ncols)
-      return fail(PSP_EINVAL, "psp_csr_create: column index %d out of range at %d", col_host[k], k);
+  // small triples are checked here; large ones on the device once they are there (csr_validate_kernel: the loop over
+  // 4e7 entries was 20 ms of host time) -- either way before any kernel indexes with a column
+  const bool check_on_device = nnz >= (1 << 22);
+  if (!check_on_device)
+    for (int k = 0; k < nnz; ++k)
+      if (col_host[k] < 0 || col_host[k] >= ncols)
+        return fail(PSP_EINVAL, "psp_csr_create: column index %d out of range at %d", col_host[k], k);
   psp_csr *A;
   PSP_TRY(alloc_csr(nrows, ncols, nnz, &A));
   PSP_HIP(hipMemcpyAsync(A->ind, ind_host, sizeof(int) * ((size_t)nrows + 1),
                          hipMemcpyHostToDevice, stream()));
   if (nnz > 0) {
-    PSP_HIP(hipMemcpyAsync(A->col, col_host, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice,
-                           stream()));
-    PSP_HIP(hipMemcpyAsync(A->val, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice,
-                           stream()));
+    PSP_HIP(hipMemcpyAsync(A->col, col_host, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, stream()));
+    PSP_HIP(hipMemcpyAsync(A->val, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream()));
+  }
+  if (check_on_device) {
+    unsigned long long *d_bad = nullptr, bad = ~0ull;
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof(bad));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bad, &bad, sizeof(bad), hipMemcpyHostToDevice, stream());
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(csr_validate_kernel, dim3(std::min((nnz + 255) / 256, 65536)), dim3(256), 0, stream(), nnz, ncols, A->col, d_bad);
+      e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream());
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    if (d_bad) (void)hipFree(d_bad);
+    if (e != hipSuccess || bad != ~0ull) {
+      psp_csr_destroy(A);
+      if (e != hipSuccess) return fail(PSP_ENODEV, "psp_csr_create: %s", hipGetErrorString(e));
+      return fail(PSP_EINVAL, "psp_csr_create: column index %d out of range at %d", col_host[bad], (int)bad);
+    }
   }
   PSP_HIP(hipStreamSynchronize(stream()));
   PSP_TRY(finalize_csr(A));
@@ -5194,6 +5361,30 @@ int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
   return PSP_OK;
 }
 
+int psp_csr_prepare(psp_csr_t *A, long long expected_products) {
+  PSP_API_GUARD_H(A);
+  if (!A) return fail(PSP_EINVAL, "psp_csr_prepare: NULL handle");
+  if (A->host || A->multi || A->nparts) return PSP_OK;  // nothing to decide for these
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  g_extra[A].expected_products = expected_products < 0 ? 0 : (expected_products > 0x7fffffffffffLL ? 0x7fffffffffffLL : (long)expected_products);
+  return PSP_OK;
+}
+
+int psp_csr_setup_info(psp_csr_t *A, double *info4) {
+  PSP_API_GUARD_H(A);
+  if (!A || !info4) return fail(PSP_EINVAL, "psp_csr_setup_info: NULL argument");
+  info4[0] = info4[1] = info4[2] = info4[3] = 0.0;
+  if (A->host || A->multi || A->nparts) return PSP_OK;
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  auto it = g_extra.find(A);
+  if (it == g_extra.end()) return PSP_OK;
+  info4[0] = it->second.reorder_ms;
+  info4[1] = (double)it->second.products;
+  info4[2] = (double)reorder_after();
+  info4[3] = (double)it->second.reorder_state;
+  return PSP_OK;
+}
+
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info) {
   PSP_API_GUARD_H(A);
   if (!A) return fail(PSP_EINVAL, "psp_csr_kernel_info: NULL handle");
@@ -5316,6 +5507,18 @@ int64_t psp_csr_device_bytes(const psp_csr_t *A) {
 
 // ------------------------------------------------------------------ C ABI: sss
 
+// 0 <= col < row for every stored entry of an sss_mat's lower triangle; *bad = the smallest (row << 32 | position) that
+// is not (unchanged: all are)
+__global__ __launch_bounds__(256) void sss_validate_kernel(int n, const int *__restrict__ ind, const int *__restrict__ col,
+                                                           unsigned long long *bad) {
+  const int lane = threadIdx.x & 63;
+  for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4)
+    for (int k = ind[i] + lane; k < ind[i + 1]; k += 64) {
+      const int c = col[k];
+      if (c < 0 || c >= i) atomicMin(bad, ((unsigned long long)(unsigned)i << 32) | (unsigned)k);
+    }
+}
+
 // rows of the full mirror of an sss_mat: lower entries, the diagonal, the transposed lower triangle's row
 __global__ __launch_bounds__(256) void sss_full_len_kernel(int n, const int *__restrict__ lind,
                                                            const int *__restrict__ tind, int *__restrict__ flen) {
@@ -5354,19 +5557,18 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
   if (!out || !ind_host || !diag_host || (nnz_lower > 0 && (!col_host || !val_host)))
     return fail(PSP_EINVAL, "psp_sss_create: NULL argument");
   if (n < 0 || nnz_lower < 0) return fail(PSP_EINVAL, "psp_sss_create: negative size");
+  psp::setup_mark(nullptr);
   if (ind_host[0] != 0 || ind_host[n] != nnz_lower)
     return fail(PSP_EINVAL, "psp_sss_create: ind[0] must be 0 and ind[n] == nnz");
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n; ++i)
     if (ind_host[i + 1] < ind_host[i])
       return fail(PSP_EINVAL, "psp_sss_create: ind not monotone at row %d", i);
-    for (int k = ind_host[i]; k < ind_host[i + 1]; ++k)
-      if (col_host[k] < 0 || col_host[k] >= i)
-        return fail(PSP_EINVAL, "psp_sss_create: entry (%d,%d) is not strictly lower", i,
-                    col_host[k]);
-  }
+  // (the columns -- 0 <= col < row for every stored entry -- are checked on the device once they are there:
+  // sss_validate_kernel below; on the host the loop over 2e7 entries was 9 ms of a 60 ms upload)
   if (2L * nnz_lower + n > 0x7fffffffL)
     return fail(PSP_EINVAL, "psp_sss_create: expanded matrix exceeds 32-bit indices");
   PSP_TRY(ensure_device());
+  psp::setup_mark("sss_create: host validation");
 
   // Expand to the full, column-sorted CSR the device multiplies with -- on the device.  Row i receives its
   // lower entries (stored order), the diagonal, then the mirrored entries (i, r) for the rows r > i that
@@ -5404,18 +5606,42 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
       return cleanup(fail(e_ == hipErrorOutOfMemory ? PSP_ENOMEM : PSP_ENODEV, "%s: %s", #call,        \
                           hipGetErrorString(e_)));                                                     \
   } while (0)
+  // (plain copies from the caller's pageable arrays: they run at the wire's 57 GB/s once a process has made its first large
+  // copy -- which costs ~160 ms whatever it copies; staging through pinned buffers filled by host threads was built and
+  // measured slower, 11.5 against 2.8 ms for the 79 MB of columns: profiles/r6_config5_setup.txt)
   SSS_HIP(hipMemcpyAsync(S->ind, ind_host, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, stream()));
   if (nnz_lower) {
     SSS_HIP(hipMemcpyAsync(S->col, col_host, sizeof(int) * (size_t)nnz_lower, hipMemcpyHostToDevice, stream()));
     SSS_HIP(hipMemcpyAsync(S->val, val_host, sizeof(double) * (size_t)nnz_lower, hipMemcpyHostToDevice, stream()));
   }
   if (n) SSS_HIP(hipMemcpyAsync(S->diag, diag_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream()));
+  psp::setup_mark("sss_create: allocate + copy the arrays up");
+  if (nnz_lower) {  // every entry strictly below the diagonal, before anything indexes with the columns
+    unsigned long long *d_bad = nullptr, bad = ~0ull;
+    SSS_HIP(hipMalloc((void **)&d_bad, sizeof(bad)));
+    hipError_t ev = hipMemcpyAsync(d_bad, &bad, sizeof(bad), hipMemcpyHostToDevice, stream());
+    if (ev == hipSuccess) {
+      hipLaunchKernelGGL(sss_validate_kernel, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, stream(), n, S->ind, S->col, d_bad);
+      ev = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream());
+    }
+    if (ev == hipSuccess) ev = hipStreamSynchronize(stream());
+    (void)hipFree(d_bad);
+    SSS_HIP(ev);
+    if (bad != ~0ull) {
+      const int k = (int)(bad & 0xffffffffull);
+      return cleanup(fail(PSP_EINVAL, "psp_sss_create: entry (%d,%d) is not strictly lower", (int)(bad >> 32), col_host[k]));
+    }
+  }
+  psp::setup_mark("sss_create: validate the columns (device)");
   rc = alloc_csr(n, n, nnz_lower, &T);
   if (rc != PSP_OK) return cleanup(rc);
+  psp::setup_mark("sss_create: allocate the transpose");
   rc = transpose_into(n, n, nnz_lower, S->ind, S->col, S->val, T);
   if (rc != PSP_OK) return cleanup(rc);
+  psp::setup_mark("sss_create: transpose (radix sort)");
   rc = alloc_csr(n, n, 2L * nnz_lower + n, &F);
   if (rc != PSP_OK) return cleanup(rc);
+  psp::setup_mark("sss_create: allocate the mirror");
   {
     SSS_HIP(hipMalloc((void **)&flen, sizeof(int) * ((size_t)n + 1)));
     hipLaunchKernelGGL(sss_full_len_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, stream(), n, S->ind, T->ind, flen);
@@ -5430,10 +5656,13 @@ int psp_sss_create(int n, int nnz_lower, const int *ind_host, const int *col_hos
     SSS_HIP(hipStreamSynchronize(stream()));
   }
 #undef SSS_HIP
+  psp::setup_mark("sss_create: fill the mirror");
   rc = finalize_csr(F);
   if (rc != PSP_OK) return cleanup(rc);
+  psp::setup_mark("sss_create: finalize_csr(mirror)");
   S->full = F;
   (void)cleanup(PSP_OK);
+  psp::setup_mark("sss_create: free the scratch");
   S->full->sym_owner = S;
   *out = S;
   return PSP_OK;
@@ -5568,6 +5797,23 @@ int psp_sss_kernel_info(psp_sss_t *S, char *name, int name_cap, int *info) {
     return PSP_OK;
   }
   return psp_csr_kernel_info(S->full, name, name_cap, info);
+}
+
+int psp_sss_prepare(psp_sss_t *S, long long expected_products) {
+  PSP_API_GUARD_H(S);
+  if (!S) return fail(PSP_EINVAL, "psp_sss_prepare: NULL handle");
+  if (S->host) return PSP_OK;
+  return psp_csr_prepare(S->full, expected_products);
+}
+
+int psp_sss_setup_info(psp_sss_t *S, double *info4) {
+  PSP_API_GUARD_H(S);
+  if (!S || !info4) return fail(PSP_EINVAL, "psp_sss_setup_info: NULL argument");
+  if (S->host) {
+    info4[0] = info4[1] = info4[2] = info4[3] = 0.0;
+    return PSP_OK;
+  }
+  return psp_csr_setup_info(S->full, info4);
 }
 
 int psp_sss_set_variant(psp_sss_t *S, int variant) {

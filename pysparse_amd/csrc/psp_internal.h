@@ -25,6 +25,10 @@ const char *tuning_env(const char *name);
 void note_solve(const char *loop, int launches_per_iter, int vec_bytes_per_row, int dinv_streamed);
 void note_fallback();
 bool single_kernel_loops_enabled();
+// PSP_TUNING=1 PSP_SETUP_TRACE=1: where the set-up of a handle goes -- setup_mark(label) waits for the calling thread's
+// stream and prints the milliseconds since the previous mark to stderr (label == nullptr: restart the clock silently).
+// One relaxed load otherwise.  tools/setup_breakdown.py reads the lines.
+void setup_mark(const char *label);
 // Threading model (round 4; SURVEY 8b: "one HIP stream per handle; handles not thread-safe").
 //   * What an entry point enqueues on -- device, stream, reduction workspace, host staging -- belongs to the CALLING
 //     THREAD (a thread-local context).  The first thread that touches the library keeps the null stream (or whatever it

@@ -499,6 +499,11 @@ __global__ __launch_bounds__(256) void sym_rows_kernel(long m, int n, const unsi
   if (i < m) scol[i] = (int)(keys[i] & 0xffffffffull);
 }
 
+// (Round 6 measured the whole numbering as ONE cooperative kernel -- grid barriers instead of launches, children ranked
+// among their siblings in LDS instead of a radix sort per level: 22 ms against the 12 ms of the launch-per-level loop
+// below at n = 9.3e5 in a warm process.  What crosses workgroups there must be read with device-coherent loads, each a
+// 2-3 us round trip, and a lane's dozen of them per level are dependent; the per-level kernels read through the caches
+// with n threads in flight.  Backed out; profiles/r6_config5_setup.txt.)
 struct DevBuf {  // frees on scope exit
   void *p = nullptr;
   ~DevBuf() {
@@ -545,6 +550,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
   unsigned long long *d_min = reinterpret_cast<unsigned long long *>(d_ok + 4);
   unsigned long long *d_degsum = reinterpret_cast<unsigned long long *>(d_ok + 6);
 
+  setup_mark("rcm: scratch allocations");
   // degrees + the symmetry / ordering check
   {
     const int init[8] = {1, 0, 0, 0, 0, 0, 0, 0};
@@ -554,6 +560,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
     int res[8];
     PSP_HIP(hipMemcpyAsync(res, d_ok, sizeof(res), hipMemcpyDeviceToHost, st));
     PSP_HIP(hipStreamSynchronize(st));
+    setup_mark("rcm: degrees + symmetry check (rcm_deg_kernel)");
     if (!res[0]) {
       *status = -1;  // not structurally symmetric with ascending rows: reorder_symmetrize_device first
       return PSP_OK;
@@ -570,6 +577,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
       PSP_HIP(hipStreamSynchronize(st));
       if ((long)hubs * 100 > (long)n) thr = 0x7fffffff;
     }
+    setup_mark("rcm: hubs");
     int degbits = 1, posbits = 1;
     while ((1L << degbits) <= res[1]) ++degbits;
     while ((1L << posbits) < n) ++posbits;
@@ -587,6 +595,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
     PSP_HIP(hipMemsetAsync(pos, 0xff, sizeof(int) * (size_t)n, st));      // -1: not placed
     PSP_HIP(hipMemsetAsync(parent, 0x7f, sizeof(int) * (size_t)n, st));   // kRcmInf: no parent yet
     pred = RcmDiscovered{pos, parent};
+    setup_mark("rcm: degrees, symmetry check, hubs, sort scratch");
 
     int levels_walked = 0;
     // breadth-first level structure from `root` inside the unplaced part; returns the number of levels (0 = gave up)
@@ -680,6 +689,7 @@ int reorder_rcm_device(int n, const int *ind, const int *col, int **perm_dev, in
       }
       placed = hi;
     }
+    setup_mark("rcm: numbering (launch per level)");
     if (placed < n) {  // the hubs, by id, behind everybody else
       size_t tb = bytes_tmp;
       RcmHub is_hub{deg, thr};

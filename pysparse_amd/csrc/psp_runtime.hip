@@ -101,6 +101,21 @@ void note_solve(const char *loop, int launches_per_iter, int vec_bytes_per_row, 
 void note_fallback() { g_sk_fallbacks.fetch_add(1, std::memory_order_relaxed); }
 bool single_kernel_loops_enabled() { return g_sk_enabled.load(std::memory_order_relaxed) != 0; }
 
+void setup_mark(const char *label) {
+  static const bool on = [] {
+    const char *e = tuning_env("PSP_SETUP_TRACE");
+    return e && atoi(e) != 0;
+  }();
+  if (!on) return;
+  static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  if (tl.dev_state == 1) {
+    if (hipStreamSynchronize(stream()) != hipSuccess) (void)hipGetLastError();
+  }
+  const auto now = std::chrono::steady_clock::now();
+  if (label) fprintf(stderr, "[psp setup] %-44s +%9.3f ms\n", label, std::chrono::duration<double, std::milli>(now - last).count());
+  last = now;
+}
+
 HandleEntry &handle_entry(const void *handle) {
   static std::mutex mu;
   static std::unordered_map<const void *, std::unique_ptr<HandleEntry>> tab;  // entries live as long as the process

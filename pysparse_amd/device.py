@@ -220,6 +220,17 @@ class DeviceCSR:
         return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
                                      "half_band": info[3]}
 
+    def prepare(self, expected_products):
+        """psp_csr_prepare: the caller expects about this many products / solver iterations with this handle -- whatever
+        pays for itself within them (the renumbered copy of an irregular numbering: from 4096 on) is built at the next
+        product instead of after that many have been counted"""
+        check(lib().psp_csr_prepare(self._h, int(expected_products)))
+
+    def setup_info(self):
+        v = (C.c_double * 4)()
+        check(lib().psp_csr_setup_info(self._h, v))
+        return {"reorder_ms": v[0], "products_counted": int(v[1]), "reorder_after": int(v[2]), "reorder_state": int(v[3])}
+
     def renumbering(self):
         """perm[new] = old row of the renumbered copy behind csr_spmv_w3_rcm, or None when the handle has none."""
         perm = np.empty(self.shape[0], dtype=np.int32)
@@ -284,6 +295,15 @@ class DeviceSSS:
 
     def set_variant(self, v):
         check(lib().psp_sss_set_variant(self._h, int(v)))
+
+    def prepare(self, expected_products):
+        """psp_sss_prepare (see DeviceCSR.prepare)"""
+        check(lib().psp_sss_prepare(self._h, int(expected_products)))
+
+    def setup_info(self):
+        v = (C.c_double * 4)()
+        check(lib().psp_sss_setup_info(self._h, v))
+        return {"reorder_ms": v[0], "products_counted": int(v[1]), "reorder_after": int(v[2]), "reorder_state": int(v[3])}
 
     def kernel_info(self):
         name = C.create_string_buffer(64)

@@ -23,7 +23,7 @@ def parse(stdout):
     line, full = bench_line.read(stdout)
     for k in line:  # whatever the line says, the side file says too (the launcher object: in full there, in short here)
         if k not in ("side_file", "side_keys", "launcher", "config", "roofline", "cpu_baseline", "parity_check", "phases",
-                     "parity_vs_n1", "preflight", "transport", "provenance", "published_table"):
+                     "parity_vs_n1", "preflight", "transport", "provenance", "published_table", "config5"):
             assert full.get(k) == line[k], k
     d = dict(full)
     d["_line"] = line
@@ -314,6 +314,12 @@ def test_bench_mtx_leg_on_a_matrix_market_file(tmp_path):
     assert c["minres"]["info"] == 0 and c["minres"]["us_per_iteration"] > 0 and c["kernel"]
     assert 0 < d["roofline"]["frac"] <= 1.0 and c["csr_model_frac_of_peak"] <= 1.0
     assert "error" not in d and d["data"] == "user file"
+    # round 6: time to solution (the handle's cost rule) beside the steady state (products announced)
+    t = c["time_to_solution"]
+    assert t["end_to_end_ms"] >= t["upload_ms"] + t["first_solve_ms"] > 0 and c["cold"]["kernel"] and c["setup_ms"] >= 0.0
+    assert c["kernel_info"]["setup_ms"] == c["setup_ms"] and c["parity"]["x_max_rel_diff_renumbered"] <= 1e-12
+    l5 = d["_line"]["config5"]
+    assert l5["parity_ok"] is True and l5["time_to_solution"]["end_to_end_ms"] == t["end_to_end_ms"]
 
 
 def _run_external(*extra, timeout=240):

@@ -538,6 +538,8 @@ def test_csr_matvec_scattered_numbering_bit_exact(oracle, shuffle, form):
     So.matvec(x, yo)
     for M in (S, A):
         M.set_variant(variant)
+        if form == "rcm":
+            M.prepare(1 << 30)  # the copy at first use; without the announcement the cost rule starts on csr_spmv_w5
         kern, info = M.kernel_info()
         if form == "w5":
             assert kern == "csr_spmv_w5" and info["max_blocks"] > 64 and info["half_band"] <= info["nb"] <= 512, (kern, info)
@@ -812,3 +814,52 @@ def test_csr_matvec_w6_streams_the_stored_arrays_bit_exact(oracle, case):
         y2 = np.full(m, np.nan)
         D.matvec(x, y2)
         assert np.array_equal(y2, yo, equal_nan=True), v
+
+
+def test_renumbered_copy_cost_rule(oracle):
+    """Round 6 (VERDICT r5 #4a): the renumbered copy costs 17-57 ms and buys 7-12 us per product, so a handle multiplies on
+    its stored numbering (csr_spmv_w5) until it has done 4096 products or its caller announces that many (psp_csr_prepare);
+    y keeps its bits across the switch, the counters say what happened, and a solve that starts after the switch runs in
+    the copy's numbering (rounding-level differences in its iterates, the oracle's count)."""
+    from pysparse_amd import device as dev
+    from pysparse_amd.tools.standins import fem_sss_arrays
+    n, ind, col, val, diag = fem_sss_arrays(20, 18, 16, 512)
+    So = oracle.SSS(n, val, diag, col, ind)
+    S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    x = np.random.default_rng(3).standard_normal(n)
+    yo = np.empty(n)
+    So.matvec(x, yo)
+    assert S.kernel_info()[0] == "csr_spmv_w5" and S.setup_info()["reorder_state"] == -1
+    xd, yd = dev.DeviceBuffer.from_host(x), dev.DeviceBuffer(n)
+    S.matvec_dev(xd.ptr, yd.ptr)
+    assert np.array_equal(yd.download(), yo)
+    info = S.setup_info()
+    assert info["products_counted"] == 1 and info["reorder_after"] == 4096 and info["reorder_ms"] == 0.0
+    K = dev.DeviceJacobi(S)
+    b = np.zeros(n)
+    b[0] = 1.0
+    x1 = np.zeros(n)
+    r1 = dev.minres(S, b, x1, 1e-10, 500, K)  # on the stored numbering
+    ref = oracle.minres(So, b, np.zeros(n), 1e-10, 500, oracle.jacobi_dinv(diag))
+    assert r1[:2] == ref[:2] and S.kernel_info()[0] == "csr_spmv_w5"
+    assert 1 < S.setup_info()["products_counted"] < 4096
+    for _ in range(4096):  # (asynchronous launches of a 17 000-row product: a fraction of a second)
+        S.matvec_dev(xd.ptr, yd.ptr)
+    assert S.setup_info()["products_counted"] == 4096 and S.kernel_info()[0] == "csr_spmv_w3_rcm"
+    S.matvec_dev(xd.ptr, yd.ptr)
+    assert np.array_equal(yd.download(), yo)  # the same bits through the copy
+    info = S.setup_info()
+    assert info["reorder_state"] == 1 and info["reorder_ms"] > 0.0 and info["products_counted"] == 4096
+    x2 = np.zeros(n)
+    r2 = dev.minres(S, b, x2, 1e-10, 500, K)  # in the copy's numbering
+    assert r2[:2] == r1[:2] and np.abs(x2 - x1).max() <= 1e-12 * np.abs(x1).max()
+    # announced: the copy at the first product
+    S2 = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)
+    S2.prepare(10000)
+    assert S2.kernel_info()[0] == "csr_spmv_w3_rcm"
+    y2 = np.full(n, np.nan)
+    S2.matvec(x, y2)
+    assert np.array_equal(y2, yo)
+    x3 = np.zeros(n)
+    r3 = dev.minres(S2, b, x3, 1e-10, 500, dev.DeviceJacobi(S2))
+    assert r3 == r2 and np.array_equal(x3, x2)  # the same numbering from the start: the same bits

@@ -143,6 +143,7 @@ def test_two_threads_sharing_one_handle_take_turns_and_stay_correct(oracle):
     O = oracle.sss_to_csr(S)
     n = O.shape[0]
     A = dev.DeviceCSR.from_arrays(O.shape, O.ind, O.col, O.val)
+    A.prepare(1 << 30)  # (round 6: the copy is built at first use only when that many products are announced)
     D = dev.DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
     K = dev.DeviceSSOR(D, 1.0, 1)
     xs = [rng.standard_normal(n) for _ in range(2)]
@@ -191,6 +192,7 @@ def test_two_threads_async_dev_entry_points_on_one_handle(oracle):
     O = oracle.sss_to_csr(S)
     n = O.shape[0]
     A = dev.DeviceCSR.from_arrays(O.shape, O.ind, O.col, O.val)
+    A.prepare(1 << 30)  # the renumbered copy (whose scratch vectors the race was about) at first use
     D = dev.DeviceSSS.from_arrays(S.n, S.ind, S.col, S.val, S.diag)
     K = dev.DeviceSSOR(D, 1.0, 1)
     reps = 24
