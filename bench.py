@@ -503,7 +503,7 @@ def mtx_leg(spec, steps=50, minres_iters=200):
     sync()
     # ---- time to solution, as a script that solves ONCE sees it (examples/demo_pcg.py:47-98): arrays up, Jacobi, converged
     # MINRES with x back in the caller's array.  The handle decides by its cost rule what to build (psp_csr.hip
-    # pick_scattered: an irregular numbering multiplies with csr_spmv_w5 and gets its renumbered copy after 4096 products)
+    # pick_scattered: an irregular numbering multiplies with csr_spmv_w5 and gets its renumbered copy after 2048 products)
     t_all = time.perf_counter()
     t0 = time.perf_counter()
     S = dev.DeviceSSS.from_arrays(n, ind, col, val, diag)

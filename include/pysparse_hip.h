@@ -274,11 +274,11 @@ int psp_csr_set_schedule(psp_csr_t *A, int strip_rows);
  *   to right (csr_mat.c:49-54), so the choice never changes a bit of y. */
 int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
 /* Set-up against steady state for irregular numberings (round 6; no reference analogue: csr_mat.c:259-296 builds nothing).
- * A csr_mat whose stored numbering scatters its columns (an FEM mesh as it comes out of a generator) multiplies 7-12 us
- * faster per product through a renumbered copy (reverse Cuthill-McKee, "csr_spmv_w3_rcm") than on the stored numbering
- * ("csr_spmv_w5") -- and the copy costs 17-57 ms to build at n = 9.3e5.  The library therefore builds it only once a handle
- * has done 4096 products (solver iterations included), or at the next product after the caller has announced at least that
- * many here.  y = A x has the same bits either way; a fused solve's iterates differ at rounding level between the two
+ * A csr_mat whose stored numbering scatters its columns (an FEM mesh as it comes out of a generator) multiplies 4-12 us
+ * faster per product, and iterates 16-24 us faster per Jacobi-MINRES iteration, through a renumbered copy (reverse
+ * Cuthill-McKee, "csr_spmv_w3_rcm") than on the stored numbering ("csr_spmv_w5") -- and the copy costs 17-57 ms to build at
+ * n = 9.3e5.  The library therefore builds it only once a handle has done 2048 products (solver iterations included), or at
+ * the next product after the caller has announced at least that many here.  y = A x has the same bits either way; a fused solve's iterates differ at rounding level between the two
  * numberings (its dot products add in the numbering it runs in), deterministically for a given sequence of calls.
  * psp_csr_setup_info: info4 = {ms the copy took to build (0: not built), products counted so far, the threshold,
  * state (-1 undecided, 0 examined and not built, 1 built)}. */

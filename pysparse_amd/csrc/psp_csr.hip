@@ -3693,17 +3693,19 @@ static void launch_w5(const psp_csr *A, const ChunkTable *t, int grid, int strip
 // stand-ins and the only form that cuts the cache-line traffic of the x gathers), 2 = csr_spmv_w5, 0 = neither
 // (csr_spmv_w2).  A/B: variant bit 27 switches the renumbered copy off, bit 28 csr_spmv_w5.
 // THE COST RULE OF THE RENUMBERED COPY (round 6, VERDICT r5 #4a).  Building it -- reverse Cuthill-McKee on the device, R =
-// P A P^T, R's tables -- takes 17-20 ms at n = 9.3e5 / 4.1e7 nonzeros in a warm process (45-57 ms in a fresh one); what it
-// buys is 7-12 us per product against csr_spmv_w5 on the stored numbering (0.092-0.097 against 0.099-0.109 ms; 117
-// against 127 us per Jacobi-MINRES iteration): it pays for itself after ~2 000-4 000 products, and the solve of
-// BASELINE.json configs[4] converges in 14.  So a handle multiplies with csr_spmv_w5 until it HAS done kReorderAfter
-// products (counted here: every product and every solver iteration on the stored numbering) or its caller announces that
-// many (psp_csr_prepare / psp_sss_prepare); the copy is then built at the next product or at the start of the next solve
-// -- never in the middle of one: a fused solve runs in one numbering from its first reduction to its last.
+// P A P^T, R's tables -- takes 17-20 ms at n = 9.3e5 / 4.1e7 nonzeros in a warm process (46-57 ms the first time a process
+// does it); what it buys is 4-12 us per product against csr_spmv_w5 on the stored numbering (0.092-0.093 against
+// 0.097-0.105 ms) and 16-24 us per Jacobi-MINRES iteration (106 against 122-130: the fused loops then run in the copy's
+// numbering without permutation passes) -- profiles/r6_mtx_leg_standins.jsonl.  It pays for itself after 800 ... 4 000
+// products, and the solve of BASELINE.json configs[4] converges in 14.  So a handle multiplies with csr_spmv_w5 until it
+// HAS done kReorderAfter products (counted here: every product and every solver iteration on the stored numbering) or
+// its caller announces that many (psp_csr_prepare / psp_sss_prepare); the copy is then built at the next product.  A
+// fused solve that is under way keeps the numbering it started in from its first reduction to its last (its products go
+// through the copy's two permutation passes meanwhile); the next solve starts in the copy's numbering.
 // y = A x has the same bits either way; a solve's iterates differ at rounding level between the two numberings (its
 // reductions add in the numbering it runs in), deterministically for a given sequence of calls.
 // PSP_SPMV_REORDER_AFTER (tuning) moves the threshold; 0 = the copy at first use, as rounds 2-5 built it.
-constexpr long kReorderAfter = 4096;
+constexpr long kReorderAfter = 2048;
 static long reorder_after() {
   static const long v = [] {
     const char *e = psp::tuning_env("PSP_SPMV_REORDER_AFTER");

@@ -222,7 +222,7 @@ class DeviceCSR:
 
     def prepare(self, expected_products):
         """psp_csr_prepare: the caller expects about this many products / solver iterations with this handle -- whatever
-        pays for itself within them (the renumbered copy of an irregular numbering: from 4096 on) is built at the next
+        pays for itself within them (the renumbered copy of an irregular numbering: from 2048 on) is built at the next
         product instead of after that many have been counted"""
         check(lib().psp_csr_prepare(self._h, int(expected_products)))
 

@@ -71,7 +71,7 @@ def renumbering_of(name):
     from pysparse_amd import device as dev
     n, ind, col, val = case_arrays(name)
     A = dev.DeviceCSR.from_arrays((n, n), ind, col, val)
-    A.prepare(1 << 30)  # the copy at first use (the cost rule would wait for 4096 products)
+    A.prepare(1 << 30)  # the copy at first use (the cost rule would wait for 2048 products)
     kern, _ = A.kernel_info()
     x = np.random.default_rng(5).standard_normal(n)
     y = np.empty(n)

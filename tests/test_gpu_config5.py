@@ -40,7 +40,7 @@ def test_config5_sss_matvec_and_minres_at_scale(oracle, name):
     So = oracle.SSS(n, val, diag, col, ind)
     kern, info = S.kernel_info()
     if name.startswith("fem"):
-        # round 6: a fresh handle multiplies on its stored numbering (the renumbered copy comes after 4096 products, or when
+        # round 6: a fresh handle multiplies on its stored numbering (the renumbered copy comes after 2048 products, or when
         # announced -- test_gpu_spmv.py::test_renumbered_copy_cost_rule); one solve on it against the oracle, then the rest
         # of this test through the copy, as rounds 2-5 ran it
         assert kern == "csr_spmv_w5" and info["max_blocks"] > 64, (kern, info)
