@@ -300,10 +300,16 @@ def published_table_leg(O, sizes=(100, 300, 500)):
                 os.makedirs(os.path.join(td, "matrices"))
                 with open(os.path.join(td, "matrices", "poi2d_100.mtx"), "w") as f:
                     f.write("%%%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (n, n, So.nnz_lower + n))
+                    # row by row: a row's lower entries, then its diagonal -- the order oracle/make_golden.py wrote the pinned
+                    # files in (the program's COO -> SSS lists use 0 as "no entry": the file's FIRST entry must be a diagonal
+                    # one, and a row's columns come out in reverse file order, which its own product does not mind)
                     rr = np.repeat(np.arange(n), np.diff(So.ind))
-                    ii = np.concatenate([rr, np.arange(n)]) + 1
-                    jj = np.concatenate([So.col, np.arange(n)]) + 1
-                    vv = np.concatenate([So.val, So.diag])
+                    tot = So.nnz_lower + n
+                    ii, jj, vv = np.empty(tot, dtype=np.int64), np.empty(tot, dtype=np.int64), np.empty(tot)
+                    pl = np.arange(So.nnz_lower) + rr
+                    pd = np.asarray(So.ind[1:], dtype=np.int64) + np.arange(n)
+                    ii[pl], jj[pl], vv[pl] = rr + 1, np.asarray(So.col, dtype=np.int64) + 1, So.val
+                    ii[pd], jj[pd], vv[pd] = np.arange(n) + 1, np.arange(n) + 1, So.diag
                     np.savetxt(f, np.column_stack([ii, jj, vv]), fmt="%d %d %.17g")
                 t0 = time.perf_counter()
                 out = subprocess.run([O.REF_BIN_PATH], cwd=td, capture_output=True, text=True,

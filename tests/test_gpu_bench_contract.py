@@ -388,7 +388,7 @@ def test_bench_rank_guard_falls_back_to_the_single_process_stage_on_the_gpu():
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--backend", "gloo", "--share-gpu", "--grid", "64,48,36", "--steps", "4",
                           "--warmup", "2", "--pcg-iters", "24", "--no-cpu-baseline", "--no-clocks", "--inject", "hang:1",
-                          "--rank-deadline", "20"],
+                          "--rank-deadline", "12"],
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     d = parse(out.stdout)

@@ -69,13 +69,28 @@ def _check(out, k, with_oracle, need_ref):
     assert out["ok"]
 
 
+@pytest.fixture(scope="module")
+def c3_host(oracle):
+    """the 512^3 operator and right-hand side on the host, shared by the two C3 tests below (generating them twice was 18 s
+    of the suite); None where the box has no room"""
+    if _mem_available_gb() < 64:
+        yield None
+        return
+    A = oracle.poisson_csr(512, 512, 512)
+    b = np.empty(A.shape[0])
+    A.matvec(np.ones(A.shape[0]), b)
+    yield A, b
+    del A, b
+
+
 @pytest.mark.parametrize("grid,k", [((4096, 4096, 0), 10), ((512, 512, 512), 3)])
-def test_gpu_iterates_against_oracle_and_reference_at_baseline_sizes(oracle, grid, k):
+def test_gpu_iterates_against_oracle_and_reference_at_baseline_sizes(oracle, grid, k, c3_host):
     import bench
     from pysparse_amd import device as dev
-    if grid[2] and _mem_available_gb() < 48:
+    if grid[2] and c3_host is None:
         pytest.skip("512^3 on the host (14 GB of matrix + vectors) needs more memory than this box has free")
-    out = bench.gpu_parity_case(dev, oracle, grid, k)
+    A, b = c3_host if grid[2] else (None, None)
+    out = bench.gpu_parity_case(dev, oracle, grid, k, A=A, b=b)
     assert out["n"] == grid[0] * grid[1] * max(grid[2], 1)
     assert bench.parity_bound(out["n"], k) < 5e-10 and bench.parity_bound(out["n"], k, "reference") < 4e-11
     need_ref = oracle.have_ref() and oracle.have_ref_krylov()
@@ -84,18 +99,19 @@ def test_gpu_iterates_against_oracle_and_reference_at_baseline_sizes(oracle, gri
     _check(out, k, True, need_ref)
 
 
-def test_gpu_against_compiled_reference_20_iterations_at_512_cubed(oracle):
+def test_gpu_against_compiled_reference_20_iterations_at_512_cubed(oracle, c3_host):
     """drift, not just the first steps: k = 20 at C3 against the reference's own pcg.c and minres.c (no oracle leg: its
     sequential products would take minutes; the compiled kernels get the row-parallel callbacks)"""
     import bench
     from pysparse_amd import device as dev
     if not (oracle.have_ref() and oracle.have_ref_krylov()):
         pytest.skip("oracle/_ref was not built (needs /root/reference at build time)")
-    if _mem_available_gb() < 64:
+    if c3_host is None:
         pytest.skip("512^3 on the host + the reference kernels' 8 n work array need more memory than this box has free")
     k = 20
     threads = bench._usable_cores()
-    out = bench.gpu_parity_case(dev, oracle, (512, 512, 512), k, with_oracle=False, ref_threads=threads)
+    out = bench.gpu_parity_case(dev, oracle, (512, 512, 512), k, A=c3_host[0], b=c3_host[1], with_oracle=False,
+                                ref_threads=threads)
     assert bench.parity_bound(out["n"], k, "reference") < 2.1e-10
     _check(out, k, False, True)
     for name in ("pcg", "minres"):
