@@ -283,6 +283,13 @@ int psp_csr_kernel_info(psp_csr_t *A, char *name, int name_cap, int *info);
  * psp_csr_setup_info: info4 = {ms the copy took to build (0: not built), products counted so far, the threshold,
  * state (-1 undecided, 0 examined and not built, 1 built)}. */
 int psp_csr_prepare(psp_csr_t *A, long long expected_products);
+/* An offset-structured csr_mat (csr_spmv_w4, <= 16 distinct col - row) multiplies with its index-free tables; the CSR arrays
+ * it was created from stay for download, the variants and ABI parity with CSRMatObject (csr_mat.h:6-13) -- 1.65 x the
+ * memory (512^3: 11.8 GB of arrays beside 7.8 GB of tables).  A caller that needs neither frees them here: the handle then
+ * supports matvec (incl. the transposed product), diagonal / jacobi, the solvers and kernel_info, like the operator of
+ * psp_csr_poisson_big; psp_csr_download fails with PSP_EINVAL and psp_csr_set_variant has nothing left to select.  Results do not change by a bit.
+ * PSP_EINVAL for handles that stream their CSR arrays (w3 / w6 / w2 / w5). */
+int psp_csr_release_arrays(psp_csr_t *A);
 int psp_csr_setup_info(psp_csr_t *A, double *info4);
 /* The renumbering behind "csr_spmv_w3_rcm" (irregular square operators): perm_host[new] = old row
  * (nrows ints) and *available = 2 (numbering computed on the device) or 1 (on the host: fallback, A/B switch) when

@@ -23,7 +23,7 @@ psp_event_create psp_event_destroy psp_event_record psp_event_elapsed_ms psp_str
 psp_csr_create psp_csr_poisson psp_csr_poisson_slab psp_csr_poisson_big psp_csr_poisson_big_slab psp_csr_nnz64 psp_csr_create64 psp_csr_random_banded psp_csr_download_rows psp_csr_destroy psp_csr_shape
 psp_csr_download psp_csr_diagonal psp_csr_matvec psp_csr_matvec_stride psp_csr_matvec_transp
 psp_csr_matvec_transp_stride psp_csr_matvec_dev psp_csr_matvec_transp_dev psp_csr_set_variant
-psp_csr_set_schedule psp_csr_kernel_info psp_csr_prepare psp_csr_setup_info psp_csr_renumbering psp_csr_device_bytes
+psp_csr_set_schedule psp_csr_kernel_info psp_csr_prepare psp_csr_setup_info psp_csr_release_arrays psp_csr_renumbering psp_csr_device_bytes
 psp_csr_poisson_multi psp_csr_create_multi psp_csr_multi_info psp_csr_multi_spmv_time psp_csr_multi_phase_time psp_multi_plan
 psp_sss_create psp_sss_poisson psp_sss_destroy psp_sss_shape psp_sss_download psp_sss_getitem
 psp_sss_matvec psp_sss_matvec_stride psp_sss_matvec_dev psp_sss_device_bytes
@@ -166,7 +166,7 @@ def _declare(L):
         "psp_kd_minres_lanczos": [vp, i, vp, vp, vp, vp, vp, vp], "psp_kd_minres_scalar": [vp, i, vp],
         "psp_kd_minres_wx": [vp, i, vp, vp, vp, vp],
         "psp_last_solve_info": [C.c_char_p, i, C.POINTER(i)], "psp_set_single_kernel_loops": [i],
-        "psp_csr_prepare": [vp, C.c_longlong], "psp_sss_prepare": [vp, C.c_longlong],
+        "psp_csr_release_arrays": [vp], "psp_csr_prepare": [vp, C.c_longlong], "psp_sss_prepare": [vp, C.c_longlong],
         "psp_csr_setup_info": [vp, C.POINTER(d)], "psp_sss_setup_info": [vp, C.POINTER(d)],
     }
     for name, argtypes in sig.items():

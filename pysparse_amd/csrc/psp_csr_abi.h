@@ -291,7 +291,7 @@ int psp_csr_download_rows(const psp_csr_t *A, int row_lo, int row_hi, int64_t *i
                           double *val_host) {
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_download_rows");
   if (!A || !ind_host) return fail(PSP_EINVAL, "psp_csr_download_rows: NULL argument");
-  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download_rows: the operator has no CSR arrays");
+  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download_rows: the operator has no CSR arrays (psp_csr_poisson_big, psp_csr_release_arrays)");
   if (row_lo < 0 || row_hi > A->nrows || row_lo > row_hi) return fail(PSP_EINVAL, "psp_csr_download_rows: bad row range");
   int64_t written = 0;
   ind_host[0] = 0;
@@ -377,7 +377,7 @@ int psp_csr_download(const psp_csr_t *A, int *ind_host, int *col_host, double *v
   if (A && A->host) return psp::cpu::csr_download(A, ind_host, col_host, val_host);
   if (A && A->multi) return fail(PSP_EINVAL, "%s is not available on a multi-device matrix (psp_csr_*_multi): use matvec, jacobi, pcg, minres", "psp_csr_download");
   if (!A) return fail(PSP_EINVAL, "psp_csr_download: NULL handle");
-  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big)");
+  if (A->w4_only) return fail(PSP_EINVAL, "psp_csr_download: the operator has no CSR arrays (psp_csr_poisson_big, psp_csr_release_arrays)");
   if (A->nparts) return fail(PSP_EINVAL, "psp_csr_download: more than 2^31 nonzeros: use psp_csr_download_rows");
   if (ind_host)
     PSP_HIP(hipMemcpyAsync(ind_host, A->ind, sizeof(int) * ((size_t)A->nrows + 1),
@@ -476,7 +476,7 @@ int psp_csr_matvec_transp_dev(psp_csr_t *A, const double *x_dev, double *y_dev) 
     PSP_TRY(launch_w4_transp(A, x_dev, y_dev, &done));
     if (done) return PSP_OK;
   }
-  if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big)");
+  if (A->w4_only) return fail(PSP_EINVAL, "matvec_transp: the operator has no CSR arrays (psp_csr_poisson_big, psp_csr_release_arrays)");
   if (A->nparts) return fail(PSP_EINVAL, "matvec_transp: not available for a partitioned (> 2^31 nonzeros) matrix");
   if (A->ncols == 0) return PSP_OK;
   // irregular matrices: multiply with A^T stored as CSR (built once): every y[c] adds its terms by
@@ -540,6 +540,58 @@ int psp_csr_renumbering(psp_csr_t *A, int *perm_host, int *available) {
   if (!dperm) return PSP_OK;
   PSP_HIP(hipMemcpy(perm_host, dperm, sizeof(int) * (size_t)A->nrows, hipMemcpyDeviceToHost));
   *available = on_device ? 2 : 1;
+  return PSP_OK;
+}
+
+int psp_csr_release_arrays(psp_csr_t *A) {
+  PSP_API_GUARD_H(A);
+  if (!A) return fail(PSP_EINVAL, "psp_csr_release_arrays: NULL handle");
+  if (A->w4_only) return PSP_OK;
+  if (A->host || A->multi || A->nparts || A->sym_owner)
+    return fail(PSP_EINVAL, "psp_csr_release_arrays: not available for this kind of handle");
+  PSP_TRY(ensure_device());
+  psp::CsrExtra *ex;
+  PSP_TRY(ensure_w4(A, &ex));
+  if (ex->dia_state != 1 || ex->dia_no > 16)
+    return fail(PSP_EINVAL, "psp_csr_release_arrays: the operator does not multiply with the index-free layout (csr_spmv_w4, "
+                            "<= 16 offsets): its CSR arrays are what it streams");
+  PSP_HIP(hipStreamSynchronize(stream()));  // nothing in flight reads the arrays
+  int slot = -1;
+  for (int o = 0; o < ex->dia_no; ++o)
+    if (ex->dia_offs.o[o] == 0) slot = o;
+  psp_csr *transposed = nullptr, *reordered = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);  // side tables that index into the arrays go with them
+    transposed = ex->transposed;
+    reordered = ex->reordered;
+    ex->transposed = ex->reordered = nullptr;
+    for (auto &t : ex->t) {
+      if (t.second.tab) (void)hipFree(t.second.tab);
+      if (t.second.rowoff) (void)hipFree(t.second.rowoff);
+      if (t.second.blist) (void)hipFree(t.second.blist);
+      if (t.second.blist6) (void)hipFree(t.second.blist6);
+      if (t.second.col16) (void)hipFree(t.second.col16);
+      if (t.second.ulist) (void)hipFree(t.second.ulist);
+      if (t.second.colu) (void)hipFree(t.second.colu);
+      if (t.second.perm) (void)hipFree(t.second.perm);
+    }
+    ex->t.clear();
+    if (ex->packed) (void)hipFree(ex->packed);
+    ex->packed = nullptr;
+  }
+  if (transposed) psp_csr_destroy(transposed);
+  if (reordered) psp_csr_destroy(reordered);
+  if (A->ind) (void)hipFree(A->ind);
+  if (A->col) (void)hipFree(A->col);
+  if (A->val) (void)hipFree(A->val);
+  A->ind = A->col = nullptr;
+  A->val = nullptr;
+  A->padded = 0;
+  A->nnz64 = A->nnz;
+  A->w4_diag_slot = slot;
+  A->max_row_nnz = ex->dia_no;  // what psp_csr_device_bytes prices an index-free handle with
+  A->variant = -1;
+  A->w4_only = true;
   return PSP_OK;
 }
 

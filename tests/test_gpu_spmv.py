@@ -864,3 +864,52 @@ def test_renumbered_copy_cost_rule(oracle):
     x3 = np.zeros(n)
     r3 = dev.minres(S2, b, x3, 1e-10, 500, dev.DeviceJacobi(S2))
     assert r3 == r2 and np.array_equal(x3, x2)  # the same numbering from the start: the same bits
+
+
+def test_release_arrays_keeps_the_bits_and_frees_the_csr_copy(oracle):
+    """psp_csr_release_arrays (round 6): an offset-structured operator multiplies with its index-free tables; the CSR arrays
+    it was created from (1.65 x the memory) can be given back.  Products, the transposed product, the diagonal and the
+    solvers keep their bits; download is refused; operators that stream their CSR arrays refuse the call."""
+    from pysparse_amd import device as dev
+    from pysparse_amd._capi import check, lib
+    grid = (160, 150, 100)  # 2.4e6 rows: large against the allocator's granularity
+    O = oracle.poisson_csr(*grid)
+    n = O.shape[0]
+    A = dev.DeviceCSR.from_arrays(O.shape, O.ind, O.col, O.val)  # (a user's arrays, not the device generator)
+    x = rng_vec(n, 5)
+    yo, yt = np.empty(n), np.empty(n)
+    O.matvec(x, yo)
+    O.matvec_transp(x, yt)
+    assert A.kernel_info()[0] == "csr_spmv_w4"
+    b = np.empty(n)
+    O.matvec(np.ones(n), b)
+    x1 = np.zeros(n)
+    r1 = dev.pcg(A, b, x1, 0.0, 30, dev.DeviceJacobi(A))
+    before = A.device_bytes
+    free0 = _free_bytes(lib(), check)
+    A.release_arrays()
+    A.release_arrays()  # idempotent
+    assert _free_bytes(lib(), check) - free0 >= 11 * O.nnz  # col + val (+ ind) came back
+    assert A.device_bytes < before and A.kernel_info()[0] == "csr_spmv_w4" and A.nnz == O.nnz and A.shape == O.shape
+    y = np.full(n, np.nan)
+    A.matvec(x, y)
+    assert np.array_equal(y, yo)
+    A.matvec_transp(x, y)
+    assert np.array_equal(y, yt)
+    x2 = np.zeros(n)
+    r2 = dev.pcg(A, b, x2, 0.0, 30, dev.DeviceJacobi(A))
+    assert r2 == r1 and np.array_equal(x1, x2)
+    with pytest.raises(Exception):
+        A.download()
+    # an operator that streams its CSR arrays keeps them
+    R = random_csr(oracle, 3000, 3000, 9, 12)
+    B = dev.DeviceCSR.from_arrays(R.shape, R.ind, R.col, R.val)
+    with pytest.raises(Exception, match="index-free"):
+        B.release_arrays()
+
+
+def _free_bytes(L, check):
+    import ctypes as C
+    f, t = C.c_int64(), C.c_int64()
+    check(L.psp_mem_info(C.byref(f), C.byref(t)))
+    return f.value
