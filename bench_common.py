@@ -20,8 +20,8 @@ W2_VARIANT = 128 + 64 + 2 + (64 << 8)              # csr_spmv_w2 (int32 col + fp
 W6_VARIANT = W2_VARIANT + (1 << 23)                # csr_spmv_w6 (the same streams, x staged in LDS; round 5)
 
 
-PMC_FILES = {"csr_spmv_w4": "r5_spmv_pmc.json", "csr_spmv_w3": "r5_spmv_w3_pmc.json",
-             "csr_spmv_w6": "r5_spmv_w6_pmc.json", "csr_spmv_w2": "r5_spmv_w2_pmc.json"}
+PMC_FILES = {"csr_spmv_w4": "r6_spmv_pmc.json", "csr_spmv_w3": "r5_spmv_w3_pmc.json",
+             "csr_spmv_w6": "r6_spmv_w6_pmc.json", "csr_spmv_w2": "r5_spmv_w2_pmc.json"}
 
 
 def csr_model_bytes(n, nnz):
