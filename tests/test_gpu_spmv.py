@@ -913,3 +913,65 @@ def _free_bytes(L, check):
     f, t = C.c_int64(), C.c_int64()
     check(L.psp_mem_info(C.byref(f), C.byref(t)))
     return f.value
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_transpose_by_counting_keeps_the_stable_order(oracle, seed):
+    """Round 6: transposes (the mirror of an sss_mat, A^T of an irregular csr_mat) are built by counting + a sort of each
+    column's entries by (row, stored position) instead of a stable radix sort by column.  Same result by construction;
+    checked where the order matters: duplicate (row, column) entries (their products are added in stored order),
+    unsorted rows, empty columns, rectangular shapes, one very long column -- y = A^T x bit for bit against the
+    oracle's row-wise scatter (csr_mat.c:74-88), twice (atomics decide slots, never the result)."""
+    from pysparse_amd.device import DeviceCSR
+    rng = np.random.default_rng(100 + seed)
+    m, n = ((700, 450), (300, 2000), (1500, 1500))[seed]
+    lens = rng.integers(0, 30, size=m)
+    lens[rng.random(m) < 0.1] = 0
+    ind = np.zeros(m + 1, dtype=np.int32)
+    np.cumsum(lens, out=ind[1:])
+    col = rng.integers(0, n, size=ind[-1]).astype(np.int32)  # unsorted, with duplicates inside rows
+    col[rng.random(col.size) < 0.2] = 7  # a long column
+    col[col == 11] = 12  # an empty one
+    val = rng.standard_normal(col.size)
+    A = oracle.CSR((m, n), val, col, ind)
+    x = rng.standard_normal(m)
+    x[3] = np.inf if seed == 1 else x[3]
+    yo = np.empty(n)
+    A.matvec_transp(x, yo)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)
+    for _ in range(2):
+        y = np.full(n, 7.0)
+        D.matvec_transp(x, y)
+        assert np.array_equal(y, yo, equal_nan=True)
+    D2 = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)  # a second handle: another run of the atomics
+    y2 = np.full(n, 7.0)
+    D2.matvec_transp(x, y2)
+    assert np.array_equal(y2, yo, equal_nan=True)
+
+
+def test_malformed_arrays_are_refused_before_any_kernel_indexes_with_them(oracle):
+    """the column checks moved to the device in round 6 (a loop over 2e7 entries on the host was 9 ms of an upload): they
+    still come before anything indexes with a column, and still name the offending entry"""
+    from pysparse_amd.device import DeviceCSR, DeviceSSS
+    S = oracle.poisson_sss(40, 40)
+    col = S.col.copy()
+    col[1234] = 10 ** 6  # far outside
+    with pytest.raises(Exception, match="not strictly lower"):
+        DeviceSSS.from_arrays(S.n, S.ind, col, S.val, S.diag)
+    col = S.col.copy()
+    row = int(np.searchsorted(S.ind, 777, side="right") - 1)
+    col[777] = row  # on the diagonal: not strictly lower
+    with pytest.raises(Exception, match="not strictly lower"):
+        DeviceSSS.from_arrays(S.n, S.ind, col, S.val, S.diag)
+    col = S.col.copy()
+    col[5] = -1
+    with pytest.raises(Exception, match="not strictly lower"):
+        DeviceSSS.from_arrays(S.n, S.ind, col, S.val, S.diag)
+    A = oracle.poisson_csr(1100, 1000)  # 5.5e6 entries: the large-triple path (checked on the device)
+    assert A.nnz >= (1 << 22)
+    col = A.col.copy()
+    col[A.nnz // 2] = A.shape[1]
+    with pytest.raises(Exception, match="out of range"):
+        DeviceCSR.from_arrays(A.shape, A.ind, col, A.val)
+    D = DeviceCSR.from_arrays(A.shape, A.ind, A.col, A.val)  # and the well-formed triple is accepted
+    assert D.nnz == A.nnz
