@@ -2175,6 +2175,15 @@ __global__ void transp_slot_kernel(int nrows, const int *__restrict__ ind, const
     }
 }
 
+// the longest column (one thread sorts a column: the counting form is for columns of a few thousand entries at most)
+__global__ void transp_maxlen_kernel(int ncols, const int *__restrict__ tind, int *maxlen) {
+  int m = 0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) m = max(m, tind[c + 1] - tind[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxlen, m);
+}
+
 // one thread per column: insertion sort of its keys (short segments; the keys are distinct)
 __global__ void transp_sort_kernel(int ncols, const int *__restrict__ tind, unsigned long long *__restrict__ key) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {

@@ -773,14 +773,16 @@ static int transpose_into(int nrows, int ncols, int nnz, const int *ind, const i
   if (nnz > 0 && !by_sort) {
     // counting form (kernels above); scratch from the solvers' vector pool: no hipMalloc / hipFree of 80 MB arrays
     double *kbuf = nullptr, *cbuf = nullptr;
-    const size_t nk = (size_t)nnz, ncur = ((size_t)ncols + 2) / 2 + 1;
+    const size_t nk = (size_t)nnz, ncur = ((size_t)ncols + 3) / 2 + 1;
+    constexpr int kTranspMaxColumn = 4096;  // a longer column (a dense one) goes to the radix sort below: one thread sorts a column
+    bool too_long = false;
     rc = psp::scratch_get(nk, &kbuf);
     if (rc == PSP_OK) rc = psp::scratch_get(ncur, &cbuf);
     if (rc == PSP_OK) {
       unsigned long long *key = reinterpret_cast<unsigned long long *>(kbuf);
       int *cursor = reinterpret_cast<int *>(cbuf);  // ncols + 1 ints: the counts, then the cursors; [ncols] = the flag
       size_t bytes = 0;
-      hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * ((size_t)ncols + 2), stream());
+      hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * ((size_t)ncols + 3), stream());
       const int g = (int)std::min<long>(((long)nnz + 255) / 256, 65536);
       if (e == hipSuccess) {
         hipLaunchKernelGGL(transp_count_kernel, dim3(g), dim3(256), 0, stream(), nnz, ncols, col, cursor, cursor + ncols + 1);
@@ -788,12 +790,18 @@ static int transpose_into(int nrows, int ncols, int nnz, const int *ind, const i
       }
       if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 1);
       if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cursor, T->ind, ncols + 1, stream());
-      int bad = 0;
-      if (e == hipSuccess) e = hipMemcpyAsync(&bad, cursor + ncols + 1, sizeof(int), hipMemcpyDeviceToHost, stream());
+      int flags[2] = {0, 0};  // {a column index out of range, the longest column}
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(transp_maxlen_kernel, dim3(std::min((ncols + 255) / 256, 4096)), dim3(256), 0, stream(), ncols, T->ind,
+                           cursor + ncols + 2);
+        e = hipMemcpyAsync(flags, cursor + ncols + 1, sizeof(flags), hipMemcpyDeviceToHost, stream());
+      }
       if (e == hipSuccess) e = hipStreamSynchronize(stream());
+      const int bad = flags[0];
+      too_long = flags[1] > kTranspMaxColumn;
       if (e == hipSuccess && bad) rc = fail(PSP_EINVAL, "transpose: a column index is out of range");
-      if (e == hipSuccess && !bad) e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)ncols, stream());
-      if (e == hipSuccess && !bad) {
+      if (e == hipSuccess && !bad && !too_long) e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)ncols, stream());
+      if (e == hipSuccess && !bad && !too_long) {
         hipLaunchKernelGGL(transp_slot_kernel, dim3(std::min((nrows + 3) / 4, 65536)), dim3(256), 0, stream(), nrows, ind, col,
                            T->ind, cursor, key);
         hipLaunchKernelGGL(transp_sort_kernel, dim3(std::min((ncols + 255) / 256, 65536)), dim3(256), 0, stream(), ncols, T->ind,
@@ -808,8 +816,12 @@ static int transpose_into(int nrows, int ncols, int nnz, const int *ind, const i
     psp::scratch_put(kbuf, nk);
     psp::scratch_put(cbuf, ncur);
     if (rc != PSP_OK) goto done;
-    rc = finalize_csr(T);
-    goto done;
+    if (!too_long) {
+      rc = finalize_csr(T);
+      goto done;
+    }
+    if (tmp) (void)hipFree(tmp);  // (the scan's scratch; the radix sort below sizes its own)
+    tmp = nullptr;
   }
   if (nnz > 0) {
     const size_t ib = sizeof(int) * (size_t)nnz;

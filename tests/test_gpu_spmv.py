@@ -915,7 +915,7 @@ def _free_bytes(L, check):
     return f.value
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_transpose_by_counting_keeps_the_stable_order(oracle, seed):
     """Round 6: transposes (the mirror of an sss_mat, A^T of an irregular csr_mat) are built by counting + a sort of each
     column's entries by (row, stored position) instead of a stable radix sort by column.  Same result by construction;
@@ -924,13 +924,15 @@ def test_transpose_by_counting_keeps_the_stable_order(oracle, seed):
     oracle's row-wise scatter (csr_mat.c:74-88), twice (atomics decide slots, never the result)."""
     from pysparse_amd.device import DeviceCSR
     rng = np.random.default_rng(100 + seed)
-    m, n = ((700, 450), (300, 2000), (1500, 1500))[seed]
-    lens = rng.integers(0, 30, size=m)
+    m, n = ((700, 450), (300, 2000), (1500, 1500), (9000, 800))[seed]
+    lens = rng.integers(1 if seed == 3 else 0, 30, size=m)
     lens[rng.random(m) < 0.1] = 0
     ind = np.zeros(m + 1, dtype=np.int32)
     np.cumsum(lens, out=ind[1:])
     col = rng.integers(0, n, size=ind[-1]).astype(np.int32)  # unsorted, with duplicates inside rows
     col[rng.random(col.size) < 0.2] = 7  # a long column
+    if seed == 3:  # a column of 9 000+ entries: beyond what one thread sorts (4096) -> the radix-sort path takes over
+        col[ind[:-1]] = 3
     col[col == 11] = 12  # an empty one
     val = rng.standard_normal(col.size)
     A = oracle.CSR((m, n), val, col, ind)
