@@ -190,6 +190,29 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert d["provenance"]["match"] is True
 
 
+def test_bench_eight_ranks_dry_run_is_the_shape_of_the_scaling_run():
+    """the driver's scaling run ends at N = 8: the same launcher + row-range driver over gloo with the oracle-backed test
+    backend at eight ranks (a 16^3 grid: two planes per rank, every interior rank with halos on both sides) -- the line stays
+    under the limit, names its stage, passes its in-job parity check and carries the prediction it will be judged against"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--grid", "16,16,16",
+                          "--steps", "3", "--warmup", "1", "--pcg-iters", "5", "--no-cpu-baseline",
+                          "--test-backend", "tests.dist_oracle_backend:bench_factory"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = parse(out.stdout)
+    line = d["_line"]
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong" and "dry_run" in d
+    assert d["config"]["n"] == 4096 and d["config"]["rows_per_gpu"] == 512
+    assert d["launcher"]["stage"] == "torch_rccl_ranks" and d["launcher"]["fallback_from"] == []
+    assert d["parity_vs_n1"]["ok"] and d["parity_vs_n1"]["max_rel_diff"] <= 1e-9
+    assert d["pcg_check"]["info"] == -1 and d["pcg_check"]["iter"] == 6
+    p = line["predicted"]
+    assert p["allreduce_us"] == [30.0, 30.0] and p["halo_exposed_ms"] == 0.0 and "missed_budget" in p
+    assert line["roofline"]["pcg_iters_per_s"] == d["pcg_iters_per_s"] > 0 and line["phases"]["iteration_ms"] > 0
+    assert d["preflight"]["world"] == 8
+
+
 def _run_ladder(*extra, timeout=240):
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
