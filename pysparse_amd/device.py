@@ -218,7 +218,7 @@ class DeviceCSR:
         info = (C.c_int * 4)()
         check(lib().psp_csr_kernel_info(self._h, name, 160, info))
         return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
-                                     "half_band": info[3]}
+                                     "half_band": info[3], "setup_ms": self.setup_info()["reorder_ms"]}
 
     def release_arrays(self):
         """psp_csr_release_arrays: an offset-structured operator keeps its index-free tables only (no download, no
@@ -315,7 +315,7 @@ class DeviceSSS:
         info = (C.c_int * 4)()
         check(lib().psp_sss_kernel_info(self._h, name, 64, info))
         return name.value.decode(), {"nb": info[0], "max_blocks": info[1], "scheduled": bool(info[2]),
-                                     "half_band": info[3]}
+                                     "half_band": info[3], "setup_ms": self.setup_info()["reorder_ms"]}
 
     def __getitem__(self, ij):
         if not (isinstance(ij, tuple) and len(ij) == 2 and all(isinstance(t, (int, np.integer)) for t in ij)):
